@@ -1,0 +1,199 @@
+/*
+ * mtb.h -- C ABI of the MI355X-native metamer classification engine.
+ *
+ * Drop-in boundary for the hot path of `metabuli classify`
+ * (steineggerlab/Metabuli).  The reference has no FFI; its seam is three C++
+ * member calls made by Classifier::startClassify (src/commons/Classifier.cpp:
+ * 105-119).  Every entry point below names the reference interface it
+ * replaces.  Plain C types only: pointers + sizes, caller-allocated outputs
+ * with capacity and a required-size return, status codes instead of exit().
+ *
+ * Memory spaces: every pointer parameter documented as "host" is ordinary
+ * host memory; parameters documented as "device" are HIP device pointers
+ * (e.g. torch.Tensor.data_ptr()).  The stage-level entry points take host
+ * buffers (they are the parity seam); mtb_classify_batch_device takes device
+ * buffers so that a step can be timed with inputs already resident in HBM.
+ *
+ * Threading: one host thread per mtb_ctx; one mtb_ctx per GPU.
+ */
+#ifndef MTB_H
+#define MTB_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    MTB_OK = 0,
+    MTB_ERR_ARG = 1,        /* bad argument                                            */
+    MTB_ERR_IO = 2,         /* database / taxonomy file missing or malformed           */
+    MTB_ERR_DEVICE = 3,     /* HIP runtime error (message in mtb_last_error)           */
+    MTB_ERR_CAPACITY = 4,   /* output buffer too small; required size was returned     */
+    MTB_ERR_OOM = 5,        /* not enough HBM for the request                          */
+    MTB_ERR_UNSUPPORTED = 6 /* feature of the reference not implemented yet            */
+} mtb_status;
+
+/* Kmer (src/commons/Kmer.h:24-47): 16 bytes.
+ * qinfo = pos[0:31] | sequenceID[32:60] | frame[61:63]  (Kmer.h:11-16). */
+typedef struct { uint64_t value; uint64_t qinfo; } mtb_kmer;
+
+/* Match payload (src/commons/Match.h:9-25) packed to 24 bytes (the reference
+ * object is 32 bytes because of its vptr).                                  */
+typedef struct {
+    uint64_t qinfo;
+    int32_t  target_id;          /* taxonomy id stored in `info`              */
+    int32_t  species_id;         /* taxId2speciesId[target_id]                */
+    uint32_t dna;                /* target value & 0xFFFFFF                   */
+    uint16_t right_end_hamming;  /* 2 bits per codon                          */
+    uint8_t  hamming;            /* sum of per-codon Hamming distances        */
+    uint8_t  pad;
+} mtb_match;
+
+/* The subset of LocalParameters (src/commons/LocalParameters.h:157-248) read
+ * on the path; defaults are `classify`'s (src/workflow/classify.cpp:10-37),
+ * overridden by DBDIR/db.parameters (src/commons/common.cpp:88-133).        */
+typedef struct {
+    int32_t seq_mode;          /* 1 single-end, 2 paired-end, 3 long read     */
+    int32_t syncmer;           /* 0/1                                         */
+    int32_t smer_len;          /* 5                                           */
+    int32_t kmer_format;       /* 2 (only format implemented)                 */
+    int32_t min_cons_cnt;      /* 4                                           */
+    int32_t min_cons_cnt_euk;  /* 9                                           */
+    float   min_score;         /* 0                                           */
+    float   min_sp_score;      /* 0                                           */
+    float   tie_ratio;         /* 0.95                                        */
+    int32_t accession_level;   /* 0                                           */
+    int32_t skip_redundancy;   /* 1 for DBs written by `build`                */
+} mtb_params;
+
+/* Per-read outcome: the fields of Query (src/commons/common.h:94-122) that
+ * Taxonomer::chooseBestTaxon assigns (Taxonomer.cpp:130-202).               */
+typedef struct {
+    int32_t  classification;   /* taxonomy id, 0 = unclassified               */
+    float    score;
+    int32_t  query_length;     /* getMaxCoveredLength(L1) (LocalUtil.h:51-59) */
+    int32_t  query_length2;    /* same for mate 2, else 0                     */
+    uint8_t  is_classified;
+    uint8_t  reserved;
+    uint16_t n_taxcnt;         /* entries of Query::taxCnt                    */
+    uint32_t taxcnt_off;       /* first entry in the taxcnt arrays            */
+} mtb_result;
+
+typedef struct mtb_ctx mtb_ctx;
+typedef struct mtb_index mtb_index;
+
+/* Per-stage device time of the last mtb_classify_batch* call (HIP events on
+ * the context's stream) and the run-time counters of SURVEY.md 8(d).        */
+typedef struct {
+    float    ms_extract, ms_sort, ms_join, ms_regroup, ms_segsort, ms_score, ms_total;
+    uint64_t n_reads, n_bases, n_kmers, n_matches, n_targets;
+} mtb_batch_stats;
+
+const char *mtb_version(void);
+const char *mtb_last_error(void);
+void mtb_default_params(mtb_params *p);          /* classify.cpp:10-37       */
+
+/* One context per GPU.  `stream` is a hipStream_t (or NULL for the default
+ * stream); all kernels of the context are launched on it.                   */
+mtb_status mtb_ctx_create(int device, void *stream, mtb_ctx **out);
+void       mtb_ctx_destroy(mtb_ctx *);
+mtb_status mtb_ctx_sync(mtb_ctx *);
+
+/* ---- index residency ---------------------------------------------------
+ * Replaces the per-call fopen/fread/mmap of diffIdx, info, split inside
+ * KmerMatcher::matchKmers (KmerMatcher.cpp:127-137, 212-217) and
+ * KmerMatcher::loadTaxIdList (KmerMatcher.cpp:56-120) plus loadTaxonomy /
+ * loadDbParameters (common.cpp:50-133): the delta-coded index is decoded
+ * once on the GPU into a flat {u64 value[T]; u32 info[T]} held in HBM.
+ * `taxonomy_dir` may be NULL (then DBDIR/taxonomy/{names,nodes,merged}.dmp).
+ * `params` is in/out: db.parameters overrides are written back.             */
+mtb_status mtb_index_open(mtb_ctx *, const char *dbdir, const char *taxonomy_dir,
+                          mtb_params *params, mtb_index **out);
+/* Same, from an already flat index resident on the device (synthetic-index
+ * benchmark path).  The arrays are borrowed, not copied: they must outlive
+ * the index.  taxonomy_dir must hold the *.dmp files; taxid_list (host) is
+ * the content of DBDIR/taxID_list.                                          */
+mtb_status mtb_index_from_device(mtb_ctx *, const uint64_t *d_values, const uint32_t *d_info,
+                                 uint64_t n_targets, const char *taxonomy_dir,
+                                 const int32_t *taxid_list, size_t n_taxids,
+                                 const mtb_params *params, mtb_index **out);
+void       mtb_index_close(mtb_index *);
+uint64_t   mtb_index_num_targets(const mtb_index *);
+/* Copy the decoded flat index back to the host (parity seam for the codec). */
+mtb_status mtb_index_download(mtb_index *, uint64_t *values, uint32_t *info, uint64_t cap);
+/* Taxonomy services (TaxonomyWrapper / NcbiTaxonomy) for the host side.     */
+int32_t    mtb_tax_lca(const mtb_index *, int32_t a, int32_t b);
+int32_t    mtb_tax_species(const mtb_index *, int32_t taxid);  /* taxId2speciesId */
+int32_t    mtb_tax_parent(const mtb_index *, int32_t taxid);
+int32_t    mtb_tax_max_id(const mtb_index *);
+
+/* ---- stage-level entry points (host buffers; the parity seam) ----------
+ * KmerExtractor::extractQueryKmers minus the sort (KmerExtractor.cpp:52-77,
+ * 83-373): reads are concatenated in `bases` with offs[n_reads+1]; mates of
+ * seq_mode 2 in bases2/offs2 (else NULL).  Emits only real k-mers (no blank
+ * slots).  *count receives the number produced (required size if > cap).
+ * qlen/qlen2 receive Query::queryLength/queryLength2.                       */
+mtb_status mtb_extract(mtb_ctx *, const mtb_params *, const char *bases, const uint64_t *offs,
+                       const char *bases2, const uint64_t *offs2, uint64_t n_reads,
+                       mtb_kmer *out, uint64_t cap, uint64_t *count,
+                       int32_t *qlen, int32_t *qlen2);
+/* SORT_PARALLEL(..., Kmer::compareQueryKmer) (KmerExtractor.cpp:79): stable
+ * LSD radix sort on the 64-bit value (extraction order is by sequenceID).   */
+mtb_status mtb_sort_kmers(mtb_ctx *, mtb_kmer *kmers, uint64_t n);
+/* KmerMatcher::matchKmers (KmerMatcher.cpp:123-481).  Output order is
+ * unspecified (as in the reference); *count = matches found.  Returns
+ * MTB_ERR_CAPACITY where the reference returns false.                       */
+mtb_status mtb_match_kmers(mtb_ctx *, mtb_index *, const mtb_kmer *sorted, uint64_t n,
+                     mtb_match *out, uint64_t cap, uint64_t *count);
+/* KmerMatcher::sortMatches (KmerMatcher.cpp:1071-1078, 1149-1166); n_reads =
+ * number of reads of the batch (sequenceID is 1..n_reads).                  */
+mtb_status mtb_sort_matches(mtb_ctx *, mtb_match *matches, uint64_t n, uint64_t n_reads);
+/* Classifier::assignTaxonomy (Classifier.cpp:166-208) -> per read
+ * Taxonomer::chooseBestTaxon.  taxcnt_* receive the concatenated
+ * Query::taxCnt maps (ascending taxid per read); *n_taxcnt = entries.       */
+mtb_status mtb_score(mtb_ctx *, mtb_index *, const mtb_params *, const mtb_match *sorted,
+                     uint64_t n_matches, uint64_t n_reads, const int32_t *qlen,
+                     const int32_t *qlen2, mtb_result *results, int32_t *taxcnt_tax,
+                     uint32_t *taxcnt_cnt, uint64_t taxcnt_cap, uint64_t *n_taxcnt);
+
+/* ---- fused batch (the product path) ------------------------------------
+ * One pass of Classifier::startClassify's loop body (Classifier.cpp:81-125)
+ * for one batch.  Host-buffer variant copies inputs over PCIe first.        */
+mtb_status mtb_classify_batch(mtb_ctx *, mtb_index *, const mtb_params *, const char *bases,
+                              const uint64_t *offs, const char *bases2, const uint64_t *offs2,
+                              uint64_t n_reads, mtb_result *results, int32_t *taxcnt_tax,
+                              uint32_t *taxcnt_cnt, uint64_t taxcnt_cap, uint64_t *n_taxcnt);
+/* Device-buffer variant: d_bases/d_offs (and mates) are device pointers;
+ * results stay on the device in d_results (n_reads entries) and the taxcnt
+ * arrays d_taxcnt_* (capacity taxcnt_cap); nothing crosses PCIe except the
+ * scalar counters.  This is what bench.py times.                            */
+mtb_status mtb_classify_batch_device(mtb_ctx *, mtb_index *, const mtb_params *,
+                                     const char *d_bases, const uint64_t *d_offs,
+                                     const char *d_bases2, const uint64_t *d_offs2,
+                                     uint64_t n_reads, uint64_t n_bases_total,
+                                     mtb_result *d_results, int32_t *d_taxcnt_tax,
+                                     uint32_t *d_taxcnt_cnt, uint64_t taxcnt_cap,
+                                     uint64_t *n_taxcnt);
+mtb_status mtb_last_batch_stats(mtb_ctx *, mtb_batch_stats *out);
+
+/* ---- synthetic data on the device (bench / tests) ------
+ * Builds a flat sorted target index of `n_filler` pseudo-random valid
+ * metamers (seeded) merged with `n_real` caller-provided (value,taxid)
+ * entries (host, any order).  Output arrays are device buffers with room
+ * for n_filler+n_real entries; *n_out = entries written (duplicates of
+ * (value, taxid) removed).                                                  */
+mtb_status mtb_synth_index(mtb_ctx *, uint64_t seed, uint64_t n_filler, int32_t filler_tax_lo,
+                           int32_t filler_tax_hi, const uint64_t *real_values,
+                           const int32_t *real_taxids, uint64_t n_real,
+                           uint64_t *d_values, uint32_t *d_info, uint64_t *n_out);
+/* Target-side extraction used to build synthetic indices: all six-frame
+ * (sync)metamers of a genome, as (value) list on the host.                  */
+mtb_status mtb_extract_targets(mtb_ctx *, const mtb_params *, const char *genome, uint64_t len,
+                               uint64_t *values, uint64_t cap, uint64_t *count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MTB_H */

@@ -1,0 +1,587 @@
+/*
+ * mtb_core.h -- per-lane arithmetic of the hot path, written once and used by
+ * the HIP kernels (device) and by tests/emu (host build of the very same
+ * functions, to check the kernel logic against the oracle without a GPU).
+ *
+ * This is NOT a restatement of the reference's control flow: it is the
+ * functional specification of each stage, laid out for one
+ * lane of a 64-wide wavefront:
+ *   - a metamer window is a pure function of 8 consecutive codons;
+ *   - a query's matches are a pure function of its AA-run in the flat index;
+ *   - a (species, frame) block of sorted matches yields at most one path per
+ *     match, stored at the match's own slot.
+ * Reference citations (src/commons/...) are given per function.
+ */
+#ifndef MTB_CORE_H
+#define MTB_CORE_H
+#include <stdint.h>
+#include "../../include/mtb.h"
+
+#if defined(__HIPCC__)
+#define MTB_HD __host__ __device__ __forceinline__
+#else
+#define MTB_HD inline
+#endif
+#if defined(__HIPCC__)
+#define MTB_UNROLL _Pragma("unroll")
+#else
+#define MTB_UNROLL
+#endif
+
+/* ------------------------------------------------------------------ */
+/* qinfo helpers (Kmer.h:11-16)                                        */
+/* ------------------------------------------------------------------ */
+MTB_HD uint64_t mtb_qinfo(uint32_t seq_id, uint32_t pos, uint32_t frame) {
+    return (uint64_t)pos | ((uint64_t)(seq_id & 0x1FFFFFFFu) << 32) | ((uint64_t)(frame & 7u) << 61);
+}
+MTB_HD uint32_t mtb_q_pos(uint64_t q)   { return (uint32_t)q; }
+MTB_HD uint32_t mtb_q_seq(uint64_t q)   { return (uint32_t)((q >> 32) & 0x1FFFFFFFu); }
+MTB_HD uint32_t mtb_q_frame(uint64_t q) { return (uint32_t)(q >> 61); }
+
+/* LocalUtil.h:51-59 */
+MTB_HD int32_t mtb_used_len(int32_t len) {
+    int32_t r = len % 3;
+    return r == 2 ? len - 2 : (r == 1 ? len - 4 : len - 3);
+}
+/* LocalUtil.h:46-48: reads with fewer than one dense slot are skipped */
+MTB_HD bool mtb_read_too_short(int32_t len) { return (mtb_used_len(len) / 3 - 8 + 1) * 6 < 1; }
+
+/* ------------------------------------------------------------------ */
+/* Tables                                                              */
+/* ------------------------------------------------------------------ */
+/* Built on the host by mtb_build_tables(); copied to the device once. */
+typedef struct {
+    uint8_t  base[256];   /* ASCII -> 0..3 (A C T G classes incl. IUPAC), 7 = invalid;
+                             common.cpp:13-23 + GeneticCode.h:6.  Complement = code ^ 2. */
+    uint8_t  codon[64];   /* index c0*16+c1*4+c2 -> aa(5 bits) | codon id << 5;
+                             GeneticCode.h:34-193                                      */
+    uint32_t hamrow[8];   /* hammingLookup[a][b] as nibble b of word a;
+                             KmerMatcher.h:66-70                                       */
+} mtb_tables;
+
+static inline void mtb_build_tables(mtb_tables *t) {
+    for (int i = 0; i < 256; i++) t->base[i] = 7;
+    const char *cls[4] = {"ARW", "CMS", "HTY", "BDGKU"};
+    for (int c = 0; c < 4; c++)
+        for (const char *p = cls[c]; *p; ++p) {
+            t->base[(unsigned char)*p] = (uint8_t)c;
+            t->base[(unsigned char)(*p | 0x20)] = (uint8_t)c;
+        }
+    /* amino acid per codon, our base order A C T G; index into
+       "ARNDCQEGHILKMFPSTWYV", '*' = 20 */
+    static const char *AA_ACTG =
+        "KNNK" "TTTT" "IIIM" "RSSR"   /* A?? : AA. AC. AT. AG. */
+        "QHHQ" "PPPP" "LLLL" "RRRR"   /* C?? */
+        "*YY*" "SSSS" "LFFL" "*CCW"   /* T?? */
+        "EDDE" "AAAA" "VVVV" "GGGG";  /* G?? */
+    static const char *LET = "ARNDCQEGHILKMFPSTWYV";
+    for (int i = 0; i < 64; i++) {
+        char r = AA_ACTG[i];
+        int aa = 20;
+        if (r != '*') { aa = 0; while (LET[aa] != r) aa++; }
+        int cid = i & 3;                      /* third base */
+        t->codon[i] = (uint8_t)(aa | (cid << 5));
+    }
+    /* six-codon families and TGA: AGG4 AGA5 TTG4 TTA5 AGT6 AGC7 TGA5 */
+    #define MTB_SETCID(c0, c1, c2, id) t->codon[(c0) * 16 + (c1) * 4 + (c2)] = (uint8_t)((t->codon[(c0) * 16 + (c1) * 4 + (c2)] & 31) | ((id) << 5))
+    MTB_SETCID(0, 3, 3, 4); MTB_SETCID(0, 3, 0, 5);
+    MTB_SETCID(2, 2, 3, 4); MTB_SETCID(2, 2, 0, 5);
+    MTB_SETCID(0, 3, 2, 6); MTB_SETCID(0, 3, 1, 7);
+    MTB_SETCID(2, 3, 0, 5);
+    #undef MTB_SETCID
+    /* codon-id Hamming distances: ids 0-3 are the third base; 4/5 are the
+       second family of Arg/Leu (and TGA), 6/7 the second family of Ser. */
+    static const uint8_t H[8][8] = {
+        {0, 1, 1, 1, 2, 1, 3, 3}, {1, 0, 1, 1, 2, 2, 3, 2},
+        {1, 1, 0, 1, 2, 2, 2, 3}, {1, 1, 1, 0, 1, 2, 3, 3},
+        {2, 2, 2, 1, 0, 1, 4, 4}, {1, 2, 2, 2, 1, 0, 4, 4},
+        {3, 3, 2, 3, 4, 4, 0, 1}, {3, 2, 3, 3, 4, 4, 1, 0}};
+    for (int a = 0; a < 8; a++) {
+        uint32_t w = 0;
+        for (int b = 0; b < 8; b++) w |= (uint32_t)H[a][b] << (4 * b);
+        t->hamrow[a] = w;
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* Extraction: one window = 8 codon bytes -> metamer + syncmer test    */
+/* ------------------------------------------------------------------ */
+/* Codon byte of the codon whose first base (in reading direction) sits at
+ * forward coordinate ci.  Forward frames read ci, ci+1, ci+2; reverse frames
+ * read the complement of ci, ci-1, ci-2 (KmerScanner.h:89-98).  0xFF if any
+ * base is not A/C/G/T-like.                                                 */
+MTB_HD uint8_t mtb_codon_byte(const mtb_tables *t, const char *seq, int64_t ci, bool fwd) {
+    uint32_t a, b, c;
+    if (fwd) {
+        a = t->base[(uint8_t)seq[ci]]; b = t->base[(uint8_t)seq[ci + 1]]; c = t->base[(uint8_t)seq[ci + 2]];
+    } else {
+        a = t->base[(uint8_t)seq[ci]]; b = t->base[(uint8_t)seq[ci - 1]]; c = t->base[(uint8_t)seq[ci - 2]];
+        if ((a | b | c) < 4) { a ^= 2; b ^= 2; c ^= 2; }
+    }
+    if ((a | b | c) > 3) return 0xFF;
+    return t->codon[a * 16 + b * 4 + c];
+}
+
+/* Frame geometry (KmerExtractor.cpp:350-362): begin of frame f in a read of
+ * length len; the scanner window is [begin, begin + used - 1].              */
+MTB_HD int32_t mtb_frame_begin(int32_t len, int32_t frame) {
+    if (frame < 3) return frame;
+    int32_t b = (len % 3) - (frame % 3);
+    return b < 0 ? b + 3 : b;
+}
+/* forward coordinate of the first base of codon j of frame f */
+MTB_HD int64_t mtb_codon_ci(int32_t begin, int32_t used, int32_t j, bool fwd) {
+    return fwd ? (int64_t)begin + 3 * (int64_t)j : (int64_t)begin + used - 1 - 3 * (int64_t)j;
+}
+/* position reported for window p (KmerScanner.h:110-114, SyncmerScanner.h:93-97) */
+MTB_HD uint32_t mtb_window_pos(int32_t begin, int32_t used, int32_t p, bool fwd) {
+    return fwd ? (uint32_t)(begin + 3 * p) : (uint32_t)(begin + used - 1 - (p + 8) * 3 + 1);
+}
+
+/* cod[0..7] are the codon bytes of the window in reading direction.  Returns
+ * false if the window holds an invalid codon or (syncmer mode) is not a
+ * closed syncmer: the leftmost minimal s-mer must sit at offset 0 or 8-s
+ * (SyncmerScanner.h:58-73).  value = AA40 << 24 | DNA24 (KmerScanner.h:99-111). */
+MTB_HD bool mtb_window_metamer(const uint8_t *cod, int syncmer, int smer_len, uint64_t *value) {
+    uint64_t aa = 0, dna = 0;
+    uint32_t bad = 0;
+MTB_UNROLL
+    for (int i = 0; i < 8; i++) {
+        uint32_t b = cod[i];
+        bad |= (b == 0xFFu);
+        aa = (aa << 5) | (b & 31u);
+        dna = (dna << 3) | (b >> 5);
+    }
+    if (bad) return false;
+    *value = (aa << 24) | (dna & 0xFFFFFFull);
+    if (!syncmer) return true;
+    int ns = 8 - smer_len + 1;
+    uint64_t mask = (1ull << (5 * smer_len)) - 1;
+    uint64_t best = ~0ull; int arg = 0;
+    for (int k = 0; k < ns; k++) {
+        uint64_t s = (aa >> (5 * (8 - smer_len - k))) & mask;   /* AAs k .. k+s-1 */
+        if (s < best) { best = s; arg = k; }                      /* leftmost on ties */
+    }
+    return arg == 0 || arg == ns - 1;
+}
+
+/* ------------------------------------------------------------------ */
+/* Join: Hamming arithmetic on 24-bit codon-id strings                  */
+/* ------------------------------------------------------------------ */
+typedef struct { uint32_t row[8]; uint32_t qdna; } mtb_qrows;   /* row[i]: hamming row of query codon i (i=0 is the LSB codon) */
+
+MTB_HD void mtb_prepare_query(const mtb_tables *t, uint64_t qvalue, mtb_qrows *q) {
+    uint32_t d = (uint32_t)qvalue & 0xFFFFFFu;
+    q->qdna = d;
+MTB_UNROLL
+    for (int i = 0; i < 8; i++) q->row[i] = t->hamrow[(d >> (3 * i)) & 7u];
+}
+/* getHammingDistanceSum (KmerMatcher.h:348-360) */
+MTB_HD uint32_t mtb_ham_sum(const mtb_qrows *q, uint32_t tdna) {
+    uint32_t s = 0;
+MTB_UNROLL
+    for (int i = 0; i < 8; i++) s += (q->row[i] >> (4 * ((tdna >> (3 * i)) & 7u))) & 15u;
+    return s;
+}
+/* getHammings / getHammings_reverse (KmerMatcher.h:386-416) with the tables
+ * HAMMING_LUT0..7 (KmerMatcher.h:72-158): 2-bit field = h<4 ? h : 0, except
+ * that the field at bits 14-15 (LUT7) is 1 for query id 4|5 vs target id 6|7. */
+MTB_HD uint16_t mtb_hammings(const mtb_qrows *q, uint32_t tdna, bool reverse) {
+    uint32_t out = 0;
+MTB_UNROLL
+    for (int i = 0; i < 8; i++) {
+        uint32_t b = (tdna >> (3 * i)) & 7u;
+        uint32_t h = (q->row[i] >> (4 * b)) & 15u;
+        uint32_t f = reverse ? 7 - i : i;
+        uint32_t code = h < 4 ? h : 0;
+        if (f == 7 && h == 4) {
+            uint32_t a = (q->qdna >> (3 * i)) & 7u;
+            if ((a == 4 || a == 5) && (b == 6 || b == 7)) code = 1;
+        }
+        out |= code << (2 * f);
+    }
+    return (uint16_t)out;
+}
+/* orientation rule of compareDna (KmerMatcher.cpp:1140-1142) */
+MTB_HD bool mtb_hammings_reversed(uint32_t frame, int kmer_format) {
+    return ((frame < 3) ^ (kmer_format == 2)) != 0;
+}
+/* selection threshold (KmerMatcher.cpp:1136) */
+MTB_HD uint32_t mtb_ham_threshold(uint32_t min_ham) { uint32_t t = 2 * min_ham; return t < 7 ? t : 7; }
+
+/* lower bound of key in sorted v[0..n) */
+MTB_HD uint64_t mtb_lower_bound(const uint64_t *v, uint64_t n, uint64_t key) {
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) {
+        uint64_t mid = lo + ((hi - lo) >> 1);
+        if (v[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+/* One query against the flat index (functional form of KmerMatcher::matchKmers,
+ * KmerMatcher.cpp:275-450): candidates are the targets t < T-1 (the last entry
+ * of the index is never a candidate, :363/:378) with the query's AA part.
+ * Pass 1 (emit == 0) returns the number of selected candidates; pass 2 writes
+ * them in index order.                                                       */
+typedef struct {
+    const uint64_t *values; const uint32_t *info; uint64_t n_targets;
+    const int32_t *tax2species; int32_t max_taxid; uint32_t info_mask; int32_t kmer_format;
+} mtb_index_view;
+
+MTB_HD uint32_t mtb_join_query(const mtb_tables *t, const mtb_index_view *ix, uint64_t qvalue,
+                               uint64_t qinfo, mtb_match *out, uint32_t out_cap, int emit,
+                               uint64_t *run_start_io, uint32_t *run_len_io) {
+    uint64_t s, e;
+    if (emit) { s = *run_start_io; e = s + *run_len_io; }
+    else {
+        uint64_t aa = qvalue & ~0xFFFFFFull;
+        uint64_t limit = ix->n_targets ? ix->n_targets - 1 : 0;      /* exclude last entry */
+        s = mtb_lower_bound(ix->values, limit, aa);
+        e = s;
+        while (e < limit && (ix->values[e] & ~0xFFFFFFull) == aa) e++;
+        *run_start_io = s; *run_len_io = (uint32_t)(e - s);
+    }
+    if (s >= e) return 0;
+    mtb_qrows q; mtb_prepare_query(t, qvalue, &q);
+    uint32_t mn = 255;
+    for (uint64_t i = s; i < e; i++) { uint32_t h = mtb_ham_sum(&q, (uint32_t)ix->values[i] & 0xFFFFFFu); mn = h < mn ? h : mn; }
+    uint32_t thr = mtb_ham_threshold(mn);
+    uint32_t cnt = 0;
+    bool rev = mtb_hammings_reversed(mtb_q_frame(qinfo), ix->kmer_format);
+    for (uint64_t i = s; i < e; i++) {
+        uint32_t td = (uint32_t)ix->values[i] & 0xFFFFFFu;
+        uint32_t h = mtb_ham_sum(&q, td);
+        if (h <= thr) {
+            if (emit && cnt < out_cap) {
+                int32_t tid = (int32_t)(ix->info[i] & ix->info_mask);
+                int32_t sp = (tid >= 0 && tid <= ix->max_taxid) ? ix->tax2species[tid] : 0;
+                mtb_match m;
+                m.qinfo = qinfo; m.target_id = tid; m.species_id = sp; m.dna = td;
+                m.right_end_hamming = mtb_hammings(&q, td, rev); m.hamming = (uint8_t)h; m.pad = 0;
+                out[cnt] = m;
+            }
+            cnt++;
+        }
+    }
+    return cnt;
+}
+
+/* ------------------------------------------------------------------ */
+/* Match ordering (KmerMatcher.cpp:1149-1166)                           */
+/* ------------------------------------------------------------------ */
+MTB_HD bool mtb_match_less(const mtb_match &a, const mtb_match &b) {
+    uint32_t sa = mtb_q_seq(a.qinfo), sb = mtb_q_seq(b.qinfo);
+    if (sa != sb) return sa < sb;
+    if (a.species_id != b.species_id) return a.species_id < b.species_id;
+    uint32_t fa = mtb_q_frame(a.qinfo), fb = mtb_q_frame(b.qinfo);
+    if (fa != fb) return fa < fb;
+    uint32_t pa = mtb_q_pos(a.qinfo), pb = mtb_q_pos(b.qinfo);
+    if (pa != pb) return pa < pb;
+    if (a.hamming != b.hamming) return a.hamming < b.hamming;
+    return a.dna < b.dna;
+}
+
+/* ------------------------------------------------------------------ */
+/* Scoring                                                             */
+/* ------------------------------------------------------------------ */
+typedef struct {
+    const int32_t *parent;      /* by taxid; parent[root] = root; -1 absent (aliases resolved) */
+    const int32_t *depth;       /* by taxid                                                    */
+    const uint8_t *under_euk;   /* IsAncestor(eukaryota, taxid)  (Taxonomer.cpp:497-500)       */
+    const int32_t *sp_parent;   /* parent(getTaxIdAtRank(taxid,"species")) (Taxonomer.cpp:178-185) */
+    int32_t max_taxid;
+} mtb_tax_view;
+
+typedef struct {
+    int32_t max_codon_shift, dna_shift, denominator;  /* Taxonomer.cpp:34-48 */
+    int32_t min_cons_cnt, min_cons_cnt_euk, kmer_format;
+    float   min_score, min_sp_score, tie_ratio;
+} mtb_score_params;
+
+MTB_HD void mtb_make_score_params(const mtb_params *p, mtb_score_params *s) {
+    if (p->syncmer) { s->dna_shift = (8 - p->smer_len) * 3; s->max_codon_shift = 8 - p->smer_len; }
+    else { s->dna_shift = 3; s->max_codon_shift = 1; }
+    s->denominator = (p->seq_mode == 1 || p->seq_mode == 2) ? 100 : 1000;
+    s->min_cons_cnt = p->min_cons_cnt; s->min_cons_cnt_euk = p->min_cons_cnt_euk; s->kmer_format = p->kmer_format;
+    s->min_score = p->min_score; s->min_sp_score = p->min_sp_score; s->tie_ratio = p->tie_ratio;
+}
+
+MTB_HD bool mtb_tax_exists(const mtb_tax_view *t, int32_t x) { return x >= 0 && x <= t->max_taxid && t->parent[x] >= 0; }
+/* NcbiTaxonomy::LCA(a,b): a missing node yields the other one */
+MTB_HD int32_t mtb_lca(const mtb_tax_view *t, int32_t a, int32_t b) {
+    if (!mtb_tax_exists(t, a)) return b;
+    if (!mtb_tax_exists(t, b)) return a;
+    int32_t da = t->depth[a], db = t->depth[b];
+    while (da > db) { a = t->parent[a]; da--; }
+    while (db > da) { b = t->parent[b]; db--; }
+    while (a != b) { a = t->parent[a]; b = t->parent[b]; }
+    return a;
+}
+
+/* Match.h:32-44 / Taxonomer.cpp:650-661: score of the `n` codons starting at
+ * 2-bit field `first`, walking up (dir=+1) or down (dir=-1) */
+MTB_HD float mtb_codon_score(uint32_t h) { return h == 0 ? 3.0f : 2.0f - 0.5f * (float)h; }
+MTB_HD float mtb_part_score(uint32_t reh, int n, bool left) {
+    float s = 0.0f;
+    for (int c = 0; c < n; c++) s += mtb_codon_score((reh >> (left ? 14 - 2 * c : 2 * c)) & 3u);
+    return s;
+}
+MTB_HD int32_t mtb_part_ham(uint32_t reh, int n, bool left) {
+    int32_t s = 0;
+    for (int c = 0; c < n; c++) s += (int32_t)((reh >> (left ? 14 - 2 * c : 2 * c)) & 3u);
+    return s;
+}
+
+typedef struct {           /* MatchPath (Taxonomer.h:34-57); endMatch = own slot */
+    int32_t start, end;
+    float   score;
+    int32_t ham;
+    int32_t depth;
+    int32_t start_idx;     /* slot of startMatch */
+} mtb_path;
+
+#define MTB_PF_CONNECTED 1u
+#define MTB_PF_EMITTED   2u
+
+/* Taxonomer::isConsecutive / isConsecutive2 with shift (Taxonomer.cpp:684-699) */
+MTB_HD bool mtb_consecutive(uint32_t dna_cur, uint32_t dna_next, int shift, bool fwd, int kmer_format) {
+    uint32_t a = fwd ? dna_cur : dna_next, b = fwd ? dna_next : dna_cur;
+    uint32_t keep = (1u << (24 - 3 * shift)) - 1u;
+    if (kmer_format == 2) return (a & keep) == (b >> (3 * shift));
+    return (a >> (3 * shift)) == (b & keep);
+}
+
+/* Taxonomer::getMatchPaths (Taxonomer.cpp:487-648) for one (species, frame)
+ * block m[s..e) of the sorted match list, e - s >= 2.  path[i]/flag[i] are
+ * per-match slots.  A path is "emitted" (pushed to filteredMatchPaths in the
+ * reference) when it was not extended and is deep enough; emission order in
+ * the reference equals slot order.                                          */
+MTB_HD void mtb_sf_block_paths(const mtb_match *m, int32_t s, int32_t e, mtb_path *path, uint8_t *flag,
+                               const mtb_score_params *sp, int32_t min_depth) {
+    bool fwd = mtb_q_frame(m[s].qinfo) < 3;
+    for (int32_t i = s; i < e; i++) {
+        path[i].start = (int32_t)mtb_q_pos(m[i].qinfo); path[i].end = path[i].start + 23;
+        path[i].score = mtb_part_score(m[i].right_end_hamming, 8, false);
+        path[i].ham = m[i].hamming; path[i].depth = 1; path[i].start_idx = i; flag[i] = 0;
+    }
+    int32_t cs = s, ce = s;
+    uint32_t cur_pos = mtb_q_pos(m[s].qinfo);
+    while (ce < e && mtb_q_pos(m[ce].qinfo) == cur_pos) ce++;
+    int32_t i = ce;
+    while (i < e) {
+        uint32_t next_pos = mtb_q_pos(m[i].qinfo);
+        int32_t ns = i;
+        while (i < e && mtb_q_pos(m[i].qinfo) == next_pos) i++;
+        int32_t ne = i;
+        int32_t shift = (int32_t)(next_pos - cur_pos) / 3;
+        if (shift > 0 && shift <= sp->max_codon_shift) {
+            for (int32_t nx = ns; nx < ne; nx++) {
+                int32_t best = -1; float best_score = 0.0f;
+                for (int32_t cu = cs; cu < ce; cu++) {
+                    if (mtb_consecutive(m[cu].dna, m[nx].dna, shift, fwd, sp->kmer_format)) {
+                        flag[cu] |= MTB_PF_CONNECTED;
+                        if (path[cu].score > best_score) { best = cu; best_score = path[cu].score; }
+                    }
+                }
+                if (best >= 0) {
+                    path[nx].start = path[best].start;
+                    path[nx].score = path[best].score + mtb_part_score(m[nx].right_end_hamming, shift, false);
+                    path[nx].ham = path[best].ham + mtb_part_ham(m[nx].right_end_hamming, shift, false);
+                    path[nx].depth = path[best].depth + shift;
+                    path[nx].start_idx = path[best].start_idx;
+                }
+            }
+        }
+        for (int32_t cu = cs; cu < ce; cu++)
+            if (!(flag[cu] & MTB_PF_CONNECTED) && path[cu].depth >= min_depth) flag[cu] |= MTB_PF_EMITTED;
+        if (i == e)
+            for (int32_t nx = ns; nx < ne; nx++)
+                if (path[nx].depth >= min_depth) flag[nx] |= MTB_PF_EMITTED;
+        cs = ns; ce = ne; cur_pos = next_pos;
+    }
+}
+
+/* ordering of combineMatchPaths (Taxonomer.cpp:417-426): a before b */
+MTB_HD bool mtb_path_before(const mtb_path &a, const mtb_path &b) {
+    if (a.score != b.score) return a.score > b.score;
+    if (a.ham != b.ham) return a.ham < b.ham;
+    return a.start > b.start;
+}
+
+/* Taxonomer::combineMatchPaths (Taxonomer.cpp:410-468) for the species block
+ * m[s..e): stable order of the emitted paths, greedy non-overlap selection
+ * with in-place trimming (trimMatchPath, :475-485).  order[] and acc[] are
+ * per-match scratch slots.  Returns Sum(score)/read_len; *n_paths = number of
+ * emitted paths of the species.                                             */
+MTB_HD float mtb_species_combine(const mtb_match *m, int32_t s, int32_t e, mtb_path *path, const uint8_t *flag,
+                                 int32_t *order, int32_t *acc, int32_t read_len, int32_t *n_paths) {
+    int32_t n = 0;
+    for (int32_t i = s; i < e; i++) {
+        if (!(flag[i] & MTB_PF_EMITTED)) continue;
+        int32_t j = n++;                                   /* stable insertion */
+        while (j > 0 && mtb_path_before(path[i], path[order[s + j - 1]])) { order[s + j] = order[s + j - 1]; j--; }
+        order[s + j] = i;
+    }
+    *n_paths = n;
+    if (n == 0) return 0.0f;
+    float score = 0.0f;
+    int32_t na = 0;
+    for (int32_t k = 0; k < n; k++) {
+        mtb_path &p = path[order[s + k]];
+        int32_t pi = order[s + k];
+        bool drop = false;
+        for (int32_t a = 0; a < na && !drop; a++) {
+            const mtb_path &c = path[acc[s + a]];
+            if (!((p.end < c.start) || (c.end < p.start))) {
+                int32_t ov = (p.end < c.end ? p.end : c.end) - (p.start > c.start ? p.start : c.start) + 1;
+                if (ov == p.end - p.start + 1) { drop = true; break; }
+                if (ov < 24) {
+                    if (p.start < c.start) {
+                        p.end = c.start - 1;
+                        int32_t h = p.ham - mtb_part_ham(m[pi].right_end_hamming, ov / 3, false);
+                        p.ham = h > 0 ? h : 0;
+                        p.score = p.score - mtb_part_score(m[pi].right_end_hamming, ov / 3, false) - (float)(ov % 3);
+                    } else {
+                        p.start = c.end + 1;
+                        int32_t h = p.ham - mtb_part_ham(m[p.start_idx].right_end_hamming, ov / 3, true);
+                        p.ham = h > 0 ? h : 0;
+                        p.score = p.score - mtb_part_score(m[p.start_idx].right_end_hamming, ov / 3, true) - (float)(ov % 3);
+                    }
+                } else drop = true;
+            }
+        }
+        if (!drop) { acc[s + na++] = pi; score += p.score; }
+    }
+    return score / (float)read_len;
+}
+
+/* Taxonomer::filterRedundantMatches (Taxonomer.cpp:205-241) over the best
+ * species block m[s..e).  b_tax/b_ham are bucket arrays of n_buckets entries
+ * (pos / dna_shift); out_tax/out_cnt receive Query::taxCnt in ascending taxid
+ * order (std::map).  Returns the number of entries (<= out_cap written).    */
+MTB_HD int32_t mtb_filter_redundant(const mtb_match *m, int32_t s, int32_t e, const mtb_tax_view *tx,
+                                    int32_t dna_shift, int32_t *b_tax, uint8_t *b_ham, int32_t n_buckets,
+                                    int32_t *out_tax, uint32_t *out_cnt, int32_t out_cap) {
+    for (int32_t q = 0; q < n_buckets; q++) { b_tax[q] = 0; b_ham[q] = 255; }
+    for (int32_t i = s; i < e; i++) {
+        int32_t q = (int32_t)(mtb_q_pos(m[i].qinfo) / (uint32_t)dna_shift);
+        if (q >= n_buckets) continue;            /* cannot happen: see mtb_num_buckets */
+        uint8_t h = m[i].hamming;
+        if (b_ham[q] == 255 || h < b_ham[q]) { b_tax[q] = m[i].target_id; b_ham[q] = h; }
+        else if (h == b_ham[q]) b_tax[q] = mtb_lca(tx, b_tax[q], m[i].target_id);
+    }
+    int32_t n = 0;
+    for (int32_t q = 0; q < n_buckets; q++) {
+        if (b_ham[q] == 255) continue;
+        int32_t t = b_tax[q];
+        int32_t k = 0;
+        while (k < n && out_tax[k] < t) k++;
+        if (k < n && out_tax[k] == t) { out_cnt[k]++; continue; }
+        if (n < out_cap) {
+            for (int32_t j = n; j > k; j--) { out_tax[j] = out_tax[j - 1]; out_cnt[j] = out_cnt[j - 1]; }
+            out_tax[k] = t; out_cnt[k] = 1; n++;
+        }
+    }
+    return n;
+}
+/* bucket count that covers every position of a read (Taxonomer.cpp:210) */
+MTB_HD int32_t mtb_num_buckets(int32_t read_len, int32_t dna_shift) { return (read_len + 3) / dna_shift + 2; }
+
+/* Taxonomer::lowerRankClassification + getSpeciesCladeCounts + BFS
+ * (Taxonomer.cpp:252-314), accession_level != 2.  Descend from the species
+ * while exactly one child holds the maximal clade count and that count is
+ * >= max((len-1)/denominator, ...) in the sense of BFS's compare chain.      */
+MTB_HD int32_t mtb_lower_rank(const mtb_tax_view *tx, const int32_t *tc_tax, const uint32_t *tc_cnt, int32_t n,
+                              int32_t species, int32_t read_len, int32_t denominator) {
+    uint32_t thr = (uint32_t)((read_len - 1) / denominator);
+    int32_t root = species;
+    for (int guard = 0; guard < 64; guard++) {
+        /* children of root on the paths taxon -> species, with clade counts */
+        uint32_t max_cnt = thr; int32_t best = -1; int32_t n_best = 0; bool any_child = false;
+        for (int32_t i = 0; i < n; i++) {
+            /* child of root above tc_tax[i], if tc_tax[i] is a strict descendant of root */
+            int32_t t = tc_tax[i];
+            if (!mtb_tax_exists(tx, t) || tx->depth[t] <= tx->depth[root]) continue;
+            int32_t c = t;
+            while (tx->depth[c] > tx->depth[root] + 1) c = tx->parent[c];
+            if (tx->parent[c] != root) continue;
+            any_child = true;
+            /* count each distinct child once: only at its first contributing entry */
+            bool first = true;
+            for (int32_t j = 0; j < i && first; j++) {
+                int32_t u = tc_tax[j];
+                if (!mtb_tax_exists(tx, u) || tx->depth[u] <= tx->depth[root]) continue;
+                int32_t d = u;
+                while (tx->depth[d] > tx->depth[root] + 1) d = tx->parent[d];
+                if (d == c) first = false;
+            }
+            if (!first) continue;
+            uint32_t clade = 0;
+            for (int32_t j = i; j < n; j++) {
+                int32_t u = tc_tax[j];
+                if (!mtb_tax_exists(tx, u) || tx->depth[u] <= tx->depth[root]) continue;
+                int32_t d = u;
+                while (tx->depth[d] > tx->depth[root] + 1) d = tx->parent[d];
+                if (d == c) clade += tc_cnt[j];
+            }
+            if (clade > max_cnt) { best = c; n_best = 1; max_cnt = clade; }
+            else if (clade == max_cnt) { if (n_best == 0) best = c; n_best++; }
+        }
+        if (!any_child) return root;
+        if (n_best == 1) root = best; else return root;
+    }
+    return root;
+}
+
+/* Second half of Taxonomer::getBestSpeciesMatches (Taxonomer.cpp:354-407) and
+ * Taxonomer::chooseBestTaxon (Taxonomer.cpp:130-202) for one read.  sps[s]
+ * holds, at the first slot s of every species block, min(combine(),1) or
+ * -1 if the species produced no path.  Scratch: bucket arrays (n_buckets),
+ * out_tax/out_cnt (out_cap) receive Query::taxCnt.                           */
+MTB_HD void mtb_read_decide(const mtb_match *m, int32_t n, const float *sps, const mtb_tax_view *tx,
+                            const mtb_score_params *sp, int32_t read_len, int32_t *b_tax, uint8_t *b_ham,
+                            int32_t n_buckets, int32_t *out_tax, uint32_t *out_cnt, int32_t out_cap,
+                            mtb_result *R) {
+    R->classification = 0; R->score = 0.0f; R->is_classified = 0; R->n_taxcnt = 0;
+    float best_sp = 0.0f; int32_t best_s = 0, best_e = 0; int32_t meaningful = 0;
+    int32_t i = 0;
+    while (i < n) {
+        int32_t s = i; int32_t spc = m[i].species_id;
+        while (i < n && m[i].species_id == spc) i++;
+        float sc = sps[s];
+        if (sc == -1.0f) continue;                 /* no path for this species          */
+        if (sc < sp->min_score) continue;          /* Taxonomer.cpp:357-359             */
+        if (sc > 0.0f) meaningful++;
+        if (sc > best_sp) { best_sp = sc; best_s = s; best_e = i; }
+    }
+    if (meaningful == 0) return;                   /* score 0, unclassified (:372-375)  */
+    /* ties within tie_ratio (:388-402); LCA(vector) skips unknown ids */
+    float sum = 0.0f; int32_t n_max = 0; int32_t lca = -1; int32_t only = 0;
+    float cut = best_sp * sp->tie_ratio;
+    i = 0;
+    while (i < n) {
+        int32_t s = i; int32_t spc = m[i].species_id;
+        while (i < n && m[i].species_id == spc) i++;
+        float sc = sps[s];
+        if (sc == -1.0f || sc < sp->min_score) continue;
+        if (sc >= cut) {
+            sum += sc; only = spc; n_max++;
+            if (mtb_tax_exists(tx, spc)) lca = lca < 0 ? spc : mtb_lca(tx, lca, spc);
+        }
+    }
+    float score = n_max > 1 ? sum / (float)n_max : sum;
+    R->score = score;
+    if (score == 0.0f || score < sp->min_score) return;          /* :149-156 */
+    if (n_max > 1) { R->is_classified = 1; R->classification = lca < 0 ? 0 : lca; return; }   /* :159-165 */
+    int32_t ntc = mtb_filter_redundant(m, best_s, best_e, tx, sp->dna_shift, b_tax, b_ham, n_buckets, out_tax, out_cnt, out_cap);
+    R->n_taxcnt = (uint16_t)ntc;
+    R->is_classified = 1;
+    if (score < sp->min_sp_score) {                                /* :178-185 */
+        R->classification = (only >= 0 && only <= tx->max_taxid) ? tx->sp_parent[only] : 0;
+        return;
+    }
+    R->classification = mtb_lower_rank(tx, out_tax, out_cnt, ntc, only, read_len, sp->denominator);
+}
+
+#endif /* MTB_CORE_H */

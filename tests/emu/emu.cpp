@@ -1,0 +1,122 @@
+/*
+ * tests/emu/emu.cpp -- TEST-ONLY host build of metabuli_amd/csrc/mtb_core.h.
+ *
+ * The HIP kernels call the per-lane functions of mtb_core.h; this file calls
+ * the same functions from plain sequential loops so that the kernel
+ * arithmetic can be checked against the oracle in a container without a GPU.
+ * It is not a CPU fallback: nothing in the product library or in bench.py
+ * links or loads it.
+ */
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+#include "../../metabuli_amd/csrc/mtb_core.h"
+
+extern "C" {
+
+void emu_tables(mtb_tables *t) { mtb_build_tables(t); }
+
+// mirrors kernels_extract.hip: per read, per frame, per window
+size_t emu_extract_batch(const char *bases, const uint64_t *offs, const char *bases2, const uint64_t *offs2,
+                         size_t n_reads, const mtb_params *p, mtb_kmer *out, size_t cap, int32_t *qlen, int32_t *qlen2) {
+    mtb_tables t; mtb_build_tables(&t);
+    size_t n = 0;
+    for (size_t r = 0; r < n_reads; r++) {
+        int32_t len1 = (int32_t)(offs[r + 1] - offs[r]);
+        int32_t len2 = p->seq_mode == 2 ? (int32_t)(offs2[r + 1] - offs2[r]) : 0;
+        qlen[r] = mtb_used_len(len1); qlen2[r] = p->seq_mode == 2 ? mtb_used_len(len2) : 0;
+        bool skip = mtb_read_too_short(len1) || (p->seq_mode == 2 && mtb_read_too_short(len2));
+        if (skip) continue;
+        for (int mate = 0; mate < (p->seq_mode == 2 ? 2 : 1); mate++) {
+            const char *seq = mate ? bases2 + offs2[r] : bases + offs[r];
+            int32_t len = mate ? len2 : len1;
+            uint32_t off = mate ? (uint32_t)(qlen[r] + 3) : 0;
+            int32_t used = mtb_used_len(len);
+            int32_t n_cod = used / 3, n_win = n_cod - 7;
+            for (int f = 0; f < 6; f++) {
+                bool fwd = f < 3;
+                int32_t begin = mtb_frame_begin(len, f);
+                std::vector<uint8_t> cod((size_t)n_cod);
+                for (int j = 0; j < n_cod; j++) cod[(size_t)j] = mtb_codon_byte(&t, seq, mtb_codon_ci(begin, used, j, fwd), fwd);
+                for (int w = 0; w < n_win; w++) {
+                    uint64_t v;
+                    if (mtb_window_metamer(&cod[(size_t)w], p->syncmer, p->smer_len, &v)) {
+                        if (n < cap) out[n] = {v, mtb_qinfo((uint32_t)(r + 1), mtb_window_pos(begin, used, w, fwd) + off, (uint32_t)f)};
+                        n++;
+                    }
+                }
+            }
+        }
+    }
+    return n;
+}
+
+size_t emu_join(const uint64_t *values, const uint32_t *info, uint64_t T, const int32_t *tax2species, int32_t max_taxid,
+                uint32_t info_mask, int kmer_format, const mtb_kmer *q, size_t n, mtb_match *out, size_t cap) {
+    mtb_tables t; mtb_build_tables(&t);
+    mtb_index_view ix{values, info, T, tax2species, max_taxid, info_mask, kmer_format};
+    size_t m = 0;
+    for (size_t j = 0; j < n; j++) {
+        uint64_t rs = 0; uint32_t rl = 0;
+        uint32_t c = mtb_join_query(&t, &ix, q[j].value, q[j].qinfo, nullptr, 0, 0, &rs, &rl);
+        if (c == 0) continue;
+        if (m + c <= cap) mtb_join_query(&t, &ix, q[j].value, q[j].qinfo, out + m, c, 1, &rs, &rl);
+        m += c;
+    }
+    return m;
+}
+
+void emu_sort_matches(mtb_match *m, size_t n) { std::sort(m, m + n, [](const mtb_match &a, const mtb_match &b) { return mtb_match_less(a, b); }); }
+
+// mirrors kernels_score.hip score_read(): sequential over the sf blocks / species blocks
+size_t emu_score(const int32_t *parent, const int32_t *depth, const uint8_t *under_euk, const int32_t *sp_parent, int32_t max_taxid,
+                 const mtb_params *p, const mtb_match *ml, size_t nM, size_t n_reads, const int32_t *qlen, const int32_t *qlen2,
+                 mtb_result *res, int32_t *tc_tax, uint32_t *tc_cnt, size_t cap) {
+    mtb_tax_view tx{parent, depth, under_euk, sp_parent, max_taxid};
+    mtb_score_params sp; mtb_make_score_params(p, &sp);
+    for (size_t r = 0; r < n_reads; r++) { res[r] = mtb_result{0, 0.f, qlen[r], qlen2 ? qlen2[r] : 0, 0, 0, 0, 0}; }
+    size_t w = 0, idx = 0;
+    while (idx < nM) {
+        uint32_t seq = mtb_q_seq(ml[idx].qinfo);
+        size_t s0 = idx; while (idx < nM && mtb_q_seq(ml[idx].qinfo) == seq) idx++;
+        int32_t n = (int32_t)(idx - s0);
+        const mtb_match *m = ml + s0;
+        size_t r = seq - 1;
+        int32_t read_len = qlen[r] + (qlen2 ? qlen2[r] : 0);
+        std::vector<mtb_path> path((size_t)n); std::vector<uint8_t> flag((size_t)n, 0);
+        std::vector<int32_t> order((size_t)n), acc((size_t)n);
+        // phase 1: paths per (species, frame) block
+        int32_t i = 0;
+        while (i < n) {
+            int32_t s = i; int32_t spc = m[i].species_id; uint32_t fr = mtb_q_frame(m[i].qinfo);
+            while (i < n && m[i].species_id == spc && mtb_q_frame(m[i].qinfo) == fr) i++;
+            if (i - s > 1) {
+                int32_t md = (spc >= 0 && spc <= max_taxid && under_euk[spc]) ? sp.min_cons_cnt_euk : sp.min_cons_cnt;
+                mtb_sf_block_paths(m, s, i, path.data(), flag.data(), &sp, md);
+            }
+        }
+        // phase 2: per species combine (score at the species' first slot)
+        std::vector<float> sps((size_t)n, -1.0f);
+        i = 0;
+        while (i < n) {
+            int32_t s = i; int32_t spc = m[i].species_id;
+            while (i < n && m[i].species_id == spc) i++;
+            int32_t np = 0;
+            float sc = mtb_species_combine(m, s, i, path.data(), flag.data(), order.data(), acc.data(), read_len, &np);
+            if (np > 0) sps[(size_t)s] = sc < 1.0f ? sc : 1.0f;
+        }
+        // phase 3: decision
+        int32_t nb = mtb_num_buckets(read_len, sp.dna_shift);
+        std::vector<int32_t> btax((size_t)nb); std::vector<uint8_t> bham((size_t)nb);
+        std::vector<int32_t> ot((size_t)nb); std::vector<uint32_t> oc((size_t)nb);
+        mtb_result R = res[r];
+        mtb_read_decide(m, n, sps.data(), &tx, &sp, read_len, btax.data(), bham.data(), nb, ot.data(), oc.data(), nb, &R);
+        R.taxcnt_off = (uint32_t)w;
+        for (int32_t k = 0; k < (int32_t)R.n_taxcnt; k++) { if (w < cap) { tc_tax[w] = ot[(size_t)k]; tc_cnt[w] = oc[(size_t)k]; } w++; }
+        res[r] = R;
+    }
+    return w;
+}
+
+} // extern "C"
