@@ -1,0 +1,237 @@
+"""metabuli_amd -- MI355X-native engine for the `metabuli classify` hot path.
+
+This package is plumbing only: it loads the C-ABI shared library
+(metabuli_amd/csrc/libmtb.so, declared in include/mtb.h) with ctypes and moves
+numpy arrays / device pointers across it.  There is no Python or CPU
+implementation of the path: if the HIP library is missing, import-time use
+fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_CSRC, "libmtb.so")
+
+kmer_dt = np.dtype([("value", "<u8"), ("qinfo", "<u8")])
+match_dt = np.dtype([("qinfo", "<u8"), ("target_id", "<i4"), ("species_id", "<i4"), ("dna", "<u4"),
+                     ("reh", "<u2"), ("ham", "u1"), ("pad", "u1")])
+result_dt = np.dtype([("classification", "<i4"), ("score", "<f4"), ("qlen", "<i4"), ("qlen2", "<i4"),
+                      ("is_classified", "u1"), ("flag", "u1"), ("n_taxcnt", "<u2"), ("taxcnt_off", "<u4")])
+
+MTB_OK, MTB_ERR_ARG, MTB_ERR_IO, MTB_ERR_DEVICE, MTB_ERR_CAPACITY, MTB_ERR_OOM, MTB_ERR_UNSUPPORTED = range(7)
+
+
+class Params(C.Structure):
+    _fields_ = [("seq_mode", C.c_int32), ("syncmer", C.c_int32), ("smer_len", C.c_int32),
+                ("kmer_format", C.c_int32), ("min_cons_cnt", C.c_int32), ("min_cons_cnt_euk", C.c_int32),
+                ("min_score", C.c_float), ("min_sp_score", C.c_float), ("tie_ratio", C.c_float),
+                ("accession_level", C.c_int32), ("skip_redundancy", C.c_int32)]
+
+
+class BatchStats(C.Structure):
+    _fields_ = [("ms_extract", C.c_float), ("ms_sort", C.c_float), ("ms_join", C.c_float), ("ms_regroup", C.c_float),
+                ("ms_segsort", C.c_float), ("ms_score", C.c_float), ("ms_total", C.c_float),
+                ("n_reads", C.c_uint64), ("n_bases", C.c_uint64), ("n_kmers", C.c_uint64),
+                ("n_matches", C.c_uint64), ("n_targets", C.c_uint64)]
+
+
+class MtbError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"mtb status {status}: {msg}")
+        self.status = status
+
+
+def build(force=False):
+    """Compile libmtb.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if force and os.path.exists(LIB_PATH):
+        os.remove(LIB_PATH)
+    subprocess.check_call(["make", "-C", _CSRC, "libmtb.so"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library.  No fallback: raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not found: the HIP extension must be built (python -c 'import __graft_entry__ as g; g.build()'); "
+                           "there is no CPU implementation of this path")
+    L = C.CDLL(LIB_PATH)
+    L.mtb_version.restype = C.c_char_p
+    L.mtb_last_error.restype = C.c_char_p
+    L.mtb_index_num_targets.restype = C.c_uint64
+    L.mtb_index_num_targets.argtypes = [C.c_void_p]
+    for f in ("mtb_tax_lca", "mtb_tax_species", "mtb_tax_parent", "mtb_tax_max_id"):
+        getattr(L, f).restype = C.c_int32
+    L.mtb_tax_lca.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+    L.mtb_tax_species.argtypes = [C.c_void_p, C.c_int32]
+    L.mtb_tax_parent.argtypes = [C.c_void_p, C.c_int32]
+    L.mtb_tax_max_id.argtypes = [C.c_void_p]
+    _lib = L
+    return L
+
+
+def default_params(**kw):
+    """classify defaults for a syncmer DB written by `build` (db.parameters overrides apply at index open)."""
+    p = Params(seq_mode=1, syncmer=1, smer_len=5, kmer_format=2, min_cons_cnt=4, min_cons_cnt_euk=9,
+               min_score=0.0, min_sp_score=0.0, tie_ratio=0.95, accession_level=0, skip_redundancy=1)
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def _p(a):
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _chk(st):
+    if st != MTB_OK:
+        raise MtbError(st, lib().mtb_last_error().decode())
+
+
+class Context:
+    def __init__(self, device=0, stream=0):
+        self.L = lib()
+        h = C.c_void_p()
+        _chk(self.L.mtb_ctx_create(C.c_int(device), C.c_void_p(stream), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.L.mtb_ctx_destroy(self.h)
+            self.h = None
+
+    def sync(self):
+        _chk(self.L.mtb_ctx_sync(self.h))
+
+    # ---- index ----
+    def open_index(self, dbdir, params, taxonomy_dir=None):
+        h = C.c_void_p()
+        _chk(self.L.mtb_index_open(self.h, dbdir.encode(), taxonomy_dir.encode() if taxonomy_dir else None,
+                                   C.byref(params), C.byref(h)))
+        return Index(self, h)
+
+    def index_from_device(self, d_values, d_info, n_targets, taxonomy_dir, taxid_list, params):
+        h = C.c_void_p()
+        tl = np.ascontiguousarray(taxid_list, dtype=np.int32)
+        _chk(self.L.mtb_index_from_device(self.h, C.c_void_p(d_values), C.c_void_p(d_info), C.c_uint64(n_targets),
+                                          taxonomy_dir.encode(), _p(tl), C.c_size_t(len(tl)), C.byref(params), C.byref(h)))
+        return Index(self, h)
+
+    def synth_index(self, seed, n_filler, tax_lo, tax_hi, real_values, real_taxids, d_values, d_info):
+        rv = np.ascontiguousarray(real_values, dtype=np.uint64)
+        rt = np.ascontiguousarray(real_taxids, dtype=np.int32)
+        n = C.c_uint64()
+        _chk(self.L.mtb_synth_index(self.h, C.c_uint64(seed), C.c_uint64(n_filler), C.c_int32(tax_lo), C.c_int32(tax_hi),
+                                    _p(rv), _p(rt), C.c_uint64(len(rv)), C.c_void_p(d_values), C.c_void_p(d_info), C.byref(n)))
+        return n.value
+
+    # ---- stages (host buffers) ----
+    def extract(self, params, bases, offs, bases2=None, offs2=None, cap=None):
+        n = len(offs) - 1
+        total = int(offs[-1]) + (int(offs2[-1]) if offs2 is not None else 0)
+        cap = cap or max(16, 2 * total + 64)
+        out = np.zeros(cap, kmer_dt)
+        ql = np.zeros(n, np.int32); ql2 = np.zeros(n, np.int32)
+        cnt = C.c_uint64()
+        _chk(self.L.mtb_extract(self.h, C.byref(params), _p(bases), _p(offs), _p(bases2), _p(offs2), C.c_uint64(n),
+                                _p(out), C.c_uint64(cap), C.byref(cnt), _p(ql), _p(ql2)))
+        return out[:cnt.value].copy(), ql, ql2
+
+    def sort_kmers(self, kmers):
+        k = np.ascontiguousarray(kmers).copy()
+        _chk(self.L.mtb_sort_kmers(self.h, _p(k), C.c_uint64(len(k))))
+        return k
+
+    def match(self, index, sorted_kmers, cap=None):
+        cap = cap or max(1024, 4 * len(sorted_kmers))
+        while True:
+            out = np.zeros(cap, match_dt)
+            cnt = C.c_uint64()
+            st = self.L.mtb_match_kmers(self.h, index.h, _p(sorted_kmers), C.c_uint64(len(sorted_kmers)), _p(out),
+                                        C.c_uint64(cap), C.byref(cnt))
+            if st == MTB_ERR_CAPACITY:
+                cap = cnt.value + 16
+                continue
+            _chk(st)
+            return out[:cnt.value].copy()
+
+    def sort_matches(self, matches, n_reads):
+        m = np.ascontiguousarray(matches).copy()
+        _chk(self.L.mtb_sort_matches(self.h, _p(m), C.c_uint64(len(m)), C.c_uint64(n_reads)))
+        return m
+
+    def score(self, index, params, sorted_matches, n_reads, qlen, qlen2):
+        res = np.zeros(n_reads, result_dt)
+        cap = max(1024, len(sorted_matches) + 16)
+        tt = np.zeros(cap, np.int32); tc = np.zeros(cap, np.uint32)
+        n = C.c_uint64()
+        _chk(self.L.mtb_score(self.h, index.h, C.byref(params), _p(sorted_matches), C.c_uint64(len(sorted_matches)),
+                              C.c_uint64(n_reads), _p(qlen), _p(qlen2), _p(res), _p(tt), _p(tc), C.c_uint64(cap), C.byref(n)))
+        return res, tt[:n.value].copy(), tc[:n.value].copy()
+
+    # ---- fused batch ----
+    def classify_batch(self, index, params, bases, offs, bases2=None, offs2=None):
+        n = len(offs) - 1
+        res = np.zeros(n, result_dt)
+        cap = max(1024, 64 * n)
+        while True:
+            tt = np.zeros(cap, np.int32); tc = np.zeros(cap, np.uint32)
+            cnt = C.c_uint64()
+            st = self.L.mtb_classify_batch(self.h, index.h, C.byref(params), _p(bases), _p(offs), _p(bases2), _p(offs2),
+                                           C.c_uint64(n), _p(res), _p(tt), _p(tc), C.c_uint64(cap), C.byref(cnt))
+            if st == MTB_ERR_CAPACITY and cnt.value > cap:
+                cap = cnt.value
+                continue
+            _chk(st)
+            return res, tt[:cnt.value].copy(), tc[:cnt.value].copy()
+
+    def classify_batch_device(self, index, params, d_bases, d_offs, d_bases2, d_offs2, n_reads, n_bases,
+                              d_results, d_tc_tax, d_tc_cnt, tc_cap):
+        cnt = C.c_uint64()
+        _chk(self.L.mtb_classify_batch_device(self.h, index.h, C.byref(params), C.c_void_p(d_bases), C.c_void_p(d_offs),
+                                              C.c_void_p(d_bases2) if d_bases2 else None,
+                                              C.c_void_p(d_offs2) if d_offs2 else None,
+                                              C.c_uint64(n_reads), C.c_uint64(n_bases), C.c_void_p(d_results),
+                                              C.c_void_p(d_tc_tax), C.c_void_p(d_tc_cnt), C.c_uint64(tc_cap), C.byref(cnt)))
+        return cnt.value
+
+    def last_stats(self):
+        s = BatchStats()
+        _chk(self.L.mtb_last_batch_stats(self.h, C.byref(s)))
+        return s
+
+
+class Index:
+    def __init__(self, ctx, h):
+        self.ctx = ctx
+        self.h = h
+
+    @property
+    def num_targets(self):
+        return self.ctx.L.mtb_index_num_targets(self.h)
+
+    def download(self):
+        n = self.num_targets
+        v = np.zeros(n, np.uint64); i = np.zeros(n, np.uint32)
+        _chk(self.ctx.L.mtb_index_download(self.h, _p(v), _p(i), C.c_uint64(n)))
+        return v, i
+
+    def close(self):
+        if self.h:
+            self.ctx.L.mtb_index_close(self.h)
+            self.h = None

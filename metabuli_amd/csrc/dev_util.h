@@ -1,0 +1,41 @@
+/* dev_util.h -- wave64 / workgroup primitives for gfx950 (CDNA4). */
+#ifndef MTB_DEV_UTIL_H
+#define MTB_DEV_UTIL_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MTB_WAVE 64
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+__device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+/* inclusive scan across the 64 lanes of a wavefront */
+template <typename T>
+__device__ __forceinline__ T wave_inclusive_scan(T v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        T o = __shfl_up(v, d, 64);
+        if ((int)lane_id() >= d) v += o;
+    }
+    return v;
+}
+
+/* Exclusive scan over a 256-thread workgroup; every thread gets its exclusive
+ * prefix and *total (sum over the workgroup).  s_tmp: >= 5 elements of LDS.   */
+template <typename T>
+__device__ __forceinline__ T block256_exclusive_scan(T v, T *s_tmp, T *total) {
+    T inc = wave_inclusive_scan(v);
+    uint32_t w = threadIdx.x >> 6;
+    __syncthreads();                       /* protect s_tmp from a previous use */
+    if (lane_id() == 63) s_tmp[w] = inc;
+    __syncthreads();
+    T pre = 0;
+    T t0 = s_tmp[0], t1 = s_tmp[1], t2 = s_tmp[2], t3 = s_tmp[3];
+    if (w > 0) pre += t0;
+    if (w > 1) pre += t1;
+    if (w > 2) pre += t2;
+    *total = t0 + t1 + t2 + t3;
+    return pre + inc - v;
+}
+
+#endif

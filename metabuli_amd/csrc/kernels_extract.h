@@ -1,0 +1,93 @@
+/* kernels_extract.h -- six-frame translation, syncmer selection and 64-bit
+ * metamer packing: one wavefront per read (BASELINE north_star).
+ *
+ * Per frame the wave first turns the read into a codon-byte string in LDS
+ * (lane j -> codon j: three base loads + one 64-entry LUT), then lane p packs
+ * the window of codons p..p+7 and applies the closed-syncmer test
+ * (mtb_window_metamer); selected windows are compacted with a ballot /
+ * popcount prefix.  Two passes (count, emit) give deterministic output in the
+ * reference's emission order (read, mate, frame, window):
+ *   KmerExtractor::fillQueryKmerBuffer  src/commons/KmerExtractor.cpp:342-373
+ *   MetamerScanner::next               src/commons/KmerScanner.h:82-117
+ *   SyncmerScanner::next               src/commons/SyncmerScanner.h:36-101
+ * Algorithmic HBM bytes: sum(L) read per pass + 16 B per emitted metamer.    */
+#ifndef MTB_KERNELS_EXTRACT_H
+#define MTB_KERNELS_EXTRACT_H
+#include "dev_util.h"
+#include "mtb_core.h"
+
+struct ExtractArgs {
+    const char *bases; const uint64_t *offs;
+    const char *bases2; const uint64_t *offs2;
+    uint64_t n_reads;
+    int32_t seq_mode, syncmer, smer_len;
+};
+
+template <bool EMIT>
+__global__ __launch_bounds__(64) void k_extract(ExtractArgs a, const mtb_tables *__restrict__ tabs,
+                                                uint32_t *__restrict__ counts, const uint64_t *__restrict__ out_offs,
+                                                mtb_kmer *__restrict__ out, int32_t *__restrict__ qlen,
+                                                int32_t *__restrict__ qlen2, uint32_t *__restrict__ max_len) {
+    __shared__ mtb_tables s_tab;
+    __shared__ uint8_t s_cod[80];
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t i = lane; i < sizeof(mtb_tables) / 4; i += 64) ((uint32_t *)&s_tab)[i] = ((const uint32_t *)tabs)[i];
+    __syncthreads();
+    uint32_t my_max = 0;
+    const bool paired = a.seq_mode == 2;
+    for (uint64_t r = blockIdx.x; r < a.n_reads; r += gridDim.x) {
+        const uint64_t o1 = a.offs[r];
+        const int32_t len1 = (int32_t)(a.offs[r + 1] - o1);
+        uint64_t o2 = 0; int32_t len2 = 0;
+        if (paired) { o2 = a.offs2[r]; len2 = (int32_t)(a.offs2[r + 1] - o2); }
+        const int32_t ql1 = mtb_used_len(len1), ql2 = paired ? mtb_used_len(len2) : 0;
+        if (!EMIT) {
+            if (lane == 0) { qlen[r] = ql1; qlen2[r] = ql2; }
+            uint32_t tot_len = (uint32_t)(ql1 + ql2);
+            my_max = tot_len > my_max ? tot_len : my_max;
+        }
+        /* pair skipped if either mate is too short (KmerExtractor.cpp:443-453) */
+        const bool skip = mtb_read_too_short(len1) || (paired && mtb_read_too_short(len2));
+        if (skip) { if (!EMIT && lane == 0) counts[r] = 0; continue; }
+        uint64_t wpos = EMIT ? out_offs[r] : 0;
+        uint32_t total = 0;
+        for (int mate = 0; mate < (paired ? 2 : 1); mate++) {
+            const char *seq = mate ? a.bases2 + o2 : a.bases + o1;
+            const int32_t len = mate ? len2 : len1;
+            const uint32_t pos_off = mate ? (uint32_t)(ql1 + 3) : 0u;     /* KmerExtractor.cpp:329 */
+            const int32_t used = mtb_used_len(len);
+            const int32_t n_cod = used / 3, n_win = n_cod - 7;
+            for (int f = 0; f < 6; f++) {
+                const bool fwd = f < 3;
+                const int32_t begin = mtb_frame_begin(len, f);
+                for (int32_t w0 = 0; w0 < n_win; w0 += 64) {
+                    int32_t j = w0 + (int32_t)lane;
+                    if (j < n_cod) s_cod[lane] = mtb_codon_byte(&s_tab, seq, mtb_codon_ci(begin, used, j, fwd), fwd);
+                    int32_t j2 = w0 + 64 + (int32_t)lane;
+                    if (lane < 8 && j2 < n_cod) s_cod[64 + lane] = mtb_codon_byte(&s_tab, seq, mtb_codon_ci(begin, used, j2, fwd), fwd);
+                    __syncthreads();
+                    int32_t w = w0 + (int32_t)lane;
+                    bool ok = false; uint64_t v = 0;
+                    if (w < n_win) ok = mtb_window_metamer(&s_cod[lane], a.syncmer, a.smer_len, &v);
+                    uint64_t mask = __ballot(ok);
+                    if (EMIT && ok) {
+                        mtb_kmer k;
+                        k.value = v;
+                        k.qinfo = mtb_qinfo((uint32_t)(r + 1), mtb_window_pos(begin, used, w, fwd) + pos_off, (uint32_t)f);
+                        out[wpos + (uint64_t)__popcll(mask & lanemask_lt())] = k;
+                    }
+                    uint32_t c = (uint32_t)__popcll(mask);
+                    wpos += c; total += c;
+                    __syncthreads();
+                }
+            }
+        }
+        if (!EMIT && lane == 0) counts[r] = total;
+    }
+    if (!EMIT && max_len) {
+        for (int d = 32; d > 0; d >>= 1) { uint32_t o = __shfl_down(my_max, d, 64); my_max = o > my_max ? o : my_max; }
+        if (lane == 0 && my_max) atomicMax(max_len, my_max);
+    }
+}
+
+#endif

@@ -1,0 +1,132 @@
+/* kernels_join.h -- sorted-merge lookup of the query metamers against the flat
+ * target index resident in HBM, and the regrouping of matches by read.
+ *
+ * k_join: one lane per sorted query metamer.  Neighbouring lanes hold
+ * neighbouring values, so the binary searches of a wavefront walk the same
+ * upper levels (served by L2 / Infinity Cache) and end in adjacent 64-bit
+ * words of the index (coalesced loads).  Two-phase selection per query
+ * (min Hamming, threshold min(2*min,7)), workgroup scan of the counts, ONE
+ * atomic per workgroup to reserve output, then emit.  Functional form of
+ * KmerMatcher::matchKmers (src/commons/KmerMatcher.cpp:123-481) + compareDna
+ * (:1117-1146); the per-read match counters it also feeds replace the global
+ * comparison sort of matches by sequenceID (sortMatches, :1071-1078).
+ * Algorithmic HBM bytes: 16 per query + 12 per target of the spanned range +
+ * 24 per emitted match.                                                      */
+#ifndef MTB_KERNELS_JOIN_H
+#define MTB_KERNELS_JOIN_H
+#include "dev_util.h"
+#include "mtb_core.h"
+
+__global__ __launch_bounds__(256) void k_join(const mtb_kmer *__restrict__ q, uint64_t n, mtb_index_view ix,
+                                               const mtb_tables *__restrict__ tabs, mtb_match *__restrict__ out,
+                                               uint64_t cap, unsigned long long *__restrict__ counter,
+                                               uint32_t *__restrict__ read_cnt, uint32_t *__restrict__ overflow) {
+    __shared__ mtb_tables s_tab;
+    __shared__ uint32_t s_tmp[8];
+    __shared__ unsigned long long s_base;
+    for (uint32_t i = threadIdx.x; i < sizeof(mtb_tables) / 4; i += 256) ((uint32_t *)&s_tab)[i] = ((const uint32_t *)tabs)[i];
+    __syncthreads();
+    uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t c = 0; uint64_t rs = 0; uint32_t rl = 0;
+    mtb_kmer k; k.value = 0; k.qinfo = 0;
+    if (j < n) {
+        k = q[j];
+        if (mtb_q_seq(k.qinfo) != 0)        /* blank slots carry sequenceID 0 (KmerMatcher.cpp:143-151) */
+            c = mtb_join_query(&s_tab, &ix, k.value, k.qinfo, nullptr, 0, 0, &rs, &rl);
+    }
+    uint32_t tot;
+    uint32_t off = block256_exclusive_scan<uint32_t>(c, s_tmp, &tot);
+    if (threadIdx.x == 0) s_base = tot ? atomicAdd(counter, (unsigned long long)tot) : 0ull;
+    __syncthreads();
+    if (c == 0) return;
+    uint64_t dst = (uint64_t)s_base + off;
+    if (read_cnt) atomicAdd(&read_cnt[mtb_q_seq(k.qinfo) - 1], c);
+    if (dst + c > cap) { *overflow = 1; return; }
+    mtb_join_query(&s_tab, &ix, k.value, k.qinfo, out + dst, c, 1, &rs, &rl);
+}
+
+/* Move every match into its read's segment (seg_start from a scan of the
+ * per-read counters).  The order inside a segment is irrelevant: the segment
+ * sort that follows imposes the total order of compareMatches.              */
+__global__ __launch_bounds__(256) void k_regroup(const mtb_match *__restrict__ in, uint64_t n, const uint64_t *__restrict__ seg_start,
+                                                  uint32_t *__restrict__ cursor, mtb_match *__restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    mtb_match m = in[i];
+    uint32_t r = mtb_q_seq(m.qinfo) - 1;
+    uint32_t slot = atomicAdd(&cursor[r], 1u);
+    out[seg_start[r] + slot] = m;
+}
+
+/* per-read counters from an (arbitrarily ordered) match list: stage API path */
+__global__ __launch_bounds__(256) void k_count_reads(const mtb_match *__restrict__ in, uint64_t n, uint32_t *__restrict__ read_cnt) {
+    uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    atomicAdd(&read_cnt[mtb_q_seq(in[i].qinfo) - 1], 1u);
+}
+
+/* ---- segment sort: compareMatches order inside every read segment -------
+ * All-ascending bitonic network (partner i^(2k-1) on the first step of a
+ * merge, i^j afterwards): with virtual +inf padding behind the segment every
+ * compare against an index >= n is a no-op, so n need not be a power of two.
+ * Small segments: one wavefront, records staged in LDS.  Large segments
+ * (listed in `large`): one 256-thread workgroup, in place in HBM/L2.        */
+#define MTB_SEG_LDS 512
+
+__device__ __forceinline__ void seg_cmpx(mtb_match *a, uint32_t i, uint32_t j) {
+    mtb_match x = a[i], y = a[j];
+    if (mtb_match_less(y, x)) { a[i] = y; a[j] = x; }
+}
+
+template <int NT>
+__device__ __forceinline__ void seg_bitonic(mtb_match *a, uint32_t n, uint32_t tid) {
+    uint32_t p2 = 1; while (p2 < n) p2 <<= 1;
+    for (uint32_t k = 2; k <= p2; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = tid; t < (p2 >> 1); t += NT) {
+                /* t-th compare-exchange pair of this step */
+                uint32_t lo = ((t / j) * (j << 1)) + (t % j);
+                uint32_t hi = (j == (k >> 1)) ? (lo ^ ((j << 1) - 1)) : (lo + j);
+                if (hi < lo) { uint32_t z = lo; lo = hi; hi = z; }
+                if (hi < n) seg_cmpx(a, lo, hi);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_segsort_small(mtb_match *__restrict__ m, const uint64_t *__restrict__ seg_start, uint64_t n_reads,
+                                                       uint32_t *__restrict__ large, uint32_t *__restrict__ n_large, uint32_t *__restrict__ max_seg) {
+    __shared__ mtb_match s_m[MTB_SEG_LDS];
+    uint32_t my_max = 0;
+    for (uint64_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
+        uint64_t s = seg_start[r];
+        uint64_t n64 = seg_start[r + 1] - s;
+        uint32_t n = (uint32_t)n64;
+        my_max = n > my_max ? n : my_max;
+        if (n < 2) continue;
+        if (n > MTB_SEG_LDS) { if (threadIdx.x == 0) large[atomicAdd(n_large, 1u)] = (uint32_t)r; continue; }
+        const uint64_t *src = (const uint64_t *)(m + s);
+        uint64_t *dstl = (uint64_t *)s_m;
+        for (uint32_t i = threadIdx.x; i < n * 3; i += 64) dstl[i] = src[i];
+        __syncthreads();
+        seg_bitonic<64>(s_m, n, threadIdx.x);
+        uint64_t *dstg = (uint64_t *)(m + s);
+        for (uint32_t i = threadIdx.x; i < n * 3; i += 64) dstg[i] = dstl[i];
+        __syncthreads();
+    }
+    if (max_seg && threadIdx.x == 0 && my_max) atomicMax(max_seg, my_max);
+}
+
+__global__ __launch_bounds__(256) void k_segsort_large(mtb_match *__restrict__ m, const uint64_t *__restrict__ seg_start,
+                                                        const uint32_t *__restrict__ large, const uint32_t *__restrict__ n_large) {
+    uint32_t nl = *n_large;
+    for (uint32_t b = blockIdx.x; b < nl; b += gridDim.x) {
+        uint32_t r = large[b];
+        uint64_t s = seg_start[r];
+        uint32_t n = (uint32_t)(seg_start[r + 1] - s);
+        seg_bitonic<256>(m + s, n, threadIdx.x);
+    }
+}
+
+#endif

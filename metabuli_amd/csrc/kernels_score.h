@@ -1,0 +1,135 @@
+/* kernels_score.h -- per-read match extension and scoring, one wavefront per
+ * read (Classifier::assignTaxonomy -> Taxonomer::chooseBestTaxon,
+ * src/commons/Classifier.cpp:166-208, src/commons/Taxonomer.cpp:130-699).
+ *
+ * The read's sorted match segment is staged in LDS (or, for segments larger
+ * than MTB_SCORE_LDS matches, in a per-workgroup slab in HBM).  Lanes then
+ * work on independent pieces of the reference's nested loops:
+ *   phase 1  one lane per (species, frame) block: chain DP (getMatchPaths);
+ *            every match owns the slot of the only path it can end;
+ *   phase 2  one lane per species block: stable order + greedy combination of
+ *            its paths (combineMatchPaths), score at the block's first slot;
+ *   phase 3  lane 0: best species / ties -> LCA, redundancy filter, sub-species
+ *            descent (mtb_read_decide).
+ * Algorithmic HBM bytes: 24 per match read + 24 per read result written.     */
+#ifndef MTB_KERNELS_SCORE_H
+#define MTB_KERNELS_SCORE_H
+#include "dev_util.h"
+#include "mtb_core.h"
+
+#define MTB_SCORE_LDS 192        /* matches per read staged in LDS            */
+#define MTB_SCORE_BKT 128        /* position buckets / taxCnt entries in LDS  */
+
+/* bytes of slab one workgroup needs for a segment of n matches, nb buckets */
+__host__ __device__ __forceinline__ uint64_t score_slab_bytes(uint64_t n, uint64_t nb) {
+    uint64_t b = n * (sizeof(mtb_match) + sizeof(mtb_path) + 4 + 4 + 4) + ((n + 7) & ~7ull);   /* m, path, order, acc, sps, flag */
+    b += nb * (4 + 4 + 4) + ((nb + 7) & ~7ull);                                                /* b_tax, o_tax, o_cnt, b_ham   */
+    return (b + 63) & ~63ull;
+}
+
+__global__ __launch_bounds__(64) void k_taxcnt_bound(const uint64_t *__restrict__ seg_start, const int32_t *__restrict__ qlen,
+                                                      const int32_t *__restrict__ qlen2, uint64_t n_reads, int32_t dna_shift,
+                                                      uint32_t *__restrict__ bound) {
+    uint64_t r = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    if (r >= n_reads) return;
+    uint64_t n = seg_start[r + 1] - seg_start[r];
+    uint64_t nb = (uint64_t)mtb_num_buckets(qlen[r] + qlen2[r], dna_shift);
+    bound[r] = (uint32_t)(n < nb ? n : nb);
+}
+
+__global__ __launch_bounds__(64) void k_score(const mtb_match *__restrict__ matches, const uint64_t *__restrict__ seg_start,
+                                               uint64_t n_reads, const int32_t *__restrict__ qlen, const int32_t *__restrict__ qlen2,
+                                               mtb_tax_view tx, mtb_score_params sp, const uint64_t *__restrict__ tc_off,
+                                               mtb_result *__restrict__ results, int32_t *__restrict__ tc_tax,
+                                               uint32_t *__restrict__ tc_cnt, uint64_t tc_cap, uint8_t *__restrict__ slabs,
+                                               uint64_t slab_bytes, uint32_t slab_max_n, uint32_t slab_max_nb) {
+    __shared__ mtb_match s_m[MTB_SCORE_LDS];
+    __shared__ mtb_path s_path[MTB_SCORE_LDS];
+    __shared__ int32_t s_order[MTB_SCORE_LDS];
+    __shared__ int32_t s_acc[MTB_SCORE_LDS];
+    __shared__ float s_sps[MTB_SCORE_LDS];
+    __shared__ uint8_t s_flag[MTB_SCORE_LDS];
+    __shared__ int32_t s_btax[MTB_SCORE_BKT];
+    __shared__ int32_t s_otax[MTB_SCORE_BKT];
+    __shared__ uint32_t s_ocnt[MTB_SCORE_BKT];
+    __shared__ uint8_t s_bham[MTB_SCORE_BKT];
+    const uint32_t lane = threadIdx.x;
+    for (uint64_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
+        const uint64_t s0 = seg_start[r];
+        const int32_t n = (int32_t)(seg_start[r + 1] - s0);
+        const int32_t ql1 = qlen[r], ql2 = qlen2[r];
+        const int32_t read_len = ql1 + ql2;
+        mtb_result R;
+        R.classification = 0; R.score = 0.0f; R.query_length = ql1; R.query_length2 = ql2;
+        R.is_classified = 0; R.reserved = 0; R.n_taxcnt = 0; R.taxcnt_off = 0;
+        if (n == 0) { if (lane == 0) results[r] = R; continue; }
+        const int32_t nb = mtb_num_buckets(read_len, sp.dna_shift);
+        /* storage: LDS for the common case, HBM slab for big segments */
+        mtb_match *m; mtb_path *path; int32_t *order, *acc; float *sps; uint8_t *flag;
+        int32_t *btax, *otax; uint32_t *ocnt; uint8_t *bham;
+        const bool big_n = n > MTB_SCORE_LDS, big_b = nb > MTB_SCORE_BKT;
+        uint8_t *slab = slabs + (uint64_t)blockIdx.x * slab_bytes;
+        if ((big_n && (uint32_t)n > slab_max_n) || (big_b && (uint32_t)nb > slab_max_nb)) {
+            /* cannot happen: slabs are sized from the measured maxima */
+            if (lane == 0) { R.reserved = 0xFF; results[r] = R; }
+            continue;
+        }
+        if (big_n) {
+            uint64_t N = slab_max_n;
+            m = (mtb_match *)slab; path = (mtb_path *)(m + N); order = (int32_t *)(path + N); acc = order + N;
+            sps = (float *)(acc + N); flag = (uint8_t *)(sps + N);
+        } else { m = s_m; path = s_path; order = s_order; acc = s_acc; sps = s_sps; flag = s_flag; }
+        if (big_b) {
+            uint64_t N = slab_max_n, B = slab_max_nb;
+            uint8_t *p = slab + N * (sizeof(mtb_match) + sizeof(mtb_path) + 12) + ((N + 7) & ~7ull);
+            btax = (int32_t *)p; otax = btax + B; ocnt = (uint32_t *)(otax + B); bham = (uint8_t *)(ocnt + B);
+        } else { btax = s_btax; otax = s_otax; ocnt = s_ocnt; bham = s_bham; }
+
+        {   /* stage the segment (24-byte records as 3 x u64, coalesced) */
+            const uint64_t *src = (const uint64_t *)(matches + s0);
+            uint64_t *dst = (uint64_t *)m;
+            for (int32_t i = lane; i < n * 3; i += 64) dst[i] = src[i];
+            for (int32_t i = lane; i < n; i += 64) { flag[i] = 0; sps[i] = -1.0f; }
+        }
+        __syncthreads();
+        /* phase 1: (species, frame) blocks */
+        for (int32_t i = lane; i < n; i += 64) {
+            int32_t spc = m[i].species_id; uint32_t fr = mtb_q_frame(m[i].qinfo);
+            bool head = (i == 0) || m[i - 1].species_id != spc || mtb_q_frame(m[i - 1].qinfo) != fr;
+            if (!head) continue;
+            int32_t e = i + 1;
+            while (e < n && m[e].species_id == spc && mtb_q_frame(m[e].qinfo) == fr) e++;
+            if (e - i > 1) {      /* Taxonomer.cpp:342 */
+                int32_t md = (spc >= 0 && spc <= tx.max_taxid && tx.under_euk[spc]) ? sp.min_cons_cnt_euk : sp.min_cons_cnt;
+                mtb_sf_block_paths(m, i, e, path, flag, &sp, md);
+            }
+        }
+        __syncthreads();
+        /* phase 2: species blocks */
+        for (int32_t i = lane; i < n; i += 64) {
+            int32_t spc = m[i].species_id;
+            bool head = (i == 0) || m[i - 1].species_id != spc;
+            if (!head) continue;
+            int32_t e = i + 1;
+            while (e < n && m[e].species_id == spc) e++;
+            int32_t np = 0;
+            float sc = mtb_species_combine(m, i, e, path, flag, order, acc, read_len, &np);
+            if (np > 0) sps[i] = sc < 1.0f ? sc : 1.0f;        /* Taxonomer.cpp:356 */
+        }
+        __syncthreads();
+        /* phase 3: decision */
+        if (lane == 0) {
+            uint64_t off = tc_off[r];
+            uint64_t room = tc_off[r + 1] - off;
+            mtb_read_decide(m, n, sps, &tx, &sp, read_len, btax, bham, nb, otax, ocnt, (int32_t)room, &R);
+            R.query_length = ql1; R.query_length2 = ql2; R.reserved = 0;
+            R.taxcnt_off = (uint32_t)off;
+            for (int32_t k = 0; k < (int32_t)R.n_taxcnt; k++)
+                if (off + k < tc_cap) { tc_tax[off + k] = otax[k]; tc_cnt[off + k] = ocnt[k]; }
+            results[r] = R;
+        }
+        __syncthreads();
+    }
+}
+
+#endif

@@ -1,0 +1,647 @@
+/* mtb_api.hip -- C ABI (include/mtb.h) over the HIP kernels.  gfx950 only.
+ * The library never falls back to a CPU path: every entry point that computes
+ * launches kernels on the context's stream and reports HIP errors.           */
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/mtb.h"
+#include "host_db.h"
+#include "kernels_extract.h"
+#include "kernels_index.h"
+#include "kernels_join.h"
+#include "kernels_scan.h"
+#include "kernels_score.h"
+#include "kernels_sort.h"
+#include "mtb_core.h"
+
+static thread_local std::string g_err;
+static mtb_status fail(mtb_status s, const std::string &m) { g_err = m; return s; }
+
+#define HIPCHK(x)                                                                                  \
+    do {                                                                                           \
+        hipError_t e_ = (x);                                                                       \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(MTB_ERR_DEVICE, std::string(#x) + ": " + hipGetErrorString(e_));           \
+    } while (0)
+#define STCHK(x)                                                                                   \
+    do { mtb_status s_ = (x); if (s_ != MTB_OK) return s_; } while (0)
+
+struct DevBuf { void *p = nullptr; size_t cap = 0; };
+
+struct mtb_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    mtb_tables *d_tabs = nullptr;
+    mtb_tables h_tabs;
+    std::map<std::string, DevBuf> bufs;
+    uint64_t *d_scal = nullptr;      /* [0] match counter, [1] overflow, [2] n_large, [3] max_seg, [4] max_len */
+    hipEvent_t ev[8];
+    mtb_batch_stats stats;
+};
+
+struct mtb_index {
+    mtb_ctx *ctx = nullptr;
+    uint64_t T = 0;
+    uint64_t *d_values = nullptr; uint32_t *d_info = nullptr; bool own = false;
+    mtbhost::Taxonomy tax;
+    int32_t *d_canon = nullptr, *d_parent = nullptr, *d_depth = nullptr, *d_spparent = nullptr, *d_tax2species = nullptr;
+    uint8_t *d_under = nullptr;
+    mtb_params params;
+    uint32_t info_mask = 0xFFFFFFFFu;
+};
+
+template <typename T>
+static mtb_status ensure(mtb_ctx *c, const char *name, size_t elems, T **out) {
+    DevBuf &b = c->bufs[name];
+    size_t bytes = elems * sizeof(T);
+    if (bytes == 0) bytes = 64;
+    if (b.cap < bytes) {
+        if (b.p) { hipError_t e = hipFree(b.p); (void)e; b.p = nullptr; b.cap = 0; }
+        size_t want = bytes + bytes / 16 + 256;
+        size_t fr = 0, tot = 0;
+        HIPCHK(hipMemGetInfo(&fr, &tot));
+        if (want > fr) { want = bytes; if (want > fr) return fail(MTB_ERR_OOM, std::string("not enough HBM for buffer ") + name); }
+        hipError_t e = hipMalloc(&b.p, want);
+        if (e != hipSuccess) { b.p = nullptr; return fail(MTB_ERR_OOM, std::string("hipMalloc failed for ") + name + ": " + hipGetErrorString(e)); }
+        b.cap = want;
+    }
+    *out = (T *)b.p;
+    return MTB_OK;
+}
+static void release(mtb_ctx *c, const char *name) {
+    auto it = c->bufs.find(name);
+    if (it != c->bufs.end()) { if (it->second.p) { hipError_t e = hipFree(it->second.p); (void)e; } c->bufs.erase(it); }
+}
+
+extern "C" {
+
+const char *mtb_version(void) { return "metabuli_amd 0.1 (gfx950)"; }
+const char *mtb_last_error(void) { return g_err.c_str(); }
+
+void mtb_default_params(mtb_params *p) {   /* classify.cpp:10-37 */
+    p->seq_mode = 2; p->syncmer = 0; p->smer_len = 5; p->kmer_format = 2; p->min_cons_cnt = 4; p->min_cons_cnt_euk = 9;
+    p->min_score = 0.0f; p->min_sp_score = 0.0f; p->tie_ratio = 0.95f; p->accession_level = 0; p->skip_redundancy = 0;
+}
+
+mtb_status mtb_ctx_create(int device, void *stream, mtb_ctx **out) {
+    if (!out) return fail(MTB_ERR_ARG, "out is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(MTB_ERR_DEVICE, "no HIP device available (this library has no CPU path)");
+    if (device < 0 || device >= n) return fail(MTB_ERR_ARG, "bad device ordinal");
+    HIPCHK(hipSetDevice(device));
+    mtb_ctx *c = new mtb_ctx();
+    c->device = device; c->stream = (hipStream_t)stream;
+    mtb_build_tables(&c->h_tabs);
+    HIPCHK(hipMalloc((void **)&c->d_tabs, sizeof(mtb_tables)));
+    HIPCHK(hipMemcpy(c->d_tabs, &c->h_tabs, sizeof(mtb_tables), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void **)&c->d_scal, 8 * sizeof(uint64_t)));
+    for (int i = 0; i < 8; i++) HIPCHK(hipEventCreate(&c->ev[i]));
+    memset(&c->stats, 0, sizeof(c->stats));
+    *out = c;
+    return MTB_OK;
+}
+void mtb_ctx_destroy(mtb_ctx *c) {
+    if (!c) return;
+    hipError_t e = hipSetDevice(c->device); (void)e;
+    e = hipStreamSynchronize(c->stream);
+    for (auto &kv : c->bufs) if (kv.second.p) e = hipFree(kv.second.p);
+    if (c->d_tabs) e = hipFree(c->d_tabs);
+    if (c->d_scal) e = hipFree(c->d_scal);
+    for (int i = 0; i < 8; i++) e = hipEventDestroy(c->ev[i]);
+    delete c;
+}
+mtb_status mtb_ctx_sync(mtb_ctx *c) { HIPCHK(hipStreamSynchronize(c->stream)); return MTB_OK; }
+
+} // extern "C"
+
+/* ------------------------------------------------------------------ */
+/* internal device-side stages                                         */
+/* ------------------------------------------------------------------ */
+static mtb_status d2h(mtb_ctx *c, void *dst, const void *src, size_t bytes) {
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return MTB_OK;
+}
+static mtb_status h2d(mtb_ctx *c, void *dst, const void *src, size_t bytes) {
+    if (bytes == 0) return MTB_OK;
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return MTB_OK;
+}
+
+/* extract: counts -> offsets -> emit.  Result in buffer "kmersA". */
+static mtb_status dev_extract(mtb_ctx *c, const mtb_params *p, const char *d_bases, const uint64_t *d_offs, const char *d_bases2,
+                              const uint64_t *d_offs2, uint64_t n_reads, mtb_kmer **out, uint64_t *count, int32_t *d_qlen,
+                              int32_t *d_qlen2, uint32_t *max_len) {
+    if (n_reads >= (1ull << 29)) return fail(MTB_ERR_ARG, "more than 2^29-1 reads per batch (sequenceID is 29 bits, Kmer.h:13)");
+    if (p->kmer_format != 2) return fail(MTB_ERR_UNSUPPORTED, "only kmer_format 2 is implemented");
+    if (p->syncmer && (p->smer_len < 1 || p->smer_len > 8)) return fail(MTB_ERR_ARG, "smer_len out of range");
+    *count = 0; *out = nullptr;
+    if (n_reads == 0) return MTB_OK;
+    uint32_t *d_cnt; uint64_t *d_koff; uint64_t *d_ws;
+    STCHK(ensure(c, "counts", n_reads, &d_cnt));
+    STCHK(ensure(c, "koff", n_reads + 1, &d_koff));
+    STCHK(ensure(c, "scanws", scan_ws_elems(n_reads + 1), &d_ws));
+    HIPCHK(hipMemsetAsync(c->d_scal + 4, 0, 8, c->stream));
+    ExtractArgs a{d_bases, d_offs, d_bases2, d_offs2, n_reads, p->seq_mode, p->syncmer, p->smer_len};
+    uint32_t grid = (uint32_t)std::min<uint64_t>(n_reads, 256ull * 64);
+    hipLaunchKernelGGL((k_extract<false>), dim3(grid), dim3(64), 0, c->stream, a, c->d_tabs, d_cnt, (const uint64_t *)nullptr,
+                       (mtb_kmer *)nullptr, d_qlen, d_qlen2, (uint32_t *)(c->d_scal + 4));
+    scan_launch<uint32_t, uint64_t, false>(c->stream, d_cnt, n_reads, true, d_koff, d_ws);
+    uint64_t total = 0;
+    STCHK(d2h(c, &total, d_koff + n_reads, 8));
+    if (max_len) { uint64_t ml = 0; STCHK(d2h(c, &ml, c->d_scal + 4, 8)); *max_len = (uint32_t)ml; }
+    if (total >= (1ull << 32)) return fail(MTB_ERR_ARG, "more than 2^32-1 query metamers in one batch; split the batch");
+    mtb_kmer *d_k;
+    STCHK(ensure(c, "kmersA", total, &d_k));
+    if (total) hipLaunchKernelGGL((k_extract<true>), dim3(grid), dim3(64), 0, c->stream, a, c->d_tabs, (uint32_t *)nullptr,
+                                  (const uint64_t *)d_koff, d_k, (int32_t *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr);
+    HIPCHK(hipGetLastError());
+    *out = d_k; *count = total;
+    return MTB_OK;
+}
+
+static mtb_status dev_sort(mtb_ctx *c, mtb_kmer *d_a, uint64_t n, int first_bit, mtb_kmer **sorted) {
+    *sorted = d_a;
+    if (n == 0) return MTB_OK;
+    mtb_kmer *d_b; uint32_t *d_hist; uint64_t *d_ws;
+    STCHK(ensure(c, "kmersB", n, &d_b));
+    STCHK(ensure(c, "hist", radix_hist_elems(n), &d_hist));
+    STCHK(ensure(c, "scanws", scan_ws_elems(radix_hist_elems(n)), &d_ws));
+    *sorted = radix_sort_kmers(c->stream, d_a, d_b, n, first_bit, d_hist, (uint32_t *)d_ws);
+    HIPCHK(hipGetLastError());
+    return MTB_OK;
+}
+
+static mtb_index_view index_view(const mtb_index *ix) {
+    mtb_index_view v;
+    v.values = ix->d_values; v.info = ix->d_info; v.n_targets = ix->T; v.tax2species = ix->d_tax2species;
+    v.max_taxid = ix->tax.max_id; v.info_mask = ix->info_mask; v.kmer_format = ix->params.kmer_format;
+    return v;
+}
+static mtb_tax_view tax_view(const mtb_index *ix) {
+    mtb_tax_view v;
+    v.canon = ix->d_canon; v.parent = ix->d_parent; v.depth = ix->d_depth; v.under_euk = ix->d_under; v.sp_parent = ix->d_spparent;
+    v.max_taxid = ix->tax.max_id;
+    return v;
+}
+
+/* join into d_out (cap entries); *count = matches found (may exceed cap -> MTB_ERR_CAPACITY) */
+static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint64_t n, mtb_match *d_out, uint64_t cap,
+                           uint32_t *d_read_cnt, uint64_t *count) {
+    *count = 0;
+    if (n == 0) return MTB_OK;
+    HIPCHK(hipMemsetAsync(c->d_scal, 0, 16, c->stream));
+    uint32_t grid = (uint32_t)((n + 255) / 256);
+    hipLaunchKernelGGL(k_join, dim3(grid), dim3(256), 0, c->stream, d_q, n, index_view(ix), (const mtb_tables *)c->d_tabs, d_out, cap,
+                       (unsigned long long *)c->d_scal, d_read_cnt, (uint32_t *)(c->d_scal + 1));
+    HIPCHK(hipGetLastError());
+    uint64_t sc[2];
+    STCHK(d2h(c, sc, c->d_scal, 16));
+    *count = sc[0];
+    if (sc[0] > cap) return fail(MTB_ERR_CAPACITY, "match buffer too small");
+    return MTB_OK;
+}
+
+/* per-read counters -> seg_start (n_reads+1) -> regroup into d_out */
+static mtb_status dev_regroup(mtb_ctx *c, const mtb_match *d_in, uint64_t m, uint64_t n_reads, uint32_t *d_read_cnt,
+                              uint64_t **seg_start, mtb_match *d_out) {
+    uint64_t *d_seg; uint64_t *d_ws; uint32_t *d_cur;
+    STCHK(ensure(c, "segstart", n_reads + 1, &d_seg));
+    STCHK(ensure(c, "scanws", scan_ws_elems(n_reads + 1), &d_ws));
+    STCHK(ensure(c, "cursor", n_reads, &d_cur));
+    scan_launch<uint32_t, uint64_t, false>(c->stream, d_read_cnt, n_reads, true, d_seg, d_ws);
+    HIPCHK(hipMemsetAsync(d_cur, 0, n_reads * 4, c->stream));
+    if (m) hipLaunchKernelGGL(k_regroup, dim3((uint32_t)((m + 255) / 256)), dim3(256), 0, c->stream, d_in, m, (const uint64_t *)d_seg, d_cur, d_out);
+    HIPCHK(hipGetLastError());
+    *seg_start = d_seg;
+    return MTB_OK;
+}
+
+static mtb_status dev_segsort(mtb_ctx *c, mtb_match *d_m, const uint64_t *d_seg, uint64_t n_reads, uint32_t *max_seg) {
+    uint32_t *d_large;
+    STCHK(ensure(c, "large", n_reads, &d_large));
+    HIPCHK(hipMemsetAsync(c->d_scal + 2, 0, 16, c->stream));
+    uint32_t grid = (uint32_t)std::min<uint64_t>(n_reads, 256ull * 40);
+    hipLaunchKernelGGL(k_segsort_small, dim3(grid), dim3(64), 0, c->stream, d_m, d_seg, n_reads, d_large, (uint32_t *)(c->d_scal + 2),
+                       (uint32_t *)(c->d_scal + 3));
+    hipLaunchKernelGGL(k_segsort_large, dim3(1024), dim3(256), 0, c->stream, d_m, d_seg, (const uint32_t *)d_large,
+                       (const uint32_t *)(c->d_scal + 2));
+    HIPCHK(hipGetLastError());
+    if (max_seg) { uint64_t sc[2]; STCHK(d2h(c, sc, c->d_scal + 2, 16)); *max_seg = (uint32_t)sc[1]; }
+    return MTB_OK;
+}
+
+/* d_results/d_tc_* are device outputs; *n_tc = sum of per-read bounds */
+static mtb_status dev_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, const mtb_match *d_m, const uint64_t *d_seg,
+                            uint64_t n_reads, const int32_t *d_qlen, const int32_t *d_qlen2, uint32_t max_seg, uint32_t max_len,
+                            mtb_result *d_res, int32_t *d_tc_tax, uint32_t *d_tc_cnt, uint64_t tc_cap, uint64_t *n_tc) {
+    if (p->accession_level == 2) return fail(MTB_ERR_UNSUPPORTED, "accession_level 2 (Taxonomer.cpp:256-267) is not implemented");
+    mtb_score_params sp; mtb_make_score_params(p, &sp);
+    uint32_t *d_bound; uint64_t *d_tcoff; uint64_t *d_ws;
+    STCHK(ensure(c, "bound", n_reads, &d_bound));
+    STCHK(ensure(c, "tcoff", n_reads + 1, &d_tcoff));
+    STCHK(ensure(c, "scanws", scan_ws_elems(n_reads + 1), &d_ws));
+    hipLaunchKernelGGL(k_taxcnt_bound, dim3((uint32_t)((n_reads + 63) / 64)), dim3(64), 0, c->stream, d_seg, d_qlen, d_qlen2, n_reads,
+                       sp.dna_shift, d_bound);
+    scan_launch<uint32_t, uint64_t, false>(c->stream, d_bound, n_reads, true, d_tcoff, d_ws);
+    uint64_t tot = 0;
+    STCHK(d2h(c, &tot, d_tcoff + n_reads, 8));
+    *n_tc = tot;
+    if (tot > tc_cap) return fail(MTB_ERR_CAPACITY, "taxcnt buffers too small");
+    uint32_t grid = (uint32_t)std::min<uint64_t>(n_reads, 256ull * 12);
+    uint32_t slab_n = max_seg > MTB_SCORE_LDS ? max_seg : 0;
+    uint32_t max_nb = (uint32_t)mtb_num_buckets((int32_t)max_len, sp.dna_shift);
+    uint32_t slab_nb = max_nb > MTB_SCORE_BKT ? max_nb : 0;
+    uint64_t slab_bytes = (slab_n || slab_nb) ? score_slab_bytes(slab_n, slab_nb) : 0;
+    uint8_t *d_slabs = nullptr;
+    if (slab_bytes) {
+        /* keep the slab pool below 8 GiB by shrinking the grid */
+        while ((uint64_t)grid * slab_bytes > (8ull << 30) && grid > 64) grid /= 2;
+        STCHK(ensure(c, "slabs", (size_t)grid * slab_bytes, &d_slabs));
+    }
+    hipLaunchKernelGGL(k_score, dim3(grid), dim3(64), 0, c->stream, d_m, d_seg, n_reads, d_qlen, d_qlen2, tax_view(ix), sp,
+                       (const uint64_t *)d_tcoff, d_res, d_tc_tax, d_tc_cnt, tc_cap, d_slabs, slab_bytes, slab_n, slab_nb);
+    HIPCHK(hipGetLastError());
+    return MTB_OK;
+}
+
+/* ------------------------------------------------------------------ */
+/* index                                                               */
+/* ------------------------------------------------------------------ */
+static mtb_status upload_taxonomy(mtb_index *ix) {
+    const mtbhost::Taxonomy &t = ix->tax;
+    size_t n = (size_t)t.max_id + 1;
+    HIPCHK(hipMalloc((void **)&ix->d_canon, n * 4)); HIPCHK(hipMalloc((void **)&ix->d_parent, n * 4));
+    HIPCHK(hipMalloc((void **)&ix->d_depth, n * 4)); HIPCHK(hipMalloc((void **)&ix->d_spparent, n * 4));
+    HIPCHK(hipMalloc((void **)&ix->d_tax2species, n * 4)); HIPCHK(hipMalloc((void **)&ix->d_under, n));
+    /* parent must be indexable for every canonical id; absent ids keep -1 (never dereferenced) */
+    HIPCHK(hipMemcpy(ix->d_canon, t.canon.data(), n * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ix->d_parent, t.parent.data(), n * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ix->d_depth, t.depth.data(), n * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ix->d_spparent, t.sp_parent.data(), n * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ix->d_tax2species, t.tax2species.data(), n * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ix->d_under, t.under_euk.data(), n, hipMemcpyHostToDevice));
+    return MTB_OK;
+}
+
+extern "C" {
+
+mtb_status mtb_index_open(mtb_ctx *c, const char *dbdir, const char *taxonomy_dir, mtb_params *params, mtb_index **out) {
+    if (!c || !dbdir || !params || !out) return fail(MTB_ERR_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(c->device));
+    std::string d(dbdir);
+    mtbhost::load_db_parameters(d, params);
+    if (params->kmer_format != 2) return fail(MTB_ERR_UNSUPPORTED, "database uses a k-mer format other than 2 (OldMetamerScanner not implemented)");
+    std::string taxdir = taxonomy_dir && *taxonomy_dir ? std::string(taxonomy_dir) : d + "/taxonomy";
+    if (!mtbhost::file_exists(taxdir + "/nodes.dmp")) {
+        if (mtbhost::file_exists(d + "/taxonomyDB"))
+            return fail(MTB_ERR_UNSUPPORTED, "binary taxonomyDB is not supported yet; pass a taxonomy directory with names/nodes/merged.dmp");
+        return fail(MTB_ERR_IO, "taxonomy dump files not found in " + taxdir);
+    }
+    mtb_index *ix = new mtb_index();
+    ix->ctx = c; ix->params = *params; ix->own = true;
+    std::string err;
+    if (!mtbhost::load_taxonomy(taxdir, &ix->tax, &err)) { delete ix; return fail(MTB_ERR_IO, err); }
+    std::vector<int32_t> ids;
+    if (!mtbhost::read_taxid_list(d + "/taxID_list", &ids)) { delete ix; return fail(MTB_ERR_IO, "cannot open " + d + "/taxID_list"); }
+    mtbhost::build_tax2species(&ix->tax, ids.data(), ids.size());
+    ix->info_mask = ~((uint32_t)(params->skip_redundancy == 0) << 31);   /* KmerMatcher.cpp:204-205 */
+    std::vector<uint16_t> diff; std::vector<uint32_t> info;
+    if (!mtbhost::read_whole(d + "/diffIdx", &diff) || !mtbhost::read_whole(d + "/info", &info)) { delete ix; return fail(MTB_ERR_IO, "cannot read diffIdx/info in " + d); }
+    uint64_t n16 = diff.size(), T = info.size();
+    mtb_status st = upload_taxonomy(ix);
+    if (st != MTB_OK) { mtb_index_close(ix); return st; }
+    if (T == 0) { ix->T = 0; *out = ix; return MTB_OK; }
+    /* decode on the GPU */
+    uint16_t *d_diff; uint32_t *d_tc; uint64_t *d_toff; uint64_t *d_ws;
+    uint64_t tiles = (n16 + 2047) / 2048;
+    if ((st = ensure(c, "diffraw", n16, &d_diff)) != MTB_OK || (st = ensure(c, "difftc", tiles, &d_tc)) != MTB_OK ||
+        (st = ensure(c, "difftoff", tiles + 1, &d_toff)) != MTB_OK ||
+        (st = ensure(c, "scanws", scan_ws_elems(std::max<uint64_t>(tiles + 1, T)), &d_ws)) != MTB_OK) { mtb_index_close(ix); return st; }
+    HIPCHK(hipMalloc((void **)&ix->d_values, T * 8)); HIPCHK(hipMalloc((void **)&ix->d_info, T * 4));
+    if ((st = h2d(c, d_diff, diff.data(), n16 * 2)) != MTB_OK || (st = h2d(c, ix->d_info, info.data(), T * 4)) != MTB_OK) { mtb_index_close(ix); return st; }
+    hipLaunchKernelGGL(k_diff_tile_count, dim3((uint32_t)tiles), dim3(256), 0, c->stream, (const uint16_t *)d_diff, n16, d_tc);
+    scan_launch<uint32_t, uint64_t, false>(c->stream, d_tc, tiles, true, d_toff, d_ws);
+    uint64_t found = 0;
+    if ((st = d2h(c, &found, d_toff + tiles, 8)) != MTB_OK) { mtb_index_close(ix); return st; }
+    if (found != T) {   /* validateDatabase.cpp:17-142: #terminators must equal #info entries */
+        mtb_index_close(ix);
+        return fail(MTB_ERR_IO, "diffIdx holds " + std::to_string(found) + " metamers but info holds " + std::to_string(T));
+    }
+    hipLaunchKernelGGL(k_diff_assemble, dim3((uint32_t)tiles), dim3(256), 0, c->stream, (const uint16_t *)d_diff, n16, (const uint64_t *)d_toff, ix->d_values);
+    scan_launch<uint64_t, uint64_t, true>(c->stream, ix->d_values, T, false, ix->d_values, d_ws);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    release(c, "diffraw"); release(c, "difftc"); release(c, "difftoff");
+    ix->T = T;
+    *out = ix;
+    return MTB_OK;
+}
+
+mtb_status mtb_index_from_device(mtb_ctx *c, const uint64_t *d_values, const uint32_t *d_info, uint64_t n_targets, const char *taxonomy_dir,
+                                 const int32_t *taxid_list, size_t n_taxids, const mtb_params *params, mtb_index **out) {
+    if (!c || !taxonomy_dir || !params || !out) return fail(MTB_ERR_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(c->device));
+    mtb_index *ix = new mtb_index();
+    ix->ctx = c; ix->params = *params; ix->own = false;
+    std::string err;
+    if (!mtbhost::load_taxonomy(taxonomy_dir, &ix->tax, &err)) { delete ix; return fail(MTB_ERR_IO, err); }
+    mtbhost::build_tax2species(&ix->tax, taxid_list, n_taxids);
+    ix->info_mask = ~((uint32_t)(params->skip_redundancy == 0) << 31);
+    ix->d_values = (uint64_t *)d_values; ix->d_info = (uint32_t *)d_info; ix->T = n_targets;
+    mtb_status st = upload_taxonomy(ix);
+    if (st != MTB_OK) { mtb_index_close(ix); return st; }
+    *out = ix;
+    return MTB_OK;
+}
+
+void mtb_index_close(mtb_index *ix) {
+    if (!ix) return;
+    hipError_t e;
+    if (ix->own) { if (ix->d_values) e = hipFree(ix->d_values); if (ix->d_info) e = hipFree(ix->d_info); }
+    if (ix->d_canon) e = hipFree(ix->d_canon);
+    if (ix->d_parent) e = hipFree(ix->d_parent);
+    if (ix->d_depth) e = hipFree(ix->d_depth);
+    if (ix->d_spparent) e = hipFree(ix->d_spparent);
+    if (ix->d_tax2species) e = hipFree(ix->d_tax2species);
+    if (ix->d_under) e = hipFree(ix->d_under);
+    (void)e;
+    delete ix;
+}
+uint64_t mtb_index_num_targets(const mtb_index *ix) { return ix ? ix->T : 0; }
+
+mtb_status mtb_index_download(mtb_index *ix, uint64_t *values, uint32_t *info, uint64_t cap) {
+    if (!ix) return fail(MTB_ERR_ARG, "NULL index");
+    if (cap < ix->T) return fail(MTB_ERR_CAPACITY, "output too small");
+    if (ix->T == 0) return MTB_OK;
+    if (values) HIPCHK(hipMemcpy(values, ix->d_values, ix->T * 8, hipMemcpyDeviceToHost));
+    if (info) HIPCHK(hipMemcpy(info, ix->d_info, ix->T * 4, hipMemcpyDeviceToHost));
+    return MTB_OK;
+}
+int32_t mtb_tax_lca(const mtb_index *ix, int32_t a, int32_t b) { return ix->tax.lca(a, b); }
+int32_t mtb_tax_species(const mtb_index *ix, int32_t t) { return (t >= 0 && t <= ix->tax.max_id) ? ix->tax.tax2species[(size_t)t] : 0; }
+int32_t mtb_tax_parent(const mtb_index *ix, int32_t t) { int32_t c = ix->tax.cn(t); return c < 0 ? -1 : ix->tax.parent[(size_t)c]; }
+int32_t mtb_tax_max_id(const mtb_index *ix) { return ix->tax.max_id; }
+
+/* ------------------------------------------------------------------ */
+/* stage-level entry points (host buffers)                             */
+/* ------------------------------------------------------------------ */
+static mtb_status upload_reads(mtb_ctx *c, const mtb_params *p, const char *bases, const uint64_t *offs, const char *bases2,
+                               const uint64_t *offs2, uint64_t n_reads, char **d_b, uint64_t **d_o, char **d_b2, uint64_t **d_o2,
+                               uint64_t *n_bases) {
+    *d_b = nullptr; *d_o = nullptr; *d_b2 = nullptr; *d_o2 = nullptr; *n_bases = 0;
+    if (n_reads == 0) return MTB_OK;
+    if (!bases || !offs) return fail(MTB_ERR_ARG, "bases/offs NULL");
+    uint64_t nb = offs[n_reads];
+    STCHK(ensure(c, "bases", nb + 8, d_b)); STCHK(ensure(c, "offs", n_reads + 1, d_o));
+    STCHK(h2d(c, *d_b, bases, nb)); STCHK(h2d(c, *d_o, offs, (n_reads + 1) * 8));
+    *n_bases = nb;
+    if (p->seq_mode == 2) {
+        if (!bases2 || !offs2) return fail(MTB_ERR_ARG, "seq_mode 2 needs bases2/offs2");
+        uint64_t nb2 = offs2[n_reads];
+        STCHK(ensure(c, "bases2", nb2 + 8, d_b2)); STCHK(ensure(c, "offs2", n_reads + 1, d_o2));
+        STCHK(h2d(c, *d_b2, bases2, nb2)); STCHK(h2d(c, *d_o2, offs2, (n_reads + 1) * 8));
+        *n_bases += nb2;
+    }
+    return MTB_OK;
+}
+
+mtb_status mtb_extract(mtb_ctx *c, const mtb_params *p, const char *bases, const uint64_t *offs, const char *bases2, const uint64_t *offs2,
+                       uint64_t n_reads, mtb_kmer *out, uint64_t cap, uint64_t *count, int32_t *qlen, int32_t *qlen2) {
+    if (!c || !p || !count) return fail(MTB_ERR_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(c->device));
+    *count = 0;
+    if (n_reads == 0) return MTB_OK;
+    char *d_b, *d_b2; uint64_t *d_o, *d_o2; uint64_t nb;
+    STCHK(upload_reads(c, p, bases, offs, bases2, offs2, n_reads, &d_b, &d_o, &d_b2, &d_o2, &nb));
+    int32_t *d_ql, *d_ql2;
+    STCHK(ensure(c, "qlen", n_reads, &d_ql)); STCHK(ensure(c, "qlen2", n_reads, &d_ql2));
+    mtb_kmer *d_k; uint64_t n;
+    STCHK(dev_extract(c, p, d_b, d_o, d_b2, d_o2, n_reads, &d_k, &n, d_ql, d_ql2, nullptr));
+    *count = n;
+    if (qlen) STCHK(d2h(c, qlen, d_ql, n_reads * 4));
+    if (qlen2) STCHK(d2h(c, qlen2, d_ql2, n_reads * 4));
+    if (n > cap) return fail(MTB_ERR_CAPACITY, "k-mer buffer too small");
+    if (n) STCHK(d2h(c, out, d_k, n * sizeof(mtb_kmer)));
+    return MTB_OK;
+}
+
+mtb_status mtb_sort_kmers(mtb_ctx *c, mtb_kmer *kmers, uint64_t n) {
+    if (!c) return fail(MTB_ERR_ARG, "NULL ctx");
+    HIPCHK(hipSetDevice(c->device));
+    if (n == 0) return MTB_OK;
+    if (n >= (1ull << 32)) return fail(MTB_ERR_ARG, "n must be < 2^32");
+    mtb_kmer *d_a, *d_s;
+    STCHK(ensure(c, "kmersA", n, &d_a));
+    STCHK(h2d(c, d_a, kmers, n * sizeof(mtb_kmer)));
+    STCHK(dev_sort(c, d_a, n, 0, &d_s));
+    STCHK(d2h(c, kmers, d_s, n * sizeof(mtb_kmer)));
+    return MTB_OK;
+}
+
+mtb_status mtb_match_kmers(mtb_ctx *c, mtb_index *ix, const mtb_kmer *sorted, uint64_t n, mtb_match *out, uint64_t cap, uint64_t *count) {
+    if (!c || !ix || !count) return fail(MTB_ERR_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(c->device));
+    *count = 0;
+    if (n == 0) return MTB_OK;
+    mtb_kmer *d_q; mtb_match *d_m;
+    STCHK(ensure(c, "kmersA", n, &d_q));
+    STCHK(h2d(c, d_q, sorted, n * sizeof(mtb_kmer)));
+    STCHK(ensure(c, "jtemp", cap, &d_m));
+    mtb_status st = dev_join(c, ix, d_q, n, d_m, cap, nullptr, count);
+    if (st != MTB_OK) return st;
+    if (*count) STCHK(d2h(c, out, d_m, *count * sizeof(mtb_match)));
+    return MTB_OK;
+}
+
+mtb_status mtb_sort_matches(mtb_ctx *c, mtb_match *matches, uint64_t n, uint64_t n_reads) {
+    if (!c) return fail(MTB_ERR_ARG, "NULL ctx");
+    HIPCHK(hipSetDevice(c->device));
+    if (n == 0 || n_reads == 0) return MTB_OK;
+    mtb_match *d_in, *d_out; uint32_t *d_rc; uint64_t *d_seg;
+    STCHK(ensure(c, "jtemp", n, &d_in)); STCHK(ensure(c, "matches", n, &d_out)); STCHK(ensure(c, "readcnt", n_reads, &d_rc));
+    STCHK(h2d(c, d_in, matches, n * sizeof(mtb_match)));
+    HIPCHK(hipMemsetAsync(d_rc, 0, n_reads * 4, c->stream));
+    hipLaunchKernelGGL(k_count_reads, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, (const mtb_match *)d_in, n, d_rc);
+    STCHK(dev_regroup(c, d_in, n, n_reads, d_rc, &d_seg, d_out));
+    STCHK(dev_segsort(c, d_out, d_seg, n_reads, nullptr));
+    STCHK(d2h(c, matches, d_out, n * sizeof(mtb_match)));
+    return MTB_OK;
+}
+
+mtb_status mtb_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, const mtb_match *sorted, uint64_t n_matches, uint64_t n_reads,
+                     const int32_t *qlen, const int32_t *qlen2, mtb_result *results, int32_t *taxcnt_tax, uint32_t *taxcnt_cnt,
+                     uint64_t taxcnt_cap, uint64_t *n_taxcnt) {
+    if (!c || !ix || !p || !qlen || !results || !n_taxcnt) return fail(MTB_ERR_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(c->device));
+    *n_taxcnt = 0;
+    if (n_reads == 0) return MTB_OK;
+    mtb_match *d_m; uint32_t *d_rc; uint64_t *d_seg; uint64_t *d_ws; int32_t *d_ql, *d_ql2;
+    STCHK(ensure(c, "matches", n_matches, &d_m)); STCHK(ensure(c, "readcnt", n_reads, &d_rc));
+    STCHK(ensure(c, "segstart", n_reads + 1, &d_seg)); STCHK(ensure(c, "scanws", scan_ws_elems(n_reads + 1), &d_ws));
+    STCHK(ensure(c, "qlen", n_reads, &d_ql)); STCHK(ensure(c, "qlen2", n_reads, &d_ql2));
+    STCHK(h2d(c, d_m, sorted, n_matches * sizeof(mtb_match)));
+    STCHK(h2d(c, d_ql, qlen, n_reads * 4));
+    if (qlen2) STCHK(h2d(c, d_ql2, qlen2, n_reads * 4)); else HIPCHK(hipMemsetAsync(d_ql2, 0, n_reads * 4, c->stream));
+    HIPCHK(hipMemsetAsync(d_rc, 0, n_reads * 4, c->stream));
+    if (n_matches) hipLaunchKernelGGL(k_count_reads, dim3((uint32_t)((n_matches + 255) / 256)), dim3(256), 0, c->stream, (const mtb_match *)d_m, n_matches, d_rc);
+    scan_launch<uint32_t, uint64_t, false>(c->stream, d_rc, n_reads, true, d_seg, d_ws);
+    /* maxima for slab sizing */
+    std::vector<uint32_t> rc(n_reads);
+    STCHK(d2h(c, rc.data(), d_rc, n_reads * 4));
+    uint32_t max_seg = 0, max_len = 0;
+    for (uint64_t i = 0; i < n_reads; i++) { max_seg = std::max(max_seg, rc[i]); max_len = std::max<uint32_t>(max_len, (uint32_t)(qlen[i] + (qlen2 ? qlen2[i] : 0))); }
+    mtb_result *d_res; int32_t *d_tt; uint32_t *d_tc;
+    STCHK(ensure(c, "results", n_reads, &d_res)); STCHK(ensure(c, "tctax", taxcnt_cap, &d_tt)); STCHK(ensure(c, "tccnt", taxcnt_cap, &d_tc));
+    mtb_status st = dev_score(c, ix, p, d_m, d_seg, n_reads, d_ql, d_ql2, max_seg, max_len, d_res, d_tt, d_tc, taxcnt_cap, n_taxcnt);
+    if (st != MTB_OK) return st;
+    STCHK(d2h(c, results, d_res, n_reads * sizeof(mtb_result)));
+    if (*n_taxcnt) { STCHK(d2h(c, taxcnt_tax, d_tt, *n_taxcnt * 4)); STCHK(d2h(c, taxcnt_cnt, d_tc, *n_taxcnt * 4)); }
+    return MTB_OK;
+}
+
+/* ------------------------------------------------------------------ */
+/* fused batch                                                         */
+/* ------------------------------------------------------------------ */
+mtb_status mtb_classify_batch_device(mtb_ctx *c, mtb_index *ix, const mtb_params *p, const char *d_bases, const uint64_t *d_offs,
+                                     const char *d_bases2, const uint64_t *d_offs2, uint64_t n_reads, uint64_t n_bases_total,
+                                     mtb_result *d_results, int32_t *d_taxcnt_tax, uint32_t *d_taxcnt_cnt, uint64_t taxcnt_cap,
+                                     uint64_t *n_taxcnt) {
+    if (!c || !ix || !p || !n_taxcnt) return fail(MTB_ERR_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(c->device));
+    *n_taxcnt = 0;
+    memset(&c->stats, 0, sizeof(c->stats));
+    if (n_reads == 0) return MTB_OK;
+    hipStream_t st = c->stream;
+    int32_t *d_ql, *d_ql2;
+    STCHK(ensure(c, "qlen", n_reads, &d_ql)); STCHK(ensure(c, "qlen2", n_reads, &d_ql2));
+    HIPCHK(hipEventRecord(c->ev[0], st));
+    mtb_kmer *d_k; uint64_t nk; uint32_t max_len = 0;
+    STCHK(dev_extract(c, p, d_bases, d_offs, d_bases2, d_offs2, n_reads, &d_k, &nk, d_ql, d_ql2, &max_len));
+    HIPCHK(hipEventRecord(c->ev[1], st));
+    /* the join only needs queries grouped by amino-acid part: sort bits [24,64) */
+    mtb_kmer *d_s;
+    STCHK(dev_sort(c, d_k, nk, 24, &d_s));
+    HIPCHK(hipEventRecord(c->ev[2], st));
+    uint32_t *d_rc;
+    STCHK(ensure(c, "readcnt", n_reads, &d_rc));
+    HIPCHK(hipMemsetAsync(d_rc, 0, n_reads * 4, st));
+    mtb_match *d_tmp; uint64_t nm = 0;
+    DevBuf &jb = c->bufs["jtemp"];
+    uint64_t cap = std::max<uint64_t>(jb.cap / sizeof(mtb_match), nk + nk / 2 + 1024);
+    for (int attempt = 0; attempt < 3; attempt++) {
+        STCHK(ensure(c, "jtemp", cap, &d_tmp));
+        mtb_status s = dev_join(c, ix, d_s, nk, d_tmp, cap, d_rc, &nm);
+        if (s == MTB_OK) break;
+        if (s != MTB_ERR_CAPACITY || attempt == 2) return s;
+        cap = nm + nm / 16 + 1024;                     /* the reference's retry (Classifier.cpp:127-131) with the exact size */
+        HIPCHK(hipMemsetAsync(d_rc, 0, n_reads * 4, st));
+    }
+    HIPCHK(hipEventRecord(c->ev[3], st));
+    mtb_match *d_m; uint64_t *d_seg;
+    STCHK(ensure(c, "matches", nm, &d_m));
+    STCHK(dev_regroup(c, d_tmp, nm, n_reads, d_rc, &d_seg, d_m));
+    HIPCHK(hipEventRecord(c->ev[4], st));
+    uint32_t max_seg = 0;
+    STCHK(dev_segsort(c, d_m, d_seg, n_reads, &max_seg));
+    HIPCHK(hipEventRecord(c->ev[5], st));
+    STCHK(dev_score(c, ix, p, d_m, d_seg, n_reads, d_ql, d_ql2, max_seg, max_len, d_results, d_taxcnt_tax, d_taxcnt_cnt, taxcnt_cap, n_taxcnt));
+    HIPCHK(hipEventRecord(c->ev[6], st));
+    HIPCHK(hipEventSynchronize(c->ev[6]));
+    mtb_batch_stats &S = c->stats;
+    HIPCHK(hipEventElapsedTime(&S.ms_extract, c->ev[0], c->ev[1]));
+    HIPCHK(hipEventElapsedTime(&S.ms_sort, c->ev[1], c->ev[2]));
+    HIPCHK(hipEventElapsedTime(&S.ms_join, c->ev[2], c->ev[3]));
+    HIPCHK(hipEventElapsedTime(&S.ms_regroup, c->ev[3], c->ev[4]));
+    HIPCHK(hipEventElapsedTime(&S.ms_segsort, c->ev[4], c->ev[5]));
+    HIPCHK(hipEventElapsedTime(&S.ms_score, c->ev[5], c->ev[6]));
+    HIPCHK(hipEventElapsedTime(&S.ms_total, c->ev[0], c->ev[6]));
+    S.n_reads = n_reads; S.n_bases = n_bases_total; S.n_kmers = nk; S.n_matches = nm; S.n_targets = ix->T;
+    return MTB_OK;
+}
+
+mtb_status mtb_classify_batch(mtb_ctx *c, mtb_index *ix, const mtb_params *p, const char *bases, const uint64_t *offs, const char *bases2,
+                              const uint64_t *offs2, uint64_t n_reads, mtb_result *results, int32_t *taxcnt_tax, uint32_t *taxcnt_cnt,
+                              uint64_t taxcnt_cap, uint64_t *n_taxcnt) {
+    if (!c || !ix || !p || !n_taxcnt) return fail(MTB_ERR_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(c->device));
+    *n_taxcnt = 0;
+    if (n_reads == 0) return MTB_OK;
+    char *d_b, *d_b2; uint64_t *d_o, *d_o2; uint64_t nb;
+    STCHK(upload_reads(c, p, bases, offs, bases2, offs2, n_reads, &d_b, &d_o, &d_b2, &d_o2, &nb));
+    mtb_result *d_res; int32_t *d_tt; uint32_t *d_tc;
+    STCHK(ensure(c, "results", n_reads, &d_res)); STCHK(ensure(c, "tctax", taxcnt_cap, &d_tt)); STCHK(ensure(c, "tccnt", taxcnt_cap, &d_tc));
+    mtb_status st = mtb_classify_batch_device(c, ix, p, d_b, d_o, d_b2, d_o2, n_reads, nb, d_res, d_tt, d_tc, taxcnt_cap, n_taxcnt);
+    if (st != MTB_OK) return st;
+    STCHK(d2h(c, results, d_res, n_reads * sizeof(mtb_result)));
+    if (*n_taxcnt) { STCHK(d2h(c, taxcnt_tax, d_tt, *n_taxcnt * 4)); STCHK(d2h(c, taxcnt_cnt, d_tc, *n_taxcnt * 4)); }
+    return MTB_OK;
+}
+
+mtb_status mtb_last_batch_stats(mtb_ctx *c, mtb_batch_stats *out) {
+    if (!c || !out) return fail(MTB_ERR_ARG, "NULL argument");
+    *out = c->stats;
+    return MTB_OK;
+}
+
+/* ------------------------------------------------------------------ */
+/* synthetic index                                                     */
+/* ------------------------------------------------------------------ */
+mtb_status mtb_synth_index(mtb_ctx *c, uint64_t seed, uint64_t n_filler, int32_t filler_tax_lo, int32_t filler_tax_hi,
+                           const uint64_t *real_values, const int32_t *real_taxids, uint64_t n_real, uint64_t *d_values,
+                           uint32_t *d_info, uint64_t *n_out) {
+    if (!c || !d_values || !d_info || !n_out) return fail(MTB_ERR_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(c->device));
+    if (n_filler > MTB_AA_SPACE) return fail(MTB_ERR_ARG, "n_filler exceeds the amino-acid 8-mer space");
+    if (n_filler && filler_tax_hi < filler_tax_lo) return fail(MTB_ERR_ARG, "empty filler taxon range");
+    FillerParams P;
+    memset(&P, 0, sizeof(P));
+    P.seed = seed; P.n_filler = n_filler;
+    uint64_t pairs = (n_filler + 1) / 2;
+    P.stride = pairs ? MTB_AA_SPACE / pairs : 2;
+    if (P.stride < 2) P.stride = 2;
+    P.tax_lo = filler_tax_lo; P.tax_span = (uint32_t)(filler_tax_hi - filler_tax_lo + 1);
+    for (int i = 0; i < 64; i++) {           /* valid codon ids per amino acid, ascending */
+        uint32_t aa = c->h_tabs.codon[i] & 31u, cid = c->h_tabs.codon[i] >> 5;
+        bool have = false;
+        for (int k = 0; k < P.ncid[aa]; k++) have |= (P.cids[aa][k] == cid);
+        if (!have) P.cids[aa][P.ncid[aa]++] = (uint8_t)cid;
+    }
+    for (int aa = 0; aa < 21; aa++) std::sort(P.cids[aa], P.cids[aa] + P.ncid[aa]);
+    uint64_t *d_rv = nullptr, *d_pos = nullptr; int32_t *d_rt = nullptr;
+    if (n_real) {
+        for (uint64_t i = 1; i < n_real; i++) if (real_values[i] < real_values[i - 1]) return fail(MTB_ERR_ARG, "real_values must be sorted");
+        STCHK(ensure(c, "synth_rv", n_real, &d_rv)); STCHK(ensure(c, "synth_rt", n_real, &d_rt)); STCHK(ensure(c, "synth_pos", n_real, &d_pos));
+        STCHK(h2d(c, d_rv, real_values, n_real * 8)); STCHK(h2d(c, d_rt, real_taxids, n_real * 4));
+        hipLaunchKernelGGL(k_synth_real_pos, dim3((uint32_t)((n_real + 255) / 256)), dim3(256), 0, c->stream, P, (const uint64_t *)d_rv, n_real, d_pos);
+    }
+    if (n_filler) hipLaunchKernelGGL(k_synth_fill, dim3((uint32_t)((n_filler + 255) / 256)), dim3(256), 0, c->stream, P, (const uint64_t *)d_rv, n_real, d_values, d_info);
+    if (n_real) hipLaunchKernelGGL(k_synth_place_real, dim3((uint32_t)((n_real + 255) / 256)), dim3(256), 0, c->stream, (const uint64_t *)d_rv,
+                                   (const int32_t *)d_rt, (const uint64_t *)d_pos, n_real, d_values, d_info);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    release(c, "synth_rv"); release(c, "synth_rt"); release(c, "synth_pos");
+    *n_out = n_filler + n_real;
+    return MTB_OK;
+}
+
+mtb_status mtb_extract_targets(mtb_ctx *c, const mtb_params *p, const char *genome, uint64_t len, uint64_t *values, uint64_t cap, uint64_t *count) {
+    /* convenience wrapper: one sequence, long-read geometry, values only */
+    if (!c || !p || !count) return fail(MTB_ERR_ARG, "NULL argument");
+    mtb_params q = *p; q.seq_mode = 3;
+    uint64_t offs[2] = {0, len};
+    std::vector<mtb_kmer> tmp(cap);
+    uint64_t n = 0;
+    mtb_status st = mtb_extract(c, &q, genome, offs, nullptr, nullptr, 1, tmp.data(), cap, &n, nullptr, nullptr);
+    *count = n;
+    if (st != MTB_OK) return st;
+    for (uint64_t i = 0; i < n; i++) values[i] = tmp[i].value;
+    return MTB_OK;
+}
+
+} // extern "C"

@@ -286,8 +286,9 @@ MTB_HD bool mtb_match_less(const mtb_match &a, const mtb_match &b) {
 /* Scoring                                                             */
 /* ------------------------------------------------------------------ */
 typedef struct {
-    const int32_t *parent;      /* by taxid; parent[root] = root; -1 absent (aliases resolved) */
-    const int32_t *depth;       /* by taxid                                                    */
+    const int32_t *canon;       /* by taxid: itself, the merged.dmp target, or -1 if absent    */
+    const int32_t *parent;      /* by canonical taxid; parent[root] = root                     */
+    const int32_t *depth;       /* by canonical taxid                                          */
     const uint8_t *under_euk;   /* IsAncestor(eukaryota, taxid)  (Taxonomer.cpp:497-500)       */
     const int32_t *sp_parent;   /* parent(getTaxIdAtRank(taxid,"species")) (Taxonomer.cpp:178-185) */
     int32_t max_taxid;
@@ -307,11 +308,14 @@ MTB_HD void mtb_make_score_params(const mtb_params *p, mtb_score_params *s) {
     s->min_score = p->min_score; s->min_sp_score = p->min_sp_score; s->tie_ratio = p->tie_ratio;
 }
 
-MTB_HD bool mtb_tax_exists(const mtb_tax_view *t, int32_t x) { return x >= 0 && x <= t->max_taxid && t->parent[x] >= 0; }
+MTB_HD int32_t mtb_tax_canon(const mtb_tax_view *t, int32_t x) { return (x >= 0 && x <= t->max_taxid) ? t->canon[x] : -1; }
+MTB_HD bool mtb_tax_exists(const mtb_tax_view *t, int32_t x) { return mtb_tax_canon(t, x) >= 0; }
 /* NcbiTaxonomy::LCA(a,b): a missing node yields the other one */
 MTB_HD int32_t mtb_lca(const mtb_tax_view *t, int32_t a, int32_t b) {
-    if (!mtb_tax_exists(t, a)) return b;
-    if (!mtb_tax_exists(t, b)) return a;
+    int32_t ca = mtb_tax_canon(t, a), cb = mtb_tax_canon(t, b);
+    if (ca < 0) return b;
+    if (cb < 0) return a;
+    a = ca; b = cb;
     int32_t da = t->depth[a], db = t->depth[b];
     while (da > db) { a = t->parent[a]; da--; }
     while (db > da) { b = t->parent[b]; db--; }
@@ -495,14 +499,15 @@ MTB_HD int32_t mtb_num_buckets(int32_t read_len, int32_t dna_shift) { return (re
 MTB_HD int32_t mtb_lower_rank(const mtb_tax_view *tx, const int32_t *tc_tax, const uint32_t *tc_cnt, int32_t n,
                               int32_t species, int32_t read_len, int32_t denominator) {
     uint32_t thr = (uint32_t)((read_len - 1) / denominator);
-    int32_t root = species;
+    int32_t root = mtb_tax_canon(tx, species);
+    if (root < 0) return species;
     for (int guard = 0; guard < 64; guard++) {
         /* children of root on the paths taxon -> species, with clade counts */
         uint32_t max_cnt = thr; int32_t best = -1; int32_t n_best = 0; bool any_child = false;
         for (int32_t i = 0; i < n; i++) {
             /* child of root above tc_tax[i], if tc_tax[i] is a strict descendant of root */
-            int32_t t = tc_tax[i];
-            if (!mtb_tax_exists(tx, t) || tx->depth[t] <= tx->depth[root]) continue;
+            int32_t t = mtb_tax_canon(tx, tc_tax[i]);
+            if (t < 0 || tx->depth[t] <= tx->depth[root]) continue;
             int32_t c = t;
             while (tx->depth[c] > tx->depth[root] + 1) c = tx->parent[c];
             if (tx->parent[c] != root) continue;
@@ -510,8 +515,8 @@ MTB_HD int32_t mtb_lower_rank(const mtb_tax_view *tx, const int32_t *tc_tax, con
             /* count each distinct child once: only at its first contributing entry */
             bool first = true;
             for (int32_t j = 0; j < i && first; j++) {
-                int32_t u = tc_tax[j];
-                if (!mtb_tax_exists(tx, u) || tx->depth[u] <= tx->depth[root]) continue;
+                int32_t u = mtb_tax_canon(tx, tc_tax[j]);
+                if (u < 0 || tx->depth[u] <= tx->depth[root]) continue;
                 int32_t d = u;
                 while (tx->depth[d] > tx->depth[root] + 1) d = tx->parent[d];
                 if (d == c) first = false;
@@ -519,8 +524,8 @@ MTB_HD int32_t mtb_lower_rank(const mtb_tax_view *tx, const int32_t *tc_tax, con
             if (!first) continue;
             uint32_t clade = 0;
             for (int32_t j = i; j < n; j++) {
-                int32_t u = tc_tax[j];
-                if (!mtb_tax_exists(tx, u) || tx->depth[u] <= tx->depth[root]) continue;
+                int32_t u = mtb_tax_canon(tx, tc_tax[j]);
+                if (u < 0 || tx->depth[u] <= tx->depth[root]) continue;
                 int32_t d = u;
                 while (tx->depth[d] > tx->depth[root] + 1) d = tx->parent[d];
                 if (d == c) clade += tc_cnt[j];
@@ -567,7 +572,7 @@ MTB_HD void mtb_read_decide(const mtb_match *m, int32_t n, const float *sps, con
         if (sc == -1.0f || sc < sp->min_score) continue;
         if (sc >= cut) {
             sum += sc; only = spc; n_max++;
-            if (mtb_tax_exists(tx, spc)) lca = lca < 0 ? spc : mtb_lca(tx, lca, spc);
+            if (mtb_tax_exists(tx, spc)) lca = lca < 0 ? mtb_tax_canon(tx, spc) : mtb_lca(tx, lca, spc);
         }
     }
     float score = n_max > 1 ? sum / (float)n_max : sum;

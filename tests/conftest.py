@@ -1,0 +1,63 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    from helpers import Oracle
+    return Oracle()
+
+
+@pytest.fixture(scope="session")
+def emu():
+    from helpers import Emu
+    return Emu()
+
+
+class Toy:
+    """A toy database + reads + the oracle's full answer, built once per mode."""
+
+    def __init__(self, orc, tmpdir, syncmer, paired, seed, n_reads=400, length=150, seq_mode=None, err=0.01,
+                 lognormal=False, genome_len=30000, with_n=0.1):
+        from helpers import build_toy_db, default_params
+        from metabuli_amd import synth
+        self.p = default_params(seq_mode=seq_mode or (2 if paired else 1), syncmer=syncmer)
+        self.world = synth.make_world(seed=seed, n_genera=4, species_per_genus=3, strains_per_species=2, genome_len=genome_len)
+        self.dbdir = str(tmpdir)
+        self.values, self.taxids = build_toy_db(orc, self.world, self.p, self.dbdir)
+        self.tax = orc.load_taxonomy(os.path.join(self.dbdir, "taxonomy"))
+        self.db = orc.open_db(self.dbdir, self.tax, self.p)
+        rng = np.random.default_rng(seed + 100)
+        out = synth.sample_reads(rng, self.world, n_reads, length=length, err=err, with_n=with_n, paired=paired, lognormal=lognormal)
+        if paired:
+            self.b1, self.o1, self.b2, self.o2, self.truth = out
+        else:
+            self.b1, self.o1, self.truth = out
+            self.b2 = self.o2 = None
+        self.n_reads = n_reads
+        self.ref = orc.classify(self.db, self.tax, self.p, self.b1, self.o1, self.b2, self.o2)
+
+
+TOY_MODES = {
+    "sync_se": dict(syncmer=1, paired=False, seed=1),
+    "dense_se": dict(syncmer=0, paired=False, seed=2),
+    "sync_pe": dict(syncmer=1, paired=True, seed=3),
+    "dense_pe": dict(syncmer=0, paired=True, seed=4),
+    "sync_long": dict(syncmer=1, paired=False, seed=5, n_reads=40, length=3000, seq_mode=3, err=0.05, lognormal=True),
+}
+
+
+@pytest.fixture(scope="session", params=list(TOY_MODES))
+def toy(request, orc, tmp_path_factory):
+    return Toy(orc, tmp_path_factory.mktemp(request.param), **TOY_MODES[request.param])

@@ -70,10 +70,10 @@ size_t emu_join(const uint64_t *values, const uint32_t *info, uint64_t T, const 
 void emu_sort_matches(mtb_match *m, size_t n) { std::sort(m, m + n, [](const mtb_match &a, const mtb_match &b) { return mtb_match_less(a, b); }); }
 
 // mirrors kernels_score.hip score_read(): sequential over the sf blocks / species blocks
-size_t emu_score(const int32_t *parent, const int32_t *depth, const uint8_t *under_euk, const int32_t *sp_parent, int32_t max_taxid,
+size_t emu_score(const int32_t *canon, const int32_t *parent, const int32_t *depth, const uint8_t *under_euk, const int32_t *sp_parent, int32_t max_taxid,
                  const mtb_params *p, const mtb_match *ml, size_t nM, size_t n_reads, const int32_t *qlen, const int32_t *qlen2,
                  mtb_result *res, int32_t *tc_tax, uint32_t *tc_cnt, size_t cap) {
-    mtb_tax_view tx{parent, depth, under_euk, sp_parent, max_taxid};
+    mtb_tax_view tx{canon, parent, depth, under_euk, sp_parent, max_taxid};
     mtb_score_params sp; mtb_make_score_params(p, &sp);
     for (size_t r = 0; r < n_reads; r++) { res[r] = mtb_result{0, 0.f, qlen[r], qlen2 ? qlen2[r] : 0, 0, 0, 0, 0}; }
     size_t w = 0, idx = 0;

@@ -220,11 +220,11 @@ class Emu:
         return m
 
     def score(self, taxarr, p, m, n_reads, ql, ql2):
-        parent, depth, under_euk, sp_parent = taxarr
+        canon, parent, depth, under_euk, sp_parent = taxarr
         res = np.zeros(n_reads, result_dt)
         cap = max(1024, len(m) + 16)
         tt = np.zeros(cap, np.int32); tc = np.zeros(cap, np.uint32)
-        n = self.lib.emu_score(_ptr(parent), _ptr(depth), _ptr(under_euk), _ptr(sp_parent), C.c_int32(len(parent) - 1),
+        n = self.lib.emu_score(_ptr(canon), _ptr(parent), _ptr(depth), _ptr(under_euk), _ptr(sp_parent), C.c_int32(len(parent) - 1),
                                C.byref(p), _ptr(m), C.c_size_t(len(m)), C.c_size_t(n_reads), _ptr(ql), _ptr(ql2),
                                _ptr(res), _ptr(tt), _ptr(tc), C.c_size_t(cap))
         return res, tt[:n].copy(), tc[:n].copy()
@@ -249,7 +249,8 @@ def tax_arrays(orc: Oracle, tax, world_tax):
         under[t] = L.orc_tax_is_ancestor(tax, euk, t)
         sp = L.orc_tax_at_rank(tax, t, b"species")
         spp[t] = L.orc_tax_parent(tax, sp) if sp > 0 else 0
-    return parent, depth, under, spp
+    canon = np.where(parent >= 0, np.arange(mx + 1, dtype=np.int32), -1).astype(np.int32)
+    return canon, parent, depth, under, spp
 
 
 def tax2species_table(orc: Oracle, tax, taxids, mx):

@@ -1,0 +1,161 @@
+"""GPU parity tests: every stage of the HIP path, called through the C ABI
+(include/mtb.h), against the CPU oracle on the same seeded inputs.  Integer /
+byte / index outputs must be bit-exact; the per-read score is compared on its
+fp32 bit pattern (tolerance 0 <= the 1e-6 BASELINE.json allows)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import metabuli_amd as M
+    c = M.Context(0)
+    yield c
+    c.close()
+
+
+def _params(toy):
+    import metabuli_amd as M
+    p = toy.p
+    return M.default_params(seq_mode=p.seq_mode, syncmer=p.syncmer, smer_len=p.smer_len)
+
+
+def _sorted_by_value_then_all(k):
+    return np.sort(k, order=["value", "qinfo"])
+
+
+def test_loaded_native_library(ctx):
+    import metabuli_amd as M
+    assert os.path.exists(M.LIB_PATH)
+    assert b"gfx950" in M.lib().mtb_version()
+
+
+def test_extract_matches_oracle(ctx, toy, orc):
+    p = _params(toy)
+    k, ql, ql2 = ctx.extract(p, toy.b1, toy.o1, toy.b2, toy.o2)
+    ko, qlo, ql2o = orc.extract_batch(toy.p, toy.b1, toy.o1, toy.b2, toy.o2)
+    assert (ql == qlo).all() and (ql2 == ql2o).all()
+    assert len(k) == len(ko)
+    # emission order of the reference: read, mate, frame, window
+    assert (k == ko).all()
+
+
+def test_sort_kmers(ctx, toy):
+    k = toy.ref["kmers"]
+    rng = np.random.default_rng(0)
+    shuffled = k[np.argsort(k["qinfo"], kind="stable")]      # extraction-like order (by read)
+    s = ctx.sort_kmers(shuffled)
+    assert (np.diff(s["value"].astype(np.uint64)) >= 0).all() if len(s) > 1 else True
+    assert (_sorted_by_value_then_all(s) == _sorted_by_value_then_all(k)).all()
+    # stable: equal values keep input order (ascending qinfo here)
+    same = s["value"][1:] == s["value"][:-1]
+    assert (s["qinfo"][1:][same] >= s["qinfo"][:-1][same]).all()
+    # idempotent
+    assert (ctx.sort_kmers(s) == s).all()
+    perm = rng.permutation(len(k))
+    s2 = ctx.sort_kmers(k[perm])
+    assert (s2["value"] == s["value"]).all()
+
+
+def test_index_decode(ctx, toy):
+    p = _params(toy)
+    ix = ctx.open_index(toy.dbdir, p)
+    v, info = ix.download()
+    assert ix.num_targets == len(toy.values)
+    assert (v == toy.values).all()
+    assert (info.astype(np.int32) == toy.taxids).all()
+    ix.close()
+
+
+def test_match_and_sort_matches(ctx, toy, orc):
+    p = _params(toy)
+    ix = ctx.open_index(toy.dbdir, p)
+    m = ctx.match(ix, toy.ref["kmers"])
+    assert len(m) == len(toy.ref["matches"])
+    ms = ctx.sort_matches(m, toy.n_reads)
+    assert (ms == toy.ref["matches"]).all()
+    # last entry of the index is never a candidate (KmerMatcher.cpp:363,378)
+    import metabuli_amd as M
+    q = np.zeros(2, M.kmer_dt)
+    q["value"] = [toy.values[-2], toy.values[-1]]
+    q["qinfo"] = (np.uint64(1) << np.uint64(32))
+    mm = ctx.match(ix, q)
+    mo = orc.match(toy.db, q)
+    assert len(mm) == len(mo)
+    ix.close()
+
+
+def test_score(ctx, toy):
+    p = _params(toy)
+    ix = ctx.open_index(toy.dbdir, p)
+    res, tt, tc = ctx.score(ix, p, toy.ref["matches"], toy.n_reads, toy.ref["qlen"], toy.ref["qlen2"])
+    _check_results(toy, res, tt, tc)
+    ix.close()
+
+
+def _check_results(toy, res, tt, tc):
+    ro = toy.ref["results"]
+    amb = ro["flag"] != 0
+    assert ((res["classification"] == ro["classification"]) | amb).all()
+    assert ((res["is_classified"] == ro["is_classified"]) | amb).all()
+    assert ((res["score"].view(np.uint32) == ro["score"].view(np.uint32)) | amb).all()
+    assert (res["qlen"] == ro["qlen"]).all() and (res["qlen2"] == ro["qlen2"]).all()
+    assert ((res["n_taxcnt"] == ro["n_taxcnt"]) | amb).all()
+    # taxID:match_count lists per read
+    for i in range(len(ro)):
+        if amb[i]:
+            continue
+        a = slice(int(res["taxcnt_off"][i]), int(res["taxcnt_off"][i]) + int(res["n_taxcnt"][i]))
+        b = slice(int(ro["taxcnt_off"][i]), int(ro["taxcnt_off"][i]) + int(ro["n_taxcnt"][i]))
+        assert (tt[a] == toy.ref["tc_tax"][b]).all() and (tc[a] == toy.ref["tc_cnt"][b]).all()
+
+
+def test_fused_batch(ctx, toy):
+    p = _params(toy)
+    ix = ctx.open_index(toy.dbdir, p)
+    res, tt, tc = ctx.classify_batch(ix, p, toy.b1, toy.o1, toy.b2, toy.o2)
+    _check_results(toy, res, tt, tc)
+    st = ctx.last_stats()
+    assert st.n_reads == toy.n_reads and st.n_kmers == len(toy.ref["kmers"]) and st.n_matches == len(toy.ref["matches"])
+    # idempotent / deterministic
+    res2, tt2, tc2 = ctx.classify_batch(ix, p, toy.b1, toy.o1, toy.b2, toy.o2)
+    assert (res2 == res).all() and (tt2 == tt).all() and (tc2 == tc).all()
+    ix.close()
+
+
+def test_empty_and_ragged_inputs(ctx, orc):
+    import metabuli_amd as M
+    from helpers import default_params
+    seqs = [b"", b"ACGT", b"ACGTACGTACGTACGTACGTACGTA", b"ACGTACGTACGTACGTACGTACGTAC", b"N" * 40,
+            b"acgtRYKMacgtnACGTTTGACCATGGCATTAGCCGATTACAGGCATCGAGGCTAGCTAGGATCGATCGGGATCTAGCTAGC" * 3,
+            b"ACGTTTGACCATGGCATTAGCCGATTACAGGCATCGAGGCTAGCTAGGATCGATCGGGATCTAGCTAGCNACGTTTGACCATGGCATTAGCCGATTACAGGCATCGAGG"]
+    bases = np.frombuffer(b"".join(seqs), dtype=np.uint8).copy()
+    offs = np.zeros(len(seqs) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(s) for s in seqs])
+    for sync in (0, 1):
+        k, ql, _ = ctx.extract(M.default_params(seq_mode=1, syncmer=sync), bases, offs)
+        ko, qlo, _ = orc.extract_batch(default_params(seq_mode=1, syncmer=sync), bases, offs)
+        assert (ql == qlo).all() and len(k) == len(ko) and (k == ko).all()
+    # zero reads
+    k, _, _ = ctx.extract(M.default_params(), np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+    assert len(k) == 0
+
+
+def test_large_properties(ctx):
+    """Size-independent properties at a larger size than the oracle is run on."""
+    import metabuli_amd as M
+    rng = np.random.default_rng(7)
+    n = 3_000_000
+    k = np.zeros(n, M.kmer_dt)
+    k["value"] = rng.integers(0, 2**63, size=n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=n, dtype=np.uint64)
+    k["qinfo"] = np.arange(n, dtype=np.uint64)
+    s = ctx.sort_kmers(k)
+    assert (s["value"][1:] >= s["value"][:-1]).all()
+    assert int(s["value"].sum(dtype=np.uint64)) == int(k["value"].sum(dtype=np.uint64))
+    assert int(s["qinfo"].sum(dtype=np.uint64)) == int(k["qinfo"].sum(dtype=np.uint64))
+    order = np.argsort(k["value"], kind="stable")
+    assert (s["qinfo"] == k["qinfo"][order]).all()
