@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""bench.py -- `metabuli classify` hot path on MI355X: Mreads/s (+ Gbp/s) with
+the reads and the target index already resident in HBM.
+
+One "step" = one pass of the whole hot path (extract -> radix sort -> join
+against the resident index -> regroup/segment sort -> per-read scoring) over one
+batch of synthetic reads (BASELINE.json configs[1]: 10 M x 150 bp single-end
+vs a GTDB-scale synthetic index).  One process per GPU; reads are sharded, the
+index is replicated, there is no data-path collective (weak scaling).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8 ...
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_world(seed, n_species, genome_len, n_filler_species):
+    from metabuli_amd import synth
+    return synth.make_world(seed=seed, n_genera=max(1, n_species // 4), species_per_genus=4, strains_per_species=1,
+                            genome_len=genome_len, n_filler_species=n_filler_species)
+
+
+def extract_targets(ctx, M, world, params):
+    """Six-frame (sync)metamers of every genome, on the GPU, via the public
+    extraction entry point (long-read geometry, overlapping 20 kb pieces)."""
+    piece, ov = 20000, 32
+    seqs, owner = [], []
+    for gi, (tid, g) in enumerate(world.genomes):
+        for st in range(0, len(g), piece - ov):
+            seqs.append(g[st:st + piece])
+            owner.append(gi)
+            if st + piece >= len(g):
+                break
+    offs = np.zeros(len(seqs) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(s) for s in seqs])
+    bases = np.concatenate(seqs).astype(np.uint8)
+    p = M.default_params(seq_mode=3, syncmer=params.syncmer, smer_len=params.smer_len)
+    k, _, _ = ctx.extract(p, bases, offs)
+    owner = np.asarray(owner, dtype=np.int64)
+    seq = ((k["qinfo"] >> np.uint64(32)) & np.uint64(0x1FFFFFFF)).astype(np.int64) - 1
+    g_of = owner[seq]
+    vals, tids = [], []
+    for gi, (tid, g) in enumerate(world.genomes):
+        v = np.unique(k["value"][g_of == gi])
+        vals.append(v)
+        tids.append(np.full(len(v), tid, np.int32))
+    vals = np.concatenate(vals); tids = np.concatenate(tids)
+    # one strain per species here, so (value, species) pairs are already unique;
+    # strain ids are allocated right after their species id, so taxid order = species order
+    order = np.lexsort((tids, vals))
+    return vals[order], tids[order]
+
+
+def gen_reads(torch, dev, world, n_reads, read_len, frac_random, err, seed):
+    """Reads sampled from the genomes (both strands, substitutions) + random
+    reads, generated on the device so that the inputs are HBM-resident."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    G = torch.from_numpy(np.concatenate([x for _, x in world.genomes]).astype(np.uint8)).to(dev)
+    lens = torch.tensor([len(x) for _, x in world.genomes], device=dev, dtype=torch.int64)
+    starts = torch.cumsum(lens, 0) - lens
+    comp = torch.full((256,), ord("N"), dtype=torch.uint8, device=dev)
+    for a, b in zip(b"ACGT", b"TGCA"):
+        comp[a] = b
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    out = torch.empty(n_reads * read_len, dtype=torch.uint8, device=dev)
+    ar = torch.arange(read_len, device=dev, dtype=torch.int64)
+    chunk = 1_000_000
+    for c0 in range(0, n_reads, chunk):
+        n = min(chunk, n_reads - c0)
+        gi = torch.randint(0, len(lens), (n,), generator=g, device=dev)
+        st = (torch.rand(n, generator=g, device=dev) * (lens[gi] - read_len + 1).float()).long().clamp_(min=0) + starts[gi]
+        r = G[st[:, None] + ar[None, :]]
+        rc = torch.rand(n, generator=g, device=dev) < 0.5
+        r = torch.where(rc[:, None], comp[r.long()].flip(1), r)
+        sub = torch.rand(n, read_len, generator=g, device=dev) < err
+        r = torch.where(sub, acgt[torch.randint(0, 4, (n, read_len), generator=g, device=dev)], r)
+        rnd = torch.rand(n, generator=g, device=dev) < frac_random
+        r = torch.where(rnd[:, None], acgt[torch.randint(0, 4, (n, read_len), generator=g, device=dev)], r)
+        out[c0 * read_len:(c0 + n) * read_len] = r.reshape(-1)
+    offs = torch.arange(n_reads + 1, device=dev, dtype=torch.int64) * read_len
+    return out, offs
+
+
+def cpu_baseline(ctx, M, torch, dev, world, real_v, real_t, params, taxdir, d_bases, read_len, n_sample, n_filler_small, seed):
+    """Oracle (CPU restatement of the reference algorithm, 1 thread) on a bounded
+    sample: the first n_sample reads of this rank against an index built by the
+    same generator with fewer filler metamers."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import Oracle, default_params as odp
+    orc = Oracle()
+    T = n_filler_small + len(real_v)
+    dv = torch.empty(T, dtype=torch.int64, device=dev); di = torch.empty(T, dtype=torch.int32, device=dev)
+    n = ctx.synth_index(seed, n_filler_small, world.filler_tax_lo, world.filler_tax_hi, real_v, real_t, dv.data_ptr(), di.data_ptr())
+    vals = dv[:n].cpu().numpy().view(np.uint64); tids = di[:n].cpu().numpy()
+    del dv, di
+    d = tempfile.mkdtemp(prefix="mtb_cpu_")
+    op = odp(seq_mode=params.seq_mode, syncmer=params.syncmer, smer_len=params.smer_len)
+    orc.write_db(d, vals, tids, op)
+    tax = orc.load_taxonomy(taxdir)
+    db = orc.open_db(d, tax, op)
+    bases = d_bases[: n_sample * read_len].cpu().numpy()
+    offs = (np.arange(n_sample + 1, dtype=np.uint64) * np.uint64(read_len))
+    t0 = time.perf_counter()
+    R = orc.classify(db, tax, op, bases, offs)
+    dt = time.perf_counter() - t0
+    cls = int((R["results"]["is_classified"] != 0).sum())
+    return dict(value=n_sample / dt / 1e6, unit="Mreads/s", cores=1, kind="port",
+                sample=f"{n_sample} x {read_len} bp reads vs {n} target metamers ({len(real_v)} genome-derived + {n_filler_small} filler), "
+                       f"oracle/liboracle.so single thread, {dt:.1f} s, {cls} classified", seconds=dt), R
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--targets", type=float, default=8e9, help="filler metamers in the synthetic index (per GPU, replicated)")
+    ap.add_argument("--species", type=int, default=24)
+    ap.add_argument("--genome-len", type=int, default=1_000_000)
+    ap.add_argument("--filler-species", type=int, default=130_000)
+    ap.add_argument("--cpu-reads", type=int, default=100_000)
+    ap.add_argument("--cpu-targets", type=float, default=16e6)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--seed", type=int, default=1234)
+    args = ap.parse_args()
+
+    import torch  # before libmtb: both must share one HIP runtime (libamdhip64.so.7)
+    rank = int(os.environ.get("RANK", "0")); world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world_size != args.gpus:
+        log(f"warning: WORLD_SIZE={world_size} but --gpus {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world_size > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
+    import metabuli_amd as M
+    ctx = M.Context(local_rank)
+    params = M.default_params(seq_mode=1, syncmer=1, smer_len=5)
+
+    t_setup = time.perf_counter()
+    world = build_world(args.seed, args.species, args.genome_len, args.filler_species)
+    taxdir = tempfile.mkdtemp(prefix="mtb_tax_")
+    world.tax.write(taxdir)
+    real_v, real_t = extract_targets(ctx, M, world, params)
+    n_filler = int(args.targets)
+    T_cap = n_filler + len(real_v)
+    free, total = torch.cuda.mem_get_info(dev)
+    need = T_cap * 12 + args.reads * (args.read_len + 8)
+    if need > free * 0.9:
+        raise SystemExit(f"index of {T_cap} targets needs {need/2**30:.0f} GiB, only {free/2**30:.0f} GiB free")
+    d_values = torch.empty(T_cap, dtype=torch.int64, device=dev)
+    d_info = torch.empty(T_cap, dtype=torch.int32, device=dev)
+    T = ctx.synth_index(args.seed, n_filler, world.filler_tax_lo, world.filler_tax_hi, real_v, real_t, d_values.data_ptr(), d_info.data_ptr())
+    taxid_list = np.concatenate([np.unique(real_t), np.arange(world.filler_tax_lo, world.filler_tax_hi + 1, dtype=np.int32)])
+    index = ctx.index_from_device(d_values.data_ptr(), d_info.data_ptr(), T, taxdir, taxid_list, params)
+    d_bases, d_offs = gen_reads(torch, dev, world, args.reads, args.read_len, 0.10, 0.005, args.seed + 17 * (rank + 1))
+    d_res = torch.empty(args.reads * 24, dtype=torch.uint8, device=dev)
+    tc_cap = args.reads * 20 + 1024
+    d_tt = torch.empty(tc_cap, dtype=torch.int32, device=dev); d_tc = torch.empty(tc_cap, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    log(f"[rank {rank}] setup {time.perf_counter()-t_setup:.1f}s: T={T} ({len(real_v)} genome-derived), reads={args.reads}x{args.read_len}")
+
+    def step():
+        return ctx.classify_batch_device(index, params, d_bases.data_ptr(), d_offs.data_ptr(), 0, 0, args.reads,
+                                         args.reads * args.read_len, d_res.data_ptr(), d_tt.data_ptr(), d_tc.data_ptr(), tc_cap)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    st = ctx.last_stats()
+
+    # one extra, untimed, profiled step: HIP events around every kernel launch
+    ctx.set_profiling(True)
+    step()
+    ps = ctx.last_stats()
+    ctx.set_profiling(False)
+    kern = {M.KERNEL_NAMES[i]: dict(ms=float(ps.ms_kernel[i]), launches=int(ps.n_launch[i])) for i in range(len(M.KERNEL_NAMES))}
+    Kq, Mm, N, L = ps.n_kmers, ps.n_matches, ps.n_reads, ps.n_bases
+    n_pass = max(1, kern["radix_scatter"]["launches"])
+    alg = {   # algorithmic bytes per launch (SURVEY.md 8(d) per-stage split; DESIGN.md "Roofline")
+        "extract_count": L, "extract_emit": L + 16 * Kq, "radix_hist": 16 * Kq / n_pass, "radix_scatter": 32 * Kq / n_pass,
+        "join": 16 * Kq + 12 * ps.n_targets + 24 * Mm, "regroup": 24 * Mm, "segsort": 24 * Mm, "score": 24 * Mm + 16 * N}
+    dom = max((k for k in alg), key=lambda k: kern[k]["ms"])
+    avg_ms = kern[dom]["ms"] / max(1, kern[dom]["launches"])
+    achieved = alg[dom] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    roofline = dict(bound="hbm", kernel=dom, achieved=achieved, peak=8000.0, unit="GB/s", frac=achieved / 8000.0, traffic=None,
+                    avg_launch_ms=avg_ms, launches=kern[dom]["launches"], algorithmic_bytes_per_launch=alg[dom])
+
+    # sanity of the timed output: fraction of reads classified
+    res = np.frombuffer(d_res.cpu().numpy().tobytes(), dtype=M.result_dt)
+    frac_cls = float((res["is_classified"] != 0).mean())
+
+    cpu = None
+    if rank == 0 and not args.no_cpu and world_size == 1:
+        cpu, R = cpu_baseline(ctx, M, torch, dev, world, real_v, real_t, params, taxdir, d_bases, args.read_len,
+                              min(args.cpu_reads, args.reads), int(args.cpu_targets), args.seed)
+        cpu.pop("seconds", None)
+
+    if rank == 0:
+        total_reads = args.reads * world_size * args.steps
+        value = total_reads / dt / 1e6
+        out = dict(metric="Mreads/s classified (metabuli classify hot path, reads + index resident in HBM)",
+                   value=value, unit="Mreads/s", n_gpus=world_size, steps=args.steps, warmup=args.warmup,
+                   ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None,
+                   dtype="u64", data="synthetic",
+                   config=dict(workload=f"{args.reads/1e6:g}M x {args.read_len} bp synthetic single-end reads per GPU vs synthetic "
+                                        f"GTDB-scale index of {T/1e9:.2f} G metamers ({T*12/2**30:.0f} GiB flat, replicated per GPU), "
+                                        f"syncmer s=5, kmer_format 2 (BASELINE.json configs[1])",
+                               reads_per_gpu=args.reads, read_len=args.read_len, targets=int(T), seq_mode=1,
+                               gbp_per_s=value * args.read_len / 1e3, query_metamers=int(st.n_kmers), matches=int(st.n_matches),
+                               classified_fraction=frac_cls, parallelism=f"reads sharded x{world_size}, index replicated"),
+                   stage_ms=dict(extract=st.ms_extract, sort=st.ms_sort, join=st.ms_join, regroup=st.ms_regroup,
+                                 segsort=st.ms_segsort, score=st.ms_score, total=st.ms_total),
+                   kernel_ms=kern, roofline=roofline, cpu_baseline=cpu)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

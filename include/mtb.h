@@ -84,11 +84,23 @@ typedef struct {
 typedef struct mtb_ctx mtb_ctx;
 typedef struct mtb_index mtb_index;
 
+/* kernel ids for mtb_batch_stats.ms_kernel / n_launch */
+enum {
+    MTB_K_EXTRACT_COUNT = 0, MTB_K_EXTRACT_EMIT = 1, MTB_K_RADIX_HIST = 2, MTB_K_RADIX_SCATTER = 3,
+    MTB_K_JOIN = 4, MTB_K_REGROUP = 5, MTB_K_SEGSORT = 6, MTB_K_SCORE = 7, MTB_K_SCAN = 8,
+    MTB_NUM_KERNELS = 9
+};
+
 /* Per-stage device time of the last mtb_classify_batch* call (HIP events on
  * the context's stream) and the run-time counters of SURVEY.md 8(d).        */
 typedef struct {
     float    ms_extract, ms_sort, ms_join, ms_regroup, ms_segsort, ms_score, ms_total;
     uint64_t n_reads, n_bases, n_kmers, n_matches, n_targets;
+    /* per-kernel sums over the batch (filled when profiling is on, see
+     * mtb_ctx_set_profiling): HIP events recorded on the context's stream
+     * immediately before and after every launch of that kernel.            */
+    float    ms_kernel[MTB_NUM_KERNELS];
+    uint32_t n_launch[MTB_NUM_KERNELS];
 } mtb_batch_stats;
 
 const char *mtb_version(void);
@@ -100,6 +112,9 @@ void mtb_default_params(mtb_params *p);          /* classify.cpp:10-37       */
 mtb_status mtb_ctx_create(int device, void *stream, mtb_ctx **out);
 void       mtb_ctx_destroy(mtb_ctx *);
 mtb_status mtb_ctx_sync(mtb_ctx *);
+/* 1: bracket every kernel launch of mtb_classify_batch* with HIP events
+ * (adds a few microseconds per launch); 0 (default): stage-level events only. */
+mtb_status mtb_ctx_set_profiling(mtb_ctx *, int on);
 
 /* ---- index residency ---------------------------------------------------
  * Replaces the per-call fopen/fread/mmap of diffIdx, info, split inside

@@ -38,7 +38,11 @@ class BatchStats(C.Structure):
     _fields_ = [("ms_extract", C.c_float), ("ms_sort", C.c_float), ("ms_join", C.c_float), ("ms_regroup", C.c_float),
                 ("ms_segsort", C.c_float), ("ms_score", C.c_float), ("ms_total", C.c_float),
                 ("n_reads", C.c_uint64), ("n_bases", C.c_uint64), ("n_kmers", C.c_uint64),
-                ("n_matches", C.c_uint64), ("n_targets", C.c_uint64)]
+                ("n_matches", C.c_uint64), ("n_targets", C.c_uint64),
+                ("ms_kernel", C.c_float * 9), ("n_launch", C.c_uint32 * 9)]
+
+
+KERNEL_NAMES = ["extract_count", "extract_emit", "radix_hist", "radix_scatter", "join", "regroup", "segsort", "score", "scan"]
 
 
 class MtbError(RuntimeError):
@@ -117,6 +121,9 @@ class Context:
 
     def sync(self):
         _chk(self.L.mtb_ctx_sync(self.h))
+
+    def set_profiling(self, on):
+        _chk(self.L.mtb_ctx_set_profiling(self.h, C.c_int(1 if on else 0)))
 
     # ---- index ----
     def open_index(self, dbdir, params, taxonomy_dir=None):

@@ -40,7 +40,40 @@ struct mtb_ctx {
     uint64_t *d_scal = nullptr;      /* [0] match counter, [1] overflow, [2] n_large, [3] max_seg, [4] max_len */
     hipEvent_t ev[8];
     mtb_batch_stats stats;
+    int profiling = 0;
+    struct KEv { int id; hipEvent_t a, b; };
+    std::vector<KEv> kev;            /* events of the current batch      */
+    std::vector<hipEvent_t> ev_pool; /* recycled events                  */
 };
+
+/* RAII bracket around one kernel launch (only when profiling is on) */
+struct KTimer {
+    mtb_ctx *c; int id; hipEvent_t a = nullptr, b = nullptr;
+    KTimer(mtb_ctx *c_, int id_) : c(c_), id(id_) {
+        if (!c->profiling) return;
+        a = take(); b = take();
+        hipError_t e = hipEventRecord(a, c->stream); (void)e;
+    }
+    ~KTimer() {
+        if (!c->profiling) return;
+        hipError_t e = hipEventRecord(b, c->stream); (void)e;
+        c->kev.push_back({id, a, b});
+    }
+    hipEvent_t take() {
+        hipEvent_t ev;
+        if (!c->ev_pool.empty()) { ev = c->ev_pool.back(); c->ev_pool.pop_back(); return ev; }
+        hipError_t e = hipEventCreate(&ev); (void)e;
+        return ev;
+    }
+};
+static void collect_kernel_times(mtb_ctx *c) {
+    for (auto &k : c->kev) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, k.a, k.b) == hipSuccess) { c->stats.ms_kernel[k.id] += ms; c->stats.n_launch[k.id]++; }
+        c->ev_pool.push_back(k.a); c->ev_pool.push_back(k.b);
+    }
+    c->kev.clear();
+}
 
 struct mtb_index {
     mtb_ctx *ctx = nullptr;
@@ -112,9 +145,12 @@ void mtb_ctx_destroy(mtb_ctx *c) {
     if (c->d_tabs) e = hipFree(c->d_tabs);
     if (c->d_scal) e = hipFree(c->d_scal);
     for (int i = 0; i < 8; i++) e = hipEventDestroy(c->ev[i]);
+    for (auto &k : c->kev) { e = hipEventDestroy(k.a); e = hipEventDestroy(k.b); }
+    for (auto &x : c->ev_pool) e = hipEventDestroy(x);
     delete c;
 }
 mtb_status mtb_ctx_sync(mtb_ctx *c) { HIPCHK(hipStreamSynchronize(c->stream)); return MTB_OK; }
+mtb_status mtb_ctx_set_profiling(mtb_ctx *c, int on) { if (!c) return fail(MTB_ERR_ARG, "NULL ctx"); c->profiling = on; return MTB_OK; }
 
 } // extern "C"
 
@@ -149,17 +185,19 @@ static mtb_status dev_extract(mtb_ctx *c, const mtb_params *p, const char *d_bas
     HIPCHK(hipMemsetAsync(c->d_scal + 4, 0, 8, c->stream));
     ExtractArgs a{d_bases, d_offs, d_bases2, d_offs2, n_reads, p->seq_mode, p->syncmer, p->smer_len};
     uint32_t grid = (uint32_t)std::min<uint64_t>(n_reads, 256ull * 64);
+    { KTimer kt(c, MTB_K_EXTRACT_COUNT);
     hipLaunchKernelGGL((k_extract<false>), dim3(grid), dim3(64), 0, c->stream, a, c->d_tabs, d_cnt, (const uint64_t *)nullptr,
-                       (mtb_kmer *)nullptr, d_qlen, d_qlen2, (uint32_t *)(c->d_scal + 4));
-    scan_launch<uint32_t, uint64_t, false>(c->stream, d_cnt, n_reads, true, d_koff, d_ws);
+                       (mtb_kmer *)nullptr, d_qlen, d_qlen2, (uint32_t *)(c->d_scal + 4)); }
+    { KTimer kt(c, MTB_K_SCAN); scan_launch<uint32_t, uint64_t, false>(c->stream, d_cnt, n_reads, true, d_koff, d_ws); }
     uint64_t total = 0;
     STCHK(d2h(c, &total, d_koff + n_reads, 8));
     if (max_len) { uint64_t ml = 0; STCHK(d2h(c, &ml, c->d_scal + 4, 8)); *max_len = (uint32_t)ml; }
     if (total >= (1ull << 32)) return fail(MTB_ERR_ARG, "more than 2^32-1 query metamers in one batch; split the batch");
     mtb_kmer *d_k;
     STCHK(ensure(c, "kmersA", total, &d_k));
-    if (total) hipLaunchKernelGGL((k_extract<true>), dim3(grid), dim3(64), 0, c->stream, a, c->d_tabs, (uint32_t *)nullptr,
-                                  (const uint64_t *)d_koff, d_k, (int32_t *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr);
+    if (total) { KTimer kt(c, MTB_K_EXTRACT_EMIT);
+        hipLaunchKernelGGL((k_extract<true>), dim3(grid), dim3(64), 0, c->stream, a, c->d_tabs, (uint32_t *)nullptr,
+                           (const uint64_t *)d_koff, d_k, (int32_t *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr); }
     HIPCHK(hipGetLastError());
     *out = d_k; *count = total;
     return MTB_OK;
@@ -172,7 +210,17 @@ static mtb_status dev_sort(mtb_ctx *c, mtb_kmer *d_a, uint64_t n, int first_bit,
     STCHK(ensure(c, "kmersB", n, &d_b));
     STCHK(ensure(c, "hist", radix_hist_elems(n), &d_hist));
     STCHK(ensure(c, "scanws", scan_ws_elems(radix_hist_elems(n)), &d_ws));
-    *sorted = radix_sort_kmers(c->stream, d_a, d_b, n, first_bit, d_hist, (uint32_t *)d_ws);
+    {
+        uint32_t tiles = (uint32_t)((n + MTB_SORT_TILE - 1) / MTB_SORT_TILE);
+        mtb_kmer *src = d_a, *dst = d_b;
+        for (int shift = first_bit; shift < 64; shift += 8) {
+            { KTimer kt(c, MTB_K_RADIX_HIST); hipLaunchKernelGGL(k_radix_hist, dim3(tiles), dim3(256), 0, c->stream, (const mtb_kmer *)src, n, shift, d_hist, tiles); }
+            { KTimer kt(c, MTB_K_SCAN); scan_launch<uint32_t, uint32_t, false>(c->stream, d_hist, 256ull * tiles, false, d_hist, (uint32_t *)d_ws); }
+            { KTimer kt(c, MTB_K_RADIX_SCATTER); hipLaunchKernelGGL(k_radix_scatter, dim3(tiles), dim3(256), 0, c->stream, (const mtb_kmer *)src, dst, n, shift, (const uint32_t *)d_hist, tiles); }
+            mtb_kmer *tmp = src; src = dst; dst = tmp;
+        }
+        *sorted = src;
+    }
     HIPCHK(hipGetLastError());
     return MTB_OK;
 }
@@ -197,8 +245,9 @@ static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint6
     if (n == 0) return MTB_OK;
     HIPCHK(hipMemsetAsync(c->d_scal, 0, 16, c->stream));
     uint32_t grid = (uint32_t)((n + 255) / 256);
+    { KTimer kt(c, MTB_K_JOIN);
     hipLaunchKernelGGL(k_join, dim3(grid), dim3(256), 0, c->stream, d_q, n, index_view(ix), (const mtb_tables *)c->d_tabs, d_out, cap,
-                       (unsigned long long *)c->d_scal, d_read_cnt, (uint32_t *)(c->d_scal + 1));
+                       (unsigned long long *)c->d_scal, d_read_cnt, (uint32_t *)(c->d_scal + 1)); }
     HIPCHK(hipGetLastError());
     uint64_t sc[2];
     STCHK(d2h(c, sc, c->d_scal, 16));
@@ -214,9 +263,9 @@ static mtb_status dev_regroup(mtb_ctx *c, const mtb_match *d_in, uint64_t m, uin
     STCHK(ensure(c, "segstart", n_reads + 1, &d_seg));
     STCHK(ensure(c, "scanws", scan_ws_elems(n_reads + 1), &d_ws));
     STCHK(ensure(c, "cursor", n_reads, &d_cur));
-    scan_launch<uint32_t, uint64_t, false>(c->stream, d_read_cnt, n_reads, true, d_seg, d_ws);
+    { KTimer kt(c, MTB_K_SCAN); scan_launch<uint32_t, uint64_t, false>(c->stream, d_read_cnt, n_reads, true, d_seg, d_ws); }
     HIPCHK(hipMemsetAsync(d_cur, 0, n_reads * 4, c->stream));
-    if (m) hipLaunchKernelGGL(k_regroup, dim3((uint32_t)((m + 255) / 256)), dim3(256), 0, c->stream, d_in, m, (const uint64_t *)d_seg, d_cur, d_out);
+    if (m) { KTimer kt(c, MTB_K_REGROUP); hipLaunchKernelGGL(k_regroup, dim3((uint32_t)((m + 255) / 256)), dim3(256), 0, c->stream, d_in, m, (const uint64_t *)d_seg, d_cur, d_out); }
     HIPCHK(hipGetLastError());
     *seg_start = d_seg;
     return MTB_OK;
@@ -227,8 +276,9 @@ static mtb_status dev_segsort(mtb_ctx *c, mtb_match *d_m, const uint64_t *d_seg,
     STCHK(ensure(c, "large", n_reads, &d_large));
     HIPCHK(hipMemsetAsync(c->d_scal + 2, 0, 16, c->stream));
     uint32_t grid = (uint32_t)std::min<uint64_t>(n_reads, 256ull * 40);
+    { KTimer kt(c, MTB_K_SEGSORT);
     hipLaunchKernelGGL(k_segsort_small, dim3(grid), dim3(64), 0, c->stream, d_m, d_seg, n_reads, d_large, (uint32_t *)(c->d_scal + 2),
-                       (uint32_t *)(c->d_scal + 3));
+                       (uint32_t *)(c->d_scal + 3)); }
     hipLaunchKernelGGL(k_segsort_large, dim3(1024), dim3(256), 0, c->stream, d_m, d_seg, (const uint32_t *)d_large,
                        (const uint32_t *)(c->d_scal + 2));
     HIPCHK(hipGetLastError());
@@ -264,8 +314,9 @@ static mtb_status dev_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, cons
         while ((uint64_t)grid * slab_bytes > (8ull << 30) && grid > 64) grid /= 2;
         STCHK(ensure(c, "slabs", (size_t)grid * slab_bytes, &d_slabs));
     }
+    { KTimer kt(c, MTB_K_SCORE);
     hipLaunchKernelGGL(k_score, dim3(grid), dim3(64), 0, c->stream, d_m, d_seg, n_reads, d_qlen, d_qlen2, tax_view(ix), sp,
-                       (const uint64_t *)d_tcoff, d_res, d_tc_tax, d_tc_cnt, tc_cap, d_slabs, slab_bytes, slab_n, slab_nb);
+                       (const uint64_t *)d_tcoff, d_res, d_tc_tax, d_tc_cnt, tc_cap, d_slabs, slab_bytes, slab_n, slab_nb); }
     HIPCHK(hipGetLastError());
     return MTB_OK;
 }
@@ -516,6 +567,8 @@ mtb_status mtb_classify_batch_device(mtb_ctx *c, mtb_index *ix, const mtb_params
     HIPCHK(hipSetDevice(c->device));
     *n_taxcnt = 0;
     memset(&c->stats, 0, sizeof(c->stats));
+    collect_kernel_times(c);          /* drop events of stage-level calls */
+    memset(&c->stats, 0, sizeof(c->stats));
     if (n_reads == 0) return MTB_OK;
     hipStream_t st = c->stream;
     int32_t *d_ql, *d_ql2;
@@ -561,6 +614,7 @@ mtb_status mtb_classify_batch_device(mtb_ctx *c, mtb_index *ix, const mtb_params
     HIPCHK(hipEventElapsedTime(&S.ms_segsort, c->ev[4], c->ev[5]));
     HIPCHK(hipEventElapsedTime(&S.ms_score, c->ev[5], c->ev[6]));
     HIPCHK(hipEventElapsedTime(&S.ms_total, c->ev[0], c->ev[6]));
+    collect_kernel_times(c);
     S.n_reads = n_reads; S.n_bases = n_bases_total; S.n_kmers = nk; S.n_matches = nm; S.n_targets = ix->T;
     return MTB_OK;
 }
