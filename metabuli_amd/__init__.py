@@ -107,6 +107,18 @@ def _chk(st):
         raise MtbError(st, lib().mtb_last_error().decode())
 
 
+def compact_taxcnt(res, tt, tc):
+    """The C ABI leaves every read's taxID:match_count entries at res.taxcnt_off
+    inside bound-sized slots; pack them back to back (host-side convenience)."""
+    n = res["n_taxcnt"].astype(np.int64)
+    new_off = np.zeros(len(res) + 1, np.int64)
+    np.cumsum(n, out=new_off[1:])
+    idx = np.repeat(res["taxcnt_off"].astype(np.int64) - new_off[:-1], n) + np.arange(int(new_off[-1]))
+    out = res.copy()
+    out["taxcnt_off"] = new_off[:-1].astype(np.uint32)
+    return out, tt[idx].copy(), tc[idx].copy()
+
+
 class Context:
     def __init__(self, device=0, stream=0):
         self.L = lib()
@@ -189,7 +201,7 @@ class Context:
         n = C.c_uint64()
         _chk(self.L.mtb_score(self.h, index.h, C.byref(params), _p(sorted_matches), C.c_uint64(len(sorted_matches)),
                               C.c_uint64(n_reads), _p(qlen), _p(qlen2), _p(res), _p(tt), _p(tc), C.c_uint64(cap), C.byref(n)))
-        return res, tt[:n.value].copy(), tc[:n.value].copy()
+        return compact_taxcnt(res, tt, tc)
 
     # ---- fused batch ----
     def classify_batch(self, index, params, bases, offs, bases2=None, offs2=None):
@@ -205,7 +217,7 @@ class Context:
                 cap = cnt.value
                 continue
             _chk(st)
-            return res, tt[:cnt.value].copy(), tc[:cnt.value].copy()
+            return compact_taxcnt(res, tt, tc)
 
     def classify_batch_device(self, index, params, d_bases, d_offs, d_bases2, d_offs2, n_reads, n_bases,
                               d_results, d_tc_tax, d_tc_cnt, tc_cap):

@@ -16,6 +16,7 @@
 #define MTB_KERNELS_SCORE_H
 #include "dev_util.h"
 #include "mtb_core.h"
+#include "kernels_join.h"
 
 #define MTB_SCORE_LDS 192        /* matches per read staged in LDS            */
 #define MTB_SCORE_BKT 128        /* position buckets / taxCnt entries in LDS  */
@@ -37,12 +38,92 @@ __global__ __launch_bounds__(64) void k_taxcnt_bound(const uint64_t *__restrict_
     bound[r] = (uint32_t)(n < nb ? n : nb);
 }
 
+/* list the reads whose segment does not fit the LDS staging of k_score; they
+ * are sorted in HBM by k_segsort_large and scored out of per-workgroup slabs */
+__global__ __launch_bounds__(256) void k_list_large(const uint64_t *__restrict__ seg_start, uint64_t n_reads, uint32_t threshold,
+                                                     uint32_t *__restrict__ large, uint32_t *__restrict__ n_large, uint32_t *__restrict__ max_seg) {
+    uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t n = 0;
+    if (r < n_reads) {
+        n = (uint32_t)(seg_start[r + 1] - seg_start[r]);
+        if (n > threshold) large[atomicAdd(n_large, 1u)] = (uint32_t)r;
+    }
+    for (int d = 32; d > 0; d >>= 1) { uint32_t o = __shfl_down(n, d, 64); n = o > n ? o : n; }
+    if ((threadIdx.x & 63) == 0 && n > threshold) atomicMax(max_seg, n);
+}
+
+/* One read, all storage in ONE address space per call site (LDS or HBM slab)
+ * so that the compiler emits ds_* / global_* instead of flat accesses.       */
+template <bool SORT>
+__device__ __forceinline__ void score_read_body(const mtb_match *__restrict__ src, int32_t n, mtb_match *m, mtb_path *path,
+                                                int32_t *order, int32_t *acc, float *sps, uint8_t *flag, int32_t *btax,
+                                                uint8_t *bham, int32_t *otax, uint32_t *ocnt, int32_t nb, int32_t read_len,
+                                                const mtb_tax_view &tx, const mtb_score_params &sp, uint64_t tc_off, uint64_t tc_room,
+                                                int32_t *__restrict__ tc_tax, uint32_t *__restrict__ tc_cnt, uint64_t tc_cap,
+                                                mtb_match *__restrict__ sorted_out, mtb_result &R) {
+    const int32_t lane = (int32_t)threadIdx.x;
+    if ((const mtb_match *)m != src) {        /* stage the segment (24-byte records as 3 x u64, coalesced) */
+        const uint64_t *s64 = (const uint64_t *)src;
+        uint64_t *d64 = (uint64_t *)m;
+        for (int32_t i = lane; i < n * 3; i += 64) d64[i] = s64[i];
+    }
+    for (int32_t i = lane; i < n; i += 64) { flag[i] = 0; sps[i] = -1.0f; }
+    __syncthreads();
+    if (SORT) {
+        seg_bitonic<64>(m, (uint32_t)n, (uint32_t)lane);
+        if (sorted_out) {
+            const uint64_t *s64 = (const uint64_t *)m;
+            uint64_t *d64 = (uint64_t *)sorted_out;
+            for (int32_t i = lane; i < n * 3; i += 64) d64[i] = s64[i];
+        }
+    }
+    /* phase 1: (species, frame) blocks */
+    for (int32_t i = lane; i < n; i += 64) {
+        int32_t spc = m[i].species_id; uint32_t fr = mtb_q_frame(m[i].qinfo);
+        bool head = (i == 0) || m[i - 1].species_id != spc || mtb_q_frame(m[i - 1].qinfo) != fr;
+        if (!head) continue;
+        int32_t e = i + 1;
+        while (e < n && m[e].species_id == spc && mtb_q_frame(m[e].qinfo) == fr) e++;
+        if (e - i > 1) {      /* Taxonomer.cpp:342 */
+            int32_t md = (spc >= 0 && spc <= tx.max_taxid && tx.under_euk[spc]) ? sp.min_cons_cnt_euk : sp.min_cons_cnt;
+            mtb_sf_block_paths(m, i, e, path, flag, &sp, md);
+        }
+    }
+    __syncthreads();
+    /* phase 2: species blocks */
+    for (int32_t i = lane; i < n; i += 64) {
+        int32_t spc = m[i].species_id;
+        bool head = (i == 0) || m[i - 1].species_id != spc;
+        if (!head) continue;
+        int32_t e = i + 1;
+        while (e < n && m[e].species_id == spc) e++;
+        int32_t np = 0;
+        float sc = mtb_species_combine(m, i, e, path, flag, order, acc, read_len, &np);
+        if (np > 0) sps[i] = sc < 1.0f ? sc : 1.0f;        /* Taxonomer.cpp:356 */
+    }
+    __syncthreads();
+    /* phase 3: decision */
+    if (lane == 0) {
+        mtb_read_decide(m, n, sps, &tx, &sp, read_len, btax, bham, nb, otax, ocnt, (int32_t)tc_room, &R);
+        R.taxcnt_off = (uint32_t)tc_off;
+        for (int32_t k = 0; k < (int32_t)R.n_taxcnt; k++)
+            if (tc_off + k < tc_cap) { tc_tax[tc_off + k] = otax[k]; tc_cnt[tc_off + k] = ocnt[k]; }
+    }
+    __syncthreads();
+}
+
+/* SORT = true: segments arrive grouped by read but unordered (fused path): the
+ * wave sorts the staged segment in LDS first (compareMatches order) and, if
+ * sorted_out != NULL, writes it back.  Segments larger than MTB_SCORE_LDS must
+ * already be sorted in HBM (k_segsort_large).                               */
+template <bool SORT>
 __global__ __launch_bounds__(64) void k_score(const mtb_match *__restrict__ matches, const uint64_t *__restrict__ seg_start,
                                                uint64_t n_reads, const int32_t *__restrict__ qlen, const int32_t *__restrict__ qlen2,
                                                mtb_tax_view tx, mtb_score_params sp, const uint64_t *__restrict__ tc_off,
                                                mtb_result *__restrict__ results, int32_t *__restrict__ tc_tax,
                                                uint32_t *__restrict__ tc_cnt, uint64_t tc_cap, uint8_t *__restrict__ slabs,
-                                               uint64_t slab_bytes, uint32_t slab_max_n, uint32_t slab_max_nb) {
+                                               uint64_t slab_bytes, uint32_t slab_max_n, uint32_t slab_max_nb,
+                                               mtb_match *__restrict__ sorted_out) {
     __shared__ mtb_match s_m[MTB_SCORE_LDS];
     __shared__ mtb_path s_path[MTB_SCORE_LDS];
     __shared__ int32_t s_order[MTB_SCORE_LDS];
@@ -64,71 +145,31 @@ __global__ __launch_bounds__(64) void k_score(const mtb_match *__restrict__ matc
         R.is_classified = 0; R.reserved = 0; R.n_taxcnt = 0; R.taxcnt_off = 0;
         if (n == 0) { if (lane == 0) results[r] = R; continue; }
         const int32_t nb = mtb_num_buckets(read_len, sp.dna_shift);
-        /* storage: LDS for the common case, HBM slab for big segments */
-        mtb_match *m; mtb_path *path; int32_t *order, *acc; float *sps; uint8_t *flag;
-        int32_t *btax, *otax; uint32_t *ocnt; uint8_t *bham;
-        const bool big_n = n > MTB_SCORE_LDS, big_b = nb > MTB_SCORE_BKT;
-        uint8_t *slab = slabs + (uint64_t)blockIdx.x * slab_bytes;
-        if ((big_n && (uint32_t)n > slab_max_n) || (big_b && (uint32_t)nb > slab_max_nb)) {
-            /* cannot happen: slabs are sized from the measured maxima */
-            if (lane == 0) { R.reserved = 0xFF; results[r] = R; }
-            continue;
-        }
-        if (big_n) {
-            uint64_t N = slab_max_n;
-            m = (mtb_match *)slab; path = (mtb_path *)(m + N); order = (int32_t *)(path + N); acc = order + N;
-            sps = (float *)(acc + N); flag = (uint8_t *)(sps + N);
-        } else { m = s_m; path = s_path; order = s_order; acc = s_acc; sps = s_sps; flag = s_flag; }
-        if (big_b) {
-            uint64_t N = slab_max_n, B = slab_max_nb;
-            uint8_t *p = slab + N * (sizeof(mtb_match) + sizeof(mtb_path) + 12) + ((N + 7) & ~7ull);
-            btax = (int32_t *)p; otax = btax + B; ocnt = (uint32_t *)(otax + B); bham = (uint8_t *)(ocnt + B);
-        } else { btax = s_btax; otax = s_otax; ocnt = s_ocnt; bham = s_bham; }
-
-        {   /* stage the segment (24-byte records as 3 x u64, coalesced) */
-            const uint64_t *src = (const uint64_t *)(matches + s0);
-            uint64_t *dst = (uint64_t *)m;
-            for (int32_t i = lane; i < n * 3; i += 64) dst[i] = src[i];
-            for (int32_t i = lane; i < n; i += 64) { flag[i] = 0; sps[i] = -1.0f; }
-        }
-        __syncthreads();
-        /* phase 1: (species, frame) blocks */
-        for (int32_t i = lane; i < n; i += 64) {
-            int32_t spc = m[i].species_id; uint32_t fr = mtb_q_frame(m[i].qinfo);
-            bool head = (i == 0) || m[i - 1].species_id != spc || mtb_q_frame(m[i - 1].qinfo) != fr;
-            if (!head) continue;
-            int32_t e = i + 1;
-            while (e < n && m[e].species_id == spc && mtb_q_frame(m[e].qinfo) == fr) e++;
-            if (e - i > 1) {      /* Taxonomer.cpp:342 */
-                int32_t md = (spc >= 0 && spc <= tx.max_taxid && tx.under_euk[spc]) ? sp.min_cons_cnt_euk : sp.min_cons_cnt;
-                mtb_sf_block_paths(m, i, e, path, flag, &sp, md);
+        const bool big = n > MTB_SCORE_LDS || nb > MTB_SCORE_BKT;
+        const uint64_t off = tc_off[r], room = tc_off[r + 1] - off;
+        if (!big) {
+            score_read_body<SORT>(matches + s0, n, s_m, s_path, s_order, s_acc, s_sps, s_flag, s_btax, s_bham, s_otax, s_ocnt, nb,
+                                  read_len, tx, sp, off, room, tc_tax, tc_cnt, tc_cap, sorted_out ? sorted_out + s0 : nullptr, R);
+        } else {
+            if ((uint32_t)n > slab_max_n || (uint32_t)nb > slab_max_nb) {      /* cannot happen: slabs are sized from the maxima */
+                if (lane == 0) { R.reserved = 0xFF; results[r] = R; }
+                continue;
             }
+            uint8_t *slab = slabs + (uint64_t)blockIdx.x * slab_bytes;
+            uint64_t N = slab_max_n, B = slab_max_nb;
+            mtb_match *m = (mtb_match *)slab; mtb_path *path = (mtb_path *)(m + N); int32_t *order = (int32_t *)(path + N);
+            int32_t *acc = order + N; float *sps = (float *)(acc + N); uint8_t *flag = (uint8_t *)(sps + N);
+            uint8_t *p = slab + N * (sizeof(mtb_match) + sizeof(mtb_path) + 12) + ((N + 7) & ~7ull);
+            int32_t *btax = (int32_t *)p; int32_t *otax = btax + B; uint32_t *ocnt = (uint32_t *)(otax + B); uint8_t *bham = (uint8_t *)(ocnt + B);
+            /* big segments are pre-sorted in HBM; a small segment of a long read still needs its sort */
+            if (SORT && n <= MTB_SCORE_LDS)
+                score_read_body<true>(matches + s0, n, m, path, order, acc, sps, flag, btax, bham, otax, ocnt, nb, read_len, tx, sp,
+                                      off, room, tc_tax, tc_cnt, tc_cap, sorted_out ? sorted_out + s0 : nullptr, R);
+            else
+                score_read_body<false>(matches + s0, n, m, path, order, acc, sps, flag, btax, bham, otax, ocnt, nb, read_len, tx, sp,
+                                       off, room, tc_tax, tc_cnt, tc_cap, (mtb_match *)nullptr, R);
         }
-        __syncthreads();
-        /* phase 2: species blocks */
-        for (int32_t i = lane; i < n; i += 64) {
-            int32_t spc = m[i].species_id;
-            bool head = (i == 0) || m[i - 1].species_id != spc;
-            if (!head) continue;
-            int32_t e = i + 1;
-            while (e < n && m[e].species_id == spc) e++;
-            int32_t np = 0;
-            float sc = mtb_species_combine(m, i, e, path, flag, order, acc, read_len, &np);
-            if (np > 0) sps[i] = sc < 1.0f ? sc : 1.0f;        /* Taxonomer.cpp:356 */
-        }
-        __syncthreads();
-        /* phase 3: decision */
-        if (lane == 0) {
-            uint64_t off = tc_off[r];
-            uint64_t room = tc_off[r + 1] - off;
-            mtb_read_decide(m, n, sps, &tx, &sp, read_len, btax, bham, nb, otax, ocnt, (int32_t)room, &R);
-            R.query_length = ql1; R.query_length2 = ql2; R.reserved = 0;
-            R.taxcnt_off = (uint32_t)off;
-            for (int32_t k = 0; k < (int32_t)R.n_taxcnt; k++)
-                if (off + k < tc_cap) { tc_tax[off + k] = otax[k]; tc_cnt[off + k] = ocnt[k]; }
-            results[r] = R;
-        }
-        __syncthreads();
+        if (lane == 0) { R.query_length = ql1; R.query_length2 = ql2; R.reserved = 0; results[r] = R; }
     }
 }
 

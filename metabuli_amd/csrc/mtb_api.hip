@@ -289,7 +289,8 @@ static mtb_status dev_segsort(mtb_ctx *c, mtb_match *d_m, const uint64_t *d_seg,
 /* d_results/d_tc_* are device outputs; *n_tc = sum of per-read bounds */
 static mtb_status dev_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, const mtb_match *d_m, const uint64_t *d_seg,
                             uint64_t n_reads, const int32_t *d_qlen, const int32_t *d_qlen2, uint32_t max_seg, uint32_t max_len,
-                            mtb_result *d_res, int32_t *d_tc_tax, uint32_t *d_tc_cnt, uint64_t tc_cap, uint64_t *n_tc) {
+                            mtb_result *d_res, int32_t *d_tc_tax, uint32_t *d_tc_cnt, uint64_t tc_cap, uint64_t *n_tc,
+                            bool fused_sort = false) {
     if (p->accession_level == 2) return fail(MTB_ERR_UNSUPPORTED, "accession_level 2 (Taxonomer.cpp:256-267) is not implemented");
     mtb_score_params sp; mtb_make_score_params(p, &sp);
     uint32_t *d_bound; uint64_t *d_tcoff; uint64_t *d_ws;
@@ -315,8 +316,12 @@ static mtb_status dev_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, cons
         STCHK(ensure(c, "slabs", (size_t)grid * slab_bytes, &d_slabs));
     }
     { KTimer kt(c, MTB_K_SCORE);
-    hipLaunchKernelGGL(k_score, dim3(grid), dim3(64), 0, c->stream, d_m, d_seg, n_reads, d_qlen, d_qlen2, tax_view(ix), sp,
-                       (const uint64_t *)d_tcoff, d_res, d_tc_tax, d_tc_cnt, tc_cap, d_slabs, slab_bytes, slab_n, slab_nb); }
+    if (fused_sort)
+        hipLaunchKernelGGL((k_score<true>), dim3(grid), dim3(64), 0, c->stream, d_m, d_seg, n_reads, d_qlen, d_qlen2, tax_view(ix), sp,
+                           (const uint64_t *)d_tcoff, d_res, d_tc_tax, d_tc_cnt, tc_cap, d_slabs, slab_bytes, slab_n, slab_nb, (mtb_match *)nullptr);
+    else
+        hipLaunchKernelGGL((k_score<false>), dim3(grid), dim3(64), 0, c->stream, d_m, d_seg, n_reads, d_qlen, d_qlen2, tax_view(ix), sp,
+                           (const uint64_t *)d_tcoff, d_res, d_tc_tax, d_tc_cnt, tc_cap, d_slabs, slab_bytes, slab_n, slab_nb, (mtb_match *)nullptr); }
     HIPCHK(hipGetLastError());
     return MTB_OK;
 }
@@ -600,10 +605,23 @@ mtb_status mtb_classify_batch_device(mtb_ctx *c, mtb_index *ix, const mtb_params
     STCHK(ensure(c, "matches", nm, &d_m));
     STCHK(dev_regroup(c, d_tmp, nm, n_reads, d_rc, &d_seg, d_m));
     HIPCHK(hipEventRecord(c->ev[4], st));
+    /* segments that fit LDS are sorted inside k_score; only the big ones are sorted in HBM here */
     uint32_t max_seg = 0;
-    STCHK(dev_segsort(c, d_m, d_seg, n_reads, &max_seg));
+    {
+        uint32_t *d_large;
+        STCHK(ensure(c, "large", n_reads, &d_large));
+        HIPCHK(hipMemsetAsync(c->d_scal + 2, 0, 16, st));
+        { KTimer kt(c, MTB_K_SEGSORT);
+        hipLaunchKernelGGL(k_list_large, dim3((uint32_t)((n_reads + 255) / 256)), dim3(256), 0, st, (const uint64_t *)d_seg, n_reads,
+                           (uint32_t)MTB_SCORE_LDS, d_large, (uint32_t *)(c->d_scal + 2), (uint32_t *)(c->d_scal + 3));
+        hipLaunchKernelGGL(k_segsort_large, dim3(1024), dim3(256), 0, st, d_m, (const uint64_t *)d_seg, (const uint32_t *)d_large,
+                           (const uint32_t *)(c->d_scal + 2)); }
+        uint64_t sc[2];
+        STCHK(d2h(c, sc, c->d_scal + 2, 16));
+        max_seg = (uint32_t)sc[1];
+    }
     HIPCHK(hipEventRecord(c->ev[5], st));
-    STCHK(dev_score(c, ix, p, d_m, d_seg, n_reads, d_ql, d_ql2, max_seg, max_len, d_results, d_taxcnt_tax, d_taxcnt_cnt, taxcnt_cap, n_taxcnt));
+    STCHK(dev_score(c, ix, p, d_m, d_seg, n_reads, d_ql, d_ql2, max_seg, max_len, d_results, d_taxcnt_tax, d_taxcnt_cnt, taxcnt_cap, n_taxcnt, true));
     HIPCHK(hipEventRecord(c->ev[6], st));
     HIPCHK(hipEventSynchronize(c->ev[6]));
     mtb_batch_stats &S = c->stats;
