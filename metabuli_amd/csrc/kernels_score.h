@@ -18,6 +18,17 @@
 #include "mtb_core.h"
 #include "kernels_join.h"
 
+/* profiling build only (-DMTB_SCORE_PHASE_CYCLES): cycles per phase of k_score,
+ * accumulated into mtb_phase_cycles[4] = {stage+sort, paths, combine, decide} */
+#ifdef MTB_SCORE_PHASE_CYCLES
+__device__ unsigned long long mtb_phase_cycles[4];
+#define MTB_PHASE_BEGIN() unsigned long long ph_t0_ = __builtin_readcyclecounter()
+#define MTB_PHASE_MARK(k) do { unsigned long long t_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&mtb_phase_cycles[k], t_ - ph_t0_); ph_t0_ = t_; } while (0)
+#else
+#define MTB_PHASE_BEGIN() do {} while (0)
+#define MTB_PHASE_MARK(k) do {} while (0)
+#endif
+
 #define MTB_SCORE_LDS 192        /* matches per read staged in LDS            */
 #define MTB_SCORE_BKT 128        /* position buckets / taxCnt entries in LDS  */
 
@@ -62,6 +73,7 @@ __device__ __forceinline__ void score_read_body(const mtb_match *__restrict__ sr
                                                 int32_t *__restrict__ tc_tax, uint32_t *__restrict__ tc_cnt, uint64_t tc_cap,
                                                 mtb_match *__restrict__ sorted_out, mtb_result &R) {
     const int32_t lane = (int32_t)threadIdx.x;
+    MTB_PHASE_BEGIN();
     if ((const mtb_match *)m != src) {        /* stage the segment (24-byte records as 3 x u64, coalesced) */
         const uint64_t *s64 = (const uint64_t *)src;
         uint64_t *d64 = (uint64_t *)m;
@@ -77,6 +89,7 @@ __device__ __forceinline__ void score_read_body(const mtb_match *__restrict__ sr
             for (int32_t i = lane; i < n * 3; i += 64) d64[i] = s64[i];
         }
     }
+    MTB_PHASE_MARK(0);
     /* phase 1: (species, frame) blocks */
     for (int32_t i = lane; i < n; i += 64) {
         int32_t spc = m[i].species_id; uint32_t fr = mtb_q_frame(m[i].qinfo);
@@ -90,6 +103,7 @@ __device__ __forceinline__ void score_read_body(const mtb_match *__restrict__ sr
         }
     }
     __syncthreads();
+    MTB_PHASE_MARK(1);
     /* phase 2: species blocks */
     for (int32_t i = lane; i < n; i += 64) {
         int32_t spc = m[i].species_id;
@@ -102,14 +116,30 @@ __device__ __forceinline__ void score_read_body(const mtb_match *__restrict__ sr
         if (np > 0) sps[i] = sc < 1.0f ? sc : 1.0f;        /* Taxonomer.cpp:356 */
     }
     __syncthreads();
-    /* phase 3: decision */
-    if (lane == 0) {
-        mtb_read_decide(m, n, sps, &tx, &sp, read_len, btax, bham, nb, otax, ocnt, (int32_t)tc_room, &R);
-        R.taxcnt_off = (uint32_t)tc_off;
-        for (int32_t k = 0; k < (int32_t)R.n_taxcnt; k++)
-            if (tc_off + k < tc_cap) { tc_tax[tc_off + k] = otax[k]; tc_cnt[tc_off + k] = ocnt[k]; }
+    MTB_PHASE_MARK(2);
+    /* phase 3: decision.  Lane 0 picks the species; the redundancy filter runs
+     * one lane per position bucket (their LCA chains are independent). */
+    int32_t bs = 0, be = 0, species = 0, go = 0;
+    if (lane == 0) go = mtb_read_select(m, n, sps, &tx, &sp, &R, &bs, &be, &species) ? 1 : 0;
+    go = __shfl(go, 0, 64);
+    if (go) {
+        bs = __shfl(bs, 0, 64); be = __shfl(be, 0, 64);
+        for (int32_t q = lane; q < nb; q += 64) {
+            int32_t t;
+            bool used = mtb_filter_bucket(m, bs, be, &tx, sp.dna_shift, q, &t);
+            btax[q] = t; bham[q] = used ? 0 : 255;
+        }
+        __syncthreads();
+        if (lane == 0) {
+            int32_t ntc = mtb_taxcnt_gather(btax, bham, nb, otax, ocnt, (int32_t)tc_room);
+            mtb_read_finish(&tx, &sp, species, read_len, otax, ocnt, ntc, &R);
+            R.taxcnt_off = (uint32_t)tc_off;
+            for (int32_t k = 0; k < ntc; k++)
+                if (tc_off + k < tc_cap) { tc_tax[tc_off + k] = otax[k]; tc_cnt[tc_off + k] = ocnt[k]; }
+        }
     }
     __syncthreads();
+    MTB_PHASE_MARK(3);
 }
 
 /* SORT = true: segments arrive grouped by read but unordered (fused path): the

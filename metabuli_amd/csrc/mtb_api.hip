@@ -305,10 +305,12 @@ static mtb_status dev_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, cons
     *n_tc = tot;
     if (tot > tc_cap) return fail(MTB_ERR_CAPACITY, "taxcnt buffers too small");
     uint32_t grid = (uint32_t)std::min<uint64_t>(n_reads, 256ull * 12);
-    uint32_t slab_n = max_seg > MTB_SCORE_LDS ? max_seg : 0;
+    /* reads with a big segment OR many position buckets are scored entirely out of a slab */
     uint32_t max_nb = (uint32_t)mtb_num_buckets((int32_t)max_len, sp.dna_shift);
-    uint32_t slab_nb = max_nb > MTB_SCORE_BKT ? max_nb : 0;
-    uint64_t slab_bytes = (slab_n || slab_nb) ? score_slab_bytes(slab_n, slab_nb) : 0;
+    bool need_slab = max_seg > MTB_SCORE_LDS || max_nb > MTB_SCORE_BKT;
+    uint32_t slab_n = need_slab ? std::max<uint32_t>(max_seg, 1) : 0;
+    uint32_t slab_nb = need_slab ? max_nb : 0;
+    uint64_t slab_bytes = need_slab ? score_slab_bytes(slab_n, slab_nb) : 0;
     uint8_t *d_slabs = nullptr;
     if (slab_bytes) {
         /* keep the slab pool below 8 GiB by shrinking the grid */
@@ -654,6 +656,17 @@ mtb_status mtb_classify_batch(mtb_ctx *c, mtb_index *ix, const mtb_params *p, co
     if (*n_taxcnt) { STCHK(d2h(c, taxcnt_tax, d_tt, *n_taxcnt * 4)); STCHK(d2h(c, taxcnt_cnt, d_tc, *n_taxcnt * 4)); }
     return MTB_OK;
 }
+
+#ifdef MTB_SCORE_PHASE_CYCLES
+/* profiling build only: read and reset the k_score phase cycle counters */
+mtb_status mtb_debug_phase_cycles(mtb_ctx *c, unsigned long long *out4) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpyFromSymbol(out4, HIP_SYMBOL(mtb_phase_cycles), 32));
+    unsigned long long z[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(mtb_phase_cycles), z, 32));
+    return MTB_OK;
+}
+#endif
 
 mtb_status mtb_last_batch_stats(mtb_ctx *c, mtb_batch_stats *out) {
     if (!c || !out) return fail(MTB_ERR_ARG, "NULL argument");

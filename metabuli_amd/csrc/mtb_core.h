@@ -312,10 +312,12 @@ MTB_HD int32_t mtb_tax_canon(const mtb_tax_view *t, int32_t x) { return (x >= 0 
 MTB_HD bool mtb_tax_exists(const mtb_tax_view *t, int32_t x) { return mtb_tax_canon(t, x) >= 0; }
 /* NcbiTaxonomy::LCA(a,b): a missing node yields the other one */
 MTB_HD int32_t mtb_lca(const mtb_tax_view *t, int32_t a, int32_t b) {
+    if (a == b) { int32_t c = mtb_tax_canon(t, a); return c < 0 ? a : c; }
     int32_t ca = mtb_tax_canon(t, a), cb = mtb_tax_canon(t, b);
     if (ca < 0) return b;
     if (cb < 0) return a;
     a = ca; b = cb;
+    if (a == b) return a;
     int32_t da = t->depth[a], db = t->depth[b];
     while (da > db) { a = t->parent[a]; da--; }
     while (db > da) { b = t->parent[b]; db--; }
@@ -464,17 +466,25 @@ MTB_HD float mtb_species_combine(const mtb_match *m, int32_t s, int32_t e, mtb_p
  * species block m[s..e).  b_tax/b_ham are bucket arrays of n_buckets entries
  * (pos / dna_shift); out_tax/out_cnt receive Query::taxCnt in ascending taxid
  * order (std::map).  Returns the number of entries (<= out_cap written).    */
-MTB_HD int32_t mtb_filter_redundant(const mtb_match *m, int32_t s, int32_t e, const mtb_tax_view *tx,
-                                    int32_t dna_shift, int32_t *b_tax, uint8_t *b_ham, int32_t n_buckets,
-                                    int32_t *out_tax, uint32_t *out_cnt, int32_t out_cap) {
-    for (int32_t q = 0; q < n_buckets; q++) { b_tax[q] = 0; b_ham[q] = 255; }
+/* one bucket q of filterRedundantMatches: the bucket's taxon is the LCA of the
+ * target ids of its minimum-Hamming matches (the reference's replace / LCA-merge
+ * chain in match order gives exactly that).  Returns false if the bucket is empty. */
+MTB_HD bool mtb_filter_bucket(const mtb_match *m, int32_t s, int32_t e, const mtb_tax_view *tx, int32_t dna_shift,
+                              int32_t q, int32_t *tax_out) {
+    int32_t tax = 0; uint32_t ham = 255;
     for (int32_t i = s; i < e; i++) {
-        int32_t q = (int32_t)(mtb_q_pos(m[i].qinfo) / (uint32_t)dna_shift);
-        if (q >= n_buckets) continue;            /* cannot happen: see mtb_num_buckets */
-        uint8_t h = m[i].hamming;
-        if (b_ham[q] == 255 || h < b_ham[q]) { b_tax[q] = m[i].target_id; b_ham[q] = h; }
-        else if (h == b_ham[q]) b_tax[q] = mtb_lca(tx, b_tax[q], m[i].target_id);
+        if ((int32_t)(mtb_q_pos(m[i].qinfo) / (uint32_t)dna_shift) != q) continue;
+        uint32_t h = m[i].hamming;
+        if (ham == 255 || h < ham) { tax = m[i].target_id; ham = h; }
+        else if (h == ham) tax = mtb_lca(tx, tax, m[i].target_id);
     }
+    *tax_out = tax;
+    return ham != 255;
+}
+/* bucket taxa (b_ham[q] != 255 marks a used bucket) -> Query::taxCnt in
+ * ascending taxid order (std::map).  Returns the number of entries.        */
+MTB_HD int32_t mtb_taxcnt_gather(const int32_t *b_tax, const uint8_t *b_ham, int32_t n_buckets,
+                                 int32_t *out_tax, uint32_t *out_cnt, int32_t out_cap) {
     int32_t n = 0;
     for (int32_t q = 0; q < n_buckets; q++) {
         if (b_ham[q] == 255) continue;
@@ -488,6 +498,16 @@ MTB_HD int32_t mtb_filter_redundant(const mtb_match *m, int32_t s, int32_t e, co
         }
     }
     return n;
+}
+MTB_HD int32_t mtb_filter_redundant(const mtb_match *m, int32_t s, int32_t e, const mtb_tax_view *tx,
+                                    int32_t dna_shift, int32_t *b_tax, uint8_t *b_ham, int32_t n_buckets,
+                                    int32_t *out_tax, uint32_t *out_cnt, int32_t out_cap) {
+    for (int32_t q = 0; q < n_buckets; q++) {
+        int32_t t;
+        bool used = mtb_filter_bucket(m, s, e, tx, dna_shift, q, &t);
+        b_tax[q] = t; b_ham[q] = used ? 0 : 255;
+    }
+    return mtb_taxcnt_gather(b_tax, b_ham, n_buckets, out_tax, out_cnt, out_cap);
 }
 /* bucket count that covers every position of a read (Taxonomer.cpp:210) */
 MTB_HD int32_t mtb_num_buckets(int32_t read_len, int32_t dna_shift) { return (read_len + 3) / dna_shift + 2; }
@@ -540,14 +560,13 @@ MTB_HD int32_t mtb_lower_rank(const mtb_tax_view *tx, const int32_t *tc_tax, con
 }
 
 /* Second half of Taxonomer::getBestSpeciesMatches (Taxonomer.cpp:354-407) and
- * Taxonomer::chooseBestTaxon (Taxonomer.cpp:130-202) for one read.  sps[s]
- * holds, at the first slot s of every species block, min(combine(),1) or
- * -1 if the species produced no path.  Scratch: bucket arrays (n_buckets),
- * out_tax/out_cnt (out_cap) receive Query::taxCnt.                           */
-MTB_HD void mtb_read_decide(const mtb_match *m, int32_t n, const float *sps, const mtb_tax_view *tx,
-                            const mtb_score_params *sp, int32_t read_len, int32_t *b_tax, uint8_t *b_ham,
-                            int32_t n_buckets, int32_t *out_tax, uint32_t *out_cnt, int32_t out_cap,
-                            mtb_result *R) {
+ * the early exits of Taxonomer::chooseBestTaxon (Taxonomer.cpp:130-165) for one
+ * read.  sps[s] holds, at the first slot s of every species block,
+ * min(combine(),1) or -1 if the species produced no path.  Returns true when
+ * a single best species was chosen (then best_s..best_e bound its matches and
+ * *species is its id) and the redundancy filter / sub-species descent must run. */
+MTB_HD bool mtb_read_select(const mtb_match *m, int32_t n, const float *sps, const mtb_tax_view *tx,
+                            const mtb_score_params *sp, mtb_result *R, int32_t *best_s_out, int32_t *best_e_out, int32_t *species) {
     R->classification = 0; R->score = 0.0f; R->is_classified = 0; R->n_taxcnt = 0;
     float best_sp = 0.0f; int32_t best_s = 0, best_e = 0; int32_t meaningful = 0;
     int32_t i = 0;
@@ -560,9 +579,9 @@ MTB_HD void mtb_read_decide(const mtb_match *m, int32_t n, const float *sps, con
         if (sc > 0.0f) meaningful++;
         if (sc > best_sp) { best_sp = sc; best_s = s; best_e = i; }
     }
-    if (meaningful == 0) return;                   /* score 0, unclassified (:372-375)  */
+    if (meaningful == 0) return false;             /* score 0, unclassified (:372-375)  */
     /* ties within tie_ratio (:388-402); LCA(vector) skips unknown ids */
-    float sum = 0.0f; int32_t n_max = 0; int32_t lca = -1; int32_t only = 0;
+    float sum = 0.0f; int32_t n_max = 0; int32_t lca = -1; int32_t only = 0, first_spc = 0;
     float cut = best_sp * sp->tie_ratio;
     i = 0;
     while (i < n) {
@@ -572,21 +591,39 @@ MTB_HD void mtb_read_decide(const mtb_match *m, int32_t n, const float *sps, con
         if (sc == -1.0f || sc < sp->min_score) continue;
         if (sc >= cut) {
             sum += sc; only = spc; n_max++;
-            if (mtb_tax_exists(tx, spc)) lca = lca < 0 ? mtb_tax_canon(tx, spc) : mtb_lca(tx, lca, spc);
+            if (n_max == 1) first_spc = spc;       /* the LCA is only needed for ties */
+            else {
+                if (n_max == 2) lca = mtb_tax_exists(tx, first_spc) ? mtb_tax_canon(tx, first_spc) : -1;
+                if (mtb_tax_exists(tx, spc)) lca = lca < 0 ? mtb_tax_canon(tx, spc) : mtb_lca(tx, lca, spc);
+            }
         }
     }
     float score = n_max > 1 ? sum / (float)n_max : sum;
     R->score = score;
-    if (score == 0.0f || score < sp->min_score) return;          /* :149-156 */
-    if (n_max > 1) { R->is_classified = 1; R->classification = lca < 0 ? 0 : lca; return; }   /* :159-165 */
-    int32_t ntc = mtb_filter_redundant(m, best_s, best_e, tx, sp->dna_shift, b_tax, b_ham, n_buckets, out_tax, out_cnt, out_cap);
-    R->n_taxcnt = (uint16_t)ntc;
+    if (score == 0.0f || score < sp->min_score) return false;    /* :149-156 */
+    if (n_max > 1) { R->is_classified = 1; R->classification = lca < 0 ? 0 : lca; return false; }   /* :159-165 */
+    *best_s_out = best_s; *best_e_out = best_e; *species = only;
     R->is_classified = 1;
-    if (score < sp->min_sp_score) {                                /* :178-185 */
-        R->classification = (only >= 0 && only <= tx->max_taxid) ? tx->sp_parent[only] : 0;
+    return true;
+}
+/* after the redundancy filter: Taxonomer.cpp:178-198 */
+MTB_HD void mtb_read_finish(const mtb_tax_view *tx, const mtb_score_params *sp, int32_t species, int32_t read_len,
+                            const int32_t *out_tax, const uint32_t *out_cnt, int32_t ntc, mtb_result *R) {
+    R->n_taxcnt = (uint16_t)ntc;
+    if (R->score < sp->min_sp_score) {
+        R->classification = (species >= 0 && species <= tx->max_taxid) ? tx->sp_parent[species] : 0;
         return;
     }
-    R->classification = mtb_lower_rank(tx, out_tax, out_cnt, ntc, only, read_len, sp->denominator);
+    R->classification = mtb_lower_rank(tx, out_tax, out_cnt, ntc, species, read_len, sp->denominator);
+}
+MTB_HD void mtb_read_decide(const mtb_match *m, int32_t n, const float *sps, const mtb_tax_view *tx,
+                            const mtb_score_params *sp, int32_t read_len, int32_t *b_tax, uint8_t *b_ham,
+                            int32_t n_buckets, int32_t *out_tax, uint32_t *out_cnt, int32_t out_cap,
+                            mtb_result *R) {
+    int32_t bs, be, species;
+    if (!mtb_read_select(m, n, sps, tx, sp, R, &bs, &be, &species)) return;
+    int32_t ntc = mtb_filter_redundant(m, bs, be, tx, sp->dna_shift, b_tax, b_ham, n_buckets, out_tax, out_cnt, out_cap);
+    mtb_read_finish(tx, sp, species, read_len, out_tax, out_cnt, ntc, R);
 }
 
 #endif /* MTB_CORE_H */
