@@ -1,0 +1,28 @@
+# profiling-build driver: k_score phase cycles on the small bench workload
+import os, sys, ctypes as C, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np, torch
+import bench, metabuli_amd as M
+dev = torch.device('cuda', 0)
+ctx = M.Context(0)
+params = M.default_params(seq_mode=1, syncmer=1, smer_len=5)
+import tempfile
+world = bench.build_world(1234, 8, 500000, 5000)
+taxdir = tempfile.mkdtemp(); world.tax.write(taxdir)
+rv, rt = bench.extract_targets(ctx, M, world, params)
+nf = int(2e8); Tc = nf + len(rv)
+dv = torch.empty(Tc, dtype=torch.int64, device=dev); di = torch.empty(Tc, dtype=torch.int32, device=dev)
+T = ctx.synth_index(1234, nf, world.filler_tax_lo, world.filler_tax_hi, rv, rt, dv.data_ptr(), di.data_ptr())
+tl = np.concatenate([np.unique(rt), np.arange(world.filler_tax_lo, world.filler_tax_hi + 1, dtype=np.int32)])
+ix = ctx.index_from_device(dv.data_ptr(), di.data_ptr(), T, taxdir, tl, params)
+N = 500000
+db, do = bench.gen_reads(torch, dev, world, N, 150, 0.10, 0.005, 99)
+dres = torch.empty(N * 24, dtype=torch.uint8, device=dev); cap = N * 20 + 1024
+dtt = torch.empty(cap, dtype=torch.int32, device=dev); dtc = torch.empty(cap, dtype=torch.int32, device=dev)
+out = (C.c_ulonglong * 4)()
+for it in range(2):
+    ctx.classify_batch_device(ix, params, db.data_ptr(), do.data_ptr(), 0, 0, N, N * 150, dres.data_ptr(), dtt.data_ptr(), dtc.data_ptr(), cap)
+    M.lib().mtb_debug_phase_cycles(ctx.h, out)
+st = ctx.last_stats()
+tot = sum(out)
+print("score ms", st.ms_score, "phase cycles/read [stage+sort, paths, combine, decide]:", [int(x / N) for x in out], "total/read", int(tot / N))
