@@ -225,6 +225,8 @@ def main():
     # sanity of the timed output: fraction of reads classified
     res = np.frombuffer(d_res.cpu().numpy().tobytes(), dtype=M.result_dt)
     frac_cls = float((res["is_classified"] != 0).mean())
+    if frac_cls < 0.5:   # 90 % of the reads come from genomes that are in the index
+        raise SystemExit(f"sanity check failed: only {frac_cls:.4f} of the reads were classified")
 
     cpu = None
     if rank == 0 and not args.no_cpu and world_size == 1:

@@ -119,26 +119,32 @@ __global__ void k_synth_real_pos(FillerParams P, const uint64_t *__restrict__ rv
     pos[j] = j + lo;
 }
 
+/* grid-stride over 256-entry chunks: an AQL dispatch holds at most 2^32-1
+ * work-items, fewer than the entries of a GTDB-scale index */
 __global__ __launch_bounds__(256) void k_synth_fill(FillerParams P, const uint64_t *__restrict__ rv, uint64_t n_real,
                                                      uint64_t *__restrict__ values, uint32_t *__restrict__ info) {
     __shared__ uint64_t s_r0;
-    uint64_t i0 = (uint64_t)blockIdx.x * 256;
-    if (threadIdx.x == 0) {
-        uint64_t fv; int32_t ft;
-        filler_entry(P, i0, &fv, &ft);
-        uint64_t lo = 0, hi = n_real;           /* reals with value <= fv */
-        while (lo < hi) { uint64_t mid = lo + ((hi - lo) >> 1); if (rv[mid] <= fv) lo = mid + 1; else hi = mid; }
-        s_r0 = lo;
+    const uint64_t chunks = (P.n_filler + 255) / 256;
+    for (uint64_t ch = blockIdx.x; ch < chunks; ch += gridDim.x) {
+        uint64_t i0 = ch * 256;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t fv; int32_t ft;
+            filler_entry(P, i0, &fv, &ft);
+            uint64_t lo = 0, hi = n_real;           /* reals with value <= fv */
+            while (lo < hi) { uint64_t mid = lo + ((hi - lo) >> 1); if (rv[mid] <= fv) lo = mid + 1; else hi = mid; }
+            s_r0 = lo;
+        }
+        __syncthreads();
+        uint64_t i = i0 + threadIdx.x;
+        if (i >= P.n_filler) continue;
+        uint64_t v; int32_t t;
+        filler_entry(P, i, &v, &t);
+        uint64_t r = s_r0;
+        while (r < n_real && rv[r] <= v) r++;
+        values[i + r] = v;
+        info[i + r] = (uint32_t)t;
     }
-    __syncthreads();
-    uint64_t i = i0 + threadIdx.x;
-    if (i >= P.n_filler) return;
-    uint64_t v; int32_t t;
-    filler_entry(P, i, &v, &t);
-    uint64_t r = s_r0;
-    while (r < n_real && rv[r] <= v) r++;
-    values[i + r] = v;
-    info[i + r] = (uint32_t)t;
 }
 
 __global__ void k_synth_place_real(const uint64_t *__restrict__ rv, const int32_t *__restrict__ rt, const uint64_t *__restrict__ pos,

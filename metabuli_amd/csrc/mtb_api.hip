@@ -252,6 +252,7 @@ static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint6
     uint64_t sc[2];
     STCHK(d2h(c, sc, c->d_scal, 16));
     *count = sc[0];
+    if (sc[0] >= (1ull << 32)) return fail(MTB_ERR_ARG, "more than 2^32-1 matches in one batch; split the batch");
     if (sc[0] > cap) return fail(MTB_ERR_CAPACITY, "match buffer too small");
     return MTB_OK;
 }
@@ -705,7 +706,7 @@ mtb_status mtb_synth_index(mtb_ctx *c, uint64_t seed, uint64_t n_filler, int32_t
         STCHK(h2d(c, d_rv, real_values, n_real * 8)); STCHK(h2d(c, d_rt, real_taxids, n_real * 4));
         hipLaunchKernelGGL(k_synth_real_pos, dim3((uint32_t)((n_real + 255) / 256)), dim3(256), 0, c->stream, P, (const uint64_t *)d_rv, n_real, d_pos);
     }
-    if (n_filler) hipLaunchKernelGGL(k_synth_fill, dim3((uint32_t)((n_filler + 255) / 256)), dim3(256), 0, c->stream, P, (const uint64_t *)d_rv, n_real, d_values, d_info);
+    if (n_filler) hipLaunchKernelGGL(k_synth_fill, dim3((uint32_t)std::min<uint64_t>((n_filler + 255) / 256, 1ull << 20)), dim3(256), 0, c->stream, P, (const uint64_t *)d_rv, n_real, d_values, d_info);
     if (n_real) hipLaunchKernelGGL(k_synth_place_real, dim3((uint32_t)((n_real + 255) / 256)), dim3(256), 0, c->stream, (const uint64_t *)d_rv,
                                    (const int32_t *)d_rt, (const uint64_t *)d_pos, n_real, d_values, d_info);
     HIPCHK(hipGetLastError());
