@@ -17,6 +17,7 @@
 #include "dev_util.h"
 #include "mtb_core.h"
 #include "kernels_join.h"
+#include "mtb_score_par.h"
 
 /* profiling build only (-DMTB_SCORE_PHASE_CYCLES): cycles per phase of k_score,
  * accumulated into mtb_phase_cycles[4] = {stage+sort, paths, combine, decide} */
@@ -34,8 +35,8 @@ __device__ unsigned long long mtb_phase_cycles[4];
 
 /* bytes of slab one workgroup needs for a segment of n matches, nb buckets */
 __host__ __device__ __forceinline__ uint64_t score_slab_bytes(uint64_t n, uint64_t nb) {
-    uint64_t b = n * (sizeof(mtb_match) + sizeof(mtb_path) + 4 + 4 + 4) + ((n + 7) & ~7ull);   /* m, path, order, acc, sps, flag */
-    b += nb * (4 + 4 + 4) + ((nb + 7) & ~7ull);                                                /* b_tax, o_tax, o_cnt, b_ham   */
+    uint64_t b = mtb_sws_bytes<uint32_t>(n);
+    b += nb * 12 + (MTB_LR_MAXE + MTB_LR_MAXE * MTB_LR_K) * 4 + ((nb + 15) & ~15ull);   /* btax, otax, ocnt, lev, anc, bham */
     return (b + 63) & ~63ull;
 }
 
@@ -63,76 +64,147 @@ __global__ __launch_bounds__(256) void k_list_large(const uint64_t *__restrict__
     if ((threadIdx.x & 63) == 0 && n > threshold) atomicMax(max_seg, n);
 }
 
-/* One read, all storage in ONE address space per call site (LDS or HBM slab)
- * so that the compiler emits ds_* / global_* instead of flat accesses.       */
-template <bool SORT>
-__device__ __forceinline__ void score_read_body(const mtb_match *__restrict__ src, int32_t n, mtb_match *m, mtb_path *path,
-                                                int32_t *order, int32_t *acc, float *sps, uint8_t *flag, int32_t *btax,
-                                                uint8_t *bham, int32_t *otax, uint32_t *ocnt, int32_t nb, int32_t read_len,
-                                                const mtb_tax_view &tx, const mtb_score_params &sp, uint64_t tc_off, uint64_t tc_room,
-                                                int32_t *__restrict__ tc_tax, uint32_t *__restrict__ tc_cnt, uint64_t tc_cap,
-                                                mtb_match *__restrict__ sorted_out, mtb_result &R) {
+/* One read, data-parallel (phases of mtb_score_par.h).  All storage of a call
+ * site lives in ONE address space (LDS or an HBM slab) so that the compiler
+ * emits ds_* / global_* instead of flat accesses.  SORT: the segment arrives
+ * unordered and holds at most 64*MAXPER matches: rank sort on 12-byte keys. */
+#define MTB_SCORE_MAXPER 3
+template <typename IDX, bool SORT>
+__device__ __forceinline__ void score_read_par(const mtb_match *__restrict__ src, int32_t n, mtb_sws<IDX> w, int32_t *btax,
+                                               uint8_t *bham, int32_t *otax, uint32_t *ocnt, int32_t *lr_lev, int32_t *lr_anc,
+                                               int32_t nb, int32_t read_len, const mtb_tax_view &tx, const mtb_score_params &sp,
+                                               uint64_t tc_off, uint64_t tc_room, int32_t *__restrict__ tc_tax,
+                                               uint32_t *__restrict__ tc_cnt, uint64_t tc_cap, mtb_match *__restrict__ sorted_out,
+                                               mtb_result &R) {
     const int32_t lane = (int32_t)threadIdx.x;
+    const uint64_t lt = lanemask_lt();
+    w.n = n;
     MTB_PHASE_BEGIN();
-    if ((const mtb_match *)m != src) {        /* stage the segment (24-byte records as 3 x u64, coalesced) */
-        const uint64_t *s64 = (const uint64_t *)src;
-        uint64_t *d64 = (uint64_t *)m;
-        for (int32_t i = lane; i < n * 3; i += 64) d64[i] = s64[i];
-    }
-    for (int32_t i = lane; i < n; i += 64) { flag[i] = 0; sps[i] = -1.0f; }
-    __syncthreads();
     if (SORT) {
-        seg_bitonic<64>(m, (uint32_t)n, (uint32_t)lane);
+        /* rank sort: keys in the (not yet live) path area, records in registers */
+        uint64_t *k1 = (uint64_t *)w.path; uint32_t *k2 = (uint32_t *)(k1 + n);
+        mtb_match rec[MTB_SCORE_MAXPER]; uint64_t a1[MTB_SCORE_MAXPER]; uint32_t a2[MTB_SCORE_MAXPER]; int32_t rank[MTB_SCORE_MAXPER];
+#pragma unroll
+        for (int k = 0; k < MTB_SCORE_MAXPER; k++) {
+            int32_t i = lane + 64 * k;
+            rank[k] = 0; a1[k] = 0; a2[k] = 0;
+            if (i < n) { rec[k] = src[i]; a1[k] = mtb_key1(rec[k]); a2[k] = mtb_key2(rec[k]); k1[i] = a1[k]; k2[i] = a2[k]; }
+        }
+        __syncthreads();
+        for (int32_t j = 0; j < n; j++) {
+            uint64_t b1 = k1[j]; uint32_t b2 = k2[j];
+#pragma unroll
+            for (int k = 0; k < MTB_SCORE_MAXPER; k++) {
+                int32_t i = lane + 64 * k;
+                rank[k] += (b1 < a1[k]) || (b1 == a1[k] && (b2 < a2[k] || (b2 == a2[k] && j < i)));
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < MTB_SCORE_MAXPER; k++) { int32_t i = lane + 64 * k; if (i < n) w.m[rank[k]] = rec[k]; }
+        __syncthreads();
         if (sorted_out) {
-            const uint64_t *s64 = (const uint64_t *)m;
-            uint64_t *d64 = (uint64_t *)sorted_out;
+            const uint64_t *s64 = (const uint64_t *)w.m; uint64_t *d64 = (uint64_t *)sorted_out;
             for (int32_t i = lane; i < n * 3; i += 64) d64[i] = s64[i];
         }
+    } else {
+        const uint64_t *s64 = (const uint64_t *)src; uint64_t *d64 = (uint64_t *)w.m;
+        for (int32_t i = lane; i < n * 3; i += 64) d64[i] = s64[i];
+        __syncthreads();
     }
     MTB_PHASE_MARK(0);
-    /* phase 1: (species, frame) blocks */
-    for (int32_t i = lane; i < n; i += 64) {
-        int32_t spc = m[i].species_id; uint32_t fr = mtb_q_frame(m[i].qinfo);
-        bool head = (i == 0) || m[i - 1].species_id != spc || mtb_q_frame(m[i - 1].qinfo) != fr;
-        if (!head) continue;
-        int32_t e = i + 1;
-        while (e < n && m[e].species_id == spc && mtb_q_frame(m[e].qinfo) == fr) e++;
-        if (e - i > 1) {      /* Taxonomer.cpp:342 */
-            int32_t md = (spc >= 0 && spc <= tx.max_taxid && tx.under_euk[spc]) ? sp.min_cons_cnt_euk : sp.min_cons_cnt;
-            mtb_sf_block_paths(m, i, e, path, flag, &sp, md);
+    /* flags, ids */
+    for (int32_t i = lane; i < n; i += 64) mtb_ph_flags(w, i);
+    __syncthreads();
+    int32_t ng = 0, nbk = 0, nsp = 0;
+    for (int32_t c0 = 0; c0 < n; c0 += 64) {
+        int32_t i = c0 + lane;
+        uint32_t f = (i < n) ? w.flag[i] : 0u;
+        uint64_t mg = __ballot(f & MTB_F_GHEAD), mb = __ballot(f & MTB_F_BHEAD), ms = __ballot(f & MTB_F_SHEAD);
+        if (i < n) {
+            w.gid[i] = (IDX)(ng + __popcll(mg & lt) + ((f & MTB_F_GHEAD) ? 1 : 0) - 1);
+            w.bid[i] = (IDX)(nbk + __popcll(mb & lt) + ((f & MTB_F_BHEAD) ? 1 : 0) - 1);
+            w.sid[i] = (IDX)(nsp + __popcll(ms & lt) + ((f & MTB_F_SHEAD) ? 1 : 0) - 1);
         }
+        ng += __popcll(mg); nbk += __popcll(mb); nsp += __popcll(ms);
     }
     __syncthreads();
+    for (int32_t i = lane; i < n; i += 64) mtb_ph_starts(w, i, &tx);
+    __syncthreads();
+    int32_t maxrank = 0;
+    for (int32_t i = lane; i < n; i += 64) { mtb_ph_links(w, i, &tx, &sp, ng, nbk); int32_t rr = w.rk[i]; maxrank = rr > maxrank ? rr : maxrank; }
+    for (int d = 32; d > 0; d >>= 1) { int32_t o = __shfl_xor(maxrank, d, 64); maxrank = o > maxrank ? o : maxrank; }
+    __syncthreads();
+    /* rounds */
+    for (int32_t r = 1; r <= maxrank; r++) {
+        for (int32_t i = lane; i < n; i += 64) mtb_ph_round(w, i, r, &sp);
+        __syncthreads();
+    }
     MTB_PHASE_MARK(1);
-    /* phase 2: species blocks */
-    for (int32_t i = lane; i < n; i += 64) {
-        int32_t spc = m[i].species_id;
-        bool head = (i == 0) || m[i - 1].species_id != spc;
-        if (!head) continue;
-        int32_t e = i + 1;
-        while (e < n && m[e].species_id == spc) e++;
-        int32_t np = 0;
-        float sc = mtb_species_combine(m, i, e, path, flag, order, acc, read_len, &np);
-        if (np > 0) sps[i] = sc < 1.0f ? sc : 1.0f;        /* Taxonomer.cpp:356 */
+    /* emit + compaction: elist = gid[], exclusive emitted prefix = rk[] */
+    IDX *elist = w.gid, *ec = w.rk;
+    int32_t ne = 0;
+    for (int32_t c0 = 0; c0 < n; c0 += 64) {
+        int32_t i = c0 + lane;
+        bool e = (i < n) && mtb_ph_emit(w, i, &sp);
+        uint64_t me = __ballot(e);
+        int32_t pre = ne + (int32_t)__popcll(me & lt);
+        if (i < n) ec[i] = (IDX)pre;
+        if (e) elist[pre] = (IDX)i;
+        ne += (int32_t)__popcll(me);
+    }
+    __syncthreads();
+    /* combine: one lane per species */
+    float *sps = (float *)w.grp_start;
+    for (int32_t s0 = 0; s0 < nsp; s0 += 64) {
+        int32_t s = s0 + lane;
+        float sc = -1.0f;
+        if (s < nsp) {
+            int32_t lo = ec[w.sp_start[s]], hi = (s + 1 < nsp) ? (int32_t)ec[w.sp_start[s + 1]] : ne;
+            if (hi > lo) { sc = mtb_ph_combine(w, elist, lo, hi, read_len); sc = sc < 1.0f ? sc : 1.0f; }
+        }
+        __syncthreads();                 /* sps[] aliases grp_start/blk_start: all reads above are done */
+        if (s < nsp) sps[s] = sc;
     }
     __syncthreads();
     MTB_PHASE_MARK(2);
-    /* phase 3: decision.  Lane 0 picks the species; the redundancy filter runs
-     * one lane per position bucket (their LCA chains are independent). */
+    /* select (lane 0), then the redundancy filter over the best species' matches */
     int32_t bs = 0, be = 0, species = 0, go = 0;
-    if (lane == 0) go = mtb_read_select(m, n, sps, &tx, &sp, &R, &bs, &be, &species) ? 1 : 0;
+    if (lane == 0) go = mtb_ph_select(w, sps, nsp, &tx, &sp, &R, &bs, &be, &species) ? 1 : 0;
     go = __shfl(go, 0, 64);
     if (go) {
-        bs = __shfl(bs, 0, 64); be = __shfl(be, 0, 64);
-        for (int32_t q = lane; q < nb; q += 64) {
-            int32_t t;
-            bool used = mtb_filter_bucket(m, bs, be, &tx, sp.dna_shift, q, &t);
-            btax[q] = t; bham[q] = used ? 0 : 255;
+        bs = __shfl(bs, 0, 64); be = __shfl(be, 0, 64); species = __shfl(species, 0, 64);
+        uint32_t *hmin = ocnt;
+        for (int32_t q = lane; q < nb; q += 64) { hmin[q] = 255u; btax[q] = -1; }
+        __syncthreads();
+        for (int32_t i = bs + lane; i < be; i += 64) mtb_ph_filter_min(w.m, i, sp.dna_shift, nb, hmin);
+        __syncthreads();
+        for (int32_t i = bs + lane; i < be; i += 64) mtb_ph_filter_merge(w.m, i, sp.dna_shift, nb, hmin, btax, &tx);
+        __syncthreads();
+        for (int32_t q = lane; q < nb; q += 64) bham[q] = hmin[q] == 255u ? 255 : 0;
+        __syncthreads();
+        int32_t ntc = 0;
+        if (lane == 0) ntc = mtb_taxcnt_gather(btax, bham, nb, otax, ocnt, (int32_t)tc_room);
+        ntc = __shfl(ntc, 0, 64);
+        __syncthreads();
+        /* sub-species descent: climb the (few) taxa in parallel, walk the chains on lane 0 */
+        bool to_parent = R.score < sp.min_sp_score;          /* R valid on lane 0 only; recomputed below on lane 0 */
+        int32_t slow = ntc > MTB_LR_MAXE ? 1 : 0;
+        if (!slow && lane < ntc) {
+            int32_t lv;
+            mtb_lr_climb(&tx, otax[lane], species, &lv, lr_anc + lane * MTB_LR_K);
+            lr_lev[lane] = lv;
+            if (lv > MTB_LR_K) slow = 1;
         }
+        slow = __any(slow) ? 1 : 0;
         __syncthreads();
         if (lane == 0) {
-            int32_t ntc = mtb_taxcnt_gather(btax, bham, nb, otax, ocnt, (int32_t)tc_room);
-            mtb_read_finish(&tx, &sp, species, read_len, otax, ocnt, ntc, &R);
+            R.n_taxcnt = (uint16_t)ntc;
+            to_parent = R.score < sp.min_sp_score;
+            int32_t cs = mtb_tax_canon(&tx, species);
+            if (to_parent) R.classification = (species >= 0 && species <= tx.max_taxid) ? tx.sp_parent[species] : 0;
+            else if (slow || cs < 0) R.classification = mtb_lower_rank(&tx, otax, ocnt, ntc, species, read_len, sp.denominator);
+            else R.classification = mtb_lr_bfs(lr_lev, lr_anc, ocnt, ntc, cs, read_len, sp.denominator);
             R.taxcnt_off = (uint32_t)tc_off;
             for (int32_t k = 0; k < ntc; k++)
                 if (tc_off + k < tc_cap) { tc_tax[tc_off + k] = otax[k]; tc_cnt[tc_off + k] = ocnt[k]; }
@@ -143,9 +215,10 @@ __device__ __forceinline__ void score_read_body(const mtb_match *__restrict__ sr
 }
 
 /* SORT = true: segments arrive grouped by read but unordered (fused path): the
- * wave sorts the staged segment in LDS first (compareMatches order) and, if
+ * wave rank-sorts the staged segment (compareMatches order) and, if
  * sorted_out != NULL, writes it back.  Segments larger than MTB_SCORE_LDS must
  * already be sorted in HBM (k_segsort_large).                               */
+#define MTB_SCORE_WS_BYTES ((MTB_SCORE_LDS * (24 + 24 + 3) + (MTB_SCORE_LDS + 1) * 8 * 2 + 64 + 15) & ~15)
 template <bool SORT>
 __global__ __launch_bounds__(64) void k_score(const mtb_match *__restrict__ matches, const uint64_t *__restrict__ seg_start,
                                                uint64_t n_reads, const int32_t *__restrict__ qlen, const int32_t *__restrict__ qlen2,
@@ -154,16 +227,13 @@ __global__ __launch_bounds__(64) void k_score(const mtb_match *__restrict__ matc
                                                uint32_t *__restrict__ tc_cnt, uint64_t tc_cap, uint8_t *__restrict__ slabs,
                                                uint64_t slab_bytes, uint32_t slab_max_n, uint32_t slab_max_nb,
                                                mtb_match *__restrict__ sorted_out) {
-    __shared__ mtb_match s_m[MTB_SCORE_LDS];
-    __shared__ mtb_path s_path[MTB_SCORE_LDS];
-    __shared__ int32_t s_order[MTB_SCORE_LDS];
-    __shared__ int32_t s_acc[MTB_SCORE_LDS];
-    __shared__ float s_sps[MTB_SCORE_LDS];
-    __shared__ uint8_t s_flag[MTB_SCORE_LDS];
+    __shared__ __attribute__((aligned(16))) uint8_t s_ws[MTB_SCORE_WS_BYTES];
     __shared__ int32_t s_btax[MTB_SCORE_BKT];
     __shared__ int32_t s_otax[MTB_SCORE_BKT];
     __shared__ uint32_t s_ocnt[MTB_SCORE_BKT];
     __shared__ uint8_t s_bham[MTB_SCORE_BKT];
+    __shared__ int32_t s_lev[MTB_LR_MAXE];
+    __shared__ int32_t s_anc[MTB_LR_MAXE * MTB_LR_K];
     const uint32_t lane = threadIdx.x;
     for (uint64_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
         const uint64_t s0 = seg_start[r];
@@ -178,26 +248,29 @@ __global__ __launch_bounds__(64) void k_score(const mtb_match *__restrict__ matc
         const bool big = n > MTB_SCORE_LDS || nb > MTB_SCORE_BKT;
         const uint64_t off = tc_off[r], room = tc_off[r + 1] - off;
         if (!big) {
-            score_read_body<SORT>(matches + s0, n, s_m, s_path, s_order, s_acc, s_sps, s_flag, s_btax, s_bham, s_otax, s_ocnt, nb,
-                                  read_len, tx, sp, off, room, tc_tax, tc_cnt, tc_cap, sorted_out ? sorted_out + s0 : nullptr, R);
+            mtb_sws<uint16_t> w;
+            mtb_sws_carve<uint16_t>(&w, s_ws, MTB_SCORE_LDS);
+            score_read_par<uint16_t, SORT>(matches + s0, n, w, s_btax, s_bham, s_otax, s_ocnt, s_lev, s_anc, nb, read_len, tx, sp, off, room,
+                                           tc_tax, tc_cnt, tc_cap, sorted_out ? sorted_out + s0 : nullptr, R);
         } else {
             if ((uint32_t)n > slab_max_n || (uint32_t)nb > slab_max_nb) {      /* cannot happen: slabs are sized from the maxima */
                 if (lane == 0) { R.reserved = 0xFF; results[r] = R; }
                 continue;
             }
             uint8_t *slab = slabs + (uint64_t)blockIdx.x * slab_bytes;
-            uint64_t N = slab_max_n, B = slab_max_nb;
-            mtb_match *m = (mtb_match *)slab; mtb_path *path = (mtb_path *)(m + N); int32_t *order = (int32_t *)(path + N);
-            int32_t *acc = order + N; float *sps = (float *)(acc + N); uint8_t *flag = (uint8_t *)(sps + N);
-            uint8_t *p = slab + N * (sizeof(mtb_match) + sizeof(mtb_path) + 12) + ((N + 7) & ~7ull);
-            int32_t *btax = (int32_t *)p; int32_t *otax = btax + B; uint32_t *ocnt = (uint32_t *)(otax + B); uint8_t *bham = (uint8_t *)(ocnt + B);
+            mtb_sws<uint32_t> w;
+            mtb_sws_carve<uint32_t>(&w, slab, slab_max_n);
+            uint8_t *p = slab + mtb_sws_bytes<uint32_t>(slab_max_n);
+            uint64_t B = slab_max_nb;
+            int32_t *btax = (int32_t *)p; int32_t *otax = btax + B; uint32_t *ocnt = (uint32_t *)(otax + B);
+            int32_t *lev = (int32_t *)(ocnt + B); int32_t *anc = lev + MTB_LR_MAXE; uint8_t *bham = (uint8_t *)(anc + MTB_LR_MAXE * MTB_LR_K);
             /* big segments are pre-sorted in HBM; a small segment of a long read still needs its sort */
             if (SORT && n <= MTB_SCORE_LDS)
-                score_read_body<true>(matches + s0, n, m, path, order, acc, sps, flag, btax, bham, otax, ocnt, nb, read_len, tx, sp,
-                                      off, room, tc_tax, tc_cnt, tc_cap, sorted_out ? sorted_out + s0 : nullptr, R);
+                score_read_par<uint32_t, true>(matches + s0, n, w, btax, bham, otax, ocnt, lev, anc, nb, read_len, tx, sp, off, room, tc_tax, tc_cnt,
+                                               tc_cap, sorted_out ? sorted_out + s0 : nullptr, R);
             else
-                score_read_body<false>(matches + s0, n, m, path, order, acc, sps, flag, btax, bham, otax, ocnt, nb, read_len, tx, sp,
-                                       off, room, tc_tax, tc_cnt, tc_cap, (mtb_match *)nullptr, R);
+                score_read_par<uint32_t, false>(matches + s0, n, w, btax, bham, otax, ocnt, lev, anc, nb, read_len, tx, sp, off, room, tc_tax, tc_cnt,
+                                                tc_cap, (mtb_match *)nullptr, R);
         }
         if (lane == 0) { R.query_length = ql1; R.query_length2 = ql2; R.reserved = 0; results[r] = R; }
     }

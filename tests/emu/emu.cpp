@@ -12,6 +12,7 @@
 #include <vector>
 #include <algorithm>
 #include "../../metabuli_amd/csrc/mtb_core.h"
+#include "../../metabuli_amd/csrc/mtb_score_par.h"
 
 extern "C" {
 
@@ -117,6 +118,101 @@ size_t emu_score(const int32_t *canon, const int32_t *parent, const int32_t *dep
         res[r] = R;
     }
     return w;
+}
+
+// mirrors kernels_score.h score_read_par(): the per-element phases of
+// mtb_score_par.h run in plain loops (one loop == one lane-strided phase + barrier)
+size_t emu_score_par(const int32_t *canon, const int32_t *parent, const int32_t *depth, const uint8_t *under_euk, const int32_t *sp_parent,
+                     int32_t max_taxid, const mtb_params *p, const mtb_match *ml_in, size_t nM, size_t n_reads, const int32_t *qlen,
+                     const int32_t *qlen2, mtb_result *res, int32_t *tc_tax, uint32_t *tc_cnt, size_t cap, int presorted) {
+    mtb_tax_view tx{canon, parent, depth, under_euk, sp_parent, max_taxid};
+    mtb_score_params sp; mtb_make_score_params(p, &sp);
+    for (size_t r = 0; r < n_reads; r++) { res[r] = mtb_result{0, 0.f, qlen[r], qlen2 ? qlen2[r] : 0, 0, 0, 0, 0}; }
+    size_t wout = 0, idx = 0;
+    typedef uint16_t IDX;
+    while (idx < nM) {
+        uint32_t seq = mtb_q_seq(ml_in[idx].qinfo);
+        size_t s0 = idx; while (idx < nM && mtb_q_seq(ml_in[idx].qinfo) == seq) idx++;
+        int32_t n = (int32_t)(idx - s0);
+        size_t r = seq - 1;
+        int32_t read_len = qlen[r] + (qlen2 ? qlen2[r] : 0);
+        std::vector<uint8_t> slab(mtb_sws_bytes<IDX>((uint64_t)n) + 64);
+        mtb_sws<IDX> w; mtb_sws_carve<IDX>(&w, slab.data(), (uint64_t)n); w.n = n;
+        // rank sort (keys alias the path area)
+        const mtb_match *src = ml_in + s0;
+        if (presorted) { for (int32_t i = 0; i < n; i++) w.m[i] = src[i]; }
+        else {
+            uint64_t *k1 = (uint64_t *)w.path; uint32_t *k2 = (uint32_t *)(k1 + n);
+            for (int32_t i = 0; i < n; i++) { k1[i] = mtb_key1(src[i]); k2[i] = mtb_key2(src[i]); }
+            std::vector<int32_t> rank((size_t)n);
+            for (int32_t i = 0; i < n; i++) {
+                int32_t c = 0;
+                for (int32_t j = 0; j < n; j++) c += (k1[j] < k1[i]) || (k1[j] == k1[i] && (k2[j] < k2[i] || (k2[j] == k2[i] && j < i)));
+                rank[(size_t)i] = c;
+            }
+            for (int32_t i = 0; i < n; i++) w.m[rank[(size_t)i]] = src[i];
+        }
+        for (int32_t i = 0; i < n; i++) mtb_ph_flags(w, i);
+        int32_t ng = 0, nbk = 0, nsp = 0;
+        for (int32_t i = 0; i < n; i++) {
+            uint32_t f = w.flag[i];
+            ng += (f & MTB_F_GHEAD) ? 1 : 0; nbk += (f & MTB_F_BHEAD) ? 1 : 0; nsp += (f & MTB_F_SHEAD) ? 1 : 0;
+            w.gid[i] = (IDX)(ng - 1); w.bid[i] = (IDX)(nbk - 1); w.sid[i] = (IDX)(nsp - 1);
+        }
+        for (int32_t i = 0; i < n; i++) mtb_ph_starts(w, i, &tx);
+        int32_t maxrank = 0;
+        // links: every element reads shared arrays written by EARLIER phases only, except its own slots
+        {
+            // emulate "all lanes read, then write" per chunk is unnecessary: reads touch gid/grp_start/blk_start/acc/sid/m, writes touch path/flag/shift/cmask/rk/bid[own]
+            for (int32_t i = 0; i < n; i++) { mtb_ph_links(w, i, &tx, &sp, ng, nbk); }
+            for (int32_t i = 0; i < n; i++) maxrank = std::max<int32_t>(maxrank, w.rk[i]);
+        }
+        for (int32_t rr = 1; rr <= maxrank; rr++) for (int32_t i = 0; i < n; i++) mtb_ph_round(w, i, rr, &sp);
+        // emit + compaction (elist = gid array, prefix = rk array)
+        IDX *elist = w.gid, *ec = w.rk;
+        int32_t ne = 0;
+        {
+            std::vector<uint8_t> em((size_t)n);
+            for (int32_t i = 0; i < n; i++) em[(size_t)i] = mtb_ph_emit(w, i, &sp) ? 1 : 0;
+            for (int32_t i = 0; i < n; i++) { ec[i] = (IDX)ne; if (em[(size_t)i]) elist[ne++] = (IDX)i; }
+        }
+        float *sps = (float *)w.grp_start;
+        {
+            std::vector<float> tmp((size_t)nsp);
+            for (int32_t s = 0; s < nsp; s++) {
+                int32_t lo = ec[w.sp_start[s]], hi = (s + 1 < nsp) ? (int32_t)ec[w.sp_start[s + 1]] : ne;
+                float sc = -1.0f;
+                if (hi > lo) { sc = mtb_ph_combine(w, elist, lo, hi, read_len); sc = sc < 1.0f ? sc : 1.0f; }
+                tmp[(size_t)s] = sc;
+            }
+            for (int32_t s = 0; s < nsp; s++) sps[s] = tmp[(size_t)s];
+        }
+        mtb_result R = res[r];
+        int32_t bs = 0, be = 0, species = 0;
+        bool go = mtb_ph_select(w, sps, nsp, &tx, &sp, &R, &bs, &be, &species);
+        R.taxcnt_off = (uint32_t)wout;
+        if (go) {
+            int32_t nb = mtb_num_buckets(read_len, sp.dna_shift);
+            std::vector<int32_t> btax((size_t)nb, -1), otax((size_t)nb); std::vector<uint32_t> hmin((size_t)nb, 255), ocnt((size_t)nb); std::vector<uint8_t> bham((size_t)nb);
+            for (int32_t i = bs; i < be; i++) mtb_ph_filter_min(w.m, i, sp.dna_shift, nb, hmin.data());
+            for (int32_t i = be - 1; i >= bs; i--) mtb_ph_filter_merge(w.m, i, sp.dna_shift, nb, hmin.data(), btax.data(), &tx);   // reverse order on purpose
+            for (int32_t q = 0; q < nb; q++) bham[(size_t)q] = hmin[(size_t)q] == 255 ? 255 : 0;
+            int32_t ntc = mtb_taxcnt_gather(btax.data(), bham.data(), nb, otax.data(), ocnt.data(), nb);
+            R.n_taxcnt = (uint16_t)ntc;
+            if (R.score < sp.min_sp_score) R.classification = (species >= 0 && species <= max_taxid) ? sp_parent[species] : 0;
+            else {
+                bool slow = ntc > MTB_LR_MAXE;
+                std::vector<int32_t> lev((size_t)std::max(ntc, 1)), anc((size_t)std::max(ntc, 1) * MTB_LR_K);
+                if (!slow) for (int32_t i = 0; i < ntc; i++) { mtb_lr_climb(&tx, otax[(size_t)i], species, &lev[(size_t)i], &anc[(size_t)i * MTB_LR_K]); if (lev[(size_t)i] > MTB_LR_K) slow = true; }
+                int32_t cs = mtb_tax_canon(&tx, species);
+                if (slow || cs < 0) R.classification = mtb_lower_rank(&tx, otax.data(), ocnt.data(), ntc, species, read_len, sp.denominator);
+                else R.classification = mtb_lr_bfs(lev.data(), anc.data(), ocnt.data(), ntc, cs, read_len, sp.denominator);
+            }
+            for (int32_t k = 0; k < ntc; k++) { if (wout < cap) { tc_tax[wout] = otax[(size_t)k]; tc_cnt[wout] = ocnt[(size_t)k]; } wout++; }
+        }
+        res[r] = R;
+    }
+    return wout;
 }
 
 } // extern "C"

@@ -187,6 +187,7 @@ class Emu:
         self.lib.emu_extract_batch.restype = C.c_size_t
         self.lib.emu_join.restype = C.c_size_t
         self.lib.emu_score.restype = C.c_size_t
+        self.lib.emu_score_par.restype = C.c_size_t
 
     def tables(self):
         buf = np.zeros(256 + 64 + 32, np.uint8)
@@ -228,6 +229,20 @@ class Emu:
                                C.byref(p), _ptr(m), C.c_size_t(len(m)), C.c_size_t(n_reads), _ptr(ql), _ptr(ql2),
                                _ptr(res), _ptr(tt), _ptr(tc), C.c_size_t(cap))
         return res, tt[:n].copy(), tc[:n].copy()
+
+
+def _emu_score_par(self, taxarr, p, m, n_reads, ql, ql2, presorted=True):
+    canon, parent, depth, under_euk, sp_parent = taxarr
+    res = np.zeros(n_reads, result_dt)
+    cap = max(1024, len(m) + 16)
+    tt = np.zeros(cap, np.int32); tc = np.zeros(cap, np.uint32)
+    n = self.lib.emu_score_par(_ptr(canon), _ptr(parent), _ptr(depth), _ptr(under_euk), _ptr(sp_parent), C.c_int32(len(parent) - 1),
+                               C.byref(p), _ptr(m), C.c_size_t(len(m)), C.c_size_t(n_reads), _ptr(ql), _ptr(ql2),
+                               _ptr(res), _ptr(tt), _ptr(tc), C.c_size_t(cap), C.c_int(1 if presorted else 0))
+    return res, tt[:n].copy(), tc[:n].copy()
+
+
+Emu.score_par = _emu_score_par
 
 
 def tax_arrays(orc: Oracle, tax, world_tax):
