@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void k_list_large(const uint64_t *__restrict__
  * emits ds_* / global_* instead of flat accesses.  SORT: the segment arrives
  * unordered and holds at most 64*MAXPER matches: rank sort on 12-byte keys. */
 #define MTB_SCORE_MAXPER 3
-template <typename IDX, bool SORT>
+template <typename IDX, bool SORT, bool KEY64>
 __device__ __forceinline__ void score_read_par(const mtb_match *__restrict__ src, int32_t n, mtb_sws<IDX> w, int32_t *btax,
                                                uint8_t *bham, int32_t *otax, uint32_t *ocnt, int32_t *lr_lev, int32_t *lr_anc,
                                                int32_t nb, int32_t read_len, const mtb_tax_view &tx, const mtb_score_params &sp,
@@ -81,22 +81,52 @@ __device__ __forceinline__ void score_read_par(const mtb_match *__restrict__ src
     w.n = n;
     MTB_PHASE_BEGIN();
     if (SORT) {
-        /* rank sort: keys in the (not yet live) path area, records in registers */
+        /* rank sort: keys in the (not yet live) path area, records in registers.
+         * KEY64 (host-checked: taxids < 2^22, positions < 2^11): the whole
+         * compareMatches key fits one 64-bit word. */
         uint64_t *k1 = (uint64_t *)w.path; uint32_t *k2 = (uint32_t *)(k1 + n);
         mtb_match rec[MTB_SCORE_MAXPER]; uint64_t a1[MTB_SCORE_MAXPER]; uint32_t a2[MTB_SCORE_MAXPER]; int32_t rank[MTB_SCORE_MAXPER];
 #pragma unroll
         for (int k = 0; k < MTB_SCORE_MAXPER; k++) {
             int32_t i = lane + 64 * k;
             rank[k] = 0; a1[k] = 0; a2[k] = 0;
-            if (i < n) { rec[k] = src[i]; a1[k] = mtb_key1(rec[k]); a2[k] = mtb_key2(rec[k]); k1[i] = a1[k]; k2[i] = a2[k]; }
+            if (i < n) {
+                rec[k] = src[i];
+                if (KEY64) {
+                    a1[k] = ((uint64_t)(uint32_t)rec[k].species_id << 41) | ((uint64_t)mtb_q_frame(rec[k].qinfo) << 38) |
+                            ((uint64_t)(mtb_q_pos(rec[k].qinfo) & 0x7FFu) << 27) | ((uint64_t)(rec[k].hamming & 7u) << 24) | (rec[k].dna & 0xFFFFFFu);
+                    k1[i] = a1[k];
+                } else { a1[k] = mtb_key1(rec[k]); a2[k] = mtb_key2(rec[k]); k1[i] = a1[k]; k2[i] = a2[k]; }
+            }
         }
         __syncthreads();
-        for (int32_t j = 0; j < n; j++) {
-            uint64_t b1 = k1[j]; uint32_t b2 = k2[j];
+        {
+            const int32_t nslot = (n + 63) >> 6;          /* live register slots (wave-uniform) */
+            int32_t j = 0;
+            for (; j + 4 <= n; j += 4) {                  /* 4 independent LDS reads in flight */
+                uint64_t b1[4]; uint32_t b2[4];
 #pragma unroll
-            for (int k = 0; k < MTB_SCORE_MAXPER; k++) {
-                int32_t i = lane + 64 * k;
-                rank[k] += (b1 < a1[k]) || (b1 == a1[k] && (b2 < a2[k] || (b2 == a2[k] && j < i)));
+                for (int u = 0; u < 4; u++) { b1[u] = k1[j + u]; b2[u] = KEY64 ? 0u : k2[j + u]; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+#pragma unroll
+                    for (int k = 0; k < MTB_SCORE_MAXPER; k++) {
+                        if (k < nslot) {
+                            int32_t i = lane + 64 * k;
+                            if (KEY64) rank[k] += (b1[u] < a1[k]) || (b1[u] == a1[k] && (j + u) < i);
+                            else rank[k] += (b1[u] < a1[k]) || (b1[u] == a1[k] && (b2[u] < a2[k] || (b2[u] == a2[k] && (j + u) < i)));
+                        }
+                    }
+                }
+            }
+            for (; j < n; j++) {
+                uint64_t b1 = k1[j]; uint32_t b2 = KEY64 ? 0u : k2[j];
+#pragma unroll
+                for (int k = 0; k < MTB_SCORE_MAXPER; k++) {
+                    int32_t i = lane + 64 * k;
+                    if (KEY64) rank[k] += (b1 < a1[k]) || (b1 == a1[k] && j < i);
+                    else rank[k] += (b1 < a1[k]) || (b1 == a1[k] && (b2 < a2[k] || (b2 == a2[k] && j < i)));
+                }
             }
         }
         __syncthreads();
@@ -136,9 +166,51 @@ __device__ __forceinline__ void score_read_par(const mtb_match *__restrict__ src
     for (int d = 32; d > 0; d >>= 1) { int32_t o = __shfl_xor(maxrank, d, 64); maxrank = o > maxrank ? o : maxrank; }
     __syncthreads();
     /* rounds */
-    for (int32_t r = 1; r <= maxrank; r++) {
-        for (int32_t i = lane; i < n; i += 64) mtb_ph_round(w, i, r, &sp);
-        __syncthreads();
+    if (n <= 64 * MTB_SCORE_MAXPER) {
+        /* register-cached round state: idle lanes touch no memory in a round */
+        int32_t c_rk[MTB_SCORE_MAXPER]; uint32_t c_sh[MTB_SCORE_MAXPER], c_cm[MTB_SCORE_MAXPER], c_reh[MTB_SCORE_MAXPER]; int32_t c_pl[MTB_SCORE_MAXPER];
+#pragma unroll
+        for (int k = 0; k < MTB_SCORE_MAXPER; k++) {
+            int32_t i = lane + 64 * k;
+            c_rk[k] = -1; c_sh[k] = 0; c_cm[k] = 0; c_pl[k] = 0; c_reh[k] = 0;
+            if (i < n) {
+                uint32_t sh = w.shift[i];
+                if (sh) { c_rk[k] = w.rk[i]; c_sh[k] = sh; c_cm[k] = w.cmask[i]; c_pl[k] = w.bid[i]; c_reh[k] = w.m[i].right_end_hamming; }
+            }
+        }
+        for (int32_t r = 1; r <= maxrank; r++) {
+#pragma unroll
+            for (int k = 0; k < MTB_SCORE_MAXPER; k++) {
+                bool act = c_rk[k] == r;
+                if (!__any(act)) continue;
+                if (act) {
+                    int32_t i = lane + 64 * k;
+                    if (c_sh[k] & MTB_SHIFT_SLOW) mtb_ph_round(w, i, r, &sp);
+                    else {
+                        int32_t shift = (int32_t)(c_sh[k] & 0x7Fu);
+                        int32_t best = -1; float best_score = 0.0f;
+                        uint32_t cm = c_cm[k]; int32_t pl = c_pl[k];
+                        for (int32_t q = 0; cm; q++, cm >>= 1)
+                            if (cm & 1u) { float sc = w.path[pl + q].score; if (sc > best_score) { best = pl + q; best_score = sc; } }
+                        if (best >= 0) {
+                            mtb_path b = w.path[best];
+                            mtb_path p;
+                            p.start = b.start; p.end = w.path[i].end;
+                            p.score = b.score + mtb_part_score(c_reh[k], shift, false);
+                            p.ham = b.ham + mtb_part_ham(c_reh[k], shift, false);
+                            p.depth = b.depth + shift; p.start_idx = b.start_idx;
+                            w.path[i] = p;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    } else {
+        for (int32_t r = 1; r <= maxrank; r++) {
+            for (int32_t i = lane; i < n; i += 64) mtb_ph_round(w, i, r, &sp);
+            __syncthreads();
+        }
     }
     MTB_PHASE_MARK(1);
     /* emit + compaction: elist = gid[], exclusive emitted prefix = rk[] */
@@ -219,7 +291,7 @@ __device__ __forceinline__ void score_read_par(const mtb_match *__restrict__ src
  * sorted_out != NULL, writes it back.  Segments larger than MTB_SCORE_LDS must
  * already be sorted in HBM (k_segsort_large).                               */
 #define MTB_SCORE_WS_BYTES ((MTB_SCORE_LDS * (24 + 24 + 3) + (MTB_SCORE_LDS + 1) * 8 * 2 + 64 + 15) & ~15)
-template <bool SORT>
+template <bool SORT, bool KEY64>
 __global__ __launch_bounds__(64) void k_score(const mtb_match *__restrict__ matches, const uint64_t *__restrict__ seg_start,
                                                uint64_t n_reads, const int32_t *__restrict__ qlen, const int32_t *__restrict__ qlen2,
                                                mtb_tax_view tx, mtb_score_params sp, const uint64_t *__restrict__ tc_off,
@@ -250,7 +322,7 @@ __global__ __launch_bounds__(64) void k_score(const mtb_match *__restrict__ matc
         if (!big) {
             mtb_sws<uint16_t> w;
             mtb_sws_carve<uint16_t>(&w, s_ws, MTB_SCORE_LDS);
-            score_read_par<uint16_t, SORT>(matches + s0, n, w, s_btax, s_bham, s_otax, s_ocnt, s_lev, s_anc, nb, read_len, tx, sp, off, room,
+            score_read_par<uint16_t, SORT, KEY64>(matches + s0, n, w, s_btax, s_bham, s_otax, s_ocnt, s_lev, s_anc, nb, read_len, tx, sp, off, room,
                                            tc_tax, tc_cnt, tc_cap, sorted_out ? sorted_out + s0 : nullptr, R);
         } else {
             if ((uint32_t)n > slab_max_n || (uint32_t)nb > slab_max_nb) {      /* cannot happen: slabs are sized from the maxima */
@@ -266,10 +338,10 @@ __global__ __launch_bounds__(64) void k_score(const mtb_match *__restrict__ matc
             int32_t *lev = (int32_t *)(ocnt + B); int32_t *anc = lev + MTB_LR_MAXE; uint8_t *bham = (uint8_t *)(anc + MTB_LR_MAXE * MTB_LR_K);
             /* big segments are pre-sorted in HBM; a small segment of a long read still needs its sort */
             if (SORT && n <= MTB_SCORE_LDS)
-                score_read_par<uint32_t, true>(matches + s0, n, w, btax, bham, otax, ocnt, lev, anc, nb, read_len, tx, sp, off, room, tc_tax, tc_cnt,
+                score_read_par<uint32_t, true, KEY64>(matches + s0, n, w, btax, bham, otax, ocnt, lev, anc, nb, read_len, tx, sp, off, room, tc_tax, tc_cnt,
                                                tc_cap, sorted_out ? sorted_out + s0 : nullptr, R);
             else
-                score_read_par<uint32_t, false>(matches + s0, n, w, btax, bham, otax, ocnt, lev, anc, nb, read_len, tx, sp, off, room, tc_tax, tc_cnt,
+                score_read_par<uint32_t, false, false>(matches + s0, n, w, btax, bham, otax, ocnt, lev, anc, nb, read_len, tx, sp, off, room, tc_tax, tc_cnt,
                                                 tc_cap, (mtb_match *)nullptr, R);
         }
         if (lane == 0) { R.query_length = ql1; R.query_length2 = ql2; R.reserved = 0; results[r] = R; }

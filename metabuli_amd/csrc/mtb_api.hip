@@ -319,12 +319,14 @@ static mtb_status dev_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, cons
         STCHK(ensure(c, "slabs", (size_t)grid * slab_bytes, &d_slabs));
     }
     { KTimer kt(c, MTB_K_SCORE);
-    if (fused_sort)
-        hipLaunchKernelGGL((k_score<true>), dim3(grid), dim3(64), 0, c->stream, d_m, d_seg, n_reads, d_qlen, d_qlen2, tax_view(ix), sp,
-                           (const uint64_t *)d_tcoff, d_res, d_tc_tax, d_tc_cnt, tc_cap, d_slabs, slab_bytes, slab_n, slab_nb, (mtb_match *)nullptr);
-    else
-        hipLaunchKernelGGL((k_score<false>), dim3(grid), dim3(64), 0, c->stream, d_m, d_seg, n_reads, d_qlen, d_qlen2, tax_view(ix), sp,
-                           (const uint64_t *)d_tcoff, d_res, d_tc_tax, d_tc_cnt, tc_cap, d_slabs, slab_bytes, slab_n, slab_nb, (mtb_match *)nullptr); }
+    /* single-word sort key when taxids < 2^22 and positions < 2^11 (hamming of a match is <= 7) */
+    bool key64 = ix->tax.max_id < (1 << 22) && max_len + 3 < (1u << 11);
+#define MTB_LAUNCH_SCORE(S, K) hipLaunchKernelGGL((k_score<S, K>), dim3(grid), dim3(64), 0, c->stream, d_m, d_seg, n_reads, d_qlen, d_qlen2, \
+        tax_view(ix), sp, (const uint64_t *)d_tcoff, d_res, d_tc_tax, d_tc_cnt, tc_cap, d_slabs, slab_bytes, slab_n, slab_nb, (mtb_match *)nullptr)
+    if (fused_sort) { if (key64) MTB_LAUNCH_SCORE(true, true); else MTB_LAUNCH_SCORE(true, false); }
+    else MTB_LAUNCH_SCORE(false, false);
+#undef MTB_LAUNCH_SCORE
+    }
     HIPCHK(hipGetLastError());
     return MTB_OK;
 }
