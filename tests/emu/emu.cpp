@@ -13,6 +13,7 @@
 #include <algorithm>
 #include "../../metabuli_amd/csrc/mtb_core.h"
 #include "../../metabuli_amd/csrc/mtb_score_par.h"
+#include "../../metabuli_amd/csrc/host_db.h"
 
 extern "C" {
 
@@ -214,5 +215,20 @@ size_t emu_score_par(const int32_t *canon, const int32_t *parent, const int32_t 
     }
     return wout;
 }
+
+// host_db.h (what mtb_index_open does on the host) exposed for CPU tests
+int emu_load_taxonomy(const char *dir, const int32_t *taxid_list, size_t n_ids, int32_t cap, int32_t *max_id, int32_t *canon, int32_t *parent,
+                      int32_t *depth, uint8_t *under_euk, int32_t *sp_parent, int32_t *tax2species) {
+    mtbhost::Taxonomy t; std::string err;
+    if (!mtbhost::load_taxonomy(dir, &t, &err)) return 1;
+    mtbhost::build_tax2species(&t, taxid_list, n_ids);
+    *max_id = t.max_id;
+    if (t.max_id + 1 > cap) return 2;
+    size_t n = (size_t)t.max_id + 1;
+    memcpy(canon, t.canon.data(), n * 4); memcpy(parent, t.parent.data(), n * 4); memcpy(depth, t.depth.data(), n * 4);
+    memcpy(under_euk, t.under_euk.data(), n); memcpy(sp_parent, t.sp_parent.data(), n * 4); memcpy(tax2species, t.tax2species.data(), n * 4);
+    return 0;
+}
+int emu_load_db_parameters(const char *dir, mtb_params *p) { return mtbhost::load_db_parameters(dir, p) ? 0 : 1; }
 
 } // extern "C"

@@ -60,6 +60,7 @@ def build_emu():
     d = os.path.join(ROOT, "tests", "emu")
     so = os.path.join(d, "libmtb_emu.so")
     src = [os.path.join(d, "emu.cpp"), os.path.join(ROOT, "metabuli_amd", "csrc", "mtb_core.h"),
+           os.path.join(ROOT, "metabuli_amd", "csrc", "mtb_score_par.h"), os.path.join(ROOT, "metabuli_amd", "csrc", "host_db.h"),
            os.path.join(ROOT, "include", "mtb.h")]
     if (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared", "-o", so,
@@ -243,6 +244,23 @@ def _emu_score_par(self, taxarr, p, m, n_reads, ql, ql2, presorted=True):
 
 
 Emu.score_par = _emu_score_par
+
+
+def _emu_load_taxonomy(self, d, taxids):
+    """host_db.h: the dense taxonomy arrays libmtb uploads at index-open time."""
+    cap = 1 << 22
+    arrs = [np.zeros(cap, np.int32) for _ in range(3)]
+    under = np.zeros(cap, np.uint8); spp = np.zeros(cap, np.int32); t2s = np.zeros(cap, np.int32)
+    mx = C.c_int32()
+    ids = np.ascontiguousarray(taxids, dtype=np.int32)
+    rc = self.lib.emu_load_taxonomy(d.encode(), _ptr(ids), C.c_size_t(len(ids)), C.c_int32(cap), C.byref(mx), _ptr(arrs[0]), _ptr(arrs[1]),
+                                    _ptr(arrs[2]), _ptr(under), _ptr(spp), _ptr(t2s))
+    assert rc == 0
+    n = mx.value + 1
+    return (arrs[0][:n].copy(), arrs[1][:n].copy(), arrs[2][:n].copy(), under[:n].copy(), spp[:n].copy()), t2s[:n].copy()
+
+
+Emu.load_taxonomy = _emu_load_taxonomy
 
 
 def tax_arrays(orc: Oracle, tax, world_tax):

@@ -1,0 +1,152 @@
+"""CPU checks of the kernel arithmetic (tests/emu = host build of mtb_core.h /
+mtb_score_par.h, the exact functions the HIP kernels call) against the oracle,
+and of the oracle against the committed golden vectors."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import default_params, tax2species_table, tax_arrays
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_extract_equals_oracle(toy, orc, emu):
+    ke, el, el2 = emu.extract_batch(toy.p, toy.b1, toy.o1, toy.b2, toy.o2)
+    ko, ql, ql2 = orc.extract_batch(toy.p, toy.b1, toy.o1, toy.b2, toy.o2)
+    assert (el == ql).all() and (el2 == ql2).all()
+    assert len(ke) == len(ko) and (ke == ko).all()
+
+
+@pytest.mark.parametrize("syncmer", [0, 1])
+@pytest.mark.parametrize("smer_len", [3, 5, 7])
+def test_extract_edge_cases(orc, emu, syncmer, smer_len):
+    rng = np.random.default_rng(1)
+    seqs = [b"", b"A", b"ACGTACGTACGTACGTACGTACGTA", b"ACGTACGTACGTACGTACGTACGTAC", b"ACGTACGTACGTACGTACGTACGTACG", b"N" * 60,
+            b"acgtnRYKMSWBDHVU" * 8]
+    for L in list(range(20, 40)) + [149, 150, 151, 152, 300, 1001]:
+        s = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=L)
+        if L > 30:
+            s[rng.integers(0, L, size=max(1, L // 50))] = ord("N")
+        seqs.append(s.tobytes())
+    bases = np.frombuffer(b"".join(seqs), dtype=np.uint8).copy()
+    offs = np.zeros(len(seqs) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(s) for s in seqs])
+    p = default_params(seq_mode=1, syncmer=syncmer, smer_len=smer_len)
+    ke, el, _ = emu.extract_batch(p, bases, offs)
+    ko, ql, _ = orc.extract_batch(p, bases, offs)
+    assert (el == ql).all() and len(ke) == len(ko) and (ke == ko).all()
+    # mates of different lengths, one of them too short -> the pair is skipped
+    p2 = default_params(seq_mode=2, syncmer=syncmer, smer_len=smer_len)
+    order = rng.permutation(len(seqs))
+    b2 = np.frombuffer(b"".join(seqs[i] for i in order), dtype=np.uint8).copy()
+    o2 = np.zeros(len(seqs) + 1, np.uint64)
+    o2[1:] = np.cumsum([len(seqs[i]) for i in order])
+    ke, el, el2 = emu.extract_batch(p2, bases, offs, b2, o2)
+    ko, ql, ql2 = orc.extract_batch(p2, bases, offs, b2, o2)
+    assert (el == ql).all() and (el2 == ql2).all() and len(ke) == len(ko) and (ke == ko).all()
+
+
+def _tables(toy, orc):
+    mx = orc.lib.orc_tax_max_id(toy.tax)
+    return tax2species_table(orc, toy.tax, toy.taxids, mx), tax_arrays(orc, toy.tax, toy.world.tax)
+
+
+def test_join_equals_oracle(toy, orc, emu):
+    t2s, _ = _tables(toy, orc)
+    q = np.sort(toy.ref["kmers"], order=["value"], kind="stable")
+    m = emu.join(toy.values, toy.taxids.astype(np.uint32), t2s, 0xFFFFFFFF, 2, q)
+    ms = emu.sort_matches(m)
+    assert len(ms) == len(toy.ref["matches"]) and (ms == toy.ref["matches"]).all()
+
+
+def test_join_last_index_entry_is_never_a_candidate(toy, orc, emu):
+    from helpers import kmer_dt
+    t2s, _ = _tables(toy, orc)
+    q = np.zeros(2, kmer_dt)
+    q["value"] = [toy.values[-2], toy.values[-1]]
+    q["qinfo"] = np.uint64(1) << np.uint64(32)
+    me = emu.sort_matches(emu.join(toy.values, toy.taxids.astype(np.uint32), t2s, 0xFFFFFFFF, 2, q))
+    mo = orc.sort_matches(orc.match(toy.db, q))
+    assert len(me) == len(mo) and (me == mo).all()
+    # a query equal to the last entry alone finds nothing unless earlier entries share its amino-acid part
+    q1 = q[1:].copy()
+    m1 = emu.join(toy.values, toy.taxids.astype(np.uint32), t2s, 0xFFFFFFFF, 2, q1)
+    aam = ~np.uint64(0xFFFFFF)
+    n_same = int(((toy.values[:-1] & aam) == (toy.values[-1] & aam)).sum())
+    assert (len(m1) == 0) == (n_same == 0)
+    assert len(m1) == len(orc.match(toy.db, q1))
+
+
+def _same_results(toy, res, tt, tc):
+    ro = toy.ref["results"]
+    amb = ro["flag"] != 0
+    assert ((res["classification"] == ro["classification"]) | amb).all()
+    assert ((res["score"].view(np.uint32) == ro["score"].view(np.uint32)) | amb).all()
+    assert ((res["is_classified"] == ro["is_classified"]) | amb).all()
+    if not amb.any():
+        assert (tt == toy.ref["tc_tax"]).all() and (tc == toy.ref["tc_cnt"]).all()
+
+
+def test_score_sequential_core_equals_oracle(toy, orc, emu):
+    _, ta = _tables(toy, orc)
+    res, tt, tc = emu.score(ta, toy.p, toy.ref["matches"], toy.n_reads, toy.ref["qlen"], toy.ref["qlen2"])
+    _same_results(toy, res, tt, tc)
+
+
+def test_score_parallel_phases_equal_oracle(toy, orc, emu):
+    """Data-parallel scorer (rank sort + rounds DP + parallel filter), fed with the
+    matches of every read in random order, exactly as k_regroup leaves them."""
+    _, ta = _tables(toy, orc)
+    m = toy.ref["matches"]
+    rng = np.random.default_rng(3)
+    seqs = (m["qinfo"] >> np.uint64(32)) & np.uint64(0x1FFFFFFF)
+    sh = m[np.lexsort((rng.random(len(m)), seqs))]
+    res, tt, tc = emu.score_par(ta, toy.p, sh, toy.n_reads, toy.ref["qlen"], toy.ref["qlen2"], presorted=False)
+    _same_results(toy, res, tt, tc)
+
+
+@pytest.mark.parametrize("kw", [dict(min_score=0.2), dict(min_sp_score=0.9), dict(tie_ratio=0.5), dict(min_cons_cnt=2, min_cons_cnt_euk=3),
+                                dict(min_cons_cnt=1)])
+def test_score_parameter_variants(orc, emu, tmp_path, kw):
+    from conftest import Toy
+    t = Toy(orc, tmp_path, syncmer=1, paired=False, seed=8, n_reads=150)
+    for k, v in kw.items():
+        setattr(t.p, k, v)
+    ref = orc.classify(t.db, t.tax, t.p, t.b1, t.o1)
+    _, ta = _tables(t, orc)
+    t.ref = ref
+    res, tt, tc = emu.score(ta, t.p, ref["matches"], t.n_reads, ref["qlen"], ref["qlen2"])
+    _same_results(t, res, tt, tc)
+    res, tt, tc = emu.score_par(ta, t.p, ref["matches"], t.n_reads, ref["qlen"], ref["qlen2"], presorted=True)
+    _same_results(t, res, tt, tc)
+
+
+def test_host_taxonomy_loader_equals_oracle(toy, orc, emu):
+    """host_db.h (libmtb's loader) vs the oracle's taxonomy services."""
+    (canon, parent, depth, under, spp), t2s = emu.load_taxonomy(os.path.join(toy.dbdir, "taxonomy"), np.unique(toy.taxids))
+    t2s_o, (canon_o, parent_o, depth_o, under_o, spp_o) = _tables(toy, orc)
+    assert (canon == canon_o).all() and (depth == depth_o).all() and (under == under_o).all() and (spp == spp_o).all()
+    assert (parent[canon >= 0] == parent_o[canon >= 0]).all()
+    assert (t2s == t2s_o).all()
+
+
+@pytest.mark.parametrize("name", ["toy_sync_se", "toy_dense_pe"])
+def test_oracle_reproduces_golden_vectors(orc, tmp_path, name):
+    """Regression pin of the oracle on committed vectors (tests/golden/make_golden.py)."""
+    from metabuli_amd import synth
+    g = np.load(os.path.join(HERE, "golden", name + ".npz"))
+    p = default_params(seq_mode=2 if int(g["paired"]) else 1, syncmer=int(g["syncmer"]))
+    tax = synth.Taxonomy()
+    for (t, par), r, nm in zip(g["tax_nodes"], g["tax_ranks"], g["tax_names"]):
+        tax.add(int(t), int(par), str(r), str(nm))
+    d = str(tmp_path)
+    tax.write(os.path.join(d, "taxonomy"))
+    orc.write_db(d, g["db_values"], g["db_taxids"], p)
+    assert (np.fromfile(os.path.join(d, "diffIdx"), dtype=np.uint16) == g["diffidx"]).all()
+    t = orc.load_taxonomy(os.path.join(d, "taxonomy"))
+    db = orc.open_db(d, t, p)
+    paired = bool(int(g["paired"]))
+    R = orc.classify(db, t, p, g["bases"], g["offs"], g["bases2"] if paired else None, g["offs2"] if paired else None)
+    assert (R["kmers"] == g["kmers"]).all() and (R["matches"] == g["matches"]).all()
+    assert (R["results"] == g["results"]).all() and (R["tc_tax"] == g["tc_tax"]).all() and (R["tc_cnt"] == g["tc_cnt"]).all()
