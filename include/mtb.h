@@ -143,6 +143,10 @@ int32_t    mtb_tax_lca(const mtb_index *, int32_t a, int32_t b);
 int32_t    mtb_tax_species(const mtb_index *, int32_t taxid);  /* taxId2speciesId */
 int32_t    mtb_tax_parent(const mtb_index *, int32_t taxid);
 int32_t    mtb_tax_max_id(const mtb_index *);
+/* rank / scientific name of a node ("" if unknown); pointers stay valid while the index is open
+ * (TaxonomyWrapper::getString(taxonNode(t)->rankIdx / nameIdx), used by Reporter.cpp:35-193) */
+const char *mtb_tax_rank(const mtb_index *, int32_t taxid);
+const char *mtb_tax_name(const mtb_index *, int32_t taxid);
 
 /* ---- stage-level entry points (host buffers; the parity seam) ----------
  * KmerExtractor::extractQueryKmers minus the sort (KmerExtractor.cpp:52-77,

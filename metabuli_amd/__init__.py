@@ -81,6 +81,9 @@ def lib():
     L.mtb_tax_species.argtypes = [C.c_void_p, C.c_int32]
     L.mtb_tax_parent.argtypes = [C.c_void_p, C.c_int32]
     L.mtb_tax_max_id.argtypes = [C.c_void_p]
+    for f in ("mtb_tax_rank", "mtb_tax_name"):
+        getattr(L, f).restype = C.c_char_p
+        getattr(L, f).argtypes = [C.c_void_p, C.c_int32]
     _lib = L
     return L
 

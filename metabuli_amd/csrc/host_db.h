@@ -61,6 +61,7 @@ struct Taxonomy {
     int32_t max_id = 0;
     std::vector<int32_t> canon, parent, depth, rank_idx, sp_parent, tax2species;
     std::vector<uint8_t> under_euk;
+    std::vector<std::string> rank, name;     /* by canonical id (reporting only) */
     int32_t eukaryota = 0;
 
     int32_t cn(int32_t t) const { return (t >= 0 && t <= max_id) ? canon[(size_t)t] : -1; }
@@ -101,14 +102,14 @@ inline std::vector<std::string> split_dmp(const std::string &line) {
 inline bool load_taxonomy(const std::string &dir, Taxonomy *t, std::string *err) {
     std::ifstream fn(dir + "/nodes.dmp");
     if (!fn) { *err = "cannot open " + dir + "/nodes.dmp"; return false; }
-    struct N { int32_t id, parent; int rank; };
+    struct N { int32_t id, parent; int rank; std::string rank_name; };
     std::vector<N> nodes;
     std::string line;
     int32_t mx = 1;
     while (std::getline(fn, line)) {
         auto c = split_dmp(line);
         if (c.size() < 3) continue;
-        N n{(int32_t)atoi(c[0].c_str()), (int32_t)atoi(c[1].c_str()), find_rank_index(c[2])};
+        N n{(int32_t)atoi(c[0].c_str()), (int32_t)atoi(c[1].c_str()), find_rank_index(c[2]), c[2]};
         mx = std::max(mx, std::max(n.id, n.parent));
         nodes.push_back(n);
     }
@@ -126,7 +127,8 @@ inline bool load_taxonomy(const std::string &dir, Taxonomy *t, std::string *err)
     size_t sz = (size_t)mx + 1;
     t->canon.assign(sz, -1); t->parent.assign(sz, -1); t->depth.assign(sz, 0); t->rank_idx.assign(sz, -1);
     t->sp_parent.assign(sz, 0); t->tax2species.assign(sz, 0); t->under_euk.assign(sz, 0);
-    for (auto &n : nodes) { t->canon[(size_t)n.id] = n.id; t->parent[(size_t)n.id] = n.parent; t->rank_idx[(size_t)n.id] = n.rank; }
+    t->rank.assign(sz, std::string()); t->name.assign(sz, std::string());
+    for (auto &n : nodes) { t->canon[(size_t)n.id] = n.id; t->parent[(size_t)n.id] = n.parent; t->rank_idx[(size_t)n.id] = n.rank; t->rank[(size_t)n.id] = n.rank_name; }
     for (auto &n : nodes) if (t->canon[(size_t)n.parent] < 0) { *err = "nodes.dmp: missing parent taxon"; return false; }
     for (auto &m : merged) if (t->canon[(size_t)m.first] < 0 && t->canon[(size_t)m.second] >= 0) t->canon[(size_t)m.first] = m.second;
     for (auto &n : nodes) {
@@ -139,7 +141,10 @@ inline bool load_taxonomy(const std::string &dir, Taxonomy *t, std::string *err)
         while (fnm && std::getline(fnm, line)) {
             if (line.find("scientific name") == std::string::npos) continue;
             auto c = split_dmp(line);
-            if (c.size() >= 2 && c[1] == "Eukaryota") { t->eukaryota = (int32_t)atoi(c[0].c_str()); break; }
+            if (c.size() < 2) continue;
+            int32_t id = (int32_t)atoi(c[0].c_str());
+            if (id >= 0 && id <= mx && t->canon[(size_t)id] == id) t->name[(size_t)id] = c[1];
+            if (c[1] == "Eukaryota" && t->eukaryota == 0) t->eukaryota = id;
         }
     }
     const int SPECIES = find_rank_index("species");

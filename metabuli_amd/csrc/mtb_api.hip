@@ -448,6 +448,8 @@ int32_t mtb_tax_lca(const mtb_index *ix, int32_t a, int32_t b) { return ix->tax.
 int32_t mtb_tax_species(const mtb_index *ix, int32_t t) { return (t >= 0 && t <= ix->tax.max_id) ? ix->tax.tax2species[(size_t)t] : 0; }
 int32_t mtb_tax_parent(const mtb_index *ix, int32_t t) { int32_t c = ix->tax.cn(t); return c < 0 ? -1 : ix->tax.parent[(size_t)c]; }
 int32_t mtb_tax_max_id(const mtb_index *ix) { return ix->tax.max_id; }
+const char *mtb_tax_rank(const mtb_index *ix, int32_t t) { int32_t c = ix->tax.cn(t); return c < 0 ? "" : ix->tax.rank[(size_t)c].c_str(); }
+const char *mtb_tax_name(const mtb_index *ix, int32_t t) { int32_t c = ix->tax.cn(t); return c < 0 ? "" : ix->tax.name[(size_t)c].c_str(); }
 
 /* ------------------------------------------------------------------ */
 /* stage-level entry points (host buffers)                             */

@@ -1008,3 +1008,75 @@ extern "C" size_t orc_score(const orc_db *db, const orc_taxonomy *tax, const orc
     }
     return w;
 }
+
+/* ------------------------------------------------------------------ */
+/* Reporter                                                            */
+/* ------------------------------------------------------------------ */
+#include <functional>
+#include <iostream>
+#include <sstream>
+extern "C" {
+// Reporter::writeReadClassification (Reporter.cpp:35-80), lineage off.
+// names: '\n'-separated read names.  Returns 0 on success.
+int orc_write_classifications(const char *path, const orc_taxonomy *tax, const char *names, size_t n_reads, const orc_result *res,
+                              const int32_t *tcTax, const uint32_t *tcCnt) {
+    std::ofstream f(path);
+    if (!f) return 1;
+    f << "#is_classified\tname\ttaxID\tquery_length\tscore\trank\ttaxID:match_count\n";
+    std::istringstream nm(names);
+    std::string name;
+    for (size_t i = 0; i < n_reads; i++) {
+        std::getline(nm, name);
+        const orc_result &r = res[i];
+        bool cls = r.is_classified != 0;
+        if (cls) {
+            int c = tax->canon(r.classification);
+            f << cls << "\t" << name << "\t" << r.classification << "\t" << r.query_length + r.query_length2 << "\t" << r.score << "\t"
+              << (c >= 0 ? tax->rank[(size_t)c] : std::string()) << "\t";
+            for (uint32_t k = 0; k < r.n_taxcnt; k++) f << tcTax[r.taxcnt_off + k] << ":" << tcCnt[r.taxcnt_off + k] << " ";
+            f << "\n";
+        } else {
+            f << cls << "\t" << name << "\t" << r.classification << "\t" << r.query_length + r.query_length2 << "\t" << r.score << "\t-\t-\t\n";
+        }
+    }
+    return 0;
+}
+// Reporter::writeReportFile / writeReport (Reporter.cpp:115-193) with clade counts as
+// NcbiTaxonomy::getCladeCounts; children ordered by (clade count desc, taxid asc).
+int orc_write_report(const char *path, const orc_taxonomy *tax, size_t n_reads, const orc_result *res) {
+    std::map<int, unsigned> taxCounts;
+    for (size_t i = 0; i < n_reads; i++) ++taxCounts[res[i].classification];      // Classifier.cpp:201-203
+    std::unordered_map<int, unsigned> clade, own;
+    std::unordered_map<int, std::vector<int>> children;
+    for (auto &kv : taxCounts) {
+        own[kv.first] = kv.second;
+        if (kv.first == 0) { clade[0] += kv.second; continue; }
+        int t = tax->canon(kv.first);
+        int guard = 0;
+        while (t >= 0 && guard++ < 1000) {
+            bool fresh = clade.find(t) == clade.end();
+            clade[t] += kv.second;
+            int p = tax->parent[(size_t)t];
+            if (p == t) break;
+            if (fresh) children[p].push_back(t);
+            t = p;
+        }
+    }
+    FILE *fp = fopen(path, "w");
+    if (!fp) return 1;
+    fprintf(fp, "#clade_proportion\tclade_count\ttaxon_count\trank\ttaxID\tname\n");
+    if (clade.count(0) && clade[0] > 0) fprintf(fp, "%.4f\t%i\t%i\tno rank\t0\tunclassified\n", 100 * clade[0] / double(n_reads), (int)clade[0], (int)own[0]);
+    std::function<void(int, int)> rec = [&](int t, int depth) {
+        auto it = clade.find(t);
+        if (it == clade.end() || it->second == 0) return;
+        fprintf(fp, "%.4f\t%i\t%i\t%s\t%i\t%s%s\n", 100 * it->second / double(n_reads), (int)it->second, (int)(own.count(t) ? own[t] : 0),
+                tax->rank[(size_t)t].c_str(), t, std::string(2 * (size_t)depth, ' ').c_str(), tax->name[(size_t)t].c_str());
+        std::vector<int> ch = children[t];
+        std::sort(ch.begin(), ch.end(), [&](int a, int b) { return clade[a] != clade[b] ? clade[a] > clade[b] : a < b; });
+        for (int c : ch) rec(c, depth + 1);
+    };
+    rec(1, 0);
+    fclose(fp);
+    return 0;
+}
+}

@@ -126,6 +126,11 @@ size_t orc_score(const orc_db *, const orc_taxonomy *, const orc_params *p,
                  size_t n_reads, const int32_t *qlen, const int32_t *qlen2,
                  orc_result *res, int32_t *taxcnt_tax, uint32_t *taxcnt_cnt, size_t cap);
 
+/* ---- Reporter (Reporter.cpp:35-80, 115-193) ---------------------------- */
+int orc_write_classifications(const char *path, const orc_taxonomy *, const char *names_nl, size_t n_reads,
+                              const orc_result *res, const int32_t *taxcnt_tax, const uint32_t *taxcnt_cnt);
+int orc_write_report(const char *path, const orc_taxonomy *, size_t n_reads, const orc_result *res);
+
 #ifdef __cplusplus
 }
 #endif

@@ -159,3 +159,37 @@ def test_large_properties(ctx):
     assert int(s["qinfo"].sum(dtype=np.uint64)) == int(k["qinfo"].sum(dtype=np.uint64))
     order = np.argsort(k["value"], kind="stable")
     assert (s["qinfo"] == k["qinfo"][order]).all()
+
+
+def test_classify_driver_tsv_outputs(toy, orc, tmp_path):
+    """mtb_classify (host loop over the C ABI, reference command line) writes the same
+    _classifications.tsv / _report.tsv as the oracle's restated Reporter."""
+    import ctypes as C
+    import subprocess
+    import metabuli_amd as M
+    exe = os.path.join(os.path.dirname(M.LIB_PATH), "mtb_classify")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.dirname(M.LIB_PATH), "mtb_classify"])
+    names = [f"read{i}/x" for i in range(toy.n_reads)]
+
+    def write_fastq(path, bases, offs):
+        with open(path, "w") as f:
+            for i, nm in enumerate(names):
+                s = bytes(bases[int(offs[i]):int(offs[i + 1])]).decode()
+                f.write(f"@{nm} some comment\n{s}\n+\n{'I' * len(s)}\n")
+    fq1 = str(tmp_path / "r1.fq"); write_fastq(fq1, toy.b1, toy.o1)
+    args = [exe, "--seq-mode", str(toy.p.seq_mode), "--max-reads", "97"]
+    args.append(fq1)
+    if toy.b2 is not None:
+        fq2 = str(tmp_path / "r2.fq"); write_fastq(fq2, toy.b2, toy.o2); args.append(fq2)
+    args += [toy.dbdir, str(tmp_path), "job"]
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    ref = toy.ref
+    cpath = str(tmp_path / "oracle_classifications.tsv"); rpath = str(tmp_path / "oracle_report.tsv")
+    nm = ("\n".join(names) + "\n").encode()
+    assert orc.lib.orc_write_classifications(cpath.encode(), toy.tax, nm, C.c_size_t(toy.n_reads), ref["results"].ctypes.data_as(C.c_void_p),
+                                             ref["tc_tax"].ctypes.data_as(C.c_void_p), ref["tc_cnt"].ctypes.data_as(C.c_void_p)) == 0
+    assert orc.lib.orc_write_report(rpath.encode(), toy.tax, C.c_size_t(toy.n_reads), ref["results"].ctypes.data_as(C.c_void_p)) == 0
+    if not (ref["results"]["flag"] != 0).any():
+        assert open(str(tmp_path / "job_classifications.tsv")).read() == open(cpath).read()
+        assert sorted(open(str(tmp_path / "job_report.tsv")).read().split("\n")) == sorted(open(rpath).read().split("\n"))
