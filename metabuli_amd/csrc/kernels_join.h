@@ -17,32 +17,115 @@
 #include "dev_util.h"
 #include "mtb_core.h"
 
+#define MTB_JOIN_QPT 2                      /* queries per thread                              */
+#define MTB_JOIN_QPB (256 * MTB_JOIN_QPT)   /* sorted queries per workgroup                     */
+#define MTB_JOIN_WIN 4096                   /* target values staged in LDS (32 KB)              */
+
+/* block-wide count of a predicate pair (A in the low, B in the high half) */
+__device__ __forceinline__ void block_count2(bool a, bool b, uint32_t *s_red, uint32_t *ca, uint32_t *cb) {
+    uint32_t wa = (uint32_t)__popcll(__ballot(a)), wb = (uint32_t)__popcll(__ballot(b));
+    __syncthreads();
+    if (lane_id() == 0) s_red[threadIdx.x >> 6] = wa | (wb << 16);
+    __syncthreads();
+    uint32_t t = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    *ca = t & 0xFFFFu; *cb = t >> 16;
+}
+
+/* Two lower bounds (keyA <= keyB) in the sorted array v[0..n) by a 256-ary
+ * cooperative search: every step all 256 lanes probe one position each, so a
+ * 2^33-entry index is bounded in 5 dependent memory steps instead of 33.    */
+__device__ __forceinline__ void block_kary_lower_bound2(const uint64_t *__restrict__ v, uint64_t n, uint64_t keyA, uint64_t keyB,
+                                                        uint64_t *outA, uint64_t *outB, uint32_t *s_red) {
+    uint64_t lA = 0, rA = n, lB = 0, rB = n;
+    const uint64_t t = threadIdx.x;
+    while (rA > lA || rB > lB) {
+        uint64_t lenA = rA - lA, lenB = rB - lB;
+        uint64_t stA = (lenA + 255) >> 8, stB = (lenB + 255) >> 8;
+        uint64_t pA = lA + t * stA, pB = lB + t * stB;
+        bool a = lenA && pA < rA && v[pA] < keyA;
+        bool b = lenB && pB < rB && v[pB] < keyB;
+        uint32_t cA, cB;
+        block_count2(a, b, s_red, &cA, &cB);
+        if (lenA) {
+            if (stA == 1) { lA = rA = lA + cA; }
+            else { uint64_t nl = cA ? lA + (uint64_t)(cA - 1) * stA + 1 : lA; uint64_t nr = lA + (uint64_t)cA * stA; rA = nr < rA ? nr : rA; lA = nl; }
+        }
+        if (lenB) {
+            if (stB == 1) { lB = rB = lB + cB; }
+            else { uint64_t nl = cB ? lB + (uint64_t)(cB - 1) * stB + 1 : lB; uint64_t nr = lB + (uint64_t)cB * stB; rB = nr < rB ? nr : rB; lB = nl; }
+        }
+    }
+    *outA = lA; *outB = lB;
+}
+
 __global__ __launch_bounds__(256) void k_join(const mtb_kmer *__restrict__ q, uint64_t n, mtb_index_view ix,
                                                const mtb_tables *__restrict__ tabs, mtb_match *__restrict__ out,
                                                uint64_t cap, unsigned long long *__restrict__ counter,
                                                uint32_t *__restrict__ read_cnt, uint32_t *__restrict__ overflow) {
     __shared__ mtb_tables s_tab;
     __shared__ uint32_t s_tmp[8];
+    __shared__ uint32_t s_red[4];
     __shared__ unsigned long long s_base;
+    __shared__ uint64_t s_win[MTB_JOIN_WIN];
     for (uint32_t i = threadIdx.x; i < sizeof(mtb_tables) / 4; i += 256) ((uint32_t *)&s_tab)[i] = ((const uint32_t *)tabs)[i];
+    const uint64_t base = (uint64_t)blockIdx.x * MTB_JOIN_QPB;
+    const uint64_t last = (base + MTB_JOIN_QPB <= n ? base + MTB_JOIN_QPB : n) - 1;
+    const uint64_t limit = ix.n_targets ? ix.n_targets - 1 : 0;          /* the last index entry is never a candidate */
+    mtb_kmer k[MTB_JOIN_QPT];
+    bool valid[MTB_JOIN_QPT];
+#pragma unroll
+    for (int u = 0; u < MTB_JOIN_QPT; u++) {
+        uint64_t j = base + (uint64_t)u * 256 + threadIdx.x;
+        valid[u] = j < n;
+        if (valid[u]) { k[u] = q[j]; valid[u] = mtb_q_seq(k[u].qinfo) != 0; }   /* blank slots carry sequenceID 0 */
+        else { k[u].value = 0; k[u].qinfo = 0; }
+    }
+    /* target window of the tile: [lower_bound(AA(first)), lower_bound(AA(last) + 1)) */
+    const uint64_t keyA = q[base].value & ~0xFFFFFFull;
+    const uint64_t keyB = (q[last].value & ~0xFFFFFFull) + (1ull << 24);
+    uint64_t lo, hi;
+    block_kary_lower_bound2(ix.values, limit, keyA, keyB, &lo, &hi, s_red);
+    const uint64_t span = hi - lo;
+    const bool in_lds = span <= MTB_JOIN_WIN;
+    if (in_lds) for (uint64_t i = threadIdx.x; i < span; i += 256) s_win[i] = ix.values[lo + i];      /* coalesced 64-bit loads */
     __syncthreads();
-    uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    uint32_t c = 0; uint64_t rs = 0; uint32_t rl = 0;
-    mtb_kmer k; k.value = 0; k.qinfo = 0;
-    if (j < n) {
-        k = q[j];
-        if (mtb_q_seq(k.qinfo) != 0)        /* blank slots carry sequenceID 0 (KmerMatcher.cpp:143-151) */
-            c = mtb_join_query(&s_tab, &ix, k.value, k.qinfo, nullptr, 0, 0, &rs, &rl);
+    uint32_t c[MTB_JOIN_QPT]; uint64_t rs[MTB_JOIN_QPT]; uint32_t rl[MTB_JOIN_QPT];
+    uint32_t csum = 0;
+#pragma unroll
+    for (int u = 0; u < MTB_JOIN_QPT; u++) {
+        c[u] = 0; rs[u] = 0; rl[u] = 0;
+        if (valid[u]) {
+            if (in_lds) {
+                mtb_join_find(s_win, span, k[u].value, &rs[u], &rl[u]);
+                c[u] = mtb_join_select(&s_tab, s_win, rs[u], rl[u], k[u].value, k[u].qinfo, ix.info, lo, ix.tax2species, ix.max_taxid,
+                                       ix.info_mask, ix.kmer_format, (mtb_match *)nullptr, 0);
+            } else {
+                mtb_join_find(ix.values + lo, span, k[u].value, &rs[u], &rl[u]);
+                c[u] = mtb_join_select(&s_tab, ix.values + lo, rs[u], rl[u], k[u].value, k[u].qinfo, ix.info, lo, ix.tax2species, ix.max_taxid,
+                                       ix.info_mask, ix.kmer_format, (mtb_match *)nullptr, 0);
+            }
+        }
+        csum += c[u];
     }
     uint32_t tot;
-    uint32_t off = block256_exclusive_scan<uint32_t>(c, s_tmp, &tot);
+    uint32_t off = block256_exclusive_scan<uint32_t>(csum, s_tmp, &tot);
     if (threadIdx.x == 0) s_base = tot ? atomicAdd(counter, (unsigned long long)tot) : 0ull;
     __syncthreads();
-    if (c == 0) return;
+    if (csum == 0) return;
     uint64_t dst = (uint64_t)s_base + off;
-    if (read_cnt) atomicAdd(&read_cnt[mtb_q_seq(k.qinfo) - 1], c);
-    if (dst + c > cap) { *overflow = 1; return; }
-    mtb_join_query(&s_tab, &ix, k.value, k.qinfo, out + dst, c, 1, &rs, &rl);
+    if (dst + csum > cap) { *overflow = 1; }
+#pragma unroll
+    for (int u = 0; u < MTB_JOIN_QPT; u++) {
+        if (c[u] == 0) continue;
+        if (read_cnt) atomicAdd(&read_cnt[mtb_q_seq(k[u].qinfo) - 1], c[u]);
+        if (dst + c[u] <= cap) {
+            if (in_lds) mtb_join_select(&s_tab, s_win, rs[u], rl[u], k[u].value, k[u].qinfo, ix.info, lo, ix.tax2species, ix.max_taxid,
+                                        ix.info_mask, ix.kmer_format, out + dst, c[u]);
+            else mtb_join_select(&s_tab, ix.values + lo, rs[u], rl[u], k[u].value, k[u].qinfo, ix.info, lo, ix.tax2species, ix.max_taxid,
+                                 ix.info_mask, ix.kmer_format, out + dst, c[u]);
+        }
+        dst += c[u];
+    }
 }
 
 /* Move every match into its read's segment (seg_start from a scan of the

@@ -244,7 +244,7 @@ static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint6
     *count = 0;
     if (n == 0) return MTB_OK;
     HIPCHK(hipMemsetAsync(c->d_scal, 0, 16, c->stream));
-    uint32_t grid = (uint32_t)((n + 255) / 256);
+    uint32_t grid = (uint32_t)((n + MTB_JOIN_QPB - 1) / MTB_JOIN_QPB);
     { KTimer kt(c, MTB_K_JOIN);
     hipLaunchKernelGGL(k_join, dim3(grid), dim3(256), 0, c->stream, d_q, n, index_view(ix), (const mtb_tables *)c->d_tabs, d_out, cap,
                        (unsigned long long *)c->d_scal, d_read_cnt, (uint32_t *)(c->d_scal + 1)); }

@@ -219,43 +219,42 @@ MTB_HD uint64_t mtb_lower_bound(const uint64_t *v, uint64_t n, uint64_t key) {
     return lo;
 }
 
-/* One query against the flat index (functional form of KmerMatcher::matchKmers,
- * KmerMatcher.cpp:275-450): candidates are the targets t < T-1 (the last entry
- * of the index is never a candidate, :363/:378) with the query's AA part.
- * Pass 1 (emit == 0) returns the number of selected candidates; pass 2 writes
- * them in index order.                                                       */
+/* the flat target index resident in HBM */
 typedef struct {
     const uint64_t *values; const uint32_t *info; uint64_t n_targets;
     const int32_t *tax2species; int32_t max_taxid; uint32_t info_mask; int32_t kmer_format;
 } mtb_index_view;
 
-MTB_HD uint32_t mtb_join_query(const mtb_tables *t, const mtb_index_view *ix, uint64_t qvalue,
-                               uint64_t qinfo, mtb_match *out, uint32_t out_cap, int emit,
-                               uint64_t *run_start_io, uint32_t *run_len_io) {
-    uint64_t s, e;
-    if (emit) { s = *run_start_io; e = s + *run_len_io; }
-    else {
-        uint64_t aa = qvalue & ~0xFFFFFFull;
-        uint64_t limit = ix->n_targets ? ix->n_targets - 1 : 0;      /* exclude last entry */
-        s = mtb_lower_bound(ix->values, limit, aa);
-        e = s;
-        while (e < limit && (ix->values[e] & ~0xFFFFFFull) == aa) e++;
-        *run_start_io = s; *run_len_io = (uint32_t)(e - s);
-    }
-    if (s >= e) return 0;
+/* Candidate run of one query inside a sorted window v[0..n) of target values
+ * (the whole index or an LDS-staged slice of it): first index and length of
+ * the entries sharing the query's amino-acid part.                          */
+MTB_HD void mtb_join_find(const uint64_t *v, uint64_t n, uint64_t qvalue, uint64_t *run_start, uint32_t *run_len) {
+    uint64_t aa = qvalue & ~0xFFFFFFull;
+    uint64_t s = mtb_lower_bound(v, n, aa);
+    uint64_t e = s;
+    while (e < n && (v[e] & ~0xFFFFFFull) == aa) e++;
+    *run_start = s; *run_len = (uint32_t)(e - s);
+}
+/* Selection over a run v[s..s+len): pass 1 (out == NULL) counts the candidates
+ * with ham <= min(2*minHam, 7) (compareDna, KmerMatcher.cpp:1117-1146); pass 2
+ * writes them in index order.  info/tax2species are indexed with info_base + i. */
+MTB_HD uint32_t mtb_join_select(const mtb_tables *t, const uint64_t *v, uint64_t s, uint32_t len, uint64_t qvalue, uint64_t qinfo,
+                                const uint32_t *info, uint64_t info_base, const int32_t *tax2species, int32_t max_taxid,
+                                uint32_t info_mask, int32_t kmer_format, mtb_match *out, uint32_t out_cap) {
+    if (len == 0) return 0;
     mtb_qrows q; mtb_prepare_query(t, qvalue, &q);
     uint32_t mn = 255;
-    for (uint64_t i = s; i < e; i++) { uint32_t h = mtb_ham_sum(&q, (uint32_t)ix->values[i] & 0xFFFFFFu); mn = h < mn ? h : mn; }
+    for (uint32_t i = 0; i < len; i++) { uint32_t h = mtb_ham_sum(&q, (uint32_t)v[s + i] & 0xFFFFFFu); mn = h < mn ? h : mn; }
     uint32_t thr = mtb_ham_threshold(mn);
     uint32_t cnt = 0;
-    bool rev = mtb_hammings_reversed(mtb_q_frame(qinfo), ix->kmer_format);
-    for (uint64_t i = s; i < e; i++) {
-        uint32_t td = (uint32_t)ix->values[i] & 0xFFFFFFu;
+    bool rev = mtb_hammings_reversed(mtb_q_frame(qinfo), kmer_format);
+    for (uint32_t i = 0; i < len; i++) {
+        uint32_t td = (uint32_t)v[s + i] & 0xFFFFFFu;
         uint32_t h = mtb_ham_sum(&q, td);
         if (h <= thr) {
-            if (emit && cnt < out_cap) {
-                int32_t tid = (int32_t)(ix->info[i] & ix->info_mask);
-                int32_t sp = (tid >= 0 && tid <= ix->max_taxid) ? ix->tax2species[tid] : 0;
+            if (out && cnt < out_cap) {
+                int32_t tid = (int32_t)(info[info_base + s + i] & info_mask);
+                int32_t sp = (tid >= 0 && tid <= max_taxid) ? tax2species[tid] : 0;
                 mtb_match m;
                 m.qinfo = qinfo; m.target_id = tid; m.species_id = sp; m.dna = td;
                 m.right_end_hamming = mtb_hammings(&q, td, rev); m.hamming = (uint8_t)h; m.pad = 0;
@@ -265,6 +264,18 @@ MTB_HD uint32_t mtb_join_query(const mtb_tables *t, const mtb_index_view *ix, ui
         }
     }
     return cnt;
+}
+
+/* One query against the whole flat index (functional form of KmerMatcher::matchKmers,
+ * KmerMatcher.cpp:275-450): candidates are the targets t < T-1 (the last entry
+ * of the index is never a candidate, :363/:378) with the query's AA part.   */
+MTB_HD uint32_t mtb_join_query(const mtb_tables *t, const mtb_index_view *ix, uint64_t qvalue,
+                               uint64_t qinfo, mtb_match *out, uint32_t out_cap, int emit,
+                               uint64_t *run_start_io, uint32_t *run_len_io) {
+    uint64_t limit = ix->n_targets ? ix->n_targets - 1 : 0;      /* exclude last entry */
+    if (!emit) mtb_join_find(ix->values, limit, qvalue, run_start_io, run_len_io);
+    return mtb_join_select(t, ix->values, *run_start_io, *run_len_io, qvalue, qinfo, ix->info, 0, ix->tax2species, ix->max_taxid,
+                           ix->info_mask, ix->kmer_format, emit ? out : (mtb_match *)0, out_cap);
 }
 
 /* ------------------------------------------------------------------ */
