@@ -225,6 +225,8 @@ def main():
     # sanity of the timed output: fraction of reads classified
     res = np.frombuffer(d_res.cpu().numpy().tobytes(), dtype=M.result_dt)
     frac_cls = float((res["is_classified"] != 0).mean())
+    log(f"[rank {rank}] stage ms: extract {st.ms_extract:.1f} sort {st.ms_sort:.1f} join {st.ms_join:.1f} regroup {st.ms_regroup:.1f} "
+        f"segsort {st.ms_segsort:.2f} score {st.ms_score:.1f} total {st.ms_total:.1f}; classified {frac_cls:.4f}")
     if frac_cls < 0.5:   # 90 % of the reads come from genomes that are in the index
         raise SystemExit(f"sanity check failed: only {frac_cls:.4f} of the reads were classified")
 

@@ -69,8 +69,8 @@ __global__ __launch_bounds__(256) void k_list_large(const uint64_t *__restrict__
  * emits ds_* / global_* instead of flat accesses.  SORT: the segment arrives
  * unordered and holds at most 64*MAXPER matches: rank sort on 12-byte keys. */
 #define MTB_SCORE_MAXPER 3
-template <typename IDX, bool SORT, bool KEY64>
-__device__ __forceinline__ void score_read_par(const mtb_match *__restrict__ src, int32_t n, mtb_sws<IDX> w, int32_t *btax,
+template <typename IDX, bool SORT, bool KEY64, typename REC>
+__device__ __forceinline__ void score_read_par(const REC *__restrict__ src, int32_t n, mtb_sws<IDX> w, int32_t *btax,
                                                uint8_t *bham, int32_t *otax, uint32_t *ocnt, int32_t *lr_lev, int32_t *lr_anc,
                                                int32_t nb, int32_t read_len, const mtb_tax_view &tx, const mtb_score_params &sp,
                                                uint64_t tc_off, uint64_t tc_room, int32_t *__restrict__ tc_tax,
@@ -91,7 +91,7 @@ __device__ __forceinline__ void score_read_par(const mtb_match *__restrict__ src
             int32_t i = lane + 64 * k;
             rank[k] = 0; a1[k] = 0; a2[k] = 0;
             if (i < n) {
-                rec[k] = src[i];
+                rec[k] = rec_m(src[i]);
                 if (KEY64) {
                     a1[k] = ((uint64_t)(uint32_t)rec[k].species_id << 41) | ((uint64_t)mtb_q_frame(rec[k].qinfo) << 38) |
                             ((uint64_t)(mtb_q_pos(rec[k].qinfo) & 0x7FFu) << 27) | ((uint64_t)(rec[k].hamming & 7u) << 24) | (rec[k].dna & 0xFFFFFFu);
@@ -138,8 +138,7 @@ __device__ __forceinline__ void score_read_par(const mtb_match *__restrict__ src
             for (int32_t i = lane; i < n * 3; i += 64) d64[i] = s64[i];
         }
     } else {
-        const uint64_t *s64 = (const uint64_t *)src; uint64_t *d64 = (uint64_t *)w.m;
-        for (int32_t i = lane; i < n * 3; i += 64) d64[i] = s64[i];
+        for (int32_t i = lane; i < n; i += 64) w.m[i] = rec_m(src[i]);
         __syncthreads();
     }
     MTB_PHASE_MARK(0);
@@ -291,8 +290,8 @@ __device__ __forceinline__ void score_read_par(const mtb_match *__restrict__ src
  * sorted_out != NULL, writes it back.  Segments larger than MTB_SCORE_LDS must
  * already be sorted in HBM (k_segsort_large).                               */
 #define MTB_SCORE_WS_BYTES ((MTB_SCORE_LDS * (24 + 24 + 3) + (MTB_SCORE_LDS + 1) * 8 * 2 + 64 + 15) & ~15)
-template <bool SORT, bool KEY64>
-__global__ __launch_bounds__(64) void k_score(const mtb_match *__restrict__ matches, const uint64_t *__restrict__ seg_start,
+template <bool SORT, bool KEY64, typename REC>
+__global__ __launch_bounds__(64) void k_score(const REC *__restrict__ matches, const uint64_t *__restrict__ seg_start,
                                                uint64_t n_reads, const int32_t *__restrict__ qlen, const int32_t *__restrict__ qlen2,
                                                mtb_tax_view tx, mtb_score_params sp, const uint64_t *__restrict__ tc_off,
                                                mtb_result *__restrict__ results, int32_t *__restrict__ tc_tax,
@@ -322,7 +321,7 @@ __global__ __launch_bounds__(64) void k_score(const mtb_match *__restrict__ matc
         if (!big) {
             mtb_sws<uint16_t> w;
             mtb_sws_carve<uint16_t>(&w, s_ws, MTB_SCORE_LDS);
-            score_read_par<uint16_t, SORT, KEY64>(matches + s0, n, w, s_btax, s_bham, s_otax, s_ocnt, s_lev, s_anc, nb, read_len, tx, sp, off, room,
+            score_read_par<uint16_t, SORT, KEY64, REC>(matches + s0, n, w, s_btax, s_bham, s_otax, s_ocnt, s_lev, s_anc, nb, read_len, tx, sp, off, room,
                                            tc_tax, tc_cnt, tc_cap, sorted_out ? sorted_out + s0 : nullptr, R);
         } else {
             if ((uint32_t)n > slab_max_n || (uint32_t)nb > slab_max_nb) {      /* cannot happen: slabs are sized from the maxima */
@@ -338,10 +337,10 @@ __global__ __launch_bounds__(64) void k_score(const mtb_match *__restrict__ matc
             int32_t *lev = (int32_t *)(ocnt + B); int32_t *anc = lev + MTB_LR_MAXE; uint8_t *bham = (uint8_t *)(anc + MTB_LR_MAXE * MTB_LR_K);
             /* big segments are pre-sorted in HBM; a small segment of a long read still needs its sort */
             if (SORT && n <= MTB_SCORE_LDS)
-                score_read_par<uint32_t, true, KEY64>(matches + s0, n, w, btax, bham, otax, ocnt, lev, anc, nb, read_len, tx, sp, off, room, tc_tax, tc_cnt,
+                score_read_par<uint32_t, true, KEY64, REC>(matches + s0, n, w, btax, bham, otax, ocnt, lev, anc, nb, read_len, tx, sp, off, room, tc_tax, tc_cnt,
                                                tc_cap, sorted_out ? sorted_out + s0 : nullptr, R);
             else
-                score_read_par<uint32_t, false, false>(matches + s0, n, w, btax, bham, otax, ocnt, lev, anc, nb, read_len, tx, sp, off, room, tc_tax, tc_cnt,
+                score_read_par<uint32_t, false, false, REC>(matches + s0, n, w, btax, bham, otax, ocnt, lev, anc, nb, read_len, tx, sp, off, room, tc_tax, tc_cnt,
                                                 tc_cap, (mtb_match *)nullptr, R);
         }
         if (lane == 0) { R.query_length = ql1; R.query_length2 = ql2; R.reserved = 0; results[r] = R; }

@@ -258,15 +258,16 @@ static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint6
 }
 
 /* per-read counters -> seg_start (n_reads+1) -> regroup into d_out */
+template <typename REC>
 static mtb_status dev_regroup(mtb_ctx *c, const mtb_match *d_in, uint64_t m, uint64_t n_reads, uint32_t *d_read_cnt,
-                              uint64_t **seg_start, mtb_match *d_out) {
+                              uint64_t **seg_start, REC *d_out) {
     uint64_t *d_seg; uint64_t *d_ws; uint32_t *d_cur;
     STCHK(ensure(c, "segstart", n_reads + 1, &d_seg));
     STCHK(ensure(c, "scanws", scan_ws_elems(n_reads + 1), &d_ws));
     STCHK(ensure(c, "cursor", n_reads, &d_cur));
     { KTimer kt(c, MTB_K_SCAN); scan_launch<uint32_t, uint64_t, false>(c->stream, d_read_cnt, n_reads, true, d_seg, d_ws); }
     HIPCHK(hipMemsetAsync(d_cur, 0, n_reads * 4, c->stream));
-    if (m) { KTimer kt(c, MTB_K_REGROUP); hipLaunchKernelGGL(k_regroup, dim3((uint32_t)((m + 255) / 256)), dim3(256), 0, c->stream, d_in, m, (const uint64_t *)d_seg, d_cur, d_out); }
+    if (m) { KTimer kt(c, MTB_K_REGROUP); hipLaunchKernelGGL((k_regroup<REC>), dim3((uint32_t)((m + 255) / 256)), dim3(256), 0, c->stream, d_in, m, (const uint64_t *)d_seg, d_cur, d_out); }
     HIPCHK(hipGetLastError());
     *seg_start = d_seg;
     return MTB_OK;
@@ -280,7 +281,7 @@ static mtb_status dev_segsort(mtb_ctx *c, mtb_match *d_m, const uint64_t *d_seg,
     { KTimer kt(c, MTB_K_SEGSORT);
     hipLaunchKernelGGL(k_segsort_small, dim3(grid), dim3(64), 0, c->stream, d_m, d_seg, n_reads, d_large, (uint32_t *)(c->d_scal + 2),
                        (uint32_t *)(c->d_scal + 3)); }
-    hipLaunchKernelGGL(k_segsort_large, dim3(1024), dim3(256), 0, c->stream, d_m, d_seg, (const uint32_t *)d_large,
+    hipLaunchKernelGGL((k_segsort_large<mtb_match>), dim3(1024), dim3(256), 0, c->stream, d_m, d_seg, (const uint32_t *)d_large,
                        (const uint32_t *)(c->d_scal + 2));
     HIPCHK(hipGetLastError());
     if (max_seg) { uint64_t sc[2]; STCHK(d2h(c, sc, c->d_scal + 2, 16)); *max_seg = (uint32_t)sc[1]; }
@@ -288,7 +289,8 @@ static mtb_status dev_segsort(mtb_ctx *c, mtb_match *d_m, const uint64_t *d_seg,
 }
 
 /* d_results/d_tc_* are device outputs; *n_tc = sum of per-read bounds */
-static mtb_status dev_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, const mtb_match *d_m, const uint64_t *d_seg,
+template <typename REC>
+static mtb_status dev_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, const REC *d_m, const uint64_t *d_seg,
                             uint64_t n_reads, const int32_t *d_qlen, const int32_t *d_qlen2, uint32_t max_seg, uint32_t max_len,
                             mtb_result *d_res, int32_t *d_tc_tax, uint32_t *d_tc_cnt, uint64_t tc_cap, uint64_t *n_tc,
                             bool fused_sort = false) {
@@ -321,7 +323,7 @@ static mtb_status dev_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, cons
     { KTimer kt(c, MTB_K_SCORE);
     /* single-word sort key when taxids < 2^22 and positions < 2^11 (hamming of a match is <= 7) */
     bool key64 = ix->tax.max_id < (1 << 22) && max_len + 3 < (1u << 11);
-#define MTB_LAUNCH_SCORE(S, K) hipLaunchKernelGGL((k_score<S, K>), dim3(grid), dim3(64), 0, c->stream, d_m, d_seg, n_reads, d_qlen, d_qlen2, \
+#define MTB_LAUNCH_SCORE(S, K) hipLaunchKernelGGL((k_score<S, K, REC>), dim3(grid), dim3(64), 0, c->stream, d_m, d_seg, n_reads, d_qlen, d_qlen2, \
         tax_view(ix), sp, (const uint64_t *)d_tcoff, d_res, d_tc_tax, d_tc_cnt, tc_cap, d_slabs, slab_bytes, slab_n, slab_nb, (mtb_match *)nullptr)
     if (fused_sort) { if (key64) MTB_LAUNCH_SCORE(true, true); else MTB_LAUNCH_SCORE(true, false); }
     else MTB_LAUNCH_SCORE(false, false);
@@ -608,8 +610,8 @@ mtb_status mtb_classify_batch_device(mtb_ctx *c, mtb_index *ix, const mtb_params
         HIPCHK(hipMemsetAsync(d_rc, 0, n_reads * 4, st));
     }
     HIPCHK(hipEventRecord(c->ev[3], st));
-    mtb_match *d_m; uint64_t *d_seg;
-    STCHK(ensure(c, "matches", nm, &d_m));
+    mtb_match32 *d_m; uint64_t *d_seg;       /* one 32-byte sector per record: full-sector scattered stores */
+    STCHK(ensure(c, "matches32", nm, &d_m));
     STCHK(dev_regroup(c, d_tmp, nm, n_reads, d_rc, &d_seg, d_m));
     HIPCHK(hipEventRecord(c->ev[4], st));
     /* segments that fit LDS are sorted inside k_score; only the big ones are sorted in HBM here */
@@ -621,7 +623,7 @@ mtb_status mtb_classify_batch_device(mtb_ctx *c, mtb_index *ix, const mtb_params
         { KTimer kt(c, MTB_K_SEGSORT);
         hipLaunchKernelGGL(k_list_large, dim3((uint32_t)((n_reads + 255) / 256)), dim3(256), 0, st, (const uint64_t *)d_seg, n_reads,
                            (uint32_t)MTB_SCORE_LDS, d_large, (uint32_t *)(c->d_scal + 2), (uint32_t *)(c->d_scal + 3));
-        hipLaunchKernelGGL(k_segsort_large, dim3(1024), dim3(256), 0, st, d_m, (const uint64_t *)d_seg, (const uint32_t *)d_large,
+        hipLaunchKernelGGL((k_segsort_large<mtb_match32>), dim3(1024), dim3(256), 0, st, d_m, (const uint64_t *)d_seg, (const uint32_t *)d_large,
                            (const uint32_t *)(c->d_scal + 2)); }
         uint64_t sc[2];
         STCHK(d2h(c, sc, c->d_scal + 2, 16));
