@@ -17,10 +17,9 @@
 #include "dev_util.h"
 #include "mtb_core.h"
 
-/* Segment records of the fused path are padded to one 32-byte sector: a
- * scattered 24-byte store dirties partial sectors and costs a read-modify-write
- * in HBM (measured 3.3x traffic amplification in k_regroup), a 32-byte aligned
- * 32-byte store does not. */
+/* Optional 32-byte padded segment record.  Measured (profiles/r01_notes.md): full-sector
+ * stores do NOT remove the 3.3x traffic amplification of the scattered regroup writes
+ * (the L2 write-allocates whole lines), so the fused path keeps 24-byte records. */
 struct __attribute__((aligned(32))) mtb_match32 { mtb_match m; uint64_t pad; };
 __device__ __forceinline__ const mtb_match &rec_m(const mtb_match &r) { return r; }
 __device__ __forceinline__ const mtb_match &rec_m(const mtb_match32 &r) { return r.m; }

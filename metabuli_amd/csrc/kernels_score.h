@@ -164,8 +164,32 @@ __device__ __forceinline__ void score_read_par(const REC *__restrict__ src, int3
     for (int32_t i = lane; i < n; i += 64) { mtb_ph_links(w, i, &tx, &sp, ng, nbk); int32_t rr = w.rk[i]; maxrank = rr > maxrank ? rr : maxrank; }
     for (int d = 32; d > 0; d >>= 1) { int32_t o = __shfl_xor(maxrank, d, 64); maxrank = o > maxrank ? o : maxrank; }
     __syncthreads();
-    /* rounds */
-    if (n <= 64 * MTB_SCORE_MAXPER) {
+    /* chain DP: pointer doubling when every match has <= 1 consecutive predecessor, else rounds */
+    bool simple = n <= 64 * MTB_SCORE_MAXPER;
+    if (simple) {
+        for (int32_t i = lane; i < n; i += 64) simple = simple && mtb_chain_simple(w, i);
+        simple = __all(simple);
+    }
+    if (simple) {
+        mtb_jump *jump = (mtb_jump *)w.path;          /* fresh paths are rebuilt from the roots at the end */
+        mtb_jump t[MTB_SCORE_MAXPER];
+        for (int32_t i = lane; i < n; i += 64) mtb_ph_jump_init(w, i, jump);
+        __syncthreads();
+        for (int32_t span = 1; span <= maxrank; span <<= 1) {
+#pragma unroll
+            for (int k = 0; k < MTB_SCORE_MAXPER; k++) { int32_t i = lane + 64 * k; if (i < n) t[k] = mtb_ph_jump_step(jump, i); }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < MTB_SCORE_MAXPER; k++) { int32_t i = lane + 64 * k; if (i < n) jump[i] = t[k]; }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int k = 0; k < MTB_SCORE_MAXPER; k++) { int32_t i = lane + 64 * k; if (i < n) t[k] = jump[i]; }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < MTB_SCORE_MAXPER; k++) { int32_t i = lane + 64 * k; if (i < n) w.path[i] = mtb_ph_jump_final(w, i, t[k]); }
+        __syncthreads();
+    } else if (n <= 64 * MTB_SCORE_MAXPER) {
         /* register-cached round state: idle lanes touch no memory in a round */
         int32_t c_rk[MTB_SCORE_MAXPER]; uint32_t c_sh[MTB_SCORE_MAXPER], c_cm[MTB_SCORE_MAXPER], c_reh[MTB_SCORE_MAXPER]; int32_t c_pl[MTB_SCORE_MAXPER];
 #pragma unroll
@@ -305,6 +329,11 @@ __global__ __launch_bounds__(64) void k_score(const REC *__restrict__ matches, c
     __shared__ uint8_t s_bham[MTB_SCORE_BKT];
     __shared__ int32_t s_lev[MTB_LR_MAXE];
     __shared__ int32_t s_anc[MTB_LR_MAXE * MTB_LR_K];
+#ifdef MTB_EXP_HALF_OCCUPANCY
+    __shared__ uint32_t s_dummy[4096];
+    if (n_reads == 0xFFFFFFFFFFull) s_dummy[threadIdx.x] = 1;   /* keep the allocation alive */
+    if (n_reads == 0xFFFFFFFFFEull) results[0].classification = (int32_t)s_dummy[threadIdx.x ^ 1];
+#endif
     const uint32_t lane = threadIdx.x;
     for (uint64_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
         const uint64_t s0 = seg_start[r];

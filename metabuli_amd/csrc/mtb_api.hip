@@ -610,8 +610,8 @@ mtb_status mtb_classify_batch_device(mtb_ctx *c, mtb_index *ix, const mtb_params
         HIPCHK(hipMemsetAsync(d_rc, 0, n_reads * 4, st));
     }
     HIPCHK(hipEventRecord(c->ev[3], st));
-    mtb_match32 *d_m; uint64_t *d_seg;       /* one 32-byte sector per record: full-sector scattered stores */
-    STCHK(ensure(c, "matches32", nm, &d_m));
+    mtb_match *d_m; uint64_t *d_seg;
+    STCHK(ensure(c, "matches", nm, &d_m));
     STCHK(dev_regroup(c, d_tmp, nm, n_reads, d_rc, &d_seg, d_m));
     HIPCHK(hipEventRecord(c->ev[4], st));
     /* segments that fit LDS are sorted inside k_score; only the big ones are sorted in HBM here */
@@ -623,7 +623,7 @@ mtb_status mtb_classify_batch_device(mtb_ctx *c, mtb_index *ix, const mtb_params
         { KTimer kt(c, MTB_K_SEGSORT);
         hipLaunchKernelGGL(k_list_large, dim3((uint32_t)((n_reads + 255) / 256)), dim3(256), 0, st, (const uint64_t *)d_seg, n_reads,
                            (uint32_t)MTB_SCORE_LDS, d_large, (uint32_t *)(c->d_scal + 2), (uint32_t *)(c->d_scal + 3));
-        hipLaunchKernelGGL((k_segsort_large<mtb_match32>), dim3(1024), dim3(256), 0, st, d_m, (const uint64_t *)d_seg, (const uint32_t *)d_large,
+        hipLaunchKernelGGL((k_segsort_large<mtb_match>), dim3(1024), dim3(256), 0, st, d_m, (const uint64_t *)d_seg, (const uint32_t *)d_large,
                            (const uint32_t *)(c->d_scal + 2)); }
         uint64_t sc[2];
         STCHK(d2h(c, sc, c->d_scal + 2, 16));

@@ -359,4 +359,59 @@ MTB_HD int32_t mtb_lr_bfs(const int32_t *lev, const int32_t *anc, const uint32_t
     return root;
 }
 
+/* ---- chain DP by pointer doubling -----------------------------------------
+ * When every match has at most one consecutive predecessor (cmask has <= 1 bit
+ * and no SLOW group) the DP of getMatchPaths is a forest of chains:
+ *   V[i] = V[pred[i]] + (score, hamming, depth) increment of i,   V[root] = fresh path.
+ * Scores are sums of multiples of 0.5 (exact in fp32), hamming / depth are
+ * integers, so the fold is associative: ceil(log2(max rank + 1)) doubling steps
+ * give bit-identical paths.  jump[] lives in the storage of path[] (16 B <= 24 B
+ * per match); the final paths are rebuilt from the roots' matches.          */
+typedef struct { int32_t ptr; float score; int32_t ham; int32_t depth; } mtb_jump;
+
+/* true if match i allows the chain formulation */
+template <typename IDX>
+MTB_HD bool mtb_chain_simple(const mtb_sws<IDX> &w, int32_t i) {
+    uint32_t sh = w.shift[i], cm = w.cmask[i];
+    if (sh & MTB_SHIFT_SLOW) return false;
+    return (cm & (cm - 1u)) == 0;
+}
+template <typename IDX>
+MTB_HD void mtb_ph_jump_init(const mtb_sws<IDX> &w, int32_t i, mtb_jump *jump) {
+    uint32_t sh = w.shift[i], cm = w.cmask[i];
+    mtb_jump j; j.ptr = -1; j.score = 0.0f; j.ham = 0; j.depth = 0;
+    if (sh && cm) {
+        int32_t k = 0; while (!((cm >> k) & 1u)) k++;
+        int32_t shift = (int32_t)(sh & 0x7Fu);
+        uint32_t reh = w.m[i].right_end_hamming;
+        j.ptr = (int32_t)w.bid[i] + k;
+        j.score = mtb_part_score(reh, shift, false);
+        j.ham = mtb_part_ham(reh, shift, false);
+        j.depth = shift;
+    }
+    jump[i] = j;
+}
+/* one doubling step, read half: returns the new value of jump[i] */
+MTB_HD mtb_jump mtb_ph_jump_step(const mtb_jump *jump, int32_t i) {
+    mtb_jump j = jump[i];
+    if (j.ptr >= 0) {
+        mtb_jump p = jump[j.ptr];
+        if (p.ptr >= 0) { j.score += p.score; j.ham += p.ham; j.depth += p.depth; j.ptr = p.ptr; }
+    }
+    return j;
+}
+/* final path of match i from its resolved jump record (ptr = root or -1) */
+template <typename IDX>
+MTB_HD mtb_path mtb_ph_jump_final(const mtb_sws<IDX> &w, int32_t i, const mtb_jump &j) {
+    const mtb_match *m = w.m;
+    int32_t r = j.ptr >= 0 ? j.ptr : i;
+    mtb_path p;
+    p.start = (int32_t)mtb_q_pos(m[r].qinfo);
+    p.end = (int32_t)mtb_q_pos(m[i].qinfo) + 23;
+    p.score = mtb_part_score(m[r].right_end_hamming, 8, false) + (j.ptr >= 0 ? j.score : 0.0f);
+    p.ham = (int32_t)m[r].hamming + (j.ptr >= 0 ? j.ham : 0);
+    p.depth = 1 + (j.ptr >= 0 ? j.depth : 0);
+    p.start_idx = r;
+    return p;
+}
 #endif

@@ -125,7 +125,9 @@ size_t emu_score(const int32_t *canon, const int32_t *parent, const int32_t *dep
 // mtb_score_par.h run in plain loops (one loop == one lane-strided phase + barrier)
 size_t emu_score_par(const int32_t *canon, const int32_t *parent, const int32_t *depth, const uint8_t *under_euk, const int32_t *sp_parent,
                      int32_t max_taxid, const mtb_params *p, const mtb_match *ml_in, size_t nM, size_t n_reads, const int32_t *qlen,
-                     const int32_t *qlen2, mtb_result *res, int32_t *tc_tax, uint32_t *tc_cnt, size_t cap, int presorted) {
+                     const int32_t *qlen2, mtb_result *res, int32_t *tc_tax, uint32_t *tc_cnt, size_t cap, int presorted, int use_chain,
+                     size_t *n_chain_out) {
+    size_t n_chain_reads = 0;
     mtb_tax_view tx{canon, parent, depth, under_euk, sp_parent, max_taxid};
     mtb_score_params sp; mtb_make_score_params(p, &sp);
     for (size_t r = 0; r < n_reads; r++) { res[r] = mtb_result{0, 0.f, qlen[r], qlen2 ? qlen2[r] : 0, 0, 0, 0, 0}; }
@@ -168,6 +170,20 @@ size_t emu_score_par(const int32_t *canon, const int32_t *parent, const int32_t 
             for (int32_t i = 0; i < n; i++) { mtb_ph_links(w, i, &tx, &sp, ng, nbk); }
             for (int32_t i = 0; i < n; i++) maxrank = std::max<int32_t>(maxrank, w.rk[i]);
         }
+        bool simple = use_chain != 0;
+        for (int32_t i = 0; i < n; i++) simple = simple && mtb_chain_simple(w, i);
+        if (simple) {       // pointer doubling (jump[] aliases the path storage, as in the kernel)
+            mtb_jump *jump = (mtb_jump *)w.path;
+            for (int32_t i = 0; i < n; i++) mtb_ph_jump_init(w, i, jump);
+            std::vector<mtb_jump> tmp((size_t)n);
+            for (int32_t span = 1; span <= maxrank; span <<= 1) {
+                for (int32_t i = 0; i < n; i++) tmp[(size_t)i] = mtb_ph_jump_step(jump, i);
+                for (int32_t i = 0; i < n; i++) jump[i] = tmp[(size_t)i];
+            }
+            for (int32_t i = 0; i < n; i++) tmp[(size_t)i] = jump[i];
+            for (int32_t i = 0; i < n; i++) w.path[i] = mtb_ph_jump_final(w, i, tmp[(size_t)i]);
+            n_chain_reads++;
+        } else
         for (int32_t rr = 1; rr <= maxrank; rr++) for (int32_t i = 0; i < n; i++) mtb_ph_round(w, i, rr, &sp);
         // emit + compaction (elist = gid array, prefix = rk array)
         IDX *elist = w.gid, *ec = w.rk;
@@ -213,6 +229,7 @@ size_t emu_score_par(const int32_t *canon, const int32_t *parent, const int32_t 
         }
         res[r] = R;
     }
+    if (n_chain_out) *n_chain_out = n_chain_reads;
     return wout;
 }
 

@@ -232,14 +232,17 @@ class Emu:
         return res, tt[:n].copy(), tc[:n].copy()
 
 
-def _emu_score_par(self, taxarr, p, m, n_reads, ql, ql2, presorted=True):
+def _emu_score_par(self, taxarr, p, m, n_reads, ql, ql2, presorted=True, use_chain=True):
     canon, parent, depth, under_euk, sp_parent = taxarr
     res = np.zeros(n_reads, result_dt)
     cap = max(1024, len(m) + 16)
     tt = np.zeros(cap, np.int32); tc = np.zeros(cap, np.uint32)
+    nchain = C.c_size_t(0)
     n = self.lib.emu_score_par(_ptr(canon), _ptr(parent), _ptr(depth), _ptr(under_euk), _ptr(sp_parent), C.c_int32(len(parent) - 1),
                                C.byref(p), _ptr(m), C.c_size_t(len(m)), C.c_size_t(n_reads), _ptr(ql), _ptr(ql2),
-                               _ptr(res), _ptr(tt), _ptr(tc), C.c_size_t(cap), C.c_int(1 if presorted else 0))
+                               _ptr(res), _ptr(tt), _ptr(tc), C.c_size_t(cap), C.c_int(1 if presorted else 0),
+                               C.c_int(1 if use_chain else 0), C.byref(nchain))
+    self.last_chain_reads = nchain.value
     return res, tt[:n].copy(), tc[:n].copy()
 
 

@@ -104,6 +104,10 @@ def test_score_parallel_phases_equal_oracle(toy, orc, emu):
     sh = m[np.lexsort((rng.random(len(m)), seqs))]
     res, tt, tc = emu.score_par(ta, toy.p, sh, toy.n_reads, toy.ref["qlen"], toy.ref["qlen2"], presorted=False)
     _same_results(toy, res, tt, tc)
+    assert emu.last_chain_reads > 0           # the pointer-doubling path is exercised ...
+    res2, tt2, tc2 = emu.score_par(ta, toy.p, sh, toy.n_reads, toy.ref["qlen"], toy.ref["qlen2"], presorted=False, use_chain=False)
+    assert emu.last_chain_reads == 0          # ... and equals the round-by-round DP bit for bit
+    assert (res2 == res).all() and (tt2 == tt).all() and (tc2 == tc).all()
 
 
 @pytest.mark.parametrize("kw", [dict(min_score=0.2), dict(min_sp_score=0.9), dict(tie_ratio=0.5), dict(min_cons_cnt=2, min_cons_cnt_euk=3),
