@@ -323,12 +323,9 @@ __global__ __launch_bounds__(64) void k_score(const REC *__restrict__ matches, c
                                                uint64_t slab_bytes, uint32_t slab_max_n, uint32_t slab_max_nb,
                                                mtb_match *__restrict__ sorted_out) {
     __shared__ __attribute__((aligned(16))) uint8_t s_ws[MTB_SCORE_WS_BYTES];
-    __shared__ int32_t s_btax[MTB_SCORE_BKT];
-    __shared__ int32_t s_otax[MTB_SCORE_BKT];
-    __shared__ uint32_t s_ocnt[MTB_SCORE_BKT];
-    __shared__ uint8_t s_bham[MTB_SCORE_BKT];
-    __shared__ int32_t s_lev[MTB_LR_MAXE];
-    __shared__ int32_t s_anc[MTB_LR_MAXE * MTB_LR_K];
+    /* bucket / taxCnt / chain arrays of the decide phase live in the path storage,
+     * which is dead once the species scores exist (keeps LDS per wave small -> occupancy) */
+    static_assert(MTB_SCORE_LDS * sizeof(mtb_path) >= MTB_SCORE_BKT * 13 + (MTB_LR_MAXE + MTB_LR_MAXE * MTB_LR_K) * 4, "decide arrays must fit the path area");
 #ifdef MTB_EXP_HALF_OCCUPANCY
     __shared__ uint32_t s_dummy[4096];
     if (n_reads == 0xFFFFFFFFFFull) s_dummy[threadIdx.x] = 1;   /* keep the allocation alive */
@@ -350,6 +347,10 @@ __global__ __launch_bounds__(64) void k_score(const REC *__restrict__ matches, c
         if (!big) {
             mtb_sws<uint16_t> w;
             mtb_sws_carve<uint16_t>(&w, s_ws, MTB_SCORE_LDS);
+            int32_t *s_btax = (int32_t *)w.path, *s_otax = s_btax + MTB_SCORE_BKT;
+            uint32_t *s_ocnt = (uint32_t *)(s_otax + MTB_SCORE_BKT);
+            int32_t *s_lev = (int32_t *)(s_ocnt + MTB_SCORE_BKT), *s_anc = s_lev + MTB_LR_MAXE;
+            uint8_t *s_bham = (uint8_t *)(s_anc + MTB_LR_MAXE * MTB_LR_K);
             score_read_par<uint16_t, SORT, KEY64, REC>(matches + s0, n, w, s_btax, s_bham, s_otax, s_ocnt, s_lev, s_anc, nb, read_len, tx, sp, off, room,
                                            tc_tax, tc_cnt, tc_cap, sorted_out ? sorted_out + s0 : nullptr, R);
         } else {
