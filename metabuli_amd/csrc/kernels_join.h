@@ -76,6 +76,7 @@ __global__ __launch_bounds__(256) void k_join(const mtb_kmer *__restrict__ q, ui
     __shared__ uint32_t s_red[4];
     __shared__ unsigned long long s_base;
     __shared__ uint64_t s_win[MTB_JOIN_WIN];
+    __shared__ uint64_t s_mm[8];
     for (uint32_t i = threadIdx.x; i < sizeof(mtb_tables) / 4; i += 256) ((uint32_t *)&s_tab)[i] = ((const uint32_t *)tabs)[i];
     const uint64_t base = (uint64_t)blockIdx.x * MTB_JOIN_QPB;
     const uint64_t last = (base + MTB_JOIN_QPB <= n ? base + MTB_JOIN_QPB : n) - 1;
@@ -89,9 +90,24 @@ __global__ __launch_bounds__(256) void k_join(const mtb_kmer *__restrict__ q, ui
         if (valid[u]) { k[u] = q[j]; valid[u] = mtb_q_seq(k[u].qinfo) != 0; }   /* blank slots carry sequenceID 0 */
         else { k[u].value = 0; k[u].qinfo = 0; }
     }
-    /* target window of the tile: [lower_bound(AA(first)), lower_bound(AA(last) + 1)) */
-    const uint64_t keyA = q[base].value & ~0xFFFFFFull;
-    const uint64_t keyB = (q[last].value & ~0xFFFFFFull) + (1ull << 24);
+    /* target window of the tile: [lower_bound(min AA), lower_bound(max AA + 1)).  The tile
+     * need not be sorted internally (the fused path radix-sorts only the top 24 bits): the
+     * bounds are the block-wide minimum / maximum of the amino-acid parts. */
+    uint64_t mn = ~0ull, mx = 0;
+#pragma unroll
+    for (int u = 0; u < MTB_JOIN_QPT; u++) if (valid[u]) { uint64_t a = k[u].value & ~0xFFFFFFull; mn = a < mn ? a : mn; mx = a > mx ? a : mx; }
+    for (int d = 32; d > 0; d >>= 1) {
+        uint64_t om = __shfl_xor(mn, d, 64), ox = __shfl_xor(mx, d, 64);
+        mn = om < mn ? om : mn; mx = ox > mx ? ox : mx;
+    }
+    if (lane_id() == 0) { s_mm[(threadIdx.x >> 6) * 2] = mn; s_mm[(threadIdx.x >> 6) * 2 + 1] = mx; }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 4; w++) { uint64_t a = s_mm[2 * w], b = s_mm[2 * w + 1]; mn = a < mn ? a : mn; mx = b > mx ? b : mx; }
+    (void)last;
+    if (mn > mx) return;                                  /* no valid query in this tile (uniform) */
+    const uint64_t keyA = mn;
+    const uint64_t keyB = mx + (1ull << 24);
     uint64_t lo, hi;
     block_kary_lower_bound2(ix.values, limit, keyA, keyB, &lo, &hi, s_red);
     const uint64_t span = hi - lo;

@@ -30,7 +30,12 @@ __device__ unsigned long long mtb_phase_cycles[4];
 #define MTB_PHASE_MARK(k) do {} while (0)
 #endif
 
-#define MTB_SCORE_LDS 192        /* matches per read staged in LDS            */
+#ifndef MTB_SCORE_LDS
+#define MTB_SCORE_LDS 160        /* matches per read staged in LDS (10.8 KB/wave -> 14 waves/CU; sweep in profiles/r01_notes.md) */
+#endif
+#ifndef MTB_SCORE_MINWAVES
+#define MTB_SCORE_MINWAVES 4      /* <= 128 VGPRs: occupancy beats the ~90 B/lane of spills (measured) */
+#endif
 #define MTB_SCORE_BKT 128        /* position buckets / taxCnt entries in LDS  */
 
 /* bytes of slab one workgroup needs for a segment of n matches, nb buckets */
@@ -315,7 +320,7 @@ __device__ __forceinline__ void score_read_par(const REC *__restrict__ src, int3
  * already be sorted in HBM (k_segsort_large).                               */
 #define MTB_SCORE_WS_BYTES ((MTB_SCORE_LDS * (24 + 24 + 3) + (MTB_SCORE_LDS + 1) * 8 * 2 + 64 + 15) & ~15)
 template <bool SORT, bool KEY64, typename REC>
-__global__ __launch_bounds__(64) void k_score(const REC *__restrict__ matches, const uint64_t *__restrict__ seg_start,
+__global__ __launch_bounds__(64, MTB_SCORE_MINWAVES) void k_score(const REC *__restrict__ matches, const uint64_t *__restrict__ seg_start,
                                                uint64_t n_reads, const int32_t *__restrict__ qlen, const int32_t *__restrict__ qlen2,
                                                mtb_tax_view tx, mtb_score_params sp, const uint64_t *__restrict__ tc_off,
                                                mtb_result *__restrict__ results, int32_t *__restrict__ tc_tax,

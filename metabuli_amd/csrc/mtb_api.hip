@@ -591,9 +591,10 @@ mtb_status mtb_classify_batch_device(mtb_ctx *c, mtb_index *ix, const mtb_params
     mtb_kmer *d_k; uint64_t nk; uint32_t max_len = 0;
     STCHK(dev_extract(c, p, d_bases, d_offs, d_bases2, d_offs2, n_reads, &d_k, &nk, d_ql, d_ql2, &max_len));
     HIPCHK(hipEventRecord(c->ev[1], st));
-    /* the join only needs queries grouped by amino-acid part: sort bits [24,64) */
+    /* the join needs tiles with a narrow amino-acid range, not a total order: sort the top
+     * 24 bits only (3 passes); the tile bounds come from a block-wide min/max in k_join */
     mtb_kmer *d_s;
-    STCHK(dev_sort(c, d_k, nk, 24, &d_s));
+    STCHK(dev_sort(c, d_k, nk, 40, &d_s));
     HIPCHK(hipEventRecord(c->ev[2], st));
     uint32_t *d_rc;
     STCHK(ensure(c, "readcnt", n_reads, &d_rc));
