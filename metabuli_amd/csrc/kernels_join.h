@@ -1,12 +1,14 @@
 /* kernels_join.h -- sorted-merge lookup of the query metamers against the flat
  * target index resident in HBM, and the regrouping of matches by read.
  *
- * k_join: one lane per sorted query metamer.  Neighbouring lanes hold
- * neighbouring values, so the binary searches of a wavefront walk the same
- * upper levels (served by L2 / Infinity Cache) and end in adjacent 64-bit
- * words of the index (coalesced loads).  Two-phase selection per query
- * (min Hamming, threshold min(2*min,7)), workgroup scan of the counts, ONE
- * atomic per workgroup to reserve output, then emit.  Functional form of
+ * k_join_bounds finds, for every tile of 512 sorted query metamers, the slice
+ * of the target index that holds the tile's amino-acid range (one lane per
+ * tile).  k_join stages that slice in LDS with coalesced 64-bit loads (32 KB
+ * window; slices that do not fit are searched in place), every lane then
+ * locates its query's amino-acid run in the window by binary search in LDS and
+ * applies the two-phase selection (min Hamming, threshold min(2*min,7));
+ * workgroup scan of the counts, ONE atomic per workgroup to reserve output,
+ * then emit.  Functional form of
  * KmerMatcher::matchKmers (src/commons/KmerMatcher.cpp:123-481) + compareDna
  * (:1117-1146); the per-read match counters it also feeds replace the global
  * comparison sort of matches by sequenceID (sortMatches, :1071-1078).
@@ -26,61 +28,42 @@ __device__ __forceinline__ const mtb_match &rec_m(const mtb_match32 &r) { return
 __device__ __forceinline__ void rec_set(mtb_match &r, const mtb_match &m) { r = m; }
 __device__ __forceinline__ void rec_set(mtb_match32 &r, const mtb_match &m) { r.m = m; r.pad = 0; }
 
+#ifndef MTB_JOIN_QPT
 #define MTB_JOIN_QPT 2                      /* queries per thread                              */
+#endif
 #define MTB_JOIN_QPB (256 * MTB_JOIN_QPT)   /* sorted queries per workgroup                     */
+#ifndef MTB_JOIN_WIN
 #define MTB_JOIN_WIN 4096                   /* target values staged in LDS (32 KB)              */
+#endif
 
-/* block-wide count of a predicate pair (A in the low, B in the high half) */
-__device__ __forceinline__ void block_count2(bool a, bool b, uint32_t *s_red, uint32_t *ca, uint32_t *cb) {
-    uint32_t wa = (uint32_t)__popcll(__ballot(a)), wb = (uint32_t)__popcll(__ballot(b));
-    __syncthreads();
-    if (lane_id() == 0) s_red[threadIdx.x >> 6] = wa | (wb << 16);
-    __syncthreads();
-    uint32_t t = s_red[0] + s_red[1] + s_red[2] + s_red[3];
-    *ca = t & 0xFFFFu; *cb = t >> 16;
-}
-
-/* Two lower bounds (keyA <= keyB) in the sorted array v[0..n) by a 256-ary
- * cooperative search: every step all 256 lanes probe one position each, so a
- * 2^33-entry index is bounded in 5 dependent memory steps instead of 33.    */
-__device__ __forceinline__ void block_kary_lower_bound2(const uint64_t *__restrict__ v, uint64_t n, uint64_t keyA, uint64_t keyB,
-                                                        uint64_t *outA, uint64_t *outB, uint32_t *s_red) {
-    uint64_t lA = 0, rA = n, lB = 0, rB = n;
-    const uint64_t t = threadIdx.x;
-    while (rA > lA || rB > lB) {
-        uint64_t lenA = rA - lA, lenB = rB - lB;
-        uint64_t stA = (lenA + 255) >> 8, stB = (lenB + 255) >> 8;
-        uint64_t pA = lA + t * stA, pB = lB + t * stB;
-        bool a = lenA && pA < rA && v[pA] < keyA;
-        bool b = lenB && pB < rB && v[pB] < keyB;
-        uint32_t cA, cB;
-        block_count2(a, b, s_red, &cA, &cB);
-        if (lenA) {
-            if (stA == 1) { lA = rA = lA + cA; }
-            else { uint64_t nl = cA ? lA + (uint64_t)(cA - 1) * stA + 1 : lA; uint64_t nr = lA + (uint64_t)cA * stA; rA = nr < rA ? nr : rA; lA = nl; }
-        }
-        if (lenB) {
-            if (stB == 1) { lB = rB = lB + cB; }
-            else { uint64_t nl = cB ? lB + (uint64_t)(cB - 1) * stB + 1 : lB; uint64_t nr = lB + (uint64_t)cB * stB; rB = nr < rB ? nr : rB; lB = nl; }
-        }
-    }
-    *outA = lA; *outB = lB;
+/* Target window of every query tile, one lane per tile: the tile is sorted at
+ * least on its top 32 bits, so its amino-acid range lies inside
+ * [first & ~(2^32-1), (last | (2^32-1)) + 1).  Two binary searches per tile,
+ * all tiles in parallel: the 33 dependent loads of a search are paid once per
+ * tile here instead of serialising every workgroup of k_join.               */
+__global__ __launch_bounds__(256) void k_join_bounds(const mtb_kmer *__restrict__ q, uint64_t n, const uint64_t *__restrict__ values,
+                                                      uint64_t limit, uint64_t n_tiles, uint64_t *__restrict__ bounds) {
+    uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_tiles) return;
+    uint64_t base = t * MTB_JOIN_QPB;
+    uint64_t last = (base + MTB_JOIN_QPB <= n ? base + MTB_JOIN_QPB : n) - 1;
+    uint64_t ka = q[base].value & ~0xFFFFFFFFull;
+    uint64_t kb = q[last].value | 0xFFFFFFFFull;
+    uint64_t lo = mtb_lower_bound(values, limit, ka);
+    uint64_t hi = (kb == ~0ull) ? limit : mtb_lower_bound(values, limit, kb + 1);
+    bounds[2 * t] = lo; bounds[2 * t + 1] = hi;
 }
 
 __global__ __launch_bounds__(256) void k_join(const mtb_kmer *__restrict__ q, uint64_t n, mtb_index_view ix,
-                                               const mtb_tables *__restrict__ tabs, mtb_match *__restrict__ out,
-                                               uint64_t cap, unsigned long long *__restrict__ counter,
+                                               const mtb_tables *__restrict__ tabs, const uint64_t *__restrict__ bounds,
+                                               mtb_match *__restrict__ out, uint64_t cap, unsigned long long *__restrict__ counter,
                                                uint32_t *__restrict__ read_cnt, uint32_t *__restrict__ overflow) {
     __shared__ mtb_tables s_tab;
     __shared__ uint32_t s_tmp[8];
-    __shared__ uint32_t s_red[4];
     __shared__ unsigned long long s_base;
     __shared__ uint64_t s_win[MTB_JOIN_WIN];
-    __shared__ uint64_t s_mm[8];
     for (uint32_t i = threadIdx.x; i < sizeof(mtb_tables) / 4; i += 256) ((uint32_t *)&s_tab)[i] = ((const uint32_t *)tabs)[i];
     const uint64_t base = (uint64_t)blockIdx.x * MTB_JOIN_QPB;
-    const uint64_t last = (base + MTB_JOIN_QPB <= n ? base + MTB_JOIN_QPB : n) - 1;
-    const uint64_t limit = ix.n_targets ? ix.n_targets - 1 : 0;          /* the last index entry is never a candidate */
     mtb_kmer k[MTB_JOIN_QPT];
     bool valid[MTB_JOIN_QPT];
 #pragma unroll
@@ -90,26 +73,7 @@ __global__ __launch_bounds__(256) void k_join(const mtb_kmer *__restrict__ q, ui
         if (valid[u]) { k[u] = q[j]; valid[u] = mtb_q_seq(k[u].qinfo) != 0; }   /* blank slots carry sequenceID 0 */
         else { k[u].value = 0; k[u].qinfo = 0; }
     }
-    /* target window of the tile: [lower_bound(min AA), lower_bound(max AA + 1)).  The tile
-     * need not be sorted internally (the fused path radix-sorts only the top 24 bits): the
-     * bounds are the block-wide minimum / maximum of the amino-acid parts. */
-    uint64_t mn = ~0ull, mx = 0;
-#pragma unroll
-    for (int u = 0; u < MTB_JOIN_QPT; u++) if (valid[u]) { uint64_t a = k[u].value & ~0xFFFFFFull; mn = a < mn ? a : mn; mx = a > mx ? a : mx; }
-    for (int d = 32; d > 0; d >>= 1) {
-        uint64_t om = __shfl_xor(mn, d, 64), ox = __shfl_xor(mx, d, 64);
-        mn = om < mn ? om : mn; mx = ox > mx ? ox : mx;
-    }
-    if (lane_id() == 0) { s_mm[(threadIdx.x >> 6) * 2] = mn; s_mm[(threadIdx.x >> 6) * 2 + 1] = mx; }
-    __syncthreads();
-#pragma unroll
-    for (int w = 0; w < 4; w++) { uint64_t a = s_mm[2 * w], b = s_mm[2 * w + 1]; mn = a < mn ? a : mn; mx = b > mx ? b : mx; }
-    (void)last;
-    if (mn > mx) return;                                  /* no valid query in this tile (uniform) */
-    const uint64_t keyA = mn;
-    const uint64_t keyB = mx + (1ull << 24);
-    uint64_t lo, hi;
-    block_kary_lower_bound2(ix.values, limit, keyA, keyB, &lo, &hi, s_red);
+    const uint64_t lo = bounds[2 * (uint64_t)blockIdx.x], hi = bounds[2 * (uint64_t)blockIdx.x + 1];
     const uint64_t span = hi - lo;
     const bool in_lds = span <= MTB_JOIN_WIN;
     if (in_lds) for (uint64_t i = threadIdx.x; i < span; i += 256) s_win[i] = ix.values[lo + i];      /* coalesced 64-bit loads */

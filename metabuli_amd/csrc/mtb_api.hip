@@ -245,9 +245,14 @@ static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint6
     if (n == 0) return MTB_OK;
     HIPCHK(hipMemsetAsync(c->d_scal, 0, 16, c->stream));
     uint32_t grid = (uint32_t)((n + MTB_JOIN_QPB - 1) / MTB_JOIN_QPB);
+    uint64_t *d_bounds;
+    STCHK(ensure(c, "jbounds", 2ull * grid, &d_bounds));
+    uint64_t limit = ix->T ? ix->T - 1 : 0;          /* the last index entry is never a candidate */
     { KTimer kt(c, MTB_K_JOIN);
-    hipLaunchKernelGGL(k_join, dim3(grid), dim3(256), 0, c->stream, d_q, n, index_view(ix), (const mtb_tables *)c->d_tabs, d_out, cap,
-                       (unsigned long long *)c->d_scal, d_read_cnt, (uint32_t *)(c->d_scal + 1)); }
+    hipLaunchKernelGGL(k_join_bounds, dim3((grid + 255) / 256), dim3(256), 0, c->stream, d_q, n, (const uint64_t *)ix->d_values, limit,
+                       (uint64_t)grid, d_bounds);
+    hipLaunchKernelGGL(k_join, dim3(grid), dim3(256), 0, c->stream, d_q, n, index_view(ix), (const mtb_tables *)c->d_tabs,
+                       (const uint64_t *)d_bounds, d_out, cap, (unsigned long long *)c->d_scal, d_read_cnt, (uint32_t *)(c->d_scal + 1)); }
     HIPCHK(hipGetLastError());
     uint64_t sc[2];
     STCHK(d2h(c, sc, c->d_scal, 16));
@@ -592,9 +597,10 @@ mtb_status mtb_classify_batch_device(mtb_ctx *c, mtb_index *ix, const mtb_params
     STCHK(dev_extract(c, p, d_bases, d_offs, d_bases2, d_offs2, n_reads, &d_k, &nk, d_ql, d_ql2, &max_len));
     HIPCHK(hipEventRecord(c->ev[1], st));
     /* the join needs tiles with a narrow amino-acid range, not a total order: sort the top
-     * 24 bits only (3 passes); the tile bounds come from a block-wide min/max in k_join */
+     * 32 bits only (4 passes; 3 passes make the tiles too wide for the LDS window, measured);
+     * the tile bounds come from a block-wide min/max in k_join */
     mtb_kmer *d_s;
-    STCHK(dev_sort(c, d_k, nk, 40, &d_s));
+    STCHK(dev_sort(c, d_k, nk, 32, &d_s));
     HIPCHK(hipEventRecord(c->ev[2], st));
     uint32_t *d_rc;
     STCHK(ensure(c, "readcnt", n_reads, &d_rc));
