@@ -23,11 +23,16 @@
  * accumulated into mtb_phase_cycles[4] = {stage+sort, paths, combine, decide} */
 #ifdef MTB_SCORE_PHASE_CYCLES
 __device__ unsigned long long mtb_phase_cycles[4];
+__shared__ unsigned long long mtb_phase_lds[4];      /* per-workgroup accumulators, flushed once at kernel end */
 #define MTB_PHASE_BEGIN() unsigned long long ph_t0_ = __builtin_readcyclecounter()
-#define MTB_PHASE_MARK(k) do { unsigned long long t_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&mtb_phase_cycles[k], t_ - ph_t0_); ph_t0_ = t_; } while (0)
+#define MTB_PHASE_MARK(k) do { unsigned long long t_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) mtb_phase_lds[k] += t_ - ph_t0_; ph_t0_ = t_; } while (0)
+#define MTB_PHASE_KERNEL_BEGIN() do { if (threadIdx.x < 4) mtb_phase_lds[threadIdx.x] = 0; __syncthreads(); } while (0)
+#define MTB_PHASE_KERNEL_END() do { __syncthreads(); if (threadIdx.x < 4) atomicAdd(&mtb_phase_cycles[threadIdx.x], mtb_phase_lds[threadIdx.x]); } while (0)
 #else
 #define MTB_PHASE_BEGIN() do {} while (0)
 #define MTB_PHASE_MARK(k) do {} while (0)
+#define MTB_PHASE_KERNEL_BEGIN() do {} while (0)
+#define MTB_PHASE_KERNEL_END() do {} while (0)
 #endif
 
 #ifndef MTB_SCORE_LDS
@@ -105,8 +110,40 @@ __device__ __forceinline__ void score_read_par(const REC *__restrict__ src, int3
             }
         }
         __syncthreads();
-        {
-            const int32_t nslot = (n + 63) >> 6;          /* live register slots (wave-uniform) */
+        const int32_t nslot = (n + 63) >> 6;          /* live register slots (wave-uniform) */
+        bool unique = true;
+        if (KEY64) {
+            /* fast path: rank = number of strictly smaller keys (2 VALU per comparison).  Keys are
+             * distinct unless the index holds duplicate entries; equal keys are detected below. */
+            int32_t j = 0;
+            for (; j + 4 <= n; j += 4) {
+                uint64_t b1[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) b1[u] = k1[j + u];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+#pragma unroll
+                    for (int k = 0; k < MTB_SCORE_MAXPER; k++) if (k < nslot) rank[k] += (b1[u] < a1[k]);
+                }
+            }
+            for (; j < n; j++) {
+                uint64_t b1 = k1[j];
+#pragma unroll
+                for (int k = 0; k < MTB_SCORE_MAXPER; k++) rank[k] += (b1 < a1[k]);
+            }
+            /* two equal keys get the same rank: then some key differs from the one stored at its rank */
+            __syncthreads();
+            uint64_t *chk = (uint64_t *)w.m;          /* m[] is not written yet */
+#pragma unroll
+            for (int k = 0; k < MTB_SCORE_MAXPER; k++) { int32_t i = lane + 64 * k; if (i < n) chk[rank[k]] = (uint64_t)i; }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < MTB_SCORE_MAXPER; k++) { int32_t i = lane + 64 * k; if (i < n && chk[rank[k]] != (uint64_t)i) unique = false; }
+            unique = __all(unique);
+        }
+        if (!KEY64 || !unique) {
+#pragma unroll
+            for (int k = 0; k < MTB_SCORE_MAXPER; k++) rank[k] = 0;
             int32_t j = 0;
             for (; j + 4 <= n; j += 4) {                  /* 4 independent LDS reads in flight */
                 uint64_t b1[4]; uint32_t b2[4];
@@ -337,6 +374,7 @@ __global__ __launch_bounds__(64, MTB_SCORE_MINWAVES) void k_score(const REC *__r
     if (n_reads == 0xFFFFFFFFFEull) results[0].classification = (int32_t)s_dummy[threadIdx.x ^ 1];
 #endif
     const uint32_t lane = threadIdx.x;
+    MTB_PHASE_KERNEL_BEGIN();
     for (uint64_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
         const uint64_t s0 = seg_start[r];
         const int32_t n = (int32_t)(seg_start[r + 1] - s0);
@@ -380,6 +418,7 @@ __global__ __launch_bounds__(64, MTB_SCORE_MINWAVES) void k_score(const REC *__r
         }
         if (lane == 0) { R.query_length = ql1; R.query_length2 = ql2; R.reserved = 0; results[r] = R; }
     }
+    MTB_PHASE_KERNEL_END();
 }
 
 #endif
