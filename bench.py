@@ -140,6 +140,7 @@ def main():
     ap.add_argument("--cpu-reads", type=int, default=100_000)
     ap.add_argument("--cpu-targets", type=float, default=16e6)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--seq-mode", type=int, default=1, choices=[1, 3], help="1 = short single-end (configs[1]); 3 = long reads (configs[2])")
     ap.add_argument("--seed", type=int, default=1234)
     args = ap.parse_args()
 
@@ -156,7 +157,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
     import metabuli_amd as M
     ctx = M.Context(local_rank)
-    params = M.default_params(seq_mode=1, syncmer=1, smer_len=5)
+    params = M.default_params(seq_mode=args.seq_mode, syncmer=1, smer_len=5)
 
     t_setup = time.perf_counter()
     world = build_world(args.seed, args.species, args.genome_len, args.filler_species)
@@ -176,7 +177,7 @@ def main():
     index = ctx.index_from_device(d_values.data_ptr(), d_info.data_ptr(), T, taxdir, taxid_list, params)
     d_bases, d_offs = gen_reads(torch, dev, world, args.reads, args.read_len, 0.10, 0.005, args.seed + 17 * (rank + 1))
     d_res = torch.empty(args.reads * 24, dtype=torch.uint8, device=dev)
-    tc_cap = args.reads * 20 + 1024
+    tc_cap = args.reads * (20 + args.read_len // 9) + 1024
     d_tt = torch.empty(tc_cap, dtype=torch.int32, device=dev); d_tc = torch.empty(tc_cap, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
     log(f"[rank {rank}] setup {time.perf_counter()-t_setup:.1f}s: T={T} ({len(real_v)} genome-derived), reads={args.reads}x{args.read_len}")
@@ -246,7 +247,7 @@ def main():
                    config=dict(workload=f"{args.reads/1e6:g}M x {args.read_len} bp synthetic single-end reads per GPU vs synthetic "
                                         f"GTDB-scale index of {T/1e9:.2f} G metamers ({T*12/2**30:.0f} GiB flat, replicated per GPU), "
                                         f"syncmer s=5, kmer_format 2 (BASELINE.json configs[1])",
-                               reads_per_gpu=args.reads, read_len=args.read_len, targets=int(T), seq_mode=1,
+                               reads_per_gpu=args.reads, read_len=args.read_len, targets=int(T), seq_mode=args.seq_mode,
                                gbp_per_s=value * args.read_len / 1e3, query_metamers=int(st.n_kmers), matches=int(st.n_matches),
                                classified_fraction=frac_cls, parallelism=f"reads sharded x{world_size}, index replicated"),
                    stage_ms=dict(extract=st.ms_extract, sort=st.ms_sort, join=st.ms_join, regroup=st.ms_regroup,

@@ -193,3 +193,35 @@ def test_classify_driver_tsv_outputs(toy, orc, tmp_path):
     if not (ref["results"]["flag"] != 0).any():
         assert open(str(tmp_path / "job_classifications.tsv")).read() == open(cpath).read()
         assert sorted(open(str(tmp_path / "job_report.tsv")).read().split("\n")) == sorted(open(rpath).read().split("\n"))
+
+
+def test_duplicate_index_entries(ctx, orc, tmp_path):
+    """An index with repeated (value, taxid) entries yields identical match records:
+    the scorer's strict-compare rank sort must detect the equal keys and fall back."""
+    from conftest import Toy
+    from helpers import default_params
+    import metabuli_amd as M
+    t = Toy(orc, tmp_path / "a", syncmer=1, paired=False, seed=31, n_reads=120)
+    rng = np.random.default_rng(1)
+    dup = np.sort(rng.choice(len(t.values), size=len(t.values) // 10, replace=False))
+    idx = np.sort(np.concatenate([np.arange(len(t.values)), dup]))
+    vals, tids = t.values[idx], t.taxids[idx]
+    d = str(tmp_path / "dup")
+    os.makedirs(d)
+    t.world.tax.write(os.path.join(d, "taxonomy"))
+    p = default_params(seq_mode=1, syncmer=1)
+    orc.write_db(d, vals, tids, p)
+    tax = orc.load_taxonomy(os.path.join(d, "taxonomy"))
+    db = orc.open_db(d, tax, p)
+    ref = orc.classify(db, tax, p, t.b1, t.o1)
+    assert len(ref["matches"]) > len(t.ref["matches"])       # duplicates really produce extra matches
+    mp = M.default_params(seq_mode=1, syncmer=1)
+    ix = ctx.open_index(d, mp)
+    res, tt, tc = ctx.classify_batch(ix, mp, t.b1, t.o1)
+    ro = ref["results"]
+    amb = ro["flag"] != 0
+    assert ((res["classification"] == ro["classification"]) | amb).all()
+    assert ((res["score"].view(np.uint32) == ro["score"].view(np.uint32)) | amb).all()
+    if not amb.any():
+        assert (tt == ref["tc_tax"]).all() and (tc == ref["tc_cnt"]).all()
+    ix.close()
