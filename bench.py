@@ -137,7 +137,7 @@ def main():
     ap.add_argument("--species", type=int, default=24)
     ap.add_argument("--genome-len", type=int, default=1_000_000)
     ap.add_argument("--filler-species", type=int, default=130_000)
-    ap.add_argument("--cpu-reads", type=int, default=100_000)
+    ap.add_argument("--cpu-reads", type=int, default=400_000)
     ap.add_argument("--cpu-targets", type=float, default=16e6)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--seq-mode", type=int, default=1, choices=[1, 3], help="1 = short single-end (configs[1]); 3 = long reads (configs[2])")
