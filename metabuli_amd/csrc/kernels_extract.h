@@ -16,6 +16,8 @@
 #include "dev_util.h"
 #include "mtb_core.h"
 
+#define MTB_EXTRACT_STAGE 320        /* reads up to this length are staged in LDS once */
+
 struct ExtractArgs {
     const char *bases; const uint64_t *offs;
     const char *bases2; const uint64_t *offs2;
@@ -30,6 +32,7 @@ __global__ __launch_bounds__(64) void k_extract(ExtractArgs a, const mtb_tables 
                                                 int32_t *__restrict__ qlen2, uint32_t *__restrict__ max_len) {
     __shared__ mtb_tables s_tab;
     __shared__ uint8_t s_cod[80];
+    __shared__ uint8_t s_code[MTB_EXTRACT_STAGE];      /* a short read's bases as codes: one global load serves all six frames */
     const uint32_t lane = threadIdx.x;
     for (uint32_t i = lane; i < sizeof(mtb_tables) / 4; i += 64) ((uint32_t *)&s_tab)[i] = ((const uint32_t *)tabs)[i];
     __syncthreads();
@@ -57,14 +60,25 @@ __global__ __launch_bounds__(64) void k_extract(ExtractArgs a, const mtb_tables 
             const uint32_t pos_off = mate ? (uint32_t)(ql1 + 3) : 0u;     /* KmerExtractor.cpp:329 */
             const int32_t used = mtb_used_len(len);
             const int32_t n_cod = used / 3, n_win = n_cod - 7;
+            const bool staged = len <= MTB_EXTRACT_STAGE;
+            if (staged) {
+                __syncthreads();
+                for (int32_t i = (int32_t)lane; i < len; i += 64) s_code[i] = s_tab.base[(uint8_t)seq[i]];
+                __syncthreads();
+            }
             for (int f = 0; f < 6; f++) {
                 const bool fwd = f < 3;
                 const int32_t begin = mtb_frame_begin(len, f);
                 for (int32_t w0 = 0; w0 < n_win; w0 += 64) {
                     int32_t j = w0 + (int32_t)lane;
-                    if (j < n_cod) s_cod[lane] = mtb_codon_byte(&s_tab, seq, mtb_codon_ci(begin, used, j, fwd), fwd);
                     int32_t j2 = w0 + 64 + (int32_t)lane;
-                    if (lane < 8 && j2 < n_cod) s_cod[64 + lane] = mtb_codon_byte(&s_tab, seq, mtb_codon_ci(begin, used, j2, fwd), fwd);
+                    if (staged) {
+                        if (j < n_cod) s_cod[lane] = mtb_codon_byte_codes(&s_tab, s_code, mtb_codon_ci(begin, used, j, fwd), fwd);
+                        if (lane < 8 && j2 < n_cod) s_cod[64 + lane] = mtb_codon_byte_codes(&s_tab, s_code, mtb_codon_ci(begin, used, j2, fwd), fwd);
+                    } else {
+                        if (j < n_cod) s_cod[lane] = mtb_codon_byte(&s_tab, seq, mtb_codon_ci(begin, used, j, fwd), fwd);
+                        if (lane < 8 && j2 < n_cod) s_cod[64 + lane] = mtb_codon_byte(&s_tab, seq, mtb_codon_ci(begin, used, j2, fwd), fwd);
+                    }
                     __syncthreads();
                     int32_t w = w0 + (int32_t)lane;
                     bool ok = false; uint64_t v = 0;

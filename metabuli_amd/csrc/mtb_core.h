@@ -122,6 +122,15 @@ MTB_HD uint8_t mtb_codon_byte(const mtb_tables *t, const char *seq, int64_t ci, 
     return t->codon[a * 16 + b * 4 + c];
 }
 
+/* same, from bases already canonicalised to codes 0..3 / 7 (staged in LDS) */
+MTB_HD uint8_t mtb_codon_byte_codes(const mtb_tables *t, const uint8_t *code, int64_t ci, bool fwd) {
+    uint32_t a, b, c;
+    if (fwd) { a = code[ci]; b = code[ci + 1]; c = code[ci + 2]; }
+    else { a = code[ci]; b = code[ci - 1]; c = code[ci - 2]; if ((a | b | c) < 4) { a ^= 2; b ^= 2; c ^= 2; } }
+    if ((a | b | c) > 3) return 0xFF;
+    return t->codon[a * 16 + b * 4 + c];
+}
+
 /* Frame geometry (KmerExtractor.cpp:350-362): begin of frame f in a read of
  * length len; the scanner window is [begin, begin + used - 1].              */
 MTB_HD int32_t mtb_frame_begin(int32_t len, int32_t frame) {
