@@ -140,6 +140,7 @@ def main():
     ap.add_argument("--cpu-reads", type=int, default=400_000)
     ap.add_argument("--cpu-targets", type=float, default=16e6)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--streams", type=int, default=2, help="HIP streams a batch is pipelined over inside the library")
     ap.add_argument("--seq-mode", type=int, default=1, choices=[1, 3], help="1 = short single-end (configs[1]); 3 = long reads (configs[2])")
     ap.add_argument("--seed", type=int, default=1234)
     args = ap.parse_args()
@@ -157,6 +158,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
     import metabuli_amd as M
     ctx = M.Context(local_rank)
+    ctx.set_streams(args.streams)
     params = M.default_params(seq_mode=args.seq_mode, syncmer=1, smer_len=5)
 
     t_setup = time.perf_counter()
@@ -213,10 +215,11 @@ def main():
     ctx.set_profiling(False)
     kern = {M.KERNEL_NAMES[i]: dict(ms=float(ps.ms_kernel[i]), launches=int(ps.n_launch[i])) for i in range(len(M.KERNEL_NAMES))}
     Kq, Mm, N, L = ps.n_kmers, ps.n_matches, ps.n_reads, ps.n_bases
-    n_pass = max(1, kern["radix_scatter"]["launches"])
-    alg = {   # algorithmic bytes per launch (SURVEY.md 8(d) per-stage split; DESIGN.md "Roofline")
-        "extract_count": L, "extract_emit": L + 16 * Kq, "radix_hist": 16 * Kq / n_pass, "radix_scatter": 32 * Kq / n_pass,
-        "join": 16 * Kq + 12 * ps.n_targets + 24 * Mm, "regroup": 24 * Mm, "segsort": 24 * Mm, "score": 24 * Mm + 16 * N}
+    # algorithmic bytes of one whole step per kernel (SURVEY.md 8(d) per-stage split);
+    # a step launches every kernel once per stream (and per radix pass): bytes per launch = total / launches
+    alg_step = {"extract_count": L, "extract_emit": L + 16 * Kq, "radix_hist": 16 * Kq, "radix_scatter": 32 * Kq,
+                "join": 16 * Kq + 12 * ps.n_targets * max(1, args.streams) + 24 * Mm, "regroup": 48 * Mm, "score": 24 * Mm + 16 * N}
+    alg = {k: v / max(1, kern[k]["launches"]) for k, v in alg_step.items()}
     dom = max((k for k in alg), key=lambda k: kern[k]["ms"])
     avg_ms = kern[dom]["ms"] / max(1, kern[dom]["launches"])
     achieved = alg[dom] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -249,7 +252,7 @@ def main():
                                         f"syncmer s=5, kmer_format 2 (BASELINE.json configs[1])",
                                reads_per_gpu=args.reads, read_len=args.read_len, targets=int(T), seq_mode=args.seq_mode,
                                gbp_per_s=value * args.read_len / 1e3, query_metamers=int(st.n_kmers), matches=int(st.n_matches),
-                               classified_fraction=frac_cls, parallelism=f"reads sharded x{world_size}, index replicated"),
+                               classified_fraction=frac_cls, parallelism=f"reads sharded x{world_size}, index replicated", streams_per_gpu=args.streams),
                    stage_ms=dict(extract=st.ms_extract, sort=st.ms_sort, join=st.ms_join, regroup=st.ms_regroup,
                                  segsort=st.ms_segsort, score=st.ms_score, total=st.ms_total),
                    kernel_ms=kern, roofline=roofline, cpu_baseline=cpu)

@@ -115,6 +115,12 @@ mtb_status mtb_ctx_sync(mtb_ctx *);
 /* 1: bracket every kernel launch of mtb_classify_batch* with HIP events
  * (adds a few microseconds per launch); 0 (default): stage-level events only. */
 mtb_status mtb_ctx_set_profiling(mtb_ctx *, int on);
+/* Number of HIP streams mtb_classify_batch* pipelines a batch over (default 1).  With n > 1
+ * the batch is cut into n contiguous read ranges that run concurrently, each on its own
+ * non-blocking stream and workspace (one host thread per stream inside the call), so that
+ * latency-bound kernels of one range overlap bandwidth-bound kernels of another.  Results are
+ * identical; per-read taxcnt slots of range i live in the i-th n-th of the taxcnt arrays.   */
+mtb_status mtb_ctx_set_streams(mtb_ctx *, int n);
 
 /* ---- index residency ---------------------------------------------------
  * Replaces the per-call fopen/fread/mmap of diffIdx, info, split inside

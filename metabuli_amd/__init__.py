@@ -140,6 +140,9 @@ class Context:
     def set_profiling(self, on):
         _chk(self.L.mtb_ctx_set_profiling(self.h, C.c_int(1 if on else 0)))
 
+    def set_streams(self, n):
+        _chk(self.L.mtb_ctx_set_streams(self.h, C.c_int(n)))
+
     # ---- index ----
     def open_index(self, dbdir, params, taxonomy_dir=None):
         h = C.c_void_p()

@@ -363,7 +363,7 @@ __global__ __launch_bounds__(64, MTB_SCORE_MINWAVES) void k_score(const REC *__r
                                                mtb_result *__restrict__ results, int32_t *__restrict__ tc_tax,
                                                uint32_t *__restrict__ tc_cnt, uint64_t tc_cap, uint8_t *__restrict__ slabs,
                                                uint64_t slab_bytes, uint32_t slab_max_n, uint32_t slab_max_nb,
-                                               mtb_match *__restrict__ sorted_out) {
+                                               mtb_match *__restrict__ sorted_out, uint64_t tc_base) {
     __shared__ __attribute__((aligned(16))) uint8_t s_ws[MTB_SCORE_WS_BYTES];
     /* bucket / taxCnt / chain arrays of the decide phase live in the path storage,
      * which is dead once the species scores exist (keeps LDS per wave small -> occupancy) */
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(64, MTB_SCORE_MINWAVES) void k_score(const REC *__r
                 score_read_par<uint32_t, false, false, REC>(matches + s0, n, w, btax, bham, otax, ocnt, lev, anc, nb, read_len, tx, sp, off, room, tc_tax, tc_cnt,
                                                 tc_cap, (mtb_match *)nullptr, R);
         }
-        if (lane == 0) { R.query_length = ql1; R.query_length2 = ql2; R.reserved = 0; results[r] = R; }
+        if (lane == 0) { R.query_length = ql1; R.query_length2 = ql2; R.reserved = 0; R.taxcnt_off += (uint32_t)tc_base; results[r] = R; }
     }
     MTB_PHASE_KERNEL_END();
 }

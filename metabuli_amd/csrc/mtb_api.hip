@@ -3,8 +3,10 @@
  * launches kernels on the context's stream and reports HIP errors.           */
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/mtb.h"
@@ -44,6 +46,8 @@ struct mtb_ctx {
     struct KEv { int id; hipEvent_t a, b; };
     std::vector<KEv> kev;            /* events of the current batch      */
     std::vector<hipEvent_t> ev_pool; /* recycled events                  */
+    std::vector<mtb_ctx *> lanes;    /* extra stream contexts (mtb_ctx_set_streams) */
+    bool is_lane = false;            /* lanes share the parent's tables  */
 };
 
 /* RAII bracket around one kernel launch (only when profiling is on) */
@@ -139,18 +143,41 @@ mtb_status mtb_ctx_create(int device, void *stream, mtb_ctx **out) {
 }
 void mtb_ctx_destroy(mtb_ctx *c) {
     if (!c) return;
+    for (mtb_ctx *l : c->lanes) mtb_ctx_destroy(l);
+    c->lanes.clear();
     hipError_t e = hipSetDevice(c->device); (void)e;
     e = hipStreamSynchronize(c->stream);
     for (auto &kv : c->bufs) if (kv.second.p) e = hipFree(kv.second.p);
-    if (c->d_tabs) e = hipFree(c->d_tabs);
+    if (c->d_tabs && !c->is_lane) e = hipFree(c->d_tabs);
     if (c->d_scal) e = hipFree(c->d_scal);
+    if (c->is_lane && c->stream) e = hipStreamDestroy(c->stream);
     for (int i = 0; i < 8; i++) e = hipEventDestroy(c->ev[i]);
     for (auto &k : c->kev) { e = hipEventDestroy(k.a); e = hipEventDestroy(k.b); }
     for (auto &x : c->ev_pool) e = hipEventDestroy(x);
     delete c;
 }
 mtb_status mtb_ctx_sync(mtb_ctx *c) { HIPCHK(hipStreamSynchronize(c->stream)); return MTB_OK; }
-mtb_status mtb_ctx_set_profiling(mtb_ctx *c, int on) { if (!c) return fail(MTB_ERR_ARG, "NULL ctx"); c->profiling = on; return MTB_OK; }
+mtb_status mtb_ctx_set_profiling(mtb_ctx *c, int on) {
+    if (!c) return fail(MTB_ERR_ARG, "NULL ctx");
+    c->profiling = on;
+    for (mtb_ctx *l : c->lanes) l->profiling = on;
+    return MTB_OK;
+}
+mtb_status mtb_ctx_set_streams(mtb_ctx *c, int n) {
+    if (!c || n < 1 || n > 8) return fail(MTB_ERR_ARG, "streams must be 1..8");
+    HIPCHK(hipSetDevice(c->device));
+    while ((int)c->lanes.size() > (n == 1 ? 0 : n)) { mtb_ctx_destroy(c->lanes.back()); c->lanes.pop_back(); }
+    while (n > 1 && (int)c->lanes.size() < n) {
+        mtb_ctx *l = new mtb_ctx();
+        l->device = c->device; l->is_lane = true; l->d_tabs = c->d_tabs; l->h_tabs = c->h_tabs; l->profiling = c->profiling;
+        HIPCHK(hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking));
+        HIPCHK(hipMalloc((void **)&l->d_scal, 8 * sizeof(uint64_t)));
+        for (int i = 0; i < 8; i++) HIPCHK(hipEventCreate(&l->ev[i]));
+        memset(&l->stats, 0, sizeof(l->stats));
+        c->lanes.push_back(l);
+    }
+    return MTB_OK;
+}
 
 } // extern "C"
 
@@ -298,7 +325,7 @@ template <typename REC>
 static mtb_status dev_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, const REC *d_m, const uint64_t *d_seg,
                             uint64_t n_reads, const int32_t *d_qlen, const int32_t *d_qlen2, uint32_t max_seg, uint32_t max_len,
                             mtb_result *d_res, int32_t *d_tc_tax, uint32_t *d_tc_cnt, uint64_t tc_cap, uint64_t *n_tc,
-                            bool fused_sort = false) {
+                            bool fused_sort = false, uint64_t tc_base = 0) {
     if (p->accession_level == 2) return fail(MTB_ERR_UNSUPPORTED, "accession_level 2 (Taxonomer.cpp:256-267) is not implemented");
     mtb_score_params sp; mtb_make_score_params(p, &sp);
     uint32_t *d_bound; uint64_t *d_tcoff; uint64_t *d_ws;
@@ -329,7 +356,7 @@ static mtb_status dev_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, cons
     /* single-word sort key when taxids < 2^22 and positions < 2^11 (hamming of a match is <= 7) */
     bool key64 = ix->tax.max_id < (1 << 22) && max_len + 3 < (1u << 11);
 #define MTB_LAUNCH_SCORE(S, K) hipLaunchKernelGGL((k_score<S, K, REC>), dim3(grid), dim3(64), 0, c->stream, d_m, d_seg, n_reads, d_qlen, d_qlen2, \
-        tax_view(ix), sp, (const uint64_t *)d_tcoff, d_res, d_tc_tax, d_tc_cnt, tc_cap, d_slabs, slab_bytes, slab_n, slab_nb, (mtb_match *)nullptr)
+        tax_view(ix), sp, (const uint64_t *)d_tcoff, d_res, d_tc_tax, d_tc_cnt, tc_cap, d_slabs, slab_bytes, slab_n, slab_nb, (mtb_match *)nullptr, tc_base)
     if (fused_sort) { if (key64) MTB_LAUNCH_SCORE(true, true); else MTB_LAUNCH_SCORE(true, false); }
     else MTB_LAUNCH_SCORE(false, false);
 #undef MTB_LAUNCH_SCORE
@@ -578,11 +605,13 @@ mtb_status mtb_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, const mtb_m
 /* ------------------------------------------------------------------ */
 /* fused batch                                                         */
 /* ------------------------------------------------------------------ */
-mtb_status mtb_classify_batch_device(mtb_ctx *c, mtb_index *ix, const mtb_params *p, const char *d_bases, const uint64_t *d_offs,
-                                     const char *d_bases2, const uint64_t *d_offs2, uint64_t n_reads, uint64_t n_bases_total,
-                                     mtb_result *d_results, int32_t *d_taxcnt_tax, uint32_t *d_taxcnt_cnt, uint64_t taxcnt_cap,
-                                     uint64_t *n_taxcnt) {
-    if (!c || !ix || !p || !n_taxcnt) return fail(MTB_ERR_ARG, "NULL argument");
+} // extern "C"
+
+/* one read range on one stream; taxcnt slots of this range start at tc_base of the caller's arrays */
+static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, const char *d_bases, const uint64_t *d_offs,
+                               const char *d_bases2, const uint64_t *d_offs2, uint64_t n_reads, uint64_t n_bases_total,
+                               mtb_result *d_results, int32_t *d_taxcnt_tax, uint32_t *d_taxcnt_cnt, uint64_t taxcnt_cap,
+                               uint64_t *n_taxcnt, uint64_t tc_base) {
     HIPCHK(hipSetDevice(c->device));
     *n_taxcnt = 0;
     memset(&c->stats, 0, sizeof(c->stats));
@@ -637,7 +666,7 @@ mtb_status mtb_classify_batch_device(mtb_ctx *c, mtb_index *ix, const mtb_params
         max_seg = (uint32_t)sc[1];
     }
     HIPCHK(hipEventRecord(c->ev[5], st));
-    STCHK(dev_score(c, ix, p, d_m, d_seg, n_reads, d_ql, d_ql2, max_seg, max_len, d_results, d_taxcnt_tax, d_taxcnt_cnt, taxcnt_cap, n_taxcnt, true));
+    STCHK(dev_score(c, ix, p, d_m, d_seg, n_reads, d_ql, d_ql2, max_seg, max_len, d_results, d_taxcnt_tax, d_taxcnt_cnt, taxcnt_cap, n_taxcnt, true, tc_base));
     HIPCHK(hipEventRecord(c->ev[6], st));
     HIPCHK(hipEventSynchronize(c->ev[6]));
     mtb_batch_stats &S = c->stats;
@@ -650,6 +679,54 @@ mtb_status mtb_classify_batch_device(mtb_ctx *c, mtb_index *ix, const mtb_params
     HIPCHK(hipEventElapsedTime(&S.ms_total, c->ev[0], c->ev[6]));
     collect_kernel_times(c);
     S.n_reads = n_reads; S.n_bases = n_bases_total; S.n_kmers = nk; S.n_matches = nm; S.n_targets = ix->T;
+    return MTB_OK;
+}
+
+static void merge_stats(mtb_batch_stats &S, const mtb_batch_stats &L) {
+    S.ms_extract += L.ms_extract; S.ms_sort += L.ms_sort; S.ms_join += L.ms_join; S.ms_regroup += L.ms_regroup;
+    S.ms_segsort += L.ms_segsort; S.ms_score += L.ms_score;
+    S.n_reads += L.n_reads; S.n_bases += L.n_bases; S.n_kmers += L.n_kmers; S.n_matches += L.n_matches; S.n_targets = L.n_targets;
+    for (int i = 0; i < MTB_NUM_KERNELS; i++) { S.ms_kernel[i] += L.ms_kernel[i]; S.n_launch[i] += L.n_launch[i]; }
+}
+
+extern "C" {
+
+mtb_status mtb_classify_batch_device(mtb_ctx *c, mtb_index *ix, const mtb_params *p, const char *d_bases, const uint64_t *d_offs,
+                                     const char *d_bases2, const uint64_t *d_offs2, uint64_t n_reads, uint64_t n_bases_total,
+                                     mtb_result *d_results, int32_t *d_taxcnt_tax, uint32_t *d_taxcnt_cnt, uint64_t taxcnt_cap,
+                                     uint64_t *n_taxcnt) {
+    if (!c || !ix || !p || !n_taxcnt) return fail(MTB_ERR_ARG, "NULL argument");
+    const size_t L = c->lanes.size();
+    if (L < 2 || n_reads < 4096 * L)
+        return classify_one(c, ix, p, d_bases, d_offs, d_bases2, d_offs2, n_reads, n_bases_total, d_results, d_taxcnt_tax, d_taxcnt_cnt,
+                            taxcnt_cap, n_taxcnt, 0);
+    /* L contiguous read ranges, one host thread + one non-blocking stream each */
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));          /* inputs produced on the caller's stream are complete */
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<mtb_status> st(L, MTB_OK);
+    std::vector<std::string> errs(L);
+    std::vector<uint64_t> ntc(L, 0);
+    std::vector<std::thread> th;
+    const uint64_t tc_share = taxcnt_cap / L;
+    for (size_t i = 0; i < L; i++) {
+        uint64_t lo = n_reads * i / L, hi = n_reads * (i + 1) / L;
+        th.emplace_back([&, i, lo, hi]() {
+            mtb_ctx *l = c->lanes[i];
+            st[i] = classify_one(l, ix, p, d_bases, d_offs + lo, d_bases2, d_offs2 ? d_offs2 + lo : nullptr, hi - lo,
+                                 n_bases_total * (hi - lo) / n_reads, d_results + lo, d_taxcnt_tax + tc_share * i,
+                                 d_taxcnt_cnt + tc_share * i, tc_share, &ntc[i], tc_share * i);
+            if (st[i] != MTB_OK) errs[i] = g_err;
+        });
+    }
+    for (auto &t : th) t.join();
+    memset(&c->stats, 0, sizeof(c->stats));
+    uint64_t need = 0;
+    for (size_t i = 0; i < L; i++) { merge_stats(c->stats, c->lanes[i]->stats); need = std::max(need, ntc[i] * L); }
+    c->stats.ms_total = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    *n_taxcnt = taxcnt_cap;                             /* slots are spread over the whole array */
+    for (size_t i = 0; i < L; i++)
+        if (st[i] != MTB_OK) { if (st[i] == MTB_ERR_CAPACITY) *n_taxcnt = std::max<uint64_t>(need, taxcnt_cap + 1); return fail(st[i], errs[i]); }
     return MTB_OK;
 }
 

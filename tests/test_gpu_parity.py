@@ -225,3 +225,28 @@ def test_duplicate_index_entries(ctx, orc, tmp_path):
     if not amb.any():
         assert (tt == ref["tc_tax"]).all() and (tc == ref["tc_cnt"]).all()
     ix.close()
+
+
+def test_two_streams_give_identical_results(toy):
+    """mtb_ctx_set_streams(2): the batch is cut into two read ranges that run concurrently on
+    two streams; per-read results and taxcnt entries must equal the single-stream run."""
+    import metabuli_amd as M
+    c = M.Context(0)
+    p = _params(toy)
+    ix = c.open_index(toy.dbdir, p)
+    big = 5000 // toy.n_reads + 1          # the split needs >= 4096 reads per stream: tile the toy batch
+    b1 = np.tile(toy.b1, big); o1 = np.concatenate([[0], np.cumsum(np.tile(np.diff(toy.o1.astype(np.int64)), big))]).astype(np.uint64)
+    b2 = o2 = None
+    if toy.b2 is not None:
+        b2 = np.tile(toy.b2, big); o2 = np.concatenate([[0], np.cumsum(np.tile(np.diff(toy.o2.astype(np.int64)), big))]).astype(np.uint64)
+    if len(o1) - 1 < 8192:
+        ix.close(); c.close(); pytest.skip("batch too small to be split")
+    r1, t1, c1 = c.classify_batch(ix, p, b1, o1, b2, o2)
+    c.set_streams(2)
+    r2, t2, c2 = c.classify_batch(ix, p, b1, o1, b2, o2)
+    assert (r1 == r2).all() and (t1 == t2).all() and (c1 == c2).all()
+    n = toy.n_reads
+    ro = toy.ref["results"]
+    amb = np.tile(ro["flag"] != 0, big)
+    assert ((r2["classification"] == np.tile(ro["classification"], big)) | amb).all()
+    ix.close(); c.close()
