@@ -234,7 +234,7 @@ def test_two_streams_give_identical_results(toy):
     c = M.Context(0)
     p = _params(toy)
     ix = c.open_index(toy.dbdir, p)
-    big = 5000 // toy.n_reads + 1          # the split needs >= 4096 reads per stream: tile the toy batch
+    big = 8192 // toy.n_reads + 1          # the split needs >= 4096 reads per stream: tile the toy batch
     b1 = np.tile(toy.b1, big); o1 = np.concatenate([[0], np.cumsum(np.tile(np.diff(toy.o1.astype(np.int64)), big))]).astype(np.uint64)
     b2 = o2 = None
     if toy.b2 is not None:
