@@ -208,23 +208,27 @@ def main():
         dt = float(t.item())
     st = ctx.last_stats()
 
-    # one extra, untimed, profiled step: HIP events around every kernel launch
+    # one extra, untimed, profiled step on ONE stream (kernels not overlapped, full-batch launches):
+    # HIP events on the library's stream around every kernel launch
+    ctx.set_streams(1)
     ctx.set_profiling(True)
     step()
     ps = ctx.last_stats()
     ctx.set_profiling(False)
+    ctx.set_streams(args.streams)
     kern = {M.KERNEL_NAMES[i]: dict(ms=float(ps.ms_kernel[i]), launches=int(ps.n_launch[i])) for i in range(len(M.KERNEL_NAMES))}
     Kq, Mm, N, L = ps.n_kmers, ps.n_matches, ps.n_reads, ps.n_bases
     # algorithmic bytes of one whole step per kernel (SURVEY.md 8(d) per-stage split);
     # a step launches every kernel once per stream (and per radix pass): bytes per launch = total / launches
     alg_step = {"extract_count": L, "extract_emit": L + 16 * Kq, "radix_hist": 16 * Kq, "radix_scatter": 32 * Kq,
-                "join": 16 * Kq + 12 * ps.n_targets * max(1, args.streams) + 24 * Mm, "regroup": 48 * Mm, "score": 24 * Mm + 16 * N}
+                "join": 16 * Kq + 12 * ps.n_targets + 24 * Mm, "regroup": 48 * Mm, "score": 24 * Mm + 16 * N}
     alg = {k: v / max(1, kern[k]["launches"]) for k, v in alg_step.items()}
     dom = max((k for k in alg), key=lambda k: kern[k]["ms"])
     avg_ms = kern[dom]["ms"] / max(1, kern[dom]["launches"])
     achieved = alg[dom] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     roofline = dict(bound="hbm", kernel=dom, achieved=achieved, peak=8000.0, unit="GB/s", frac=achieved / 8000.0, traffic=None,
-                    avg_launch_ms=avg_ms, launches=kern[dom]["launches"], algorithmic_bytes_per_launch=alg[dom])
+                    avg_launch_ms=avg_ms, launches=kern[dom]["launches"], algorithmic_bytes_per_launch=alg[dom],
+                    note="per-kernel durations from an extra single-stream step (no overlap); PMC traffic in profiles/")
 
     # sanity of the timed output: fraction of reads classified
     res = np.frombuffer(d_res.cpu().numpy().tobytes(), dtype=M.result_dt)
