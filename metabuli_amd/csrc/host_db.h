@@ -60,7 +60,7 @@ inline int find_rank_index(const std::string &r) {
 struct Taxonomy {
     int32_t max_id = 0;
     std::vector<int32_t> canon, parent, depth, rank_idx, sp_parent, tax2species;
-    std::vector<uint8_t> under_euk;
+    std::vector<uint8_t> under_euk, acc_leaf;
     std::vector<std::string> rank, name;     /* by canonical id (reporting only) */
     int32_t eukaryota = 0;
 
@@ -127,8 +127,9 @@ inline bool load_taxonomy(const std::string &dir, Taxonomy *t, std::string *err)
     size_t sz = (size_t)mx + 1;
     t->canon.assign(sz, -1); t->parent.assign(sz, -1); t->depth.assign(sz, 0); t->rank_idx.assign(sz, -1);
     t->sp_parent.assign(sz, 0); t->tax2species.assign(sz, 0); t->under_euk.assign(sz, 0);
-    t->rank.assign(sz, std::string()); t->name.assign(sz, std::string());
-    for (auto &n : nodes) { t->canon[(size_t)n.id] = n.id; t->parent[(size_t)n.id] = n.parent; t->rank_idx[(size_t)n.id] = n.rank; t->rank[(size_t)n.id] = n.rank_name; }
+    t->rank.assign(sz, std::string()); t->name.assign(sz, std::string()); t->acc_leaf.assign(sz, 0);
+    for (auto &n : nodes) { t->canon[(size_t)n.id] = n.id; t->parent[(size_t)n.id] = n.parent; t->rank_idx[(size_t)n.id] = n.rank; t->rank[(size_t)n.id] = n.rank_name;
+                            t->acc_leaf[(size_t)n.id] = (n.rank_name.empty() || n.rank_name == "accession") ? 1 : 0; }
     for (auto &n : nodes) if (t->canon[(size_t)n.parent] < 0) { *err = "nodes.dmp: missing parent taxon"; return false; }
     for (auto &m : merged) if (t->canon[(size_t)m.first] < 0 && t->canon[(size_t)m.second] >= 0) t->canon[(size_t)m.first] = m.second;
     for (auto &n : nodes) {

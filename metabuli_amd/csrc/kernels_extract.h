@@ -22,7 +22,7 @@ struct ExtractArgs {
     const char *bases; const uint64_t *offs;
     const char *bases2; const uint64_t *offs2;
     uint64_t n_reads;
-    int32_t seq_mode, syncmer, smer_len;
+    int32_t seq_mode, syncmer, smer_len, kmer_format;
 };
 
 template <bool EMIT>
@@ -60,7 +60,8 @@ __global__ __launch_bounds__(64) void k_extract(ExtractArgs a, const mtb_tables 
             const uint32_t pos_off = mate ? (uint32_t)(ql1 + 3) : 0u;     /* KmerExtractor.cpp:329 */
             const int32_t used = mtb_used_len(len);
             const int32_t n_cod = used / 3, n_win = n_cod - 7;
-            const bool staged = len <= MTB_EXTRACT_STAGE;
+            const bool old_fmt = a.kmer_format == 1;          /* OldMetamerScanner geometry, base-21 amino-acid part */
+            const bool staged = !old_fmt && len <= MTB_EXTRACT_STAGE;
             if (staged) {
                 __syncthreads();
                 for (int32_t i = (int32_t)lane; i < len; i += 64) s_code[i] = s_tab.base[(uint8_t)seq[i]];
@@ -75,6 +76,9 @@ __global__ __launch_bounds__(64) void k_extract(ExtractArgs a, const mtb_tables 
                     if (staged) {
                         if (j < n_cod) s_cod[lane] = mtb_codon_byte_codes(&s_tab, s_code, mtb_codon_ci(begin, used, j, fwd), fwd);
                         if (lane < 8 && j2 < n_cod) s_cod[64 + lane] = mtb_codon_byte_codes(&s_tab, s_code, mtb_codon_ci(begin, used, j2, fwd), fwd);
+                    } else if (old_fmt) {
+                        if (j < n_cod) s_cod[lane] = mtb_codon_byte_old(&s_tab, seq, mtb_codon_ci_old(begin, used, j, fwd), fwd);
+                        if (lane < 8 && j2 < n_cod) s_cod[64 + lane] = mtb_codon_byte_old(&s_tab, seq, mtb_codon_ci_old(begin, used, j2, fwd), fwd);
                     } else {
                         if (j < n_cod) s_cod[lane] = mtb_codon_byte(&s_tab, seq, mtb_codon_ci(begin, used, j, fwd), fwd);
                         if (lane < 8 && j2 < n_cod) s_cod[64 + lane] = mtb_codon_byte(&s_tab, seq, mtb_codon_ci(begin, used, j2, fwd), fwd);
@@ -82,12 +86,12 @@ __global__ __launch_bounds__(64) void k_extract(ExtractArgs a, const mtb_tables 
                     __syncthreads();
                     int32_t w = w0 + (int32_t)lane;
                     bool ok = false; uint64_t v = 0;
-                    if (w < n_win) ok = mtb_window_metamer(&s_cod[lane], a.syncmer, a.smer_len, &v);
+                    if (w < n_win) ok = old_fmt ? mtb_window_metamer_old(&s_cod[lane], &v) : mtb_window_metamer(&s_cod[lane], a.syncmer, a.smer_len, &v);
                     uint64_t mask = __ballot(ok);
                     if (EMIT && ok) {
                         mtb_kmer k;
                         k.value = v;
-                        k.qinfo = mtb_qinfo((uint32_t)(r + 1), mtb_window_pos(begin, used, w, fwd) + pos_off, (uint32_t)f);
+                        k.qinfo = mtb_qinfo((uint32_t)(r + 1), (old_fmt ? mtb_window_pos_old(begin, used, w, fwd) : mtb_window_pos(begin, used, w, fwd)) + pos_off, (uint32_t)f);
                         out[wpos + (uint64_t)__popcll(mask & lanemask_lt())] = k;
                     }
                     uint32_t c = (uint32_t)__popcll(mask);

@@ -340,8 +340,8 @@ __device__ __forceinline__ void score_read_par(const REC *__restrict__ src, int3
             to_parent = R.score < sp.min_sp_score;
             int32_t cs = mtb_tax_canon(&tx, species);
             if (to_parent) R.classification = (species >= 0 && species <= tx.max_taxid) ? tx.sp_parent[species] : 0;
-            else if (slow || cs < 0) R.classification = mtb_lower_rank(&tx, otax, ocnt, ntc, species, read_len, sp.denominator);
-            else R.classification = mtb_lr_bfs(lr_lev, lr_anc, ocnt, ntc, cs, read_len, sp.denominator);
+            else if (slow || cs < 0) R.classification = mtb_lower_rank(&tx, otax, ocnt, ntc, species, read_len, sp.denominator, sp.accession_level);
+            else R.classification = mtb_lr_bfs(lr_lev, lr_anc, ocnt, ntc, cs, read_len, sp.denominator, &tx, sp.accession_level);
             R.taxcnt_off = (uint32_t)tc_off;
             for (int32_t k = 0; k < ntc; k++)
                 if (tc_off + k < tc_cap) { tc_tax[tc_off + k] = otax[k]; tc_cnt[tc_off + k] = ocnt[k]; }

@@ -85,7 +85,7 @@ struct mtb_index {
     uint64_t *d_values = nullptr; uint32_t *d_info = nullptr; bool own = false;
     mtbhost::Taxonomy tax;
     int32_t *d_canon = nullptr, *d_parent = nullptr, *d_depth = nullptr, *d_spparent = nullptr, *d_tax2species = nullptr;
-    uint8_t *d_under = nullptr;
+    uint8_t *d_under = nullptr, *d_accleaf = nullptr;
     mtb_params params;
     uint32_t info_mask = 0xFFFFFFFFu;
 };
@@ -201,7 +201,7 @@ static mtb_status dev_extract(mtb_ctx *c, const mtb_params *p, const char *d_bas
                               const uint64_t *d_offs2, uint64_t n_reads, mtb_kmer **out, uint64_t *count, int32_t *d_qlen,
                               int32_t *d_qlen2, uint32_t *max_len) {
     if (n_reads >= (1ull << 29)) return fail(MTB_ERR_ARG, "more than 2^29-1 reads per batch (sequenceID is 29 bits, Kmer.h:13)");
-    if (p->kmer_format != 2) return fail(MTB_ERR_UNSUPPORTED, "only kmer_format 2 is implemented");
+    if (p->kmer_format != 1 && p->kmer_format != 2) return fail(MTB_ERR_UNSUPPORTED, "only kmer_format 1 and 2 are implemented");
     if (p->syncmer && (p->smer_len < 1 || p->smer_len > 8)) return fail(MTB_ERR_ARG, "smer_len out of range");
     *count = 0; *out = nullptr;
     if (n_reads == 0) return MTB_OK;
@@ -210,7 +210,7 @@ static mtb_status dev_extract(mtb_ctx *c, const mtb_params *p, const char *d_bas
     STCHK(ensure(c, "koff", n_reads + 1, &d_koff));
     STCHK(ensure(c, "scanws", scan_ws_elems(n_reads + 1), &d_ws));
     HIPCHK(hipMemsetAsync(c->d_scal + 4, 0, 8, c->stream));
-    ExtractArgs a{d_bases, d_offs, d_bases2, d_offs2, n_reads, p->seq_mode, p->syncmer, p->smer_len};
+    ExtractArgs a{d_bases, d_offs, d_bases2, d_offs2, n_reads, p->seq_mode, p->syncmer, p->smer_len, p->kmer_format};
     uint32_t grid = (uint32_t)std::min<uint64_t>(n_reads, 256ull * 64);
     { KTimer kt(c, MTB_K_EXTRACT_COUNT);
     hipLaunchKernelGGL((k_extract<false>), dim3(grid), dim3(64), 0, c->stream, a, c->d_tabs, d_cnt, (const uint64_t *)nullptr,
@@ -260,7 +260,7 @@ static mtb_index_view index_view(const mtb_index *ix) {
 }
 static mtb_tax_view tax_view(const mtb_index *ix) {
     mtb_tax_view v;
-    v.canon = ix->d_canon; v.parent = ix->d_parent; v.depth = ix->d_depth; v.under_euk = ix->d_under; v.sp_parent = ix->d_spparent;
+    v.acc_leaf = ix->d_accleaf; v.canon = ix->d_canon; v.parent = ix->d_parent; v.depth = ix->d_depth; v.under_euk = ix->d_under; v.sp_parent = ix->d_spparent;
     v.max_taxid = ix->tax.max_id;
     return v;
 }
@@ -326,7 +326,6 @@ static mtb_status dev_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, cons
                             uint64_t n_reads, const int32_t *d_qlen, const int32_t *d_qlen2, uint32_t max_seg, uint32_t max_len,
                             mtb_result *d_res, int32_t *d_tc_tax, uint32_t *d_tc_cnt, uint64_t tc_cap, uint64_t *n_tc,
                             bool fused_sort = false, uint64_t tc_base = 0) {
-    if (p->accession_level == 2) return fail(MTB_ERR_UNSUPPORTED, "accession_level 2 (Taxonomer.cpp:256-267) is not implemented");
     mtb_score_params sp; mtb_make_score_params(p, &sp);
     uint32_t *d_bound; uint64_t *d_tcoff; uint64_t *d_ws;
     STCHK(ensure(c, "bound", n_reads, &d_bound));
@@ -373,7 +372,7 @@ static mtb_status upload_taxonomy(mtb_index *ix) {
     size_t n = (size_t)t.max_id + 1;
     HIPCHK(hipMalloc((void **)&ix->d_canon, n * 4)); HIPCHK(hipMalloc((void **)&ix->d_parent, n * 4));
     HIPCHK(hipMalloc((void **)&ix->d_depth, n * 4)); HIPCHK(hipMalloc((void **)&ix->d_spparent, n * 4));
-    HIPCHK(hipMalloc((void **)&ix->d_tax2species, n * 4)); HIPCHK(hipMalloc((void **)&ix->d_under, n));
+    HIPCHK(hipMalloc((void **)&ix->d_tax2species, n * 4)); HIPCHK(hipMalloc((void **)&ix->d_under, n)); HIPCHK(hipMalloc((void **)&ix->d_accleaf, n));
     /* parent must be indexable for every canonical id; absent ids keep -1 (never dereferenced) */
     HIPCHK(hipMemcpy(ix->d_canon, t.canon.data(), n * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ix->d_parent, t.parent.data(), n * 4, hipMemcpyHostToDevice));
@@ -381,6 +380,7 @@ static mtb_status upload_taxonomy(mtb_index *ix) {
     HIPCHK(hipMemcpy(ix->d_spparent, t.sp_parent.data(), n * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ix->d_tax2species, t.tax2species.data(), n * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ix->d_under, t.under_euk.data(), n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ix->d_accleaf, t.acc_leaf.data(), n, hipMemcpyHostToDevice));
     return MTB_OK;
 }
 
@@ -391,7 +391,7 @@ mtb_status mtb_index_open(mtb_ctx *c, const char *dbdir, const char *taxonomy_di
     HIPCHK(hipSetDevice(c->device));
     std::string d(dbdir);
     mtbhost::load_db_parameters(d, params);
-    if (params->kmer_format != 2) return fail(MTB_ERR_UNSUPPORTED, "database uses a k-mer format other than 2 (OldMetamerScanner not implemented)");
+    if (params->kmer_format != 1 && params->kmer_format != 2) return fail(MTB_ERR_UNSUPPORTED, "database uses a k-mer format other than 1 or 2");
     std::string taxdir = taxonomy_dir && *taxonomy_dir ? std::string(taxonomy_dir) : d + "/taxonomy";
     if (!mtbhost::file_exists(taxdir + "/nodes.dmp")) {
         if (mtbhost::file_exists(d + "/taxonomyDB"))
@@ -465,6 +465,7 @@ void mtb_index_close(mtb_index *ix) {
     if (ix->d_spparent) e = hipFree(ix->d_spparent);
     if (ix->d_tax2species) e = hipFree(ix->d_tax2species);
     if (ix->d_under) e = hipFree(ix->d_under);
+    if (ix->d_accleaf) e = hipFree(ix->d_accleaf);
     (void)e;
     delete ix;
 }

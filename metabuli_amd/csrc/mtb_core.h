@@ -110,6 +110,18 @@ static inline void mtb_build_tables(mtb_tables *t) {
  * forward coordinate ci.  Forward frames read ci, ci+1, ci+2; reverse frames
  * read the complement of ci, ci-1, ci-2 (KmerScanner.h:89-98).  0xFF if any
  * base is not A/C/G/T-like.                                                 */
+/* kmer_format 1 (OldMetamerScanner, KmerScanner.h:137-160): forward frames walk the window from
+ * its END (codon = bases ci-2, ci-1, ci), reverse frames from its START (complement of ci+2, ci+1, ci) */
+MTB_HD uint8_t mtb_codon_byte_old(const mtb_tables *t, const char *seq, int64_t ci, bool fwd) {
+    uint32_t a, b, c;
+    if (fwd) { a = t->base[(uint8_t)seq[ci - 2]]; b = t->base[(uint8_t)seq[ci - 1]]; c = t->base[(uint8_t)seq[ci]]; }
+    else {
+        a = t->base[(uint8_t)seq[ci + 2]]; b = t->base[(uint8_t)seq[ci + 1]]; c = t->base[(uint8_t)seq[ci]];
+        if ((a | b | c) < 4) { a ^= 2; b ^= 2; c ^= 2; }
+    }
+    if ((a | b | c) > 3) return 0xFF;
+    return t->codon[a * 16 + b * 4 + c];
+}
 MTB_HD uint8_t mtb_codon_byte(const mtb_tables *t, const char *seq, int64_t ci, bool fwd) {
     uint32_t a, b, c;
     if (fwd) {
@@ -142,6 +154,13 @@ MTB_HD int32_t mtb_frame_begin(int32_t len, int32_t frame) {
 MTB_HD int64_t mtb_codon_ci(int32_t begin, int32_t used, int32_t j, bool fwd) {
     return fwd ? (int64_t)begin + 3 * (int64_t)j : (int64_t)begin + used - 1 - 3 * (int64_t)j;
 }
+/* kmer_format 1: scan coordinate of codon j and reported position of window p (KmerScanner.h:145-176) */
+MTB_HD int64_t mtb_codon_ci_old(int32_t begin, int32_t used, int32_t j, bool fwd) {
+    return fwd ? (int64_t)begin + used - 1 - 3 * (int64_t)j : (int64_t)begin + 3 * (int64_t)j;
+}
+MTB_HD uint32_t mtb_window_pos_old(int32_t begin, int32_t used, int32_t p, bool fwd) {
+    return fwd ? (uint32_t)(begin + used - 1 - (p + 8) * 3 + 1) : (uint32_t)(begin + 3 * p);
+}
 /* position reported for window p (KmerScanner.h:110-114, SyncmerScanner.h:93-97) */
 MTB_HD uint32_t mtb_window_pos(int32_t begin, int32_t used, int32_t p, bool fwd) {
     return fwd ? (uint32_t)(begin + 3 * p) : (uint32_t)(begin + used - 1 - (p + 8) * 3 + 1);
@@ -151,6 +170,22 @@ MTB_HD uint32_t mtb_window_pos(int32_t begin, int32_t used, int32_t p, bool fwd)
  * false if the window holds an invalid codon or (syncmer mode) is not a
  * closed syncmer: the leftmost minimal s-mer must sit at offset 0 or 8-s
  * (SyncmerScanner.h:58-73).  value = AA40 << 24 | DNA24 (KmerScanner.h:99-111). */
+/* kmer_format 1: amino-acid part is the base-21 number of the 8 residues (first scanned = most
+ * significant), no syncmer selection */
+MTB_HD bool mtb_window_metamer_old(const uint8_t *cod, uint64_t *value) {
+    uint64_t aa = 0, dna = 0;
+    uint32_t bad = 0;
+MTB_UNROLL
+    for (int i = 0; i < 8; i++) {
+        uint32_t b = cod[i];
+        bad |= (b == 0xFFu);
+        aa = aa * 21u + (b & 31u);
+        dna = (dna << 3) | (b >> 5);
+    }
+    if (bad) return false;
+    *value = (aa << 24) | (dna & 0xFFFFFFull);
+    return true;
+}
 MTB_HD bool mtb_window_metamer(const uint8_t *cod, int syncmer, int smer_len, uint64_t *value) {
     uint64_t aa = 0, dna = 0;
     uint32_t bad = 0;
@@ -306,6 +341,7 @@ MTB_HD bool mtb_match_less(const mtb_match &a, const mtb_match &b) {
 /* Scoring                                                             */
 /* ------------------------------------------------------------------ */
 typedef struct {
+    const uint8_t *acc_leaf;    /* rank "" or "accession": dropped from the descent when accession_level == 2 (Taxonomer.cpp:256-267); may be NULL */
     const int32_t *canon;       /* by taxid: itself, the merged.dmp target, or -1 if absent    */
     const int32_t *parent;      /* by canonical taxid; parent[root] = root                     */
     const int32_t *depth;       /* by canonical taxid                                          */
@@ -316,7 +352,7 @@ typedef struct {
 
 typedef struct {
     int32_t max_codon_shift, dna_shift, denominator;  /* Taxonomer.cpp:34-48 */
-    int32_t min_cons_cnt, min_cons_cnt_euk, kmer_format;
+    int32_t min_cons_cnt, min_cons_cnt_euk, kmer_format, accession_level;
     float   min_score, min_sp_score, tie_ratio;
 } mtb_score_params;
 
@@ -326,6 +362,7 @@ MTB_HD void mtb_make_score_params(const mtb_params *p, mtb_score_params *s) {
     s->denominator = (p->seq_mode == 1 || p->seq_mode == 2) ? 100 : 1000;
     s->min_cons_cnt = p->min_cons_cnt; s->min_cons_cnt_euk = p->min_cons_cnt_euk; s->kmer_format = p->kmer_format;
     s->min_score = p->min_score; s->min_sp_score = p->min_sp_score; s->tie_ratio = p->tie_ratio;
+    s->accession_level = p->accession_level;
 }
 
 MTB_HD int32_t mtb_tax_canon(const mtb_tax_view *t, int32_t x) { return (x >= 0 && x <= t->max_taxid) ? t->canon[x] : -1; }
@@ -537,7 +574,7 @@ MTB_HD int32_t mtb_num_buckets(int32_t read_len, int32_t dna_shift) { return (re
  * while exactly one child holds the maximal clade count and that count is
  * >= max((len-1)/denominator, ...) in the sense of BFS's compare chain.      */
 MTB_HD int32_t mtb_lower_rank(const mtb_tax_view *tx, const int32_t *tc_tax, const uint32_t *tc_cnt, int32_t n,
-                              int32_t species, int32_t read_len, int32_t denominator) {
+                              int32_t species, int32_t read_len, int32_t denominator, int32_t accession_level = 0) {
     uint32_t thr = (uint32_t)((read_len - 1) / denominator);
     int32_t root = mtb_tax_canon(tx, species);
     if (root < 0) return species;
@@ -551,6 +588,7 @@ MTB_HD int32_t mtb_lower_rank(const mtb_tax_view *tx, const int32_t *tc_tax, con
             int32_t c = t;
             while (tx->depth[c] > tx->depth[root] + 1) c = tx->parent[c];
             if (tx->parent[c] != root) continue;
+            if (accession_level == 2 && tx->acc_leaf && tx->acc_leaf[c]) continue;     /* erased from the children list */
             any_child = true;
             /* count each distinct child once: only at its first contributing entry */
             bool first = true;
@@ -634,7 +672,7 @@ MTB_HD void mtb_read_finish(const mtb_tax_view *tx, const mtb_score_params *sp, 
         R->classification = (species >= 0 && species <= tx->max_taxid) ? tx->sp_parent[species] : 0;
         return;
     }
-    R->classification = mtb_lower_rank(tx, out_tax, out_cnt, ntc, species, read_len, sp->denominator);
+    R->classification = mtb_lower_rank(tx, out_tax, out_cnt, ntc, species, read_len, sp->denominator, sp->accession_level);
 }
 MTB_HD void mtb_read_decide(const mtb_match *m, int32_t n, const float *sps, const mtb_tax_view *tx,
                             const mtb_score_params *sp, int32_t read_len, int32_t *b_tax, uint8_t *b_ham,

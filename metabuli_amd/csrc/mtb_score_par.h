@@ -332,7 +332,7 @@ MTB_HD void mtb_lr_climb(const mtb_tax_view *tx, int32_t tax, int32_t species, i
     *lev_out = (a == cs) ? L : -1;
 }
 MTB_HD int32_t mtb_lr_bfs(const int32_t *lev, const int32_t *anc, const uint32_t *cnt, int32_t n, int32_t species_canon,
-                          int32_t read_len, int32_t denominator) {
+                          int32_t read_len, int32_t denominator, const mtb_tax_view *tx = 0, int32_t accession_level = 0) {
     uint32_t thr = (uint32_t)((read_len - 1) / denominator);
     int32_t root = species_canon;
     for (int32_t level = 0; level < MTB_LR_K; level++) {
@@ -342,6 +342,7 @@ MTB_HD int32_t mtb_lr_bfs(const int32_t *lev, const int32_t *anc, const uint32_t
             if (lev[i] <= level) continue;
             if (level > 0 && anc[i * MTB_LR_K + level - 1] != root) continue;
             int32_t c = anc[i * MTB_LR_K + level];
+            if (accession_level == 2 && tx && tx->acc_leaf && tx->acc_leaf[c]) continue;      /* Taxonomer.cpp:256-267 */
             any = true;
             bool first = true;
             for (int32_t j = 0; j < i && first; j++)

@@ -93,7 +93,7 @@ def mutate(rng, seq, rate):
 
 def make_world(seed=1, n_genera=4, species_per_genus=2, strains_per_species=2,
                genome_len=30000, genus_div=0.15, strain_div=0.01, with_euk=True,
-               n_filler_species=0) -> World:
+               n_filler_species=0, strain_rank="no rank") -> World:
     """root -> {Bacteria, Eukaryota} -> genus -> species -> strain (no rank)."""
     rng = np.random.default_rng(seed)
     tax = Taxonomy()
@@ -114,7 +114,7 @@ def make_world(seed=1, n_genera=4, species_per_genus=2, strains_per_species=2,
             sp_seq = mutate(rng, anc, genus_div)
             for k in range(strains_per_species):
                 tid = nxt; nxt += 1
-                tax.add(tid, sid, "no rank", f"Genus{g} species{s} strain{k}")
+                tax.add(tid, sid, strain_rank, f"Genus{g} species{s} strain{k}")
                 genomes.append((tid, mutate(rng, sp_seq, strain_div)))
     lo = nxt
     for i in range(n_filler_species):

@@ -171,6 +171,46 @@ struct MetamerScanner {
     }
 };
 
+// OldMetamerScanner (KmerScanner.h:119-181): kmerFormat 1.  Forward frames consume
+// codons from the END of the window, reverse frames from its start; the amino-acid
+// part is a base-21 number kept with a deque of positional weights.
+struct OldMetamerScanner {
+    const char *seq; int seqStart, seqEnd; bool fwd; int aaLen, posStart, loaded; uint64_t dnaPart, aaPart;
+    std::deque<uint64_t> dq;
+    void init(const char *s, int a, int b, bool f) { seq = s; seqStart = a; seqEnd = b; fwd = f; aaLen = (b - a + 1) / 3; posStart = 0; loaded = 0; dnaPart = aaPart = 0; dq.clear(); }
+    bool next(ScanOut &o) {
+        while (posStart <= aaLen - 8) {
+            bool sawN = false;
+            loaded -= (loaded == 8);
+            while (loaded < 8) {
+                int a, b, c;
+                if (fwd) {
+                    int ci = seqEnd - (posStart + loaded) * 3;
+                    a = BT.fwd[(unsigned char)seq[ci - 2]]; b = BT.fwd[(unsigned char)seq[ci - 1]]; c = BT.fwd[(unsigned char)seq[ci]];
+                } else {
+                    int ci = seqStart + (posStart + loaded) * 3;
+                    a = BT.rev[(unsigned char)seq[ci + 2]]; b = BT.rev[(unsigned char)seq[ci + 1]]; c = BT.rev[(unsigned char)seq[ci]];
+                }
+                int aa = CT.aa[a][b][c], codon = CT.num[a][b][c];
+                if (aa < 0) { sawN = true; break; }
+                if (dq.size() == 8) { aaPart = aaPart - dq.back(); dq.pop_back(); }
+                for (auto &x : dq) x *= 21;
+                dq.push_front((uint64_t)aa);
+                aaPart = aaPart * 21 + (uint64_t)aa;
+                dnaPart = (dnaPart << 3) | (uint64_t)codon;
+                loaded++;
+            }
+            if (sawN) { posStart += loaded + 1; dnaPart = aaPart = 0; loaded = 0; dq.clear(); continue; }
+            o.value = (aaPart << 24) | (dnaPart & 0xFFFFFFull);
+            if (fwd) o.pos = (uint32_t)(seqEnd - (posStart + 8) * 3 + 1);
+            else     o.pos = (uint32_t)(seqStart + posStart * 3);
+            posStart++;
+            return true;
+        }
+        return false;
+    }
+};
+
 // SyncmerScanner (SyncmerScanner.h:9-101)
 struct SyncmerScanner {
     CodonReader rd; int aaLen; int posStart; int loaded; uint64_t dnaPart, aaPart;
@@ -233,14 +273,17 @@ size_t fill_query_kmers(const char *seq, int seqLen, const orc_params &p, uint32
                         uint32_t offset, orc_kmer *out, size_t cap) {
     size_t n = 0;
     int usedLen = max_covered_length(seqLen);
-    MetamerScanner ms; SyncmerScanner ss;
+    MetamerScanner ms; SyncmerScanner ss; OldMetamerScanner os;
     for (int frame = 0; frame < 6; frame++) {
         bool fwd = frame < 3;
         int begin;
         if (fwd) begin = frame % 3;
         else { begin = (seqLen % 3) - (frame % 3); if (begin < 0) begin += 3; }
         ScanOut o;
-        if (p.syncmer) {
+        if (p.kmer_format == 1) {          // KmerExtractor.cpp:13-17: format 1 always uses OldMetamerScanner
+            os.init(seq, begin, begin + usedLen - 1, fwd);
+            while (os.next(o)) { if (n < cap) out[n] = {o.value, qinfo_pack(seqID, o.pos + offset, (uint32_t)frame)}; n++; }
+        } else if (p.syncmer) {
             ss.init(seq, begin, begin + usedLen - 1, fwd, p.smer_len);
             while (ss.next(o)) { if (n < cap) out[n] = {o.value, qinfo_pack(seqID, o.pos + offset, (uint32_t)frame)}; n++; }
         } else {

@@ -29,11 +29,13 @@ class Toy:
     """A toy database + reads + the oracle's full answer, built once per mode."""
 
     def __init__(self, orc, tmpdir, syncmer, paired, seed, n_reads=400, length=150, seq_mode=None, err=0.01,
-                 lognormal=False, genome_len=30000, with_n=0.1):
+                 lognormal=False, genome_len=30000, with_n=0.1, kmer_format=2, accession_level=0, strain_rank="no rank"):
         from helpers import build_toy_db, default_params
         from metabuli_amd import synth
-        self.p = default_params(seq_mode=seq_mode or (2 if paired else 1), syncmer=syncmer)
-        self.world = synth.make_world(seed=seed, n_genera=4, species_per_genus=3, strains_per_species=2, genome_len=genome_len)
+        self.p = default_params(seq_mode=seq_mode or (2 if paired else 1), syncmer=syncmer, kmer_format=kmer_format,
+                                accession_level=accession_level)
+        self.world = synth.make_world(seed=seed, n_genera=4, species_per_genus=3, strains_per_species=2, genome_len=genome_len,
+                                      strain_rank=strain_rank)
         self.dbdir = str(tmpdir)
         self.values, self.taxids = build_toy_db(orc, self.world, self.p, self.dbdir)
         self.tax = orc.load_taxonomy(os.path.join(self.dbdir, "taxonomy"))
@@ -54,6 +56,8 @@ TOY_MODES = {
     "dense_se": dict(syncmer=0, paired=False, seed=2),
     "sync_pe": dict(syncmer=1, paired=True, seed=3),
     "dense_pe": dict(syncmer=0, paired=True, seed=4),
+    "old_format_pe": dict(syncmer=0, paired=True, seed=6, kmer_format=1),
+    "sync_se_acc2": dict(syncmer=1, paired=False, seed=7, accession_level=2, strain_rank="accession"),
     "sync_long": dict(syncmer=1, paired=False, seed=5, n_reads=40, length=3000, seq_mode=3, err=0.05, lognormal=True),
 }
 

@@ -40,11 +40,16 @@ size_t emu_extract_batch(const char *bases, const uint64_t *offs, const char *ba
                 bool fwd = f < 3;
                 int32_t begin = mtb_frame_begin(len, f);
                 std::vector<uint8_t> cod((size_t)n_cod);
-                for (int j = 0; j < n_cod; j++) cod[(size_t)j] = mtb_codon_byte(&t, seq, mtb_codon_ci(begin, used, j, fwd), fwd);
+                const bool old_fmt = p->kmer_format == 1;
+                for (int j = 0; j < n_cod; j++)
+                    cod[(size_t)j] = old_fmt ? mtb_codon_byte_old(&t, seq, mtb_codon_ci_old(begin, used, j, fwd), fwd)
+                                             : mtb_codon_byte(&t, seq, mtb_codon_ci(begin, used, j, fwd), fwd);
                 for (int w = 0; w < n_win; w++) {
                     uint64_t v;
-                    if (mtb_window_metamer(&cod[(size_t)w], p->syncmer, p->smer_len, &v)) {
-                        if (n < cap) out[n] = {v, mtb_qinfo((uint32_t)(r + 1), mtb_window_pos(begin, used, w, fwd) + off, (uint32_t)f)};
+                    bool ok = old_fmt ? mtb_window_metamer_old(&cod[(size_t)w], &v) : mtb_window_metamer(&cod[(size_t)w], p->syncmer, p->smer_len, &v);
+                    if (ok) {
+                        uint32_t wp = old_fmt ? mtb_window_pos_old(begin, used, w, fwd) : mtb_window_pos(begin, used, w, fwd);
+                        if (n < cap) out[n] = {v, mtb_qinfo((uint32_t)(r + 1), wp + off, (uint32_t)f)};
                         n++;
                     }
                 }
@@ -72,10 +77,10 @@ size_t emu_join(const uint64_t *values, const uint32_t *info, uint64_t T, const 
 void emu_sort_matches(mtb_match *m, size_t n) { std::sort(m, m + n, [](const mtb_match &a, const mtb_match &b) { return mtb_match_less(a, b); }); }
 
 // mirrors kernels_score.hip score_read(): sequential over the sf blocks / species blocks
-size_t emu_score(const int32_t *canon, const int32_t *parent, const int32_t *depth, const uint8_t *under_euk, const int32_t *sp_parent, int32_t max_taxid,
+size_t emu_score(const uint8_t *acc_leaf, const int32_t *canon, const int32_t *parent, const int32_t *depth, const uint8_t *under_euk, const int32_t *sp_parent, int32_t max_taxid,
                  const mtb_params *p, const mtb_match *ml, size_t nM, size_t n_reads, const int32_t *qlen, const int32_t *qlen2,
                  mtb_result *res, int32_t *tc_tax, uint32_t *tc_cnt, size_t cap) {
-    mtb_tax_view tx{canon, parent, depth, under_euk, sp_parent, max_taxid};
+    mtb_tax_view tx{acc_leaf, canon, parent, depth, under_euk, sp_parent, max_taxid};
     mtb_score_params sp; mtb_make_score_params(p, &sp);
     for (size_t r = 0; r < n_reads; r++) { res[r] = mtb_result{0, 0.f, qlen[r], qlen2 ? qlen2[r] : 0, 0, 0, 0, 0}; }
     size_t w = 0, idx = 0;
@@ -123,12 +128,12 @@ size_t emu_score(const int32_t *canon, const int32_t *parent, const int32_t *dep
 
 // mirrors kernels_score.h score_read_par(): the per-element phases of
 // mtb_score_par.h run in plain loops (one loop == one lane-strided phase + barrier)
-size_t emu_score_par(const int32_t *canon, const int32_t *parent, const int32_t *depth, const uint8_t *under_euk, const int32_t *sp_parent,
+size_t emu_score_par(const uint8_t *acc_leaf, const int32_t *canon, const int32_t *parent, const int32_t *depth, const uint8_t *under_euk, const int32_t *sp_parent,
                      int32_t max_taxid, const mtb_params *p, const mtb_match *ml_in, size_t nM, size_t n_reads, const int32_t *qlen,
                      const int32_t *qlen2, mtb_result *res, int32_t *tc_tax, uint32_t *tc_cnt, size_t cap, int presorted, int use_chain,
                      size_t *n_chain_out) {
     size_t n_chain_reads = 0;
-    mtb_tax_view tx{canon, parent, depth, under_euk, sp_parent, max_taxid};
+    mtb_tax_view tx{acc_leaf, canon, parent, depth, under_euk, sp_parent, max_taxid};
     mtb_score_params sp; mtb_make_score_params(p, &sp);
     for (size_t r = 0; r < n_reads; r++) { res[r] = mtb_result{0, 0.f, qlen[r], qlen2 ? qlen2[r] : 0, 0, 0, 0, 0}; }
     size_t wout = 0, idx = 0;
@@ -222,8 +227,8 @@ size_t emu_score_par(const int32_t *canon, const int32_t *parent, const int32_t 
                 std::vector<int32_t> lev((size_t)std::max(ntc, 1)), anc((size_t)std::max(ntc, 1) * MTB_LR_K);
                 if (!slow) for (int32_t i = 0; i < ntc; i++) { mtb_lr_climb(&tx, otax[(size_t)i], species, &lev[(size_t)i], &anc[(size_t)i * MTB_LR_K]); if (lev[(size_t)i] > MTB_LR_K) slow = true; }
                 int32_t cs = mtb_tax_canon(&tx, species);
-                if (slow || cs < 0) R.classification = mtb_lower_rank(&tx, otax.data(), ocnt.data(), ntc, species, read_len, sp.denominator);
-                else R.classification = mtb_lr_bfs(lev.data(), anc.data(), ocnt.data(), ntc, cs, read_len, sp.denominator);
+                if (slow || cs < 0) R.classification = mtb_lower_rank(&tx, otax.data(), ocnt.data(), ntc, species, read_len, sp.denominator, sp.accession_level);
+                else R.classification = mtb_lr_bfs(lev.data(), anc.data(), ocnt.data(), ntc, cs, read_len, sp.denominator, &tx, sp.accession_level);
             }
             for (int32_t k = 0; k < ntc; k++) { if (wout < cap) { tc_tax[wout] = otax[(size_t)k]; tc_cnt[wout] = ocnt[(size_t)k]; } wout++; }
         }
@@ -235,7 +240,7 @@ size_t emu_score_par(const int32_t *canon, const int32_t *parent, const int32_t 
 
 // host_db.h (what mtb_index_open does on the host) exposed for CPU tests
 int emu_load_taxonomy(const char *dir, const int32_t *taxid_list, size_t n_ids, int32_t cap, int32_t *max_id, int32_t *canon, int32_t *parent,
-                      int32_t *depth, uint8_t *under_euk, int32_t *sp_parent, int32_t *tax2species) {
+                      int32_t *depth, uint8_t *under_euk, int32_t *sp_parent, int32_t *tax2species, uint8_t *acc_leaf) {
     mtbhost::Taxonomy t; std::string err;
     if (!mtbhost::load_taxonomy(dir, &t, &err)) return 1;
     mtbhost::build_tax2species(&t, taxid_list, n_ids);
@@ -243,7 +248,7 @@ int emu_load_taxonomy(const char *dir, const int32_t *taxid_list, size_t n_ids, 
     if (t.max_id + 1 > cap) return 2;
     size_t n = (size_t)t.max_id + 1;
     memcpy(canon, t.canon.data(), n * 4); memcpy(parent, t.parent.data(), n * 4); memcpy(depth, t.depth.data(), n * 4);
-    memcpy(under_euk, t.under_euk.data(), n); memcpy(sp_parent, t.sp_parent.data(), n * 4); memcpy(tax2species, t.tax2species.data(), n * 4);
+    memcpy(acc_leaf, t.acc_leaf.data(), n); memcpy(under_euk, t.under_euk.data(), n); memcpy(sp_parent, t.sp_parent.data(), n * 4); memcpy(tax2species, t.tax2species.data(), n * 4);
     return 0;
 }
 int emu_load_db_parameters(const char *dir, mtb_params *p) { return mtbhost::load_db_parameters(dir, p) ? 0 : 1; }

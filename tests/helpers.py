@@ -222,23 +222,23 @@ class Emu:
         return m
 
     def score(self, taxarr, p, m, n_reads, ql, ql2):
-        canon, parent, depth, under_euk, sp_parent = taxarr
+        canon, parent, depth, under_euk, sp_parent, acc = taxarr
         res = np.zeros(n_reads, result_dt)
         cap = max(1024, len(m) + 16)
         tt = np.zeros(cap, np.int32); tc = np.zeros(cap, np.uint32)
-        n = self.lib.emu_score(_ptr(canon), _ptr(parent), _ptr(depth), _ptr(under_euk), _ptr(sp_parent), C.c_int32(len(parent) - 1),
+        n = self.lib.emu_score(_ptr(acc), _ptr(canon), _ptr(parent), _ptr(depth), _ptr(under_euk), _ptr(sp_parent), C.c_int32(len(parent) - 1),
                                C.byref(p), _ptr(m), C.c_size_t(len(m)), C.c_size_t(n_reads), _ptr(ql), _ptr(ql2),
                                _ptr(res), _ptr(tt), _ptr(tc), C.c_size_t(cap))
         return res, tt[:n].copy(), tc[:n].copy()
 
 
 def _emu_score_par(self, taxarr, p, m, n_reads, ql, ql2, presorted=True, use_chain=True):
-    canon, parent, depth, under_euk, sp_parent = taxarr
+    canon, parent, depth, under_euk, sp_parent, acc = taxarr
     res = np.zeros(n_reads, result_dt)
     cap = max(1024, len(m) + 16)
     tt = np.zeros(cap, np.int32); tc = np.zeros(cap, np.uint32)
     nchain = C.c_size_t(0)
-    n = self.lib.emu_score_par(_ptr(canon), _ptr(parent), _ptr(depth), _ptr(under_euk), _ptr(sp_parent), C.c_int32(len(parent) - 1),
+    n = self.lib.emu_score_par(_ptr(acc), _ptr(canon), _ptr(parent), _ptr(depth), _ptr(under_euk), _ptr(sp_parent), C.c_int32(len(parent) - 1),
                                C.byref(p), _ptr(m), C.c_size_t(len(m)), C.c_size_t(n_reads), _ptr(ql), _ptr(ql2),
                                _ptr(res), _ptr(tt), _ptr(tc), C.c_size_t(cap), C.c_int(1 if presorted else 0),
                                C.c_int(1 if use_chain else 0), C.byref(nchain))
@@ -253,14 +253,14 @@ def _emu_load_taxonomy(self, d, taxids):
     """host_db.h: the dense taxonomy arrays libmtb uploads at index-open time."""
     cap = 1 << 22
     arrs = [np.zeros(cap, np.int32) for _ in range(3)]
-    under = np.zeros(cap, np.uint8); spp = np.zeros(cap, np.int32); t2s = np.zeros(cap, np.int32)
+    under = np.zeros(cap, np.uint8); spp = np.zeros(cap, np.int32); t2s = np.zeros(cap, np.int32); acc = np.zeros(cap, np.uint8)
     mx = C.c_int32()
     ids = np.ascontiguousarray(taxids, dtype=np.int32)
     rc = self.lib.emu_load_taxonomy(d.encode(), _ptr(ids), C.c_size_t(len(ids)), C.c_int32(cap), C.byref(mx), _ptr(arrs[0]), _ptr(arrs[1]),
-                                    _ptr(arrs[2]), _ptr(under), _ptr(spp), _ptr(t2s))
+                                    _ptr(arrs[2]), _ptr(under), _ptr(spp), _ptr(t2s), _ptr(acc))
     assert rc == 0
     n = mx.value + 1
-    return (arrs[0][:n].copy(), arrs[1][:n].copy(), arrs[2][:n].copy(), under[:n].copy(), spp[:n].copy()), t2s[:n].copy()
+    return (arrs[0][:n].copy(), arrs[1][:n].copy(), arrs[2][:n].copy(), under[:n].copy(), spp[:n].copy(), acc[:n].copy()), t2s[:n].copy()
 
 
 Emu.load_taxonomy = _emu_load_taxonomy
@@ -286,7 +286,10 @@ def tax_arrays(orc: Oracle, tax, world_tax):
         sp = L.orc_tax_at_rank(tax, t, b"species")
         spp[t] = L.orc_tax_parent(tax, sp) if sp > 0 else 0
     canon = np.where(parent >= 0, np.arange(mx + 1, dtype=np.int32), -1).astype(np.int32)
-    return canon, parent, depth, under, spp
+    acc = np.zeros(mx + 1, np.uint8)
+    for t, r in world_tax.rank.items():
+        acc[t] = 1 if r in ("", "accession") else 0
+    return canon, parent, depth, under, spp, acc
 
 
 def tax2species_table(orc: Oracle, tax, taxids, mx):
@@ -316,7 +319,7 @@ def build_toy_db(orc: Oracle, world, p, dbdir, extra=None):
     per = []
     for tid, g in world.genomes:
         offs = np.array([0, len(g)], dtype=np.uint64)
-        pp = default_params(seq_mode=3, syncmer=p.syncmer, smer_len=p.smer_len)
+        pp = default_params(seq_mode=3, syncmer=p.syncmer, smer_len=p.smer_len, kmer_format=p.kmer_format)
         k, _, _ = orc.extract_batch(pp, g, offs)
         per.append(k["value"].copy())
     vals, tids = synth.dedup_targets(world, per)

@@ -38,7 +38,7 @@ def test_db_files_and_split_checkpoints(toy, orc):
         assert toy.values[j] == ad and ends[j] + 1 == doff
         assert (toy.values[j] & aam) != (toy.values[j - 1] & aam)   # checkpoints sit on a new amino-acid part
     txt = open(os.path.join(d, "db.parameters")).read()
-    assert "Skip_redundancy\t1" in txt and "Kmer_format\t2" in txt
+    assert "Skip_redundancy\t1" in txt and f"Kmer_format\t{toy.p.kmer_format}" in txt
 
 
 def test_db_parameters_override(toy, emu):
@@ -46,5 +46,5 @@ def test_db_parameters_override(toy, emu):
     from helpers import Params
     p = Params(seq_mode=2, syncmer=0, smer_len=5, kmer_format=1, skip_redundancy=0)
     assert emu.lib.emu_load_db_parameters(toy.dbdir.encode(), C.byref(p)) == 0
-    assert p.kmer_format == 2 and p.skip_redundancy == 1 and p.syncmer == toy.p.syncmer
+    assert p.kmer_format == toy.p.kmer_format and p.skip_redundancy == 1 and p.syncmer == toy.p.syncmer
     assert p.smer_len == 5     # the DB writes "Syncmer_len", the loader reads "S-mer_len" 

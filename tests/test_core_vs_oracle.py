@@ -55,7 +55,7 @@ def _tables(toy, orc):
 def test_join_equals_oracle(toy, orc, emu):
     t2s, _ = _tables(toy, orc)
     q = np.sort(toy.ref["kmers"], order=["value"], kind="stable")
-    m = emu.join(toy.values, toy.taxids.astype(np.uint32), t2s, 0xFFFFFFFF, 2, q)
+    m = emu.join(toy.values, toy.taxids.astype(np.uint32), t2s, 0xFFFFFFFF, toy.p.kmer_format, q)
     ms = emu.sort_matches(m)
     assert len(ms) == len(toy.ref["matches"]) and (ms == toy.ref["matches"]).all()
 
@@ -66,12 +66,12 @@ def test_join_last_index_entry_is_never_a_candidate(toy, orc, emu):
     q = np.zeros(2, kmer_dt)
     q["value"] = [toy.values[-2], toy.values[-1]]
     q["qinfo"] = np.uint64(1) << np.uint64(32)
-    me = emu.sort_matches(emu.join(toy.values, toy.taxids.astype(np.uint32), t2s, 0xFFFFFFFF, 2, q))
+    me = emu.sort_matches(emu.join(toy.values, toy.taxids.astype(np.uint32), t2s, 0xFFFFFFFF, toy.p.kmer_format, q))
     mo = orc.sort_matches(orc.match(toy.db, q))
     assert len(me) == len(mo) and (me == mo).all()
     # a query equal to the last entry alone finds nothing unless earlier entries share its amino-acid part
     q1 = q[1:].copy()
-    m1 = emu.join(toy.values, toy.taxids.astype(np.uint32), t2s, 0xFFFFFFFF, 2, q1)
+    m1 = emu.join(toy.values, toy.taxids.astype(np.uint32), t2s, 0xFFFFFFFF, toy.p.kmer_format, q1)
     aam = ~np.uint64(0xFFFFFF)
     n_same = int(((toy.values[:-1] & aam) == (toy.values[-1] & aam)).sum())
     assert (len(m1) == 0) == (n_same == 0)
@@ -128,9 +128,9 @@ def test_score_parameter_variants(orc, emu, tmp_path, kw):
 
 def test_host_taxonomy_loader_equals_oracle(toy, orc, emu):
     """host_db.h (libmtb's loader) vs the oracle's taxonomy services."""
-    (canon, parent, depth, under, spp), t2s = emu.load_taxonomy(os.path.join(toy.dbdir, "taxonomy"), np.unique(toy.taxids))
-    t2s_o, (canon_o, parent_o, depth_o, under_o, spp_o) = _tables(toy, orc)
-    assert (canon == canon_o).all() and (depth == depth_o).all() and (under == under_o).all() and (spp == spp_o).all()
+    (canon, parent, depth, under, spp, acc), t2s = emu.load_taxonomy(os.path.join(toy.dbdir, "taxonomy"), np.unique(toy.taxids))
+    t2s_o, (canon_o, parent_o, depth_o, under_o, spp_o, acc_o) = _tables(toy, orc)
+    assert (canon == canon_o).all() and (depth == depth_o).all() and (under == under_o).all() and (spp == spp_o).all() and (acc == acc_o).all()
     assert (parent[canon >= 0] == parent_o[canon >= 0]).all()
     assert (t2s == t2s_o).all()
 

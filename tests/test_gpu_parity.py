@@ -21,7 +21,8 @@ def ctx():
 def _params(toy):
     import metabuli_amd as M
     p = toy.p
-    return M.default_params(seq_mode=p.seq_mode, syncmer=p.syncmer, smer_len=p.smer_len)
+    return M.default_params(seq_mode=p.seq_mode, syncmer=p.syncmer, smer_len=p.smer_len, kmer_format=p.kmer_format,
+                            accession_level=p.accession_level)
 
 
 def _sorted_by_value_then_all(k):
