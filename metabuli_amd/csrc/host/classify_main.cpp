@@ -10,7 +10,8 @@
  *   mtb_classify [flags] <FASTA/Q> [<FASTA/Q mate>] <DBDIR> <OUTDIR> <JobID>
  *   flags: --seq-mode 1|2|3  --min-score F  --min-sp-score F  --min-cons-cnt N
  *          --min-cons-cnt-euk N  --tie-ratio F  --taxonomy-path DIR
- *          --syncmer 0|1  --smer-len N  --max-reads N (batch size)  --device N
+ *          --syncmer 0|1  --smer-len N  --kmer-format 1|2  --accession-level 0|1|2
+ *          --max-reads N (batch size)  --device N
  */
 #include <cstdio>
 #include <cstring>
@@ -123,6 +124,8 @@ int main(int argc, char **argv) {
         else if (a == "--min-cons-cnt") par.min_cons_cnt = atoi(val().c_str());
         else if (a == "--min-cons-cnt-euk") par.min_cons_cnt_euk = atoi(val().c_str());
         else if (a == "--tie-ratio") par.tie_ratio = (float)atof(val().c_str());
+        else if (a == "--accession-level") par.accession_level = atoi(val().c_str());
+        else if (a == "--kmer-format") par.kmer_format = atoi(val().c_str());
         else if (a == "--taxonomy-path") taxdir = val();
         else if (a == "--syncmer") par.syncmer = atoi(val().c_str());
         else if (a == "--smer-len") par.smer_len = atoi(val().c_str());

@@ -179,7 +179,7 @@ def test_classify_driver_tsv_outputs(toy, orc, tmp_path):
                 s = bytes(bases[int(offs[i]):int(offs[i + 1])]).decode()
                 f.write(f"@{nm} some comment\n{s}\n+\n{'I' * len(s)}\n")
     fq1 = str(tmp_path / "r1.fq"); write_fastq(fq1, toy.b1, toy.o1)
-    args = [exe, "--seq-mode", str(toy.p.seq_mode), "--max-reads", "97"]
+    args = [exe, "--seq-mode", str(toy.p.seq_mode), "--max-reads", "97", "--accession-level", str(toy.p.accession_level)]
     args.append(fq1)
     if toy.b2 is not None:
         fq2 = str(tmp_path / "r2.fq"); write_fastq(fq2, toy.b2, toy.o2); args.append(fq2)
