@@ -33,7 +33,7 @@ __device__ __forceinline__ void rec_set(mtb_match32 &r, const mtb_match &m) { r.
 #endif
 #define MTB_JOIN_QPB (256 * MTB_JOIN_QPT)   /* sorted queries per workgroup                     */
 #ifndef MTB_JOIN_WIN
-#define MTB_JOIN_WIN 4096                   /* target values staged in LDS (32 KB)              */
+#define MTB_JOIN_WIN 2560                   /* target values staged in LDS (20 KB -> 7 workgroups/CU; sweep in profiles/r01_notes.md) */
 #endif
 
 /* Target window of every query tile, one lane per tile: the tile is sorted at
