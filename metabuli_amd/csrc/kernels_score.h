@@ -363,7 +363,8 @@ __global__ __launch_bounds__(64, MTB_SCORE_MINWAVES) void k_score(const REC *__r
                                                mtb_result *__restrict__ results, int32_t *__restrict__ tc_tax,
                                                uint32_t *__restrict__ tc_cnt, uint64_t tc_cap, uint8_t *__restrict__ slabs,
                                                uint64_t slab_bytes, uint32_t slab_max_n, uint32_t slab_max_nb,
-                                               mtb_match *__restrict__ sorted_out, uint64_t tc_base) {
+                                               mtb_match *__restrict__ sorted_out, uint64_t tc_base,
+                                               const uint32_t *__restrict__ list, const uint32_t *__restrict__ n_list) {
     __shared__ __attribute__((aligned(16))) uint8_t s_ws[MTB_SCORE_WS_BYTES];
     /* bucket / taxCnt / chain arrays of the decide phase live in the path storage,
      * which is dead once the species scores exist (keeps LDS per wave small -> occupancy) */
@@ -375,7 +376,9 @@ __global__ __launch_bounds__(64, MTB_SCORE_MINWAVES) void k_score(const REC *__r
 #endif
     const uint32_t lane = threadIdx.x;
     MTB_PHASE_KERNEL_BEGIN();
-    for (uint64_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
+    const uint64_t n_iter = list ? (uint64_t)*n_list : n_reads;      /* optional: only the listed reads */
+    for (uint64_t it = blockIdx.x; it < n_iter; it += gridDim.x) {
+        const uint64_t r = list ? (uint64_t)list[it] : it;
         const uint64_t s0 = seg_start[r];
         const int32_t n = (int32_t)(seg_start[r + 1] - s0);
         const int32_t ql1 = qlen[r], ql2 = qlen2[r];

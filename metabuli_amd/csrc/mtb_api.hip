@@ -339,6 +339,7 @@ static mtb_status dev_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, cons
     *n_tc = tot;
     if (tot > tc_cap) return fail(MTB_ERR_CAPACITY, "taxcnt buffers too small");
     uint32_t grid = (uint32_t)std::min<uint64_t>(n_reads, 256ull * 12);
+    const uint32_t *list = nullptr, *n_list = nullptr;
     /* reads with a big segment OR many position buckets are scored entirely out of a slab */
     uint32_t max_nb = (uint32_t)mtb_num_buckets((int32_t)max_len, sp.dna_shift);
     bool need_slab = max_seg > MTB_SCORE_LDS || max_nb > MTB_SCORE_BKT;
@@ -355,7 +356,7 @@ static mtb_status dev_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, cons
     /* single-word sort key when taxids < 2^22 and positions < 2^11 (hamming of a match is <= 7) */
     bool key64 = ix->tax.max_id < (1 << 22) && max_len + 3 < (1u << 11);
 #define MTB_LAUNCH_SCORE(S, K) hipLaunchKernelGGL((k_score<S, K, REC>), dim3(grid), dim3(64), 0, c->stream, d_m, d_seg, n_reads, d_qlen, d_qlen2, \
-        tax_view(ix), sp, (const uint64_t *)d_tcoff, d_res, d_tc_tax, d_tc_cnt, tc_cap, d_slabs, slab_bytes, slab_n, slab_nb, (mtb_match *)nullptr, tc_base)
+        tax_view(ix), sp, (const uint64_t *)d_tcoff, d_res, d_tc_tax, d_tc_cnt, tc_cap, d_slabs, slab_bytes, slab_n, slab_nb, (mtb_match *)nullptr, tc_base, list, n_list)
     if (fused_sort) { if (key64) MTB_LAUNCH_SCORE(true, true); else MTB_LAUNCH_SCORE(true, false); }
     else MTB_LAUNCH_SCORE(false, false);
 #undef MTB_LAUNCH_SCORE
@@ -709,21 +710,31 @@ mtb_status mtb_classify_batch_device(mtb_ctx *c, mtb_index *ix, const mtb_params
     std::vector<std::string> errs(L);
     std::vector<uint64_t> ntc(L, 0);
     std::vector<std::thread> th;
-    const uint64_t tc_share = taxcnt_cap / L;
+    /* `chunks` read ranges per stream, interleaved (range k runs on stream k % L) */
+    static const int chunks = getenv("MTB_CHUNKS_PER_STREAM") ? std::max(1, atoi(getenv("MTB_CHUNKS_PER_STREAM"))) : 2;   /* sweep: profiles/r01_notes.md */
+    const size_t NC = L * (size_t)chunks;
+    const uint64_t tc_share = taxcnt_cap / NC;
+    std::vector<mtb_batch_stats> lane_stats(L);
+    for (size_t i = 0; i < L; i++) memset(&lane_stats[i], 0, sizeof(mtb_batch_stats));
     for (size_t i = 0; i < L; i++) {
-        uint64_t lo = n_reads * i / L, hi = n_reads * (i + 1) / L;
-        th.emplace_back([&, i, lo, hi]() {
+        th.emplace_back([&, i]() {
             mtb_ctx *l = c->lanes[i];
-            st[i] = classify_one(l, ix, p, d_bases, d_offs + lo, d_bases2, d_offs2 ? d_offs2 + lo : nullptr, hi - lo,
-                                 n_bases_total * (hi - lo) / n_reads, d_results + lo, d_taxcnt_tax + tc_share * i,
-                                 d_taxcnt_cnt + tc_share * i, tc_share, &ntc[i], tc_share * i);
-            if (st[i] != MTB_OK) errs[i] = g_err;
+            for (size_t k = i; k < NC; k += L) {
+                uint64_t lo = n_reads * k / NC, hi = n_reads * (k + 1) / NC;
+                uint64_t n_tc = 0;
+                mtb_status s = classify_one(l, ix, p, d_bases, d_offs + lo, d_bases2, d_offs2 ? d_offs2 + lo : nullptr, hi - lo,
+                                            n_bases_total * (hi - lo) / n_reads, d_results + lo, d_taxcnt_tax + tc_share * k,
+                                            d_taxcnt_cnt + tc_share * k, tc_share, &n_tc, tc_share * k);
+                ntc[i] = std::max(ntc[i], n_tc * NC / L);
+                if (s != MTB_OK) { st[i] = s; errs[i] = g_err; break; }
+                merge_stats(lane_stats[i], l->stats);
+            }
         });
     }
     for (auto &t : th) t.join();
     memset(&c->stats, 0, sizeof(c->stats));
     uint64_t need = 0;
-    for (size_t i = 0; i < L; i++) { merge_stats(c->stats, c->lanes[i]->stats); need = std::max(need, ntc[i] * L); }
+    for (size_t i = 0; i < L; i++) { merge_stats(c->stats, lane_stats[i]); need = std::max(need, ntc[i] * L); }
     c->stats.ms_total = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     *n_taxcnt = taxcnt_cap;                             /* slots are spread over the whole array */
     for (size_t i = 0; i < L; i++)
