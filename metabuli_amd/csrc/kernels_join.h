@@ -54,10 +54,20 @@ __global__ __launch_bounds__(256) void k_join_bounds(const mtb_kmer *__restrict_
     bounds[2 * t] = lo; bounds[2 * t + 1] = hi;
 }
 
+/* SEG mode (short reads, fused path): every read owns a fixed-capacity segment of `stride` records; the
+ * query's matches go straight to seg[read * stride + slot] with slot from ONE returning atomic on the read's
+ * cursor -- no temp buffer, no regroup pass, no segment scan.  Matches beyond the capacity are appended to an
+ * overflow list and their reads complete on the large-segment path (k_big_*).                          */
+struct JoinSegArgs {
+    mtb_match *seg; uint32_t stride; uint32_t *cursor;
+    mtb_match *ovf; uint64_t ovf_cap; unsigned long long *ovf_counter;
+};
+
+template <bool SEG>
 __global__ __launch_bounds__(256) void k_join(const mtb_kmer *__restrict__ q, uint64_t n, mtb_index_view ix,
                                                const mtb_tables *__restrict__ tabs, const uint64_t *__restrict__ bounds,
                                                mtb_match *__restrict__ out, uint64_t cap, unsigned long long *__restrict__ counter,
-                                               uint32_t *__restrict__ read_cnt, uint32_t *__restrict__ overflow) {
+                                               uint32_t *__restrict__ read_cnt, uint32_t *__restrict__ overflow, JoinSegArgs sa) {
     __shared__ mtb_tables s_tab;
     __shared__ uint32_t s_tmp[8];
     __shared__ unsigned long long s_base;
@@ -96,6 +106,33 @@ __global__ __launch_bounds__(256) void k_join(const mtb_kmer *__restrict__ q, ui
         }
         csum += c[u];
     }
+    if (SEG) {
+#pragma unroll
+        for (int u = 0; u < MTB_JOIN_QPT; u++) {
+            if (c[u] == 0) continue;
+            const uint32_t r = mtb_q_seq(k[u].qinfo) - 1;
+            const uint32_t s = atomicAdd(&sa.cursor[r], c[u]);
+            const uint32_t fit = s < sa.stride ? (c[u] < sa.stride - s ? c[u] : sa.stride - s) : 0u;
+            mtb_match *dst = sa.seg + (uint64_t)r * sa.stride + s;
+            if (fit) {
+                if (in_lds) mtb_join_select(&s_tab, s_win, rs[u], rl[u], k[u].value, k[u].qinfo, ix.info, lo, ix.tax2species, ix.max_taxid,
+                                            ix.info_mask, ix.kmer_format, dst, fit, 0);
+                else mtb_join_select(&s_tab, ix.values + lo, rs[u], rl[u], k[u].value, k[u].qinfo, ix.info, lo, ix.tax2species, ix.max_taxid,
+                                     ix.info_mask, ix.kmer_format, dst, fit, 0);
+            }
+            const uint32_t n_ovf = c[u] - fit;
+            if (n_ovf) {
+                const unsigned long long o = atomicAdd(sa.ovf_counter, (unsigned long long)n_ovf);
+                if (o + n_ovf <= sa.ovf_cap) {
+                    if (in_lds) mtb_join_select(&s_tab, s_win, rs[u], rl[u], k[u].value, k[u].qinfo, ix.info, lo, ix.tax2species, ix.max_taxid,
+                                                ix.info_mask, ix.kmer_format, sa.ovf + o, n_ovf, fit);
+                    else mtb_join_select(&s_tab, ix.values + lo, rs[u], rl[u], k[u].value, k[u].qinfo, ix.info, lo, ix.tax2species, ix.max_taxid,
+                                         ix.info_mask, ix.kmer_format, sa.ovf + o, n_ovf, fit);
+                } else *overflow = 1;
+            }
+        }
+        return;
+    }
     uint32_t tot;
     uint32_t off = block256_exclusive_scan<uint32_t>(csum, s_tmp, &tot);
     if (threadIdx.x == 0) s_base = tot ? atomicAdd(counter, (unsigned long long)tot) : 0ull;
@@ -106,9 +143,7 @@ __global__ __launch_bounds__(256) void k_join(const mtb_kmer *__restrict__ q, ui
 #pragma unroll
     for (int u = 0; u < MTB_JOIN_QPT; u++) {
         if (c[u] == 0) continue;
-#ifndef MTB_EXP_NO_READCNT
         if (read_cnt) atomicAdd(&read_cnt[mtb_q_seq(k[u].qinfo) - 1], c[u]);
-#endif
         if (dst + c[u] <= cap) {
             if (in_lds) mtb_join_select(&s_tab, s_win, rs[u], rl[u], k[u].value, k[u].qinfo, ix.info, lo, ix.tax2species, ix.max_taxid,
                                         ix.info_mask, ix.kmer_format, out + dst, c[u]);
@@ -117,6 +152,39 @@ __global__ __launch_bounds__(256) void k_join(const mtb_kmer *__restrict__ q, ui
         }
         dst += c[u];
     }
+}
+
+/* ---- completion of the reads that overflowed their fixed segment ---- */
+__global__ __launch_bounds__(256) void k_big_list(const uint32_t *__restrict__ cursor, uint64_t n_reads, uint32_t stride,
+                                                   uint32_t *__restrict__ big_list, uint32_t *__restrict__ big_cnt, uint32_t *__restrict__ bigidx,
+                                                   uint32_t *__restrict__ n_big, uint32_t *__restrict__ max_seg) {
+    uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t n = 0;
+    if (r < n_reads) {
+        n = cursor[r];
+        if (n > stride) { uint32_t i = atomicAdd(n_big, 1u); big_list[i] = (uint32_t)r; big_cnt[i] = n; bigidx[r] = i; }
+    }
+    for (int d = 32; d > 0; d >>= 1) { uint32_t o = __shfl_down(n, d, 64); n = o > n ? o : n; }
+    if ((threadIdx.x & 63) == 0 && n > stride) atomicMax(max_seg, n);
+}
+__global__ __launch_bounds__(256) void k_big_copy(const mtb_match *__restrict__ seg, uint32_t stride, const uint32_t *__restrict__ big_list,
+                                                   const uint64_t *__restrict__ big_start, uint32_t n_big, uint32_t *__restrict__ bigcur,
+                                                   mtb_match *__restrict__ big) {
+    for (uint32_t b = blockIdx.x; b < n_big; b += gridDim.x) {
+        const uint64_t *src = (const uint64_t *)(seg + (uint64_t)big_list[b] * stride);
+        uint64_t *dst = (uint64_t *)(big + big_start[b]);
+        for (uint32_t i = threadIdx.x; i < stride * 3; i += 256) dst[i] = src[i];
+        if (threadIdx.x == 0) bigcur[b] = stride;
+    }
+}
+__global__ __launch_bounds__(256) void k_big_ovf(const mtb_match *__restrict__ ovf, uint64_t n_ovf, const uint32_t *__restrict__ bigidx,
+                                                  const uint64_t *__restrict__ big_start, uint32_t *__restrict__ bigcur, mtb_match *__restrict__ big) {
+    uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_ovf) return;
+    mtb_match m = ovf[i];
+    uint32_t b = bigidx[mtb_q_seq(m.qinfo) - 1];
+    uint32_t slot = atomicAdd(&bigcur[b], 1u);
+    big[big_start[b] + slot] = m;
 }
 
 /* Move every match into its read's segment (seg_start from a scan of the
@@ -200,7 +268,7 @@ __global__ __launch_bounds__(256) void k_segsort_large(REC *__restrict__ m, cons
                                                         const uint32_t *__restrict__ large, const uint32_t *__restrict__ n_large) {
     uint32_t nl = *n_large;
     for (uint32_t b = blockIdx.x; b < nl; b += gridDim.x) {
-        uint32_t r = large[b];
+        uint32_t r = large ? large[b] : b;
         uint64_t s = seg_start[r];
         uint32_t n = (uint32_t)(seg_start[r + 1] - s);
         seg_bitonic<256, REC>(m + s, n, threadIdx.x);

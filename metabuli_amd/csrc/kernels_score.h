@@ -50,12 +50,12 @@ __host__ __device__ __forceinline__ uint64_t score_slab_bytes(uint64_t n, uint64
     return (b + 63) & ~63ull;
 }
 
-__global__ __launch_bounds__(64) void k_taxcnt_bound(const uint64_t *__restrict__ seg_start, const int32_t *__restrict__ qlen,
-                                                      const int32_t *__restrict__ qlen2, uint64_t n_reads, int32_t dna_shift,
-                                                      uint32_t *__restrict__ bound) {
+__global__ __launch_bounds__(64) void k_taxcnt_bound(const uint64_t *__restrict__ seg_start, const uint32_t *__restrict__ cursor,
+                                                      const int32_t *__restrict__ qlen, const int32_t *__restrict__ qlen2, uint64_t n_reads,
+                                                      int32_t dna_shift, uint32_t *__restrict__ bound) {
     uint64_t r = (uint64_t)blockIdx.x * 64 + threadIdx.x;
     if (r >= n_reads) return;
-    uint64_t n = seg_start[r + 1] - seg_start[r];
+    uint64_t n = cursor ? (uint64_t)cursor[r] : seg_start[r + 1] - seg_start[r];
     uint64_t nb = (uint64_t)mtb_num_buckets(qlen[r] + qlen2[r], dna_shift);
     bound[r] = (uint32_t)(n < nb ? n : nb);
 }
@@ -364,7 +364,8 @@ __global__ __launch_bounds__(64, MTB_SCORE_MINWAVES) void k_score(const REC *__r
                                                uint32_t *__restrict__ tc_cnt, uint64_t tc_cap, uint8_t *__restrict__ slabs,
                                                uint64_t slab_bytes, uint32_t slab_max_n, uint32_t slab_max_nb,
                                                mtb_match *__restrict__ sorted_out, uint64_t tc_base,
-                                               const uint32_t *__restrict__ list, const uint32_t *__restrict__ n_list) {
+                                               const uint32_t *__restrict__ list, const uint32_t *__restrict__ n_list,
+                                               const uint32_t *__restrict__ cursor, uint32_t stride, int seg_by_list) {
     __shared__ __attribute__((aligned(16))) uint8_t s_ws[MTB_SCORE_WS_BYTES];
     /* bucket / taxCnt / chain arrays of the decide phase live in the path storage,
      * which is dead once the species scores exist (keeps LDS per wave small -> occupancy) */
@@ -379,8 +380,16 @@ __global__ __launch_bounds__(64, MTB_SCORE_MINWAVES) void k_score(const REC *__r
     const uint64_t n_iter = list ? (uint64_t)*n_list : n_reads;      /* optional: only the listed reads */
     for (uint64_t it = blockIdx.x; it < n_iter; it += gridDim.x) {
         const uint64_t r = list ? (uint64_t)list[it] : it;
-        const uint64_t s0 = seg_start[r];
-        const int32_t n = (int32_t)(seg_start[r + 1] - s0);
+        /* segment of read r: fixed-stride slots (cursor mode), or seg_start indexed by the read or by the list slot */
+        uint64_t s0; int32_t n;
+        if (cursor) {
+            uint32_t cn = cursor[r];
+            if (cn > stride) continue;                       /* completed on the large-segment path */
+            s0 = r * (uint64_t)stride; n = (int32_t)cn;
+        } else {
+            const uint64_t si = seg_by_list ? it : r;
+            s0 = seg_start[si]; n = (int32_t)(seg_start[si + 1] - s0);
+        }
         const int32_t ql1 = qlen[r], ql2 = qlen2[r];
         const int32_t read_len = ql1 + ql2;
         mtb_result R;

@@ -265,9 +265,11 @@ static mtb_tax_view tax_view(const mtb_index *ix) {
     return v;
 }
 
-/* join into d_out (cap entries); *count = matches found (may exceed cap -> MTB_ERR_CAPACITY) */
+/* join into d_out (cap entries); *count = matches found (may exceed cap -> MTB_ERR_CAPACITY).
+ * With `seg` (fixed-capacity per-read segments) matches go to seg->seg and the overflow list instead; *count is then
+ * the number of overflow entries needed and MTB_ERR_CAPACITY refers to the overflow list.                     */
 static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint64_t n, mtb_match *d_out, uint64_t cap,
-                           uint32_t *d_read_cnt, uint64_t *count) {
+                           uint32_t *d_read_cnt, uint64_t *count, const JoinSegArgs *seg = nullptr) {
     *count = 0;
     if (n == 0) return MTB_OK;
     HIPCHK(hipMemsetAsync(c->d_scal, 0, 16, c->stream));
@@ -278,14 +280,22 @@ static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint6
     { KTimer kt(c, MTB_K_JOIN);
     hipLaunchKernelGGL(k_join_bounds, dim3((grid + 255) / 256), dim3(256), 0, c->stream, d_q, n, (const uint64_t *)ix->d_values, limit,
                        (uint64_t)grid, d_bounds);
-    hipLaunchKernelGGL(k_join, dim3(grid), dim3(256), 0, c->stream, d_q, n, index_view(ix), (const mtb_tables *)c->d_tabs,
-                       (const uint64_t *)d_bounds, d_out, cap, (unsigned long long *)c->d_scal, d_read_cnt, (uint32_t *)(c->d_scal + 1)); }
+    if (seg) {
+        JoinSegArgs sa = *seg; sa.ovf_counter = (unsigned long long *)c->d_scal;
+        hipLaunchKernelGGL((k_join<true>), dim3(grid), dim3(256), 0, c->stream, d_q, n, index_view(ix), (const mtb_tables *)c->d_tabs,
+                           (const uint64_t *)d_bounds, (mtb_match *)nullptr, (uint64_t)0, (unsigned long long *)nullptr, (uint32_t *)nullptr,
+                           (uint32_t *)(c->d_scal + 1), sa);
+    } else {
+        JoinSegArgs sa; memset(&sa, 0, sizeof(sa));
+        hipLaunchKernelGGL((k_join<false>), dim3(grid), dim3(256), 0, c->stream, d_q, n, index_view(ix), (const mtb_tables *)c->d_tabs,
+                           (const uint64_t *)d_bounds, d_out, cap, (unsigned long long *)c->d_scal, d_read_cnt, (uint32_t *)(c->d_scal + 1), sa);
+    } }
     HIPCHK(hipGetLastError());
     uint64_t sc[2];
     STCHK(d2h(c, sc, c->d_scal, 16));
     *count = sc[0];
     if (sc[0] >= (1ull << 32)) return fail(MTB_ERR_ARG, "more than 2^32-1 matches in one batch; split the batch");
-    if (sc[0] > cap) return fail(MTB_ERR_CAPACITY, "match buffer too small");
+    if (sc[0] > (seg ? seg->ovf_cap : cap)) return fail(MTB_ERR_CAPACITY, "match buffer too small");
     return MTB_OK;
 }
 
@@ -320,45 +330,60 @@ static mtb_status dev_segsort(mtb_ctx *c, mtb_match *d_m, const uint64_t *d_seg,
     return MTB_OK;
 }
 
-/* d_results/d_tc_* are device outputs; *n_tc = sum of per-read bounds */
-template <typename REC>
-static mtb_status dev_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, const REC *d_m, const uint64_t *d_seg,
-                            uint64_t n_reads, const int32_t *d_qlen, const int32_t *d_qlen2, uint32_t max_seg, uint32_t max_len,
-                            mtb_result *d_res, int32_t *d_tc_tax, uint32_t *d_tc_cnt, uint64_t tc_cap, uint64_t *n_tc,
-                            bool fused_sort = false, uint64_t tc_base = 0) {
+/* where a scoring launch finds its segments */
+struct ScoreSrc {
+    const mtb_match *m = nullptr;
+    const uint64_t *seg = nullptr;        /* seg_start (by read, or by list slot if seg_by_list)            */
+    const uint32_t *cursor = nullptr;     /* fixed-stride mode: matches of read r at m[r*stride .. +cursor[r]) */
+    uint32_t stride = 0;
+    const uint32_t *list = nullptr, *n_list = nullptr;   /* only these reads */
+    int seg_by_list = 0;
+    bool sort = false;                    /* segments arrive unordered: rank sort in the kernel */
+    uint32_t max_seg = 0;                 /* largest segment this launch can meet */
+    uint32_t grid = 0;                    /* 0 = default */
+};
+
+/* d_results/d_tc_* are device outputs; *n_tc = sum of per-read bounds.  `second` (optional) is launched after
+ * `first` with the same per-read taxcnt slots (reads completed on the large-segment path). */
+static mtb_status dev_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, uint64_t n_reads, const int32_t *d_qlen, const int32_t *d_qlen2,
+                            uint32_t max_len, mtb_result *d_res, int32_t *d_tc_tax, uint32_t *d_tc_cnt, uint64_t tc_cap, uint64_t *n_tc,
+                            uint64_t tc_base, const ScoreSrc &first, const ScoreSrc *second) {
     mtb_score_params sp; mtb_make_score_params(p, &sp);
     uint32_t *d_bound; uint64_t *d_tcoff; uint64_t *d_ws;
     STCHK(ensure(c, "bound", n_reads, &d_bound));
     STCHK(ensure(c, "tcoff", n_reads + 1, &d_tcoff));
     STCHK(ensure(c, "scanws", scan_ws_elems(n_reads + 1), &d_ws));
-    hipLaunchKernelGGL(k_taxcnt_bound, dim3((uint32_t)((n_reads + 63) / 64)), dim3(64), 0, c->stream, d_seg, d_qlen, d_qlen2, n_reads,
-                       sp.dna_shift, d_bound);
-    scan_launch<uint32_t, uint64_t, false>(c->stream, d_bound, n_reads, true, d_tcoff, d_ws);
+    hipLaunchKernelGGL(k_taxcnt_bound, dim3((uint32_t)((n_reads + 63) / 64)), dim3(64), 0, c->stream, first.seg, first.cursor, d_qlen, d_qlen2,
+                       n_reads, sp.dna_shift, d_bound);
+    { KTimer kt(c, MTB_K_SCAN); scan_launch<uint32_t, uint64_t, false>(c->stream, d_bound, n_reads, true, d_tcoff, d_ws); }
     uint64_t tot = 0;
     STCHK(d2h(c, &tot, d_tcoff + n_reads, 8));
     *n_tc = tot;
     if (tot > tc_cap) return fail(MTB_ERR_CAPACITY, "taxcnt buffers too small");
-    uint32_t grid = (uint32_t)std::min<uint64_t>(n_reads, 256ull * 12);
-    const uint32_t *list = nullptr, *n_list = nullptr;
-    /* reads with a big segment OR many position buckets are scored entirely out of a slab */
-    uint32_t max_nb = (uint32_t)mtb_num_buckets((int32_t)max_len, sp.dna_shift);
-    bool need_slab = max_seg > MTB_SCORE_LDS || max_nb > MTB_SCORE_BKT;
-    uint32_t slab_n = need_slab ? std::max<uint32_t>(max_seg, 1) : 0;
-    uint32_t slab_nb = need_slab ? max_nb : 0;
-    uint64_t slab_bytes = need_slab ? score_slab_bytes(slab_n, slab_nb) : 0;
-    uint8_t *d_slabs = nullptr;
-    if (slab_bytes) {
-        /* keep the slab pool below 8 GiB by shrinking the grid */
-        while ((uint64_t)grid * slab_bytes > (8ull << 30) && grid > 64) grid /= 2;
-        STCHK(ensure(c, "slabs", (size_t)grid * slab_bytes, &d_slabs));
-    }
-    { KTimer kt(c, MTB_K_SCORE);
     /* single-word sort key when taxids < 2^22 and positions < 2^11 (hamming of a match is <= 7) */
-    bool key64 = ix->tax.max_id < (1 << 22) && max_len + 3 < (1u << 11);
-#define MTB_LAUNCH_SCORE(S, K) hipLaunchKernelGGL((k_score<S, K, REC>), dim3(grid), dim3(64), 0, c->stream, d_m, d_seg, n_reads, d_qlen, d_qlen2, \
-        tax_view(ix), sp, (const uint64_t *)d_tcoff, d_res, d_tc_tax, d_tc_cnt, tc_cap, d_slabs, slab_bytes, slab_n, slab_nb, (mtb_match *)nullptr, tc_base, list, n_list)
-    if (fused_sort) { if (key64) MTB_LAUNCH_SCORE(true, true); else MTB_LAUNCH_SCORE(true, false); }
-    else MTB_LAUNCH_SCORE(false, false);
+    const bool key64 = ix->tax.max_id < (1 << 22) && max_len + 3 < (1u << 11);
+    const uint32_t max_nb = (uint32_t)mtb_num_buckets((int32_t)max_len, sp.dna_shift);
+    const ScoreSrc *srcs[2] = {&first, second};
+    for (int pass = 0; pass < 2; pass++) {
+        const ScoreSrc *S = srcs[pass];
+        if (!S) continue;
+        uint32_t grid = S->grid ? S->grid : (uint32_t)std::min<uint64_t>(n_reads, 256ull * 12);
+        /* reads with a big segment OR many position buckets are scored entirely out of a slab */
+        bool need_slab = S->max_seg > MTB_SCORE_LDS || max_nb > MTB_SCORE_BKT;
+        uint32_t slab_n = need_slab ? std::max<uint32_t>(S->max_seg, 1) : 0;
+        uint32_t slab_nb = need_slab ? max_nb : 0;
+        uint64_t slab_bytes = need_slab ? score_slab_bytes(slab_n, slab_nb) : 0;
+        uint8_t *d_slabs = nullptr;
+        if (slab_bytes) {
+            while ((uint64_t)grid * slab_bytes > (8ull << 30) && grid > 64) grid /= 2;      /* keep the slab pool below 8 GiB */
+            STCHK(ensure(c, "slabs", (size_t)grid * slab_bytes, &d_slabs));
+        }
+        KTimer kt(c, MTB_K_SCORE);
+#define MTB_LAUNCH_SCORE(SRT, K) hipLaunchKernelGGL((k_score<SRT, K, mtb_match>), dim3(grid), dim3(64), 0, c->stream, S->m, S->seg, n_reads, d_qlen, \
+        d_qlen2, tax_view(ix), sp, (const uint64_t *)d_tcoff, d_res, d_tc_tax, d_tc_cnt, tc_cap, d_slabs, slab_bytes, slab_n, slab_nb, (mtb_match *)nullptr,  \
+        tc_base, S->list, S->n_list, S->cursor, S->stride, S->seg_by_list)
+        if (S->sort) { if (key64) MTB_LAUNCH_SCORE(true, true); else MTB_LAUNCH_SCORE(true, false); }
+        else MTB_LAUNCH_SCORE(false, false);
 #undef MTB_LAUNCH_SCORE
     }
     HIPCHK(hipGetLastError());
@@ -597,7 +622,8 @@ mtb_status mtb_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, const mtb_m
     for (uint64_t i = 0; i < n_reads; i++) { max_seg = std::max(max_seg, rc[i]); max_len = std::max<uint32_t>(max_len, (uint32_t)(qlen[i] + (qlen2 ? qlen2[i] : 0))); }
     mtb_result *d_res; int32_t *d_tt; uint32_t *d_tc;
     STCHK(ensure(c, "results", n_reads, &d_res)); STCHK(ensure(c, "tctax", taxcnt_cap, &d_tt)); STCHK(ensure(c, "tccnt", taxcnt_cap, &d_tc));
-    mtb_status st = dev_score(c, ix, p, d_m, d_seg, n_reads, d_ql, d_ql2, max_seg, max_len, d_res, d_tt, d_tc, taxcnt_cap, n_taxcnt);
+    ScoreSrc src; src.m = d_m; src.seg = d_seg; src.sort = false; src.max_seg = max_seg;
+    mtb_status st = dev_score(c, ix, p, n_reads, d_ql, d_ql2, max_len, d_res, d_tt, d_tc, taxcnt_cap, n_taxcnt, 0, src, nullptr);
     if (st != MTB_OK) return st;
     STCHK(d2h(c, results, d_res, n_reads * sizeof(mtb_result)));
     if (*n_taxcnt) { STCHK(d2h(c, taxcnt_tax, d_tt, *n_taxcnt * 4)); STCHK(d2h(c, taxcnt_cnt, d_tc, *n_taxcnt * 4)); }
@@ -636,39 +662,97 @@ static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, c
     uint32_t *d_rc;
     STCHK(ensure(c, "readcnt", n_reads, &d_rc));
     HIPCHK(hipMemsetAsync(d_rc, 0, n_reads * 4, st));
-    mtb_match *d_tmp; uint64_t nm = 0;
-    DevBuf &jb = c->bufs["jtemp"];
-    uint64_t cap = std::max<uint64_t>(jb.cap / sizeof(mtb_match), nk + nk / 2 + 1024);
-    for (int attempt = 0; attempt < 3; attempt++) {
-        STCHK(ensure(c, "jtemp", cap, &d_tmp));
-        mtb_status s = dev_join(c, ix, d_s, nk, d_tmp, cap, d_rc, &nm);
-        if (s == MTB_OK) break;
-        if (s != MTB_ERR_CAPACITY || attempt == 2) return s;
-        cap = nm + nm / 16 + 1024;                     /* the reference's retry (Classifier.cpp:127-131) with the exact size */
-        HIPCHK(hipMemsetAsync(d_rc, 0, n_reads * 4, st));
-    }
-    HIPCHK(hipEventRecord(c->ev[3], st));
-    mtb_match *d_m; uint64_t *d_seg;
-    STCHK(ensure(c, "matches", nm, &d_m));
-    STCHK(dev_regroup(c, d_tmp, nm, n_reads, d_rc, &d_seg, d_m));
-    HIPCHK(hipEventRecord(c->ev[4], st));
-    /* segments that fit LDS are sorted inside k_score; only the big ones are sorted in HBM here */
-    uint32_t max_seg = 0;
-    {
-        uint32_t *d_large;
-        STCHK(ensure(c, "large", n_reads, &d_large));
+    uint64_t nm = 0;
+    const bool fixed = p->seq_mode != 3;            /* short reads: fixed-capacity per-read segments */
+    if (fixed) {
+        /* ---- join straight into per-read segments of MTB_SCORE_LDS slots (d_rc = per-read cursor) ---- */
+        const uint32_t stride = MTB_SCORE_LDS;
+        mtb_match *d_segm; mtb_match *d_ovf; uint64_t n_ovf = 0;
+        STCHK(ensure(c, "segm", n_reads * (uint64_t)stride, &d_segm));
+        DevBuf &ob = c->bufs["ovf"];
+        uint64_t ovf_cap = std::max<uint64_t>(ob.cap / sizeof(mtb_match), nk / 64 + 4096);
+        for (int attempt = 0; attempt < 3; attempt++) {
+            STCHK(ensure(c, "ovf", ovf_cap, &d_ovf));
+            JoinSegArgs sa; sa.seg = d_segm; sa.stride = stride; sa.cursor = d_rc; sa.ovf = d_ovf; sa.ovf_cap = ovf_cap; sa.ovf_counter = nullptr;
+            mtb_status s2 = dev_join(c, ix, d_s, nk, nullptr, 0, nullptr, &n_ovf, &sa);
+            if (s2 == MTB_OK) break;
+            if (s2 != MTB_ERR_CAPACITY || attempt == 2) return s2;
+            ovf_cap = n_ovf + n_ovf / 16 + 1024;
+            HIPCHK(hipMemsetAsync(d_rc, 0, n_reads * 4, st));
+        }
+        HIPCHK(hipEventRecord(c->ev[3], st));
+        /* reads that overflowed: exact segments from (their fixed slots + the overflow list), sorted in HBM */
+        uint32_t *d_biglist, *d_bigcnt, *d_bigidx, *d_bigcur; uint64_t *d_bigstart = nullptr, *d_ws2; mtb_match *d_big = nullptr;
+        STCHK(ensure(c, "biglist", n_reads, &d_biglist)); STCHK(ensure(c, "bigcnt", n_reads, &d_bigcnt)); STCHK(ensure(c, "bigidx", n_reads, &d_bigidx));
         HIPCHK(hipMemsetAsync(c->d_scal + 2, 0, 16, st));
-        { KTimer kt(c, MTB_K_SEGSORT);
-        hipLaunchKernelGGL(k_list_large, dim3((uint32_t)((n_reads + 255) / 256)), dim3(256), 0, st, (const uint64_t *)d_seg, n_reads,
-                           (uint32_t)MTB_SCORE_LDS, d_large, (uint32_t *)(c->d_scal + 2), (uint32_t *)(c->d_scal + 3));
-        hipLaunchKernelGGL((k_segsort_large<mtb_match>), dim3(1024), dim3(256), 0, st, d_m, (const uint64_t *)d_seg, (const uint32_t *)d_large,
-                           (const uint32_t *)(c->d_scal + 2)); }
+        hipLaunchKernelGGL(k_big_list, dim3((uint32_t)((n_reads + 255) / 256)), dim3(256), 0, st, (const uint32_t *)d_rc, n_reads, stride, d_biglist,
+                           d_bigcnt, d_bigidx, (uint32_t *)(c->d_scal + 2), (uint32_t *)(c->d_scal + 3));
+        /* total number of matches (statistics) */
+        uint64_t *d_tot;
+        STCHK(ensure(c, "segstart", n_reads + 1, &d_tot)); STCHK(ensure(c, "scanws", scan_ws_elems(n_reads + 1), &d_ws2));
+        { KTimer kt(c, MTB_K_SCAN); scan_launch<uint32_t, uint64_t, false>(st, d_rc, n_reads, true, d_tot, d_ws2); }
         uint64_t sc[2];
         STCHK(d2h(c, sc, c->d_scal + 2, 16));
-        max_seg = (uint32_t)sc[1];
+        STCHK(d2h(c, &nm, d_tot + n_reads, 8));
+        const uint32_t n_big = (uint32_t)sc[0]; const uint32_t max_big = (uint32_t)sc[1];
+        HIPCHK(hipEventRecord(c->ev[4], st));
+        if (n_big) {
+            STCHK(ensure(c, "bigstart", (uint64_t)n_big + 1, &d_bigstart)); STCHK(ensure(c, "bigcur", n_big, &d_bigcur));
+            scan_launch<uint32_t, uint64_t, false>(st, d_bigcnt, n_big, true, d_bigstart, d_ws2);
+            uint64_t big_total = 0;
+            STCHK(d2h(c, &big_total, d_bigstart + n_big, 8));
+            STCHK(ensure(c, "bigm", big_total, &d_big));
+            KTimer kt(c, MTB_K_SEGSORT);
+            hipLaunchKernelGGL(k_big_copy, dim3(std::min<uint32_t>(n_big, 4096)), dim3(256), 0, st, (const mtb_match *)d_segm, stride, (const uint32_t *)d_biglist,
+                               (const uint64_t *)d_bigstart, n_big, d_bigcur, d_big);
+            if (n_ovf) hipLaunchKernelGGL(k_big_ovf, dim3((uint32_t)((n_ovf + 255) / 256)), dim3(256), 0, st, (const mtb_match *)d_ovf, n_ovf,
+                                          (const uint32_t *)d_bigidx, (const uint64_t *)d_bigstart, d_bigcur, d_big);
+            HIPCHK(hipMemcpyAsync(c->d_scal + 5, &n_big, 4, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL((k_segsort_large<mtb_match>), dim3(std::min<uint32_t>(n_big, 1024)), dim3(256), 0, st, d_big, (const uint64_t *)d_bigstart,
+                               (const uint32_t *)nullptr, (const uint32_t *)(c->d_scal + 5));
+        }
+        HIPCHK(hipEventRecord(c->ev[5], st));
+        ScoreSrc a; a.m = d_segm; a.cursor = d_rc; a.stride = stride; a.sort = true; a.max_seg = stride;
+        ScoreSrc b; b.m = d_big; b.seg = d_bigstart; b.list = d_biglist; b.n_list = (const uint32_t *)(c->d_scal + 5); b.seg_by_list = 1;
+        b.sort = false; b.max_seg = max_big; b.grid = std::min<uint32_t>(std::max<uint32_t>(n_big, 1), 1024);
+        STCHK(dev_score(c, ix, p, n_reads, d_ql, d_ql2, max_len, d_results, d_taxcnt_tax, d_taxcnt_cnt, taxcnt_cap, n_taxcnt, tc_base, a, n_big ? &b : nullptr));
+    } else {
+        /* ---- long reads: exact segments (temp buffer, per-read counters, scan, regroup) ---- */
+        mtb_match *d_tmp;
+        DevBuf &jb = c->bufs["jtemp"];
+        uint64_t cap = std::max<uint64_t>(jb.cap / sizeof(mtb_match), nk + nk / 2 + 1024);
+        for (int attempt = 0; attempt < 3; attempt++) {
+            STCHK(ensure(c, "jtemp", cap, &d_tmp));
+            mtb_status s2 = dev_join(c, ix, d_s, nk, d_tmp, cap, d_rc, &nm);
+            if (s2 == MTB_OK) break;
+            if (s2 != MTB_ERR_CAPACITY || attempt == 2) return s2;
+            cap = nm + nm / 16 + 1024;                     /* the reference's retry (Classifier.cpp:127-131) with the exact size */
+            HIPCHK(hipMemsetAsync(d_rc, 0, n_reads * 4, st));
+        }
+        HIPCHK(hipEventRecord(c->ev[3], st));
+        mtb_match *d_m; uint64_t *d_seg;
+        STCHK(ensure(c, "matches", nm, &d_m));
+        STCHK(dev_regroup(c, d_tmp, nm, n_reads, d_rc, &d_seg, d_m));
+        HIPCHK(hipEventRecord(c->ev[4], st));
+        /* segments that fit LDS are sorted inside k_score; only the big ones are sorted in HBM here */
+        uint32_t max_seg = 0;
+        {
+            uint32_t *d_large;
+            STCHK(ensure(c, "large", n_reads, &d_large));
+            HIPCHK(hipMemsetAsync(c->d_scal + 2, 0, 16, st));
+            { KTimer kt(c, MTB_K_SEGSORT);
+            hipLaunchKernelGGL(k_list_large, dim3((uint32_t)((n_reads + 255) / 256)), dim3(256), 0, st, (const uint64_t *)d_seg, n_reads,
+                               (uint32_t)MTB_SCORE_LDS, d_large, (uint32_t *)(c->d_scal + 2), (uint32_t *)(c->d_scal + 3));
+            hipLaunchKernelGGL((k_segsort_large<mtb_match>), dim3(1024), dim3(256), 0, st, d_m, (const uint64_t *)d_seg, (const uint32_t *)d_large,
+                               (const uint32_t *)(c->d_scal + 2)); }
+            uint64_t sc[2];
+            STCHK(d2h(c, sc, c->d_scal + 2, 16));
+            max_seg = (uint32_t)sc[1];
+        }
+        HIPCHK(hipEventRecord(c->ev[5], st));
+        ScoreSrc a; a.m = d_m; a.seg = d_seg; a.sort = true; a.max_seg = max_seg;
+        STCHK(dev_score(c, ix, p, n_reads, d_ql, d_ql2, max_len, d_results, d_taxcnt_tax, d_taxcnt_cnt, taxcnt_cap, n_taxcnt, tc_base, a, nullptr));
     }
-    HIPCHK(hipEventRecord(c->ev[5], st));
-    STCHK(dev_score(c, ix, p, d_m, d_seg, n_reads, d_ql, d_ql2, max_seg, max_len, d_results, d_taxcnt_tax, d_taxcnt_cnt, taxcnt_cap, n_taxcnt, true, tc_base));
     HIPCHK(hipEventRecord(c->ev[6], st));
     HIPCHK(hipEventSynchronize(c->ev[6]));
     mtb_batch_stats &S = c->stats;
