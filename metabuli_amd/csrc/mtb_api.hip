@@ -795,7 +795,7 @@ mtb_status mtb_classify_batch_device(mtb_ctx *c, mtb_index *ix, const mtb_params
     std::vector<uint64_t> ntc(L, 0);
     std::vector<std::thread> th;
     /* `chunks` read ranges per stream, interleaved (range k runs on stream k % L) */
-    static const int chunks = getenv("MTB_CHUNKS_PER_STREAM") ? std::max(1, atoi(getenv("MTB_CHUNKS_PER_STREAM"))) : 2;   /* sweep: profiles/r01_notes.md */
+    static const int chunks = getenv("MTB_CHUNKS_PER_STREAM") ? std::max(1, atoi(getenv("MTB_CHUNKS_PER_STREAM"))) : 1;   /* sweep: profiles/r01_notes.md */
     const size_t NC = L * (size_t)chunks;
     const uint64_t tc_share = taxcnt_cap / NC;
     std::vector<mtb_batch_stats> lane_stats(L);
