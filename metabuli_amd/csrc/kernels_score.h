@@ -207,11 +207,30 @@ __device__ __forceinline__ void score_read_par(const REC *__restrict__ src, int3
     for (int d = 32; d > 0; d >>= 1) { int32_t o = __shfl_xor(maxrank, d, 64); maxrank = o > maxrank ? o : maxrank; }
     __syncthreads();
     /* chain DP: pointer doubling when every match has <= 1 consecutive predecessor, else rounds */
-    bool simple = n <= 64 * MTB_SCORE_MAXPER;
+    const bool small_n = n <= 64 * MTB_SCORE_MAXPER;
+    bool simple = small_n || sizeof(IDX) == 4;      /* big segments need the 32-bit workspace for the ping-pong array */
     if (simple) {
         for (int32_t i = lane; i < n; i += 64) simple = simple && mtb_chain_simple(w, i);
         simple = __all(simple);
     }
+    if (simple && !small_n) {
+        /* big segment (HBM slab): ping-pong between the path storage and the (now dead) sid/rk/grp_start/blk_start block */
+        mtb_jump *ja = (mtb_jump *)w.path, *jb = (mtb_jump *)w.sid;
+        for (int32_t i = lane; i < n; i += 64) mtb_ph_jump_init(w, i, ja);
+        __syncthreads();
+        for (int32_t span = 1; span <= maxrank; span <<= 1) {
+            for (int32_t i = lane; i < n; i += 64) jb[i] = mtb_ph_jump_step(ja, i);
+            __syncthreads();
+            mtb_jump *t = ja; ja = jb; jb = t;
+        }
+        if (ja != (mtb_jump *)w.sid) {               /* final records must not sit in the path storage while paths are written */
+            for (int32_t i = lane; i < n; i += 64) jb[i] = ja[i];
+            __syncthreads();
+            ja = jb;
+        }
+        for (int32_t i = lane; i < n; i += 64) { mtb_jump j = ja[i]; w.path[i] = mtb_ph_jump_final(w, i, j); }
+        __syncthreads();
+    } else
     if (simple) {
         mtb_jump *jump = (mtb_jump *)w.path;          /* fresh paths are rebuilt from the roots at the end */
         mtb_jump t[MTB_SCORE_MAXPER];
@@ -431,6 +450,84 @@ __global__ __launch_bounds__(64, MTB_SCORE_MINWAVES) void k_score(const REC *__r
         if (lane == 0) { R.query_length = ql1; R.query_length2 = ql2; R.reserved = 0; R.taxcnt_off += (uint32_t)tc_base; results[r] = R; }
     }
     MTB_PHASE_KERNEL_END();
+}
+
+/* Large segments (long reads): one 1024-thread workgroup per read.
+ *   1. chunks of MTB_SEGLDS_CHUNK matches: (key1, key2, index) triples sorted in LDS (all-ascending bitonic network
+ *      with virtual +inf padding; ties by index = stable), records gathered into the scratch buffer;
+ *   2. runs merged pairwise by rank: every record finds its output slot with one binary search in the sibling run
+ *      (lower bound for the left run, upper bound for the right run = stable), ping-pong scratch <-> segment.
+ * HBM/L2 sees each record 2 + 2*ceil(log2(n/chunk)) times instead of ~log^2(n) times as in k_segsort_large.   */
+#define MTB_SEGLDS_CHUNK 8192
+#define MTB_SEGLDS_THREADS 1024
+MTB_HD bool mtb_key_less(uint64_t a1, uint32_t a2, uint64_t b1, uint32_t b2) { return a1 < b1 || (a1 == b1 && a2 < b2); }
+
+template <typename REC>
+__global__ __launch_bounds__(MTB_SEGLDS_THREADS) void k_segsort_lds(REC *m, const uint64_t *__restrict__ seg_start, const uint32_t *__restrict__ large,
+                                                                     const uint32_t *__restrict__ n_large, REC *scratch) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+    uint64_t *k1 = (uint64_t *)s_dyn;
+    uint32_t *k2 = (uint32_t *)(k1 + MTB_SEGLDS_CHUNK);
+    uint16_t *ix = (uint16_t *)(k2 + MTB_SEGLDS_CHUNK);
+    const uint32_t nl = *n_large, t = threadIdx.x, NT = MTB_SEGLDS_THREADS;
+    for (uint32_t b = blockIdx.x; b < nl; b += gridDim.x) {
+        const uint32_t r = large ? large[b] : b;
+        const uint64_t s0 = seg_start[r];
+        const uint32_t n = (uint32_t)(seg_start[r + 1] - s0);
+        REC *seg = m + s0, *tmp = scratch + s0;
+        for (uint32_t base = 0; base < n; base += MTB_SEGLDS_CHUNK) {
+            const uint32_t cn = n - base < MTB_SEGLDS_CHUNK ? n - base : MTB_SEGLDS_CHUNK;
+            const REC *src = seg + base;
+            __syncthreads();
+            for (uint32_t i = t; i < cn; i += NT) { const mtb_match &x = rec_m(src[i]); k1[i] = mtb_key1(x); k2[i] = mtb_key2(x); ix[i] = (uint16_t)i; }
+            __syncthreads();
+            uint32_t p2 = 1; while (p2 < cn) p2 <<= 1;
+            for (uint32_t k = 2; k <= p2; k <<= 1) {
+                for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                    for (uint32_t q = t; q < (p2 >> 1); q += NT) {
+                        uint32_t lo = ((q & ~(j - 1)) << 1) | (q & (j - 1));
+                        uint32_t hi = (j == (k >> 1)) ? (lo ^ ((j << 1) - 1)) : (lo + j);
+                        if (hi < cn) {
+                            uint64_t a1 = k1[lo], b1 = k1[hi]; uint32_t a2 = k2[lo], b2 = k2[hi];
+                            uint16_t ai = ix[lo], bi = ix[hi];
+                            bool sw = (b1 < a1) || (b1 == a1 && (b2 < a2 || (b2 == a2 && bi < ai)));
+                            if (sw) { k1[lo] = b1; k1[hi] = a1; k2[lo] = b2; k2[hi] = a2; ix[lo] = bi; ix[hi] = ai; }
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            for (uint32_t i = t; i < cn; i += NT) tmp[base + i] = src[ix[i]];
+        }
+        __syncthreads();
+        REC *src = tmp, *dst = seg;
+        for (uint32_t R = MTB_SEGLDS_CHUNK; R < n; R <<= 1) {
+            for (uint32_t i = t; i < n; i += NT) {
+                const uint32_t pair = i / (2 * R), pb = pair * 2 * R, off = i - pb;
+                const REC rec = src[i];
+                const mtb_match &x = rec_m(rec);
+                const uint64_t x1 = mtb_key1(x); const uint32_t x2 = mtb_key2(x);
+                uint32_t pos;
+                if (off < R) {                                   /* left run: + #right elements strictly smaller */
+                    uint32_t lo = pb + R < n ? pb + R : n, hi = pb + 2 * R < n ? pb + 2 * R : n;
+                    const uint32_t b0 = lo;
+                    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; const mtb_match &y = rec_m(src[mid]);
+                                      if (mtb_key_less(mtb_key1(y), mtb_key2(y), x1, x2)) lo = mid + 1; else hi = mid; }
+                    pos = off + (lo - b0);
+                } else {                                         /* right run: + #left elements smaller or equal */
+                    uint32_t lo = pb, hi = pb + R;
+                    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; const mtb_match &y = rec_m(src[mid]);
+                                      if (!mtb_key_less(x1, x2, mtb_key1(y), mtb_key2(y))) lo = mid + 1; else hi = mid; }
+                    pos = (off - R) + (lo - pb);
+                }
+                dst[pb + pos] = rec;
+            }
+            __syncthreads();
+            REC *sw = src; src = dst; dst = sw;
+        }
+        if (src != seg) { for (uint32_t i = t; i < n; i += NT) seg[i] = src[i]; }
+        __syncthreads();
+    }
 }
 
 #endif

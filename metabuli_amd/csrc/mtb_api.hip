@@ -742,12 +742,18 @@ static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, c
             HIPCHK(hipMemsetAsync(c->d_scal + 2, 0, 16, st));
             { KTimer kt(c, MTB_K_SEGSORT);
             hipLaunchKernelGGL(k_list_large, dim3((uint32_t)((n_reads + 255) / 256)), dim3(256), 0, st, (const uint64_t *)d_seg, n_reads,
-                               (uint32_t)MTB_SCORE_LDS, d_large, (uint32_t *)(c->d_scal + 2), (uint32_t *)(c->d_scal + 3));
-            hipLaunchKernelGGL((k_segsort_large<mtb_match>), dim3(1024), dim3(256), 0, st, d_m, (const uint64_t *)d_seg, (const uint32_t *)d_large,
-                               (const uint32_t *)(c->d_scal + 2)); }
+                               (uint32_t)MTB_SCORE_LDS, d_large, (uint32_t *)(c->d_scal + 2), (uint32_t *)(c->d_scal + 3)); }
             uint64_t sc[2];
             STCHK(d2h(c, sc, c->d_scal + 2, 16));
             max_seg = (uint32_t)sc[1];
+            if (sc[0]) {
+                /* big segments: chunk sort in LDS + rank merges; the join-order temp buffer is the scratch */
+                const size_t lds = (size_t)MTB_SEGLDS_CHUNK * 14;
+                HIPCHK(hipFuncSetAttribute((const void *)k_segsort_lds<mtb_match>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                KTimer kt(c, MTB_K_SEGSORT);
+                hipLaunchKernelGGL((k_segsort_lds<mtb_match>), dim3(std::min<uint32_t>((uint32_t)sc[0], 2048)), dim3(MTB_SEGLDS_THREADS), lds, st, d_m,
+                                   (const uint64_t *)d_seg, (const uint32_t *)d_large, (const uint32_t *)(c->d_scal + 2), d_tmp);
+            }
         }
         HIPCHK(hipEventRecord(c->ev[5], st));
         ScoreSrc a; a.m = d_m; a.seg = d_seg; a.sort = true; a.max_seg = max_seg;

@@ -59,6 +59,8 @@ TOY_MODES = {
     "old_format_pe": dict(syncmer=0, paired=True, seed=6, kmer_format=1),
     "sync_se_acc2": dict(syncmer=1, paired=False, seed=7, accession_level=2, strain_rank="accession"),
     "sync_long": dict(syncmer=1, paired=False, seed=5, n_reads=40, length=3000, seq_mode=3, err=0.05, lognormal=True),
+    # segments beyond one LDS sort chunk (8192 matches): chunk sort + one and two merge passes
+    "sync_xlong": dict(syncmer=1, paired=False, seed=8, n_reads=14, length=22000, seq_mode=3, err=0.03, lognormal=True),
 }
 
 
