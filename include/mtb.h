@@ -203,6 +203,50 @@ mtb_status mtb_classify_batch_device(mtb_ctx *, mtb_index *, const mtb_params *,
                                      uint64_t *n_taxcnt);
 mtb_status mtb_last_batch_stats(mtb_ctx *, mtb_batch_stats *out);
 
+/* ---- partitioned index: databases larger than one GPU's HBM -----------
+ * SURVEY.md 8(e) row 2.  The flat target array is range-partitioned by value
+ * at amino-acid-part boundaries (the invariant of the reference's `split`
+ * checkpoints, IndexCreator.cpp:848-857; KmerMatcher.cpp:157-205 uses them
+ * the same way to let threads start mid-stream), one range per GPU.  Per
+ * batch every GPU extracts + sorts its reads' metamers and cuts the sorted
+ * list at the partition bounds (mtb_part_extract); the host side exchanges
+ * the runs (RCCL all-to-all, metabuli_amd/parallel.py), each owner joins
+ * every received run against its range (mtb_part_join: the runs stay sorted,
+ * so no merge), the matches travel back and the home GPU regroups, sorts and
+ * scores them (mtb_part_score).  All d_* pointers are device pointers.
+ *
+ * mtb_index_part_bounds: bounds[p] = lower amino-acid-part bound of range p
+ * (bounds[0] = 0; an empty range repeats the next bound).
+ * mtb_index_open_part: loads only range `part` (file byte ranges given by
+ * the split checkpoints); the full taxonomy / taxID_list is loaded on every
+ * rank.  The "last entry is never a candidate" rule (KmerMatcher.cpp:363)
+ * applies to the last non-empty range only.
+ * mtb_index_slice: the same as a device view [lower_bound(lo), lower_bound(hi))
+ * of an index that is already resident (tests, synthetic indices); the view
+ * must be closed before its parent.                                         */
+mtb_status mtb_index_part_bounds(const char *dbdir, uint32_t n_parts, uint64_t *bounds);
+mtb_status mtb_index_open_part(mtb_ctx *, const char *dbdir, const char *taxonomy_dir,
+                               mtb_params *params, uint32_t part, uint32_t n_parts,
+                               mtb_index **out);
+mtb_status mtb_index_slice(mtb_index *, uint64_t lo_value, uint64_t hi_value, int is_last,
+                           mtb_index **out);
+/* *d_sorted (owned by the context, valid until its next call) = the batch's
+ * metamers sorted by value; part_counts[p] = how many fall into range p
+ * (consecutive runs).  Query lengths stay in the context for mtb_part_score. */
+mtb_status mtb_part_extract(mtb_ctx *, const mtb_params *, const char *d_bases,
+                            const uint64_t *d_offs, const char *d_bases2, const uint64_t *d_offs2,
+                            uint64_t n_reads, const uint64_t *bounds, uint32_t n_parts,
+                            const mtb_kmer **d_sorted, uint64_t *n_kmers, uint64_t *part_counts);
+/* one sorted run of metamers (from any rank) against this rank's range */
+mtb_status mtb_part_join(mtb_ctx *, mtb_index *, const mtb_kmer *d_kmers, uint64_t n,
+                         mtb_match *d_out, uint64_t cap, uint64_t *count);
+/* all matches of this rank's reads, any order (d_matches is clobbered: it
+ * becomes sort scratch); results / taxcnt arrays are host buffers.          */
+mtb_status mtb_part_score(mtb_ctx *, mtb_index *, const mtb_params *, mtb_match *d_matches,
+                          uint64_t n_matches, uint64_t n_reads, mtb_result *results,
+                          int32_t *taxcnt_tax, uint32_t *taxcnt_cnt, uint64_t taxcnt_cap,
+                          uint64_t *n_taxcnt);
+
 /* ---- synthetic data on the device (bench / tests) ------
  * Builds a flat sorted target index of `n_filler` pseudo-random valid
  * metamers (seeded) merged with `n_real` caller-provided (value,taxid)

@@ -88,6 +88,13 @@ def lib():
     return L
 
 
+def part_bounds(dbdir, n_parts):
+    """lower amino-acid-part bound of each of n_parts value ranges of a database directory (mtb_index_part_bounds)"""
+    b = np.zeros(n_parts, np.uint64)
+    _chk(lib().mtb_index_part_bounds(dbdir.encode(), C.c_uint32(n_parts), _p(b)))
+    return b
+
+
 def default_params(**kw):
     """classify defaults for a syncmer DB written by `build` (db.parameters overrides apply at index open)."""
     p = Params(seq_mode=1, syncmer=1, smer_len=5, kmer_format=2, min_cons_cnt=4, min_cons_cnt_euk=9,
@@ -235,6 +242,45 @@ class Context:
                                               C.c_void_p(d_tc_tax), C.c_void_p(d_tc_cnt), C.c_uint64(tc_cap), C.byref(cnt)))
         return cnt.value
 
+    # ---- partitioned index: device-buffer stage calls ----
+    def open_index_part(self, dbdir, params, part, n_parts, taxonomy_dir=None):
+        h = C.c_void_p()
+        _chk(self.L.mtb_index_open_part(self.h, dbdir.encode(), taxonomy_dir.encode() if taxonomy_dir else None,
+                                        C.byref(params), C.c_uint32(part), C.c_uint32(n_parts), C.byref(h)))
+        return Index(self, h)
+
+    def part_extract(self, params, d_bases, d_offs, d_bases2, d_offs2, n_reads, bounds):
+        """-> (device pointer of the sorted metamers (owned by the context), n_kmers, counts per partition)"""
+        b = np.ascontiguousarray(bounds, dtype=np.uint64)
+        ptr = C.c_void_p(); nk = C.c_uint64()
+        counts = np.zeros(len(b), np.uint64)
+        _chk(self.L.mtb_part_extract(self.h, C.byref(params), C.c_void_p(d_bases), C.c_void_p(d_offs),
+                                     C.c_void_p(d_bases2) if d_bases2 else None, C.c_void_p(d_offs2) if d_offs2 else None,
+                                     C.c_uint64(n_reads), _p(b), C.c_uint32(len(b)), C.byref(ptr), C.byref(nk), _p(counts)))
+        return ptr.value or 0, nk.value, counts
+
+    def part_join(self, index, d_kmers, n, d_out, cap):
+        """-> (status, count); status MTB_ERR_CAPACITY means `count` entries are needed"""
+        cnt = C.c_uint64()
+        st = self.L.mtb_part_join(self.h, index.h, C.c_void_p(d_kmers), C.c_uint64(n), C.c_void_p(d_out), C.c_uint64(cap), C.byref(cnt))
+        if st != MTB_ERR_CAPACITY:
+            _chk(st)
+        return st, cnt.value
+
+    def part_score(self, index, params, d_matches, n_matches, n_reads):
+        res = np.zeros(n_reads, result_dt)
+        cap = max(1024, 64 * n_reads)
+        while True:
+            tt = np.zeros(cap, np.int32); tc = np.zeros(cap, np.uint32)
+            n = C.c_uint64()
+            st = self.L.mtb_part_score(self.h, index.h, C.byref(params), C.c_void_p(d_matches), C.c_uint64(n_matches),
+                                       C.c_uint64(n_reads), _p(res), _p(tt), _p(tc), C.c_uint64(cap), C.byref(n))
+            if st == MTB_ERR_CAPACITY and n.value > cap:
+                cap = n.value
+                continue
+            _chk(st)
+            return compact_taxcnt(res, tt, tc)
+
     def last_stats(self):
         s = BatchStats()
         _chk(self.L.mtb_last_batch_stats(self.h, C.byref(s)))
@@ -249,6 +295,12 @@ class Index:
     @property
     def num_targets(self):
         return self.ctx.L.mtb_index_num_targets(self.h)
+
+    def slice(self, lo_value, hi_value, is_last):
+        """device view of the value range [lo, hi) (mtb_index_slice); close it before the parent"""
+        h = C.c_void_p()
+        _chk(self.ctx.L.mtb_index_slice(self.h, C.c_uint64(int(lo_value)), C.c_uint64(int(hi_value)), C.c_int(1 if is_last else 0), C.byref(h)))
+        return Index(self.ctx, h)
 
     def download(self):
         n = self.num_targets

@@ -48,6 +48,7 @@ struct mtb_ctx {
     std::vector<hipEvent_t> ev_pool; /* recycled events                  */
     std::vector<mtb_ctx *> lanes;    /* extra stream contexts (mtb_ctx_set_streams) */
     bool is_lane = false;            /* lanes share the parent's tables  */
+    uint64_t part_n_reads = 0; uint32_t part_max_len = 0;   /* batch state between mtb_part_extract and mtb_part_score */
 };
 
 /* RAII bracket around one kernel launch (only when profiling is on) */
@@ -83,6 +84,8 @@ struct mtb_index {
     mtb_ctx *ctx = nullptr;
     uint64_t T = 0;
     uint64_t *d_values = nullptr; uint32_t *d_info = nullptr; bool own = false;
+    bool own_tax = true;             /* slices share the parent's device taxonomy */
+    bool match_last = false;         /* partitions other than the last one match their final entry too */
     mtbhost::Taxonomy tax;
     int32_t *d_canon = nullptr, *d_parent = nullptr, *d_depth = nullptr, *d_spparent = nullptr, *d_tax2species = nullptr;
     uint8_t *d_under = nullptr, *d_accleaf = nullptr;
@@ -276,7 +279,7 @@ static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint6
     uint32_t grid = (uint32_t)((n + MTB_JOIN_QPB - 1) / MTB_JOIN_QPB);
     uint64_t *d_bounds;
     STCHK(ensure(c, "jbounds", 2ull * grid, &d_bounds));
-    uint64_t limit = ix->T ? ix->T - 1 : 0;          /* the last index entry is never a candidate */
+    uint64_t limit = ix->T ? ix->T - (ix->match_last ? 0 : 1) : 0;          /* the last entry of the (whole) index is never a candidate */
     { KTimer kt(c, MTB_K_JOIN);
     hipLaunchKernelGGL(k_join_bounds, dim3((grid + 255) / 256), dim3(256), 0, c->stream, d_q, n, (const uint64_t *)ix->d_values, limit,
                        (uint64_t)grid, d_bounds);
@@ -412,8 +415,58 @@ static mtb_status upload_taxonomy(mtb_index *ix) {
 
 extern "C" {
 
-mtb_status mtb_index_open(mtb_ctx *c, const char *dbdir, const char *taxonomy_dir, mtb_params *params, mtb_index **out) {
+} // extern "C"
+
+/* How a database directory is cut into n_parts value ranges at `split` checkpoints (IndexCreator.cpp:848-857: a
+ * checkpoint {value, diffIdx offset after it, info index + 1} sits on the first metamer of an amino-acid group).  */
+struct PartPlan {
+    struct P { bool empty = true, explicit_first = false, drop_last = false; uint64_t ad = 0, diff_lo = 0, diff_hi = 0, info_lo = 0, info_hi = 0; };
+    std::vector<P> parts;
+    std::vector<uint64_t> bounds;       /* lower amino-acid-part bound of every partition */
+};
+static mtb_status plan_parts(const std::string &d, uint32_t n_parts, PartPlan *plan) {
+    struct Split { uint64_t ad, diff_off, info_off; };
+    std::vector<Split> sp;
+    FILE *f = fopen((d + "/diffIdx").c_str(), "rb"); if (!f) return fail(MTB_ERR_IO, "cannot open " + d + "/diffIdx");
+    fseek(f, 0, SEEK_END); const uint64_t n16 = (uint64_t)ftell(f) / 2; fclose(f);
+    f = fopen((d + "/info").c_str(), "rb"); if (!f) return fail(MTB_ERR_IO, "cannot open " + d + "/info");
+    fseek(f, 0, SEEK_END); const uint64_t T = (uint64_t)ftell(f) / 4; fclose(f);
+    std::vector<Split> use; use.push_back(Split{0, 0, 0});
+    if (n_parts > 1) {
+        if (!mtbhost::read_whole(d + "/split", &sp)) return fail(MTB_ERR_IO, "cannot read " + d + "/split");
+        for (size_t i = 1; i < sp.size(); i++) if (sp[i].ad != 0 && sp[i].ad != UINT64_MAX && sp[i].info_off > use.back().info_off) use.push_back(sp[i]);
+    }
+    plan->parts.assign(n_parts, PartPlan::P()); plan->bounds.assign(n_parts, UINT64_MAX);
+    const size_t U = use.size();
+    std::vector<size_t> k(n_parts + 1);
+    for (uint32_t p = 0; p <= n_parts; p++) k[p] = (size_t)((uint64_t)p * U / n_parts);
+    for (uint32_t p = 0; p < n_parts; p++) {
+        PartPlan::P &P = plan->parts[p];
+        if (k[p] == k[p + 1] || T == 0) continue;
+        P.empty = false;
+        const Split &s0 = use[k[p]];
+        if (k[p] == 0) { P.explicit_first = false; P.ad = 0; P.diff_lo = 0; P.info_lo = 0; }
+        else { P.explicit_first = true; P.ad = s0.ad; P.diff_lo = s0.diff_off; P.info_lo = s0.info_off - 1; }
+        if (k[p + 1] >= U) { P.drop_last = false; P.diff_hi = n16; P.info_hi = T; }
+        else { P.drop_last = true; P.diff_hi = use[k[p + 1]].diff_off; P.info_hi = use[k[p + 1]].info_off - 1; }
+        plan->bounds[p] = k[p] == 0 ? 0 : (s0.ad & ~0xFFFFFFull);
+    }
+    for (int64_t p = (int64_t)n_parts - 2; p >= 0; p--) if (plan->parts[(size_t)p].empty) plan->bounds[(size_t)p] = plan->bounds[(size_t)p + 1];
+    if (T == 0) plan->bounds[0] = 0;
+    return MTB_OK;
+}
+
+template <class T> static bool read_range(const std::string &path, uint64_t lo, uint64_t hi, std::vector<T> *v) {
+    FILE *f = fopen(path.c_str(), "rb"); if (!f) return false;
+    v->resize((size_t)(hi - lo));
+    bool ok = fseek(f, (long)(lo * sizeof(T)), SEEK_SET) == 0 && fread(v->data(), sizeof(T), v->size(), f) == v->size();
+    fclose(f);
+    return ok;
+}
+
+static mtb_status open_impl(mtb_ctx *c, const char *dbdir, const char *taxonomy_dir, mtb_params *params, uint32_t part, uint32_t n_parts, mtb_index **out) {
     if (!c || !dbdir || !params || !out) return fail(MTB_ERR_ARG, "NULL argument");
+    if (n_parts == 0 || part >= n_parts) return fail(MTB_ERR_ARG, "partition index out of range");
     HIPCHK(hipSetDevice(c->device));
     std::string d(dbdir);
     mtbhost::load_db_parameters(d, params);
@@ -424,43 +477,69 @@ mtb_status mtb_index_open(mtb_ctx *c, const char *dbdir, const char *taxonomy_di
             return fail(MTB_ERR_UNSUPPORTED, "binary taxonomyDB is not supported yet; pass a taxonomy directory with names/nodes/merged.dmp");
         return fail(MTB_ERR_IO, "taxonomy dump files not found in " + taxdir);
     }
+    PartPlan plan;
+    STCHK(plan_parts(d, n_parts, &plan));
+    const PartPlan::P &P = plan.parts[part];
     mtb_index *ix = new mtb_index();
     ix->ctx = c; ix->params = *params; ix->own = true;
+    for (uint32_t q = part + 1; q < n_parts; q++) if (!plan.parts[q].empty) ix->match_last = true;
     std::string err;
     if (!mtbhost::load_taxonomy(taxdir, &ix->tax, &err)) { delete ix; return fail(MTB_ERR_IO, err); }
     std::vector<int32_t> ids;
     if (!mtbhost::read_taxid_list(d + "/taxID_list", &ids)) { delete ix; return fail(MTB_ERR_IO, "cannot open " + d + "/taxID_list"); }
     mtbhost::build_tax2species(&ix->tax, ids.data(), ids.size());
     ix->info_mask = ~((uint32_t)(params->skip_redundancy == 0) << 31);   /* KmerMatcher.cpp:204-205 */
-    std::vector<uint16_t> diff; std::vector<uint32_t> info;
-    if (!mtbhost::read_whole(d + "/diffIdx", &diff) || !mtbhost::read_whole(d + "/info", &info)) { delete ix; return fail(MTB_ERR_IO, "cannot read diffIdx/info in " + d); }
-    uint64_t n16 = diff.size(), T = info.size();
     mtb_status st = upload_taxonomy(ix);
     if (st != MTB_OK) { mtb_index_close(ix); return st; }
-    if (T == 0) { ix->T = 0; *out = ix; return MTB_OK; }
-    /* decode on the GPU */
+    if (P.empty) { ix->T = 0; *out = ix; return MTB_OK; }
+    /* only this partition's byte ranges are read from the files */
+    std::vector<uint16_t> diff; std::vector<uint32_t> info;
+    if (!read_range(d + "/diffIdx", P.diff_lo, P.diff_hi, &diff) || !read_range(d + "/info", P.info_lo, P.info_hi, &info)) {
+        mtb_index_close(ix); return fail(MTB_ERR_IO, "cannot read diffIdx/info in " + d); }
+    const uint64_t n16 = diff.size(), T = info.size();
+    const uint64_t expect = T - (P.explicit_first ? 1 : 0) + (P.drop_last ? 1 : 0);     /* metamers coded in the byte range */
+    /* decode on the GPU: terminators per tile -> offsets -> deltas -> inclusive scan */
     uint16_t *d_diff; uint32_t *d_tc; uint64_t *d_toff; uint64_t *d_ws;
-    uint64_t tiles = (n16 + 2047) / 2048;
-    if ((st = ensure(c, "diffraw", n16, &d_diff)) != MTB_OK || (st = ensure(c, "difftc", tiles, &d_tc)) != MTB_OK ||
+    uint64_t tiles = std::max<uint64_t>((n16 + 2047) / 2048, 1);
+    if ((st = ensure(c, "diffraw", n16 + 1, &d_diff)) != MTB_OK || (st = ensure(c, "difftc", tiles, &d_tc)) != MTB_OK ||
         (st = ensure(c, "difftoff", tiles + 1, &d_toff)) != MTB_OK ||
-        (st = ensure(c, "scanws", scan_ws_elems(std::max<uint64_t>(tiles + 1, T)), &d_ws)) != MTB_OK) { mtb_index_close(ix); return st; }
-    HIPCHK(hipMalloc((void **)&ix->d_values, T * 8)); HIPCHK(hipMalloc((void **)&ix->d_info, T * 4));
+        (st = ensure(c, "scanws", scan_ws_elems(std::max<uint64_t>(tiles + 1, T + 1)), &d_ws)) != MTB_OK) { mtb_index_close(ix); return st; }
+    HIPCHK(hipMalloc((void **)&ix->d_values, (T + 1) * 8)); HIPCHK(hipMalloc((void **)&ix->d_info, T * 4));
     if ((st = h2d(c, d_diff, diff.data(), n16 * 2)) != MTB_OK || (st = h2d(c, ix->d_info, info.data(), T * 4)) != MTB_OK) { mtb_index_close(ix); return st; }
     hipLaunchKernelGGL(k_diff_tile_count, dim3((uint32_t)tiles), dim3(256), 0, c->stream, (const uint16_t *)d_diff, n16, d_tc);
     scan_launch<uint32_t, uint64_t, false>(c->stream, d_tc, tiles, true, d_toff, d_ws);
     uint64_t found = 0;
     if ((st = d2h(c, &found, d_toff + tiles, 8)) != MTB_OK) { mtb_index_close(ix); return st; }
-    if (found != T) {   /* validateDatabase.cpp:17-142: #terminators must equal #info entries */
+    if (found != expect) {   /* validateDatabase.cpp:17-142: #terminators must equal #info entries */
         mtb_index_close(ix);
-        return fail(MTB_ERR_IO, "diffIdx holds " + std::to_string(found) + " metamers but info holds " + std::to_string(T));
+        return fail(MTB_ERR_IO, "diffIdx holds " + std::to_string(found) + " metamers where info and split announce " + std::to_string(expect));
     }
-    hipLaunchKernelGGL(k_diff_assemble, dim3((uint32_t)tiles), dim3(256), 0, c->stream, (const uint16_t *)d_diff, n16, (const uint64_t *)d_toff, ix->d_values);
-    scan_launch<uint64_t, uint64_t, true>(c->stream, ix->d_values, T, false, ix->d_values, d_ws);
+    const uint64_t lead = P.explicit_first ? 1 : 0;
+    if (lead && (st = h2d(c, ix->d_values, &P.ad, 8)) != MTB_OK) { mtb_index_close(ix); return st; }
+    hipLaunchKernelGGL(k_diff_assemble, dim3((uint32_t)tiles), dim3(256), 0, c->stream, (const uint16_t *)d_diff, n16, (const uint64_t *)d_toff, ix->d_values + lead);
+    scan_launch<uint64_t, uint64_t, true>(c->stream, ix->d_values, found + lead, false, ix->d_values, d_ws);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     release(c, "diffraw"); release(c, "difftc"); release(c, "difftoff");
     ix->T = T;
     *out = ix;
+    return MTB_OK;
+}
+
+extern "C" {
+
+mtb_status mtb_index_open(mtb_ctx *c, const char *dbdir, const char *taxonomy_dir, mtb_params *params, mtb_index **out) {
+    return open_impl(c, dbdir, taxonomy_dir, params, 0, 1, out);
+}
+mtb_status mtb_index_open_part(mtb_ctx *c, const char *dbdir, const char *taxonomy_dir, mtb_params *params, uint32_t part, uint32_t n_parts,
+                               mtb_index **out) {
+    return open_impl(c, dbdir, taxonomy_dir, params, part, n_parts, out);
+}
+mtb_status mtb_index_part_bounds(const char *dbdir, uint32_t n_parts, uint64_t *bounds) {
+    if (!dbdir || !bounds || n_parts == 0) return fail(MTB_ERR_ARG, "NULL argument");
+    PartPlan plan;
+    STCHK(plan_parts(dbdir, n_parts, &plan));
+    for (uint32_t p = 0; p < n_parts; p++) bounds[p] = plan.bounds[p];
     return MTB_OK;
 }
 
@@ -483,8 +562,9 @@ mtb_status mtb_index_from_device(mtb_ctx *c, const uint64_t *d_values, const uin
 
 void mtb_index_close(mtb_index *ix) {
     if (!ix) return;
-    hipError_t e;
+    hipError_t e = hipSuccess;
     if (ix->own) { if (ix->d_values) e = hipFree(ix->d_values); if (ix->d_info) e = hipFree(ix->d_info); }
+    if (!ix->own_tax) { (void)e; delete ix; return; }
     if (ix->d_canon) e = hipFree(ix->d_canon);
     if (ix->d_parent) e = hipFree(ix->d_parent);
     if (ix->d_depth) e = hipFree(ix->d_depth);
@@ -635,6 +715,43 @@ mtb_status mtb_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, const mtb_m
 /* ------------------------------------------------------------------ */
 } // extern "C"
 
+/* Exact-segment tail of the pipeline: matches in join order (d_tmp, clobbered: it becomes the sort scratch) +
+ * per-read counts -> scan, regroup, big segments sorted (chunk sort in LDS + rank merges), scoring.
+ * Records ev[4] (regrouped) and ev[5] (sorted). */
+static mtb_status score_join_order(mtb_ctx *c, mtb_index *ix, const mtb_params *p, mtb_match *d_tmp, uint64_t nm, uint64_t n_reads, uint32_t *d_rc,
+                                   const int32_t *d_ql, const int32_t *d_ql2, uint32_t max_len, mtb_result *d_results, int32_t *d_taxcnt_tax,
+                                   uint32_t *d_taxcnt_cnt, uint64_t taxcnt_cap, uint64_t *n_taxcnt, uint64_t tc_base) {
+    hipStream_t st = c->stream;
+    mtb_match *d_m; uint64_t *d_seg;
+    STCHK(ensure(c, "matches", nm, &d_m));
+    STCHK(dev_regroup(c, d_tmp, nm, n_reads, d_rc, &d_seg, d_m));
+    HIPCHK(hipEventRecord(c->ev[4], st));
+    /* segments that fit LDS are sorted inside k_score; only the big ones are sorted here */
+    uint32_t max_seg = 0;
+    {
+        uint32_t *d_large;
+        STCHK(ensure(c, "large", n_reads, &d_large));
+        HIPCHK(hipMemsetAsync(c->d_scal + 2, 0, 16, st));
+        { KTimer kt(c, MTB_K_SEGSORT);
+        hipLaunchKernelGGL(k_list_large, dim3((uint32_t)((n_reads + 255) / 256)), dim3(256), 0, st, (const uint64_t *)d_seg, n_reads,
+                           (uint32_t)MTB_SCORE_LDS, d_large, (uint32_t *)(c->d_scal + 2), (uint32_t *)(c->d_scal + 3)); }
+        uint64_t sc[2];
+        STCHK(d2h(c, sc, c->d_scal + 2, 16));
+        max_seg = (uint32_t)sc[1];
+        if (sc[0]) {
+            /* big segments: chunk sort in LDS + rank merges; the join-order buffer is the scratch */
+            const size_t lds = (size_t)MTB_SEGLDS_CHUNK * 14;
+            HIPCHK(hipFuncSetAttribute((const void *)k_segsort_lds<mtb_match>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            KTimer kt(c, MTB_K_SEGSORT);
+            hipLaunchKernelGGL((k_segsort_lds<mtb_match>), dim3(std::min<uint32_t>((uint32_t)sc[0], 2048)), dim3(MTB_SEGLDS_THREADS), lds, st, d_m,
+                               (const uint64_t *)d_seg, (const uint32_t *)d_large, (const uint32_t *)(c->d_scal + 2), d_tmp);
+        }
+    }
+    HIPCHK(hipEventRecord(c->ev[5], st));
+    ScoreSrc a; a.m = d_m; a.seg = d_seg; a.sort = true; a.max_seg = max_seg;
+    return dev_score(c, ix, p, n_reads, d_ql, d_ql2, max_len, d_results, d_taxcnt_tax, d_taxcnt_cnt, taxcnt_cap, n_taxcnt, tc_base, a, nullptr);
+}
+
 /* one read range on one stream; taxcnt slots of this range start at tc_base of the caller's arrays */
 static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, const char *d_bases, const uint64_t *d_offs,
                                const char *d_bases2, const uint64_t *d_offs2, uint64_t n_reads, uint64_t n_bases_total,
@@ -730,34 +847,7 @@ static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, c
             HIPCHK(hipMemsetAsync(d_rc, 0, n_reads * 4, st));
         }
         HIPCHK(hipEventRecord(c->ev[3], st));
-        mtb_match *d_m; uint64_t *d_seg;
-        STCHK(ensure(c, "matches", nm, &d_m));
-        STCHK(dev_regroup(c, d_tmp, nm, n_reads, d_rc, &d_seg, d_m));
-        HIPCHK(hipEventRecord(c->ev[4], st));
-        /* segments that fit LDS are sorted inside k_score; only the big ones are sorted in HBM here */
-        uint32_t max_seg = 0;
-        {
-            uint32_t *d_large;
-            STCHK(ensure(c, "large", n_reads, &d_large));
-            HIPCHK(hipMemsetAsync(c->d_scal + 2, 0, 16, st));
-            { KTimer kt(c, MTB_K_SEGSORT);
-            hipLaunchKernelGGL(k_list_large, dim3((uint32_t)((n_reads + 255) / 256)), dim3(256), 0, st, (const uint64_t *)d_seg, n_reads,
-                               (uint32_t)MTB_SCORE_LDS, d_large, (uint32_t *)(c->d_scal + 2), (uint32_t *)(c->d_scal + 3)); }
-            uint64_t sc[2];
-            STCHK(d2h(c, sc, c->d_scal + 2, 16));
-            max_seg = (uint32_t)sc[1];
-            if (sc[0]) {
-                /* big segments: chunk sort in LDS + rank merges; the join-order temp buffer is the scratch */
-                const size_t lds = (size_t)MTB_SEGLDS_CHUNK * 14;
-                HIPCHK(hipFuncSetAttribute((const void *)k_segsort_lds<mtb_match>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                KTimer kt(c, MTB_K_SEGSORT);
-                hipLaunchKernelGGL((k_segsort_lds<mtb_match>), dim3(std::min<uint32_t>((uint32_t)sc[0], 2048)), dim3(MTB_SEGLDS_THREADS), lds, st, d_m,
-                                   (const uint64_t *)d_seg, (const uint32_t *)d_large, (const uint32_t *)(c->d_scal + 2), d_tmp);
-            }
-        }
-        HIPCHK(hipEventRecord(c->ev[5], st));
-        ScoreSrc a; a.m = d_m; a.seg = d_seg; a.sort = true; a.max_seg = max_seg;
-        STCHK(dev_score(c, ix, p, n_reads, d_ql, d_ql2, max_len, d_results, d_taxcnt_tax, d_taxcnt_cnt, taxcnt_cap, n_taxcnt, tc_base, a, nullptr));
+        STCHK(score_join_order(c, ix, p, d_tmp, nm, n_reads, d_rc, d_ql, d_ql2, max_len, d_results, d_taxcnt_tax, d_taxcnt_cnt, taxcnt_cap, n_taxcnt, tc_base));
     }
     HIPCHK(hipEventRecord(c->ev[6], st));
     HIPCHK(hipEventSynchronize(c->ev[6]));
@@ -845,6 +935,99 @@ mtb_status mtb_classify_batch(mtb_ctx *c, mtb_index *ix, const mtb_params *p, co
     STCHK(ensure(c, "results", n_reads, &d_res)); STCHK(ensure(c, "tctax", taxcnt_cap, &d_tt)); STCHK(ensure(c, "tccnt", taxcnt_cap, &d_tc));
     mtb_status st = mtb_classify_batch_device(c, ix, p, d_b, d_o, d_b2, d_o2, n_reads, nb, d_res, d_tt, d_tc, taxcnt_cap, n_taxcnt);
     if (st != MTB_OK) return st;
+    STCHK(d2h(c, results, d_res, n_reads * sizeof(mtb_result)));
+    if (*n_taxcnt) { STCHK(d2h(c, taxcnt_tax, d_tt, *n_taxcnt * 4)); STCHK(d2h(c, taxcnt_cnt, d_tc, *n_taxcnt * 4)); }
+    return MTB_OK;
+}
+
+/* ------------------------------------------------------------------ */
+/* partitioned index: device-buffer stage calls  */
+/* ------------------------------------------------------------------ */
+} // extern "C"
+
+/* pos[p] = number of entries of the sorted array with value < bounds[p]; stride in 8-byte words */
+__global__ void k_lower_bounds(const uint64_t *__restrict__ v, uint64_t n, uint32_t stride, const uint64_t *__restrict__ bounds, uint32_t nb,
+                               uint64_t *__restrict__ pos) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nb) return;
+    const uint64_t b = bounds[p];
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) { uint64_t mid = (lo + hi) >> 1; if (v[mid * stride] < b) lo = mid + 1; else hi = mid; }
+    pos[p] = lo;
+}
+static mtb_status lower_bounds(mtb_ctx *c, const uint64_t *d_v, uint64_t n, uint32_t stride, const uint64_t *bounds, uint32_t nb, uint64_t *pos) {
+    uint64_t *d_b;
+    STCHK(ensure(c, "lbounds", 2ull * nb, &d_b));
+    STCHK(h2d(c, d_b, bounds, 8ull * nb));
+    hipLaunchKernelGGL(k_lower_bounds, dim3((nb + 63) / 64), dim3(64), 0, c->stream, d_v, n, stride, (const uint64_t *)d_b, nb, d_b + nb);
+    HIPCHK(hipGetLastError());
+    return d2h(c, pos, d_b + nb, 8ull * nb);
+}
+
+extern "C" {
+
+mtb_status mtb_index_slice(mtb_index *ix, uint64_t lo_value, uint64_t hi_value, int is_last, mtb_index **out) {
+    if (!ix || !out) return fail(MTB_ERR_ARG, "NULL argument");
+    mtb_ctx *c = ix->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    uint64_t b[2] = {lo_value, hi_value}, pos[2] = {0, 0};
+    if (ix->T) STCHK(lower_bounds(c, ix->d_values, ix->T, 1, b, 2, pos));
+    if (hi_value == UINT64_MAX) pos[1] = ix->T;
+    mtb_index *sl = new mtb_index(*ix);
+    sl->own = false; sl->own_tax = false;
+    sl->d_values = ix->d_values + pos[0]; sl->d_info = ix->d_info + pos[0]; sl->T = pos[1] - pos[0];
+    sl->match_last = !is_last || ix->match_last;
+    *out = sl;
+    return MTB_OK;
+}
+
+mtb_status mtb_part_extract(mtb_ctx *c, const mtb_params *p, const char *d_bases, const uint64_t *d_offs, const char *d_bases2,
+                            const uint64_t *d_offs2, uint64_t n_reads, const uint64_t *bounds, uint32_t n_parts, const mtb_kmer **d_sorted,
+                            uint64_t *n_kmers, uint64_t *part_counts) {
+    if (!c || !p || !d_offs || !bounds || !d_sorted || !n_kmers || !part_counts || n_parts == 0) return fail(MTB_ERR_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(c->device));
+    *d_sorted = nullptr; *n_kmers = 0;
+    for (uint32_t q = 0; q < n_parts; q++) part_counts[q] = 0;
+    c->part_n_reads = n_reads; c->part_max_len = 0;
+    if (n_reads == 0) return MTB_OK;
+    int32_t *d_ql, *d_ql2;
+    STCHK(ensure(c, "qlen", n_reads, &d_ql)); STCHK(ensure(c, "qlen2", n_reads, &d_ql2));
+    mtb_kmer *d_k, *d_s; uint64_t nk; uint32_t max_len = 0;
+    STCHK(dev_extract(c, p, d_bases, d_offs, d_bases2, d_offs2, n_reads, &d_k, &nk, d_ql, d_ql2, &max_len));
+    /* partition boundaries are amino-acid-part boundaries (bit 24), finer than the 32-bit tiles of the fused path: 5 passes */
+    STCHK(dev_sort(c, d_k, nk, 24, &d_s));
+    c->part_max_len = max_len;
+    std::vector<uint64_t> pos(n_parts);
+    if (nk) STCHK(lower_bounds(c, (const uint64_t *)d_s, nk, 2, bounds, n_parts, pos.data()));
+    for (uint32_t q = 0; q < n_parts; q++) { uint64_t hi = q + 1 < n_parts ? pos[q + 1] : nk; part_counts[q] = hi >= pos[q] ? hi - pos[q] : 0; }
+    if (nk && pos[0] != 0) return fail(MTB_ERR_ARG, "bounds[0] must be 0");
+    *d_sorted = d_s; *n_kmers = nk;
+    return MTB_OK;
+}
+
+mtb_status mtb_part_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_kmers, uint64_t n, mtb_match *d_out, uint64_t cap, uint64_t *count) {
+    if (!c || !ix || !count) return fail(MTB_ERR_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(c->device));
+    *count = 0;
+    if (n == 0 || ix->T == 0) return MTB_OK;
+    return dev_join(c, ix, d_kmers, n, d_out, cap, nullptr, count);
+}
+
+mtb_status mtb_part_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, mtb_match *d_matches, uint64_t n_matches, uint64_t n_reads,
+                          mtb_result *results, int32_t *taxcnt_tax, uint32_t *taxcnt_cnt, uint64_t taxcnt_cap, uint64_t *n_taxcnt) {
+    if (!c || !ix || !p || !results || !n_taxcnt) return fail(MTB_ERR_ARG, "NULL argument");
+    if (n_reads != c->part_n_reads) return fail(MTB_ERR_ARG, "mtb_part_score must follow mtb_part_extract of the same batch on the same context");
+    HIPCHK(hipSetDevice(c->device));
+    *n_taxcnt = 0;
+    if (n_reads == 0) return MTB_OK;
+    if (n_matches >= (1ull << 32)) return fail(MTB_ERR_ARG, "more than 2^32-1 matches in one batch; split the batch");
+    int32_t *d_ql, *d_ql2; uint32_t *d_rc; mtb_result *d_res; int32_t *d_tt; uint32_t *d_tc;
+    STCHK(ensure(c, "qlen", n_reads, &d_ql)); STCHK(ensure(c, "qlen2", n_reads, &d_ql2));
+    STCHK(ensure(c, "readcnt", n_reads, &d_rc));
+    STCHK(ensure(c, "results", n_reads, &d_res)); STCHK(ensure(c, "tctax", taxcnt_cap, &d_tt)); STCHK(ensure(c, "tccnt", taxcnt_cap, &d_tc));
+    HIPCHK(hipMemsetAsync(d_rc, 0, n_reads * 4, c->stream));
+    if (n_matches) hipLaunchKernelGGL(k_count_reads, dim3((uint32_t)((n_matches + 255) / 256)), dim3(256), 0, c->stream, (const mtb_match *)d_matches, n_matches, d_rc);
+    STCHK(score_join_order(c, ix, p, d_matches, n_matches, n_reads, d_rc, d_ql, d_ql2, c->part_max_len, d_res, d_tt, d_tc, taxcnt_cap, n_taxcnt, 0));
     STCHK(d2h(c, results, d_res, n_reads * sizeof(mtb_result)));
     if (*n_taxcnt) { STCHK(d2h(c, taxcnt_tax, d_tt, *n_taxcnt * 4)); STCHK(d2h(c, taxcnt_cnt, d_tc, *n_taxcnt * 4)); }
     return MTB_OK;

@@ -1,4 +1,6 @@
-"""Multi-GPU decomposition of the classify hot path (first row).
+"""Multi-GPU decomposition of the classify hot path.
+
+Row 1 (index fits one GPU, the default):
 
 Reads are independent units: with the index replicated on every GPU the path
 shards by contiguous read ranges and needs NO data-path collective.  The only
@@ -6,6 +8,13 @@ communication is control-plane: a barrier around timed regions and the sum of
 the per-taxon read counts (Classifier.cpp:201-203) at the end.  One process
 per GPU; `torch.distributed` backend "nccl" (= RCCL) on GPUs, "gloo" in the CPU
 tests.
+
+Row 2 (index larger than one HBM): `classify_partitioned` below.  The flat
+target array is range-partitioned by value at amino-acid-part boundaries, one
+range per GPU; per batch the sorted query metamers travel to the owner of their
+range (all-to-all #1, 16-byte records), are joined there, and the 24-byte
+matches travel back to the read's home GPU (all-to-all #2), which sorts and
+scores them.  Two exchange steps, no all-reduce on the data path.
 """
 from __future__ import annotations
 
@@ -41,3 +50,87 @@ def allreduce_tax_counts(counts: np.ndarray, dist=None) -> np.ndarray:
         t = t.cuda()
     dist.all_reduce(t)
     return t.cpu().numpy()
+
+
+# --------------------------------------------------------------------------
+# Row 2: range-partitioned index, two all-to-all exchanges per batch
+# --------------------------------------------------------------------------
+class GpuStages:
+    """The three device stages of one rank (libmtb's mtb_part_* calls); tensors are int64 views of the
+    16-byte metamer records ([n, 2]) and 24-byte match records ([n, 3]) on this rank's GPU."""
+
+    def __init__(self, ctx, index, params, device):
+        import torch
+        self.ctx, self.index, self.params, self.torch = ctx, index, params, torch
+        self.device = torch.device(device)
+        self.n_reads = 0
+
+    def set_reads(self, d_bases, d_offs, n_reads, d_bases2=None, d_offs2=None):
+        """device tensors: bases uint8, offs int64 (n_reads + 1); mates for seq_mode 2"""
+        self.reads = (d_bases, d_offs, d_bases2, d_offs2)
+        self.n_reads = n_reads
+
+    def extract_sorted(self, bounds):
+        torch = self.torch
+        b, o, b2, o2 = self.reads
+        ptr, nk, counts = self.ctx.part_extract(self.params, b.data_ptr(), o.data_ptr(), b2.data_ptr() if b2 is not None else 0,
+                                                o2.data_ptr() if o2 is not None else 0, self.n_reads, bounds)
+        if nk == 0:
+            return torch.empty((0, 2), dtype=torch.int64, device=self.device), [0] * len(counts)
+
+        class _View:            # zero-copy view of the context-owned buffer (valid until the next stage call)
+            __cuda_array_interface__ = {"shape": (int(nk), 2), "typestr": "<i8", "data": (int(ptr), False), "version": 2}
+        return torch.as_tensor(_View(), device=self.device), [int(c) for c in counts]
+
+    def join(self, run):
+        torch = self.torch
+        n = int(run.shape[0])
+        if n == 0:
+            return torch.empty((0, 3), dtype=torch.int64, device=self.device)
+        run = run.contiguous()
+        cap = 2 * n + 1024
+        while True:
+            out = torch.empty((cap, 3), dtype=torch.int64, device=self.device)
+            st, cnt = self.ctx.part_join(self.index, run.data_ptr(), n, out.data_ptr(), cap)
+            if st == 0:
+                return out[:cnt]
+            cap = cnt + 16
+
+    def score(self, matches):
+        matches = matches.contiguous()
+        return self.ctx.part_score(self.index, self.params, matches.data_ptr(), int(matches.shape[0]), self.n_reads)
+
+
+def _exchange(torch, dist, send, send_counts, width, xdev):
+    """all-to-all(v) of [n, width] int64 rows; returns (received rows, per-source row counts)."""
+    world = dist.get_world_size()
+    sc = torch.tensor(send_counts, dtype=torch.int64, device=xdev)
+    rc = torch.empty(world, dtype=torch.int64, device=xdev)
+    dist.all_to_all_single(rc, sc)
+    recv_counts = [int(x) for x in rc.cpu().tolist()]
+    recv = torch.empty((sum(recv_counts), width), dtype=torch.int64, device=xdev)
+    dist.all_to_all_single(recv, send.to(xdev).contiguous(), recv_counts, [int(x) for x in send_counts])
+    return recv, recv_counts
+
+
+def classify_partitioned(stages, bounds, dist):
+    """One batch on one rank of a range-partitioned index.  `stages` provides extract_sorted(bounds) ->
+    (metamers [n,2] sorted by value, count per range), join(run) -> matches [m,3], score(matches) -> results;
+    `bounds[p]` is the lower amino-acid-part bound of rank p's range.  Returns what score() returns for this
+    rank's reads.  Collectives: 2 x (counts + payload) all-to-all; with backend "gloo" (CPU tests) the payload
+    is staged through host memory."""
+    import torch
+    world = dist.get_world_size()
+    assert len(bounds) == world, "one value range per rank"
+    kmers, counts = stages.extract_sorted(bounds)
+    xdev = kmers.device if dist.get_backend() == "nccl" else torch.device("cpu")
+    home = kmers.device
+    recv, recv_counts = _exchange(torch, dist, kmers, counts, 2, xdev)           # all-to-all #1: metamers to range owners
+    recv = recv.to(home)
+    runs, o = [], 0
+    for n in recv_counts:                                                         # runs arrive sorted: one join per source, no merge
+        runs.append(stages.join(recv[o:o + n])); o += n
+    m_counts = [int(r.shape[0]) for r in runs]
+    m_send = torch.cat(runs) if runs else torch.empty((0, 3), dtype=torch.int64, device=home)
+    m_recv, _ = _exchange(torch, dist, m_send, m_counts, 3, xdev)                 # all-to-all #2: matches back to the read's home
+    return stages.score(m_recv.to(home))

@@ -1,0 +1,183 @@
+"""Range-partitioned index: every rank owns one value range of the target array, query
+metamers travel to the owner (all-to-all #1), matches travel home (all-to-all #2).
+
+CPU (gloo, world_size 2): metabuli_amd.parallel.classify_partitioned drives the exchange exactly as on GPUs; the
+per-rank stages are played by the oracle / the host build of the kernel arithmetic, and the gathered per-read
+results must equal the single-process oracle run on the whole index.
+GPU (-m gpu): the same with libmtb's mtb_part_* stage calls, two processes sharing cuda:0, ranges loaded from the
+database files through the split checkpoints (mtb_index_open_part)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+AAMASK = np.uint64(0xFFFFFFFFFF000000)
+
+
+class EmuStages:
+    """CPU stand-in for metabuli_amd.parallel.GpuStages (tests only)."""
+
+    def __init__(self, orc, emu, p, db, tax, values, info, t2s, lo, hi, is_last, bases, offs):
+        import torch
+        self.torch, self.orc, self.emu, self.p, self.db, self.tax = torch, orc, emu, p, db, tax
+        a, b = np.searchsorted(values, [lo, hi]) if hi != np.uint64(2**64 - 1) else (np.searchsorted(values, lo), len(values))
+        self.values = values[a:b].copy(); self.info = info[a:b].copy(); self.t2s = t2s
+        if not is_last:           # the "last entry is never a candidate" rule belongs to the last range only
+            self.values = np.append(self.values, np.uint64(2**64 - 1)); self.info = np.append(self.info, np.uint32(0))
+        self.bases, self.offs = bases, offs
+
+    def extract_sorted(self, bounds):
+        k, self.ql, self.ql2 = self.orc.extract_batch(self.p, self.bases, self.offs)
+        k = self.orc.sort_kmers(k)
+        pos = np.searchsorted(k["value"], np.asarray(bounds, np.uint64))
+        counts = np.diff(np.append(pos, len(k)))
+        return self.torch.from_numpy(k.view(np.int64).reshape(-1, 2).copy()), [int(c) for c in counts]
+
+    def join(self, run):
+        from helpers import kmer_dt
+        q = run.numpy().copy().view(np.uint64).reshape(-1).view(kmer_dt)
+        m = self.emu.join(self.values, self.info, self.t2s, 0xFFFFFFFF, self.p.kmer_format, q)
+        return self.torch.from_numpy(m.view(np.int64).reshape(-1, 3).copy())
+
+    def score(self, matches):
+        from helpers import match_dt
+        m = matches.numpy().copy().view(np.uint64).reshape(-1).view(match_dt)
+        m = self.orc.sort_matches(m)
+        return self.orc.score(self.db, self.tax, self.p, m, len(self.offs) - 1, self.ql, self.ql2)
+
+
+def _cpu_worker(rank, world, port, dbdir, npz, out):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from helpers import Oracle, Emu, default_params
+    import metabuli_amd
+    from metabuli_amd import parallel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = np.load(npz)
+    orc, emu = Oracle(), Emu()
+    p = default_params(seq_mode=1, syncmer=1)
+    tax = orc.load_taxonomy(os.path.join(dbdir, "taxonomy"))
+    db = orc.open_db(dbdir, tax, p)
+    bounds = metabuli_amd.part_bounds(dbdir, world)
+    _, t2s = emu.load_taxonomy(os.path.join(dbdir, "taxonomy"), g["taxids"])
+    b, o, lo, hi = parallel.shard_reads(g["bases"], g["offs"], rank, world)
+    hi_b = bounds[rank + 1] if rank + 1 < world else np.uint64(2**64 - 1)
+    st = EmuStages(orc, emu, p, db, tax, g["values"], g["taxids"].astype(np.uint32), t2s, bounds[rank], hi_b, rank == world - 1, b, o)
+    res, tt, tc = parallel.classify_partitioned(st, bounds, dist)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (lo, hi, res["classification"].tolist(), res["score"].tolist(), tt.tolist(), tc.tolist()))
+    if rank == 0:
+        n = len(g["offs"]) - 1
+        cls = np.zeros(n, np.int32); sc = np.zeros(n, np.float32); att, atc = [], []
+        for lo_, hi_, c, s, t1, t2 in gathered:
+            cls[lo_:hi_] = c; sc[lo_:hi_] = s; att += t1; atc += t2
+        np.savez(out, cls=cls, score=sc, tt=np.array(att, np.int32), tc=np.array(atc, np.uint32))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _check(out, ref):
+    r = np.load(out)
+    ro = ref["results"]
+    assert (r["cls"] == ro["classification"]).all()
+    assert (r["score"].view(np.uint32) == ro["score"].view(np.uint32)).all()
+    assert (r["tt"] == ref["tc_tax"]).all() and (r["tc"] == ref["tc_cnt"]).all()
+
+
+def test_part_bounds_are_amino_acid_boundaries(orc, tmp_path):
+    import metabuli_amd
+    from conftest import Toy
+    t = Toy(orc, tmp_path / "db", syncmer=1, paired=False, seed=21, n_reads=4)
+    for world in (1, 2, 3, 8):
+        b = metabuli_amd.part_bounds(t.dbdir, world)
+        assert b[0] == 0 and (np.diff(b.astype(np.float64)) >= 0).all()
+        assert ((b & ~AAMASK) == 0).all()
+        cuts = np.searchsorted(t.values, b)
+        sizes = np.diff(np.append(cuts, len(t.values)))
+        assert sizes.sum() == len(t.values)
+        if world > 1:        # balanced within a few checkpoints, and no amino-acid group straddles a cut
+            assert sizes.max() - sizes.min() < len(t.values) // 50 + 200
+            for c in cuts[1:]:
+                assert (t.values[c - 1] & AAMASK) != (t.values[c] & AAMASK)
+
+
+def test_two_rank_partitioned_index_matches_single_process(orc, tmp_path):
+    from conftest import Toy
+    t = Toy(orc, tmp_path / "db", syncmer=1, paired=False, seed=22, n_reads=90)
+    npz = str(tmp_path / "in.npz"); out = str(tmp_path / "out.npz")
+    np.savez(npz, bases=t.b1, offs=t.o1, values=t.values, taxids=t.taxids)
+    mp.spawn(_cpu_worker, args=(2, 30100 + os.getpid() % 500, t.dbdir, npz, out), nprocs=2, join=True)
+    _check(out, t.ref)
+
+
+# ------------------------------------------------------------------ GPU
+def _gpu_worker(rank, world, port, dbdir, npz, out, seq_mode):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    import metabuli_amd as M
+    from metabuli_amd import parallel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)     # one GPU on the test box: payload staged through the host
+    g = np.load(npz)
+    ctx = M.Context(0)
+    p = M.default_params(seq_mode=seq_mode, syncmer=1)
+    bounds = M.part_bounds(dbdir, world)
+    ix = ctx.open_index_part(dbdir, p, rank, world)
+    b, o, lo, hi = parallel.shard_reads(g["bases"], g["offs"], rank, world)
+    dev = torch.device("cuda:0")
+    st = parallel.GpuStages(ctx, ix, p, dev)
+    st.set_reads(torch.from_numpy(b.copy()).to(dev), torch.from_numpy(o.astype(np.int64)).to(dev), hi - lo)
+    res, tt, tc = parallel.classify_partitioned(st, bounds, dist)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (lo, hi, res["classification"].tolist(), res["score"].tolist(), tt.tolist(), tc.tolist(), ix.num_targets))
+    if rank == 0:
+        n = len(g["offs"]) - 1
+        cls = np.zeros(n, np.int32); sc = np.zeros(n, np.float32); att, atc = [], []; T = 0
+        for lo_, hi_, c, s, t1, t2, tn in gathered:
+            cls[lo_:hi_] = c; sc[lo_:hi_] = s; att += t1; atc += t2; T += tn
+        np.savez(out, cls=cls, score=sc, tt=np.array(att, np.int32), tc=np.array(atc, np.uint32), T=T)
+    dist.barrier()
+    ix.close(); ctx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_gpu_partitioned_two_processes(orc, tmp_path, world):
+    from conftest import Toy
+    t = Toy(orc, tmp_path / "db", syncmer=1, paired=False, seed=23, n_reads=200)
+    npz = str(tmp_path / "in.npz"); out = str(tmp_path / "out.npz")
+    np.savez(npz, bases=t.b1, offs=t.o1)
+    mp.spawn(_gpu_worker, args=(world, 30700 + os.getpid() % 500, t.dbdir, npz, out, 1), nprocs=world, join=True)
+    _check(out, t.ref)
+    assert int(np.load(out)["T"]) == len(t.values)
+
+
+@pytest.mark.gpu
+def test_gpu_partitions_concatenate_to_the_index(orc, tmp_path):
+    import metabuli_amd as M
+    from conftest import Toy
+    t = Toy(orc, tmp_path / "db", syncmer=1, paired=False, seed=24, n_reads=4)
+    ctx = M.Context(0)
+    for world in (1, 2, 5):
+        vs, infos = [], []
+        for r in range(world):
+            p = M.default_params(seq_mode=1, syncmer=1)
+            ix = ctx.open_index_part(t.dbdir, p, r, world)
+            v, i = ix.download(); vs.append(v); infos.append(i); ix.close()
+        assert (np.concatenate(vs) == t.values).all()
+        assert (np.concatenate(infos) == t.taxids.astype(np.uint32)).all()
+    # device views of a resident index cut the same way
+    p = M.default_params(seq_mode=1, syncmer=1)
+    full = ctx.open_index(t.dbdir, p)
+    b = M.part_bounds(t.dbdir, 3)
+    parts = [full.slice(b[r], b[r + 1] if r < 2 else 2**64 - 1, r == 2) for r in range(3)]
+    assert (np.concatenate([q.download()[0] for q in parts]) == t.values).all()
+    for q in parts:
+        q.close()
+    full.close(); ctx.close()
