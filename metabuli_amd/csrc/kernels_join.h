@@ -203,10 +203,13 @@ __global__ __launch_bounds__(256) void k_regroup(const mtb_match *__restrict__ i
 }
 
 /* per-read counters from an (arbitrarily ordered) match list: stage API path */
-__global__ __launch_bounds__(256) void k_count_reads(const mtb_match *__restrict__ in, uint64_t n, uint32_t *__restrict__ read_cnt) {
+__global__ __launch_bounds__(256) void k_count_reads(const mtb_match *__restrict__ in, uint64_t n, uint32_t *__restrict__ read_cnt,
+                                                      uint64_t n_reads, uint32_t *__restrict__ bad) {
     uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    atomicAdd(&read_cnt[mtb_q_seq(in[i].qinfo) - 1], 1u);
+    uint32_t r = mtb_q_seq(in[i].qinfo) - 1;
+    if (r >= n_reads) { *bad = 1; return; }          /* caller-supplied records: sequenceID outside the batch */
+    atomicAdd(&read_cnt[r], 1u);
 }
 
 /* ---- segment sort: compareMatches order inside every read segment -------

@@ -396,6 +396,18 @@ static mtb_status dev_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, uint
 /* ------------------------------------------------------------------ */
 /* index                                                               */
 /* ------------------------------------------------------------------ */
+/* per-read match counts of caller-supplied records; rejects sequenceIDs outside 1..n_reads */
+static mtb_status count_reads(mtb_ctx *c, const mtb_match *d_in, uint64_t n, uint64_t n_reads, uint32_t *d_rc) {
+    HIPCHK(hipMemsetAsync(d_rc, 0, n_reads * 4, c->stream));
+    if (n == 0) return MTB_OK;
+    HIPCHK(hipMemsetAsync(c->d_scal + 1, 0, 8, c->stream));
+    hipLaunchKernelGGL(k_count_reads, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, d_in, n, d_rc, n_reads, (uint32_t *)(c->d_scal + 1));
+    uint64_t bad = 0;
+    STCHK(d2h(c, &bad, c->d_scal + 1, 8));
+    if (bad) return fail(MTB_ERR_ARG, "match records with a sequenceID outside 1..n_reads");
+    return MTB_OK;
+}
+
 static mtb_status upload_taxonomy(mtb_index *ix) {
     const mtbhost::Taxonomy &t = ix->tax;
     size_t n = (size_t)t.max_id + 1;
@@ -670,8 +682,7 @@ mtb_status mtb_sort_matches(mtb_ctx *c, mtb_match *matches, uint64_t n, uint64_t
     mtb_match *d_in, *d_out; uint32_t *d_rc; uint64_t *d_seg;
     STCHK(ensure(c, "jtemp", n, &d_in)); STCHK(ensure(c, "matches", n, &d_out)); STCHK(ensure(c, "readcnt", n_reads, &d_rc));
     STCHK(h2d(c, d_in, matches, n * sizeof(mtb_match)));
-    HIPCHK(hipMemsetAsync(d_rc, 0, n_reads * 4, c->stream));
-    hipLaunchKernelGGL(k_count_reads, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, (const mtb_match *)d_in, n, d_rc);
+    STCHK(count_reads(c, d_in, n, n_reads, d_rc));
     STCHK(dev_regroup(c, d_in, n, n_reads, d_rc, &d_seg, d_out));
     STCHK(dev_segsort(c, d_out, d_seg, n_reads, nullptr));
     STCHK(d2h(c, matches, d_out, n * sizeof(mtb_match)));
@@ -692,8 +703,7 @@ mtb_status mtb_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, const mtb_m
     STCHK(h2d(c, d_m, sorted, n_matches * sizeof(mtb_match)));
     STCHK(h2d(c, d_ql, qlen, n_reads * 4));
     if (qlen2) STCHK(h2d(c, d_ql2, qlen2, n_reads * 4)); else HIPCHK(hipMemsetAsync(d_ql2, 0, n_reads * 4, c->stream));
-    HIPCHK(hipMemsetAsync(d_rc, 0, n_reads * 4, c->stream));
-    if (n_matches) hipLaunchKernelGGL(k_count_reads, dim3((uint32_t)((n_matches + 255) / 256)), dim3(256), 0, c->stream, (const mtb_match *)d_m, n_matches, d_rc);
+    STCHK(count_reads(c, d_m, n_matches, n_reads, d_rc));
     scan_launch<uint32_t, uint64_t, false>(c->stream, d_rc, n_reads, true, d_seg, d_ws);
     /* maxima for slab sizing */
     std::vector<uint32_t> rc(n_reads);
@@ -1025,8 +1035,7 @@ mtb_status mtb_part_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, mtb_ma
     STCHK(ensure(c, "qlen", n_reads, &d_ql)); STCHK(ensure(c, "qlen2", n_reads, &d_ql2));
     STCHK(ensure(c, "readcnt", n_reads, &d_rc));
     STCHK(ensure(c, "results", n_reads, &d_res)); STCHK(ensure(c, "tctax", taxcnt_cap, &d_tt)); STCHK(ensure(c, "tccnt", taxcnt_cap, &d_tc));
-    HIPCHK(hipMemsetAsync(d_rc, 0, n_reads * 4, c->stream));
-    if (n_matches) hipLaunchKernelGGL(k_count_reads, dim3((uint32_t)((n_matches + 255) / 256)), dim3(256), 0, c->stream, (const mtb_match *)d_matches, n_matches, d_rc);
+    STCHK(count_reads(c, d_matches, n_matches, n_reads, d_rc));
     STCHK(score_join_order(c, ix, p, d_matches, n_matches, n_reads, d_rc, d_ql, d_ql2, c->part_max_len, d_res, d_tt, d_tc, taxcnt_cap, n_taxcnt, 0));
     STCHK(d2h(c, results, d_res, n_reads * sizeof(mtb_result)));
     if (*n_taxcnt) { STCHK(d2h(c, taxcnt_tax, d_tt, *n_taxcnt * 4)); STCHK(d2h(c, taxcnt_cnt, d_tc, *n_taxcnt * 4)); }

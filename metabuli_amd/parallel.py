@@ -70,9 +70,15 @@ class GpuStages:
         self.reads = (d_bases, d_offs, d_bases2, d_offs2)
         self.n_reads = n_reads
 
+    def _fence(self):
+        # the library runs on its own HIP stream and synchronises before it returns; work torch has queued
+        # (collectives, cat/copies) must have finished before the library reads those tensors
+        self.torch.cuda.current_stream(self.device).synchronize()
+
     def extract_sorted(self, bounds):
         torch = self.torch
         b, o, b2, o2 = self.reads
+        self._fence()
         ptr, nk, counts = self.ctx.part_extract(self.params, b.data_ptr(), o.data_ptr(), b2.data_ptr() if b2 is not None else 0,
                                                 o2.data_ptr() if o2 is not None else 0, self.n_reads, bounds)
         if nk == 0:
@@ -88,7 +94,8 @@ class GpuStages:
         if n == 0:
             return torch.empty((0, 3), dtype=torch.int64, device=self.device)
         run = run.contiguous()
-        cap = 2 * n + 1024
+        self._fence()
+        cap = n + n // 4 + 1024
         while True:
             out = torch.empty((cap, 3), dtype=torch.int64, device=self.device)
             st, cnt = self.ctx.part_join(self.index, run.data_ptr(), n, out.data_ptr(), cap)
@@ -98,7 +105,14 @@ class GpuStages:
 
     def score(self, matches):
         matches = matches.contiguous()
+        self._fence()
         return self.ctx.part_score(self.index, self.params, matches.data_ptr(), int(matches.shape[0]), self.n_reads)
+
+
+# rows of one all_to_all_single call are bounded: torch 2.10 + RCCL 2.26 return corrupt data for variable-split
+# exchanges beyond ~1 GiB per call (measured on MI355X, world_size 1: 1.0 GiB intact, 1.5 GiB not); 512 MiB
+# per call still means >= 64 MiB per peer at 8 GPUs, far above the xGMI latency regime
+_XCHG_BYTES = 512 << 20
 
 
 def _exchange(torch, dist, send, send_counts, width, xdev):
@@ -107,9 +121,29 @@ def _exchange(torch, dist, send, send_counts, width, xdev):
     sc = torch.tensor(send_counts, dtype=torch.int64, device=xdev)
     rc = torch.empty(world, dtype=torch.int64, device=xdev)
     dist.all_to_all_single(rc, sc)
+    mx = torch.tensor([max(send_counts) if send_counts else 0], dtype=torch.int64, device=xdev)
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
     recv_counts = [int(x) for x in rc.cpu().tolist()]
+    send_counts = [int(x) for x in send_counts]
+    send = send.to(xdev)
     recv = torch.empty((sum(recv_counts), width), dtype=torch.int64, device=xdev)
-    dist.all_to_all_single(recv, send.to(xdev).contiguous(), recv_counts, [int(x) for x in send_counts])
+    chunk = max(1, _XCHG_BYTES // (8 * width * world))           # rows per peer per call
+    rounds = (int(mx.item()) + chunk - 1) // chunk
+    s_off = np.concatenate([[0], np.cumsum(send_counts)]).astype(np.int64)
+    r_off = np.concatenate([[0], np.cumsum(recv_counts)]).astype(np.int64)
+    for k in range(rounds):
+        s_n = [max(0, min(chunk, c - k * chunk)) for c in send_counts]
+        r_n = [max(0, min(chunk, c - k * chunk)) for c in recv_counts]
+        if rounds == 1:
+            dist.all_to_all_single(recv, send.contiguous(), r_n, s_n)
+            break
+        part = torch.cat([send[int(s_off[p]) + k * chunk: int(s_off[p]) + k * chunk + s_n[p]] for p in range(world)])
+        got = torch.empty((sum(r_n), width), dtype=torch.int64, device=xdev)
+        dist.all_to_all_single(got, part, r_n, s_n)
+        o = 0
+        for p in range(world):
+            recv[int(r_off[p]) + k * chunk: int(r_off[p]) + k * chunk + r_n[p]] = got[o:o + r_n[p]]
+            o += r_n[p]
     return recv, recv_counts
 
 

@@ -251,3 +251,14 @@ def test_two_streams_give_identical_results(toy):
     amb = np.tile(ro["flag"] != 0, big)
     assert ((r2["classification"] == np.tile(ro["classification"], big)) | amb).all()
     ix.close(); c.close()
+
+
+def test_foreign_sequence_ids_are_rejected(ctx):
+    """caller-supplied match records whose sequenceID lies outside the batch are an argument error, not a wild write"""
+    import metabuli_amd as M
+    m = np.zeros(3, M.match_dt)
+    m["qinfo"] = (np.array([1, 2, 9], np.uint64) << np.uint64(32))
+    with pytest.raises(M.MtbError) as e:
+        ctx.sort_matches(m, 2)
+    assert e.value.status == M.MTB_ERR_ARG
+    assert len(ctx.sort_matches(m[:2], 2)) == 2

@@ -57,6 +57,8 @@ def _cpu_worker(rank, world, port, dbdir, npz, out):
     from metabuli_amd import parallel
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    if os.environ.get("MTB_TEST_XCHG"):          # force the multi-round (chunked) exchange
+        parallel._XCHG_BYTES = int(os.environ["MTB_TEST_XCHG"])
     g = np.load(npz)
     orc, emu = Oracle(), Emu()
     p = default_params(seq_mode=1, syncmer=1)
@@ -105,11 +107,14 @@ def test_part_bounds_are_amino_acid_boundaries(orc, tmp_path):
                 assert (t.values[c - 1] & AAMASK) != (t.values[c] & AAMASK)
 
 
-def test_two_rank_partitioned_index_matches_single_process(orc, tmp_path):
+@pytest.mark.parametrize("xchg_bytes", [None, 20000])
+def test_two_rank_partitioned_index_matches_single_process(orc, tmp_path, xchg_bytes, monkeypatch):
     from conftest import Toy
     t = Toy(orc, tmp_path / "db", syncmer=1, paired=False, seed=22, n_reads=90)
     npz = str(tmp_path / "in.npz"); out = str(tmp_path / "out.npz")
     np.savez(npz, bases=t.b1, offs=t.o1, values=t.values, taxids=t.taxids)
+    if xchg_bytes:
+        monkeypatch.setenv("MTB_TEST_XCHG", str(xchg_bytes))
     mp.spawn(_cpu_worker, args=(2, 30100 + os.getpid() % 500, t.dbdir, npz, out), nprocs=2, join=True)
     _check(out, t.ref)
 
