@@ -20,14 +20,16 @@
 #include "mtb_score_par.h"
 
 /* profiling build only (-DMTB_SCORE_PHASE_CYCLES): cycles per phase of k_score,
- * accumulated into mtb_phase_cycles[4] = {stage+sort, paths, combine, decide} */
+ * accumulated into mtb_phase_cycles[16]: 0 load+keys, 1 rank, 2 permute, 3 flags+ids, 4 starts, 5 links, 6 chain DP,
+ * 7 emit, 8 combine, 9 select, 10 filter, 11 gather, 12 climb, 13 decide+output */
 #ifdef MTB_SCORE_PHASE_CYCLES
-__device__ unsigned long long mtb_phase_cycles[4];
-__shared__ unsigned long long mtb_phase_lds[4];      /* per-workgroup accumulators, flushed once at kernel end */
+#define MTB_NPHASE 16
+__device__ unsigned long long mtb_phase_cycles[MTB_NPHASE];
+__shared__ unsigned long long mtb_phase_lds[MTB_NPHASE];      /* per-workgroup accumulators, flushed once at kernel end */
 #define MTB_PHASE_BEGIN() unsigned long long ph_t0_ = __builtin_readcyclecounter()
 #define MTB_PHASE_MARK(k) do { unsigned long long t_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) mtb_phase_lds[k] += t_ - ph_t0_; ph_t0_ = t_; } while (0)
-#define MTB_PHASE_KERNEL_BEGIN() do { if (threadIdx.x < 4) mtb_phase_lds[threadIdx.x] = 0; __syncthreads(); } while (0)
-#define MTB_PHASE_KERNEL_END() do { __syncthreads(); if (threadIdx.x < 4) atomicAdd(&mtb_phase_cycles[threadIdx.x], mtb_phase_lds[threadIdx.x]); } while (0)
+#define MTB_PHASE_KERNEL_BEGIN() do { if (threadIdx.x < MTB_NPHASE) mtb_phase_lds[threadIdx.x] = 0; __syncthreads(); } while (0)
+#define MTB_PHASE_KERNEL_END() do { __syncthreads(); if (threadIdx.x < MTB_NPHASE) atomicAdd(&mtb_phase_cycles[threadIdx.x], mtb_phase_lds[threadIdx.x]); } while (0)
 #else
 #define MTB_PHASE_BEGIN() do {} while (0)
 #define MTB_PHASE_MARK(k) do {} while (0)
@@ -74,6 +76,28 @@ __global__ __launch_bounds__(256) void k_list_large(const uint64_t *__restrict__
     if ((threadIdx.x & 63) == 0 && n > threshold) atomicMax(max_seg, n);
 }
 
+/* Query::taxCnt from the bucket taxa, wave-parallel (same result as mtb_taxcnt_gather: ascending taxid, one
+ * entry per distinct taxon of the used buckets): every round extracts the smallest taxon not yet emitted (lane-
+ * strided minimum + wave reduction) and counts its buckets.  Rounds = distinct taxa (1-3 for most reads), against
+ * one serial insertion per bucket on lane 0 before.  The capacity is never the limit: cap = min(matches, buckets)
+ * >= used buckets >= distinct taxa (k_taxcnt_bound).                                                          */
+__device__ __forceinline__ int32_t taxcnt_gather_wave(const int32_t *btax, const uint8_t *bham, int32_t nb, int32_t *otax, uint32_t *ocnt, int32_t cap) {
+    const int32_t lane = (int32_t)threadIdx.x;
+    int32_t ntc = 0;
+    int32_t last = -1;                               /* taxids are non-negative (info & mask, canonical LCA ids) */
+    while (ntc < cap) {
+        int32_t mn = INT32_MAX;
+        for (int32_t q = lane; q < nb; q += 64) if (bham[q] != 255) { int32_t t = btax[q]; if (t > last && t < mn) mn = t; }
+        for (int d = 32; d > 0; d >>= 1) { int32_t o = __shfl_xor(mn, d, 64); mn = o < mn ? o : mn; }
+        if (mn == INT32_MAX) break;
+        uint32_t cnt = 0;
+        for (int32_t q0 = 0; q0 < nb; q0 += 64) { int32_t q = q0 + lane; cnt += (uint32_t)__popcll(__ballot(q < nb && bham[q] != 255 && btax[q] == mn)); }
+        if (lane == 0) { otax[ntc] = mn; ocnt[ntc] = cnt; }
+        ntc++; last = mn;
+    }
+    return ntc;
+}
+
 /* One read, data-parallel (phases of mtb_score_par.h).  All storage of a call
  * site lives in ONE address space (LDS or an HBM slab) so that the compiler
  * emits ds_* / global_* instead of flat accesses.  SORT: the segment arrives
@@ -110,6 +134,7 @@ __device__ __forceinline__ void score_read_par(const REC *__restrict__ src, int3
             }
         }
         __syncthreads();
+        MTB_PHASE_MARK(0);
         const int32_t nslot = (n + 63) >> 6;          /* live register slots (wave-uniform) */
         bool unique = true;
         if (KEY64) {
@@ -172,6 +197,7 @@ __device__ __forceinline__ void score_read_par(const REC *__restrict__ src, int3
             }
         }
         __syncthreads();
+        MTB_PHASE_MARK(1);
 #pragma unroll
         for (int k = 0; k < MTB_SCORE_MAXPER; k++) { int32_t i = lane + 64 * k; if (i < n) w.m[rank[k]] = rec[k]; }
         __syncthreads();
@@ -183,7 +209,7 @@ __device__ __forceinline__ void score_read_par(const REC *__restrict__ src, int3
         for (int32_t i = lane; i < n; i += 64) w.m[i] = rec_m(src[i]);
         __syncthreads();
     }
-    MTB_PHASE_MARK(0);
+    MTB_PHASE_MARK(2);
     /* flags, ids */
     for (int32_t i = lane; i < n; i += 64) mtb_ph_flags(w, i);
     __syncthreads();
@@ -200,12 +226,15 @@ __device__ __forceinline__ void score_read_par(const REC *__restrict__ src, int3
         ng += __popcll(mg); nbk += __popcll(mb); nsp += __popcll(ms);
     }
     __syncthreads();
+    MTB_PHASE_MARK(3);
     for (int32_t i = lane; i < n; i += 64) mtb_ph_starts(w, i, &tx);
     __syncthreads();
+    MTB_PHASE_MARK(4);
     int32_t maxrank = 0;
     for (int32_t i = lane; i < n; i += 64) { mtb_ph_links(w, i, &tx, &sp, ng, nbk); int32_t rr = w.rk[i]; maxrank = rr > maxrank ? rr : maxrank; }
     for (int d = 32; d > 0; d >>= 1) { int32_t o = __shfl_xor(maxrank, d, 64); maxrank = o > maxrank ? o : maxrank; }
     __syncthreads();
+    MTB_PHASE_MARK(5);
     /* chain DP: pointer doubling when every match has <= 1 consecutive predecessor, else rounds */
     const bool small_n = n <= 64 * MTB_SCORE_MAXPER;
     bool simple = small_n || sizeof(IDX) == 4;      /* big segments need the 32-bit workspace for the ping-pong array */
@@ -296,7 +325,7 @@ __device__ __forceinline__ void score_read_par(const REC *__restrict__ src, int3
             __syncthreads();
         }
     }
-    MTB_PHASE_MARK(1);
+    MTB_PHASE_MARK(6);
     /* emit + compaction: elist = gid[], exclusive emitted prefix = rk[] */
     IDX *elist = w.gid, *ec = w.rk;
     int32_t ne = 0;
@@ -310,24 +339,37 @@ __device__ __forceinline__ void score_read_par(const REC *__restrict__ src, int3
         ne += (int32_t)__popcll(me);
     }
     __syncthreads();
-    /* combine: one lane per species */
+    MTB_PHASE_MARK(7);
+    /* combine: stable order by parallel rank, certain drops in parallel, then one lane per species for the rest.
+     * Dead arrays reused: bid -> sorted list, sid -> start of the entry's species range, shift -> pre-drop flag */
+    IDX *sorted = w.bid, *elo = w.sid; uint8_t *predrop = w.shift;
+    for (int32_t e = lane; e < ne; e += 64) {
+        const int32_t s = mtb_ph_comb_species(w, nsp, (int32_t)elist[e]);
+        const int32_t lo = ec[w.sp_start[s]], hi = (s + 1 < nsp) ? (int32_t)ec[w.sp_start[s + 1]] : ne;
+        sorted[mtb_ph_comb_rank(w, elist, e, lo, hi)] = elist[e];
+        elo[e] = (IDX)lo;
+    }
+    __syncthreads();
+    for (int32_t k = lane; k < ne; k += 64) predrop[k] = mtb_ph_comb_predrop(w, sorted, k, (int32_t)elo[k]) ? 1 : 0;
+    __syncthreads();
     float *sps = (float *)w.grp_start;
     for (int32_t s0 = 0; s0 < nsp; s0 += 64) {
         int32_t s = s0 + lane;
         float sc = -1.0f;
         if (s < nsp) {
             int32_t lo = ec[w.sp_start[s]], hi = (s + 1 < nsp) ? (int32_t)ec[w.sp_start[s + 1]] : ne;
-            if (hi > lo) { sc = mtb_ph_combine(w, elist, lo, hi, read_len); sc = sc < 1.0f ? sc : 1.0f; }
+            if (hi > lo) { sc = mtb_ph_comb_greedy(w, sorted, predrop, lo, hi, read_len); sc = sc < 1.0f ? sc : 1.0f; }
         }
         __syncthreads();                 /* sps[] aliases grp_start/blk_start: all reads above are done */
         if (s < nsp) sps[s] = sc;
     }
     __syncthreads();
-    MTB_PHASE_MARK(2);
+    MTB_PHASE_MARK(8);
     /* select (lane 0), then the redundancy filter over the best species' matches */
     int32_t bs = 0, be = 0, species = 0, go = 0;
     if (lane == 0) go = mtb_ph_select(w, sps, nsp, &tx, &sp, &R, &bs, &be, &species) ? 1 : 0;
     go = __shfl(go, 0, 64);
+    MTB_PHASE_MARK(9);
     if (go) {
         bs = __shfl(bs, 0, 64); be = __shfl(be, 0, 64); species = __shfl(species, 0, 64);
         uint32_t *hmin = ocnt;
@@ -339,10 +381,10 @@ __device__ __forceinline__ void score_read_par(const REC *__restrict__ src, int3
         __syncthreads();
         for (int32_t q = lane; q < nb; q += 64) bham[q] = hmin[q] == 255u ? 255 : 0;
         __syncthreads();
-        int32_t ntc = 0;
-        if (lane == 0) ntc = mtb_taxcnt_gather(btax, bham, nb, otax, ocnt, (int32_t)tc_room);
-        ntc = __shfl(ntc, 0, 64);
+        MTB_PHASE_MARK(10);
+        const int32_t ntc = taxcnt_gather_wave(btax, bham, nb, otax, ocnt, (int32_t)tc_room);
         __syncthreads();
+        MTB_PHASE_MARK(11);
         /* sub-species descent: climb the (few) taxa in parallel, walk the chains on lane 0 */
         bool to_parent = R.score < sp.min_sp_score;          /* R valid on lane 0 only; recomputed below on lane 0 */
         int32_t slow = ntc > MTB_LR_MAXE ? 1 : 0;
@@ -354,6 +396,7 @@ __device__ __forceinline__ void score_read_par(const REC *__restrict__ src, int3
         }
         slow = __any(slow) ? 1 : 0;
         __syncthreads();
+        MTB_PHASE_MARK(12);
         if (lane == 0) {
             R.n_taxcnt = (uint16_t)ntc;
             to_parent = R.score < sp.min_sp_score;
@@ -367,7 +410,7 @@ __device__ __forceinline__ void score_read_par(const REC *__restrict__ src, int3
         }
     }
     __syncthreads();
-    MTB_PHASE_MARK(3);
+    MTB_PHASE_MARK(13);
 }
 
 /* SORT = true: segments arrive grouped by read but unordered (fused path): the

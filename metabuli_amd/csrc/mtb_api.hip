@@ -1046,9 +1046,9 @@ mtb_status mtb_part_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, mtb_ma
 /* profiling build only: read and reset the k_score phase cycle counters */
 mtb_status mtb_debug_phase_cycles(mtb_ctx *c, unsigned long long *out4) {
     HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipMemcpyFromSymbol(out4, HIP_SYMBOL(mtb_phase_cycles), 32));
-    unsigned long long z[4] = {0, 0, 0, 0};
-    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(mtb_phase_cycles), z, 32));
+    HIPCHK(hipMemcpyFromSymbol(out4, HIP_SYMBOL(mtb_phase_cycles), 8 * MTB_NPHASE));      /* out4: MTB_NPHASE (16) counters */
+    unsigned long long z[MTB_NPHASE] = {0};
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(mtb_phase_cycles), z, 8 * MTB_NPHASE));
     return MTB_OK;
 }
 #endif

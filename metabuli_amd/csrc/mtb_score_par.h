@@ -239,6 +239,77 @@ MTB_HD float mtb_ph_combine(const mtb_sws<IDX> &w, IDX *el, int32_t lo, int32_t 
     }
     return score / (float)read_len;
 }
+/* ---- combine in parallel pieces ------------------------------------------------------------------------
+ * The insertion sort + greedy pass above is serial per species.  The same result comes from
+ *   comb_lo     emitted entry e -> start `lo` of its species' range in the emitted list (binary search in sp_start)
+ *   comb_rank   position of e in the stable (score desc, hamming asc, start desc) order of its species:
+ *               lo + #{f in [lo,hi): f strictly before e, or equivalent with f < e}  (== stable insertion sort)
+ *   comb_predrop  sorted entry k > lo is dropped by the greedy pass for certain when it overlaps the species'
+ *               first path -- accepted first and untrimmed -- by its whole length or by >= 24 (that is the first
+ *               test the greedy loop makes for it, Taxonomer.cpp:436-448)
+ *   comb_greedy the greedy pass over the sorted list, skipping the pre-dropped entries (serial per species;
+ *               for a typical read nothing but the best path survives the pre-drop)                          */
+template <typename IDX>
+MTB_HD int32_t mtb_ph_comb_species(const mtb_sws<IDX> &w, int32_t n_species, int32_t i) {     /* species index of match i */
+    int32_t lo = 0, hi = n_species;            /* last s with sp_start[s] <= i */
+    while (hi - lo > 1) { int32_t mid = (lo + hi) >> 1; if ((int32_t)w.sp_start[mid] <= i) lo = mid; else hi = mid; }
+    return lo;
+}
+template <typename IDX>
+MTB_HD int32_t mtb_ph_comb_rank(const mtb_sws<IDX> &w, const IDX *el, int32_t e, int32_t lo, int32_t hi) {
+    const mtb_path *path = w.path;
+    const mtb_path px = path[el[e]];
+    int32_t r = lo;
+    for (int32_t f = lo; f < hi; f++) {
+        if (f == e) continue;
+        const mtb_path pf = path[el[f]];
+        if (mtb_path_before(pf, px) || (f < e && !mtb_path_before(px, pf))) r++;
+    }
+    return r;
+}
+template <typename IDX>
+MTB_HD bool mtb_ph_comb_predrop(const mtb_sws<IDX> &w, const IDX *sorted, int32_t k, int32_t lo) {
+    if (k == lo) return false;
+    const mtb_path c = w.path[sorted[lo]], p = w.path[sorted[k]];
+    if ((p.end < c.start) || (c.end < p.start)) return false;
+    int32_t ov = (p.end < c.end ? p.end : c.end) - (p.start > c.start ? p.start : c.start) + 1;
+    return ov == p.end - p.start + 1 || ov >= 24;
+}
+template <typename IDX>
+MTB_HD float mtb_ph_comb_greedy(const mtb_sws<IDX> &w, const IDX *sorted, const uint8_t *predrop, int32_t lo, int32_t hi, int32_t read_len) {
+    const mtb_match *m = w.m; mtb_path *path = w.path; IDX *acc = w.acc;
+    float score = 0.0f;
+    int32_t na = 0;
+    for (int32_t k = lo; k < hi; k++) {
+        if (predrop[k]) continue;
+        int32_t pi = sorted[k];
+        mtb_path p = path[pi];
+        bool drop = false;
+        for (int32_t a = 0; a < na && !drop; a++) {
+            mtb_path c = path[acc[lo + a]];
+            if (!((p.end < c.start) || (c.end < p.start))) {
+                int32_t ov = (p.end < c.end ? p.end : c.end) - (p.start > c.start ? p.start : c.start) + 1;
+                if (ov == p.end - p.start + 1) { drop = true; break; }
+                if (ov < 24) {
+                    if (p.start < c.start) {
+                        p.end = c.start - 1;
+                        int32_t h = p.ham - mtb_part_ham(m[pi].right_end_hamming, ov / 3, false);
+                        p.ham = h > 0 ? h : 0;
+                        p.score = p.score - mtb_part_score(m[pi].right_end_hamming, ov / 3, false) - (float)(ov % 3);
+                    } else {
+                        p.start = c.end + 1;
+                        int32_t h = p.ham - mtb_part_ham(m[p.start_idx].right_end_hamming, ov / 3, true);
+                        p.ham = h > 0 ? h : 0;
+                        p.score = p.score - mtb_part_score(m[p.start_idx].right_end_hamming, ov / 3, true) - (float)(ov % 3);
+                    }
+                } else drop = true;
+            }
+        }
+        if (!drop) { path[pi] = p; acc[lo + na++] = (IDX)pi; score += p.score; }
+    }
+    return score / (float)read_len;
+}
+
 /* ---- select over the species list (Taxonomer.cpp:354-407, 130-165) ---- */
 template <typename IDX>
 MTB_HD bool mtb_ph_select(const mtb_sws<IDX> &w, const float *sps, int32_t n_species, const mtb_tax_view *tx,

@@ -19,10 +19,13 @@ N = 500000
 db, do = bench.gen_reads(torch, dev, world, N, 150, 0.10, 0.005, 99)
 dres = torch.empty(N * 24, dtype=torch.uint8, device=dev); cap = N * 20 + 1024
 dtt = torch.empty(cap, dtype=torch.int32, device=dev); dtc = torch.empty(cap, dtype=torch.int32, device=dev)
-out = (C.c_ulonglong * 4)()
+out = (C.c_ulonglong * 16)()
 for it in range(2):
     ctx.classify_batch_device(ix, params, db.data_ptr(), do.data_ptr(), 0, 0, N, N * 150, dres.data_ptr(), dtt.data_ptr(), dtc.data_ptr(), cap)
     M.lib().mtb_debug_phase_cycles(ctx.h, out)
 st = ctx.last_stats()
 tot = sum(out)
-print("score ms", st.ms_score, "phase cycles/read [stage+sort, paths, combine, decide]:", [int(x / N) for x in out], "total/read", int(tot / N))
+names = ["load+keys", "rank", "permute", "flags+ids", "starts", "links", "chainDP", "emit", "combine", "select", "filter", "gather", "climb", "decide+out"]
+print("score ms", st.ms_score, "total cycles/read", int(tot / N))
+for k, nm in enumerate(names):
+    print(f"  {nm:12s} {int(out[k] / N):7d} cycles/read  {100.0 * out[k] / tot:5.1f} %")

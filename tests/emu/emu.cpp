@@ -200,11 +200,22 @@ size_t emu_score_par(const uint8_t *acc_leaf, const int32_t *canon, const int32_
         }
         float *sps = (float *)w.grp_start;
         {
+            // combine in the kernel's parallel pieces: rank -> sorted list (bid), range start (sid), pre-drop flags (shift), greedy
+            IDX *sorted = w.bid, *elo = w.sid; uint8_t *predrop = w.shift;
+            std::vector<int32_t> pos((size_t)ne);
+            for (int32_t e = 0; e < ne; e++) {
+                int32_t s = mtb_ph_comb_species(w, nsp, (int32_t)elist[e]);
+                int32_t lo = ec[w.sp_start[s]], hi = (s + 1 < nsp) ? (int32_t)ec[w.sp_start[s + 1]] : ne;
+                pos[(size_t)e] = mtb_ph_comb_rank(w, elist, e, lo, hi);
+                elo[e] = (IDX)lo;
+            }
+            for (int32_t e = 0; e < ne; e++) sorted[pos[(size_t)e]] = elist[e];
+            for (int32_t k = 0; k < ne; k++) predrop[k] = mtb_ph_comb_predrop(w, sorted, k, (int32_t)elo[k]) ? 1 : 0;
             std::vector<float> tmp((size_t)nsp);
             for (int32_t s = 0; s < nsp; s++) {
                 int32_t lo = ec[w.sp_start[s]], hi = (s + 1 < nsp) ? (int32_t)ec[w.sp_start[s + 1]] : ne;
                 float sc = -1.0f;
-                if (hi > lo) { sc = mtb_ph_combine(w, elist, lo, hi, read_len); sc = sc < 1.0f ? sc : 1.0f; }
+                if (hi > lo) { sc = mtb_ph_comb_greedy(w, sorted, predrop, lo, hi, read_len); sc = sc < 1.0f ? sc : 1.0f; }
                 tmp[(size_t)s] = sc;
             }
             for (int32_t s = 0; s < nsp; s++) sps[s] = tmp[(size_t)s];
