@@ -38,4 +38,19 @@ __device__ __forceinline__ T block256_exclusive_scan(T v, T *s_tmp, T *total) {
     return pre + inc - v;
 }
 
+/* same for a workgroup of NW wavefronts; s_tmp: >= NW elements of LDS */
+template <typename T, int NW>
+__device__ __forceinline__ T block_exclusive_scan(T v, T *s_tmp, T *total) {
+    T inc = wave_inclusive_scan(v);
+    uint32_t w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane_id() == 63) s_tmp[w] = inc;
+    __syncthreads();
+    T pre = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < NW; k++) { T t = s_tmp[k]; if ((int)w > k) pre += t; tot += t; }
+    *total = tot;
+    return pre + inc - v;
+}
+
 #endif

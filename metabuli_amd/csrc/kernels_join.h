@@ -42,13 +42,14 @@ __device__ __forceinline__ void rec_set(mtb_match32 &r, const mtb_match &m) { r.
  * all tiles in parallel: the 33 dependent loads of a search are paid once per
  * tile here instead of serialising every workgroup of k_join.               */
 __global__ __launch_bounds__(256) void k_join_bounds(const mtb_kmer *__restrict__ q, uint64_t n, const uint64_t *__restrict__ values,
-                                                      uint64_t limit, uint64_t n_tiles, uint64_t *__restrict__ bounds) {
+                                                      uint64_t limit, uint64_t n_tiles, uint64_t *__restrict__ bounds, int low_bits) {
     uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= n_tiles) return;
     uint64_t base = t * MTB_JOIN_QPB;
     uint64_t last = (base + MTB_JOIN_QPB <= n ? base + MTB_JOIN_QPB : n) - 1;
-    uint64_t ka = q[base].value & ~0xFFFFFFFFull;
-    uint64_t kb = q[last].value | 0xFFFFFFFFull;
+    const uint64_t low = (1ull << low_bits) - 1;       /* the query list is ordered on bits [low_bits, 64) at least */
+    uint64_t ka = q[base].value & ~low;
+    uint64_t kb = q[last].value | low;
     uint64_t lo = mtb_lower_bound(values, limit, ka);
     uint64_t hi = (kb == ~0ull) ? limit : mtb_lower_bound(values, limit, kb + 1);
     bounds[2 * t] = lo; bounds[2 * t + 1] = hi;

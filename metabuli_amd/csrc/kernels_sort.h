@@ -18,84 +18,109 @@
 #define MTB_SORT_TILE 2048
 #define MTB_SORT_ITEMS 8
 
-__global__ __launch_bounds__(256) void k_radix_hist(const mtb_kmer *__restrict__ in, uint64_t n, int shift,
-                                                     uint32_t *__restrict__ hist, uint32_t num_tiles) {
-    __shared__ uint32_t s_h[256];
-    s_h[threadIdx.x] = 0;
-    __syncthreads();
-    uint64_t base = (uint64_t)blockIdx.x * MTB_SORT_TILE;
-#pragma unroll
-    for (int r = 0; r < MTB_SORT_ITEMS; r++) {
-        uint64_t i = base + (uint64_t)r * 256 + threadIdx.x;
-        if (i < n) atomicAdd(&s_h[(uint32_t)(in[i].value >> shift) & 255u], 1u);
-    }
-    __syncthreads();
-    hist[(uint64_t)threadIdx.x * num_tiles + blockIdx.x] = s_h[threadIdx.x];
+/* Digit of one pass.  MODE 0: 8 binary bits at `shift` (256 bins).  MODE 1 (kmer_format 2 only): the two 5-bit
+ * amino-acid letters at `shift` as one base-21 digit, letter codes are 0..20 -> 441 of 512 bins; three such passes
+ * (shift 34, 44, 54) order the metamers by their first six amino acids = bits [34,64), where four binary passes
+ * order bits [32,64): the join only needs tiles with a narrow amino-acid range, and a six-letter prefix already
+ * resolves ~94 targets of an 8 G index.                                                                          */
+template <int MODE>
+__device__ __forceinline__ uint32_t radix_digit(uint64_t v, int shift) {
+    if (MODE == 0) return (uint32_t)(v >> shift) & 255u;
+    uint32_t two = (uint32_t)(v >> shift) & 1023u;
+    uint32_t d = (two >> 5) * 21u + (two & 31u);
+    return d < 511u ? d : 511u;                 /* letters > 20 never leave the extractor; keep the index in range anyway */
 }
 
-__global__ __launch_bounds__(256) void k_radix_scatter(const mtb_kmer *__restrict__ in, mtb_kmer *__restrict__ out,
-                                                        uint64_t n, int shift, const uint32_t *__restrict__ tile_off,
-                                                        uint32_t num_tiles) {
-    __shared__ uint32_t s_cnt[4][256];
-    __shared__ uint32_t s_run[256];
-    __shared__ uint32_t s_start[256];
-    __shared__ uint32_t s_tmp[8];
-    __shared__ mtb_kmer s_buf[MTB_SORT_TILE];
+/* THREADS x MTB_SORT_ITEMS elements per tile: a digit's run inside a tile should be about a 128-byte line
+ * (8 records) long, so 256 bins go with 2048-element tiles and 512 bins with 4096-element tiles (measured:
+ * 512 bins on 2048-element tiles made a pass 40 % slower -- 4.6-record runs). */
+template <int NB, int MODE, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_radix_hist(const mtb_kmer *__restrict__ in, uint64_t n, int shift,
+                                                         uint32_t *__restrict__ hist, uint32_t num_tiles) {
+    __shared__ uint32_t s_h[NB];
+    for (int b = threadIdx.x; b < NB; b += THREADS) s_h[b] = 0;
+    __syncthreads();
+    uint64_t base = (uint64_t)blockIdx.x * (THREADS * MTB_SORT_ITEMS);
+#pragma unroll
+    for (int r = 0; r < MTB_SORT_ITEMS; r++) {
+        uint64_t i = base + (uint64_t)r * THREADS + threadIdx.x;
+        if (i < n) atomicAdd(&s_h[radix_digit<MODE>(in[i].value, shift)], 1u);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < NB; b += THREADS) hist[(uint64_t)b * num_tiles + blockIdx.x] = s_h[b];
+}
+
+template <int NB, int MODE, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_radix_scatter(const mtb_kmer *__restrict__ in, mtb_kmer *__restrict__ out,
+                                                            uint64_t n, int shift, const uint32_t *__restrict__ tile_off,
+                                                            uint32_t num_tiles) {
+    constexpr int BITS = NB == 256 ? 8 : 9;
+    constexpr int NW = THREADS / 64;
+    constexpr int TILE = THREADS * MTB_SORT_ITEMS;
+    static_assert(NB == THREADS, "one bin per thread");
+    __shared__ uint16_t s_cnt[NW][NB];
+    __shared__ uint16_t s_run[NB];
+    __shared__ uint16_t s_start[NB];
+    __shared__ uint32_t s_tmp[NW];
+    __shared__ mtb_kmer s_buf[TILE];
     const uint32_t t = threadIdx.x, w = t >> 6;
-    const uint64_t base = (uint64_t)blockIdx.x * MTB_SORT_TILE;
+    const uint64_t base = (uint64_t)blockIdx.x * TILE;
     mtb_kmer e[MTB_SORT_ITEMS];
     uint32_t lrank[MTB_SORT_ITEMS];
     s_run[t] = 0;
 #pragma unroll
     for (int r = 0; r < MTB_SORT_ITEMS; r++) {
-        uint64_t i = base + (uint64_t)r * 256 + t;
+        uint64_t i = base + (uint64_t)r * THREADS + t;
         bool valid = i < n;
         if (valid) e[r] = in[i]; else { e[r].value = 0; e[r].qinfo = 0; }
-        uint32_t d = (uint32_t)(e[r].value >> shift) & 255u;
-        s_cnt[0][t] = 0; s_cnt[1][t] = 0; s_cnt[2][t] = 0; s_cnt[3][t] = 0;
+        uint32_t d = radix_digit<MODE>(e[r].value, shift);
+#pragma unroll
+        for (int k = 0; k < NW; k++) s_cnt[k][t] = 0;
         __syncthreads();
         /* lanes of this wave holding the same digit */
         uint64_t peers = __ballot(valid);
 #pragma unroll
-        for (int b = 0; b < 8; b++) {
+        for (int b = 0; b < BITS; b++) {
             bool bit = (d >> b) & 1u;
             uint64_t vote = __ballot(bit);
             peers &= bit ? vote : ~vote;
         }
         uint32_t rank_in_wave = (uint32_t)__popcll(peers & lanemask_lt());
-        if (valid && rank_in_wave == 0) s_cnt[w][d] = (uint32_t)__popcll(peers);
+        if (valid && rank_in_wave == 0) s_cnt[w][d] = (uint16_t)__popcll(peers);
         __syncthreads();
         uint32_t pre = s_run[d];
-        if (w > 0) pre += s_cnt[0][d];
-        if (w > 1) pre += s_cnt[1][d];
-        if (w > 2) pre += s_cnt[2][d];
+#pragma unroll
+        for (int k = 0; k < NW - 1; k++) if ((int)w > k) pre += s_cnt[k][d];
         lrank[r] = pre + rank_in_wave;
         __syncthreads();
-        s_run[t] += s_cnt[0][t] + s_cnt[1][t] + s_cnt[2][t] + s_cnt[3][t];
+        uint32_t add = 0;
+#pragma unroll
+        for (int k = 0; k < NW; k++) add += s_cnt[k][t];
+        s_run[t] = (uint16_t)(s_run[t] + add);
     }
     __syncthreads();
     uint32_t tot;
-    uint32_t ex = block256_exclusive_scan<uint32_t>(s_run[t], s_tmp, &tot);
-    s_start[t] = ex;
+    uint32_t ex = block_exclusive_scan<uint32_t, NW>((uint32_t)s_run[t], s_tmp, &tot);
+    s_start[t] = (uint16_t)ex;
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < MTB_SORT_ITEMS; r++) {
-        uint64_t i = base + (uint64_t)r * 256 + t;
+        uint64_t i = base + (uint64_t)r * THREADS + t;
         if (i < n) {
-            uint32_t d = (uint32_t)(e[r].value >> shift) & 255u;
+            uint32_t d = radix_digit<MODE>(e[r].value, shift);
             s_buf[s_start[d] + lrank[r]] = e[r];
         }
     }
     __syncthreads();
-    uint32_t cnt = (uint32_t)((n - base) < MTB_SORT_TILE ? (n - base) : MTB_SORT_TILE);
-    for (uint32_t i = t; i < cnt; i += 256) {
+    uint32_t cnt = (uint32_t)((n - base) < TILE ? (n - base) : TILE);
+    for (uint32_t i = t; i < cnt; i += THREADS) {
         mtb_kmer x = s_buf[i];
-        uint32_t d = (uint32_t)(x.value >> shift) & 255u;
+        uint32_t d = radix_digit<MODE>(x.value, shift);
         out[(uint64_t)tile_off[(uint64_t)d * num_tiles + blockIdx.x] + (i - s_start[d])] = x;
     }
 }
 
-static inline uint64_t radix_hist_elems(uint64_t n) { return 256ull * ((n + MTB_SORT_TILE - 1) / MTB_SORT_TILE); }
+static inline uint64_t radix_hist_elems(uint64_t n, uint32_t bins = 256) { uint64_t tile = (uint64_t)bins * MTB_SORT_ITEMS; return (uint64_t)bins * ((n + tile - 1) / tile); }
 
 /* Sort on bits [first_bit, 64).  a = input, b = scratch (same size); returns
  * the buffer that holds the result.  hist: radix_hist_elems(n) u32; ws:
@@ -106,9 +131,9 @@ static mtb_kmer *radix_sort_kmers(hipStream_t st, mtb_kmer *a, mtb_kmer *b, uint
     uint32_t tiles = (uint32_t)((n + MTB_SORT_TILE - 1) / MTB_SORT_TILE);
     mtb_kmer *src = a, *dst = b;
     for (int shift = first_bit; shift < 64; shift += 8) {
-        hipLaunchKernelGGL(k_radix_hist, dim3(tiles), dim3(256), 0, st, src, n, shift, hist, tiles);
+        hipLaunchKernelGGL((k_radix_hist<256, 0, 256>), dim3(tiles), dim3(256), 0, st, src, n, shift, hist, tiles);
         scan_launch<uint32_t, uint32_t, false>(st, hist, 256ull * tiles, false, hist, ws);
-        hipLaunchKernelGGL(k_radix_scatter, dim3(tiles), dim3(256), 0, st, src, dst, n, shift, hist, tiles);
+        hipLaunchKernelGGL((k_radix_scatter<256, 0, 256>), dim3(tiles), dim3(256), 0, st, src, dst, n, shift, hist, tiles);
         mtb_kmer *tmp = src; src = dst; dst = tmp;
     }
     return src;

@@ -233,20 +233,30 @@ static mtb_status dev_extract(mtb_ctx *c, const mtb_params *p, const char *d_bas
     return MTB_OK;
 }
 
+/* first_bit >= 0: binary LSD passes over bits [first_bit, 64).  first_bit == MTB_SORT_AA6 (kmer_format 2): three
+ * passes on amino-acid letter pairs = order by bits [34, 64) (kernels_sort.h). */
+#define MTB_SORT_AA6 (-6)
 static mtb_status dev_sort(mtb_ctx *c, mtb_kmer *d_a, uint64_t n, int first_bit, mtb_kmer **sorted) {
     *sorted = d_a;
     if (n == 0) return MTB_OK;
+    const bool aa = first_bit == MTB_SORT_AA6;
+    const uint32_t bins = aa ? 512u : 256u;
     mtb_kmer *d_b; uint32_t *d_hist; uint64_t *d_ws;
     STCHK(ensure(c, "kmersB", n, &d_b));
-    STCHK(ensure(c, "hist", radix_hist_elems(n), &d_hist));
-    STCHK(ensure(c, "scanws", scan_ws_elems(radix_hist_elems(n)), &d_ws));
+    STCHK(ensure(c, "hist", radix_hist_elems(n, bins), &d_hist));
+    STCHK(ensure(c, "scanws", scan_ws_elems(radix_hist_elems(n, bins)), &d_ws));
     {
-        uint32_t tiles = (uint32_t)((n + MTB_SORT_TILE - 1) / MTB_SORT_TILE);
+        const uint64_t tile = (uint64_t)bins * MTB_SORT_ITEMS;        /* one bin per thread, 8 records per thread */
+        uint32_t tiles = (uint32_t)((n + tile - 1) / tile);
         mtb_kmer *src = d_a, *dst = d_b;
-        for (int shift = first_bit; shift < 64; shift += 8) {
-            { KTimer kt(c, MTB_K_RADIX_HIST); hipLaunchKernelGGL(k_radix_hist, dim3(tiles), dim3(256), 0, c->stream, (const mtb_kmer *)src, n, shift, d_hist, tiles); }
-            { KTimer kt(c, MTB_K_SCAN); scan_launch<uint32_t, uint32_t, false>(c->stream, d_hist, 256ull * tiles, false, d_hist, (uint32_t *)d_ws); }
-            { KTimer kt(c, MTB_K_RADIX_SCATTER); hipLaunchKernelGGL(k_radix_scatter, dim3(tiles), dim3(256), 0, c->stream, (const mtb_kmer *)src, dst, n, shift, (const uint32_t *)d_hist, tiles); }
+        for (int shift = aa ? 34 : first_bit; shift < 64; shift += aa ? 10 : 8) {
+            { KTimer kt(c, MTB_K_RADIX_HIST);
+              if (aa) hipLaunchKernelGGL((k_radix_hist<512, 1, 512>), dim3(tiles), dim3(512), 0, c->stream, (const mtb_kmer *)src, n, shift, d_hist, tiles);
+              else hipLaunchKernelGGL((k_radix_hist<256, 0, 256>), dim3(tiles), dim3(256), 0, c->stream, (const mtb_kmer *)src, n, shift, d_hist, tiles); }
+            { KTimer kt(c, MTB_K_SCAN); scan_launch<uint32_t, uint32_t, false>(c->stream, d_hist, (uint64_t)bins * tiles, false, d_hist, (uint32_t *)d_ws); }
+            { KTimer kt(c, MTB_K_RADIX_SCATTER);
+              if (aa) hipLaunchKernelGGL((k_radix_scatter<512, 1, 512>), dim3(tiles), dim3(512), 0, c->stream, (const mtb_kmer *)src, dst, n, shift, (const uint32_t *)d_hist, tiles);
+              else hipLaunchKernelGGL((k_radix_scatter<256, 0, 256>), dim3(tiles), dim3(256), 0, c->stream, (const mtb_kmer *)src, dst, n, shift, (const uint32_t *)d_hist, tiles); }
             mtb_kmer *tmp = src; src = dst; dst = tmp;
         }
         *sorted = src;
@@ -272,7 +282,7 @@ static mtb_tax_view tax_view(const mtb_index *ix) {
  * With `seg` (fixed-capacity per-read segments) matches go to seg->seg and the overflow list instead; *count is then
  * the number of overflow entries needed and MTB_ERR_CAPACITY refers to the overflow list.                     */
 static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint64_t n, mtb_match *d_out, uint64_t cap,
-                           uint32_t *d_read_cnt, uint64_t *count, const JoinSegArgs *seg = nullptr) {
+                           uint32_t *d_read_cnt, uint64_t *count, const JoinSegArgs *seg = nullptr, int sort_low_bits = 32) {
     *count = 0;
     if (n == 0) return MTB_OK;
     HIPCHK(hipMemsetAsync(c->d_scal, 0, 16, c->stream));
@@ -282,7 +292,7 @@ static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint6
     uint64_t limit = ix->T ? ix->T - (ix->match_last ? 0 : 1) : 0;          /* the last entry of the (whole) index is never a candidate */
     { KTimer kt(c, MTB_K_JOIN);
     hipLaunchKernelGGL(k_join_bounds, dim3((grid + 255) / 256), dim3(256), 0, c->stream, d_q, n, (const uint64_t *)ix->d_values, limit,
-                       (uint64_t)grid, d_bounds);
+                       (uint64_t)grid, d_bounds, sort_low_bits);
     if (seg) {
         JoinSegArgs sa = *seg; sa.ovf_counter = (unsigned long long *)c->d_scal;
         hipLaunchKernelGGL((k_join<true>), dim3(grid), dim3(256), 0, c->stream, d_q, n, index_view(ix), (const mtb_tables *)c->d_tabs,
@@ -780,11 +790,14 @@ static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, c
     mtb_kmer *d_k; uint64_t nk; uint32_t max_len = 0;
     STCHK(dev_extract(c, p, d_bases, d_offs, d_bases2, d_offs2, n_reads, &d_k, &nk, d_ql, d_ql2, &max_len));
     HIPCHK(hipEventRecord(c->ev[1], st));
-    /* the join needs tiles with a narrow amino-acid range, not a total order: sort the top
-     * 32 bits only (4 passes; 3 passes make the tiles too wide for the LDS window, measured);
-     * the tile bounds come from a block-wide min/max in k_join */
+    /* the join needs tiles with a narrow amino-acid range, not a total order: kmer_format 2 sorts on the first six
+     * amino-acid letters (three base-21 pair passes = bits [34,64)), kmer_format 1 on the top 32 bits (four binary
+     * passes; three binary passes make the tiles too wide for the LDS window, measured); the tile's target window
+     * comes from k_join_bounds */
     mtb_kmer *d_s;
-    STCHK(dev_sort(c, d_k, nk, 32, &d_s));
+    const bool aa6 = p->kmer_format == 2;           /* 5-bit amino-acid letters: three base-21 pair passes order bits [34,64) */
+    const int low_bits = aa6 ? 34 : 32;
+    STCHK(dev_sort(c, d_k, nk, aa6 ? MTB_SORT_AA6 : 32, &d_s));
     HIPCHK(hipEventRecord(c->ev[2], st));
     uint32_t *d_rc;
     STCHK(ensure(c, "readcnt", n_reads, &d_rc));
@@ -801,7 +814,7 @@ static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, c
         for (int attempt = 0; attempt < 3; attempt++) {
             STCHK(ensure(c, "ovf", ovf_cap, &d_ovf));
             JoinSegArgs sa; sa.seg = d_segm; sa.stride = stride; sa.cursor = d_rc; sa.ovf = d_ovf; sa.ovf_cap = ovf_cap; sa.ovf_counter = nullptr;
-            mtb_status s2 = dev_join(c, ix, d_s, nk, nullptr, 0, nullptr, &n_ovf, &sa);
+            mtb_status s2 = dev_join(c, ix, d_s, nk, nullptr, 0, nullptr, &n_ovf, &sa, low_bits);
             if (s2 == MTB_OK) break;
             if (s2 != MTB_ERR_CAPACITY || attempt == 2) return s2;
             ovf_cap = n_ovf + n_ovf / 16 + 1024;
@@ -850,7 +863,7 @@ static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, c
         uint64_t cap = std::max<uint64_t>(jb.cap / sizeof(mtb_match), nk + nk / 2 + 1024);
         for (int attempt = 0; attempt < 3; attempt++) {
             STCHK(ensure(c, "jtemp", cap, &d_tmp));
-            mtb_status s2 = dev_join(c, ix, d_s, nk, d_tmp, cap, d_rc, &nm);
+            mtb_status s2 = dev_join(c, ix, d_s, nk, d_tmp, cap, d_rc, &nm, nullptr, low_bits);
             if (s2 == MTB_OK) break;
             if (s2 != MTB_ERR_CAPACITY || attempt == 2) return s2;
             cap = nm + nm / 16 + 1024;                     /* the reference's retry (Classifier.cpp:127-131) with the exact size */
