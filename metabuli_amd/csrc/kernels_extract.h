@@ -25,11 +25,54 @@ struct ExtractArgs {
     int32_t seq_mode, syncmer, smer_len, kmer_format;
 };
 
-template <bool EMIT>
+/* MODE 0 = count pass, 1 = emit pass (deterministic reference order: the stage API), 2 = single pass for the fused
+ * path: the count pass (the same arithmetic again, 13 of 30 ms) and the offset scan disappear.  The wave collects
+ * metamers in an LDS buffer and copies them into a chunk of `out` it owns; chunks come from one global atomic each
+ * (MTB_EXTRACT_CHUNK metamers, smaller near the end of the wave's reads; a flush per atomic on one address was
+ * 20 ms slower, measured), and the unused tail of a wave's last chunk is filled with blank records (sequenceID 0,
+ * skipped by the join; < 1 % of the list).  The order of the runs in `out` is arbitrary -- the radix sort that
+ * follows does not care.  counter: [0] records allocated, [1] set if out_cap was too small, [2] real metamers.   */
+#define MTB_EXTRACT_BUF 320          /* metamers buffered per wave in MODE 2 (5 KB) */
+#define MTB_EXTRACT_CHUNK 8192
+template <int MODE>
 __global__ __launch_bounds__(64) void k_extract(ExtractArgs a, const mtb_tables *__restrict__ tabs,
                                                 uint32_t *__restrict__ counts, const uint64_t *__restrict__ out_offs,
                                                 mtb_kmer *__restrict__ out, int32_t *__restrict__ qlen,
-                                                int32_t *__restrict__ qlen2, uint32_t *__restrict__ max_len) {
+                                                int32_t *__restrict__ qlen2, uint32_t *__restrict__ max_len,
+                                                unsigned long long *__restrict__ counter, uint64_t out_cap) {
+    constexpr bool EMIT = MODE != 0;
+    constexpr bool STATS = MODE != 1;             /* qlen / max_len are produced by the count pass or the single pass */
+    __shared__ mtb_kmer s_out[MODE == 2 ? MTB_EXTRACT_BUF : 1];
+    __shared__ unsigned long long s_base;
+    uint32_t n_buf = 0;
+    uint64_t chunk_pos = 0, chunk_end = 0, produced = 0, reads_done = 0, cur_read = 0;
+    bool overflow = false;
+    auto flush = [&]() {
+        if (MODE != 2 || n_buf == 0) return;
+        __syncthreads();
+        uint32_t done = 0;
+        while (done < n_buf) {
+            if (chunk_pos == chunk_end) {               /* new chunk: sized to what this wave still expects to produce */
+                const uint64_t need = n_buf - done;
+                const uint64_t rem_reads = (a.n_reads - 1 - cur_read) / gridDim.x + 1;
+                const uint64_t avg = reads_done ? produced / reads_done + 1 : 128;
+                uint64_t size = need + rem_reads * avg * 5 / 4 + 64;
+                size = size < MTB_EXTRACT_CHUNK ? size : MTB_EXTRACT_CHUNK;
+                size = size < need ? need : size;
+                if (threadIdx.x == 0) s_base = atomicAdd(counter, (unsigned long long)size);
+                __syncthreads();
+                chunk_pos = (uint64_t)s_base; chunk_end = chunk_pos + size;
+                __syncthreads();
+                if (chunk_end > out_cap) { overflow = true; chunk_pos = chunk_end; break; }
+            }
+            const uint32_t room = (uint32_t)(chunk_end - chunk_pos < (uint64_t)(n_buf - done) ? chunk_end - chunk_pos : (uint64_t)(n_buf - done));
+            for (uint32_t i = threadIdx.x; i < room; i += 64) out[chunk_pos + i] = s_out[done + i];
+            chunk_pos += room; done += room;
+        }
+        produced += n_buf;
+        __syncthreads();
+        n_buf = 0;
+    };
     __shared__ mtb_tables s_tab;
     __shared__ uint8_t s_cod[80];
     __shared__ uint8_t s_code[MTB_EXTRACT_STAGE];      /* a short read's bases as codes: one global load serves all six frames */
@@ -39,20 +82,21 @@ __global__ __launch_bounds__(64) void k_extract(ExtractArgs a, const mtb_tables 
     uint32_t my_max = 0;
     const bool paired = a.seq_mode == 2;
     for (uint64_t r = blockIdx.x; r < a.n_reads; r += gridDim.x) {
+        cur_read = r; reads_done++;
         const uint64_t o1 = a.offs[r];
         const int32_t len1 = (int32_t)(a.offs[r + 1] - o1);
         uint64_t o2 = 0; int32_t len2 = 0;
         if (paired) { o2 = a.offs2[r]; len2 = (int32_t)(a.offs2[r + 1] - o2); }
         const int32_t ql1 = mtb_used_len(len1), ql2 = paired ? mtb_used_len(len2) : 0;
-        if (!EMIT) {
+        if (STATS) {
             if (lane == 0) { qlen[r] = ql1; qlen2[r] = ql2; }
             uint32_t tot_len = (uint32_t)(ql1 + ql2);
             my_max = tot_len > my_max ? tot_len : my_max;
         }
         /* pair skipped if either mate is too short (KmerExtractor.cpp:443-453) */
         const bool skip = mtb_read_too_short(len1) || (paired && mtb_read_too_short(len2));
-        if (skip) { if (!EMIT && lane == 0) counts[r] = 0; continue; }
-        uint64_t wpos = EMIT ? out_offs[r] : 0;
+        if (skip) { if (MODE == 0 && lane == 0) counts[r] = 0; continue; }
+        uint64_t wpos = MODE == 1 ? out_offs[r] : 0;
         uint32_t total = 0;
         for (int mate = 0; mate < (paired ? 2 : 1); mate++) {
             const char *seq = mate ? a.bases2 + o2 : a.bases + o1;
@@ -88,21 +132,30 @@ __global__ __launch_bounds__(64) void k_extract(ExtractArgs a, const mtb_tables 
                     bool ok = false; uint64_t v = 0;
                     if (w < n_win) ok = old_fmt ? mtb_window_metamer_old(&s_cod[lane], &v) : mtb_window_metamer(&s_cod[lane], a.syncmer, a.smer_len, &v);
                     uint64_t mask = __ballot(ok);
+                    uint32_t c = (uint32_t)__popcll(mask);
+                    if (MODE == 2 && n_buf + c > MTB_EXTRACT_BUF) flush();        /* wave-uniform */
                     if (EMIT && ok) {
                         mtb_kmer k;
                         k.value = v;
                         k.qinfo = mtb_qinfo((uint32_t)(r + 1), (old_fmt ? mtb_window_pos_old(begin, used, w, fwd) : mtb_window_pos(begin, used, w, fwd)) + pos_off, (uint32_t)f);
-                        out[wpos + (uint64_t)__popcll(mask & lanemask_lt())] = k;
+                        if (MODE == 2) s_out[n_buf + (uint32_t)__popcll(mask & lanemask_lt())] = k;
+                        else out[wpos + (uint64_t)__popcll(mask & lanemask_lt())] = k;
                     }
-                    uint32_t c = (uint32_t)__popcll(mask);
+                    if (MODE == 2) n_buf += c;
                     wpos += c; total += c;
                     __syncthreads();
                 }
             }
         }
-        if (!EMIT && lane == 0) counts[r] = total;
+        if (MODE == 0 && lane == 0) counts[r] = total;
     }
-    if (!EMIT && max_len) {
+    flush();
+    if (MODE == 2) {
+        mtb_kmer blank; blank.value = 0; blank.qinfo = 0;
+        if (!overflow) for (uint64_t i = chunk_pos + threadIdx.x; i < chunk_end; i += 64) out[i] = blank;
+        if (threadIdx.x == 0) { if (overflow) counter[1] = 1ull; else atomicAdd(counter + 2, (unsigned long long)produced); }
+    }
+    if (STATS && max_len) {
         for (int d = 32; d > 0; d >>= 1) { uint32_t o = __shfl_down(my_max, d, 64); my_max = o > my_max ? o : my_max; }
         if (lane == 0 && my_max) atomicMax(max_len, my_max);
     }

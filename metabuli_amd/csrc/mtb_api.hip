@@ -39,7 +39,8 @@ struct mtb_ctx {
     mtb_tables *d_tabs = nullptr;
     mtb_tables h_tabs;
     std::map<std::string, DevBuf> bufs;
-    uint64_t *d_scal = nullptr;      /* [0] match counter, [1] overflow, [2] n_large, [3] max_seg, [4] max_len */
+    uint64_t *d_scal = nullptr;      /* [0] match counter, [1] overflow, [2] n_large, [3] max_seg, [4] max_len, [5] n_big */
+    uint64_t *d_xscal = nullptr;     /* = d_scal + 8: single-pass extraction counters */
     hipEvent_t ev[8];
     mtb_batch_stats stats;
     int profiling = 0;
@@ -48,6 +49,7 @@ struct mtb_ctx {
     std::vector<hipEvent_t> ev_pool; /* recycled events                  */
     std::vector<mtb_ctx *> lanes;    /* extra stream contexts (mtb_ctx_set_streams) */
     bool is_lane = false;            /* lanes share the parent's tables  */
+    double extract_yield = 0.0;      /* metamers per base of the previous batch (single-pass extraction buffer sizing) */
     uint64_t part_n_reads = 0; uint32_t part_max_len = 0;   /* batch state between mtb_part_extract and mtb_part_score */
 };
 
@@ -138,7 +140,8 @@ mtb_status mtb_ctx_create(int device, void *stream, mtb_ctx **out) {
     mtb_build_tables(&c->h_tabs);
     HIPCHK(hipMalloc((void **)&c->d_tabs, sizeof(mtb_tables)));
     HIPCHK(hipMemcpy(c->d_tabs, &c->h_tabs, sizeof(mtb_tables), hipMemcpyHostToDevice));
-    HIPCHK(hipMalloc((void **)&c->d_scal, 8 * sizeof(uint64_t)));
+    HIPCHK(hipMalloc((void **)&c->d_scal, 16 * sizeof(uint64_t)));
+    c->d_xscal = c->d_scal + 8;
     for (int i = 0; i < 8; i++) HIPCHK(hipEventCreate(&c->ev[i]));
     memset(&c->stats, 0, sizeof(c->stats));
     *out = c;
@@ -174,7 +177,8 @@ mtb_status mtb_ctx_set_streams(mtb_ctx *c, int n) {
         mtb_ctx *l = new mtb_ctx();
         l->device = c->device; l->is_lane = true; l->d_tabs = c->d_tabs; l->h_tabs = c->h_tabs; l->profiling = c->profiling;
         HIPCHK(hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking));
-        HIPCHK(hipMalloc((void **)&l->d_scal, 8 * sizeof(uint64_t)));
+        HIPCHK(hipMalloc((void **)&l->d_scal, 16 * sizeof(uint64_t)));
+        l->d_xscal = l->d_scal + 8;
         for (int i = 0; i < 8; i++) HIPCHK(hipEventCreate(&l->ev[i]));
         memset(&l->stats, 0, sizeof(l->stats));
         c->lanes.push_back(l);
@@ -199,25 +203,64 @@ static mtb_status h2d(mtb_ctx *c, void *dst, const void *src, size_t bytes) {
     return MTB_OK;
 }
 
-/* extract: counts -> offsets -> emit.  Result in buffer "kmersA". */
+/* extract.  Result in buffer "kmersA".  Two passes (counts -> offsets -> emit) give the reference's emission order
+ * (stage API); `single_pass` (fused path, n_bases = bases of the batch) runs the arithmetic once and lets every
+ * wave reserve its output with an atomic: run order arbitrary, which the radix sort does not mind. */
 static mtb_status dev_extract(mtb_ctx *c, const mtb_params *p, const char *d_bases, const uint64_t *d_offs, const char *d_bases2,
                               const uint64_t *d_offs2, uint64_t n_reads, mtb_kmer **out, uint64_t *count, int32_t *d_qlen,
-                              int32_t *d_qlen2, uint32_t *max_len) {
+                              int32_t *d_qlen2, uint32_t *max_len, bool single_pass = false, uint64_t n_bases = 0,
+                              uint64_t *real_count = nullptr) {
     if (n_reads >= (1ull << 29)) return fail(MTB_ERR_ARG, "more than 2^29-1 reads per batch (sequenceID is 29 bits, Kmer.h:13)");
     if (p->kmer_format != 1 && p->kmer_format != 2) return fail(MTB_ERR_UNSUPPORTED, "only kmer_format 1 and 2 are implemented");
     if (p->syncmer && (p->smer_len < 1 || p->smer_len > 8)) return fail(MTB_ERR_ARG, "smer_len out of range");
     *count = 0; *out = nullptr;
+    if (real_count) *real_count = 0;
     if (n_reads == 0) return MTB_OK;
+    ExtractArgs a{d_bases, d_offs, d_bases2, d_offs2, n_reads, p->seq_mode, p->syncmer, p->smer_len, p->kmer_format};
+    uint32_t grid = (uint32_t)std::min<uint64_t>(n_reads, 256ull * 64);
+    HIPCHK(hipMemsetAsync(c->d_scal + 4, 0, 8, c->stream));
+    if (single_pass) {
+        /* exact number of bases of this read range (the caller's figure may be an estimate) */
+        uint64_t o[2];
+        STCHK(d2h(c, &o[0], d_offs, 8)); STCHK(d2h(c, &o[1], d_offs + n_reads, 8));
+        n_bases = o[1] - o[0];
+        if (p->seq_mode == 2 && d_offs2) { STCHK(d2h(c, &o[0], d_offs2, 8)); STCHK(d2h(c, &o[1], d_offs2 + n_reads, 8)); n_bases += o[1] - o[0]; }
+    }
+    if (single_pass && n_bases) {
+        /* six frames x L/3 windows bound the output by 2 metamers per base; syncmer selection keeps about half of them:
+         * size the buffer from the previous batch's yield and fall back to the bound if that was too optimistic */
+        const uint64_t bound = 2 * n_bases + (uint64_t)grid * MTB_EXTRACT_CHUNK;      /* + at most one partly used chunk per wave */
+        uint64_t cap = c->extract_yield > 0.0 ? std::min<uint64_t>(bound, (uint64_t)((double)n_bases * c->extract_yield * 1.15) + 4096) : bound;
+        cap = std::max<uint64_t>(cap, std::min<uint64_t>(bound, c->bufs["kmersA"].cap / sizeof(mtb_kmer)));
+        for (int attempt = 0; attempt < 2; attempt++) {
+            mtb_kmer *d_k;
+            STCHK(ensure(c, "kmersA", cap, &d_k));
+            HIPCHK(hipMemsetAsync(c->d_xscal, 0, 32, c->stream));
+            { KTimer kt(c, MTB_K_EXTRACT_EMIT);
+            hipLaunchKernelGGL((k_extract<2>), dim3(grid), dim3(64), 0, c->stream, a, c->d_tabs, (uint32_t *)nullptr, (const uint64_t *)nullptr,
+                               d_k, d_qlen, d_qlen2, (uint32_t *)(c->d_scal + 4), (unsigned long long *)c->d_xscal, cap); }
+            HIPCHK(hipGetLastError());
+            uint64_t sc[4];
+            STCHK(d2h(c, sc, c->d_xscal, 32));             /* records allocated (incl. blank tails), overflow, real metamers */
+            if (max_len) { uint64_t ml = 0; STCHK(d2h(c, &ml, c->d_scal + 4, 8)); *max_len = (uint32_t)ml; }
+            if (sc[1] == 0) {
+                if (sc[0] >= (1ull << 32)) return fail(MTB_ERR_ARG, "more than 2^32-1 query metamers in one batch; split the batch");
+                c->extract_yield = (double)sc[0] / (double)n_bases;
+                *out = d_k; *count = sc[0];
+                if (real_count) *real_count = sc[2];
+                return MTB_OK;
+            }
+            if (cap >= bound) return fail(MTB_ERR_DEVICE, "extract: output bound exceeded");
+            cap = bound;
+        }
+    }
     uint32_t *d_cnt; uint64_t *d_koff; uint64_t *d_ws;
     STCHK(ensure(c, "counts", n_reads, &d_cnt));
     STCHK(ensure(c, "koff", n_reads + 1, &d_koff));
     STCHK(ensure(c, "scanws", scan_ws_elems(n_reads + 1), &d_ws));
-    HIPCHK(hipMemsetAsync(c->d_scal + 4, 0, 8, c->stream));
-    ExtractArgs a{d_bases, d_offs, d_bases2, d_offs2, n_reads, p->seq_mode, p->syncmer, p->smer_len, p->kmer_format};
-    uint32_t grid = (uint32_t)std::min<uint64_t>(n_reads, 256ull * 64);
     { KTimer kt(c, MTB_K_EXTRACT_COUNT);
-    hipLaunchKernelGGL((k_extract<false>), dim3(grid), dim3(64), 0, c->stream, a, c->d_tabs, d_cnt, (const uint64_t *)nullptr,
-                       (mtb_kmer *)nullptr, d_qlen, d_qlen2, (uint32_t *)(c->d_scal + 4)); }
+    hipLaunchKernelGGL((k_extract<0>), dim3(grid), dim3(64), 0, c->stream, a, c->d_tabs, d_cnt, (const uint64_t *)nullptr,
+                       (mtb_kmer *)nullptr, d_qlen, d_qlen2, (uint32_t *)(c->d_scal + 4), (unsigned long long *)nullptr, (uint64_t)0); }
     { KTimer kt(c, MTB_K_SCAN); scan_launch<uint32_t, uint64_t, false>(c->stream, d_cnt, n_reads, true, d_koff, d_ws); }
     uint64_t total = 0;
     STCHK(d2h(c, &total, d_koff + n_reads, 8));
@@ -226,10 +269,12 @@ static mtb_status dev_extract(mtb_ctx *c, const mtb_params *p, const char *d_bas
     mtb_kmer *d_k;
     STCHK(ensure(c, "kmersA", total, &d_k));
     if (total) { KTimer kt(c, MTB_K_EXTRACT_EMIT);
-        hipLaunchKernelGGL((k_extract<true>), dim3(grid), dim3(64), 0, c->stream, a, c->d_tabs, (uint32_t *)nullptr,
-                           (const uint64_t *)d_koff, d_k, (int32_t *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr); }
+        hipLaunchKernelGGL((k_extract<1>), dim3(grid), dim3(64), 0, c->stream, a, c->d_tabs, (uint32_t *)nullptr,
+                           (const uint64_t *)d_koff, d_k, (int32_t *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr,
+                           (unsigned long long *)nullptr, (uint64_t)0); }
     HIPCHK(hipGetLastError());
     *out = d_k; *count = total;
+    if (real_count) *real_count = total;
     return MTB_OK;
 }
 
@@ -788,7 +833,8 @@ static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, c
     STCHK(ensure(c, "qlen", n_reads, &d_ql)); STCHK(ensure(c, "qlen2", n_reads, &d_ql2));
     HIPCHK(hipEventRecord(c->ev[0], st));
     mtb_kmer *d_k; uint64_t nk; uint32_t max_len = 0;
-    STCHK(dev_extract(c, p, d_bases, d_offs, d_bases2, d_offs2, n_reads, &d_k, &nk, d_ql, d_ql2, &max_len));
+    uint64_t nk_real = 0;                 /* nk counts the blank tail records of the single-pass extraction too */
+    STCHK(dev_extract(c, p, d_bases, d_offs, d_bases2, d_offs2, n_reads, &d_k, &nk, d_ql, d_ql2, &max_len, true, n_bases_total, &nk_real));
     HIPCHK(hipEventRecord(c->ev[1], st));
     /* the join needs tiles with a narrow amino-acid range, not a total order: kmer_format 2 sorts on the first six
      * amino-acid letters (three base-21 pair passes = bits [34,64)), kmer_format 1 on the top 32 bits (four binary
@@ -883,7 +929,7 @@ static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, c
     HIPCHK(hipEventElapsedTime(&S.ms_score, c->ev[5], c->ev[6]));
     HIPCHK(hipEventElapsedTime(&S.ms_total, c->ev[0], c->ev[6]));
     collect_kernel_times(c);
-    S.n_reads = n_reads; S.n_bases = n_bases_total; S.n_kmers = nk; S.n_matches = nm; S.n_targets = ix->T;
+    S.n_reads = n_reads; S.n_bases = n_bases_total; S.n_kmers = nk_real; S.n_matches = nm; S.n_targets = ix->T;
     return MTB_OK;
 }
 
