@@ -23,6 +23,7 @@ struct ExtractArgs {
     const char *bases2; const uint64_t *offs2;
     uint64_t n_reads;
     int32_t seq_mode, syncmer, smer_len, kmer_format;
+    int32_t tag_ord;      /* MODE 2: bits 16-31 of qinfo's position field carry the metamer's ordinal within its read */
 };
 
 /* MODE 0 = count pass, 1 = emit pass (deterministic reference order: the stage API), 2 = single pass for the fused
@@ -31,7 +32,10 @@ struct ExtractArgs {
  * (MTB_EXTRACT_CHUNK metamers, smaller near the end of the wave's reads; a flush per atomic on one address was
  * 20 ms slower, measured), and the unused tail of a wave's last chunk is filled with blank records (sequenceID 0,
  * skipped by the join; < 1 % of the list).  The order of the runs in `out` is arbitrary -- the radix sort that
- * follows does not care.  counter: [0] records allocated, [1] set if out_cap was too small, [2] real metamers.   */
+ * follows does not care.  counter: [0] records allocated, [1] set if out_cap was too small, [2] real metamers,
+ * [3] largest number of metamers of one read.  With a.tag_ord the position field of qinfo (positions < 2^16) also
+ * carries the ordinal of the metamer within its read (extraction order: mate, frame, window) in bits 16-31: the
+ * join uses it as the slot of the query's first match inside the read's segment.                                  */
 #define MTB_EXTRACT_BUF 320          /* metamers buffered per wave in MODE 2 (5 KB) */
 #define MTB_EXTRACT_CHUNK 8192
 template <int MODE>
@@ -79,7 +83,7 @@ __global__ __launch_bounds__(64) void k_extract(ExtractArgs a, const mtb_tables 
     const uint32_t lane = threadIdx.x;
     for (uint32_t i = lane; i < sizeof(mtb_tables) / 4; i += 64) ((uint32_t *)&s_tab)[i] = ((const uint32_t *)tabs)[i];
     __syncthreads();
-    uint32_t my_max = 0;
+    uint32_t my_max = 0, my_maxq = 0;
     const bool paired = a.seq_mode == 2;
     for (uint64_t r = blockIdx.x; r < a.n_reads; r += gridDim.x) {
         cur_read = r; reads_done++;
@@ -114,7 +118,12 @@ __global__ __launch_bounds__(64) void k_extract(ExtractArgs a, const mtb_tables 
             for (int f = 0; f < 6; f++) {
                 const bool fwd = f < 3;
                 const int32_t begin = mtb_frame_begin(len, f);
-                for (int32_t w0 = 0; w0 < n_win; w0 += 64) {
+                /* tagged single pass: ordinals must rise with the position inside a frame, and the positions of a reverse
+                 * frame fall with the window index -> walk its chunks (and rank inside a chunk) backwards */
+                const bool back = MODE == 2 && a.tag_ord && !fwd;
+                const int32_t n_chunk = (n_win + 63) / 64;
+                for (int32_t cw = 0; cw < n_chunk; cw++) {
+                    const int32_t w0 = (back ? n_chunk - 1 - cw : cw) * 64;
                     int32_t j = w0 + (int32_t)lane;
                     int32_t j2 = w0 + 64 + (int32_t)lane;
                     if (staged) {
@@ -137,7 +146,13 @@ __global__ __launch_bounds__(64) void k_extract(ExtractArgs a, const mtb_tables 
                     if (EMIT && ok) {
                         mtb_kmer k;
                         k.value = v;
-                        k.qinfo = mtb_qinfo((uint32_t)(r + 1), (old_fmt ? mtb_window_pos_old(begin, used, w, fwd) : mtb_window_pos(begin, used, w, fwd)) + pos_off, (uint32_t)f);
+                        uint32_t pf = (old_fmt ? mtb_window_pos_old(begin, used, w, fwd) : mtb_window_pos(begin, used, w, fwd)) + pos_off;
+                        if (MODE == 2 && a.tag_ord) {
+                            const uint32_t below = (uint32_t)__popcll(mask & lanemask_lt());
+                            const uint32_t ord = total + (back ? c - 1 - below : below);
+                            pf |= (ord < 0xFFFFu ? ord : 0xFFFFu) << 16;
+                        }
+                        k.qinfo = mtb_qinfo((uint32_t)(r + 1), pf, (uint32_t)f);
                         if (MODE == 2) s_out[n_buf + (uint32_t)__popcll(mask & lanemask_lt())] = k;
                         else out[wpos + (uint64_t)__popcll(mask & lanemask_lt())] = k;
                     }
@@ -148,12 +163,13 @@ __global__ __launch_bounds__(64) void k_extract(ExtractArgs a, const mtb_tables 
             }
         }
         if (MODE == 0 && lane == 0) counts[r] = total;
+        my_maxq = total > my_maxq ? total : my_maxq;
     }
     flush();
     if (MODE == 2) {
         mtb_kmer blank; blank.value = 0; blank.qinfo = 0;
         if (!overflow) for (uint64_t i = chunk_pos + threadIdx.x; i < chunk_end; i += 64) out[i] = blank;
-        if (threadIdx.x == 0) { if (overflow) counter[1] = 1ull; else atomicAdd(counter + 2, (unsigned long long)produced); }
+        if (threadIdx.x == 0) { if (overflow) counter[1] = 1ull; else atomicAdd(counter + 2, (unsigned long long)produced); atomicMax(counter + 3, (unsigned long long)my_maxq); }
     }
     if (STATS && max_len) {
         for (int d = 32; d > 0; d >>= 1) { uint32_t o = __shfl_down(my_max, d, 64); my_max = o > my_max ? o : my_max; }

@@ -55,14 +55,28 @@ __global__ __launch_bounds__(256) void k_join_bounds(const mtb_kmer *__restrict_
     bounds[2 * t] = lo; bounds[2 * t + 1] = hi;
 }
 
-/* SEG mode (short reads, fused path): every read owns a fixed-capacity segment of `stride` records; the
- * query's matches go straight to seg[read * stride + slot] with slot from ONE returning atomic on the read's
- * cursor -- no temp buffer, no regroup pass, no segment scan.  Matches beyond the capacity are appended to an
- * overflow list and their reads complete on the large-segment path (k_big_*).                          */
+/* SEG mode (short reads, fused path): every read owns a segment of `stride` record slots.  The extractor tagged
+ * every query with its ordinal inside the read (bits 16-31 of qinfo's position field): the first match of query
+ * `ord` goes to slot `ord` (ord < direct) with NO atomic and no count -- most queries of a classifiable read have
+ * exactly one match, and in slot order those matches are already in (frame, position) order, which is the
+ * scorer's order when one species is involved.  Further matches of the query (and queries with ord >= direct) take
+ * slots direct + t of the segment's tail, t from a returning atomic on the read's tail cursor; matches beyond the
+ * tail go to an overflow list and their reads complete on the large-segment path (k_big_*).  A slot is live when
+ * its record's pad byte equals the batch's epoch tag: segments are never cleared between batches.            */
 struct JoinSegArgs {
-    mtb_match *seg; uint32_t stride; uint32_t *cursor;
+    mtb_match *seg; uint32_t stride, direct; uint32_t *cursor;
     mtb_match *ovf; uint64_t ovf_cap; unsigned long long *ovf_counter;
+    uint32_t epoch;
 };
+
+#ifdef MTB_SCORE_PHASE_CYCLES
+__device__ unsigned long long mtb_join_cycles[8];     /* 0 load+window, 1 find, 2 count, 3 reserve (atomics), 4 emit */
+#define MTB_JP_BEGIN() unsigned long long jp_t_ = __builtin_readcyclecounter()
+#define MTB_JP_MARK(k) do { unsigned long long t_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&mtb_join_cycles[k], t_ - jp_t_); jp_t_ = t_; } while (0)
+#else
+#define MTB_JP_BEGIN() do {} while (0)
+#define MTB_JP_MARK(k) do {} while (0)
+#endif
 
 template <bool SEG>
 __global__ __launch_bounds__(256) void k_join(const mtb_kmer *__restrict__ q, uint64_t n, mtb_index_view ix,
@@ -73,6 +87,7 @@ __global__ __launch_bounds__(256) void k_join(const mtb_kmer *__restrict__ q, ui
     __shared__ uint32_t s_tmp[8];
     __shared__ unsigned long long s_base;
     __shared__ uint64_t s_win[MTB_JOIN_WIN];
+    MTB_JP_BEGIN();
     for (uint32_t i = threadIdx.x; i < sizeof(mtb_tables) / 4; i += 256) ((uint32_t *)&s_tab)[i] = ((const uint32_t *)tabs)[i];
     const uint64_t base = (uint64_t)blockIdx.x * MTB_JOIN_QPB;
     mtb_kmer k[MTB_JOIN_QPT];
@@ -89,8 +104,16 @@ __global__ __launch_bounds__(256) void k_join(const mtb_kmer *__restrict__ q, ui
     const bool in_lds = span <= MTB_JOIN_WIN;
     if (in_lds) for (uint64_t i = threadIdx.x; i < span; i += 256) s_win[i] = ix.values[lo + i];      /* coalesced 64-bit loads */
     __syncthreads();
+    MTB_JP_MARK(0);
     uint32_t c[MTB_JOIN_QPT]; uint64_t rs[MTB_JOIN_QPT]; uint32_t rl[MTB_JOIN_QPT];
     uint32_t csum = 0;
+#ifdef MTB_SCORE_PHASE_CYCLES
+    for (int u = 0; u < MTB_JOIN_QPT; u++) {
+        rs[u] = 0; rl[u] = 0;
+        if (valid[u]) { if (in_lds) mtb_join_find(s_win, span, k[u].value, &rs[u], &rl[u]); else mtb_join_find(ix.values + lo, span, k[u].value, &rs[u], &rl[u]); }
+    }
+    MTB_JP_MARK(1);
+#endif
 #pragma unroll
     for (int u = 0; u < MTB_JOIN_QPT; u++) {
         c[u] = 0; rs[u] = 0; rl[u] = 0;
@@ -107,31 +130,53 @@ __global__ __launch_bounds__(256) void k_join(const mtb_kmer *__restrict__ q, ui
         }
         csum += c[u];
     }
+    MTB_JP_MARK(2);
     if (SEG) {
+        /* the (rare) returning atomics of the thread first, then the stores */
+        const uint32_t tail_cap = sa.stride - sa.direct;
+        uint32_t slot[MTB_JOIN_QPT];
+#pragma unroll
+        for (int u = 0; u < MTB_JOIN_QPT; u++) {
+            const uint32_t ord = mtb_q_pos(k[u].qinfo) >> 16;
+            const uint32_t ntail = c[u] - ((c[u] && ord < sa.direct) ? 1u : 0u);
+            slot[u] = ntail ? atomicAdd(&sa.cursor[mtb_q_seq(k[u].qinfo) - 1], ntail) : 0u;
+        }
 #pragma unroll
         for (int u = 0; u < MTB_JOIN_QPT; u++) {
             if (c[u] == 0) continue;
             const uint32_t r = mtb_q_seq(k[u].qinfo) - 1;
-            const uint32_t s = atomicAdd(&sa.cursor[r], c[u]);
-            const uint32_t fit = s < sa.stride ? (c[u] < sa.stride - s ? c[u] : sa.stride - s) : 0u;
-            mtb_match *dst = sa.seg + (uint64_t)r * sa.stride + s;
-            if (fit) {
-                if (in_lds) mtb_join_select(&s_tab, s_win, rs[u], rl[u], k[u].value, k[u].qinfo, ix.info, lo, ix.tax2species, ix.max_taxid,
-                                            ix.info_mask, ix.kmer_format, dst, fit, 0);
-                else mtb_join_select(&s_tab, ix.values + lo, rs[u], rl[u], k[u].value, k[u].qinfo, ix.info, lo, ix.tax2species, ix.max_taxid,
-                                     ix.info_mask, ix.kmer_format, dst, fit, 0);
+            const uint32_t ord = mtb_q_pos(k[u].qinfo) >> 16;
+            const uint64_t qinfo = k[u].qinfo & ~0xFFFF0000ull;          /* the record carries the reference's qinfo */
+            const uint32_t first = ord < sa.direct ? 1u : 0u;
+            mtb_match *seg = sa.seg + (uint64_t)r * sa.stride;
+            if (first) {
+                if (in_lds) mtb_join_select(&s_tab, s_win, rs[u], rl[u], k[u].value, qinfo, ix.info, lo, ix.tax2species, ix.max_taxid, ix.info_mask,
+                                            ix.kmer_format, seg + ord, 1, 0, (uint8_t)sa.epoch);
+                else mtb_join_select(&s_tab, ix.values + lo, rs[u], rl[u], k[u].value, qinfo, ix.info, lo, ix.tax2species, ix.max_taxid, ix.info_mask,
+                                     ix.kmer_format, seg + ord, 1, 0, (uint8_t)sa.epoch);
             }
-            const uint32_t n_ovf = c[u] - fit;
+            const uint32_t ntail = c[u] - first;
+            if (ntail == 0) continue;
+            const uint32_t s = slot[u];
+            const uint32_t fit = s < tail_cap ? (ntail < tail_cap - s ? ntail : tail_cap - s) : 0u;
+            if (fit) {
+                if (in_lds) mtb_join_select(&s_tab, s_win, rs[u], rl[u], k[u].value, qinfo, ix.info, lo, ix.tax2species, ix.max_taxid, ix.info_mask,
+                                            ix.kmer_format, seg + sa.direct + s, fit, first, (uint8_t)sa.epoch);
+                else mtb_join_select(&s_tab, ix.values + lo, rs[u], rl[u], k[u].value, qinfo, ix.info, lo, ix.tax2species, ix.max_taxid, ix.info_mask,
+                                     ix.kmer_format, seg + sa.direct + s, fit, first, (uint8_t)sa.epoch);
+            }
+            const uint32_t n_ovf = ntail - fit;
             if (n_ovf) {
                 const unsigned long long o = atomicAdd(sa.ovf_counter, (unsigned long long)n_ovf);
                 if (o + n_ovf <= sa.ovf_cap) {
-                    if (in_lds) mtb_join_select(&s_tab, s_win, rs[u], rl[u], k[u].value, k[u].qinfo, ix.info, lo, ix.tax2species, ix.max_taxid,
-                                                ix.info_mask, ix.kmer_format, sa.ovf + o, n_ovf, fit);
-                    else mtb_join_select(&s_tab, ix.values + lo, rs[u], rl[u], k[u].value, k[u].qinfo, ix.info, lo, ix.tax2species, ix.max_taxid,
-                                         ix.info_mask, ix.kmer_format, sa.ovf + o, n_ovf, fit);
+                    if (in_lds) mtb_join_select(&s_tab, s_win, rs[u], rl[u], k[u].value, qinfo, ix.info, lo, ix.tax2species, ix.max_taxid, ix.info_mask,
+                                                ix.kmer_format, sa.ovf + o, n_ovf, first + fit);
+                    else mtb_join_select(&s_tab, ix.values + lo, rs[u], rl[u], k[u].value, qinfo, ix.info, lo, ix.tax2species, ix.max_taxid, ix.info_mask,
+                                         ix.kmer_format, sa.ovf + o, n_ovf, first + fit);
                 } else *overflow = 1;
             }
         }
+        MTB_JP_MARK(4);
         return;
     }
     uint32_t tot;
@@ -155,27 +200,52 @@ __global__ __launch_bounds__(256) void k_join(const mtb_kmer *__restrict__ q, ui
     }
 }
 
-/* ---- completion of the reads that overflowed their fixed segment ---- */
-__global__ __launch_bounds__(256) void k_big_list(const uint32_t *__restrict__ cursor, uint64_t n_reads, uint32_t stride,
-                                                   uint32_t *__restrict__ big_list, uint32_t *__restrict__ big_cnt, uint32_t *__restrict__ bigidx,
-                                                   uint32_t *__restrict__ n_big, uint32_t *__restrict__ max_seg) {
-    uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    uint32_t n = 0;
-    if (r < n_reads) {
-        n = cursor[r];
-        if (n > stride) { uint32_t i = atomicAdd(n_big, 1u); big_list[i] = (uint32_t)r; big_cnt[i] = n; bigidx[r] = i; }
-    }
-    for (int d = 32; d > 0; d >>= 1) { uint32_t o = __shfl_down(n, d, 64); n = o > n ? o : n; }
-    if ((threadIdx.x & 63) == 0 && n > stride) atomicMax(max_seg, n);
+/* ---- completion of the reads k_score could not take from their slots (tail overflow, or more live records than
+ * its LDS staging): exact segments = live direct slots + tail slots + overflow entries, sorted in HBM, scored by a
+ * second launch.  `big_list` is filled by k_score.  One wavefront per listed read.                            */
+/* records are read as three aligned 64-bit words; the pad byte (epoch tag) is the top byte of the third */
+__device__ __forceinline__ bool seg_slot_live(uint64_t w2, uint32_t i, uint32_t direct, uint32_t tail_n, uint32_t epoch) {
+    return (uint32_t)(w2 >> 56) == (epoch & 255u) && (i < direct || i - direct < tail_n);
 }
-__global__ __launch_bounds__(256) void k_big_copy(const mtb_match *__restrict__ seg, uint32_t stride, const uint32_t *__restrict__ big_list,
-                                                   const uint64_t *__restrict__ big_start, uint32_t n_big, uint32_t *__restrict__ bigcur,
-                                                   mtb_match *__restrict__ big) {
+__global__ __launch_bounds__(64) void k_big_count(const mtb_match *__restrict__ seg, uint32_t stride, uint32_t direct, uint32_t epoch,
+                                                   const uint32_t *__restrict__ cursor, const uint32_t *__restrict__ big_list, uint32_t n_big,
+                                                   uint32_t *__restrict__ big_cnt, uint32_t *__restrict__ bigidx, uint32_t *__restrict__ max_seg) {
+    uint32_t mx = 0;
     for (uint32_t b = blockIdx.x; b < n_big; b += gridDim.x) {
-        const uint64_t *src = (const uint64_t *)(seg + (uint64_t)big_list[b] * stride);
-        uint64_t *dst = (uint64_t *)(big + big_start[b]);
-        for (uint32_t i = threadIdx.x; i < stride * 3; i += 256) dst[i] = src[i];
-        if (threadIdx.x == 0) bigcur[b] = stride;
+        const uint32_t r = big_list[b];
+        const uint32_t cur = cursor[r], tail_cap = stride - direct, tail_n = cur < tail_cap ? cur : tail_cap;
+        const mtb_match *s = seg + (uint64_t)r * stride;
+        uint32_t n = 0;
+        for (uint32_t c0 = 0; c0 < stride; c0 += 64) {
+            uint32_t i = c0 + threadIdx.x;
+            bool live = i < stride && seg_slot_live(((const uint64_t *)s)[3 * i + 2], i, direct, tail_n, epoch);
+            n += (uint32_t)__popcll(__ballot(live));
+        }
+        n += cur - tail_n;                                  /* overflow entries */
+        if (threadIdx.x == 0) { big_cnt[b] = n; bigidx[r] = b; }
+        mx = n > mx ? n : mx;
+    }
+    if (threadIdx.x == 0 && mx) atomicMax(max_seg, mx);
+}
+__global__ __launch_bounds__(64) void k_big_copy(const mtb_match *__restrict__ seg, uint32_t stride, uint32_t direct, uint32_t epoch,
+                                                  const uint32_t *__restrict__ cursor, const uint32_t *__restrict__ big_list,
+                                                  const uint64_t *__restrict__ big_start, uint32_t n_big, uint32_t *__restrict__ bigcur,
+                                                  mtb_match *__restrict__ big) {
+    for (uint32_t b = blockIdx.x; b < n_big; b += gridDim.x) {
+        const uint32_t r = big_list[b];
+        const uint32_t cur = cursor[r], tail_cap = stride - direct, tail_n = cur < tail_cap ? cur : tail_cap;
+        const mtb_match *s = seg + (uint64_t)r * stride;
+        mtb_match *dst = big + big_start[b];
+        uint32_t n = 0;
+        for (uint32_t c0 = 0; c0 < stride; c0 += 64) {
+            uint32_t i = c0 + threadIdx.x;
+            uint64_t a = 0, bb = 0, cc = 0; bool live = false;
+            if (i < stride) { const uint64_t *q = (const uint64_t *)(s + i); a = q[0]; bb = q[1]; cc = q[2]; live = seg_slot_live(cc, i, direct, tail_n, epoch); }
+            uint64_t mask = __ballot(live);
+            if (live) { uint64_t *d = (uint64_t *)(dst + n + (uint32_t)__popcll(mask & lanemask_lt())); d[0] = a; d[1] = bb; d[2] = cc & 0x00FFFFFFFFFFFFFFull; }
+            n += (uint32_t)__popcll(mask);
+        }
+        if (threadIdx.x == 0) bigcur[b] = n;
     }
 }
 __global__ __launch_bounds__(256) void k_big_ovf(const mtb_match *__restrict__ ovf, uint64_t n_ovf, const uint32_t *__restrict__ bigidx,

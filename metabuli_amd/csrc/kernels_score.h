@@ -57,8 +57,9 @@ __global__ __launch_bounds__(64) void k_taxcnt_bound(const uint64_t *__restrict_
                                                       int32_t dna_shift, uint32_t *__restrict__ bound) {
     uint64_t r = (uint64_t)blockIdx.x * 64 + threadIdx.x;
     if (r >= n_reads) return;
-    uint64_t n = cursor ? (uint64_t)cursor[r] : seg_start[r + 1] - seg_start[r];
     uint64_t nb = (uint64_t)mtb_num_buckets(qlen[r] + qlen2[r], dna_shift);
+    if (cursor) { bound[r] = (uint32_t)nb; return; }           /* slot mode: the read's match count is not known yet */
+    uint64_t n = seg_start[r + 1] - seg_start[r];
     bound[r] = (uint32_t)(n < nb ? n : nb);
 }
 
@@ -103,8 +104,8 @@ __device__ __forceinline__ int32_t taxcnt_gather_wave(const int32_t *btax, const
  * emits ds_* / global_* instead of flat accesses.  SORT: the segment arrives
  * unordered and holds at most 64*MAXPER matches: rank sort on 12-byte keys. */
 #define MTB_SCORE_MAXPER 3
-template <typename IDX, bool SORT, bool KEY64, typename REC>
-__device__ __forceinline__ void score_read_par(const REC *__restrict__ src, int32_t n, mtb_sws<IDX> w, int32_t *btax,
+template <typename IDX, bool SORT, bool KEY64, typename REC, bool INPLACE = false>
+__device__ __forceinline__ void score_read_par(const REC *src, int32_t n, mtb_sws<IDX> w, int32_t *btax,
                                                uint8_t *bham, int32_t *otax, uint32_t *ocnt, int32_t *lr_lev, int32_t *lr_anc,
                                                int32_t nb, int32_t read_len, const mtb_tax_view &tx, const mtb_score_params &sp,
                                                uint64_t tc_off, uint64_t tc_room, int32_t *__restrict__ tc_tax,
@@ -136,7 +137,23 @@ __device__ __forceinline__ void score_read_par(const REC *__restrict__ src, int3
         __syncthreads();
         MTB_PHASE_MARK(0);
         const int32_t nslot = (n + 63) >> 6;          /* live register slots (wave-uniform) */
+        /* already in order?  (slot mode: one match per query and one species = extraction order = compareMatches order) */
+        bool sorted = true;
+#pragma unroll
+        for (int k = 0; k < MTB_SCORE_MAXPER; k++) {
+            int32_t i = lane + 64 * k;
+            if (i > 0 && i < n) {
+                uint64_t p1 = k1[i - 1];
+                if (KEY64) sorted = sorted && p1 <= a1[k];
+                else { uint32_t p2 = k2[i - 1]; sorted = sorted && (p1 < a1[k] || (p1 == a1[k] && p2 <= a2[k])); }
+            }
+        }
+        sorted = __all(sorted);
         bool unique = true;
+        if (sorted) {
+#pragma unroll
+            for (int k = 0; k < MTB_SCORE_MAXPER; k++) rank[k] = lane + 64 * k;
+        } else
         if (KEY64) {
             /* fast path: rank = number of strictly smaller keys (2 VALU per comparison).  Keys are
              * distinct unless the index holds duplicate entries; equal keys are detected below. */
@@ -166,7 +183,7 @@ __device__ __forceinline__ void score_read_par(const REC *__restrict__ src, int3
             for (int k = 0; k < MTB_SCORE_MAXPER; k++) { int32_t i = lane + 64 * k; if (i < n && chk[rank[k]] != (uint64_t)i) unique = false; }
             unique = __all(unique);
         }
-        if (!KEY64 || !unique) {
+        if (!sorted && (!KEY64 || !unique)) {
 #pragma unroll
             for (int k = 0; k < MTB_SCORE_MAXPER; k++) rank[k] = 0;
             int32_t j = 0;
@@ -198,8 +215,10 @@ __device__ __forceinline__ void score_read_par(const REC *__restrict__ src, int3
         }
         __syncthreads();
         MTB_PHASE_MARK(1);
+        if (!(INPLACE && sorted)) {
 #pragma unroll
-        for (int k = 0; k < MTB_SCORE_MAXPER; k++) { int32_t i = lane + 64 * k; if (i < n) w.m[rank[k]] = rec[k]; }
+            for (int k = 0; k < MTB_SCORE_MAXPER; k++) { int32_t i = lane + 64 * k; if (i < n) w.m[rank[k]] = rec[k]; }
+        }
         __syncthreads();
         if (sorted_out) {
             const uint64_t *s64 = (const uint64_t *)w.m; uint64_t *d64 = (uint64_t *)sorted_out;
@@ -427,7 +446,9 @@ __global__ __launch_bounds__(64, MTB_SCORE_MINWAVES) void k_score(const REC *__r
                                                uint64_t slab_bytes, uint32_t slab_max_n, uint32_t slab_max_nb,
                                                mtb_match *__restrict__ sorted_out, uint64_t tc_base,
                                                const uint32_t *__restrict__ list, const uint32_t *__restrict__ n_list,
-                                               const uint32_t *__restrict__ cursor, uint32_t stride, int seg_by_list) {
+                                               const uint32_t *__restrict__ cursor, uint32_t stride, int seg_by_list,
+                                               uint32_t direct, uint32_t epoch, uint32_t *__restrict__ big_list, uint32_t *__restrict__ n_big_out,
+                                               uint32_t *__restrict__ cnt_out) {
     __shared__ __attribute__((aligned(16))) uint8_t s_ws[MTB_SCORE_WS_BYTES];
     /* bucket / taxCnt / chain arrays of the decide phase live in the path storage,
      * which is dead once the species scores exist (keeps LDS per wave small -> occupancy) */
@@ -441,14 +462,13 @@ __global__ __launch_bounds__(64, MTB_SCORE_MINWAVES) void k_score(const REC *__r
     MTB_PHASE_KERNEL_BEGIN();
     const uint64_t n_iter = list ? (uint64_t)*n_list : n_reads;      /* optional: only the listed reads */
     for (uint64_t it = blockIdx.x; it < n_iter; it += gridDim.x) {
+#ifdef MTB_SCORE_PHASE_CYCLES
+        unsigned long long kt0_ = __builtin_readcyclecounter();
+#endif
         const uint64_t r = list ? (uint64_t)list[it] : it;
-        /* segment of read r: fixed-stride slots (cursor mode), or seg_start indexed by the read or by the list slot */
-        uint64_t s0; int32_t n;
-        if (cursor) {
-            uint32_t cn = cursor[r];
-            if (cn > stride) continue;                       /* completed on the large-segment path */
-            s0 = r * (uint64_t)stride; n = (int32_t)cn;
-        } else {
+        /* segment of read r: record slots filled by k_join<SEG> (slot mode), or seg_start indexed by the read or by the list slot */
+        uint64_t s0 = 0; int32_t n = 0;
+        if (!cursor) {
             const uint64_t si = seg_by_list ? it : r;
             s0 = seg_start[si]; n = (int32_t)(seg_start[si + 1] - s0);
         }
@@ -457,10 +477,76 @@ __global__ __launch_bounds__(64, MTB_SCORE_MINWAVES) void k_score(const REC *__r
         mtb_result R;
         R.classification = 0; R.score = 0.0f; R.query_length = ql1; R.query_length2 = ql2;
         R.is_classified = 0; R.reserved = 0; R.n_taxcnt = 0; R.taxcnt_off = 0;
-        if (n == 0) { if (lane == 0) results[r] = R; continue; }
         const int32_t nb = mtb_num_buckets(read_len, sp.dna_shift);
-        const bool big = n > MTB_SCORE_LDS || nb > MTB_SCORE_BKT;
         const uint64_t off = tc_off[r], room = tc_off[r + 1] - off;
+        if (cursor) {
+            /* slot mode: live records of the read's slots -> LDS (compaction keeps slot order); reads that do not fit
+             * (tail overflow, more live records than the staging, too many position buckets) go to big_list */
+            const uint32_t cur = cursor[r], tail_cap = stride - direct;
+            mtb_sws<uint16_t> w;
+            mtb_sws_carve<uint16_t>(&w, s_ws, MTB_SCORE_LDS);
+            bool defer = cur > tail_cap || nb > MTB_SCORE_BKT;
+            if (!defer) {
+                const REC *src = matches + r * (uint64_t)stride;
+                uint32_t cnt = 0;
+                __syncthreads();
+#ifdef MTB_SCORE_PHASE_CYCLES
+                { unsigned long long t_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) mtb_phase_lds[15] += t_ - kt0_; kt0_ = t_; }
+#endif
+                /* records move as three aligned 64-bit words (a struct copy with the pad byte patched was lowered to
+                 * overlapping unaligned loads, each waiting for the previous one: 12 k cycles per read, measured);
+                 * the pad byte is the top byte of the third word */
+                const uint64_t *src64 = (const uint64_t *)src;
+                uint64_t *dst64 = (uint64_t *)w.m;
+                if (stride <= 192) {
+                    uint64_t wa[3], wb[3], wc[3];
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {          /* all slot loads of the lane in flight at once */
+                        const uint32_t i = lane + 64 * k;
+                        wa[k] = 0; wb[k] = 0; wc[k] = 0;
+                        if (i < stride) { wa[k] = src64[3 * i]; wb[k] = src64[3 * i + 1]; wc[k] = src64[3 * i + 2]; }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        const uint32_t i = lane + 64 * k;
+                        const bool live = i < stride && (uint32_t)(wc[k] >> 56) == epoch && (i < direct || i - direct < cur);
+                        const uint64_t mask = __ballot(live);
+                        const uint32_t pos = cnt + (uint32_t)__popcll(mask & lanemask_lt());
+                        if (live && pos < MTB_SCORE_LDS) { dst64[3 * pos] = wa[k]; dst64[3 * pos + 1] = wb[k]; dst64[3 * pos + 2] = wc[k] & 0x00FFFFFFFFFFFFFFull; }
+                        cnt += (uint32_t)__popcll(mask);
+                    }
+                } else
+                for (uint32_t c0 = 0; c0 < stride; c0 += 64) {
+                    const uint32_t i = c0 + lane;
+                    uint64_t a = 0, b = 0, cc = 0;
+                    if (i < stride) { a = src64[3 * (uint64_t)i]; b = src64[3 * (uint64_t)i + 1]; cc = src64[3 * (uint64_t)i + 2]; }
+                    const bool live = i < stride && (uint32_t)(cc >> 56) == epoch && (i < direct || i - direct < cur);
+                    const uint64_t mask = __ballot(live);
+                    const uint32_t pos = cnt + (uint32_t)__popcll(mask & lanemask_lt());
+                    if (live && pos < MTB_SCORE_LDS) { dst64[3 * pos] = a; dst64[3 * pos + 1] = b; dst64[3 * pos + 2] = cc & 0x00FFFFFFFFFFFFFFull; }
+                    cnt += (uint32_t)__popcll(mask);
+                }
+                n = (int32_t)cnt;
+                defer = cnt > MTB_SCORE_LDS;
+                __syncthreads();
+#ifdef MTB_SCORE_PHASE_CYCLES
+                { unsigned long long t_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) mtb_phase_lds[14] += t_ - kt0_; kt0_ = t_; }
+#endif
+            }
+            if (defer) { if (lane == 0) big_list[atomicAdd(n_big_out, 1u)] = (uint32_t)r; continue; }
+            if (lane == 0) cnt_out[r] = (uint32_t)n;
+            if (n == 0) { if (lane == 0) results[r] = R; continue; }
+            int32_t *s_btax = (int32_t *)w.path, *s_otax = s_btax + MTB_SCORE_BKT;
+            uint32_t *s_ocnt = (uint32_t *)(s_otax + MTB_SCORE_BKT);
+            int32_t *s_lev = (int32_t *)(s_ocnt + MTB_SCORE_BKT), *s_anc = s_lev + MTB_LR_MAXE;
+            uint8_t *s_bham = (uint8_t *)(s_anc + MTB_LR_MAXE * MTB_LR_K);
+            score_read_par<uint16_t, true, KEY64, mtb_match, true>(w.m, n, w, s_btax, s_bham, s_otax, s_ocnt, s_lev, s_anc, nb, read_len, tx, sp, off, room,
+                                                                     tc_tax, tc_cnt, tc_cap, (mtb_match *)nullptr, R);
+            if (lane == 0) { R.query_length = ql1; R.query_length2 = ql2; R.reserved = 0; R.taxcnt_off += (uint32_t)tc_base; results[r] = R; }
+            continue;
+        }
+        if (n == 0) { if (lane == 0) results[r] = R; continue; }
+        const bool big = n > MTB_SCORE_LDS || nb > MTB_SCORE_BKT;
         if (!big) {
             mtb_sws<uint16_t> w;
             mtb_sws_carve<uint16_t>(&w, s_ws, MTB_SCORE_LDS);

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <functional>
 #include <map>
 #include <string>
 #include <thread>
@@ -49,6 +50,7 @@ struct mtb_ctx {
     std::vector<hipEvent_t> ev_pool; /* recycled events                  */
     std::vector<mtb_ctx *> lanes;    /* extra stream contexts (mtb_ctx_set_streams) */
     bool is_lane = false;            /* lanes share the parent's tables  */
+    uint32_t seg_epoch = 0;          /* tag of the live slots in the "segm" buffer (1..255) */
     double extract_yield = 0.0;      /* metamers per base of the previous batch (single-pass extraction buffer sizing) */
     uint64_t part_n_reads = 0; uint32_t part_max_len = 0;   /* batch state between mtb_part_extract and mtb_part_score */
 };
@@ -209,14 +211,14 @@ static mtb_status h2d(mtb_ctx *c, void *dst, const void *src, size_t bytes) {
 static mtb_status dev_extract(mtb_ctx *c, const mtb_params *p, const char *d_bases, const uint64_t *d_offs, const char *d_bases2,
                               const uint64_t *d_offs2, uint64_t n_reads, mtb_kmer **out, uint64_t *count, int32_t *d_qlen,
                               int32_t *d_qlen2, uint32_t *max_len, bool single_pass = false, uint64_t n_bases = 0,
-                              uint64_t *real_count = nullptr) {
+                              uint64_t *real_count = nullptr, bool tag_ord = false, uint32_t *max_q = nullptr) {
     if (n_reads >= (1ull << 29)) return fail(MTB_ERR_ARG, "more than 2^29-1 reads per batch (sequenceID is 29 bits, Kmer.h:13)");
     if (p->kmer_format != 1 && p->kmer_format != 2) return fail(MTB_ERR_UNSUPPORTED, "only kmer_format 1 and 2 are implemented");
     if (p->syncmer && (p->smer_len < 1 || p->smer_len > 8)) return fail(MTB_ERR_ARG, "smer_len out of range");
     *count = 0; *out = nullptr;
     if (real_count) *real_count = 0;
     if (n_reads == 0) return MTB_OK;
-    ExtractArgs a{d_bases, d_offs, d_bases2, d_offs2, n_reads, p->seq_mode, p->syncmer, p->smer_len, p->kmer_format};
+    ExtractArgs a{d_bases, d_offs, d_bases2, d_offs2, n_reads, p->seq_mode, p->syncmer, p->smer_len, p->kmer_format, (single_pass && tag_ord) ? 1 : 0};
     uint32_t grid = (uint32_t)std::min<uint64_t>(n_reads, 256ull * 64);
     HIPCHK(hipMemsetAsync(c->d_scal + 4, 0, 8, c->stream));
     if (single_pass) {
@@ -248,6 +250,7 @@ static mtb_status dev_extract(mtb_ctx *c, const mtb_params *p, const char *d_bas
                 c->extract_yield = (double)sc[0] / (double)n_bases;
                 *out = d_k; *count = sc[0];
                 if (real_count) *real_count = sc[2];
+                if (max_q) *max_q = (uint32_t)sc[3];
                 return MTB_OK;
             }
             if (cap >= bound) return fail(MTB_ERR_DEVICE, "extract: output bound exceeded");
@@ -392,8 +395,10 @@ static mtb_status dev_segsort(mtb_ctx *c, mtb_match *d_m, const uint64_t *d_seg,
 struct ScoreSrc {
     const mtb_match *m = nullptr;
     const uint64_t *seg = nullptr;        /* seg_start (by read, or by list slot if seg_by_list)            */
-    const uint32_t *cursor = nullptr;     /* fixed-stride mode: matches of read r at m[r*stride .. +cursor[r]) */
-    uint32_t stride = 0;
+    const uint32_t *cursor = nullptr;     /* slot mode (k_join<SEG>): read r owns m[r*stride .. +stride), cursor[r] = entries in its tail */
+    uint32_t stride = 0, direct = 0, epoch = 0;
+    uint32_t *big_list = nullptr, *n_big = nullptr;      /* slot mode: reads deferred to the large-segment path */
+    uint32_t *cnt_out = nullptr;                         /* slot mode: live records per read */
     const uint32_t *list = nullptr, *n_list = nullptr;   /* only these reads */
     int seg_by_list = 0;
     bool sort = false;                    /* segments arrive unordered: rank sort in the kernel */
@@ -401,11 +406,13 @@ struct ScoreSrc {
     uint32_t grid = 0;                    /* 0 = default */
 };
 
-/* d_results/d_tc_* are device outputs; *n_tc = sum of per-read bounds.  `second` (optional) is launched after
- * `first` with the same per-read taxcnt slots (reads completed on the large-segment path). */
+/* d_results/d_tc_* are device outputs; *n_tc = sum of per-read bounds.  `second` (optional) runs after the launch
+ * over `first`, may build a source for the reads that launch deferred (large-segment path) and returns true to
+ * have it launched with the same per-read taxcnt slots. */
+typedef std::function<mtb_status(ScoreSrc *, bool *)> ScoreSecond;
 static mtb_status dev_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, uint64_t n_reads, const int32_t *d_qlen, const int32_t *d_qlen2,
                             uint32_t max_len, mtb_result *d_res, int32_t *d_tc_tax, uint32_t *d_tc_cnt, uint64_t tc_cap, uint64_t *n_tc,
-                            uint64_t tc_base, const ScoreSrc &first, const ScoreSrc *second) {
+                            uint64_t tc_base, const ScoreSrc &first, const ScoreSecond *second) {
     mtb_score_params sp; mtb_make_score_params(p, &sp);
     uint32_t *d_bound; uint64_t *d_tcoff; uint64_t *d_ws;
     STCHK(ensure(c, "bound", n_reads, &d_bound));
@@ -421,10 +428,16 @@ static mtb_status dev_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, uint
     /* single-word sort key when taxids < 2^22 and positions < 2^11 (hamming of a match is <= 7) */
     const bool key64 = ix->tax.max_id < (1 << 22) && max_len + 3 < (1u << 11);
     const uint32_t max_nb = (uint32_t)mtb_num_buckets((int32_t)max_len, sp.dna_shift);
-    const ScoreSrc *srcs[2] = {&first, second};
+    ScoreSrc second_src;
     for (int pass = 0; pass < 2; pass++) {
-        const ScoreSrc *S = srcs[pass];
-        if (!S) continue;
+        const ScoreSrc *S = &first;
+        if (pass == 1) {
+            if (!second) break;
+            bool go = false;
+            STCHK((*second)(&second_src, &go));
+            if (!go) break;
+            S = &second_src;
+        }
         uint32_t grid = S->grid ? S->grid : (uint32_t)std::min<uint64_t>(n_reads, 256ull * 12);
         /* reads with a big segment OR many position buckets are scored entirely out of a slab */
         bool need_slab = S->max_seg > MTB_SCORE_LDS || max_nb > MTB_SCORE_BKT;
@@ -439,7 +452,7 @@ static mtb_status dev_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, uint
         KTimer kt(c, MTB_K_SCORE);
 #define MTB_LAUNCH_SCORE(SRT, K) hipLaunchKernelGGL((k_score<SRT, K, mtb_match>), dim3(grid), dim3(64), 0, c->stream, S->m, S->seg, n_reads, d_qlen, \
         d_qlen2, tax_view(ix), sp, (const uint64_t *)d_tcoff, d_res, d_tc_tax, d_tc_cnt, tc_cap, d_slabs, slab_bytes, slab_n, slab_nb, (mtb_match *)nullptr,  \
-        tc_base, S->list, S->n_list, S->cursor, S->stride, S->seg_by_list)
+        tc_base, S->list, S->n_list, S->cursor, S->stride, S->seg_by_list, S->direct, S->epoch, S->big_list, S->n_big, S->cnt_out)
         if (S->sort) { if (key64) MTB_LAUNCH_SCORE(true, true); else MTB_LAUNCH_SCORE(true, false); }
         else MTB_LAUNCH_SCORE(false, false);
 #undef MTB_LAUNCH_SCORE
@@ -832,9 +845,16 @@ static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, c
     int32_t *d_ql, *d_ql2;
     STCHK(ensure(c, "qlen", n_reads, &d_ql)); STCHK(ensure(c, "qlen2", n_reads, &d_ql2));
     HIPCHK(hipEventRecord(c->ev[0], st));
-    mtb_kmer *d_k; uint64_t nk; uint32_t max_len = 0;
+    mtb_kmer *d_k; uint64_t nk; uint32_t max_len = 0, max_q = 0;
     uint64_t nk_real = 0;                 /* nk counts the blank tail records of the single-pass extraction too */
-    STCHK(dev_extract(c, p, d_bases, d_offs, d_bases2, d_offs2, n_reads, &d_k, &nk, d_ql, d_ql2, &max_len, true, n_bases_total, &nk_real));
+    /* short reads: per-read slot segments, the query's ordinal (tagged into qinfo by the extractor) is the slot of its
+     * first match.  Needs positions < 2^16 and a moderate number of metamers per read; otherwise exact segments. */
+    bool fixed = p->seq_mode != 3;
+    STCHK(dev_extract(c, p, d_bases, d_offs, d_bases2, d_offs2, n_reads, &d_k, &nk, d_ql, d_ql2, &max_len, true, n_bases_total, &nk_real, fixed, &max_q));
+    if (fixed && (max_len + 3 >= (1u << 16) || max_q > 384)) {
+        fixed = false;                     /* tags would collide with positions / segments would be huge: extract again untagged */
+        STCHK(dev_extract(c, p, d_bases, d_offs, d_bases2, d_offs2, n_reads, &d_k, &nk, d_ql, d_ql2, &max_len, true, n_bases_total, &nk_real, false, &max_q));
+    }
     HIPCHK(hipEventRecord(c->ev[1], st));
     /* the join needs tiles with a narrow amino-acid range, not a total order: kmer_format 2 sorts on the first six
      * amino-acid letters (three base-21 pair passes = bits [34,64)), kmer_format 1 on the top 32 bits (four binary
@@ -849,59 +869,74 @@ static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, c
     STCHK(ensure(c, "readcnt", n_reads, &d_rc));
     HIPCHK(hipMemsetAsync(d_rc, 0, n_reads * 4, st));
     uint64_t nm = 0;
-    const bool fixed = p->seq_mode != 3;            /* short reads: fixed-capacity per-read segments */
     if (fixed) {
-        /* ---- join straight into per-read segments of MTB_SCORE_LDS slots (d_rc = per-read cursor) ---- */
-        const uint32_t stride = MTB_SCORE_LDS;
+        /* ---- join straight into per-read slot segments (d_rc = per-read tail cursor) ---- */
+        const uint32_t direct = std::max<uint32_t>(8, (max_q + 7) & ~7u);
+        const uint32_t stride = direct + std::max<uint32_t>(16, (direct / 8 + 7) & ~7u);
         mtb_match *d_segm; mtb_match *d_ovf; uint64_t n_ovf = 0;
-        STCHK(ensure(c, "segm", n_reads * (uint64_t)stride, &d_segm));
+        {   /* live slots carry the batch's epoch tag in their pad byte; the buffer is cleared only when it is new or the tag wraps */
+            DevBuf &sb = c->bufs["segm"];
+            void *before = sb.p; size_t cap_before = sb.cap;
+            STCHK(ensure(c, "segm", n_reads * (uint64_t)stride, &d_segm));
+            if (sb.p != before || sb.cap != cap_before || c->seg_epoch >= 255) { HIPCHK(hipMemsetAsync(sb.p, 0, sb.cap, st)); c->seg_epoch = 0; }
+            c->seg_epoch++;
+        }
+        const uint32_t epoch = c->seg_epoch;
         DevBuf &ob = c->bufs["ovf"];
         uint64_t ovf_cap = std::max<uint64_t>(ob.cap / sizeof(mtb_match), nk / 64 + 4096);
         for (int attempt = 0; attempt < 3; attempt++) {
             STCHK(ensure(c, "ovf", ovf_cap, &d_ovf));
-            JoinSegArgs sa; sa.seg = d_segm; sa.stride = stride; sa.cursor = d_rc; sa.ovf = d_ovf; sa.ovf_cap = ovf_cap; sa.ovf_counter = nullptr;
+            JoinSegArgs sa; sa.seg = d_segm; sa.stride = stride; sa.direct = direct; sa.cursor = d_rc; sa.ovf = d_ovf; sa.ovf_cap = ovf_cap;
+            sa.ovf_counter = nullptr; sa.epoch = epoch;
             mtb_status s2 = dev_join(c, ix, d_s, nk, nullptr, 0, nullptr, &n_ovf, &sa, low_bits);
             if (s2 == MTB_OK) break;
             if (s2 != MTB_ERR_CAPACITY || attempt == 2) return s2;
             ovf_cap = n_ovf + n_ovf / 16 + 1024;
-            HIPCHK(hipMemsetAsync(d_rc, 0, n_reads * 4, st));
+            HIPCHK(hipMemsetAsync(d_rc, 0, n_reads * 4, st));     /* slots written by the failed attempt are rewritten identically */
         }
         HIPCHK(hipEventRecord(c->ev[3], st));
-        /* reads that overflowed: exact segments from (their fixed slots + the overflow list), sorted in HBM */
-        uint32_t *d_biglist, *d_bigcnt, *d_bigidx, *d_bigcur; uint64_t *d_bigstart = nullptr, *d_ws2; mtb_match *d_big = nullptr;
-        STCHK(ensure(c, "biglist", n_reads, &d_biglist)); STCHK(ensure(c, "bigcnt", n_reads, &d_bigcnt)); STCHK(ensure(c, "bigidx", n_reads, &d_bigidx));
-        HIPCHK(hipMemsetAsync(c->d_scal + 2, 0, 16, st));
-        hipLaunchKernelGGL(k_big_list, dim3((uint32_t)((n_reads + 255) / 256)), dim3(256), 0, st, (const uint32_t *)d_rc, n_reads, stride, d_biglist,
-                           d_bigcnt, d_bigidx, (uint32_t *)(c->d_scal + 2), (uint32_t *)(c->d_scal + 3));
-        /* total number of matches (statistics) */
-        uint64_t *d_tot;
-        STCHK(ensure(c, "segstart", n_reads + 1, &d_tot)); STCHK(ensure(c, "scanws", scan_ws_elems(n_reads + 1), &d_ws2));
-        { KTimer kt(c, MTB_K_SCAN); scan_launch<uint32_t, uint64_t, false>(st, d_rc, n_reads, true, d_tot, d_ws2); }
-        uint64_t sc[2];
-        STCHK(d2h(c, sc, c->d_scal + 2, 16));
-        STCHK(d2h(c, &nm, d_tot + n_reads, 8));
-        const uint32_t n_big = (uint32_t)sc[0]; const uint32_t max_big = (uint32_t)sc[1];
         HIPCHK(hipEventRecord(c->ev[4], st));
-        if (n_big) {
-            STCHK(ensure(c, "bigstart", (uint64_t)n_big + 1, &d_bigstart)); STCHK(ensure(c, "bigcur", n_big, &d_bigcur));
-            scan_launch<uint32_t, uint64_t, false>(st, d_bigcnt, n_big, true, d_bigstart, d_ws2);
-            uint64_t big_total = 0;
-            STCHK(d2h(c, &big_total, d_bigstart + n_big, 8));
-            STCHK(ensure(c, "bigm", big_total, &d_big));
+        HIPCHK(hipEventRecord(c->ev[5], st));
+        uint32_t *d_biglist, *d_bigcnt, *d_bigidx, *d_bigcur, *d_cnt; uint64_t *d_bigstart = nullptr, *d_ws2, *d_tot; mtb_match *d_big = nullptr;
+        STCHK(ensure(c, "biglist", n_reads, &d_biglist)); STCHK(ensure(c, "bigidx", n_reads, &d_bigidx)); STCHK(ensure(c, "livecnt", n_reads, &d_cnt));
+        STCHK(ensure(c, "segstart", n_reads + 1, &d_tot)); STCHK(ensure(c, "scanws", scan_ws_elems(n_reads + 1), &d_ws2));
+        HIPCHK(hipMemsetAsync(d_cnt, 0, n_reads * 4, st));
+        HIPCHK(hipMemsetAsync(c->d_scal + 2, 0, 32, st));            /* [2] unused, [3] max big segment, [5] reads deferred by the first launch */
+        uint64_t big_total = 0;
+        ScoreSrc a; a.m = d_segm; a.cursor = d_rc; a.stride = stride; a.direct = direct; a.epoch = epoch; a.sort = true; a.max_seg = MTB_SCORE_LDS;
+        a.big_list = d_biglist; a.n_big = (uint32_t *)(c->d_scal + 5); a.cnt_out = d_cnt;
+        /* reads the first launch could not take from their slots: exact segments (live slots + overflow list), sorted in HBM */
+        ScoreSecond second = [&](ScoreSrc *b, bool *go) -> mtb_status {
+            uint64_t sc = 0;
+            STCHK(d2h(c, &sc, c->d_scal + 5, 8));
+            const uint32_t n_big = (uint32_t)sc;
+            *go = n_big != 0;
+            if (!n_big) return MTB_OK;
             KTimer kt(c, MTB_K_SEGSORT);
-            hipLaunchKernelGGL(k_big_copy, dim3(std::min<uint32_t>(n_big, 4096)), dim3(256), 0, st, (const mtb_match *)d_segm, stride, (const uint32_t *)d_biglist,
-                               (const uint64_t *)d_bigstart, n_big, d_bigcur, d_big);
+            STCHK(ensure(c, "bigcnt", n_big, &d_bigcnt)); STCHK(ensure(c, "bigstart", (uint64_t)n_big + 1, &d_bigstart)); STCHK(ensure(c, "bigcur", n_big, &d_bigcur));
+            hipLaunchKernelGGL(k_big_count, dim3(std::min<uint32_t>(n_big, 4096)), dim3(64), 0, st, (const mtb_match *)d_segm, stride, direct, epoch,
+                               (const uint32_t *)d_rc, (const uint32_t *)d_biglist, n_big, d_bigcnt, d_bigidx, (uint32_t *)(c->d_scal + 3));
+            scan_launch<uint32_t, uint64_t, false>(st, d_bigcnt, n_big, true, d_bigstart, d_ws2);
+            uint64_t mx = 0;
+            STCHK(d2h(c, &big_total, d_bigstart + n_big, 8));
+            STCHK(d2h(c, &mx, c->d_scal + 3, 8));
+            STCHK(ensure(c, "bigm", big_total, &d_big));
+            hipLaunchKernelGGL(k_big_copy, dim3(std::min<uint32_t>(n_big, 4096)), dim3(64), 0, st, (const mtb_match *)d_segm, stride, direct, epoch,
+                               (const uint32_t *)d_rc, (const uint32_t *)d_biglist, (const uint64_t *)d_bigstart, n_big, d_bigcur, d_big);
             if (n_ovf) hipLaunchKernelGGL(k_big_ovf, dim3((uint32_t)((n_ovf + 255) / 256)), dim3(256), 0, st, (const mtb_match *)d_ovf, n_ovf,
                                           (const uint32_t *)d_bigidx, (const uint64_t *)d_bigstart, d_bigcur, d_big);
-            HIPCHK(hipMemcpyAsync(c->d_scal + 5, &n_big, 4, hipMemcpyHostToDevice, st));
             hipLaunchKernelGGL((k_segsort_large<mtb_match>), dim3(std::min<uint32_t>(n_big, 1024)), dim3(256), 0, st, d_big, (const uint64_t *)d_bigstart,
                                (const uint32_t *)nullptr, (const uint32_t *)(c->d_scal + 5));
-        }
-        HIPCHK(hipEventRecord(c->ev[5], st));
-        ScoreSrc a; a.m = d_segm; a.cursor = d_rc; a.stride = stride; a.sort = true; a.max_seg = stride;
-        ScoreSrc b; b.m = d_big; b.seg = d_bigstart; b.list = d_biglist; b.n_list = (const uint32_t *)(c->d_scal + 5); b.seg_by_list = 1;
-        b.sort = false; b.max_seg = max_big; b.grid = std::min<uint32_t>(std::max<uint32_t>(n_big, 1), 1024);
-        STCHK(dev_score(c, ix, p, n_reads, d_ql, d_ql2, max_len, d_results, d_taxcnt_tax, d_taxcnt_cnt, taxcnt_cap, n_taxcnt, tc_base, a, n_big ? &b : nullptr));
+            HIPCHK(hipGetLastError());
+            b->m = d_big; b->seg = d_bigstart; b->list = d_biglist; b->n_list = (const uint32_t *)(c->d_scal + 5); b->seg_by_list = 1;
+            b->sort = false; b->max_seg = (uint32_t)mx; b->grid = std::min<uint32_t>(n_big, 1024);
+            return MTB_OK;
+        };
+        STCHK(dev_score(c, ix, p, n_reads, d_ql, d_ql2, max_len, d_results, d_taxcnt_tax, d_taxcnt_cnt, taxcnt_cap, n_taxcnt, tc_base, a, &second));
+        /* number of matches (statistics): live records seen by the first launch + the deferred reads' segments */
+        { KTimer kt(c, MTB_K_SCAN); scan_launch<uint32_t, uint64_t, false>(st, d_cnt, n_reads, true, d_tot, d_ws2); }
+        STCHK(d2h(c, &nm, d_tot + n_reads, 8));
+        nm += big_total;
     } else {
         /* ---- long reads: exact segments (temp buffer, per-read counters, scan, regroup) ---- */
         mtb_match *d_tmp;
@@ -1108,6 +1143,9 @@ mtb_status mtb_debug_phase_cycles(mtb_ctx *c, unsigned long long *out4) {
     HIPCHK(hipMemcpyFromSymbol(out4, HIP_SYMBOL(mtb_phase_cycles), 8 * MTB_NPHASE));      /* out4: MTB_NPHASE (16) counters */
     unsigned long long z[MTB_NPHASE] = {0};
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(mtb_phase_cycles), z, 8 * MTB_NPHASE));
+    /* join phases ride in out4[16..23] */
+    HIPCHK(hipMemcpyFromSymbol(out4 + MTB_NPHASE, HIP_SYMBOL(mtb_join_cycles), 64));
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(mtb_join_cycles), z, 64));
     return MTB_OK;
 }
 #endif

@@ -284,7 +284,8 @@ MTB_HD void mtb_join_find(const uint64_t *v, uint64_t n, uint64_t qvalue, uint64
  * writes them in index order.  info/tax2species are indexed with info_base + i. */
 MTB_HD uint32_t mtb_join_select(const mtb_tables *t, const uint64_t *v, uint64_t s, uint32_t len, uint64_t qvalue, uint64_t qinfo,
                                 const uint32_t *info, uint64_t info_base, const int32_t *tax2species, int32_t max_taxid,
-                                uint32_t info_mask, int32_t kmer_format, mtb_match *out, uint32_t out_cap, uint32_t skip = 0) {
+                                uint32_t info_mask, int32_t kmer_format, mtb_match *out, uint32_t out_cap, uint32_t skip = 0,
+                                uint8_t pad = 0) {
     if (len == 0) return 0;
     mtb_qrows q; mtb_prepare_query(t, qvalue, &q);
     uint32_t mn = 255;
@@ -301,7 +302,7 @@ MTB_HD uint32_t mtb_join_select(const mtb_tables *t, const uint64_t *v, uint64_t
                 int32_t sp = (tid >= 0 && tid <= max_taxid) ? tax2species[tid] : 0;
                 mtb_match m;
                 m.qinfo = qinfo; m.target_id = tid; m.species_id = sp; m.dna = td;
-                m.right_end_hamming = mtb_hammings(&q, td, rev); m.hamming = (uint8_t)h; m.pad = 0;
+                m.right_end_hamming = mtb_hammings(&q, td, rev); m.hamming = (uint8_t)h; m.pad = pad;
                 out[cnt - skip] = m;
             }
             cnt++;

@@ -19,13 +19,20 @@ N = 500000
 db, do = bench.gen_reads(torch, dev, world, N, 150, 0.10, 0.005, 99)
 dres = torch.empty(N * 24, dtype=torch.uint8, device=dev); cap = N * 20 + 1024
 dtt = torch.empty(cap, dtype=torch.int32, device=dev); dtc = torch.empty(cap, dtype=torch.int32, device=dev)
-out = (C.c_ulonglong * 16)()
+out = (C.c_ulonglong * 24)()
 for it in range(2):
     ctx.classify_batch_device(ix, params, db.data_ptr(), do.data_ptr(), 0, 0, N, N * 150, dres.data_ptr(), dtt.data_ptr(), dtc.data_ptr(), cap)
     M.lib().mtb_debug_phase_cycles(ctx.h, out)
 st = ctx.last_stats()
-tot = sum(out)
-names = ["load+keys", "rank", "permute", "flags+ids", "starts", "links", "chainDP", "emit", "combine", "select", "filter", "gather", "climb", "decide+out"]
+tot = sum(out[:16])
+names = ["load+keys", "rank", "permute", "flags+ids", "starts", "links", "chainDP", "emit", "combine", "select", "filter", "gather", "climb", "decide+out", "slot load+compact", "read setup"]
 print("score ms", st.ms_score, "total cycles/read", int(tot / N))
 for k, nm in enumerate(names):
     print(f"  {nm:12s} {int(out[k] / N):7d} cycles/read  {100.0 * out[k] / tot:5.1f} %")
+
+jn = ["load+window", "find (extra pass)", "find+count", "atomic probe (extra)", "reserve+emit"]
+nblk = (st.n_kmers + 511) // 512
+jt = sum(out[16:21])
+print("join ms", st.ms_join, "cycles per 512-query workgroup (thread 0):")
+for k, nm in enumerate(jn):
+    print(f"  {nm:22s} {int(out[16 + k] / nblk):7d}  {100.0 * out[16 + k] / jt:5.1f} %")
