@@ -99,6 +99,17 @@ __device__ __forceinline__ int32_t taxcnt_gather_wave(const int32_t *btax, const
     return ntc;
 }
 
+/* Phase boundary inside one wavefront.  A k_score workgroup is ONE wave: its LDS instructions are executed in issue
+ * order, so a phase that wrote LDS and the next one that reads it need no s_barrier and no s_waitcnt vmcnt(0) (which
+ * __syncthreads() implies and which also drains every outstanding global load) -- only a compiler fence.  The HBM
+ * slab workspace of big segments (IDX = uint32_t) keeps the full barrier: global stores followed by loads of other
+ * lanes need the wait.                                                                                         */
+template <typename IDX>
+__device__ __forceinline__ void score_sync() {
+    if (sizeof(IDX) == 2) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+    else __syncthreads();
+}
+
 /* One read, data-parallel (phases of mtb_score_par.h).  All storage of a call
  * site lives in ONE address space (LDS or an HBM slab) so that the compiler
  * emits ds_* / global_* instead of flat accesses.  SORT: the segment arrives
@@ -134,7 +145,7 @@ __device__ __forceinline__ void score_read_par(const REC *src, int32_t n, mtb_sw
                 } else { a1[k] = mtb_key1(rec[k]); a2[k] = mtb_key2(rec[k]); k1[i] = a1[k]; k2[i] = a2[k]; }
             }
         }
-        __syncthreads();
+        score_sync<IDX>();
         MTB_PHASE_MARK(0);
         const int32_t nslot = (n + 63) >> 6;          /* live register slots (wave-uniform) */
         /* already in order?  (slot mode: one match per query and one species = extraction order = compareMatches order) */
@@ -174,11 +185,11 @@ __device__ __forceinline__ void score_read_par(const REC *src, int32_t n, mtb_sw
                 for (int k = 0; k < MTB_SCORE_MAXPER; k++) rank[k] += (b1 < a1[k]);
             }
             /* two equal keys get the same rank: then some key differs from the one stored at its rank */
-            __syncthreads();
+            score_sync<IDX>();
             uint64_t *chk = (uint64_t *)w.m;          /* m[] is not written yet */
 #pragma unroll
             for (int k = 0; k < MTB_SCORE_MAXPER; k++) { int32_t i = lane + 64 * k; if (i < n) chk[rank[k]] = (uint64_t)i; }
-            __syncthreads();
+            score_sync<IDX>();
 #pragma unroll
             for (int k = 0; k < MTB_SCORE_MAXPER; k++) { int32_t i = lane + 64 * k; if (i < n && chk[rank[k]] != (uint64_t)i) unique = false; }
             unique = __all(unique);
@@ -213,25 +224,25 @@ __device__ __forceinline__ void score_read_par(const REC *src, int32_t n, mtb_sw
                 }
             }
         }
-        __syncthreads();
+        score_sync<IDX>();
         MTB_PHASE_MARK(1);
         if (!(INPLACE && sorted)) {
 #pragma unroll
             for (int k = 0; k < MTB_SCORE_MAXPER; k++) { int32_t i = lane + 64 * k; if (i < n) w.m[rank[k]] = rec[k]; }
         }
-        __syncthreads();
+        score_sync<IDX>();
         if (sorted_out) {
             const uint64_t *s64 = (const uint64_t *)w.m; uint64_t *d64 = (uint64_t *)sorted_out;
             for (int32_t i = lane; i < n * 3; i += 64) d64[i] = s64[i];
         }
     } else {
         for (int32_t i = lane; i < n; i += 64) w.m[i] = rec_m(src[i]);
-        __syncthreads();
+        score_sync<IDX>();
     }
     MTB_PHASE_MARK(2);
     /* flags, ids */
     for (int32_t i = lane; i < n; i += 64) mtb_ph_flags(w, i);
-    __syncthreads();
+    score_sync<IDX>();
     int32_t ng = 0, nbk = 0, nsp = 0;
     for (int32_t c0 = 0; c0 < n; c0 += 64) {
         int32_t i = c0 + lane;
@@ -244,15 +255,15 @@ __device__ __forceinline__ void score_read_par(const REC *src, int32_t n, mtb_sw
         }
         ng += __popcll(mg); nbk += __popcll(mb); nsp += __popcll(ms);
     }
-    __syncthreads();
+    score_sync<IDX>();
     MTB_PHASE_MARK(3);
     for (int32_t i = lane; i < n; i += 64) mtb_ph_starts(w, i, &tx);
-    __syncthreads();
+    score_sync<IDX>();
     MTB_PHASE_MARK(4);
     int32_t maxrank = 0;
     for (int32_t i = lane; i < n; i += 64) { mtb_ph_links(w, i, &tx, &sp, ng, nbk); int32_t rr = w.rk[i]; maxrank = rr > maxrank ? rr : maxrank; }
     for (int d = 32; d > 0; d >>= 1) { int32_t o = __shfl_xor(maxrank, d, 64); maxrank = o > maxrank ? o : maxrank; }
-    __syncthreads();
+    score_sync<IDX>();
     MTB_PHASE_MARK(5);
     /* chain DP: pointer doubling when every match has <= 1 consecutive predecessor, else rounds */
     const bool small_n = n <= 64 * MTB_SCORE_MAXPER;
@@ -265,39 +276,39 @@ __device__ __forceinline__ void score_read_par(const REC *src, int32_t n, mtb_sw
         /* big segment (HBM slab): ping-pong between the path storage and the (now dead) sid/rk/grp_start/blk_start block */
         mtb_jump *ja = (mtb_jump *)w.path, *jb = (mtb_jump *)w.sid;
         for (int32_t i = lane; i < n; i += 64) mtb_ph_jump_init(w, i, ja);
-        __syncthreads();
+        score_sync<IDX>();
         for (int32_t span = 1; span <= maxrank; span <<= 1) {
             for (int32_t i = lane; i < n; i += 64) jb[i] = mtb_ph_jump_step(ja, i);
-            __syncthreads();
+            score_sync<IDX>();
             mtb_jump *t = ja; ja = jb; jb = t;
         }
         if (ja != (mtb_jump *)w.sid) {               /* final records must not sit in the path storage while paths are written */
             for (int32_t i = lane; i < n; i += 64) jb[i] = ja[i];
-            __syncthreads();
+            score_sync<IDX>();
             ja = jb;
         }
         for (int32_t i = lane; i < n; i += 64) { mtb_jump j = ja[i]; w.path[i] = mtb_ph_jump_final(w, i, j); }
-        __syncthreads();
+        score_sync<IDX>();
     } else
     if (simple) {
         mtb_jump *jump = (mtb_jump *)w.path;          /* fresh paths are rebuilt from the roots at the end */
         mtb_jump t[MTB_SCORE_MAXPER];
         for (int32_t i = lane; i < n; i += 64) mtb_ph_jump_init(w, i, jump);
-        __syncthreads();
+        score_sync<IDX>();
         for (int32_t span = 1; span <= maxrank; span <<= 1) {
 #pragma unroll
             for (int k = 0; k < MTB_SCORE_MAXPER; k++) { int32_t i = lane + 64 * k; if (i < n) t[k] = mtb_ph_jump_step(jump, i); }
-            __syncthreads();
+            score_sync<IDX>();
 #pragma unroll
             for (int k = 0; k < MTB_SCORE_MAXPER; k++) { int32_t i = lane + 64 * k; if (i < n) jump[i] = t[k]; }
-            __syncthreads();
+            score_sync<IDX>();
         }
 #pragma unroll
         for (int k = 0; k < MTB_SCORE_MAXPER; k++) { int32_t i = lane + 64 * k; if (i < n) t[k] = jump[i]; }
-        __syncthreads();
+        score_sync<IDX>();
 #pragma unroll
         for (int k = 0; k < MTB_SCORE_MAXPER; k++) { int32_t i = lane + 64 * k; if (i < n) w.path[i] = mtb_ph_jump_final(w, i, t[k]); }
-        __syncthreads();
+        score_sync<IDX>();
     } else if (n <= 64 * MTB_SCORE_MAXPER) {
         /* register-cached round state: idle lanes touch no memory in a round */
         int32_t c_rk[MTB_SCORE_MAXPER]; uint32_t c_sh[MTB_SCORE_MAXPER], c_cm[MTB_SCORE_MAXPER], c_reh[MTB_SCORE_MAXPER]; int32_t c_pl[MTB_SCORE_MAXPER];
@@ -336,12 +347,12 @@ __device__ __forceinline__ void score_read_par(const REC *src, int32_t n, mtb_sw
                     }
                 }
             }
-            __syncthreads();
+            score_sync<IDX>();
         }
     } else {
         for (int32_t r = 1; r <= maxrank; r++) {
             for (int32_t i = lane; i < n; i += 64) mtb_ph_round(w, i, r, &sp);
-            __syncthreads();
+            score_sync<IDX>();
         }
     }
     MTB_PHASE_MARK(6);
@@ -357,7 +368,7 @@ __device__ __forceinline__ void score_read_par(const REC *src, int32_t n, mtb_sw
         if (e) elist[pre] = (IDX)i;
         ne += (int32_t)__popcll(me);
     }
-    __syncthreads();
+    score_sync<IDX>();
     MTB_PHASE_MARK(7);
     /* combine: stable order by parallel rank, certain drops in parallel, then one lane per species for the rest.
      * Dead arrays reused: bid -> sorted list, sid -> start of the entry's species range, shift -> pre-drop flag */
@@ -368,9 +379,9 @@ __device__ __forceinline__ void score_read_par(const REC *src, int32_t n, mtb_sw
         sorted[mtb_ph_comb_rank(w, elist, e, lo, hi)] = elist[e];
         elo[e] = (IDX)lo;
     }
-    __syncthreads();
+    score_sync<IDX>();
     for (int32_t k = lane; k < ne; k += 64) predrop[k] = mtb_ph_comb_predrop(w, sorted, k, (int32_t)elo[k]) ? 1 : 0;
-    __syncthreads();
+    score_sync<IDX>();
     float *sps = (float *)w.grp_start;
     for (int32_t s0 = 0; s0 < nsp; s0 += 64) {
         int32_t s = s0 + lane;
@@ -379,10 +390,10 @@ __device__ __forceinline__ void score_read_par(const REC *src, int32_t n, mtb_sw
             int32_t lo = ec[w.sp_start[s]], hi = (s + 1 < nsp) ? (int32_t)ec[w.sp_start[s + 1]] : ne;
             if (hi > lo) { sc = mtb_ph_comb_greedy(w, sorted, predrop, lo, hi, read_len); sc = sc < 1.0f ? sc : 1.0f; }
         }
-        __syncthreads();                 /* sps[] aliases grp_start/blk_start: all reads above are done */
+        score_sync<IDX>();                 /* sps[] aliases grp_start/blk_start: all reads above are done */
         if (s < nsp) sps[s] = sc;
     }
-    __syncthreads();
+    score_sync<IDX>();
     MTB_PHASE_MARK(8);
     /* select (lane 0), then the redundancy filter over the best species' matches */
     int32_t bs = 0, be = 0, species = 0, go = 0;
@@ -393,16 +404,16 @@ __device__ __forceinline__ void score_read_par(const REC *src, int32_t n, mtb_sw
         bs = __shfl(bs, 0, 64); be = __shfl(be, 0, 64); species = __shfl(species, 0, 64);
         uint32_t *hmin = ocnt;
         for (int32_t q = lane; q < nb; q += 64) { hmin[q] = 255u; btax[q] = -1; }
-        __syncthreads();
+        score_sync<IDX>();
         for (int32_t i = bs + lane; i < be; i += 64) mtb_ph_filter_min(w.m, i, sp.dna_shift, nb, hmin);
-        __syncthreads();
+        score_sync<IDX>();
         for (int32_t i = bs + lane; i < be; i += 64) mtb_ph_filter_merge(w.m, i, sp.dna_shift, nb, hmin, btax, &tx);
-        __syncthreads();
+        score_sync<IDX>();
         for (int32_t q = lane; q < nb; q += 64) bham[q] = hmin[q] == 255u ? 255 : 0;
-        __syncthreads();
+        score_sync<IDX>();
         MTB_PHASE_MARK(10);
         const int32_t ntc = taxcnt_gather_wave(btax, bham, nb, otax, ocnt, (int32_t)tc_room);
-        __syncthreads();
+        score_sync<IDX>();
         MTB_PHASE_MARK(11);
         /* sub-species descent: climb the (few) taxa in parallel, walk the chains on lane 0 */
         bool to_parent = R.score < sp.min_sp_score;          /* R valid on lane 0 only; recomputed below on lane 0 */
@@ -414,7 +425,7 @@ __device__ __forceinline__ void score_read_par(const REC *src, int32_t n, mtb_sw
             if (lv > MTB_LR_K) slow = 1;
         }
         slow = __any(slow) ? 1 : 0;
-        __syncthreads();
+        score_sync<IDX>();
         MTB_PHASE_MARK(12);
         if (lane == 0) {
             R.n_taxcnt = (uint16_t)ntc;
@@ -428,7 +439,7 @@ __device__ __forceinline__ void score_read_par(const REC *src, int32_t n, mtb_sw
                 if (tc_off + k < tc_cap) { tc_tax[tc_off + k] = otax[k]; tc_cnt[tc_off + k] = ocnt[k]; }
         }
     }
-    __syncthreads();
+    score_sync<IDX>();
     MTB_PHASE_MARK(13);
 }
 
@@ -450,6 +461,7 @@ __global__ __launch_bounds__(64, MTB_SCORE_MINWAVES) void k_score(const REC *__r
                                                uint32_t direct, uint32_t epoch, uint32_t *__restrict__ big_list, uint32_t *__restrict__ n_big_out,
                                                uint32_t *__restrict__ cnt_out) {
     __shared__ __attribute__((aligned(16))) uint8_t s_ws[MTB_SCORE_WS_BYTES];
+    __shared__ uint32_t s_pf[64];                 /* landing zone of the slot prefetch (never read) */
     /* bucket / taxCnt / chain arrays of the decide phase live in the path storage,
      * which is dead once the species scores exist (keeps LDS per wave small -> occupancy) */
     static_assert(MTB_SCORE_LDS * sizeof(mtb_path) >= MTB_SCORE_BKT * 13 + (MTB_LR_MAXE + MTB_LR_MAXE * MTB_LR_K) * 4, "decide arrays must fit the path area");
@@ -466,6 +478,17 @@ __global__ __launch_bounds__(64, MTB_SCORE_MINWAVES) void k_score(const REC *__r
         unsigned long long kt0_ = __builtin_readcyclecounter();
 #endif
         const uint64_t r = list ? (uint64_t)list[it] : it;
+        if (cursor && !list && it + gridDim.x < n_iter) {
+            /* slot mode: start pulling the NEXT read's slots towards L2 now (one dword per 128-byte line, delivered
+             * straight into a dummy LDS area: no register, nothing waits for it) -- the slot loads are one dependent
+             * HBM round trip per read with nothing to overlap otherwise */
+            const uint32_t lines = (stride * (uint32_t)sizeof(REC) + 127u) / 128u;
+            if (lane < lines) {
+                const uint8_t *pf = (const uint8_t *)(matches + (it + gridDim.x) * (uint64_t)stride) + (uint64_t)lane * 128u;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)pf,
+                                                 (__attribute__((address_space(3))) void *)s_pf, 4, 0, 0);
+            }
+        }
         /* segment of read r: record slots filled by k_join<SEG> (slot mode), or seg_start indexed by the read or by the list slot */
         uint64_t s0 = 0; int32_t n = 0;
         if (!cursor) {
@@ -489,7 +512,7 @@ __global__ __launch_bounds__(64, MTB_SCORE_MINWAVES) void k_score(const REC *__r
             if (!defer) {
                 const REC *src = matches + r * (uint64_t)stride;
                 uint32_t cnt = 0;
-                __syncthreads();
+                score_sync<uint16_t>();
 #ifdef MTB_SCORE_PHASE_CYCLES
                 { unsigned long long t_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) mtb_phase_lds[15] += t_ - kt0_; kt0_ = t_; }
 #endif
@@ -528,7 +551,7 @@ __global__ __launch_bounds__(64, MTB_SCORE_MINWAVES) void k_score(const REC *__r
                 }
                 n = (int32_t)cnt;
                 defer = cnt > MTB_SCORE_LDS;
-                __syncthreads();
+                score_sync<uint16_t>();
 #ifdef MTB_SCORE_PHASE_CYCLES
                 { unsigned long long t_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) mtb_phase_lds[14] += t_ - kt0_; kt0_ = t_; }
 #endif
