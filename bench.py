@@ -140,7 +140,7 @@ def main():
     ap.add_argument("--cpu-reads", type=int, default=400_000)
     ap.add_argument("--cpu-targets", type=float, default=16e6)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--streams", type=int, default=2, help="HIP streams a batch is pipelined over inside the library")
+    ap.add_argument("--streams", type=int, default=1, help="HIP streams a batch is pipelined over inside the library")
     ap.add_argument("--seq-mode", type=int, default=1, choices=[1, 3], help="1 = short single-end (configs[1]); 3 = long reads (configs[2])")
     ap.add_argument("--partitioned", action="store_true",
                     help="SURVEY 8(e) row 2: every rank owns one value range of the index; metamers and matches travel by all-to-all "

@@ -449,7 +449,7 @@ static mtb_status dev_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, uint
             while ((uint64_t)grid * slab_bytes > (8ull << 30) && grid > 64) grid /= 2;      /* keep the slab pool below 8 GiB */
             STCHK(ensure(c, "slabs", (size_t)grid * slab_bytes, &d_slabs));
         }
-        KTimer kt(c, MTB_K_SCORE);
+        KTimer kt(c, pass == 0 ? MTB_K_SCORE : MTB_K_SEGSORT);      /* the deferred reads' launch is booked with the large-segment path */
 #define MTB_LAUNCH_SCORE(SRT, K) hipLaunchKernelGGL((k_score<SRT, K, mtb_match>), dim3(grid), dim3(64), 0, c->stream, S->m, S->seg, n_reads, d_qlen, \
         d_qlen2, tax_view(ix), sp, (const uint64_t *)d_tcoff, d_res, d_tc_tax, d_tc_cnt, tc_cap, d_slabs, slab_bytes, slab_n, slab_nb, (mtb_match *)nullptr,  \
         tc_base, S->list, S->n_list, S->cursor, S->stride, S->seg_by_list, S->direct, S->epoch, S->big_list, S->n_big, S->cnt_out)
