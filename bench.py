@@ -67,9 +67,11 @@ def extract_targets(ctx, M, world, params):
     return vals[order], tids[order]
 
 
-def gen_reads(torch, dev, world, n_reads, read_len, frac_random, err, seed):
+def gen_reads(torch, dev, world, n_reads, read_len, frac_random, err, seed, paired=False, frag_len=400):
     """Reads sampled from the genomes (both strands, substitutions) + random
-    reads, generated on the device so that the inputs are HBM-resident."""
+    reads, generated on the device so that the inputs are HBM-resident.
+    paired: fragments of frag_len bases, mate 1 = its first read_len bases, mate 2 = the first read_len bases of its
+    reverse complement (BASELINE.json configs[3] shape); returns (bases1, offs, bases2)."""
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
     G = torch.from_numpy(np.concatenate([x for _, x in world.genomes]).astype(np.uint8)).to(dev)
@@ -80,21 +82,29 @@ def gen_reads(torch, dev, world, n_reads, read_len, frac_random, err, seed):
         comp[a] = b
     acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
     out = torch.empty(n_reads * read_len, dtype=torch.uint8, device=dev)
-    ar = torch.arange(read_len, device=dev, dtype=torch.int64)
+    out2 = torch.empty(n_reads * read_len, dtype=torch.uint8, device=dev) if paired else None
+    span = frag_len if paired else read_len
+    ar = torch.arange(span, device=dev, dtype=torch.int64)
     chunk = 1_000_000
     for c0 in range(0, n_reads, chunk):
         n = min(chunk, n_reads - c0)
         gi = torch.randint(0, len(lens), (n,), generator=g, device=dev)
-        st = (torch.rand(n, generator=g, device=dev) * (lens[gi] - read_len + 1).float()).long().clamp_(min=0) + starts[gi]
+        st = (torch.rand(n, generator=g, device=dev) * (lens[gi] - span + 1).float()).long().clamp_(min=0) + starts[gi]
         r = G[st[:, None] + ar[None, :]]
         rc = torch.rand(n, generator=g, device=dev) < 0.5
         r = torch.where(rc[:, None], comp[r.long()].flip(1), r)
-        sub = torch.rand(n, read_len, generator=g, device=dev) < err
-        r = torch.where(sub, acgt[torch.randint(0, 4, (n, read_len), generator=g, device=dev)], r)
+        sub = torch.rand(n, span, generator=g, device=dev) < err
+        r = torch.where(sub, acgt[torch.randint(0, 4, (n, span), generator=g, device=dev)], r)
         rnd = torch.rand(n, generator=g, device=dev) < frac_random
-        r = torch.where(rnd[:, None], acgt[torch.randint(0, 4, (n, read_len), generator=g, device=dev)], r)
-        out[c0 * read_len:(c0 + n) * read_len] = r.reshape(-1)
+        r = torch.where(rnd[:, None], acgt[torch.randint(0, 4, (n, span), generator=g, device=dev)], r)
+        if paired:
+            out[c0 * read_len:(c0 + n) * read_len] = r[:, :read_len].reshape(-1)
+            out2[c0 * read_len:(c0 + n) * read_len] = comp[r.long()].flip(1)[:, :read_len].reshape(-1)
+        else:
+            out[c0 * read_len:(c0 + n) * read_len] = r.reshape(-1)
     offs = torch.arange(n_reads + 1, device=dev, dtype=torch.int64) * read_len
+    if paired:
+        return out, offs, out2
     return out, offs
 
 
@@ -141,7 +151,8 @@ def main():
     ap.add_argument("--cpu-targets", type=float, default=16e6)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams a batch is pipelined over inside the library")
-    ap.add_argument("--seq-mode", type=int, default=1, choices=[1, 3], help="1 = short single-end (configs[1]); 3 = long reads (configs[2])")
+    ap.add_argument("--seq-mode", type=int, default=1, choices=[1, 2, 3],
+                    help="1 = short single-end (configs[1]); 2 = paired-end, --reads pairs of 2 x --read-len (configs[3] shape); 3 = long reads (configs[2])")
     ap.add_argument("--partitioned", action="store_true",
                     help="SURVEY 8(e) row 2: every rank owns one value range of the index; metamers and matches travel by all-to-all "
                          "(functional/perf check of that path; the default is the replicated index)")
@@ -183,9 +194,14 @@ def main():
     T = ctx.synth_index(args.seed, n_filler, world.filler_tax_lo, world.filler_tax_hi, real_v, real_t, d_values.data_ptr(), d_info.data_ptr())
     taxid_list = np.concatenate([np.unique(real_t), np.arange(world.filler_tax_lo, world.filler_tax_hi + 1, dtype=np.int32)])
     index = ctx.index_from_device(d_values.data_ptr(), d_info.data_ptr(), T, taxdir, taxid_list, params)
-    d_bases, d_offs = gen_reads(torch, dev, world, args.reads, args.read_len, 0.10, 0.005, args.seed + 17 * (rank + 1))
+    d_bases2 = None
+    if args.seq_mode == 2:
+        d_bases, d_offs, d_bases2 = gen_reads(torch, dev, world, args.reads, args.read_len, 0.10, 0.005, args.seed + 17 * (rank + 1), paired=True)
+    else:
+        d_bases, d_offs = gen_reads(torch, dev, world, args.reads, args.read_len, 0.10, 0.005, args.seed + 17 * (rank + 1))
+    n_bases_step = args.reads * args.read_len * (2 if args.seq_mode == 2 else 1)
     d_res = torch.empty(args.reads * 24, dtype=torch.uint8, device=dev)
-    tc_cap = args.reads * (20 + args.read_len // 9) + 1024
+    tc_cap = args.reads * (20 + args.read_len // 9) * (2 if args.seq_mode == 2 else 1) + 1024
     d_tt = torch.empty(tc_cap, dtype=torch.int32, device=dev); d_tc = torch.empty(tc_cap, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
     log(f"[rank {rank}] setup {time.perf_counter()-t_setup:.1f}s: T={T} ({len(real_v)} genome-derived), reads={args.reads}x{args.read_len}")
@@ -211,8 +227,9 @@ def main():
         if part is not None:
             last["res"] = parallel.classify_partitioned(stages, bounds, dist)
             return 0
-        return ctx.classify_batch_device(index, params, d_bases.data_ptr(), d_offs.data_ptr(), 0, 0, args.reads,
-                                         args.reads * args.read_len, d_res.data_ptr(), d_tt.data_ptr(), d_tc.data_ptr(), tc_cap)
+        return ctx.classify_batch_device(index, params, d_bases.data_ptr(), d_offs.data_ptr(),
+                                         d_bases2.data_ptr() if d_bases2 is not None else 0, d_offs.data_ptr() if d_bases2 is not None else 0,
+                                         args.reads, n_bases_step, d_res.data_ptr(), d_tt.data_ptr(), d_tc.data_ptr(), tc_cap)
 
     def barrier():
         torch.cuda.synchronize()
@@ -285,7 +302,7 @@ def main():
         raise SystemExit(f"sanity check failed: only {frac_cls:.4f} of the reads were classified")
 
     cpu = None
-    if rank == 0 and not args.no_cpu and world_size == 1:
+    if rank == 0 and not args.no_cpu and world_size == 1 and args.seq_mode != 2:
         cpu, R = cpu_baseline(ctx, M, torch, dev, world, real_v, real_t, params, taxdir, d_bases, args.read_len,
                               min(args.cpu_reads, args.reads), int(args.cpu_targets), args.seed)
         cpu.pop("seconds", None)
@@ -297,11 +314,11 @@ def main():
                    value=value, unit="Mreads/s", n_gpus=world_size, steps=args.steps, warmup=args.warmup,
                    ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None,
                    dtype="u64", data="synthetic",
-                   config=dict(workload=f"{args.reads/1e6:g}M x {args.read_len} bp synthetic single-end reads per GPU vs synthetic "
+                   config=dict(workload=f"{args.reads/1e6:g}M x {'2 x ' if args.seq_mode == 2 else ''}{args.read_len} bp synthetic {'paired-end' if args.seq_mode == 2 else 'single-end'} reads per GPU vs synthetic "
                                         f"GTDB-scale index of {T/1e9:.2f} G metamers ({T*12/2**30:.0f} GiB flat, replicated per GPU), "
                                         f"syncmer s=5, kmer_format 2 (BASELINE.json configs[1])",
                                reads_per_gpu=args.reads, read_len=args.read_len, targets=int(T), seq_mode=args.seq_mode,
-                               gbp_per_s=value * args.read_len / 1e3, query_metamers=int(st.n_kmers), matches=int(st.n_matches),
+                               gbp_per_s=value * args.read_len * (2 if args.seq_mode == 2 else 1) / 1e3, query_metamers=int(st.n_kmers), matches=int(st.n_matches),
                                classified_fraction=frac_cls, parallelism=f"reads sharded x{world_size}, index replicated", streams_per_gpu=args.streams),
                    stage_ms=dict(extract=st.ms_extract, sort=st.ms_sort, join=st.ms_join, regroup=st.ms_regroup,
                                  segsort=st.ms_segsort, score=st.ms_score, total=st.ms_total),

@@ -114,14 +114,14 @@ __device__ __forceinline__ void score_sync() {
  * site lives in ONE address space (LDS or an HBM slab) so that the compiler
  * emits ds_* / global_* instead of flat accesses.  SORT: the segment arrives
  * unordered and holds at most 64*MAXPER matches: rank sort on 12-byte keys. */
-#define MTB_SCORE_MAXPER 3
-template <typename IDX, bool SORT, bool KEY64, typename REC, bool INPLACE = false>
+template <typename IDX, bool SORT, bool KEY64, typename REC, bool INPLACE = false, int CAP = MTB_SCORE_LDS>
 __device__ __forceinline__ void score_read_par(const REC *src, int32_t n, mtb_sws<IDX> w, int32_t *btax,
                                                uint8_t *bham, int32_t *otax, uint32_t *ocnt, int32_t *lr_lev, int32_t *lr_anc,
                                                int32_t nb, int32_t read_len, const mtb_tax_view &tx, const mtb_score_params &sp,
                                                uint64_t tc_off, uint64_t tc_room, int32_t *__restrict__ tc_tax,
                                                uint32_t *__restrict__ tc_cnt, uint64_t tc_cap, mtb_match *__restrict__ sorted_out,
                                                mtb_result &R) {
+    constexpr int MAXPER = (CAP + 63) / 64;          /* register slots per lane that cover a staged segment */
     const int32_t lane = (int32_t)threadIdx.x;
     const uint64_t lt = lanemask_lt();
     w.n = n;
@@ -131,9 +131,9 @@ __device__ __forceinline__ void score_read_par(const REC *src, int32_t n, mtb_sw
          * KEY64 (host-checked: taxids < 2^22, positions < 2^11): the whole
          * compareMatches key fits one 64-bit word. */
         uint64_t *k1 = (uint64_t *)w.path; uint32_t *k2 = (uint32_t *)(k1 + n);
-        mtb_match rec[MTB_SCORE_MAXPER]; uint64_t a1[MTB_SCORE_MAXPER]; uint32_t a2[MTB_SCORE_MAXPER]; int32_t rank[MTB_SCORE_MAXPER];
+        mtb_match rec[MAXPER]; uint64_t a1[MAXPER]; uint32_t a2[MAXPER]; int32_t rank[MAXPER];
 #pragma unroll
-        for (int k = 0; k < MTB_SCORE_MAXPER; k++) {
+        for (int k = 0; k < MAXPER; k++) {
             int32_t i = lane + 64 * k;
             rank[k] = 0; a1[k] = 0; a2[k] = 0;
             if (i < n) {
@@ -148,22 +148,49 @@ __device__ __forceinline__ void score_read_par(const REC *src, int32_t n, mtb_sw
         score_sync<IDX>();
         MTB_PHASE_MARK(0);
         const int32_t nslot = (n + 63) >> 6;          /* live register slots (wave-uniform) */
-        /* already in order?  (slot mode: one match per query and one species = extraction order = compareMatches order) */
-        bool sorted = true;
+        /* already in order?  (slot mode: one match per query and one species = extraction order = compareMatches order).
+         * Exactly one descent = two ordered runs (the two mates of a pair, whose slots are mate-major while the order is
+         * frame-major): merge by rank, one binary search in the other run per record. */
+        uint32_t n_desc = 0; int32_t split = 0;
 #pragma unroll
-        for (int k = 0; k < MTB_SCORE_MAXPER; k++) {
+        for (int k = 0; k < MAXPER; k++) {
             int32_t i = lane + 64 * k;
+            bool desc = false;
             if (i > 0 && i < n) {
                 uint64_t p1 = k1[i - 1];
-                if (KEY64) sorted = sorted && p1 <= a1[k];
-                else { uint32_t p2 = k2[i - 1]; sorted = sorted && (p1 < a1[k] || (p1 == a1[k] && p2 <= a2[k])); }
+                if (KEY64) desc = p1 > a1[k];
+                else { uint32_t p2 = k2[i - 1]; desc = p1 > a1[k] || (p1 == a1[k] && p2 > a2[k]); }
             }
+            const uint64_t md = __ballot(desc);
+            if (md) { if (n_desc == 0) split = 64 * k + (int32_t)__builtin_ctzll(md); n_desc += (uint32_t)__popcll(md); }
         }
-        sorted = __all(sorted);
+        const bool sorted = n_desc == 0;
+        bool merged = false;
         bool unique = true;
         if (sorted) {
 #pragma unroll
-            for (int k = 0; k < MTB_SCORE_MAXPER; k++) rank[k] = lane + 64 * k;
+            for (int k = 0; k < MAXPER; k++) rank[k] = lane + 64 * k;
+        } else if (n_desc == 1) {
+            merged = true;
+#pragma unroll
+            for (int k = 0; k < MAXPER; k++) {
+                int32_t i = lane + 64 * k;
+                if (i < n) {
+                    /* first run [0, split): + elements of the second run strictly smaller; second run: + elements of the first run <= */
+                    const bool first = i < split;
+                    int32_t lo = first ? split : 0, hi = first ? n : split;
+                    const int32_t base0 = lo;
+                    while (lo < hi) {
+                        const int32_t mid = (lo + hi) >> 1;
+                        const uint64_t b1 = k1[mid];
+                        bool less;                      /* key[mid] < key_i (first) or key[mid] <= key_i (second) */
+                        if (KEY64) less = first ? b1 < a1[k] : b1 <= a1[k];
+                        else { const uint32_t b2 = k2[mid]; less = b1 < a1[k] || (b1 == a1[k] && (first ? b2 < a2[k] : b2 <= a2[k])); }
+                        if (less) lo = mid + 1; else hi = mid;
+                    }
+                    rank[k] = (first ? i : i - split) + (lo - base0);
+                }
+            }
         } else
         if (KEY64) {
             /* fast path: rank = number of strictly smaller keys (2 VALU per comparison).  Keys are
@@ -176,27 +203,27 @@ __device__ __forceinline__ void score_read_par(const REC *src, int32_t n, mtb_sw
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
 #pragma unroll
-                    for (int k = 0; k < MTB_SCORE_MAXPER; k++) if (k < nslot) rank[k] += (b1[u] < a1[k]);
+                    for (int k = 0; k < MAXPER; k++) if (k < nslot) rank[k] += (b1[u] < a1[k]);
                 }
             }
             for (; j < n; j++) {
                 uint64_t b1 = k1[j];
 #pragma unroll
-                for (int k = 0; k < MTB_SCORE_MAXPER; k++) rank[k] += (b1 < a1[k]);
+                for (int k = 0; k < MAXPER; k++) rank[k] += (b1 < a1[k]);
             }
             /* two equal keys get the same rank: then some key differs from the one stored at its rank */
             score_sync<IDX>();
             uint64_t *chk = (uint64_t *)w.m;          /* m[] is not written yet */
 #pragma unroll
-            for (int k = 0; k < MTB_SCORE_MAXPER; k++) { int32_t i = lane + 64 * k; if (i < n) chk[rank[k]] = (uint64_t)i; }
+            for (int k = 0; k < MAXPER; k++) { int32_t i = lane + 64 * k; if (i < n) chk[rank[k]] = (uint64_t)i; }
             score_sync<IDX>();
 #pragma unroll
-            for (int k = 0; k < MTB_SCORE_MAXPER; k++) { int32_t i = lane + 64 * k; if (i < n && chk[rank[k]] != (uint64_t)i) unique = false; }
+            for (int k = 0; k < MAXPER; k++) { int32_t i = lane + 64 * k; if (i < n && chk[rank[k]] != (uint64_t)i) unique = false; }
             unique = __all(unique);
         }
-        if (!sorted && (!KEY64 || !unique)) {
+        if (!sorted && !merged && (!KEY64 || !unique)) {
 #pragma unroll
-            for (int k = 0; k < MTB_SCORE_MAXPER; k++) rank[k] = 0;
+            for (int k = 0; k < MAXPER; k++) rank[k] = 0;
             int32_t j = 0;
             for (; j + 4 <= n; j += 4) {                  /* 4 independent LDS reads in flight */
                 uint64_t b1[4]; uint32_t b2[4];
@@ -205,7 +232,7 @@ __device__ __forceinline__ void score_read_par(const REC *src, int32_t n, mtb_sw
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
 #pragma unroll
-                    for (int k = 0; k < MTB_SCORE_MAXPER; k++) {
+                    for (int k = 0; k < MAXPER; k++) {
                         if (k < nslot) {
                             int32_t i = lane + 64 * k;
                             if (KEY64) rank[k] += (b1[u] < a1[k]) || (b1[u] == a1[k] && (j + u) < i);
@@ -217,7 +244,7 @@ __device__ __forceinline__ void score_read_par(const REC *src, int32_t n, mtb_sw
             for (; j < n; j++) {
                 uint64_t b1 = k1[j]; uint32_t b2 = KEY64 ? 0u : k2[j];
 #pragma unroll
-                for (int k = 0; k < MTB_SCORE_MAXPER; k++) {
+                for (int k = 0; k < MAXPER; k++) {
                     int32_t i = lane + 64 * k;
                     if (KEY64) rank[k] += (b1 < a1[k]) || (b1 == a1[k] && j < i);
                     else rank[k] += (b1 < a1[k]) || (b1 == a1[k] && (b2 < a2[k] || (b2 == a2[k] && j < i)));
@@ -228,7 +255,7 @@ __device__ __forceinline__ void score_read_par(const REC *src, int32_t n, mtb_sw
         MTB_PHASE_MARK(1);
         if (!(INPLACE && sorted)) {
 #pragma unroll
-            for (int k = 0; k < MTB_SCORE_MAXPER; k++) { int32_t i = lane + 64 * k; if (i < n) w.m[rank[k]] = rec[k]; }
+            for (int k = 0; k < MAXPER; k++) { int32_t i = lane + 64 * k; if (i < n) w.m[rank[k]] = rec[k]; }
         }
         score_sync<IDX>();
         if (sorted_out) {
@@ -266,7 +293,7 @@ __device__ __forceinline__ void score_read_par(const REC *src, int32_t n, mtb_sw
     score_sync<IDX>();
     MTB_PHASE_MARK(5);
     /* chain DP: pointer doubling when every match has <= 1 consecutive predecessor, else rounds */
-    const bool small_n = n <= 64 * MTB_SCORE_MAXPER;
+    const bool small_n = n <= 64 * MAXPER;
     bool simple = small_n || sizeof(IDX) == 4;      /* big segments need the 32-bit workspace for the ping-pong array */
     if (simple) {
         for (int32_t i = lane; i < n; i += 64) simple = simple && mtb_chain_simple(w, i);
@@ -292,28 +319,28 @@ __device__ __forceinline__ void score_read_par(const REC *src, int32_t n, mtb_sw
     } else
     if (simple) {
         mtb_jump *jump = (mtb_jump *)w.path;          /* fresh paths are rebuilt from the roots at the end */
-        mtb_jump t[MTB_SCORE_MAXPER];
+        mtb_jump t[MAXPER];
         for (int32_t i = lane; i < n; i += 64) mtb_ph_jump_init(w, i, jump);
         score_sync<IDX>();
         for (int32_t span = 1; span <= maxrank; span <<= 1) {
 #pragma unroll
-            for (int k = 0; k < MTB_SCORE_MAXPER; k++) { int32_t i = lane + 64 * k; if (i < n) t[k] = mtb_ph_jump_step(jump, i); }
+            for (int k = 0; k < MAXPER; k++) { int32_t i = lane + 64 * k; if (i < n) t[k] = mtb_ph_jump_step(jump, i); }
             score_sync<IDX>();
 #pragma unroll
-            for (int k = 0; k < MTB_SCORE_MAXPER; k++) { int32_t i = lane + 64 * k; if (i < n) jump[i] = t[k]; }
+            for (int k = 0; k < MAXPER; k++) { int32_t i = lane + 64 * k; if (i < n) jump[i] = t[k]; }
             score_sync<IDX>();
         }
 #pragma unroll
-        for (int k = 0; k < MTB_SCORE_MAXPER; k++) { int32_t i = lane + 64 * k; if (i < n) t[k] = jump[i]; }
+        for (int k = 0; k < MAXPER; k++) { int32_t i = lane + 64 * k; if (i < n) t[k] = jump[i]; }
         score_sync<IDX>();
 #pragma unroll
-        for (int k = 0; k < MTB_SCORE_MAXPER; k++) { int32_t i = lane + 64 * k; if (i < n) w.path[i] = mtb_ph_jump_final(w, i, t[k]); }
+        for (int k = 0; k < MAXPER; k++) { int32_t i = lane + 64 * k; if (i < n) w.path[i] = mtb_ph_jump_final(w, i, t[k]); }
         score_sync<IDX>();
-    } else if (n <= 64 * MTB_SCORE_MAXPER) {
+    } else if (n <= 64 * MAXPER) {
         /* register-cached round state: idle lanes touch no memory in a round */
-        int32_t c_rk[MTB_SCORE_MAXPER]; uint32_t c_sh[MTB_SCORE_MAXPER], c_cm[MTB_SCORE_MAXPER], c_reh[MTB_SCORE_MAXPER]; int32_t c_pl[MTB_SCORE_MAXPER];
+        int32_t c_rk[MAXPER]; uint32_t c_sh[MAXPER], c_cm[MAXPER], c_reh[MAXPER]; int32_t c_pl[MAXPER];
 #pragma unroll
-        for (int k = 0; k < MTB_SCORE_MAXPER; k++) {
+        for (int k = 0; k < MAXPER; k++) {
             int32_t i = lane + 64 * k;
             c_rk[k] = -1; c_sh[k] = 0; c_cm[k] = 0; c_pl[k] = 0; c_reh[k] = 0;
             if (i < n) {
@@ -323,7 +350,7 @@ __device__ __forceinline__ void score_read_par(const REC *src, int32_t n, mtb_sw
         }
         for (int32_t r = 1; r <= maxrank; r++) {
 #pragma unroll
-            for (int k = 0; k < MTB_SCORE_MAXPER; k++) {
+            for (int k = 0; k < MAXPER; k++) {
                 bool act = c_rk[k] == r;
                 if (!__any(act)) continue;
                 if (act) {
@@ -447,9 +474,10 @@ __device__ __forceinline__ void score_read_par(const REC *src, int32_t n, mtb_sw
  * wave rank-sorts the staged segment (compareMatches order) and, if
  * sorted_out != NULL, writes it back.  Segments larger than MTB_SCORE_LDS must
  * already be sorted in HBM (k_segsort_large).                               */
-#define MTB_SCORE_WS_BYTES ((MTB_SCORE_LDS * (24 + 24 + 3) + (MTB_SCORE_LDS + 1) * 8 * 2 + 64 + 15) & ~15)
-template <bool SORT, bool KEY64, typename REC>
-__global__ __launch_bounds__(64, MTB_SCORE_MINWAVES) void k_score(const REC *__restrict__ matches, const uint64_t *__restrict__ seg_start,
+#define MTB_SCORE_WS_BYTES_(C) (((C) * (24 + 24 + 3) + ((C) + 1) * 8 * 2 + 64 + 15) & ~15)
+/* CAP = matches staged in LDS per read: 160 (10.8 KB per wave, 14 waves/CU) for single reads, 320 for read pairs */
+template <bool SORT, bool KEY64, typename REC, int CAP = MTB_SCORE_LDS>
+__global__ __launch_bounds__(64, (CAP > MTB_SCORE_LDS ? 2 : MTB_SCORE_MINWAVES)) void k_score(const REC *__restrict__ matches, const uint64_t *__restrict__ seg_start,
                                                uint64_t n_reads, const int32_t *__restrict__ qlen, const int32_t *__restrict__ qlen2,
                                                mtb_tax_view tx, mtb_score_params sp, const uint64_t *__restrict__ tc_off,
                                                mtb_result *__restrict__ results, int32_t *__restrict__ tc_tax,
@@ -460,11 +488,11 @@ __global__ __launch_bounds__(64, MTB_SCORE_MINWAVES) void k_score(const REC *__r
                                                const uint32_t *__restrict__ cursor, uint32_t stride, int seg_by_list,
                                                uint32_t direct, uint32_t epoch, uint32_t *__restrict__ big_list, uint32_t *__restrict__ n_big_out,
                                                uint32_t *__restrict__ cnt_out) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_ws[MTB_SCORE_WS_BYTES];
+    __shared__ __attribute__((aligned(16))) uint8_t s_ws[MTB_SCORE_WS_BYTES_(CAP)];
     __shared__ uint32_t s_pf[64];                 /* landing zone of the slot prefetch (never read) */
     /* bucket / taxCnt / chain arrays of the decide phase live in the path storage,
      * which is dead once the species scores exist (keeps LDS per wave small -> occupancy) */
-    static_assert(MTB_SCORE_LDS * sizeof(mtb_path) >= MTB_SCORE_BKT * 13 + (MTB_LR_MAXE + MTB_LR_MAXE * MTB_LR_K) * 4, "decide arrays must fit the path area");
+    static_assert(CAP * sizeof(mtb_path) >= MTB_SCORE_BKT * 13 + (MTB_LR_MAXE + MTB_LR_MAXE * MTB_LR_K) * 4, "decide arrays must fit the path area");
 #ifdef MTB_EXP_HALF_OCCUPANCY
     __shared__ uint32_t s_dummy[4096];
     if (n_reads == 0xFFFFFFFFFFull) s_dummy[threadIdx.x] = 1;   /* keep the allocation alive */
@@ -507,7 +535,7 @@ __global__ __launch_bounds__(64, MTB_SCORE_MINWAVES) void k_score(const REC *__r
              * (tail overflow, more live records than the staging, too many position buckets) go to big_list */
             const uint32_t cur = cursor[r], tail_cap = stride - direct;
             mtb_sws<uint16_t> w;
-            mtb_sws_carve<uint16_t>(&w, s_ws, MTB_SCORE_LDS);
+            mtb_sws_carve<uint16_t>(&w, s_ws, CAP);
             bool defer = cur > tail_cap || nb > MTB_SCORE_BKT;
             if (!defer) {
                 const REC *src = matches + r * (uint64_t)stride;
@@ -535,7 +563,7 @@ __global__ __launch_bounds__(64, MTB_SCORE_MINWAVES) void k_score(const REC *__r
                         const bool live = i < stride && (uint32_t)(wc[k] >> 56) == epoch && (i < direct || i - direct < cur);
                         const uint64_t mask = __ballot(live);
                         const uint32_t pos = cnt + (uint32_t)__popcll(mask & lanemask_lt());
-                        if (live && pos < MTB_SCORE_LDS) { dst64[3 * pos] = wa[k]; dst64[3 * pos + 1] = wb[k]; dst64[3 * pos + 2] = wc[k] & 0x00FFFFFFFFFFFFFFull; }
+                        if (live && pos < CAP) { dst64[3 * pos] = wa[k]; dst64[3 * pos + 1] = wb[k]; dst64[3 * pos + 2] = wc[k] & 0x00FFFFFFFFFFFFFFull; }
                         cnt += (uint32_t)__popcll(mask);
                     }
                 } else
@@ -546,11 +574,11 @@ __global__ __launch_bounds__(64, MTB_SCORE_MINWAVES) void k_score(const REC *__r
                     const bool live = i < stride && (uint32_t)(cc >> 56) == epoch && (i < direct || i - direct < cur);
                     const uint64_t mask = __ballot(live);
                     const uint32_t pos = cnt + (uint32_t)__popcll(mask & lanemask_lt());
-                    if (live && pos < MTB_SCORE_LDS) { dst64[3 * pos] = a; dst64[3 * pos + 1] = b; dst64[3 * pos + 2] = cc & 0x00FFFFFFFFFFFFFFull; }
+                    if (live && pos < CAP) { dst64[3 * pos] = a; dst64[3 * pos + 1] = b; dst64[3 * pos + 2] = cc & 0x00FFFFFFFFFFFFFFull; }
                     cnt += (uint32_t)__popcll(mask);
                 }
                 n = (int32_t)cnt;
-                defer = cnt > MTB_SCORE_LDS;
+                defer = cnt > CAP;
                 score_sync<uint16_t>();
 #ifdef MTB_SCORE_PHASE_CYCLES
                 { unsigned long long t_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) mtb_phase_lds[14] += t_ - kt0_; kt0_ = t_; }
@@ -563,21 +591,21 @@ __global__ __launch_bounds__(64, MTB_SCORE_MINWAVES) void k_score(const REC *__r
             uint32_t *s_ocnt = (uint32_t *)(s_otax + MTB_SCORE_BKT);
             int32_t *s_lev = (int32_t *)(s_ocnt + MTB_SCORE_BKT), *s_anc = s_lev + MTB_LR_MAXE;
             uint8_t *s_bham = (uint8_t *)(s_anc + MTB_LR_MAXE * MTB_LR_K);
-            score_read_par<uint16_t, true, KEY64, mtb_match, true>(w.m, n, w, s_btax, s_bham, s_otax, s_ocnt, s_lev, s_anc, nb, read_len, tx, sp, off, room,
+            score_read_par<uint16_t, true, KEY64, mtb_match, true, CAP>(w.m, n, w, s_btax, s_bham, s_otax, s_ocnt, s_lev, s_anc, nb, read_len, tx, sp, off, room,
                                                                      tc_tax, tc_cnt, tc_cap, (mtb_match *)nullptr, R);
             if (lane == 0) { R.query_length = ql1; R.query_length2 = ql2; R.reserved = 0; R.taxcnt_off += (uint32_t)tc_base; results[r] = R; }
             continue;
         }
         if (n == 0) { if (lane == 0) results[r] = R; continue; }
-        const bool big = n > MTB_SCORE_LDS || nb > MTB_SCORE_BKT;
+        const bool big = n > CAP || nb > MTB_SCORE_BKT;
         if (!big) {
             mtb_sws<uint16_t> w;
-            mtb_sws_carve<uint16_t>(&w, s_ws, MTB_SCORE_LDS);
+            mtb_sws_carve<uint16_t>(&w, s_ws, CAP);
             int32_t *s_btax = (int32_t *)w.path, *s_otax = s_btax + MTB_SCORE_BKT;
             uint32_t *s_ocnt = (uint32_t *)(s_otax + MTB_SCORE_BKT);
             int32_t *s_lev = (int32_t *)(s_ocnt + MTB_SCORE_BKT), *s_anc = s_lev + MTB_LR_MAXE;
             uint8_t *s_bham = (uint8_t *)(s_anc + MTB_LR_MAXE * MTB_LR_K);
-            score_read_par<uint16_t, SORT, KEY64, REC>(matches + s0, n, w, s_btax, s_bham, s_otax, s_ocnt, s_lev, s_anc, nb, read_len, tx, sp, off, room,
+            score_read_par<uint16_t, SORT, KEY64, REC, false, CAP>(matches + s0, n, w, s_btax, s_bham, s_otax, s_ocnt, s_lev, s_anc, nb, read_len, tx, sp, off, room,
                                            tc_tax, tc_cnt, tc_cap, sorted_out ? sorted_out + s0 : nullptr, R);
         } else {
             if ((uint32_t)n > slab_max_n || (uint32_t)nb > slab_max_nb) {      /* cannot happen: slabs are sized from the maxima */
@@ -592,8 +620,8 @@ __global__ __launch_bounds__(64, MTB_SCORE_MINWAVES) void k_score(const REC *__r
             int32_t *btax = (int32_t *)p; int32_t *otax = btax + B; uint32_t *ocnt = (uint32_t *)(otax + B);
             int32_t *lev = (int32_t *)(ocnt + B); int32_t *anc = lev + MTB_LR_MAXE; uint8_t *bham = (uint8_t *)(anc + MTB_LR_MAXE * MTB_LR_K);
             /* big segments are pre-sorted in HBM; a small segment of a long read still needs its sort */
-            if (SORT && n <= MTB_SCORE_LDS)
-                score_read_par<uint32_t, true, KEY64, REC>(matches + s0, n, w, btax, bham, otax, ocnt, lev, anc, nb, read_len, tx, sp, off, room, tc_tax, tc_cnt,
+            if (SORT && n <= CAP)
+                score_read_par<uint32_t, true, KEY64, REC, false, CAP>(matches + s0, n, w, btax, bham, otax, ocnt, lev, anc, nb, read_len, tx, sp, off, room, tc_tax, tc_cnt,
                                                tc_cap, sorted_out ? sorted_out + s0 : nullptr, R);
             else
                 score_read_par<uint32_t, false, false, REC>(matches + s0, n, w, btax, bham, otax, ocnt, lev, anc, nb, read_len, tx, sp, off, room, tc_tax, tc_cnt,

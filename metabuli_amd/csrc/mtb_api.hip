@@ -399,6 +399,7 @@ struct ScoreSrc {
     uint32_t stride = 0, direct = 0, epoch = 0;
     uint32_t *big_list = nullptr, *n_big = nullptr;      /* slot mode: reads deferred to the large-segment path */
     uint32_t *cnt_out = nullptr;                         /* slot mode: live records per read */
+    uint32_t cap = MTB_SCORE_LDS;                        /* matches staged in LDS per read: 160, or 320 (read pairs on the slot path) */
     const uint32_t *list = nullptr, *n_list = nullptr;   /* only these reads */
     int seg_by_list = 0;
     bool sort = false;                    /* segments arrive unordered: rank sort in the kernel */
@@ -440,7 +441,7 @@ static mtb_status dev_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, uint
         }
         uint32_t grid = S->grid ? S->grid : (uint32_t)std::min<uint64_t>(n_reads, 256ull * 12);
         /* reads with a big segment OR many position buckets are scored entirely out of a slab */
-        bool need_slab = S->max_seg > MTB_SCORE_LDS || max_nb > MTB_SCORE_BKT;
+        bool need_slab = S->max_seg > S->cap || max_nb > MTB_SCORE_BKT;
         uint32_t slab_n = need_slab ? std::max<uint32_t>(S->max_seg, 1) : 0;
         uint32_t slab_nb = need_slab ? max_nb : 0;
         uint64_t slab_bytes = need_slab ? score_slab_bytes(slab_n, slab_nb) : 0;
@@ -450,11 +451,12 @@ static mtb_status dev_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, uint
             STCHK(ensure(c, "slabs", (size_t)grid * slab_bytes, &d_slabs));
         }
         KTimer kt(c, pass == 0 ? MTB_K_SCORE : MTB_K_SEGSORT);      /* the deferred reads' launch is booked with the large-segment path */
-#define MTB_LAUNCH_SCORE(SRT, K) hipLaunchKernelGGL((k_score<SRT, K, mtb_match>), dim3(grid), dim3(64), 0, c->stream, S->m, S->seg, n_reads, d_qlen, \
+#define MTB_LAUNCH_SCORE(SRT, K, CAPV) hipLaunchKernelGGL((k_score<SRT, K, mtb_match, CAPV>), dim3(grid), dim3(64), 0, c->stream, S->m, S->seg, n_reads, d_qlen, \
         d_qlen2, tax_view(ix), sp, (const uint64_t *)d_tcoff, d_res, d_tc_tax, d_tc_cnt, tc_cap, d_slabs, slab_bytes, slab_n, slab_nb, (mtb_match *)nullptr,  \
         tc_base, S->list, S->n_list, S->cursor, S->stride, S->seg_by_list, S->direct, S->epoch, S->big_list, S->n_big, S->cnt_out)
-        if (S->sort) { if (key64) MTB_LAUNCH_SCORE(true, true); else MTB_LAUNCH_SCORE(true, false); }
-        else MTB_LAUNCH_SCORE(false, false);
+        if (S->sort && S->cap > MTB_SCORE_LDS) { if (key64) MTB_LAUNCH_SCORE(true, true, 320); else MTB_LAUNCH_SCORE(true, false, 320); }
+        else if (S->sort) { if (key64) MTB_LAUNCH_SCORE(true, true, MTB_SCORE_LDS); else MTB_LAUNCH_SCORE(true, false, MTB_SCORE_LDS); }
+        else MTB_LAUNCH_SCORE(false, false, MTB_SCORE_LDS);
 #undef MTB_LAUNCH_SCORE
     }
     HIPCHK(hipGetLastError());
@@ -903,7 +905,9 @@ static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, c
         HIPCHK(hipMemsetAsync(d_cnt, 0, n_reads * 4, st));
         HIPCHK(hipMemsetAsync(c->d_scal + 2, 0, 32, st));            /* [2] unused, [3] max big segment, [5] reads deferred by the first launch */
         uint64_t big_total = 0;
-        ScoreSrc a; a.m = d_segm; a.cursor = d_rc; a.stride = stride; a.direct = direct; a.epoch = epoch; a.sort = true; a.max_seg = MTB_SCORE_LDS;
+        ScoreSrc a; a.m = d_segm; a.cursor = d_rc; a.stride = stride; a.direct = direct; a.epoch = epoch; a.sort = true;
+        a.cap = stride > 192 ? 320 : MTB_SCORE_LDS;          /* read pairs (about twice the metamers): larger LDS staging, half the waves per CU */
+        a.max_seg = a.cap;
         a.big_list = d_biglist; a.n_big = (uint32_t *)(c->d_scal + 5); a.cnt_out = d_cnt;
         /* reads the first launch could not take from their slots: exact segments (live slots + overflow list), sorted in HBM */
         ScoreSecond second = [&](ScoreSrc *b, bool *go) -> mtb_status {
