@@ -203,6 +203,14 @@ mtb_status mtb_classify_batch_device(mtb_ctx *, mtb_index *, const mtb_params *,
                                      uint64_t *n_taxcnt);
 mtb_status mtb_last_batch_stats(mtb_ctx *, mtb_batch_stats *out);
 
+/* Writes the resident index in the reference's on-disk format -- diffIdx
+ * (IndexCreator::getDiffIdx, IndexCreator.cpp:874-892), info, split
+ * (writeTargetFilesAndSplits, :817-872, `split_num` checkpoints; the reference
+ * uses 4096), taxID_list (:329-333) and db.parameters (:1251-1272) -- into the
+ * existing directory `dbdir`.  `metabuli classify` and mtb_index_open read
+ * the result.  The taxonomy dump files are not written.                     */
+mtb_status mtb_index_write(const mtb_index *, const char *dbdir, int split_num);
+
 /* ---- partitioned index: databases larger than one GPU's HBM -----------
  * SURVEY.md 8(e) row 2.  The flat target array is range-partitioned by value
  * at amino-acid-part boundaries (the invariant of the reference's `split`

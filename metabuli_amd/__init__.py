@@ -302,6 +302,10 @@ class Index:
         _chk(self.ctx.L.mtb_index_slice(self.h, C.c_uint64(int(lo_value)), C.c_uint64(int(hi_value)), C.c_int(1 if is_last else 0), C.byref(h)))
         return Index(self.ctx, h)
 
+    def write(self, dbdir, split_num=4096):
+        """the index in the reference's on-disk format (mtb_index_write); dbdir must exist"""
+        _chk(self.ctx.L.mtb_index_write(self.h, dbdir.encode(), C.c_int(split_num)))
+
     def download(self):
         n = self.num_targets
         v = np.zeros(n, np.uint64); i = np.zeros(n, np.uint32)

@@ -667,6 +667,77 @@ mtb_status mtb_index_download(mtb_index *ix, uint64_t *values, uint32_t *info, u
     if (info) HIPCHK(hipMemcpy(info, ix->d_info, ix->T * 4, hipMemcpyDeviceToHost));
     return MTB_OK;
 }
+/* IndexCreator::writeTargetFilesAndSplits + writeDbParameters (IndexCreator.cpp:817-892, 1251-1272) and the
+ * taxID_list dump (:329-333) for an index that is resident on the device -- e.g. a synthetic one.  The metamers are
+ * streamed to the host in slices; the delta coder and the split rule are sequential by nature. */
+mtb_status mtb_index_write(const mtb_index *ix, const char *dbdir, int split_num) {
+    if (!ix || !dbdir || split_num < 2) return fail(MTB_ERR_ARG, "NULL argument / split_num < 2");
+    mtb_ctx *c = ix->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    const std::string d(dbdir);
+    FILE *fd = fopen((d + "/diffIdx").c_str(), "wb"), *fi = fopen((d + "/info").c_str(), "wb");
+    if (!fd || !fi) { if (fd) fclose(fd); if (fi) fclose(fi); return fail(MTB_ERR_IO, "cannot create diffIdx/info in " + d); }
+    struct Split { uint64_t ad, diff_off, info_off; };
+    std::vector<Split> splits((size_t)split_num, Split{0, 0, 0});
+    const uint64_t n = ix->T, AAMASK = ~0xFFFFFFull;
+    const uint64_t size_of_split = n / (uint64_t)(split_num - 1);
+    uint64_t next_off = size_of_split;                 /* offsetList[1], [2], ... = k * sizeOfSplit */
+    int split_idx = 1; bool armed = false; uint64_t aa_of_temp = UINT64_MAX;
+    std::vector<uint8_t> seen((size_t)ix->tax.max_id + 2, 0);
+    std::vector<int32_t> extra_ids;                    /* ids outside the taxonomy's range (kept for taxID_list) */
+    const uint64_t SLICE = 1ull << 24;
+    std::vector<uint64_t> hv(std::min<uint64_t>(SLICE, std::max<uint64_t>(n, 1))); std::vector<uint32_t> hi(hv.size());
+    std::vector<uint16_t> enc; enc.reserve(hv.size() * 3);
+    uint64_t last = 0, diff_count = 0;
+    bool ok = true;
+    for (uint64_t s0 = 0; s0 < n && ok; s0 += SLICE) {
+        const uint64_t m = std::min<uint64_t>(SLICE, n - s0);
+        if (hipMemcpy(hv.data(), ix->d_values + s0, m * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(hi.data(), ix->d_info + s0, m * 4, hipMemcpyDeviceToHost) != hipSuccess) { ok = false; break; }
+        enc.clear();
+        for (uint64_t j = 0; j < m; j++) {
+            const uint64_t v = hv[j];
+            uint64_t dlt = v - last; uint16_t buf[5]; int idx = 3;      /* getDiffIdx: big-endian 15-bit groups, last one flagged */
+            buf[4] = (uint16_t)(0x8000u | (dlt & 0x7FFFu)); dlt >>= 15;
+            while (dlt) { buf[idx--] = (uint16_t)(dlt & 0x7FFFu); dlt >>= 15; }
+            for (int q = idx + 1; q <= 4; q++) enc.push_back(buf[q]);
+            last = v;
+            const uint64_t info_cnt = s0 + j + 1;
+            if ((last & AAMASK) != aa_of_temp && armed) {
+                if (split_idx < split_num) splits[(size_t)split_idx++] = Split{last, diff_count + enc.size(), info_cnt};
+                armed = false;
+            }
+            if (size_of_split && info_cnt == next_off) { aa_of_temp = last & AAMASK; armed = true; next_off += size_of_split; }
+            const int32_t t = (int32_t)(hi[j] & 0x7FFFFFFFu);
+            if (t >= 0 && (size_t)t < seen.size()) seen[(size_t)t] = 1; else extra_ids.push_back(t);
+        }
+        ok = fwrite(enc.data(), 2, enc.size(), fd) == enc.size() && fwrite(hi.data(), 4, m, fi) == m;
+        diff_count += enc.size();
+    }
+    fclose(fd); fclose(fi);
+    if (!ok) return fail(MTB_ERR_IO, "short write / device copy failed while writing " + d);
+    FILE *f = fopen((d + "/split").c_str(), "wb"); if (!f) return fail(MTB_ERR_IO, "cannot create " + d + "/split");
+    fwrite(splits.data(), sizeof(Split), splits.size(), f); fclose(f);
+    std::sort(extra_ids.begin(), extra_ids.end()); extra_ids.erase(std::unique(extra_ids.begin(), extra_ids.end()), extra_ids.end());
+    f = fopen((d + "/taxID_list").c_str(), "w"); if (!f) return fail(MTB_ERR_IO, "cannot create " + d + "/taxID_list");
+    {   size_t e = 0;
+        for (size_t t = 0; t < seen.size(); t++) {
+            while (e < extra_ids.size() && extra_ids[e] < (int32_t)t) fprintf(f, "%d\n", extra_ids[e++]);
+            if (seen[t]) fprintf(f, "%zu\n", t);
+        }
+        while (e < extra_ids.size()) fprintf(f, "%d\n", extra_ids[e++]);
+    }
+    fclose(f);
+    f = fopen((d + "/db.parameters").c_str(), "w"); if (!f) return fail(MTB_ERR_IO, "cannot create " + d + "/db.parameters");
+    const mtb_params &p = ix->params;
+    fprintf(f, "DB_name\t%s\nCreation_date\t-\nReduced_alphabet\t0\nAccession_level\t%d\n", "mtb", p.accession_level == 2 ? 1 : 0);
+    fprintf(f, "Mask_mode\t0\nMask_prob\t0.900000\nSkip_redundancy\t%d\nSyncmer\t%d\n", p.skip_redundancy ? 1 : 0, p.syncmer);
+    if (p.syncmer == 1) fprintf(f, "Syncmer_len\t%d\n", p.smer_len);
+    fprintf(f, "Kmer_format\t%d\n", p.kmer_format);
+    fclose(f);
+    return MTB_OK;
+}
+
 int32_t mtb_tax_lca(const mtb_index *ix, int32_t a, int32_t b) { return ix->tax.lca(a, b); }
 int32_t mtb_tax_species(const mtb_index *ix, int32_t t) { return (t >= 0 && t <= ix->tax.max_id) ? ix->tax.tax2species[(size_t)t] : 0; }
 int32_t mtb_tax_parent(const mtb_index *ix, int32_t t) { int32_t c = ix->tax.cn(t); return c < 0 ? -1 : ix->tax.parent[(size_t)c]; }

@@ -262,3 +262,24 @@ def test_foreign_sequence_ids_are_rejected(ctx):
         ctx.sort_matches(m, 2)
     assert e.value.status == M.MTB_ERR_ARG
     assert len(ctx.sort_matches(m[:2], 2)) == 2
+
+
+def test_index_write_reproduces_the_database_files(ctx, toy, tmp_path):
+    """mtb_index_write (IndexCreator::writeTargetFilesAndSplits restated on the product side): the files written from
+    the resident index are byte-identical to the ones the oracle's writer produced, and the copy classifies alike"""
+    import shutil
+    p = _params(toy)
+    ix = ctx.open_index(toy.dbdir, p)
+    out = tmp_path / "copy"
+    out.mkdir()
+    ix.write(str(out))
+    ix.close()
+    for name in ("diffIdx", "info", "split", "taxID_list"):
+        assert (out / name).read_bytes() == open(os.path.join(toy.dbdir, name), "rb").read(), name
+    shutil.copytree(os.path.join(toy.dbdir, "taxonomy"), out / "taxonomy")
+    p2 = _params(toy)
+    ix2 = ctx.open_index(str(out), p2)
+    assert (p2.syncmer, p2.smer_len, p2.kmer_format, p2.accession_level) == (p.syncmer, p.smer_len, p.kmer_format, p.accession_level)
+    res, tt, tc = ctx.classify_batch(ix2, p2, toy.b1, toy.o1, toy.b2, toy.o2)
+    assert (res["classification"] == toy.ref["results"]["classification"]).all()
+    ix2.close()
