@@ -5,13 +5,16 @@
  * positional arguments, the subset of its flags that the hot path reads, and
  * its two TSV outputs (Reporter.cpp:35-80, 115-193).  Everything that computes
  * runs on the GPU through libmtb.so; this file only parses reads, batches them
- * and formats results.
+ * and formats results -- as a three-stage pipeline: a
+ * reader thread parses batch k+1 (fastx.h: block-parallel FASTA/FASTQ/gzip
+ * parser, flat buffers), the main thread runs batch k on the GPU, a writer
+ * thread formats batch k-1 with --threads workers and appends it in order.
  *
  *   mtb_classify [flags] <FASTA/Q> [<FASTA/Q mate>] <DBDIR> <OUTDIR> <JobID>
  *   flags: --seq-mode 1|2|3  --min-score F  --min-sp-score F  --min-cons-cnt N
  *          --min-cons-cnt-euk N  --tie-ratio F  --taxonomy-path DIR
  *          --syncmer 0|1  --smer-len N  --kmer-format 1|2  --accession-level 0|1|2
- *          --max-reads N (batch size)  --device N
+ *          --max-reads N (batch size)  --device N  --threads N (host parsing / formatting)
  */
 #include <cstdio>
 #include <cstring>
@@ -23,54 +26,52 @@
 #include <sstream>
 #include <unordered_map>
 
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+
 #include "../../../include/mtb.hpp"
+#include "fastx.h"
 
 namespace {
 
-/* FASTA / FASTQ records; name = header up to the first whitespace (kseq) */
-struct SeqReader {
-    std::ifstream in; std::string pending; bool fastq = false; bool started = false;
-    explicit SeqReader(const std::string &p) : in(p) { if (!in) throw std::runtime_error("cannot open " + p); }
-    bool next(std::string &name, std::string &seq) {
-        std::string line;
-        if (!started) {
-            while (std::getline(in, line)) if (!line.empty()) break;
-            if (line.empty()) return false;
-            fastq = line[0] == '@'; pending = line; started = true;
-        }
-        if (pending.empty()) return false;
-        size_t e = pending.find_first_of(" \t", 1);
-        name = pending.substr(1, e == std::string::npos ? std::string::npos : e - 1);
-        seq.clear(); pending.clear();
-        if (fastq) {
-            if (!std::getline(in, seq)) return false;
-            if (!seq.empty() && seq.back() == '\r') seq.pop_back();
-            std::getline(in, line); std::getline(in, line);       /* '+' and qualities */
-            while (std::getline(in, line)) if (!line.empty()) { pending = line; break; }
-        } else {
-            while (std::getline(in, line)) {
-                if (!line.empty() && line[0] == '>') { pending = line; break; }
-                if (!line.empty() && line.back() == '\r') line.pop_back();
-                seq += line;
-            }
-        }
-        return true;
-    }
+/* one batch travelling through the pipeline */
+struct Job {
+    mtbhost::FlatBatch r1, r2;
+    std::vector<mtb_result> res; std::vector<int32_t> tt; std::vector<uint32_t> tc;
+    bool last = false;
 };
 
-/* Reporter::writeReadClassification (Reporter.cpp:35-80) */
-void write_classifications(std::ostream &os, const std::vector<mtb::Query> &q, const mtb_index *ix, bool header) {
-    if (header) os << "#is_classified\tname\ttaxID\tquery_length\tscore\trank\ttaxID:match_count\n";
-    for (const auto &r : q) {
-        if (r.isClassified) {
-            os << r.isClassified << "\t" << r.name << "\t" << r.classification << "\t" << r.queryLength + r.queryLength2 << "\t"
-               << r.score << "\t" << mtb_tax_rank(ix, r.classification) << "\t";
-            for (const auto &kv : r.taxCnt) os << kv.first << ":" << kv.second << " ";
-            os << "\n";
-        } else {
-            os << r.isClassified << "\t" << r.name << "\t" << r.classification << "\t" << r.queryLength + r.queryLength2 << "\t"
-               << r.score << "\t-\t-\t\n";
-        }
+/* bounded single-producer / single-consumer hand-over */
+template <class T> class Channel {
+public:
+    explicit Channel(size_t cap) : cap_(cap) {}
+    void put(std::unique_ptr<T> v) { std::unique_lock<std::mutex> l(m_); cv_.wait(l, [&] { return q_.size() < cap_; }); q_.push_back(std::move(v)); cv_.notify_all(); }
+    std::unique_ptr<T> get() { std::unique_lock<std::mutex> l(m_); cv_.wait(l, [&] { return !q_.empty(); }); auto v = std::move(q_.front()); q_.erase(q_.begin()); cv_.notify_all(); return v; }
+private:
+    std::mutex m_; std::condition_variable cv_; std::vector<std::unique_ptr<T>> q_; size_t cap_;
+};
+
+/* Reporter::writeReadClassification (Reporter.cpp:35-80), one line per read, reads [lo, hi) of the job.  The score is
+ * printed like an ostream prints a float (6 significant digits). */
+void format_reads(const Job &j, size_t lo, size_t hi, const mtb_index *ix, std::string &out) {
+    char num[64];
+    out.clear();
+    out.reserve((hi - lo) * 96);
+    for (size_t i = lo; i < hi; i++) {
+        const mtb_result &r = j.res[i];
+        out += r.is_classified ? '1' : '0'; out += '\t';
+        out.append(j.r1.names.data() + j.r1.name_offs[i], j.r1.names.data() + j.r1.name_offs[i + 1]); out += '\t';
+        int n = snprintf(num, sizeof(num), "%d\t%d\t%g\t", r.classification, r.query_length + r.query_length2, (double)r.score);
+        out.append(num, (size_t)n);
+        if (r.is_classified) {
+            out += mtb_tax_rank(ix, r.classification); out += '\t';
+            for (uint32_t k = 0; k < r.n_taxcnt; k++) {
+                n = snprintf(num, sizeof(num), "%d:%u ", j.tt[r.taxcnt_off + k], j.tc[r.taxcnt_off + k]);
+                out.append(num, (size_t)n);
+            }
+            out += '\n';
+        } else out += "-\t-\t\n";
     }
 }
 
@@ -114,6 +115,7 @@ void write_report(FILE *fp, const std::map<int, unsigned> &taxCounts, const mtb_
 int main(int argc, char **argv) {
     mtb_params par; mtb_default_params(&par);
     std::string taxdir; int device = 0; size_t max_reads = 2000000;
+    int threads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     std::vector<std::string> pos;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -131,6 +133,7 @@ int main(int argc, char **argv) {
         else if (a == "--smer-len") par.smer_len = atoi(val().c_str());
         else if (a == "--max-reads") max_reads = (size_t)atoll(val().c_str());
         else if (a == "--device") device = atoi(val().c_str());
+        else if (a == "--threads") threads = std::max(1, atoi(val().c_str()));
         else if (a.rfind("--", 0) == 0) { fprintf(stderr, "unsupported flag %s\n", a.c_str()); return 1; }
         else pos.push_back(a);
     }
@@ -143,31 +146,76 @@ int main(int argc, char **argv) {
     const std::string dbdir = pos[paired ? 2 : 1], outdir = pos[paired ? 3 : 2], job = pos[paired ? 4 : 3];
     try {
         mtb::Engine eng(device, dbdir, taxdir, par);          /* db.parameters overrides the flags (common.cpp:88-133) */
-        mtb::Classifier cls(eng, par);
-        SeqReader r1(pos[0]);
-        std::unique_ptr<SeqReader> r2;
-        if (paired) r2.reset(new SeqReader(pos[1]));
-        std::ofstream out(outdir + "/" + job + "_classifications.tsv");
+        FILE *out = fopen((outdir + "/" + job + "_classifications.tsv").c_str(), "w");
         if (!out) throw std::runtime_error("cannot write to " + outdir);
-        unsigned long total = 0; bool first = true;
-        for (;;) {
-            mtb::ReadBatch b;
-            std::string name, seq, n2, s2;
-            while (b.size() < max_reads && r1.next(name, seq)) {
-                b.add(name, seq);
-                if (paired) { if (!r2->next(n2, s2)) throw std::runtime_error("mate file is shorter"); b.add_mate(s2); }
+        fputs("#is_classified\tname\ttaxID\tquery_length\tscore\trank\ttaxID:match_count\n", out);
+        Channel<Job> parsed(2), scored(2);
+        std::string reader_err, writer_err;
+        /* stage 1: parse */
+        std::thread reader([&] {
+            try {
+                mtbhost::FastxReader r1(pos[0], threads);
+                std::unique_ptr<mtbhost::FastxReader> r2;
+                if (paired) r2.reset(new mtbhost::FastxReader(pos[1], threads));
+                for (;;) {
+                    std::unique_ptr<Job> j(new Job());
+                    r1.next_batch(max_reads, j->r1);
+                    if (paired) { r2->next_batch(j->r1.size(), j->r2); if (j->r2.size() != j->r1.size()) throw std::runtime_error("mate file is shorter"); }
+                    j->last = j->r1.size() == 0;
+                    bool last = j->last;
+                    parsed.put(std::move(j));
+                    if (last) break;
+                }
+            } catch (const std::exception &e) { reader_err = e.what(); std::unique_ptr<Job> j(new Job()); j->last = true; parsed.put(std::move(j)); }
+        });
+        /* stage 3: format + append, per-taxon read counts (Classifier.cpp:201-203) */
+        std::vector<uint64_t> tax_counts((size_t)mtb_tax_max_id(eng.index) + 2, 0);
+        unsigned long total = 0;
+        std::thread writer([&] {
+            std::vector<std::string> parts((size_t)threads);
+            for (;;) {
+                std::unique_ptr<Job> j = scored.get();
+                if (j->last) break;
+                const size_t n = j->r1.size();
+                std::vector<std::thread> th;
+                for (int t = 0; t < threads; t++)
+                    th.emplace_back([&, t] { format_reads(*j, n * (size_t)t / (size_t)threads, n * (size_t)(t + 1) / (size_t)threads, eng.index, parts[(size_t)t]); });
+                for (auto &x : th) x.join();
+                for (auto &p : parts) if (fwrite(p.data(), 1, p.size(), out) != p.size()) writer_err = "short write";
+                for (size_t i = 0; i < n; i++) { int32_t c = j->res[i].classification; if (c >= 0 && (size_t)c < tax_counts.size()) tax_counts[(size_t)c]++; }
+                total += n;
+                std::cout << "The number of processed sequences: " << total << std::endl;
             }
-            if (b.size() == 0) break;
-            std::vector<mtb::Query> q;
-            cls.classifyBatch(b, q);
-            write_classifications(out, q, eng.index, first);
-            first = false;
-            total += b.size();
-            std::cout << "The number of processed sequences: " << total << std::endl;
+        });
+        /* stage 2: the GPU */
+        std::string gpu_err;
+        for (;;) {
+            std::unique_ptr<Job> j = parsed.get();
+            if (j->last) { scored.put(std::move(j)); break; }
+            if (!gpu_err.empty()) continue;                  /* drain the reader after a failure */
+            const size_t n = j->r1.size();
+            j->res.resize(n);
+            size_t cap = 64 * n + 1024; uint64_t ntc = 0;
+            for (;;) {
+                j->tt.resize(cap); j->tc.resize(cap);
+                mtb_status s = mtb_classify_batch(eng.ctx, eng.index, &par, j->r1.bases.data(), j->r1.offs.data(), paired ? j->r2.bases.data() : nullptr,
+                                                  paired ? j->r2.offs.data() : nullptr, n, j->res.data(), j->tt.data(), j->tc.data(), cap, &ntc);
+                if (s == MTB_ERR_CAPACITY && ntc > cap) { cap = ntc; continue; }
+                if (s != MTB_OK) gpu_err = mtb_last_error();
+                break;
+            }
+            if (gpu_err.empty()) scored.put(std::move(j));
         }
+        reader.join(); writer.join();
+        fclose(out);
+        if (!reader_err.empty()) throw std::runtime_error(reader_err);
+        if (!gpu_err.empty()) throw std::runtime_error("mtb: " + gpu_err);
+        if (!writer_err.empty()) throw std::runtime_error(writer_err);
+        std::map<int, unsigned> counts;
+        for (size_t t = 0; t < tax_counts.size(); t++) if (tax_counts[t]) counts[(int)t] = (unsigned)tax_counts[t];
         FILE *fp = fopen((outdir + "/" + job + "_report.tsv").c_str(), "w");
         if (!fp) throw std::runtime_error("cannot write the report");
-        write_report(fp, cls.getTaxCounts(), eng.index, total);
+        write_report(fp, counts, eng.index, total);
         fclose(fp);
     } catch (const std::exception &e) {
         fprintf(stderr, "mtb_classify: %s\n", e.what());
