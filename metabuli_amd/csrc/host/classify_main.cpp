@@ -26,6 +26,7 @@
 #include <sstream>
 #include <unordered_map>
 
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -145,7 +146,11 @@ int main(int argc, char **argv) {
     const bool paired = par.seq_mode == 2;
     const std::string dbdir = pos[paired ? 2 : 1], outdir = pos[paired ? 3 : 2], job = pos[paired ? 4 : 3];
     try {
+        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double t_start = now();
         mtb::Engine eng(device, dbdir, taxdir, par);          /* db.parameters overrides the flags (common.cpp:88-133) */
+        const double t_open = now() - t_start;
+        double t_parse = 0, t_gpu = 0, t_write = 0;           /* busy time of the three stages */
         FILE *out = fopen((outdir + "/" + job + "_classifications.tsv").c_str(), "w");
         if (!out) throw std::runtime_error("cannot write to " + outdir);
         fputs("#is_classified\tname\ttaxID\tquery_length\tscore\trank\ttaxID:match_count\n", out);
@@ -159,9 +164,11 @@ int main(int argc, char **argv) {
                 if (paired) r2.reset(new mtbhost::FastxReader(pos[1], threads));
                 for (;;) {
                     std::unique_ptr<Job> j(new Job());
+                    const double t0 = now();
                     r1.next_batch(max_reads, j->r1);
                     if (paired) { r2->next_batch(j->r1.size(), j->r2); if (j->r2.size() != j->r1.size()) throw std::runtime_error("mate file is shorter"); }
                     j->last = j->r1.size() == 0;
+                    t_parse += now() - t0;
                     bool last = j->last;
                     parsed.put(std::move(j));
                     if (last) break;
@@ -176,6 +183,7 @@ int main(int argc, char **argv) {
             for (;;) {
                 std::unique_ptr<Job> j = scored.get();
                 if (j->last) break;
+                const double t0 = now();
                 const size_t n = j->r1.size();
                 std::vector<std::thread> th;
                 for (int t = 0; t < threads; t++)
@@ -184,6 +192,7 @@ int main(int argc, char **argv) {
                 for (auto &p : parts) if (fwrite(p.data(), 1, p.size(), out) != p.size()) writer_err = "short write";
                 for (size_t i = 0; i < n; i++) { int32_t c = j->res[i].classification; if (c >= 0 && (size_t)c < tax_counts.size()) tax_counts[(size_t)c]++; }
                 total += n;
+                t_write += now() - t0;
                 std::cout << "The number of processed sequences: " << total << std::endl;
             }
         });
@@ -193,6 +202,7 @@ int main(int argc, char **argv) {
             std::unique_ptr<Job> j = parsed.get();
             if (j->last) { scored.put(std::move(j)); break; }
             if (!gpu_err.empty()) continue;                  /* drain the reader after a failure */
+            const double t0 = now();
             const size_t n = j->r1.size();
             j->res.resize(n);
             size_t cap = 64 * n + 1024; uint64_t ntc = 0;
@@ -204,6 +214,7 @@ int main(int argc, char **argv) {
                 if (s != MTB_OK) gpu_err = mtb_last_error();
                 break;
             }
+            t_gpu += now() - t0;
             if (gpu_err.empty()) scored.put(std::move(j));
         }
         reader.join(); writer.join();
@@ -217,6 +228,8 @@ int main(int argc, char **argv) {
         if (!fp) throw std::runtime_error("cannot write the report");
         write_report(fp, counts, eng.index, total);
         fclose(fp);
+        fprintf(stderr, "mtb_classify: %lu reads in %.2f s (index open %.2f s; stage busy time: parse %.2f s, GPU incl. PCIe %.2f s, format+write %.2f s; %d host threads)\n",
+                total, now() - t_start, t_open, t_parse, t_gpu, t_write, threads);
     } catch (const std::exception &e) {
         fprintf(stderr, "mtb_classify: %s\n", e.what());
         return 1;
