@@ -61,10 +61,11 @@ __global__ __launch_bounds__(256) void k_join_bounds(const mtb_kmer *__restrict_
  * exactly one match, and in slot order those matches are already in (frame, position) order, which is the
  * scorer's order when one species is involved.  Further matches of the query (and queries with ord >= direct) take
  * slots direct + t of the segment's tail, t from a returning atomic on the read's tail cursor; matches beyond the
- * tail go to an overflow list and their reads complete on the large-segment path (k_big_*).  A slot is live when
- * its record's pad byte equals the batch's epoch tag: segments are never cleared between batches.            */
+ * tail go to an overflow list and their reads complete on the large-segment path (k_big_*).  Slots hold the 16-byte
+ * form of a match (mtb_slot16); a slot is live when its epoch field equals the batch's tag: segments are never
+ * cleared between batches.                                                                                   */
 struct JoinSegArgs {
-    mtb_match *seg; uint32_t stride, direct; uint32_t *cursor;
+    mtb_slot16 *seg; uint32_t stride, direct; uint32_t *cursor;
     mtb_match *ovf; uint64_t ovf_cap; unsigned long long *ovf_counter;
     uint32_t epoch;
 };
@@ -148,12 +149,12 @@ __global__ __launch_bounds__(256) void k_join(const mtb_kmer *__restrict__ q, ui
             const uint32_t ord = mtb_q_pos(k[u].qinfo) >> 16;
             const uint64_t qinfo = k[u].qinfo & ~0xFFFF0000ull;          /* the record carries the reference's qinfo */
             const uint32_t first = ord < sa.direct ? 1u : 0u;
-            mtb_match *seg = sa.seg + (uint64_t)r * sa.stride;
+            mtb_slot16 *seg = sa.seg + (uint64_t)r * sa.stride;
             if (first) {
                 if (in_lds) mtb_join_select(&s_tab, s_win, rs[u], rl[u], k[u].value, qinfo, ix.info, lo, ix.tax2species, ix.max_taxid, ix.info_mask,
-                                            ix.kmer_format, seg + ord, 1, 0, (uint8_t)sa.epoch);
+                                            ix.kmer_format, (mtb_match *)nullptr, 1, 0, seg + ord, sa.epoch);
                 else mtb_join_select(&s_tab, ix.values + lo, rs[u], rl[u], k[u].value, qinfo, ix.info, lo, ix.tax2species, ix.max_taxid, ix.info_mask,
-                                     ix.kmer_format, seg + ord, 1, 0, (uint8_t)sa.epoch);
+                                     ix.kmer_format, (mtb_match *)nullptr, 1, 0, seg + ord, sa.epoch);
             }
             const uint32_t ntail = c[u] - first;
             if (ntail == 0) continue;
@@ -161,9 +162,9 @@ __global__ __launch_bounds__(256) void k_join(const mtb_kmer *__restrict__ q, ui
             const uint32_t fit = s < tail_cap ? (ntail < tail_cap - s ? ntail : tail_cap - s) : 0u;
             if (fit) {
                 if (in_lds) mtb_join_select(&s_tab, s_win, rs[u], rl[u], k[u].value, qinfo, ix.info, lo, ix.tax2species, ix.max_taxid, ix.info_mask,
-                                            ix.kmer_format, seg + sa.direct + s, fit, first, (uint8_t)sa.epoch);
+                                            ix.kmer_format, (mtb_match *)nullptr, fit, first, seg + sa.direct + s, sa.epoch);
                 else mtb_join_select(&s_tab, ix.values + lo, rs[u], rl[u], k[u].value, qinfo, ix.info, lo, ix.tax2species, ix.max_taxid, ix.info_mask,
-                                     ix.kmer_format, seg + sa.direct + s, fit, first, (uint8_t)sa.epoch);
+                                     ix.kmer_format, (mtb_match *)nullptr, fit, first, seg + sa.direct + s, sa.epoch);
             }
             const uint32_t n_ovf = ntail - fit;
             if (n_ovf) {
@@ -203,22 +204,22 @@ __global__ __launch_bounds__(256) void k_join(const mtb_kmer *__restrict__ q, ui
 /* ---- completion of the reads k_score could not take from their slots (tail overflow, or more live records than
  * its LDS staging): exact segments = live direct slots + tail slots + overflow entries, sorted in HBM, scored by a
  * second launch.  `big_list` is filled by k_score.  One wavefront per listed read.                            */
-/* records are read as three aligned 64-bit words; the pad byte (epoch tag) is the top byte of the third */
-__device__ __forceinline__ bool seg_slot_live(uint64_t w2, uint32_t i, uint32_t direct, uint32_t tail_n, uint32_t epoch) {
-    return (uint32_t)(w2 >> 56) == (epoch & 255u) && (i < direct || i - direct < tail_n);
+__device__ __forceinline__ bool seg_slot_live(const mtb_slot16 &s, uint32_t i, uint32_t direct, uint32_t tail_n, uint32_t epoch) {
+    return mtb_slot_epoch(s) == epoch && (i < direct || i - direct < tail_n);
 }
-__global__ __launch_bounds__(64) void k_big_count(const mtb_match *__restrict__ seg, uint32_t stride, uint32_t direct, uint32_t epoch,
+__global__ __launch_bounds__(64) void k_big_count(const mtb_slot16 *__restrict__ seg, uint32_t stride, uint32_t direct, uint32_t epoch,
                                                    const uint32_t *__restrict__ cursor, const uint32_t *__restrict__ big_list, uint32_t n_big,
                                                    uint32_t *__restrict__ big_cnt, uint32_t *__restrict__ bigidx, uint32_t *__restrict__ max_seg) {
     uint32_t mx = 0;
     for (uint32_t b = blockIdx.x; b < n_big; b += gridDim.x) {
         const uint32_t r = big_list[b];
         const uint32_t cur = cursor[r], tail_cap = stride - direct, tail_n = cur < tail_cap ? cur : tail_cap;
-        const mtb_match *s = seg + (uint64_t)r * stride;
+        const mtb_slot16 *s = seg + (uint64_t)r * stride;
         uint32_t n = 0;
         for (uint32_t c0 = 0; c0 < stride; c0 += 64) {
             uint32_t i = c0 + threadIdx.x;
-            bool live = i < stride && seg_slot_live(((const uint64_t *)s)[3 * i + 2], i, direct, tail_n, epoch);
+            bool live = false;
+            if (i < stride) { mtb_slot16 x = s[i]; live = seg_slot_live(x, i, direct, tail_n, epoch); }
             n += (uint32_t)__popcll(__ballot(live));
         }
         n += cur - tail_n;                                  /* overflow entries */
@@ -227,22 +228,27 @@ __global__ __launch_bounds__(64) void k_big_count(const mtb_match *__restrict__ 
     }
     if (threadIdx.x == 0 && mx) atomicMax(max_seg, mx);
 }
-__global__ __launch_bounds__(64) void k_big_copy(const mtb_match *__restrict__ seg, uint32_t stride, uint32_t direct, uint32_t epoch,
+__global__ __launch_bounds__(64) void k_big_copy(const mtb_slot16 *__restrict__ seg, uint32_t stride, uint32_t direct, uint32_t epoch,
                                                   const uint32_t *__restrict__ cursor, const uint32_t *__restrict__ big_list,
                                                   const uint64_t *__restrict__ big_start, uint32_t n_big, uint32_t *__restrict__ bigcur,
                                                   mtb_match *__restrict__ big) {
     for (uint32_t b = blockIdx.x; b < n_big; b += gridDim.x) {
         const uint32_t r = big_list[b];
         const uint32_t cur = cursor[r], tail_cap = stride - direct, tail_n = cur < tail_cap ? cur : tail_cap;
-        const mtb_match *s = seg + (uint64_t)r * stride;
+        const mtb_slot16 *s = seg + (uint64_t)r * stride;
         mtb_match *dst = big + big_start[b];
         uint32_t n = 0;
         for (uint32_t c0 = 0; c0 < stride; c0 += 64) {
             uint32_t i = c0 + threadIdx.x;
-            uint64_t a = 0, bb = 0, cc = 0; bool live = false;
-            if (i < stride) { const uint64_t *q = (const uint64_t *)(s + i); a = q[0]; bb = q[1]; cc = q[2]; live = seg_slot_live(cc, i, direct, tail_n, epoch); }
+            mtb_slot16 x; x.a = 0; x.b = 0; bool live = false;
+            if (i < stride) { x = s[i]; live = seg_slot_live(x, i, direct, tail_n, epoch); }
             uint64_t mask = __ballot(live);
-            if (live) { uint64_t *d = (uint64_t *)(dst + n + (uint32_t)__popcll(mask & lanemask_lt())); d[0] = a; d[1] = bb; d[2] = cc & 0x00FFFFFFFFFFFFFFull; }
+            if (live) {
+                const mtb_match m = mtb_slot_unpack(x, r + 1);
+                uint64_t *d = (uint64_t *)(dst + n + (uint32_t)__popcll(mask & lanemask_lt()));
+                const uint64_t *q = (const uint64_t *)&m;
+                d[0] = q[0]; d[1] = q[1]; d[2] = q[2];
+            }
             n += (uint32_t)__popcll(mask);
         }
         if (threadIdx.x == 0) bigcur[b] = n;

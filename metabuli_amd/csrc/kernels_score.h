@@ -510,9 +510,9 @@ __global__ __launch_bounds__(64, (CAP > MTB_SCORE_LDS ? 2 : MTB_SCORE_MINWAVES))
             /* slot mode: start pulling the NEXT read's slots towards L2 now (one dword per 128-byte line, delivered
              * straight into a dummy LDS area: no register, nothing waits for it) -- the slot loads are one dependent
              * HBM round trip per read with nothing to overlap otherwise */
-            const uint32_t lines = (stride * (uint32_t)sizeof(REC) + 127u) / 128u;
+            const uint32_t lines = (stride * (uint32_t)sizeof(mtb_slot16) + 127u) / 128u;
             if (lane < lines) {
-                const uint8_t *pf = (const uint8_t *)(matches + (it + gridDim.x) * (uint64_t)stride) + (uint64_t)lane * 128u;
+                const uint8_t *pf = (const uint8_t *)((const mtb_slot16 *)matches + (it + gridDim.x) * (uint64_t)stride) + (uint64_t)lane * 128u;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)pf,
                                                  (__attribute__((address_space(3))) void *)s_pf, 4, 0, 0);
             }
@@ -538,43 +538,47 @@ __global__ __launch_bounds__(64, (CAP > MTB_SCORE_LDS ? 2 : MTB_SCORE_MINWAVES))
             mtb_sws_carve<uint16_t>(&w, s_ws, CAP);
             bool defer = cur > tail_cap || nb > MTB_SCORE_BKT;
             if (!defer) {
-                const REC *src = matches + r * (uint64_t)stride;
                 uint32_t cnt = 0;
                 score_sync<uint16_t>();
 #ifdef MTB_SCORE_PHASE_CYCLES
                 { unsigned long long t_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) mtb_phase_lds[15] += t_ - kt0_; kt0_ = t_; }
 #endif
-                /* records move as three aligned 64-bit words (a struct copy with the pad byte patched was lowered to
-                 * overlapping unaligned loads, each waiting for the previous one: 12 k cycles per read, measured);
-                 * the pad byte is the top byte of the third word */
-                const uint64_t *src64 = (const uint64_t *)src;
+                /* slots hold the 16-byte form (mtb_slot16): two aligned 64-bit words per lane and slot, expanded to the
+                 * 24-byte record in LDS.  (An earlier struct copy with a patched byte was lowered to overlapping
+                 * unaligned loads that waited for each other: 12 k cycles per read, measured.) */
+                const mtb_slot16 *slots = (const mtb_slot16 *)matches + r * (uint64_t)stride;
                 uint64_t *dst64 = (uint64_t *)w.m;
+                auto put = [&](uint32_t pos, const mtb_slot16 &x) {
+                    const mtb_match m = mtb_slot_unpack(x, (uint32_t)r + 1);
+                    const uint64_t *q = (const uint64_t *)&m;
+                    dst64[3 * pos] = q[0]; dst64[3 * pos + 1] = q[1]; dst64[3 * pos + 2] = q[2];
+                };
                 if (stride <= 192) {
-                    uint64_t wa[3], wb[3], wc[3];
+                    mtb_slot16 x[3];
 #pragma unroll
                     for (int k = 0; k < 3; k++) {          /* all slot loads of the lane in flight at once */
                         const uint32_t i = lane + 64 * k;
-                        wa[k] = 0; wb[k] = 0; wc[k] = 0;
-                        if (i < stride) { wa[k] = src64[3 * i]; wb[k] = src64[3 * i + 1]; wc[k] = src64[3 * i + 2]; }
+                        x[k].a = 0; x[k].b = 0;
+                        if (i < stride) x[k] = slots[i];
                     }
 #pragma unroll
                     for (int k = 0; k < 3; k++) {
                         const uint32_t i = lane + 64 * k;
-                        const bool live = i < stride && (uint32_t)(wc[k] >> 56) == epoch && (i < direct || i - direct < cur);
+                        const bool live = i < stride && mtb_slot_epoch(x[k]) == epoch && (i < direct || i - direct < cur);
                         const uint64_t mask = __ballot(live);
                         const uint32_t pos = cnt + (uint32_t)__popcll(mask & lanemask_lt());
-                        if (live && pos < CAP) { dst64[3 * pos] = wa[k]; dst64[3 * pos + 1] = wb[k]; dst64[3 * pos + 2] = wc[k] & 0x00FFFFFFFFFFFFFFull; }
+                        if (live && pos < CAP) put(pos, x[k]);
                         cnt += (uint32_t)__popcll(mask);
                     }
                 } else
                 for (uint32_t c0 = 0; c0 < stride; c0 += 64) {
                     const uint32_t i = c0 + lane;
-                    uint64_t a = 0, b = 0, cc = 0;
-                    if (i < stride) { a = src64[3 * (uint64_t)i]; b = src64[3 * (uint64_t)i + 1]; cc = src64[3 * (uint64_t)i + 2]; }
-                    const bool live = i < stride && (uint32_t)(cc >> 56) == epoch && (i < direct || i - direct < cur);
+                    mtb_slot16 x; x.a = 0; x.b = 0;
+                    if (i < stride) x = slots[i];
+                    const bool live = i < stride && mtb_slot_epoch(x) == epoch && (i < direct || i - direct < cur);
                     const uint64_t mask = __ballot(live);
                     const uint32_t pos = cnt + (uint32_t)__popcll(mask & lanemask_lt());
-                    if (live && pos < CAP) { dst64[3 * pos] = a; dst64[3 * pos + 1] = b; dst64[3 * pos + 2] = cc & 0x00FFFFFFFFFFFFFFull; }
+                    if (live && pos < CAP) put(pos, x);
                     cnt += (uint32_t)__popcll(mask);
                 }
                 n = (int32_t)cnt;

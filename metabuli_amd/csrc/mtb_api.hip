@@ -50,7 +50,7 @@ struct mtb_ctx {
     std::vector<hipEvent_t> ev_pool; /* recycled events                  */
     std::vector<mtb_ctx *> lanes;    /* extra stream contexts (mtb_ctx_set_streams) */
     bool is_lane = false;            /* lanes share the parent's tables  */
-    uint32_t seg_epoch = 0;          /* tag of the live slots in the "segm" buffer (1..255) */
+    uint32_t seg_epoch = 0;          /* tag of the live slots in the "segm" buffer (1..MTB_SLOT_EPOCHS) */
     double extract_yield = 0.0;      /* metamers per base of the previous batch (single-pass extraction buffer sizing) */
     uint64_t part_n_reads = 0; uint32_t part_max_len = 0;   /* batch state between mtb_part_extract and mtb_part_score */
 };
@@ -921,10 +921,11 @@ static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, c
     mtb_kmer *d_k; uint64_t nk; uint32_t max_len = 0, max_q = 0;
     uint64_t nk_real = 0;                 /* nk counts the blank tail records of the single-pass extraction too */
     /* short reads: per-read slot segments, the query's ordinal (tagged into qinfo by the extractor) is the slot of its
-     * first match.  Needs positions < 2^16 and a moderate number of metamers per read; otherwise exact segments. */
+     * first match.  Needs positions < 2^12 (16-byte slot records) and a moderate number of metamers per read; otherwise
+     * exact segments. */
     bool fixed = p->seq_mode != 3;
     STCHK(dev_extract(c, p, d_bases, d_offs, d_bases2, d_offs2, n_reads, &d_k, &nk, d_ql, d_ql2, &max_len, true, n_bases_total, &nk_real, fixed, &max_q));
-    if (fixed && (max_len + 3 >= (1u << 16) || max_q > 384)) {
+    if (fixed && (max_len + 3 >= MTB_SLOT_MAX_POS || max_q > 384)) {
         fixed = false;                     /* tags would collide with positions / segments would be huge: extract again untagged */
         STCHK(dev_extract(c, p, d_bases, d_offs, d_bases2, d_offs2, n_reads, &d_k, &nk, d_ql, d_ql2, &max_len, true, n_bases_total, &nk_real, false, &max_q));
     }
@@ -946,12 +947,12 @@ static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, c
         /* ---- join straight into per-read slot segments (d_rc = per-read tail cursor) ---- */
         const uint32_t direct = std::max<uint32_t>(8, (max_q + 7) & ~7u);
         const uint32_t stride = direct + std::max<uint32_t>(16, (direct / 8 + 7) & ~7u);
-        mtb_match *d_segm; mtb_match *d_ovf; uint64_t n_ovf = 0;
-        {   /* live slots carry the batch's epoch tag in their pad byte; the buffer is cleared only when it is new or the tag wraps */
+        mtb_slot16 *d_segm; mtb_match *d_ovf; uint64_t n_ovf = 0;
+        {   /* live slots carry the batch's epoch tag; the buffer is cleared only when it is new or the tag wraps */
             DevBuf &sb = c->bufs["segm"];
             void *before = sb.p; size_t cap_before = sb.cap;
             STCHK(ensure(c, "segm", n_reads * (uint64_t)stride, &d_segm));
-            if (sb.p != before || sb.cap != cap_before || c->seg_epoch >= 255) { HIPCHK(hipMemsetAsync(sb.p, 0, sb.cap, st)); c->seg_epoch = 0; }
+            if (sb.p != before || sb.cap != cap_before || c->seg_epoch >= MTB_SLOT_EPOCHS) { HIPCHK(hipMemsetAsync(sb.p, 0, sb.cap, st)); c->seg_epoch = 0; }
             c->seg_epoch++;
         }
         const uint32_t epoch = c->seg_epoch;
@@ -976,7 +977,7 @@ static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, c
         HIPCHK(hipMemsetAsync(d_cnt, 0, n_reads * 4, st));
         HIPCHK(hipMemsetAsync(c->d_scal + 2, 0, 32, st));            /* [2] unused, [3] max big segment, [5] reads deferred by the first launch */
         uint64_t big_total = 0;
-        ScoreSrc a; a.m = d_segm; a.cursor = d_rc; a.stride = stride; a.direct = direct; a.epoch = epoch; a.sort = true;
+        ScoreSrc a; a.m = (const mtb_match *)d_segm; a.cursor = d_rc;       /* slot mode: 16-byte slot records behind the pointer */ a.stride = stride; a.direct = direct; a.epoch = epoch; a.sort = true;
         a.cap = stride > 192 ? 320 : MTB_SCORE_LDS;          /* read pairs (about twice the metamers): larger LDS staging, half the waves per CU */
         a.max_seg = a.cap;
         a.big_list = d_biglist; a.n_big = (uint32_t *)(c->d_scal + 5); a.cnt_out = d_cnt;
@@ -989,14 +990,14 @@ static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, c
             if (!n_big) return MTB_OK;
             KTimer kt(c, MTB_K_SEGSORT);
             STCHK(ensure(c, "bigcnt", n_big, &d_bigcnt)); STCHK(ensure(c, "bigstart", (uint64_t)n_big + 1, &d_bigstart)); STCHK(ensure(c, "bigcur", n_big, &d_bigcur));
-            hipLaunchKernelGGL(k_big_count, dim3(std::min<uint32_t>(n_big, 4096)), dim3(64), 0, st, (const mtb_match *)d_segm, stride, direct, epoch,
+            hipLaunchKernelGGL(k_big_count, dim3(std::min<uint32_t>(n_big, 4096)), dim3(64), 0, st, (const mtb_slot16 *)d_segm, stride, direct, epoch,
                                (const uint32_t *)d_rc, (const uint32_t *)d_biglist, n_big, d_bigcnt, d_bigidx, (uint32_t *)(c->d_scal + 3));
             scan_launch<uint32_t, uint64_t, false>(st, d_bigcnt, n_big, true, d_bigstart, d_ws2);
             uint64_t mx = 0;
             STCHK(d2h(c, &big_total, d_bigstart + n_big, 8));
             STCHK(d2h(c, &mx, c->d_scal + 3, 8));
             STCHK(ensure(c, "bigm", big_total, &d_big));
-            hipLaunchKernelGGL(k_big_copy, dim3(std::min<uint32_t>(n_big, 4096)), dim3(64), 0, st, (const mtb_match *)d_segm, stride, direct, epoch,
+            hipLaunchKernelGGL(k_big_copy, dim3(std::min<uint32_t>(n_big, 4096)), dim3(64), 0, st, (const mtb_slot16 *)d_segm, stride, direct, epoch,
                                (const uint32_t *)d_rc, (const uint32_t *)d_biglist, (const uint64_t *)d_bigstart, n_big, d_bigcur, d_big);
             if (n_ovf) hipLaunchKernelGGL(k_big_ovf, dim3((uint32_t)((n_ovf + 255) / 256)), dim3(256), 0, st, (const mtb_match *)d_ovf, n_ovf,
                                           (const uint32_t *)d_bigidx, (const uint64_t *)d_bigstart, d_bigcur, d_big);

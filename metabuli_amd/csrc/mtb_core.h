@@ -279,13 +279,38 @@ MTB_HD void mtb_join_find(const uint64_t *v, uint64_t n, uint64_t qvalue, uint64
     while (e < n && (v[e] & ~0xFFFFFFull) == aa) e++;
     *run_start = s; *run_len = (uint32_t)(e - s);
 }
+/* 16-byte form of a match inside a read's slot segment (fused short-read path): the sequenceID is implied by the
+ * segment, positions are < 2^12, the hamming sum of a selected candidate is <= 7, and the 5-bit epoch tag marks the
+ * slots written by the current batch.  One aligned 16-byte store per match instead of three 8-byte ones.
+ *   a = species_id << 32 | target_id
+ *   b = epoch[59..63] ham[55..58] frame[52..54] pos[40..51] right_end_hamming[24..39] dna[0..23]                  */
+typedef struct { uint64_t a, b; } mtb_slot16;
+#define MTB_SLOT_MAX_POS 4096u
+#define MTB_SLOT_EPOCHS 31u
+MTB_HD mtb_slot16 mtb_slot_pack(uint64_t qinfo, int32_t target_id, int32_t species_id, uint32_t dna, uint32_t reh, uint32_t ham, uint32_t epoch) {
+    mtb_slot16 s;
+    s.a = ((uint64_t)(uint32_t)species_id << 32) | (uint32_t)target_id;
+    s.b = ((uint64_t)(epoch & 31u) << 59) | ((uint64_t)(ham & 15u) << 55) | ((uint64_t)(mtb_q_frame(qinfo) & 7u) << 52) |
+          ((uint64_t)(mtb_q_pos(qinfo) & 0xFFFu) << 40) | ((uint64_t)(reh & 0xFFFFu) << 24) | (uint64_t)(dna & 0xFFFFFFu);
+    return s;
+}
+MTB_HD uint32_t mtb_slot_epoch(const mtb_slot16 &s) { return (uint32_t)(s.b >> 59); }
+MTB_HD mtb_match mtb_slot_unpack(const mtb_slot16 &s, uint32_t seq_id) {
+    mtb_match m;
+    m.qinfo = mtb_qinfo(seq_id, (uint32_t)(s.b >> 40) & 0xFFFu, (uint32_t)(s.b >> 52) & 7u);
+    m.target_id = (int32_t)(uint32_t)s.a; m.species_id = (int32_t)(uint32_t)(s.a >> 32);
+    m.dna = (uint32_t)s.b & 0xFFFFFFu; m.right_end_hamming = (uint16_t)((s.b >> 24) & 0xFFFFu);
+    m.hamming = (uint8_t)((s.b >> 55) & 15u); m.pad = 0;
+    return m;
+}
+
 /* Selection over a run v[s..s+len): pass 1 (out == NULL) counts the candidates
  * with ham <= min(2*minHam, 7) (compareDna, KmerMatcher.cpp:1117-1146); pass 2
  * writes them in index order.  info/tax2species are indexed with info_base + i. */
 MTB_HD uint32_t mtb_join_select(const mtb_tables *t, const uint64_t *v, uint64_t s, uint32_t len, uint64_t qvalue, uint64_t qinfo,
                                 const uint32_t *info, uint64_t info_base, const int32_t *tax2species, int32_t max_taxid,
                                 uint32_t info_mask, int32_t kmer_format, mtb_match *out, uint32_t out_cap, uint32_t skip = 0,
-                                uint8_t pad = 0) {
+                                mtb_slot16 *out16 = 0, uint32_t epoch = 0) {
     if (len == 0) return 0;
     mtb_qrows q; mtb_prepare_query(t, qvalue, &q);
     uint32_t mn = 255;
@@ -297,13 +322,16 @@ MTB_HD uint32_t mtb_join_select(const mtb_tables *t, const uint64_t *v, uint64_t
         uint32_t td = (uint32_t)v[s + i] & 0xFFFFFFu;
         uint32_t h = mtb_ham_sum(&q, td);
         if (h <= thr) {
-            if (out && cnt >= skip && cnt - skip < out_cap) {        /* selected candidates [skip, skip + out_cap) */
+            if ((out || out16) && cnt >= skip && cnt - skip < out_cap) {        /* selected candidates [skip, skip + out_cap) */
                 int32_t tid = (int32_t)(info[info_base + s + i] & info_mask);
                 int32_t sp = (tid >= 0 && tid <= max_taxid) ? tax2species[tid] : 0;
-                mtb_match m;
-                m.qinfo = qinfo; m.target_id = tid; m.species_id = sp; m.dna = td;
-                m.right_end_hamming = mtb_hammings(&q, td, rev); m.hamming = (uint8_t)h; m.pad = pad;
-                out[cnt - skip] = m;
+                if (out16) out16[cnt - skip] = mtb_slot_pack(qinfo, tid, sp, td, mtb_hammings(&q, td, rev), h, epoch);
+                else {
+                    mtb_match m;
+                    m.qinfo = qinfo; m.target_id = tid; m.species_id = sp; m.dna = td;
+                    m.right_end_hamming = mtb_hammings(&q, td, rev); m.hamming = (uint8_t)h; m.pad = 0;
+                    out[cnt - skip] = m;
+                }
             }
             cnt++;
         }

@@ -265,3 +265,13 @@ int emu_load_taxonomy(const char *dir, const int32_t *taxid_list, size_t n_ids, 
 int emu_load_db_parameters(const char *dir, mtb_params *p) { return mtbhost::load_db_parameters(dir, p) ? 0 : 1; }
 
 } // extern "C"
+
+// 16-byte slot form of a match (mtb_core.h): pack + unpack must return the record (pad = 0), the epoch must survive
+extern "C" int emu_slot_roundtrip(const mtb_match *m, size_t n, uint32_t epoch, mtb_match *out) {
+    for (size_t i = 0; i < n; i++) {
+        mtb_slot16 s = mtb_slot_pack(m[i].qinfo, m[i].target_id, m[i].species_id, m[i].dna, m[i].right_end_hamming, m[i].hamming, epoch);
+        if (mtb_slot_epoch(s) != (epoch & 31u)) return 1;
+        out[i] = mtb_slot_unpack(s, mtb_q_seq(m[i].qinfo));
+    }
+    return 0;
+}

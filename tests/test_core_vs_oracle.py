@@ -154,3 +154,17 @@ def test_oracle_reproduces_golden_vectors(orc, tmp_path, name):
     R = orc.classify(db, t, p, g["bases"], g["offs"], g["bases2"] if paired else None, g["offs2"] if paired else None)
     assert (R["kmers"] == g["kmers"]).all() and (R["matches"] == g["matches"]).all()
     assert (R["results"] == g["results"]).all() and (R["tc_tax"] == g["tc_tax"]).all() and (R["tc_cnt"] == g["tc_cnt"]).all()
+
+
+def test_slot16_roundtrip(toy, emu):
+    """the 16-byte slot form used inside per-read segments keeps every field of a match of a short read"""
+    import ctypes as C
+    from helpers import match_dt
+    m = toy.ref["matches"]
+    if len(m) == 0 or (m["qinfo"] & np.uint64(0xFFFFFFFF)).max() >= 4096:
+        pytest.skip("positions beyond the slot form (long reads use exact segments)")
+    out = np.zeros(len(m), match_dt)
+    for epoch in (1, 17, 31):
+        rc = emu.lib.emu_slot_roundtrip(m.ctypes.data_as(C.c_void_p), C.c_size_t(len(m)), C.c_uint32(epoch), out.ctypes.data_as(C.c_void_p))
+        assert rc == 0
+        assert (out == m).all()
