@@ -50,6 +50,11 @@ __global__ __launch_bounds__(THREADS) void k_radix_hist(const mtb_kmer *__restri
     for (int b = threadIdx.x; b < NB; b += THREADS) hist[(uint64_t)b * num_tiles + blockIdx.x] = s_h[b];
 }
 
+/* Scatter of one pass.  Every wavefront owns a contiguous eighth (THREADS/64-th) of the tile and ranks its records
+ * on its own: per round the lanes with equal digits find each other with ballots, the first of them bumps the wave's
+ * private counter of that digit and all take "counter before + rank among peers" -- LDS operations of one wave
+ * execute in order, so no workgroup barrier is needed until all rounds are done (the first version synchronised the
+ * workgroup three times per round).  Wave-major ranks = index order inside the tile, so the pass is stable.     */
 template <int NB, int MODE, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_radix_scatter(const mtb_kmer *__restrict__ in, mtb_kmer *__restrict__ out,
                                                             uint64_t n, int shift, const uint32_t *__restrict__ tile_off,
@@ -58,26 +63,28 @@ __global__ __launch_bounds__(THREADS) void k_radix_scatter(const mtb_kmer *__res
     constexpr int NW = THREADS / 64;
     constexpr int TILE = THREADS * MTB_SORT_ITEMS;
     static_assert(NB == THREADS, "one bin per thread");
-    __shared__ uint16_t s_cnt[NW][NB];
-    __shared__ uint16_t s_run[NB];
+    __shared__ uint16_t s_cnt[NW][NB];             /* per wave: records of the digit so far; later: start of the wave's run */
     __shared__ uint16_t s_start[NB];
     __shared__ uint32_t s_tmp[NW];
     __shared__ mtb_kmer s_buf[TILE];
-    const uint32_t t = threadIdx.x, w = t >> 6;
+    const uint32_t t = threadIdx.x, w = t >> 6, lane = t & 63u;
     const uint64_t base = (uint64_t)blockIdx.x * TILE;
     mtb_kmer e[MTB_SORT_ITEMS];
     uint32_t lrank[MTB_SORT_ITEMS];
-    s_run[t] = 0;
+#pragma unroll
+    for (int k = 0; k < NW; k++) s_cnt[k][t] = 0;
+    /* all loads of the thread in flight: wave w owns records [w*64*ITEMS, (w+1)*64*ITEMS) of the tile */
 #pragma unroll
     for (int r = 0; r < MTB_SORT_ITEMS; r++) {
-        uint64_t i = base + (uint64_t)r * THREADS + t;
-        bool valid = i < n;
-        if (valid) e[r] = in[i]; else { e[r].value = 0; e[r].qinfo = 0; }
-        uint32_t d = radix_digit<MODE>(e[r].value, shift);
+        uint64_t i = base + (uint64_t)w * (64 * MTB_SORT_ITEMS) + (uint64_t)r * 64 + lane;
+        if (i < n) e[r] = in[i]; else { e[r].value = 0; e[r].qinfo = 0; }
+    }
+    __syncthreads();
 #pragma unroll
-        for (int k = 0; k < NW; k++) s_cnt[k][t] = 0;
-        __syncthreads();
-        /* lanes of this wave holding the same digit */
+    for (int r = 0; r < MTB_SORT_ITEMS; r++) {
+        uint64_t i = base + (uint64_t)w * (64 * MTB_SORT_ITEMS) + (uint64_t)r * 64 + lane;
+        bool valid = i < n;
+        uint32_t d = radix_digit<MODE>(e[r].value, shift);
         uint64_t peers = __ballot(valid);
 #pragma unroll
         for (int b = 0; b < BITS; b++) {
@@ -86,29 +93,27 @@ __global__ __launch_bounds__(THREADS) void k_radix_scatter(const mtb_kmer *__res
             peers &= bit ? vote : ~vote;
         }
         uint32_t rank_in_wave = (uint32_t)__popcll(peers & lanemask_lt());
-        if (valid && rank_in_wave == 0) s_cnt[w][d] = (uint16_t)__popcll(peers);
-        __syncthreads();
-        uint32_t pre = s_run[d];
-#pragma unroll
-        for (int k = 0; k < NW - 1; k++) if ((int)w > k) pre += s_cnt[k][d];
-        lrank[r] = pre + rank_in_wave;
-        __syncthreads();
-        uint32_t add = 0;
-#pragma unroll
-        for (int k = 0; k < NW; k++) add += s_cnt[k][t];
-        s_run[t] = (uint16_t)(s_run[t] + add);
+        uint32_t before = s_cnt[w][d];                                  /* every peer reads the same value ... */
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+        if (valid && rank_in_wave == 0) s_cnt[w][d] = (uint16_t)(before + (uint32_t)__popcll(peers));   /* ... before the first one bumps it */
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+        lrank[r] = before + rank_in_wave;
     }
     __syncthreads();
+    /* bin t: exclusive offsets of the waves' runs inside the bin, bin total -> exclusive scan over bins */
+    uint32_t run = 0;
+#pragma unroll
+    for (int k = 0; k < NW; k++) { uint32_t c = s_cnt[k][t]; s_cnt[k][t] = (uint16_t)run; run += c; }
     uint32_t tot;
-    uint32_t ex = block_exclusive_scan<uint32_t, NW>((uint32_t)s_run[t], s_tmp, &tot);
+    uint32_t ex = block_exclusive_scan<uint32_t, NW>(run, s_tmp, &tot);
     s_start[t] = (uint16_t)ex;
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < MTB_SORT_ITEMS; r++) {
-        uint64_t i = base + (uint64_t)r * THREADS + t;
+        uint64_t i = base + (uint64_t)w * (64 * MTB_SORT_ITEMS) + (uint64_t)r * 64 + lane;
         if (i < n) {
             uint32_t d = radix_digit<MODE>(e[r].value, shift);
-            s_buf[s_start[d] + lrank[r]] = e[r];
+            s_buf[(uint32_t)s_start[d] + s_cnt[w][d] + lrank[r]] = e[r];
         }
     }
     __syncthreads();
