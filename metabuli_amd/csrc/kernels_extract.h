@@ -43,7 +43,8 @@ __global__ __launch_bounds__(64) void k_extract(ExtractArgs a, const mtb_tables 
                                                 uint32_t *__restrict__ counts, const uint64_t *__restrict__ out_offs,
                                                 mtb_kmer *__restrict__ out, int32_t *__restrict__ qlen,
                                                 int32_t *__restrict__ qlen2, uint32_t *__restrict__ max_len,
-                                                unsigned long long *__restrict__ counter, uint64_t out_cap) {
+                                                unsigned long long *__restrict__ counter, uint64_t out_cap,
+                                                uint16_t *__restrict__ dig_out = nullptr) {
     constexpr bool EMIT = MODE != 0;
     constexpr bool STATS = MODE != 1;             /* qlen / max_len are produced by the count pass or the single pass */
     __shared__ mtb_kmer s_out[MODE == 2 ? MTB_EXTRACT_BUF : 1];
@@ -70,7 +71,14 @@ __global__ __launch_bounds__(64) void k_extract(ExtractArgs a, const mtb_tables 
                 if (chunk_end > out_cap) { overflow = true; chunk_pos = chunk_end; break; }
             }
             const uint32_t room = (uint32_t)(chunk_end - chunk_pos < (uint64_t)(n_buf - done) ? chunk_end - chunk_pos : (uint64_t)(n_buf - done));
-            for (uint32_t i = threadIdx.x; i < room; i += 64) out[chunk_pos + i] = s_out[done + i];
+            for (uint32_t i = threadIdx.x; i < room; i += 64) {
+                const mtb_kmer x = s_out[done + i];
+                out[chunk_pos + i] = x;
+                if (dig_out) {          /* first radix pass's digit (amino-acid letters 4,5 as a base-21 pair, kernels_sort.h) */
+                    uint32_t two = (uint32_t)(x.value >> 34) & 1023u, d = (two >> 5) * 21u + (two & 31u);
+                    dig_out[chunk_pos + i] = (uint16_t)(d < 511u ? d : 511u);
+                }
+            }
             chunk_pos += room; done += room;
         }
         produced += n_buf;
@@ -168,7 +176,7 @@ __global__ __launch_bounds__(64) void k_extract(ExtractArgs a, const mtb_tables 
     flush();
     if (MODE == 2) {
         mtb_kmer blank; blank.value = 0; blank.qinfo = 0;
-        if (!overflow) for (uint64_t i = chunk_pos + threadIdx.x; i < chunk_end; i += 64) out[i] = blank;
+        if (!overflow) for (uint64_t i = chunk_pos + threadIdx.x; i < chunk_end; i += 64) { out[i] = blank; if (dig_out) dig_out[i] = 0; }
         if (threadIdx.x == 0) { if (overflow) counter[1] = 1ull; else atomicAdd(counter + 2, (unsigned long long)produced); atomicMax(counter + 3, (unsigned long long)my_maxq); }
     }
     if (STATS && max_len) {

@@ -50,6 +50,23 @@ __global__ __launch_bounds__(THREADS) void k_radix_hist(const mtb_kmer *__restri
     for (int b = threadIdx.x; b < NB; b += THREADS) hist[(uint64_t)b * num_tiles + blockIdx.x] = s_h[b];
 }
 
+/* Histogram of a pass from a side array of 16-bit digits (written by the extractor for the first pass and by the
+ * previous scatter for the later ones): 2 bytes per record instead of the 16-byte record for a 9-bit digit. */
+template <int NB, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_radix_hist_dig(const uint16_t *__restrict__ dig, uint64_t n, uint32_t *__restrict__ hist, uint32_t num_tiles) {
+    __shared__ uint32_t s_h[NB];
+    for (int b = threadIdx.x; b < NB; b += THREADS) s_h[b] = 0;
+    __syncthreads();
+    uint64_t base = (uint64_t)blockIdx.x * (THREADS * MTB_SORT_ITEMS);
+#pragma unroll
+    for (int r = 0; r < MTB_SORT_ITEMS; r++) {
+        uint64_t i = base + (uint64_t)r * THREADS + threadIdx.x;
+        if (i < n) atomicAdd(&s_h[dig[i] < NB ? dig[i] : NB - 1], 1u);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < NB; b += THREADS) hist[(uint64_t)b * num_tiles + blockIdx.x] = s_h[b];
+}
+
 /* Scatter of one pass.  Every wavefront owns a contiguous eighth (THREADS/64-th) of the tile and ranks its records
  * on its own: per round the lanes with equal digits find each other with ballots, the first of them bumps the wave's
  * private counter of that digit and all take "counter before + rank among peers" -- LDS operations of one wave
@@ -58,7 +75,7 @@ __global__ __launch_bounds__(THREADS) void k_radix_hist(const mtb_kmer *__restri
 template <int NB, int MODE, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_radix_scatter(const mtb_kmer *__restrict__ in, mtb_kmer *__restrict__ out,
                                                             uint64_t n, int shift, const uint32_t *__restrict__ tile_off,
-                                                            uint32_t num_tiles) {
+                                                            uint32_t num_tiles, uint16_t *__restrict__ dig_out = nullptr, int next_shift = 0) {
     constexpr int BITS = NB == 256 ? 8 : 9;
     constexpr int NW = THREADS / 64;
     constexpr int TILE = THREADS * MTB_SORT_ITEMS;
@@ -121,7 +138,9 @@ __global__ __launch_bounds__(THREADS) void k_radix_scatter(const mtb_kmer *__res
     for (uint32_t i = t; i < cnt; i += THREADS) {
         mtb_kmer x = s_buf[i];
         uint32_t d = radix_digit<MODE>(x.value, shift);
-        out[(uint64_t)tile_off[(uint64_t)d * num_tiles + blockIdx.x] + (i - s_start[d])] = x;
+        const uint64_t dst = (uint64_t)tile_off[(uint64_t)d * num_tiles + blockIdx.x] + (i - s_start[d]);
+        out[dst] = x;
+        if (dig_out) dig_out[dst] = (uint16_t)radix_digit<MODE>(x.value, next_shift);      /* next pass's histogram input */
     }
 }
 

@@ -211,7 +211,7 @@ static mtb_status h2d(mtb_ctx *c, void *dst, const void *src, size_t bytes) {
 static mtb_status dev_extract(mtb_ctx *c, const mtb_params *p, const char *d_bases, const uint64_t *d_offs, const char *d_bases2,
                               const uint64_t *d_offs2, uint64_t n_reads, mtb_kmer **out, uint64_t *count, int32_t *d_qlen,
                               int32_t *d_qlen2, uint32_t *max_len, bool single_pass = false, uint64_t n_bases = 0,
-                              uint64_t *real_count = nullptr, bool tag_ord = false, uint32_t *max_q = nullptr) {
+                              uint64_t *real_count = nullptr, bool tag_ord = false, uint32_t *max_q = nullptr, uint16_t **dig = nullptr) {
     if (n_reads >= (1ull << 29)) return fail(MTB_ERR_ARG, "more than 2^29-1 reads per batch (sequenceID is 29 bits, Kmer.h:13)");
     if (p->kmer_format != 1 && p->kmer_format != 2) return fail(MTB_ERR_UNSUPPORTED, "only kmer_format 1 and 2 are implemented");
     if (p->syncmer && (p->smer_len < 1 || p->smer_len > 8)) return fail(MTB_ERR_ARG, "smer_len out of range");
@@ -235,12 +235,13 @@ static mtb_status dev_extract(mtb_ctx *c, const mtb_params *p, const char *d_bas
         uint64_t cap = c->extract_yield > 0.0 ? std::min<uint64_t>(bound, (uint64_t)((double)n_bases * c->extract_yield * 1.15) + 4096) : bound;
         cap = std::max<uint64_t>(cap, std::min<uint64_t>(bound, c->bufs["kmersA"].cap / sizeof(mtb_kmer)));
         for (int attempt = 0; attempt < 2; attempt++) {
-            mtb_kmer *d_k;
+            mtb_kmer *d_k; uint16_t *d_dig = nullptr;
             STCHK(ensure(c, "kmersA", cap, &d_k));
+            if (dig) { STCHK(ensure(c, "digA", cap, &d_dig)); *dig = d_dig; }
             HIPCHK(hipMemsetAsync(c->d_xscal, 0, 32, c->stream));
             { KTimer kt(c, MTB_K_EXTRACT_EMIT);
             hipLaunchKernelGGL((k_extract<2>), dim3(grid), dim3(64), 0, c->stream, a, c->d_tabs, (uint32_t *)nullptr, (const uint64_t *)nullptr,
-                               d_k, d_qlen, d_qlen2, (uint32_t *)(c->d_scal + 4), (unsigned long long *)c->d_xscal, cap); }
+                               d_k, d_qlen, d_qlen2, (uint32_t *)(c->d_scal + 4), (unsigned long long *)c->d_xscal, cap, d_dig); }
             HIPCHK(hipGetLastError());
             uint64_t sc[4];
             STCHK(d2h(c, sc, c->d_xscal, 32));             /* records allocated (incl. blank tails), overflow, real metamers */
@@ -284,7 +285,7 @@ static mtb_status dev_extract(mtb_ctx *c, const mtb_params *p, const char *d_bas
 /* first_bit >= 0: binary LSD passes over bits [first_bit, 64).  first_bit == MTB_SORT_AA6 (kmer_format 2): three
  * passes on amino-acid letter pairs = order by bits [34, 64) (kernels_sort.h). */
 #define MTB_SORT_AA6 (-6)
-static mtb_status dev_sort(mtb_ctx *c, mtb_kmer *d_a, uint64_t n, int first_bit, mtb_kmer **sorted) {
+static mtb_status dev_sort(mtb_ctx *c, mtb_kmer *d_a, uint64_t n, int first_bit, mtb_kmer **sorted, uint16_t *d_dig = nullptr) {
     *sorted = d_a;
     if (n == 0) return MTB_OK;
     const bool aa = first_bit == MTB_SORT_AA6;
@@ -297,15 +298,22 @@ static mtb_status dev_sort(mtb_ctx *c, mtb_kmer *d_a, uint64_t n, int first_bit,
         const uint64_t tile = (uint64_t)bins * MTB_SORT_ITEMS;        /* one bin per thread, 8 records per thread */
         uint32_t tiles = (uint32_t)((n + tile - 1) / tile);
         mtb_kmer *src = d_a, *dst = d_b;
+        /* AA6 with a digit side array: every histogram reads 2-byte digits (the extractor wrote the first pass's, each
+         * scatter writes the next pass's in output order) instead of the 16-byte records */
+        uint16_t *dig_src = aa ? d_dig : nullptr, *dig_dst = nullptr;
+        if (dig_src) STCHK(ensure(c, "digB", n, &dig_dst));
         for (int shift = aa ? 34 : first_bit; shift < 64; shift += aa ? 10 : 8) {
             { KTimer kt(c, MTB_K_RADIX_HIST);
-              if (aa) hipLaunchKernelGGL((k_radix_hist<512, 1, 512>), dim3(tiles), dim3(512), 0, c->stream, (const mtb_kmer *)src, n, shift, d_hist, tiles);
+              if (aa && dig_src) hipLaunchKernelGGL((k_radix_hist_dig<512, 512>), dim3(tiles), dim3(512), 0, c->stream, (const uint16_t *)dig_src, n, d_hist, tiles);
+              else if (aa) hipLaunchKernelGGL((k_radix_hist<512, 1, 512>), dim3(tiles), dim3(512), 0, c->stream, (const mtb_kmer *)src, n, shift, d_hist, tiles);
               else hipLaunchKernelGGL((k_radix_hist<256, 0, 256>), dim3(tiles), dim3(256), 0, c->stream, (const mtb_kmer *)src, n, shift, d_hist, tiles); }
             { KTimer kt(c, MTB_K_SCAN); scan_launch<uint32_t, uint32_t, false>(c->stream, d_hist, (uint64_t)bins * tiles, false, d_hist, (uint32_t *)d_ws); }
             { KTimer kt(c, MTB_K_RADIX_SCATTER);
-              if (aa) hipLaunchKernelGGL((k_radix_scatter<512, 1, 512>), dim3(tiles), dim3(512), 0, c->stream, (const mtb_kmer *)src, dst, n, shift, (const uint32_t *)d_hist, tiles);
+              if (aa) hipLaunchKernelGGL((k_radix_scatter<512, 1, 512>), dim3(tiles), dim3(512), 0, c->stream, (const mtb_kmer *)src, dst, n, shift, (const uint32_t *)d_hist, tiles,
+                                         (dig_src && shift + 10 < 64) ? dig_dst : (uint16_t *)nullptr, shift + 10);
               else hipLaunchKernelGGL((k_radix_scatter<256, 0, 256>), dim3(tiles), dim3(256), 0, c->stream, (const mtb_kmer *)src, dst, n, shift, (const uint32_t *)d_hist, tiles); }
             mtb_kmer *tmp = src; src = dst; dst = tmp;
+            if (dig_src) { uint16_t *t2 = dig_src; dig_src = dig_dst; dig_dst = t2; }
         }
         *sorted = src;
     }
@@ -924,10 +932,12 @@ static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, c
      * first match.  Needs positions < 2^12 (16-byte slot records) and a moderate number of metamers per read; otherwise
      * exact segments. */
     bool fixed = p->seq_mode != 3;
-    STCHK(dev_extract(c, p, d_bases, d_offs, d_bases2, d_offs2, n_reads, &d_k, &nk, d_ql, d_ql2, &max_len, true, n_bases_total, &nk_real, fixed, &max_q));
+    uint16_t *d_dig = nullptr;               /* first radix pass's digits, written by the single-pass extractor */
+    const bool aa6 = p->kmer_format == 2;           /* 5-bit amino-acid letters: three base-21 pair passes order bits [34,64) */
+    STCHK(dev_extract(c, p, d_bases, d_offs, d_bases2, d_offs2, n_reads, &d_k, &nk, d_ql, d_ql2, &max_len, true, n_bases_total, &nk_real, fixed, &max_q, aa6 ? &d_dig : nullptr));
     if (fixed && (max_len + 3 >= MTB_SLOT_MAX_POS || max_q > 384)) {
         fixed = false;                     /* tags would collide with positions / segments would be huge: extract again untagged */
-        STCHK(dev_extract(c, p, d_bases, d_offs, d_bases2, d_offs2, n_reads, &d_k, &nk, d_ql, d_ql2, &max_len, true, n_bases_total, &nk_real, false, &max_q));
+        STCHK(dev_extract(c, p, d_bases, d_offs, d_bases2, d_offs2, n_reads, &d_k, &nk, d_ql, d_ql2, &max_len, true, n_bases_total, &nk_real, false, &max_q, aa6 ? &d_dig : nullptr));
     }
     HIPCHK(hipEventRecord(c->ev[1], st));
     /* the join needs tiles with a narrow amino-acid range, not a total order: kmer_format 2 sorts on the first six
@@ -935,9 +945,8 @@ static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, c
      * passes; three binary passes make the tiles too wide for the LDS window, measured); the tile's target window
      * comes from k_join_bounds */
     mtb_kmer *d_s;
-    const bool aa6 = p->kmer_format == 2;           /* 5-bit amino-acid letters: three base-21 pair passes order bits [34,64) */
     const int low_bits = aa6 ? 34 : 32;
-    STCHK(dev_sort(c, d_k, nk, aa6 ? MTB_SORT_AA6 : 32, &d_s));
+    STCHK(dev_sort(c, d_k, nk, aa6 ? MTB_SORT_AA6 : 32, &d_s, d_dig));
     HIPCHK(hipEventRecord(c->ev[2], st));
     uint32_t *d_rc;
     STCHK(ensure(c, "readcnt", n_reads, &d_rc));
