@@ -20,6 +20,24 @@ __device__ __forceinline__ T wave_inclusive_scan(T v) {
     return v;
 }
 
+/* the same with DPP row shifts / row broadcasts (gfx9: row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143):
+ * six VALU adds with a DPP operand instead of six ds_bpermute round trips.  32-bit int / float only. */
+__device__ __forceinline__ int32_t dpp_add_step(int32_t v, int32_t moved) { return v + moved; }
+__device__ __forceinline__ float dpp_add_step(float v, int32_t moved) { return v + __int_as_float(moved); }
+template <typename T>
+__device__ __forceinline__ T wave_inclusive_scan_dpp(T v) {
+    static_assert(sizeof(T) == 4, "32-bit values");
+#define MTB_DPP_STEP(ctrl, rmask, bctl) do { int32_t b_; __builtin_memcpy(&b_, &v, 4); v = dpp_add_step(v, __builtin_amdgcn_update_dpp(0, b_, ctrl, rmask, 0xF, bctl)); } while (0)
+    MTB_DPP_STEP(0x111, 0xF, true);
+    MTB_DPP_STEP(0x112, 0xF, true);
+    MTB_DPP_STEP(0x114, 0xF, true);
+    MTB_DPP_STEP(0x118, 0xF, true);
+    MTB_DPP_STEP(0x142, 0xA, false);
+    MTB_DPP_STEP(0x143, 0xC, false);
+#undef MTB_DPP_STEP
+    return v;
+}
+
 /* Exclusive scan over a 256-thread workgroup; every thread gets its exclusive
  * prefix and *total (sum over the workgroup).  s_tmp: >= 5 elements of LDS.   */
 template <typename T>

@@ -299,6 +299,64 @@ __device__ __forceinline__ void score_read_par(const REC *src, int32_t n, mtb_sw
         for (int32_t i = lane; i < n; i += 64) simple = simple && mtb_chain_simple(w, i);
         simple = __all(simple);
     }
+    /* every link goes to the slot just before (position groups of one match, the usual case): the chains are
+     * contiguous runs and V[i] = P[i] - P[root(i)] with P = ONE inclusive prefix sum of the per-link increments over
+     * the slots (in registers, 6 shuffle steps) -- no doubling rounds.  Scores are multiples of 0.5, hamming / depth
+     * small integers: the sums are exact in any association, so the paths are bit-identical. */
+    bool adjacent = simple && small_n && sizeof(IDX) == 2;
+    if (adjacent) {
+#pragma unroll
+        for (int k = 0; k < MAXPER; k++) {
+            const int32_t i = lane + 64 * k;
+            if (i < n) { const uint32_t sh = w.shift[i], cm = w.cmask[i]; if (sh && cm) adjacent = adjacent && ((int32_t)w.bid[i] + __builtin_ctz(cm) == i - 1); }
+        }
+        adjacent = __all(adjacent);
+    }
+    if (adjacent) {
+        float ps[MAXPER]; int32_t phd[MAXPER]; int32_t root[MAXPER];
+        float carry_s = 0.0f; int32_t carry_hd = 0, last_root = 0;
+        const int32_t nslot = (n + 63) >> 6;
+#pragma unroll
+        for (int k = 0; k < MAXPER; k++) {
+            ps[k] = 0.0f; phd[k] = 0; root[k] = 0;
+            if (k < nslot) {
+                const int32_t i = lane + 64 * k;
+                float is = 0.0f; int32_t ihd = 0; bool is_root = true;
+                if (i < n) {
+                    const uint32_t sh = w.shift[i], cm = w.cmask[i];
+                    if (sh && cm) {
+                        const int32_t shift = (int32_t)(sh & 0x7Fu);
+                        const uint32_t reh = w.m[i].right_end_hamming;
+                        is = mtb_part_score(reh, shift, false); ihd = (mtb_part_ham(reh, shift, false) << 16) | shift; is_root = false;
+                    }
+                }
+                ps[k] = wave_inclusive_scan_dpp(is) + carry_s; phd[k] = wave_inclusive_scan_dpp(ihd) + carry_hd;
+                carry_s = __shfl(ps[k], 63, 64); carry_hd = __shfl(phd[k], 63, 64);
+                const uint64_t mr = __ballot(is_root && i < n);
+                const uint64_t le = mr & (lt | (1ull << lane));
+                root[k] = le ? 64 * k + 63 - (int32_t)__builtin_clzll(le) : last_root;
+                if (mr) last_root = 64 * k + 63 - (int32_t)__builtin_clzll(mr);
+            }
+        }
+        mtb_jump *pre = (mtb_jump *)w.path;              /* P[] where every lane can read it (the path storage is free until the end) */
+#pragma unroll
+        for (int k = 0; k < MAXPER; k++) { const int32_t i = lane + 64 * k; if (i < n) { mtb_jump j; j.ptr = 0; j.score = ps[k]; j.ham = phd[k]; j.depth = 0; pre[i] = j; } }
+        score_sync<IDX>();
+        mtb_jump fin[MAXPER];
+#pragma unroll
+        for (int k = 0; k < MAXPER; k++) {
+            const int32_t i = lane + 64 * k;
+            if (i < n) {
+                const mtb_jump pr = pre[root[k]];
+                const int32_t dhd = phd[k] - pr.ham;
+                fin[k].ptr = root[k] == i ? -1 : root[k]; fin[k].score = ps[k] - pr.score; fin[k].ham = dhd >> 16; fin[k].depth = dhd & 0xFFFF;
+            }
+        }
+        score_sync<IDX>();
+#pragma unroll
+        for (int k = 0; k < MAXPER; k++) { const int32_t i = lane + 64 * k; if (i < n) w.path[i] = mtb_ph_jump_final(w, i, fin[k]); }
+        score_sync<IDX>();
+    } else
     if (simple && !small_n) {
         /* big segment (HBM slab): ping-pong between the path storage and the (now dead) sid/rk/grp_start/blk_start block */
         mtb_jump *ja = (mtb_jump *)w.path, *jb = (mtb_jump *)w.sid;
