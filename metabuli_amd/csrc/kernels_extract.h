@@ -86,7 +86,7 @@ __global__ __launch_bounds__(64) void k_extract(ExtractArgs a, const mtb_tables 
         n_buf = 0;
     };
     __shared__ mtb_tables s_tab;
-    __shared__ uint8_t s_cod[80];
+    __shared__ __attribute__((aligned(8))) uint8_t s_cod[80];
     __shared__ uint8_t s_code[MTB_EXTRACT_STAGE];      /* a short read's bases as codes: one global load serves all six frames */
     const uint32_t lane = threadIdx.x;
     for (uint32_t i = lane; i < sizeof(mtb_tables) / 4; i += 64) ((uint32_t *)&s_tab)[i] = ((const uint32_t *)tabs)[i];
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(64) void k_extract(ExtractArgs a, const mtb_tables 
                 const int32_t begin = mtb_frame_begin(len, f);
                 /* tagged single pass: ordinals must rise with the position inside a frame, and the positions of a reverse
                  * frame fall with the window index -> walk its chunks (and rank inside a chunk) backwards */
-                const bool back = MODE == 2 && a.tag_ord && !fwd;
+                const bool back = MODE == 2 && a.tag_ord && (old_fmt ? fwd : !fwd);      /* OldMetamerScanner: the forward frames fall */
                 const int32_t n_chunk = (n_win + 63) / 64;
                 for (int32_t cw = 0; cw < n_chunk; cw++) {
                     const int32_t w0 = (back ? n_chunk - 1 - cw : cw) * 64;
@@ -147,7 +147,15 @@ __global__ __launch_bounds__(64) void k_extract(ExtractArgs a, const mtb_tables 
                     __syncthreads();
                     int32_t w = w0 + (int32_t)lane;
                     bool ok = false; uint64_t v = 0;
-                    if (w < n_win) ok = old_fmt ? mtb_window_metamer_old(&s_cod[lane], &v) : mtb_window_metamer(&s_cod[lane], a.syncmer, a.smer_len, &v);
+                    if (w < n_win) {
+                        if (old_fmt) ok = mtb_window_metamer_old(&s_cod[lane], &v);
+                        else {          /* the window's 8 codon bytes from three aligned LDS words + two byte alignments */
+                            const uint32_t *c32 = (const uint32_t *)s_cod;
+                            const uint32_t q = lane >> 2, sh = lane & 3u;
+                            const uint32_t x0 = c32[q], x1 = c32[q + 1], x2 = c32[q + 2];
+                            ok = mtb_window_metamer_words(__builtin_amdgcn_alignbyte(x1, x0, sh), __builtin_amdgcn_alignbyte(x2, x1, sh), a.syncmer, a.smer_len, &v);
+                        }
+                    }
                     uint64_t mask = __ballot(ok);
                     uint32_t c = (uint32_t)__popcll(mask);
                     if (MODE == 2 && n_buf + c > MTB_EXTRACT_BUF) flush();        /* wave-uniform */

@@ -186,18 +186,26 @@ MTB_UNROLL
     *value = (aa << 24) | (dna & 0xFFFFFFull);
     return true;
 }
-MTB_HD bool mtb_window_metamer(const uint8_t *cod, int syncmer, int smer_len, uint64_t *value) {
-    uint64_t aa = 0, dna = 0;
-    uint32_t bad = 0;
-MTB_UNROLL
-    for (int i = 0; i < 8; i++) {
-        uint32_t b = cod[i];
-        bad |= (b == 0xFFu);
-        aa = (aa << 5) | (b & 31u);
-        dna = (dna << 3) | (b >> 5);
-    }
+/* Word form: w0 = codon bytes 0..3, w1 = codon bytes 4..7 (byte 0 of a word = the earlier codon).  The four 5-bit
+ * amino-acid fields and 3-bit codon ids of a word are gathered with mask / shift pairs instead of a byte loop
+ * (the extractor is VALU-bound: ~45 instead of ~80 instructions per window). */
+MTB_HD uint32_t mtb_pack_aa4(uint32_t w) {           /* f0<<15 | f1<<10 | f2<<5 | f3, f_i = byte_i & 31 */
+    uint32_t x = ((w & 0x001F001Fu) << 5) | ((w >> 8) & 0x001F001Fu);
+    return ((x & 0x3FFu) << 10) | (x >> 16);
+}
+MTB_HD uint32_t mtb_pack_cid4(uint32_t w) {          /* c0<<9 | c1<<6 | c2<<3 | c3, c_i = byte_i >> 5 */
+    uint32_t y = (w >> 5) & 0x07070707u;
+    uint32_t p = ((y & 0x00070007u) << 3) | ((y >> 8) & 0x00070007u);
+    return ((p & 0x3Fu) << 6) | (p >> 16);
+}
+MTB_HD bool mtb_window_metamer_words(uint32_t w0, uint32_t w1, int syncmer, int smer_len, uint64_t *value) {
+    /* an invalid codon is the byte 0xFF; no valid byte has the amino-acid field 31 */
+    uint32_t bad = (((w0 & 0x1F1F1F1Fu) + 0x01010101u) | ((w1 & 0x1F1F1F1Fu) + 0x01010101u)) & 0x20202020u;
     if (bad) return false;
-    *value = (aa << 24) | (dna & 0xFFFFFFull);
+    const uint32_t a0 = mtb_pack_aa4(w0), a1 = mtb_pack_aa4(w1);           /* 20 bits each */
+    const uint32_t dna = (mtb_pack_cid4(w0) << 12) | mtb_pack_cid4(w1);
+    const uint64_t aa = ((uint64_t)a0 << 20) | a1;
+    *value = (aa << 24) | dna;
     if (!syncmer) return true;
     int ns = 8 - smer_len + 1;
     uint64_t mask = (1ull << (5 * smer_len)) - 1;
@@ -207,6 +215,11 @@ MTB_UNROLL
         if (s < best) { best = s; arg = k; }                      /* leftmost on ties */
     }
     return arg == 0 || arg == ns - 1;
+}
+MTB_HD bool mtb_window_metamer(const uint8_t *cod, int syncmer, int smer_len, uint64_t *value) {
+    uint32_t w0 = (uint32_t)cod[0] | ((uint32_t)cod[1] << 8) | ((uint32_t)cod[2] << 16) | ((uint32_t)cod[3] << 24);
+    uint32_t w1 = (uint32_t)cod[4] | ((uint32_t)cod[5] << 8) | ((uint32_t)cod[6] << 16) | ((uint32_t)cod[7] << 24);
+    return mtb_window_metamer_words(w0, w1, syncmer, smer_len, value);
 }
 
 /* ------------------------------------------------------------------ */
