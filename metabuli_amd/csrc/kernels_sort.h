@@ -51,20 +51,39 @@ __global__ __launch_bounds__(THREADS) void k_radix_hist(const mtb_kmer *__restri
 }
 
 /* Histogram of a pass from a side array of 16-bit digits (written by the extractor for the first pass and by the
- * previous scatter for the later ones): 2 bytes per record instead of the 16-byte record for a 9-bit digit. */
+ * previous scatter for the later ones): 2 bytes per record instead of the 16-byte record for a 9-bit digit.
+ * A workgroup counts MTB_HIST_GROUP consecutive tiles and writes, per bin, the counts of those tiles as one 64-byte
+ * run of the digit-major table (one bin per thread): writing tile by tile put a lone 4-byte word into every sector,
+ * 5 GB of HBM writes for a 0.64 GB table (PMC WRITE_SIZE). */
+#define MTB_HIST_GROUP 16
 template <int NB, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_radix_hist_dig(const uint16_t *__restrict__ dig, uint64_t n, uint32_t *__restrict__ hist, uint32_t num_tiles) {
-    __shared__ uint32_t s_h[NB];
-    for (int b = threadIdx.x; b < NB; b += THREADS) s_h[b] = 0;
-    __syncthreads();
-    uint64_t base = (uint64_t)blockIdx.x * (THREADS * MTB_SORT_ITEMS);
+    static_assert(NB == THREADS, "one bin per thread");
+    __shared__ uint32_t s_h[MTB_HIST_GROUP][NB];
+    const uint32_t tile0 = blockIdx.x * MTB_HIST_GROUP;
 #pragma unroll
-    for (int r = 0; r < MTB_SORT_ITEMS; r++) {
-        uint64_t i = base + (uint64_t)r * THREADS + threadIdx.x;
-        if (i < n) atomicAdd(&s_h[dig[i] < NB ? dig[i] : NB - 1], 1u);
+    for (int g = 0; g < MTB_HIST_GROUP; g++) s_h[g][threadIdx.x] = 0;
+    __syncthreads();
+    for (int g = 0; g < MTB_HIST_GROUP; g++) {
+        const uint64_t base = (uint64_t)(tile0 + g) * (THREADS * MTB_SORT_ITEMS);
+        if (base >= n) break;
+#pragma unroll
+        for (int r = 0; r < MTB_SORT_ITEMS; r++) {
+            uint64_t i = base + (uint64_t)r * THREADS + threadIdx.x;
+            if (i < n) { uint32_t d = dig[i]; atomicAdd(&s_h[g][d < NB ? d : NB - 1], 1u); }
+        }
     }
     __syncthreads();
-    for (int b = threadIdx.x; b < NB; b += THREADS) hist[(uint64_t)b * num_tiles + blockIdx.x] = s_h[b];
+    uint32_t *row = hist + (uint64_t)threadIdx.x * num_tiles + tile0;
+    if (tile0 + MTB_HIST_GROUP <= num_tiles && (((uint64_t)threadIdx.x * num_tiles + tile0) & 3u) == 0) {
+#pragma unroll
+        for (int g = 0; g < MTB_HIST_GROUP; g += 4) {
+            uint4 v; v.x = s_h[g][threadIdx.x]; v.y = s_h[g + 1][threadIdx.x]; v.z = s_h[g + 2][threadIdx.x]; v.w = s_h[g + 3][threadIdx.x];
+            *(uint4 *)(row + g) = v;
+        }
+    } else {
+        for (int g = 0; g < MTB_HIST_GROUP && tile0 + g < num_tiles; g++) row[g] = s_h[g][threadIdx.x];
+    }
 }
 
 /* Scatter of one pass.  Every wavefront owns a contiguous eighth (THREADS/64-th) of the tile and ranks its records

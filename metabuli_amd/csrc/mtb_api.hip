@@ -304,7 +304,7 @@ static mtb_status dev_sort(mtb_ctx *c, mtb_kmer *d_a, uint64_t n, int first_bit,
         if (dig_src) STCHK(ensure(c, "digB", n, &dig_dst));
         for (int shift = aa ? 34 : first_bit; shift < 64; shift += aa ? 10 : 8) {
             { KTimer kt(c, MTB_K_RADIX_HIST);
-              if (aa && dig_src) hipLaunchKernelGGL((k_radix_hist_dig<512, 512>), dim3(tiles), dim3(512), 0, c->stream, (const uint16_t *)dig_src, n, d_hist, tiles);
+              if (aa && dig_src) hipLaunchKernelGGL((k_radix_hist_dig<512, 512>), dim3((tiles + MTB_HIST_GROUP - 1) / MTB_HIST_GROUP), dim3(512), 0, c->stream, (const uint16_t *)dig_src, n, d_hist, tiles);
               else if (aa) hipLaunchKernelGGL((k_radix_hist<512, 1, 512>), dim3(tiles), dim3(512), 0, c->stream, (const mtb_kmer *)src, n, shift, d_hist, tiles);
               else hipLaunchKernelGGL((k_radix_hist<256, 0, 256>), dim3(tiles), dim3(256), 0, c->stream, (const mtb_kmer *)src, n, shift, d_hist, tiles); }
             { KTimer kt(c, MTB_K_SCAN); scan_launch<uint32_t, uint32_t, false>(c->stream, d_hist, (uint64_t)bins * tiles, false, d_hist, (uint32_t *)d_ws); }
