@@ -289,9 +289,21 @@ def main():
     dom = max((k for k in alg), key=lambda k: kern[k]["ms"])
     avg_ms = kern[dom]["ms"] / max(1, kern[dom]["launches"])
     achieved = alg[dom] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    roofline = dict(bound="hbm", kernel=dom, achieved=achieved, peak=8000.0, unit="GB/s", frac=achieved / 8000.0, traffic=None,
+    # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 cannot run inside this process);
+    # only when they were taken on this very workload
+    traffic, traffic_note = None, "no PMC passes for this workload (profiles/pmc_traffic.json)"
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        wl = pj["workload"]
+        if (wl["reads"], wl["read_len"], wl["targets"], wl["seq_mode"]) == (args.reads, args.read_len, int(ps.n_targets), args.seq_mode) and dom in pj["kernels"]:
+            kk = pj["kernels"][dom]
+            traffic = (2.0 * kk.get("fetch_size_kb", 0.0) + kk.get("write_size_kb", 0.0)) * 1024.0
+            traffic_note = f"{pj['source']}: {pj['correction']}"
+    except (OSError, KeyError, ValueError):
+        pass
+    roofline = dict(bound="hbm", kernel=dom, achieved=achieved, peak=8000.0, unit="GB/s", frac=achieved / 8000.0, traffic=traffic, traffic_note=traffic_note,
                     avg_launch_ms=avg_ms, launches=kern[dom]["launches"], algorithmic_bytes_per_launch=alg[dom],
-                    note="per-kernel durations from an extra single-stream step (no overlap); PMC traffic in profiles/")
+                    note="per-kernel durations from HIP events around every launch of one extra step; traffic = HBM bytes per launch from the PMC passes")
 
     # sanity of the timed output: fraction of reads classified
     res = np.frombuffer(d_res.cpu().numpy().tobytes(), dtype=M.result_dt)

@@ -2,15 +2,17 @@
  * read (Classifier::assignTaxonomy -> Taxonomer::chooseBestTaxon,
  * src/commons/Classifier.cpp:166-208, src/commons/Taxonomer.cpp:130-699).
  *
- * The read's sorted match segment is staged in LDS (or, for segments larger
- * than MTB_SCORE_LDS matches, in a per-workgroup slab in HBM).  Lanes then
- * work on independent pieces of the reference's nested loops:
- *   phase 1  one lane per (species, frame) block: chain DP (getMatchPaths);
- *            every match owns the slot of the only path it can end;
- *   phase 2  one lane per species block: stable order + greedy combination of
- *            its paths (combineMatchPaths), score at the block's first slot;
- *   phase 3  lane 0: best species / ties -> LCA, redundancy filter, sub-species
- *            descent (mtb_read_decide).
+ * The read's matches are staged in LDS (slot mode: the live slots of its segment, compacted in slot order; other
+ * callers: its exact segment; segments beyond the LDS capacity work out of a per-workgroup slab in HBM).  The
+ * wave then runs the phases of mtb_score_par.h, every lane on its own matches / paths / species:
+ *   order    nothing if the staged order already is compareMatches' (usual on the slot path), a two-run merge for
+ *            read pairs, otherwise a rank sort on a 64-bit key
+ *   paths    head flags + ballot prefix sums -> position groups, (species, frame) blocks, species; links; chain DP
+ *            (getMatchPaths) as one prefix sum, by pointer doubling, or in rounds, depending on the link structure
+ *   combine  per species: parallel stable rank of its paths, parallel certain-drop test, short serial greedy pass
+ *            (combineMatchPaths)
+ *   decide   lane 0: best species / ties -> LCA; match-parallel redundancy filter; wave-parallel taxCnt gather;
+ *            sub-species descent on pre-climbed chains
  * Algorithmic HBM bytes: 24 per match read + 24 per read result written.     */
 #ifndef MTB_KERNELS_SCORE_H
 #define MTB_KERNELS_SCORE_H

@@ -335,7 +335,7 @@ static mtb_tax_view tax_view(const mtb_index *ix) {
 }
 
 /* join into d_out (cap entries); *count = matches found (may exceed cap -> MTB_ERR_CAPACITY).
- * With `seg` (fixed-capacity per-read segments) matches go to seg->seg and the overflow list instead; *count is then
+ * With `seg` (per-read slot segments, k_join<SEG>) matches go to seg->seg and the overflow list instead; *count is then
  * the number of overflow entries needed and MTB_ERR_CAPACITY refers to the overflow list.                     */
 static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint64_t n, mtb_match *d_out, uint64_t cap,
                            uint32_t *d_read_cnt, uint64_t *count, const JoinSegArgs *seg = nullptr, int sort_low_bits = 32) {
