@@ -283,3 +283,74 @@ def test_index_write_reproduces_the_database_files(ctx, toy, tmp_path):
     res, tt, tc = ctx.classify_batch(ix2, p2, toy.b1, toy.o1, toy.b2, toy.o2)
     assert (res["classification"] == toy.ref["results"]["classification"]).all()
     ix2.close()
+
+
+def test_slot_epoch_wraps_without_stale_matches(toy, orc):
+    """the slot segments of the fused path are never cleared between batches: live slots carry a 5-bit epoch tag that
+    wraps every 31 batches.  40 batches on one context, alternating two different read sets, must keep giving the
+    oracle's answers (a stale slot read as live would add foreign matches)."""
+    import metabuli_amd as M
+    if toy.p.seq_mode == 3:
+        pytest.skip("long reads use exact segments")
+    p = _params(toy)
+    ctx = M.Context(0)
+    ix = ctx.open_index(toy.dbdir, p)
+    n = toy.n_reads
+    half = n // 2
+    # second read set: the first half of the reads only (same buffers, fewer reads) -> different slot contents
+    o1b = toy.o1[:half + 1].copy(); b1b = toy.b1[:int(o1b[-1])]
+    o2b = toy.o2[:half + 1].copy() if toy.o2 is not None else None
+    b2b = toy.b2[:int(o2b[-1])] if toy.o2 is not None else None
+    ref = toy.ref["results"]
+    for it in range(40):
+        if it % 2 == 0:
+            res, tt, tc = ctx.classify_batch(ix, p, toy.b1, toy.o1, toy.b2, toy.o2)
+            assert (res["classification"] == ref["classification"]).all(), it
+            assert (res["score"].view(np.uint32) == ref["score"].view(np.uint32)).all(), it
+            assert (tt == toy.ref["tc_tax"]).all() and (tc == toy.ref["tc_cnt"]).all(), it
+        else:
+            res, tt, tc = ctx.classify_batch(ix, p, b1b, o1b, b2b, o2b)
+            assert (res["classification"] == ref["classification"][:half]).all(), it
+            assert (res["score"].view(np.uint32) == ref["score"][:half].view(np.uint32)).all(), it
+    ix.close(); ctx.close()
+
+
+def test_many_matches_per_query_take_the_large_segment_path(ctx, orc, tmp_path):
+    """every metamer of one genus is also filed under 20 further species of the same genus: a query then has ~20 matches,
+    the tail of the read's slot segment overflows, the read is deferred to the large-segment launch (exact segment from
+    live slots + overflow list, sorted in HBM).  Results must still be the oracle's."""
+    from helpers import default_params
+    from metabuli_amd import synth
+    import metabuli_amd as M
+    rng = np.random.default_rng(41)
+    w = synth.make_world(seed=41, n_genera=2, species_per_genus=2, strains_per_species=1, genome_len=20000, with_euk=False)
+    # 20 extra species under genus 0 (taxid 4), each a copy of the first genome's metamers
+    nxt = max(w.tax.parent) + 1
+    extra_sp = []
+    for i in range(20):
+        w.tax.add(nxt, 4, "species", f"copy{i}"); extra_sp.append(nxt); nxt += 1
+    p = default_params(seq_mode=1, syncmer=1)
+    from helpers import build_toy_db
+    g0 = w.genomes[0][1]
+    k, _, _ = orc.extract_batch(default_params(seq_mode=3, syncmer=1), g0, np.array([0, len(g0)], np.uint64))
+    v0 = np.unique(k["value"])
+    ev = np.tile(v0, len(extra_sp)); et = np.repeat(np.array(extra_sp, np.int32), len(v0))
+    d = str(tmp_path / "db"); os.makedirs(d)
+    vals, tids = build_toy_db(orc, w, p, d, extra=(ev, et))
+    tax = orc.load_taxonomy(os.path.join(d, "taxonomy"))
+    db = orc.open_db(d, tax, p)
+    b, o, truth = synth.sample_reads(rng, w, 150, length=150, err=0.01, frac_random=0.1)
+    ref = orc.classify(db, tax, p, b, o)
+    per_read = np.bincount((ref["matches"]["qinfo"] >> np.uint64(32)).astype(np.int64) & 0x1FFFFFFF, minlength=151)[1:]
+    assert per_read.max() > 1000                                   # far beyond the slot segment of a read
+    mp = M.default_params(seq_mode=1, syncmer=1)
+    ix = ctx.open_index(d, mp)
+    res, tt, tc = ctx.classify_batch(ix, mp, b, o)
+    ro = ref["results"]
+    amb = ro["flag"] != 0
+    assert ((res["classification"] == ro["classification"]) | amb).all()
+    assert ((res["score"].view(np.uint32) == ro["score"].view(np.uint32)) | amb).all()
+    if not amb.any():
+        assert (tt == ref["tc_tax"]).all() and (tc == ref["tc_cnt"]).all()
+    assert (res["is_classified"] != 0).sum() > 60
+    ix.close()
