@@ -547,7 +547,7 @@ __global__ __launch_bounds__(64, (CAP > MTB_SCORE_LDS ? 2 : MTB_SCORE_MINWAVES))
                                                const uint32_t *__restrict__ list, const uint32_t *__restrict__ n_list,
                                                const uint32_t *__restrict__ cursor, uint32_t stride, int seg_by_list,
                                                uint32_t direct, uint32_t epoch, uint32_t *__restrict__ big_list, uint32_t *__restrict__ n_big_out,
-                                               uint32_t *__restrict__ cnt_out) {
+                                               uint32_t *__restrict__ cnt_out, unsigned long long *__restrict__ work) {
     __shared__ __attribute__((aligned(16))) uint8_t s_ws[MTB_SCORE_WS_BYTES_(CAP)];
     __shared__ uint32_t s_pf[64];                 /* landing zone of the slot prefetch (never read) */
     /* bucket / taxCnt / chain arrays of the decide phase live in the path storage,
@@ -561,12 +561,16 @@ __global__ __launch_bounds__(64, (CAP > MTB_SCORE_LDS ? 2 : MTB_SCORE_MINWAVES))
     const uint32_t lane = threadIdx.x;
     MTB_PHASE_KERNEL_BEGIN();
     const uint64_t n_iter = list ? (uint64_t)*n_list : n_reads;      /* optional: only the listed reads */
-    for (uint64_t it = blockIdx.x; it < n_iter; it += gridDim.x) {
+    /* `work` (slab launches: long reads, each worth milliseconds): the workgroups claim reads one by one from a counter
+     * instead of striding -- the slab pool limits the grid to the resident workgroups, and a static split of a few
+     * thousand very unequal reads leaves most of them idle at the end */
+    for (uint64_t it = work ? (uint64_t)__shfl(lane == 0 ? atomicAdd(work, 1ull) : 0ull, 0, 64) : blockIdx.x; it < n_iter;
+         it = work ? (uint64_t)__shfl(lane == 0 ? atomicAdd(work, 1ull) : 0ull, 0, 64) : it + gridDim.x) {
 #ifdef MTB_SCORE_PHASE_CYCLES
         unsigned long long kt0_ = __builtin_readcyclecounter();
 #endif
         const uint64_t r = list ? (uint64_t)list[it] : it;
-        if (cursor && !list && it + gridDim.x < n_iter) {
+        if (cursor && !list && !work && it + gridDim.x < n_iter) {
             /* slot mode: start pulling the NEXT read's slots towards L2 now (one dword per 128-byte line, delivered
              * straight into a dummy LDS area: no register, nothing waits for it) -- the slot loads are one dependent
              * HBM round trip per read with nothing to overlap otherwise */

@@ -457,14 +457,18 @@ static mtb_status dev_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, uint
         uint32_t slab_nb = need_slab ? max_nb : 0;
         uint64_t slab_bytes = need_slab ? score_slab_bytes(slab_n, slab_nb) : 0;
         uint8_t *d_slabs = nullptr;
+        const bool dynamic = need_slab && !S->cursor;       /* slab launches claim reads from a counter: the grid is what is resident */
+        if (dynamic) grid = std::min<uint32_t>(grid, 256u * 14u);
         if (slab_bytes) {
             while ((uint64_t)grid * slab_bytes > (48ull << 30) && grid > 64) grid /= 2;     /* keep the slab pool below 48 GiB (a halved grid halves the waves that hide the slab's HBM latency) */
             STCHK(ensure(c, "slabs", (size_t)grid * slab_bytes, &d_slabs));
         }
+        unsigned long long *d_work = nullptr;
+        if (dynamic) { d_work = (unsigned long long *)(c->d_xscal + 4 + pass); HIPCHK(hipMemsetAsync(d_work, 0, 8, c->stream)); }
         KTimer kt(c, pass == 0 ? MTB_K_SCORE : MTB_K_SEGSORT);      /* the deferred reads' launch is booked with the large-segment path */
 #define MTB_LAUNCH_SCORE(SRT, K, CAPV) hipLaunchKernelGGL((k_score<SRT, K, mtb_match, CAPV>), dim3(grid), dim3(64), 0, c->stream, S->m, S->seg, n_reads, d_qlen, \
         d_qlen2, tax_view(ix), sp, (const uint64_t *)d_tcoff, d_res, d_tc_tax, d_tc_cnt, tc_cap, d_slabs, slab_bytes, slab_n, slab_nb, (mtb_match *)nullptr,  \
-        tc_base, S->list, S->n_list, S->cursor, S->stride, S->seg_by_list, S->direct, S->epoch, S->big_list, S->n_big, S->cnt_out)
+        tc_base, S->list, S->n_list, S->cursor, S->stride, S->seg_by_list, S->direct, S->epoch, S->big_list, S->n_big, S->cnt_out, d_work)
         if (S->sort && S->cap > MTB_SCORE_LDS) { if (key64) MTB_LAUNCH_SCORE(true, true, 320); else MTB_LAUNCH_SCORE(true, false, 320); }
         else if (S->sort) { if (key64) MTB_LAUNCH_SCORE(true, true, MTB_SCORE_LDS); else MTB_LAUNCH_SCORE(true, false, MTB_SCORE_LDS); }
         else MTB_LAUNCH_SCORE(false, false, MTB_SCORE_LDS);
