@@ -536,7 +536,7 @@ __device__ __forceinline__ void score_read_par(const REC *src, int32_t n, mtb_sw
  * already be sorted in HBM (k_segsort_large).                               */
 #define MTB_SCORE_WS_BYTES_(C) (((C) * (24 + 24 + 3) + ((C) + 1) * 8 * 2 + 64 + 15) & ~15)
 /* CAP = matches staged in LDS per read: 160 (10.8 KB per wave, 14 waves/CU) for single reads, 320 for read pairs */
-template <bool SORT, bool KEY64, typename REC, int CAP = MTB_SCORE_LDS>
+template <bool SORT, bool KEY64, typename REC, int CAP = MTB_SCORE_LDS, bool DYN = false>
 __global__ __launch_bounds__(64, (CAP > MTB_SCORE_LDS ? 2 : MTB_SCORE_MINWAVES)) void k_score(const REC *__restrict__ matches, const uint64_t *__restrict__ seg_start,
                                                uint64_t n_reads, const int32_t *__restrict__ qlen, const int32_t *__restrict__ qlen2,
                                                mtb_tax_view tx, mtb_score_params sp, const uint64_t *__restrict__ tc_off,
@@ -561,16 +561,17 @@ __global__ __launch_bounds__(64, (CAP > MTB_SCORE_LDS ? 2 : MTB_SCORE_MINWAVES))
     const uint32_t lane = threadIdx.x;
     MTB_PHASE_KERNEL_BEGIN();
     const uint64_t n_iter = list ? (uint64_t)*n_list : n_reads;      /* optional: only the listed reads */
-    /* `work` (slab launches: long reads, each worth milliseconds): the workgroups claim reads one by one from a counter
-     * instead of striding -- the slab pool limits the grid to the resident workgroups, and a static split of a few
-     * thousand very unequal reads leaves most of them idle at the end */
-    for (uint64_t it = work ? (uint64_t)__shfl(lane == 0 ? atomicAdd(work, 1ull) : 0ull, 0, 64) : blockIdx.x; it < n_iter;
-         it = work ? (uint64_t)__shfl(lane == 0 ? atomicAdd(work, 1ull) : 0ull, 0, 64) : it + gridDim.x) {
+    /* DYN (slab launches: long reads, each worth milliseconds): the workgroups claim reads one by one from the counter
+     * `work` instead of striding -- the slab pool limits the grid to the resident workgroups, and a static split of a few
+     * thousand very unequal reads leaves most of them idle at the end.  A compile-time switch: as a run-time one it cost
+     * the short-read instantiation 12 % (59 -> 66 ms, more spill traffic). */
+    for (uint64_t it = DYN ? (uint64_t)__shfl(lane == 0 ? atomicAdd(work, 1ull) : 0ull, 0, 64) : (uint64_t)blockIdx.x; it < n_iter;
+         it = DYN ? (uint64_t)__shfl(lane == 0 ? atomicAdd(work, 1ull) : 0ull, 0, 64) : it + gridDim.x) {
 #ifdef MTB_SCORE_PHASE_CYCLES
         unsigned long long kt0_ = __builtin_readcyclecounter();
 #endif
         const uint64_t r = list ? (uint64_t)list[it] : it;
-        if (cursor && !list && !work && it + gridDim.x < n_iter) {
+        if (!DYN && cursor && !list && it + gridDim.x < n_iter) {
             /* slot mode: start pulling the NEXT read's slots towards L2 now (one dword per 128-byte line, delivered
              * straight into a dummy LDS area: no register, nothing waits for it) -- the slot loads are one dependent
              * HBM round trip per read with nothing to overlap otherwise */
