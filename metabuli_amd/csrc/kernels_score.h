@@ -124,6 +124,7 @@ __device__ __forceinline__ void score_read_par(const REC *src, int32_t n, mtb_sw
                                                uint32_t *__restrict__ tc_cnt, uint64_t tc_cap, mtb_match *__restrict__ sorted_out,
                                                mtb_result &R) {
     constexpr int MAXPER = (CAP + 63) / 64;          /* register slots per lane that cover a staged segment */
+    if (sizeof(IDX) == 2) __builtin_assume(n >= 1 && n <= CAP);     /* LDS workspace: lets the compiler drop the big-segment variants */
     const int32_t lane = (int32_t)threadIdx.x;
     const uint64_t lt = lanemask_lt();
     w.n = n;
@@ -536,7 +537,9 @@ __device__ __forceinline__ void score_read_par(const REC *src, int32_t n, mtb_sw
  * already be sorted in HBM (k_segsort_large).                               */
 #define MTB_SCORE_WS_BYTES_(C) (((C) * (24 + 24 + 3) + ((C) + 1) * 8 * 2 + 64 + 15) & ~15)
 /* CAP = matches staged in LDS per read: 160 (10.8 KB per wave, 14 waves/CU) for single reads, 320 for read pairs */
-template <bool SORT, bool KEY64, typename REC, int CAP = MTB_SCORE_LDS, bool DYN = false>
+/* SLOT = slot mode (segments filled by k_join<SEG>, `cursor` set): a compile-time switch so that the instantiation the
+ * short-read path runs does not carry the exact-segment / slab code (and its register pressure) along. */
+template <bool SORT, bool KEY64, typename REC, int CAP = MTB_SCORE_LDS, bool DYN = false, bool SLOT = false>
 __global__ __launch_bounds__(64, (CAP > MTB_SCORE_LDS ? 2 : MTB_SCORE_MINWAVES)) void k_score(const REC *__restrict__ matches, const uint64_t *__restrict__ seg_start,
                                                uint64_t n_reads, const int32_t *__restrict__ qlen, const int32_t *__restrict__ qlen2,
                                                mtb_tax_view tx, mtb_score_params sp, const uint64_t *__restrict__ tc_off,
@@ -571,7 +574,7 @@ __global__ __launch_bounds__(64, (CAP > MTB_SCORE_LDS ? 2 : MTB_SCORE_MINWAVES))
         unsigned long long kt0_ = __builtin_readcyclecounter();
 #endif
         const uint64_t r = list ? (uint64_t)list[it] : it;
-        if (!DYN && cursor && !list && it + gridDim.x < n_iter) {
+        if (SLOT && !DYN && !list && it + gridDim.x < n_iter) {
             /* slot mode: start pulling the NEXT read's slots towards L2 now (one dword per 128-byte line, delivered
              * straight into a dummy LDS area: no register, nothing waits for it) -- the slot loads are one dependent
              * HBM round trip per read with nothing to overlap otherwise */
@@ -584,7 +587,7 @@ __global__ __launch_bounds__(64, (CAP > MTB_SCORE_LDS ? 2 : MTB_SCORE_MINWAVES))
         }
         /* segment of read r: record slots filled by k_join<SEG> (slot mode), or seg_start indexed by the read or by the list slot */
         uint64_t s0 = 0; int32_t n = 0;
-        if (!cursor) {
+        if (!SLOT) {
             const uint64_t si = seg_by_list ? it : r;
             s0 = seg_start[si]; n = (int32_t)(seg_start[si + 1] - s0);
         }
@@ -595,7 +598,7 @@ __global__ __launch_bounds__(64, (CAP > MTB_SCORE_LDS ? 2 : MTB_SCORE_MINWAVES))
         R.is_classified = 0; R.reserved = 0; R.n_taxcnt = 0; R.taxcnt_off = 0;
         const int32_t nb = mtb_num_buckets(read_len, sp.dna_shift);
         const uint64_t off = tc_off[r], room = tc_off[r + 1] - off;
-        if (cursor) {
+        if (SLOT) {
             /* slot mode: live records of the read's slots -> LDS (compaction keeps slot order); reads that do not fit
              * (tail overflow, more live records than the staging, too many position buckets) go to big_list */
             const uint32_t cur = cursor[r], tail_cap = stride - direct;

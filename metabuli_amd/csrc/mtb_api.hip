@@ -466,16 +466,18 @@ static mtb_status dev_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, uint
         unsigned long long *d_work = nullptr;
         if (dynamic) { d_work = (unsigned long long *)(c->d_xscal + 4 + pass); HIPCHK(hipMemsetAsync(d_work, 0, 8, c->stream)); }
         KTimer kt(c, pass == 0 ? MTB_K_SCORE : MTB_K_SEGSORT);      /* the deferred reads' launch is booked with the large-segment path */
-#define MTB_LAUNCH_SCORE(SRT, K, CAPV, DYNV) hipLaunchKernelGGL((k_score<SRT, K, mtb_match, CAPV, DYNV>), dim3(grid), dim3(64), 0, c->stream, S->m, S->seg, n_reads, d_qlen, \
+#define MTB_LAUNCH_SCORE(SRT, K, CAPV, DYNV, SLOTV) hipLaunchKernelGGL((k_score<SRT, K, mtb_match, CAPV, DYNV, SLOTV>), dim3(grid), dim3(64), 0, c->stream, S->m, S->seg, n_reads, d_qlen, \
         d_qlen2, tax_view(ix), sp, (const uint64_t *)d_tcoff, d_res, d_tc_tax, d_tc_cnt, tc_cap, d_slabs, slab_bytes, slab_n, slab_nb, (mtb_match *)nullptr,  \
         tc_base, S->list, S->n_list, S->cursor, S->stride, S->seg_by_list, S->direct, S->epoch, S->big_list, S->n_big, S->cnt_out, d_work)
-        if (S->sort && S->cap > MTB_SCORE_LDS) { if (key64) MTB_LAUNCH_SCORE(true, true, 320, false); else MTB_LAUNCH_SCORE(true, false, 320, false); }
-        else if (dynamic) {
-            if (!S->sort) MTB_LAUNCH_SCORE(false, false, MTB_SCORE_LDS, true);
-            else if (key64) MTB_LAUNCH_SCORE(true, true, MTB_SCORE_LDS, true); else MTB_LAUNCH_SCORE(true, false, MTB_SCORE_LDS, true);
+        if (S->cursor) {              /* slot mode (always sorts in the kernel) */
+            if (S->cap > MTB_SCORE_LDS) { if (key64) MTB_LAUNCH_SCORE(true, true, 320, false, true); else MTB_LAUNCH_SCORE(true, false, 320, false, true); }
+            else { if (key64) MTB_LAUNCH_SCORE(true, true, MTB_SCORE_LDS, false, true); else MTB_LAUNCH_SCORE(true, false, MTB_SCORE_LDS, false, true); }
+        } else if (dynamic) {
+            if (!S->sort) MTB_LAUNCH_SCORE(false, false, MTB_SCORE_LDS, true, false);
+            else if (key64) MTB_LAUNCH_SCORE(true, true, MTB_SCORE_LDS, true, false); else MTB_LAUNCH_SCORE(true, false, MTB_SCORE_LDS, true, false);
         }
-        else if (S->sort) { if (key64) MTB_LAUNCH_SCORE(true, true, MTB_SCORE_LDS, false); else MTB_LAUNCH_SCORE(true, false, MTB_SCORE_LDS, false); }
-        else MTB_LAUNCH_SCORE(false, false, MTB_SCORE_LDS, false);
+        else if (S->sort) { if (key64) MTB_LAUNCH_SCORE(true, true, MTB_SCORE_LDS, false, false); else MTB_LAUNCH_SCORE(true, false, MTB_SCORE_LDS, false, false); }
+        else MTB_LAUNCH_SCORE(false, false, MTB_SCORE_LDS, false, false);
 #undef MTB_LAUNCH_SCORE
     }
     HIPCHK(hipGetLastError());
