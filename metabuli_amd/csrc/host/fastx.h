@@ -17,6 +17,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -35,6 +36,7 @@ struct FlatBatch {
     }
     void append(const FlatBatch &o) {
         const uint64_t b0 = bases.size(), n0 = names.size();
+        offs.reserve(offs.size() + o.offs.size()); name_offs.reserve(name_offs.size() + o.name_offs.size());
         bases.insert(bases.end(), o.bases.begin(), o.bases.end());
         names.insert(names.end(), o.names.begin(), o.names.end());
         for (size_t i = 1; i < o.offs.size(); i++) offs.push_back(b0 + o.offs[i]);
@@ -69,21 +71,25 @@ private:
     /* one parsed block waits in pending_ (FlatBatch pieces in order) until batches have consumed it */
     bool fill() {
         if (eof_ && carry_.empty()) return false;
-        std::vector<char> buf;
-        buf.reserve(carry_.size() + block_ + 1);
-        buf.insert(buf.end(), carry_.begin(), carry_.end());
+        /* one persistent block buffer (a fresh vector would be zero-filled on every resize: 64 MB of memset per block) */
+        std::vector<char> &buf = buf_;
+        const size_t keep = carry_.size();
+        if (buf.capacity() < keep + block_ + 1) buf.reserve(keep + block_ + 1);
+        buf.resize(keep);
+        if (keep) memcpy(buf.data(), carry_.data(), keep);
         carry_.clear();
         if (!eof_) {
             size_t old = buf.size();
-            buf.resize(old + block_);
+            if (raw_.size() < block_) raw_.reset(block_);
             size_t got = 0;
             while (got < block_) {                      /* gzread takes an unsigned length */
-                int r = gzread(gz_, buf.data() + old + got, (unsigned)std::min<size_t>(block_ - got, 1u << 30));
+                int r = gzread(gz_, raw_.data() + got, (unsigned)std::min<size_t>(block_ - got, 1u << 30));
                 if (r < 0) throw std::runtime_error("read error (corrupt gzip stream?)");
                 if (r == 0) { eof_ = true; break; }
                 got += (size_t)r;
             }
-            buf.resize(old + got);
+            buf.insert(buf.end(), raw_.data(), raw_.data() + got);
+            (void)old;
         }
         if (buf.empty()) return false;
         if (format_ == 0) {
@@ -97,7 +103,7 @@ private:
         if (!eof_) {
             end = last_record_start(buf, buf.size());
             if (end == 0) {                              /* one record larger than the block: grow and retry */
-                carry_.swap(buf); block_ *= 2; return fill();
+                carry_.assign(buf.begin(), buf.end()); block_ *= 2; return fill();
             }
             carry_.assign(buf.begin() + (long)end, buf.end());
         }
@@ -184,6 +190,9 @@ private:
     }
     void parse(const char *p, const char *e, FlatBatch &out) const {
         out.clear();
+        const size_t span = (size_t)(e - p);
+        out.bases.reserve(format_ == 'q' ? span / 2 + 64 : span); out.names.reserve(span / 16 + 64);
+        out.offs.reserve(span / 64 + 16); out.name_offs.reserve(span / 64 + 16);
         while (p < e) {
             while (p < e && (*p == '\n' || *p == '\r')) p++;
             if (p >= e) break;
@@ -216,7 +225,8 @@ private:
 
     gzFile gz_ = nullptr; int threads_; size_t block_;
     bool eof_ = false; char format_ = 0;
-    std::vector<char> carry_;
+    std::vector<char> carry_, buf_;
+    struct Raw { std::unique_ptr<char[]> p; size_t n = 0; size_t size() const { return n; } void reset(size_t m) { p.reset(new char[m]); n = m; } char *data() { return p.get(); } } raw_;
     std::vector<FlatBatch> pending_; size_t pending_pos_ = 0, pending_read_ = 0;
 };
 
