@@ -14,7 +14,7 @@
  *   flags: --seq-mode 1|2|3  --min-score F  --min-sp-score F  --min-cons-cnt N
  *          --min-cons-cnt-euk N  --tie-ratio F  --taxonomy-path DIR
  *          --syncmer 0|1  --smer-len N  --kmer-format 1|2  --accession-level 0|1|2
- *          --max-reads N (batch size)  --device N  --threads N (host parsing / formatting)
+ *          --max-reads N (batch size)  --device N  --threads N (host parsing / formatting)  --lineage 0|1
  */
 #include <cstdio>
 #include <cstring>
@@ -53,9 +53,34 @@ private:
     std::mutex m_; std::condition_variable cv_; std::vector<std::unique_ptr<T>> q_; size_t cap_;
 };
 
+/* TaxonomyWrapper::taxLineage2 (TaxonomyWrapper.cpp:431-454) with findShortRank2 (:423-429, table TaxonomyWrapper.h:9-26):
+ * "<short rank>_<name>" of the node and its ancestors below the root, root side first, ';' separated */
+const char *short_rank(const char *rank) {
+    static const std::map<std::string, const char *> M = {
+        {"subspecies", "ss"}, {"species", "s"}, {"subgenus", "sg"}, {"genus", "g"}, {"subfamily", "sf"}, {"family", "f"},
+        {"suborder", "so"}, {"order", "o"}, {"subclass", "sc"}, {"class", "c"}, {"subphylum", "sp"}, {"phylum", "p"},
+        {"subkingdom", "sk"}, {"kingdom", "k"}, {"superkingdom", "d"}, {"domain", "d"}, {"realm", "r"}};
+    auto it = M.find(rank);
+    return it == M.end() ? "-" : it->second;
+}
+void append_lineage(const mtb_index *ix, int32_t taxid, std::string &out) {
+    int32_t chain[128]; int n = 0;
+    int32_t node = taxid;
+    do {                                        /* the node itself, then its ancestors; the root ends the walk unlisted */
+        if (n < 128) chain[n++] = node;
+        int32_t p = mtb_tax_parent(ix, node);
+        if (p < 0) break;
+        node = p;
+    } while (mtb_tax_parent(ix, node) != node);
+    for (int i = n - 1; i >= 0; i--) {
+        out += short_rank(mtb_tax_rank(ix, chain[i])); out += '_'; out += mtb_tax_name(ix, chain[i]);
+        if (i > 0) out += ';';
+    }
+}
+
 /* Reporter::writeReadClassification (Reporter.cpp:35-80), one line per read, reads [lo, hi) of the job.  The score is
  * printed like an ostream prints a float (6 significant digits). */
-void format_reads(const Job &j, size_t lo, size_t hi, const mtb_index *ix, std::string &out) {
+void format_reads(const Job &j, size_t lo, size_t hi, const mtb_index *ix, bool lineage, std::string &out) {
     char num[64];
     out.clear();
     out.reserve((hi - lo) * 96);
@@ -67,12 +92,13 @@ void format_reads(const Job &j, size_t lo, size_t hi, const mtb_index *ix, std::
         out.append(num, (size_t)n);
         if (r.is_classified) {
             out += mtb_tax_rank(ix, r.classification); out += '\t';
+            if (lineage) { append_lineage(ix, r.classification, out); out += '\t'; }
             for (uint32_t k = 0; k < r.n_taxcnt; k++) {
                 n = snprintf(num, sizeof(num), "%d:%u ", j.tt[r.taxcnt_off + k], j.tc[r.taxcnt_off + k]);
                 out.append(num, (size_t)n);
             }
             out += '\n';
-        } else out += "-\t-\t\n";
+        } else out += lineage ? "-\t-\t-\t\n" : "-\t-\t\n";
     }
 }
 
@@ -117,6 +143,7 @@ int main(int argc, char **argv) {
     mtb_params par; mtb_default_params(&par);
     std::string taxdir; int device = 0; size_t max_reads = 2000000;
     int threads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    bool lineage = false;
     std::vector<std::string> pos;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -135,6 +162,7 @@ int main(int argc, char **argv) {
         else if (a == "--max-reads") max_reads = (size_t)atoll(val().c_str());
         else if (a == "--device") device = atoi(val().c_str());
         else if (a == "--threads") threads = std::max(1, atoi(val().c_str()));
+        else if (a == "--lineage") lineage = atoi(val().c_str()) != 0;
         else if (a.rfind("--", 0) == 0) { fprintf(stderr, "unsupported flag %s\n", a.c_str()); return 1; }
         else pos.push_back(a);
     }
@@ -153,7 +181,8 @@ int main(int argc, char **argv) {
         double t_parse = 0, t_gpu = 0, t_write = 0;           /* busy time of the three stages */
         FILE *out = fopen((outdir + "/" + job + "_classifications.tsv").c_str(), "w");
         if (!out) throw std::runtime_error("cannot write to " + outdir);
-        fputs("#is_classified\tname\ttaxID\tquery_length\tscore\trank\ttaxID:match_count\n", out);
+        fputs(lineage ? "#is_classified\tname\ttaxID\tquery_length\tscore\trank\tlineage\ttaxID:match_count\n"
+                      : "#is_classified\tname\ttaxID\tquery_length\tscore\trank\ttaxID:match_count\n", out);
         Channel<Job> parsed(2), scored(2);
         std::string reader_err, writer_err;
         /* stage 1: parse */
@@ -187,7 +216,7 @@ int main(int argc, char **argv) {
                 const size_t n = j->r1.size();
                 std::vector<std::thread> th;
                 for (int t = 0; t < threads; t++)
-                    th.emplace_back([&, t] { format_reads(*j, n * (size_t)t / (size_t)threads, n * (size_t)(t + 1) / (size_t)threads, eng.index, parts[(size_t)t]); });
+                    th.emplace_back([&, t] { format_reads(*j, n * (size_t)t / (size_t)threads, n * (size_t)(t + 1) / (size_t)threads, eng.index, lineage, parts[(size_t)t]); });
                 for (auto &x : th) x.join();
                 for (auto &p : parts) if (fwrite(p.data(), 1, p.size(), out) != p.size()) writer_err = "short write";
                 for (size_t i = 0; i < n; i++) { int32_t c = j->res[i].classification; if (c >= 0 && (size_t)c < tax_counts.size()) tax_counts[(size_t)c]++; }

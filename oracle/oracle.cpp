@@ -1061,11 +1061,37 @@ extern "C" size_t orc_score(const orc_db *db, const orc_taxonomy *tax, const orc
 extern "C" {
 // Reporter::writeReadClassification (Reporter.cpp:35-80), lineage off.
 // names: '\n'-separated read names.  Returns 0 on success.
-int orc_write_classifications(const char *path, const orc_taxonomy *tax, const char *names, size_t n_reads, const orc_result *res,
-                              const int32_t *tcTax, const uint32_t *tcCnt) {
+// TaxonomyWrapper::taxLineage2(node, infoAsName = true) (TaxonomyWrapper.cpp:431-454); short ranks of
+// ExtendedShortRanks (TaxonomyWrapper.h:9-26), "-" for every other rank (findShortRank2, :423-429)
+static std::string orc_lineage(const orc_taxonomy *tax, int taxid) {
+    static const std::map<std::string, std::string> shortRanks = {
+        {"subspecies", "ss"}, {"species", "s"}, {"subgenus", "sg"}, {"genus", "g"}, {"subfamily", "sf"}, {"family", "f"},
+        {"suborder", "so"}, {"order", "o"}, {"subclass", "sc"}, {"class", "c"}, {"subphylum", "sp"}, {"phylum", "p"},
+        {"subkingdom", "sk"}, {"kingdom", "k"}, {"superkingdom", "d"}, {"domain", "d"}, {"realm", "r"}};
+    std::vector<int> vec;
+    int node = tax->canon(taxid);
+    if (node < 0) return std::string();
+    do {
+        vec.push_back(node);
+        node = tax->parent[(size_t)node];
+    } while (tax->parent[(size_t)node] != node);
+    std::string out;
+    for (int i = (int)vec.size() - 1; i >= 0; --i) {
+        auto it = shortRanks.find(tax->rank[(size_t)vec[(size_t)i]]);
+        out += it == shortRanks.end() ? std::string("-") : it->second;
+        out += '_';
+        out += tax->name[(size_t)vec[(size_t)i]];
+        if (i > 0) out += ";";
+    }
+    return out;
+}
+int orc_write_classifications2(const char *path, const orc_taxonomy *tax, const char *names, size_t n_reads, const orc_result *res,
+                               const int32_t *tcTax, const uint32_t *tcCnt, int printLineage) {
     std::ofstream f(path);
     if (!f) return 1;
-    f << "#is_classified\tname\ttaxID\tquery_length\tscore\trank\ttaxID:match_count\n";
+    f << "#is_classified\tname\ttaxID\tquery_length\tscore\trank";
+    if (printLineage) f << "\tlineage";
+    f << "\ttaxID:match_count\n";
     std::istringstream nm(names);
     std::string name;
     for (size_t i = 0; i < n_reads; i++) {
@@ -1076,13 +1102,20 @@ int orc_write_classifications(const char *path, const orc_taxonomy *tax, const c
             int c = tax->canon(r.classification);
             f << cls << "\t" << name << "\t" << r.classification << "\t" << r.query_length + r.query_length2 << "\t" << r.score << "\t"
               << (c >= 0 ? tax->rank[(size_t)c] : std::string()) << "\t";
+            if (printLineage) f << orc_lineage(tax, r.classification) << "\t";
             for (uint32_t k = 0; k < r.n_taxcnt; k++) f << tcTax[r.taxcnt_off + k] << ":" << tcCnt[r.taxcnt_off + k] << " ";
             f << "\n";
         } else {
-            f << cls << "\t" << name << "\t" << r.classification << "\t" << r.query_length + r.query_length2 << "\t" << r.score << "\t-\t-\t\n";
+            f << cls << "\t" << name << "\t" << r.classification << "\t" << r.query_length + r.query_length2 << "\t" << r.score << "\t-\t";
+            if (printLineage) f << "-\t";
+            f << "-\t\n";
         }
     }
     return 0;
+}
+int orc_write_classifications(const char *path, const orc_taxonomy *tax, const char *names, size_t n_reads, const orc_result *res,
+                              const int32_t *tcTax, const uint32_t *tcCnt) {
+    return orc_write_classifications2(path, tax, names, n_reads, res, tcTax, tcCnt, 0);
 }
 // Reporter::writeReportFile / writeReport (Reporter.cpp:115-193) with clade counts as
 // NcbiTaxonomy::getCladeCounts; children ordered by (clade count desc, taxid asc).

@@ -129,6 +129,9 @@ size_t orc_score(const orc_db *, const orc_taxonomy *, const orc_params *p,
 /* ---- Reporter (Reporter.cpp:35-80, 115-193) ---------------------------- */
 int orc_write_classifications(const char *path, const orc_taxonomy *, const char *names_nl, size_t n_reads,
                               const orc_result *res, const int32_t *taxcnt_tax, const uint32_t *taxcnt_cnt);
+/* the same with the --lineage column (TaxonomyWrapper::taxLineage2, TaxonomyWrapper.cpp:431-454) when print_lineage != 0 */
+int orc_write_classifications2(const char *path, const orc_taxonomy *, const char *names_nl, size_t n_reads,
+                               const orc_result *res, const int32_t *taxcnt_tax, const uint32_t *taxcnt_cnt, int print_lineage);
 int orc_write_report(const char *path, const orc_taxonomy *, size_t n_reads, const orc_result *res);
 
 #ifdef __cplusplus

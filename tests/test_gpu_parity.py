@@ -194,6 +194,16 @@ def test_classify_driver_tsv_outputs(toy, orc, tmp_path):
     if not (ref["results"]["flag"] != 0).any():
         assert open(str(tmp_path / "job_classifications.tsv")).read() == open(cpath).read()
         assert sorted(open(str(tmp_path / "job_report.tsv")).read().split("\n")) == sorted(open(rpath).read().split("\n"))
+    # --lineage 1 adds the lineage column (Reporter.cpp:38-40, 57-59, 74-76)
+    args_l = args[:1] + ["--lineage", "1"] + args[1:-1] + ["jobl"]
+    subprocess.check_call(args_l, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    lpath = str(tmp_path / "oracle_classifications_lineage.tsv")
+    assert orc.lib.orc_write_classifications2(lpath.encode(), toy.tax, nm, C.c_size_t(toy.n_reads), ref["results"].ctypes.data_as(C.c_void_p),
+                                              ref["tc_tax"].ctypes.data_as(C.c_void_p), ref["tc_cnt"].ctypes.data_as(C.c_void_p), C.c_int(1)) == 0
+    if not (ref["results"]["flag"] != 0).any():
+        got = open(str(tmp_path / "jobl_classifications.tsv")).read()
+        assert got == open(lpath).read()
+        assert "\tlineage\t" in got.split("\n")[0] and ";s_" in got
 
 
 def test_duplicate_index_entries(ctx, orc, tmp_path):
