@@ -87,6 +87,7 @@ __global__ __launch_bounds__(64) void k_extract(ExtractArgs a, const mtb_tables 
     };
     __shared__ mtb_tables s_tab;
     __shared__ __attribute__((aligned(8))) uint8_t s_cod[80];
+    __shared__ __attribute__((aligned(8))) uint8_t s_cod3[MODE == 2 ? 3 : 1][MODE == 2 ? 120 : 8];      /* codon bytes of the three frames of a strand (reads <= 320 bases: <= 106 codons) */
     __shared__ uint8_t s_code[MTB_EXTRACT_STAGE];      /* a short read's bases as codes: one global load serves all six frames */
     const uint32_t lane = threadIdx.x;
     for (uint32_t i = lane; i < sizeof(mtb_tables) / 4; i += 64) ((uint32_t *)&s_tab)[i] = ((const uint32_t *)tabs)[i];
@@ -123,6 +124,51 @@ __global__ __launch_bounds__(64) void k_extract(ExtractArgs a, const mtb_tables 
                 for (int32_t i = (int32_t)lane; i < len; i += 64) s_code[i] = s_tab.base[(uint8_t)seq[i]];
                 __syncthreads();
             }
+            if (MODE == 2 && staged) {
+                /* single pass, staged read: the three frames of a strand share n_cod / n_win, so their windows are
+                 * laid end to end over the lanes (150 bp: 3 x 42 = 126 windows = 2 wave steps instead of 3).  Codon
+                 * bytes per frame in s_cod3[frame][codon]; combined window index c -> (frame, window); the windows of
+                 * a strand whose positions fall with the window index are walked backwards, so that ordinals rise
+                 * with the position inside every frame. */
+                for (int strand = 0; strand < 2; strand++) {
+                    const bool fwd = strand == 0;
+                    const bool back = !fwd;                              /* kmer_format 2 only (staged excludes the old format) */
+                    __syncthreads();
+                    for (int fi = 0; fi < 3; fi++) {
+                        const int32_t begin = mtb_frame_begin(len, strand * 3 + fi);
+                        for (int32_t j = (int32_t)lane; j < n_cod; j += 64)
+                            s_cod3[fi][j] = mtb_codon_byte_codes(&s_tab, s_code, mtb_codon_ci(begin, used, j, fwd), fwd);
+                    }
+                    __syncthreads();
+                    const int32_t n_all = 3 * n_win;
+                    for (int32_t c0 = 0; c0 < n_all; c0 += 64) {
+                        const int32_t cidx = c0 + (int32_t)lane;
+                        const int32_t fi = (cidx >= n_win) + (cidx >= 2 * n_win);
+                        const int32_t wi = cidx - fi * n_win;
+                        const int32_t w = back ? n_win - 1 - wi : wi;
+                        bool ok = false; uint64_t v = 0;
+                        if (cidx < n_all) {
+                            const uint32_t *c32 = (const uint32_t *)&s_cod3[fi][0];
+                            const uint32_t q = (uint32_t)w >> 2, sh = (uint32_t)w & 3u;
+                            const uint32_t x0 = c32[q], x1 = c32[q + 1], x2 = c32[q + 2];
+                            ok = mtb_window_metamer_words(__builtin_amdgcn_alignbyte(x1, x0, sh), __builtin_amdgcn_alignbyte(x2, x1, sh), a.syncmer, a.smer_len, &v);
+                        }
+                        const uint64_t mask = __ballot(ok);
+                        const uint32_t c = (uint32_t)__popcll(mask);
+                        if (n_buf + c > MTB_EXTRACT_BUF) flush();        /* wave-uniform */
+                        if (ok) {
+                            const int f = strand * 3 + fi;
+                            const int32_t begin = mtb_frame_begin(len, f);
+                            const uint32_t below = (uint32_t)__popcll(mask & lanemask_lt());
+                            uint32_t pf = mtb_window_pos(begin, used, w, fwd) + pos_off;
+                            if (a.tag_ord) { const uint32_t ord = total + below; pf |= (ord < 0xFFFFu ? ord : 0xFFFFu) << 16; }
+                            mtb_kmer k; k.value = v; k.qinfo = mtb_qinfo((uint32_t)(r + 1), pf, (uint32_t)f);
+                            s_out[n_buf + below] = k;
+                        }
+                        n_buf += c; total += c;
+                    }
+                }
+            } else
             for (int f = 0; f < 6; f++) {
                 const bool fwd = f < 3;
                 const int32_t begin = mtb_frame_begin(len, f);
