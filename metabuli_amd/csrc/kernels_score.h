@@ -556,11 +556,6 @@ __global__ __launch_bounds__(64, (CAP > MTB_SCORE_LDS ? 2 : MTB_SCORE_MINWAVES))
     /* bucket / taxCnt / chain arrays of the decide phase live in the path storage,
      * which is dead once the species scores exist (keeps LDS per wave small -> occupancy) */
     static_assert(CAP * sizeof(mtb_path) >= MTB_SCORE_BKT * 13 + (MTB_LR_MAXE + MTB_LR_MAXE * MTB_LR_K) * 4, "decide arrays must fit the path area");
-#ifdef MTB_EXP_HALF_OCCUPANCY
-    __shared__ uint32_t s_dummy[4096];
-    if (n_reads == 0xFFFFFFFFFFull) s_dummy[threadIdx.x] = 1;   /* keep the allocation alive */
-    if (n_reads == 0xFFFFFFFFFEull) results[0].classification = (int32_t)s_dummy[threadIdx.x ^ 1];
-#endif
     const uint32_t lane = threadIdx.x;
     MTB_PHASE_KERNEL_BEGIN();
     const uint64_t n_iter = list ? (uint64_t)*n_list : n_reads;      /* optional: only the listed reads */
