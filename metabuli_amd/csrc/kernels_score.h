@@ -315,6 +315,17 @@ __device__ __forceinline__ void score_read_par(const REC *src, int32_t n, mtb_sw
         }
         adjacent = __all(adjacent);
     }
+    /* the same for big segments (HBM slab): chunked prefix sum over the slots, P[] and the chain roots kept in the (dead)
+     * sid/rk/grp_start/blk_start block.  One pass over the segment instead of log2(longest chain) doubling rounds of
+     * three slab accesses each (long reads: chains of ~1400 links, 41 % of the scoring time). */
+    bool adjacent_big = simple && !small_n && sizeof(IDX) == 4;
+    if (adjacent_big) {
+        for (int32_t i = lane; i < n; i += 64) {
+            const uint32_t sh = w.shift[i], cm = w.cmask[i];
+            if (sh && cm) adjacent_big = adjacent_big && ((int32_t)w.bid[i] + __builtin_ctz(cm) == i - 1);
+        }
+        adjacent_big = __all(adjacent_big);
+    }
     if (adjacent) {
         float ps[MAXPER]; int32_t phd[MAXPER]; int32_t root[MAXPER];
         float carry_s = 0.0f; int32_t carry_hd = 0, last_root = 0;
@@ -358,6 +369,37 @@ __device__ __forceinline__ void score_read_par(const REC *src, int32_t n, mtb_sw
         score_sync<IDX>();
 #pragma unroll
         for (int k = 0; k < MAXPER; k++) { const int32_t i = lane + 64 * k; if (i < n) w.path[i] = mtb_ph_jump_final(w, i, fin[k]); }
+        score_sync<IDX>();
+    } else
+    if (adjacent_big) {
+        mtb_jump *pre = (mtb_jump *)w.sid;              /* 16 B x (cap + 1), as the ping-pong array of the doubling variant */
+        float carry_s = 0.0f; int32_t carry_hd = 0, last_root = 0;
+        for (int32_t c0 = 0; c0 < n; c0 += 64) {
+            const int32_t i = c0 + lane;
+            float is = 0.0f; int32_t ihd = 0; bool is_root = true;
+            if (i < n) {
+                const uint32_t sh = w.shift[i], cm = w.cmask[i];
+                if (sh && cm) {
+                    const int32_t shift = (int32_t)(sh & 0x7Fu);
+                    const uint32_t reh = w.m[i].right_end_hamming;
+                    is = mtb_part_score(reh, shift, false); ihd = (mtb_part_ham(reh, shift, false) << 16) | shift; is_root = false;
+                }
+            }
+            const float ps = wave_inclusive_scan_dpp(is) + carry_s; const int32_t phd = wave_inclusive_scan_dpp(ihd) + carry_hd;
+            carry_s = __shfl(ps, 63, 64); carry_hd = __shfl(phd, 63, 64);
+            const uint64_t mr = __ballot(is_root && i < n);
+            const uint64_t le = mr & (lt | (1ull << lane));
+            const int32_t root = le ? c0 + 63 - (int32_t)__builtin_clzll(le) : last_root;
+            if (mr) last_root = c0 + 63 - (int32_t)__builtin_clzll(mr);
+            if (i < n) { mtb_jump j; j.ptr = root; j.score = ps; j.ham = phd; j.depth = 0; pre[i] = j; }
+        }
+        score_sync<IDX>();
+        for (int32_t i = lane; i < n; i += 64) {
+            const mtb_jump me = pre[i], pr = pre[me.ptr];
+            const int32_t dhd = me.ham - pr.ham;
+            mtb_jump fin; fin.ptr = me.ptr == i ? -1 : me.ptr; fin.score = me.score - pr.score; fin.ham = dhd >> 16; fin.depth = dhd & 0xFFFF;
+            w.path[i] = mtb_ph_jump_final(w, i, fin);
+        }
         score_sync<IDX>();
     } else
     if (simple && !small_n) {

@@ -5,7 +5,8 @@ import numpy as np, torch
 import bench, metabuli_amd as M
 dev = torch.device('cuda', 0)
 ctx = M.Context(0)
-params = M.default_params(seq_mode=1, syncmer=1, smer_len=5)
+SEQ_MODE = int(os.environ.get('PROF_SEQ_MODE', '1')); RLEN = int(os.environ.get('PROF_READ_LEN', '150')); NREADS = int(os.environ.get('PROF_READS', '500000'))
+params = M.default_params(seq_mode=SEQ_MODE, syncmer=1, smer_len=5)
 import tempfile
 world = bench.build_world(1234, 8, 500000, 5000)
 taxdir = tempfile.mkdtemp(); world.tax.write(taxdir)
@@ -15,13 +16,13 @@ dv = torch.empty(Tc, dtype=torch.int64, device=dev); di = torch.empty(Tc, dtype=
 T = ctx.synth_index(1234, nf, world.filler_tax_lo, world.filler_tax_hi, rv, rt, dv.data_ptr(), di.data_ptr())
 tl = np.concatenate([np.unique(rt), np.arange(world.filler_tax_lo, world.filler_tax_hi + 1, dtype=np.int32)])
 ix = ctx.index_from_device(dv.data_ptr(), di.data_ptr(), T, taxdir, tl, params)
-N = 500000
-db, do = bench.gen_reads(torch, dev, world, N, 150, 0.10, 0.005, 99)
-dres = torch.empty(N * 24, dtype=torch.uint8, device=dev); cap = N * 20 + 1024
+N = NREADS
+db, do = bench.gen_reads(torch, dev, world, N, RLEN, 0.10, 0.005, 99)
+dres = torch.empty(N * 24, dtype=torch.uint8, device=dev); cap = N * (20 + RLEN // 9) + 1024
 dtt = torch.empty(cap, dtype=torch.int32, device=dev); dtc = torch.empty(cap, dtype=torch.int32, device=dev)
 out = (C.c_ulonglong * 24)()
 for it in range(2):
-    ctx.classify_batch_device(ix, params, db.data_ptr(), do.data_ptr(), 0, 0, N, N * 150, dres.data_ptr(), dtt.data_ptr(), dtc.data_ptr(), cap)
+    ctx.classify_batch_device(ix, params, db.data_ptr(), do.data_ptr(), 0, 0, N, N * RLEN, dres.data_ptr(), dtt.data_ptr(), dtc.data_ptr(), cap)
     M.lib().mtb_debug_phase_cycles(ctx.h, out)
 st = ctx.last_stats()
 tot = sum(out[:16])
