@@ -503,16 +503,79 @@ __device__ __forceinline__ void score_read_par(const REC *src, int32_t n, mtb_sw
     /* combine: stable order by parallel rank, certain drops in parallel, then one lane per species for the rest.
      * Dead arrays reused: bid -> sorted list, sid -> start of the entry's species range, shift -> pre-drop flag */
     IDX *sorted = w.bid, *elo = w.sid; uint8_t *predrop = w.shift;
+    uint64_t *ckeys = (uint64_t *)w.grp_start;        /* slab workspace only: grp_start + blk_start = 8 B per match, dead until sps[] is written */
+    if (sizeof(IDX) == 4) {
+        for (int32_t e = lane; e < ne; e += 64) ckeys[e] = mtb_path_key(w.path[elist[e]]);
+        score_sync<IDX>();
+    }
     for (int32_t e = lane; e < ne; e += 64) {
         const int32_t s = mtb_ph_comb_species(w, nsp, (int32_t)elist[e]);
         const int32_t lo = ec[w.sp_start[s]], hi = (s + 1 < nsp) ? (int32_t)ec[w.sp_start[s + 1]] : ne;
-        sorted[mtb_ph_comb_rank(w, elist, e, lo, hi)] = elist[e];
+        const int32_t pos = sizeof(IDX) == 4 ? mtb_ph_comb_rank_keys(w, elist, ckeys, e, lo, hi) : mtb_ph_comb_rank(w, elist, e, lo, hi);
+        sorted[pos] = elist[e];
         elo[e] = (IDX)lo;
     }
     score_sync<IDX>();
     for (int32_t k = lane; k < ne; k += 64) predrop[k] = mtb_ph_comb_predrop(w, sorted, k, (int32_t)elo[k]) ? 1 : 0;
     score_sync<IDX>();
     float *sps = (float *)w.grp_start;
+    if (sizeof(IDX) == 4) {
+        /* slab segments (long reads): a species can have hundreds of paths and accepted paths; one lane walking the
+         * accepted list per candidate was 30 % of the scoring time.  Here the species that emitted paths are taken one
+         * after another by the whole wave: the lanes test a candidate against 64 accepted paths at a time, and only the
+         * overlapping ones (accepted paths are disjoint, so a handful at most) are applied in acceptance order, as
+         * the serial loop does -- trimming can only shrink the candidate, so no other accepted path becomes relevant. */
+        for (int32_t q = lane; q < nsp; q += 64) sps[q] = -1.0f;
+        score_sync<IDX>();
+        for (int32_t lo = 0; lo < ne;) {
+            int32_t hi = lo + 1;                                     /* range of this species in the sorted emitted list */
+            while (hi < ne && (int32_t)elo[hi] == lo) hi++;
+            const int32_t s = mtb_ph_comb_species(w, nsp, (int32_t)sorted[lo]);
+            float score = 0.0f; int32_t na = 0;
+            for (int32_t k = lo; k < hi; k++) {
+                if (predrop[k]) continue;
+                const int32_t pi = sorted[k];
+                mtb_path p = w.path[pi];
+                const mtb_path p0 = p;
+                bool drop = false;
+                for (int32_t a0 = 0; a0 < na && !drop; a0 += 64) {
+                    const int32_t a = a0 + lane;
+                    bool ov = false;
+                    if (a < na) { const mtb_path c = w.path[w.acc[lo + a]]; ov = !((p0.end < c.start) || (c.end < p0.start)); }
+                    uint64_t mask = __ballot(ov);
+                    while (mask && !drop) {
+                        const int32_t b = a0 + (int32_t)__builtin_ctzll(mask); mask &= mask - 1;
+                        const mtb_path c = w.path[w.acc[lo + b]];
+                        if (!((p.end < c.start) || (c.end < p.start))) {
+                            const int32_t ov2 = (p.end < c.end ? p.end : c.end) - (p.start > c.start ? p.start : c.start) + 1;
+                            if (ov2 == p.end - p.start + 1) { drop = true; break; }
+                            if (ov2 < 24) {
+                                if (p.start < c.start) {
+                                    p.end = c.start - 1;
+                                    const int32_t h = p.ham - mtb_part_ham(w.m[pi].right_end_hamming, ov2 / 3, false);
+                                    p.ham = h > 0 ? h : 0;
+                                    p.score = p.score - mtb_part_score(w.m[pi].right_end_hamming, ov2 / 3, false) - (float)(ov2 % 3);
+                                } else {
+                                    p.start = c.end + 1;
+                                    const int32_t h = p.ham - mtb_part_ham(w.m[p.start_idx].right_end_hamming, ov2 / 3, true);
+                                    p.ham = h > 0 ? h : 0;
+                                    p.score = p.score - mtb_part_score(w.m[p.start_idx].right_end_hamming, ov2 / 3, true) - (float)(ov2 % 3);
+                                }
+                            } else drop = true;
+                        }
+                    }
+                }
+                if (!drop) {
+                    if (lane == 0) { w.path[pi] = p; w.acc[lo + na] = (IDX)pi; }
+                    na++; score += p.score;
+                    score_sync<IDX>();
+                }
+            }
+            float sc = score / (float)read_len;
+            if (lane == 0) sps[s] = sc < 1.0f ? sc : 1.0f;
+            lo = hi;
+        }
+    } else
     for (int32_t s0 = 0; s0 < nsp; s0 += 64) {
         int32_t s = s0 + lane;
         float sc = -1.0f;

@@ -207,6 +207,12 @@ size_t emu_score_par(const uint8_t *acc_leaf, const int32_t *canon, const int32_
                 int32_t s = mtb_ph_comb_species(w, nsp, (int32_t)elist[e]);
                 int32_t lo = ec[w.sp_start[s]], hi = (s + 1 < nsp) ? (int32_t)ec[w.sp_start[s + 1]] : ne;
                 pos[(size_t)e] = mtb_ph_comb_rank(w, elist, e, lo, hi);
+                {   // the packed-key variant used by the slab scorer must rank identically
+                    static thread_local std::vector<uint64_t> keys;
+                    keys.resize((size_t)ne);
+                    for (int32_t q = 0; q < ne; q++) keys[(size_t)q] = mtb_path_key(w.path[elist[q]]);
+                    if (mtb_ph_comb_rank_keys(w, elist, keys.data(), e, lo, hi) != pos[(size_t)e]) { fprintf(stderr, "emu: comb_rank_keys mismatch\n"); abort(); }
+                }
                 elo[e] = (IDX)lo;
             }
             for (int32_t e = 0; e < ne; e++) sorted[pos[(size_t)e]] = elist[e];
