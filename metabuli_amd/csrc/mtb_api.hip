@@ -233,7 +233,9 @@ static mtb_status dev_extract(mtb_ctx *c, const mtb_params *p, const char *d_bas
         /* six frames x L/3 windows bound the output by 2 metamers per base; syncmer selection keeps about half of them:
          * size the buffer from the previous batch's yield and fall back to the bound if that was too optimistic */
         const uint64_t bound = 2 * n_bases + (uint64_t)grid * MTB_EXTRACT_CHUNK;      /* + at most one partly used chunk per wave */
-        uint64_t cap = c->extract_yield > 0.0 ? std::min<uint64_t>(bound, (uint64_t)((double)n_bases * c->extract_yield * 1.15) + 4096) : bound;
+        /* first batch of a context: syncmer selection keeps < 1 metamer per base (0.86 measured with s = 5), dense mode 2 */
+        const double guess = c->extract_yield > 0.0 ? c->extract_yield : (p->syncmer ? 1.0 : 2.0);
+        uint64_t cap = std::min<uint64_t>(bound, (uint64_t)((double)n_bases * guess * 1.15) + 4096 + (uint64_t)grid * 64);
         cap = std::max<uint64_t>(cap, std::min<uint64_t>(bound, c->bufs["kmersA"].cap / sizeof(mtb_kmer)));
         for (int attempt = 0; attempt < 2; attempt++) {
             mtb_kmer *d_k; uint16_t *d_dig = nullptr;
