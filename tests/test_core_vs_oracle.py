@@ -135,12 +135,21 @@ def test_host_taxonomy_loader_equals_oracle(toy, orc, emu):
     assert (t2s == t2s_o).all()
 
 
-@pytest.mark.parametrize("name", ["toy_sync_se", "toy_dense_pe"])
+GOLDEN = ["toy_sync_se", "toy_dense_pe", "toy_oldfmt_pe", "toy_sync_long"]
+
+
+def golden_params(g):
+    seq_mode = int(g["seq_mode"]) if "seq_mode" in g.files else (2 if int(g["paired"]) else 1)
+    kf = int(g["kmer_format"]) if "kmer_format" in g.files else 2
+    return default_params(seq_mode=seq_mode, syncmer=int(g["syncmer"]), kmer_format=kf)
+
+
+@pytest.mark.parametrize("name", GOLDEN)
 def test_oracle_reproduces_golden_vectors(orc, tmp_path, name):
     """Regression pin of the oracle on committed vectors (tests/golden/make_golden.py)."""
     from metabuli_amd import synth
     g = np.load(os.path.join(HERE, "golden", name + ".npz"))
-    p = default_params(seq_mode=2 if int(g["paired"]) else 1, syncmer=int(g["syncmer"]))
+    p = golden_params(g)
     tax = synth.Taxonomy()
     for (t, par), r, nm in zip(g["tax_nodes"], g["tax_ranks"], g["tax_names"]):
         tax.add(int(t), int(par), str(r), str(nm))

@@ -364,3 +364,36 @@ def test_many_matches_per_query_take_the_large_segment_path(ctx, orc, tmp_path):
         assert (tt == ref["tc_tax"]).all() and (tc == ref["tc_cnt"]).all()
     assert (res["is_classified"] != 0).sum() > 60
     ix.close()
+
+
+@pytest.mark.parametrize("name", ["toy_sync_se", "toy_dense_pe", "toy_oldfmt_pe", "toy_sync_long"])
+def test_golden_vectors_through_the_c_abi(ctx, orc, tmp_path, name):
+    """the committed golden vectors (tests/golden/*.npz: inputs, database arrays and the oracle's outputs at the time
+    they were generated) reproduced by the HIP path: sorted query metamers, sorted matches, per-read results"""
+    import metabuli_amd as M
+    from metabuli_amd import synth
+    from test_core_vs_oracle import golden_params
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    op = golden_params(g)
+    tax = synth.Taxonomy()
+    for (t, par), r, nm in zip(g["tax_nodes"], g["tax_ranks"], g["tax_names"]):
+        tax.add(int(t), int(par), str(r), str(nm))
+    d = str(tmp_path)
+    tax.write(os.path.join(d, "taxonomy"))
+    orc.write_db(d, g["db_values"], g["db_taxids"], op)            # the database files in the reference's format
+    p = M.default_params(seq_mode=op.seq_mode, syncmer=op.syncmer, kmer_format=op.kmer_format)
+    ix = ctx.open_index(d, p)
+    paired = bool(int(g["paired"]))
+    b2, o2 = (g["bases2"], g["offs2"]) if paired else (None, None)
+    k, ql, ql2 = ctx.extract(p, g["bases"], g["offs"], b2, o2)
+    ks = ctx.sort_kmers(k)
+    assert (_sorted_by_value_then_all(ks) == _sorted_by_value_then_all(g["kmers"])).all()
+    m = ctx.sort_matches(ctx.match(ix, g["kmers"]), len(g["offs"]) - 1)
+    assert (m == g["matches"]).all()
+    res, tt, tc = ctx.classify_batch(ix, p, g["bases"], g["offs"], b2, o2)
+    amb = g["results"]["flag"] != 0
+    assert ((res["classification"] == g["results"]["classification"]) | amb).all()
+    assert ((res["score"].view(np.uint32) == g["results"]["score"].view(np.uint32)) | amb).all()
+    if not amb.any():
+        assert (tt == g["tc_tax"]).all() and (tc == g["tc_cnt"]).all()
+    ix.close()
