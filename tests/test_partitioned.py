@@ -186,3 +186,33 @@ def test_gpu_partitions_concatenate_to_the_index(orc, tmp_path):
     for q in parts:
         q.close()
     full.close(); ctx.close()
+
+
+def test_part_bounds_of_tiny_and_coarse_databases(orc, tmp_path):
+    """fewer usable split checkpoints than ranges: the surplus ranges are empty (their bound repeats the next one or is
+    the maximum), never overlapping"""
+    import metabuli_amd
+    from helpers import default_params
+    from metabuli_amd import synth
+    p = default_params(seq_mode=1, syncmer=1)
+    w = synth.make_world(seed=5, n_genera=1, species_per_genus=1, strains_per_species=1, genome_len=2000, with_euk=False)
+    g = w.genomes[0][1]
+    k, _, _ = orc.extract_batch(default_params(seq_mode=3, syncmer=1), g, np.array([0, len(g)], np.uint64))
+    vals = np.unique(k["value"]); tids = np.full(len(vals), w.genomes[0][0], np.int32)
+    # (a) default 4096 checkpoints on ~1.5 k metamers: no checkpoint is ever set
+    d = str(tmp_path / "tiny"); os.makedirs(d)
+    w.tax.write(os.path.join(d, "taxonomy")); orc.write_db(d, vals, tids, p)
+    b = metabuli_amd.part_bounds(d, 4)
+    assert b[0] == 0 and (np.diff(b.astype(np.float64)) >= 0).all()
+    sizes = np.diff(np.append(np.searchsorted(vals, b), len(vals)))
+    assert (sizes > 0).sum() == 1 and sizes.sum() == len(vals)          # one range holds everything, the others are empty
+    # (b) 6 checkpoints, 16 ranges
+    d2 = str(tmp_path / "coarse"); os.makedirs(d2)
+    w.tax.write(os.path.join(d2, "taxonomy")); orc.write_db(d2, vals, tids, p, split_num=6)
+    b = metabuli_amd.part_bounds(d2, 16)
+    assert b[0] == 0 and (np.diff(b.astype(np.float64)) >= 0).all() and ((b & ~AAMASK) == 0).all()
+    cuts = np.searchsorted(vals, b)
+    sizes = np.diff(np.append(cuts, len(vals)))
+    assert sizes.sum() == len(vals) and (sizes > 0).sum() <= 6
+    for c in cuts[(cuts > 0) & (cuts < len(vals))]:
+        assert (vals[c - 1] & AAMASK) != (vals[c] & AAMASK)
