@@ -216,3 +216,27 @@ def test_part_bounds_of_tiny_and_coarse_databases(orc, tmp_path):
     assert sizes.sum() == len(vals) and (sizes > 0).sum() <= 6
     for c in cuts[(cuts > 0) & (cuts < len(vals))]:
         assert (vals[c - 1] & AAMASK) != (vals[c] & AAMASK)
+
+
+@pytest.mark.gpu
+def test_gpu_partitions_with_empty_ranges(orc, tmp_path):
+    """more ranges than checkpoints: empty ranges open as empty indices, the others still concatenate to the database"""
+    import metabuli_amd as M
+    from helpers import default_params
+    from metabuli_amd import synth
+    p = default_params(seq_mode=1, syncmer=1)
+    w = synth.make_world(seed=6, n_genera=1, species_per_genus=2, strains_per_species=1, genome_len=3000, with_euk=False)
+    d = str(tmp_path / "db"); os.makedirs(d)
+    from helpers import build_toy_db
+    vals, tids = build_toy_db(orc, w, p, d)
+    orc.write_db(d, vals, tids, p, split_num=6)
+    ctx = M.Context(0)
+    for world in (4, 16):
+        vs, n_empty = [], 0
+        for r in range(world):
+            mp = M.default_params(seq_mode=1, syncmer=1)
+            ix = ctx.open_index_part(d, mp, r, world)
+            v, i = ix.download(); vs.append(v); n_empty += len(v) == 0; ix.close()
+        assert (np.concatenate(vs) == vals).all()
+        assert n_empty >= world - 6
+    ctx.close()
