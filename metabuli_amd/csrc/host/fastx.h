@@ -71,41 +71,38 @@ private:
     /* one parsed block waits in pending_ (FlatBatch pieces in order) until batches have consumed it */
     bool fill() {
         if (eof_ && carry_.empty()) return false;
-        /* one persistent block buffer (a fresh vector would be zero-filled on every resize: 64 MB of memset per block) */
-        std::vector<char> &buf = buf_;
+        /* one persistent, never zero-filled block buffer; the file is read straight behind the carried-over tail */
         const size_t keep = carry_.size();
-        if (buf.capacity() < keep + block_ + 1) buf.reserve(keep + block_ + 1);
-        buf.resize(keep);
-        if (keep) memcpy(buf.data(), carry_.data(), keep);
+        if (cap_ < keep + block_ + 1) { cap_ = keep + block_ + 1; raw_.reset(new char[cap_]); }
+        char *const buf = raw_.get();
+        if (keep) memcpy(buf, carry_.data(), keep);
         carry_.clear();
+        size_t len = keep;
         if (!eof_) {
-            size_t old = buf.size();
-            if (raw_.size() < block_) raw_.reset(block_);
             size_t got = 0;
             while (got < block_) {                      /* gzread takes an unsigned length */
-                int r = gzread(gz_, raw_.data() + got, (unsigned)std::min<size_t>(block_ - got, 1u << 30));
+                int r = gzread(gz_, buf + keep + got, (unsigned)std::min<size_t>(block_ - got, 1u << 30));
                 if (r < 0) throw std::runtime_error("read error (corrupt gzip stream?)");
                 if (r == 0) { eof_ = true; break; }
                 got += (size_t)r;
             }
-            buf.insert(buf.end(), raw_.data(), raw_.data() + got);
-            (void)old;
+            len += got;
         }
-        if (buf.empty()) return false;
+        if (len == 0) return false;
         if (format_ == 0) {
-            size_t p = 0; while (p < buf.size() && (buf[p] == '\n' || buf[p] == '\r')) p++;
-            if (p == buf.size()) return false;
+            size_t p = 0; while (p < len && (buf[p] == '\n' || buf[p] == '\r')) p++;
+            if (p == len) return false;
             format_ = buf[p] == '@' ? 'q' : (buf[p] == '>' ? 'a' : 0);
             if (!format_) throw std::runtime_error("input is neither FASTA nor FASTQ");
         }
         /* the block ends inside a record unless the file ended: keep the incomplete tail for the next block */
-        size_t end = buf.size();
+        size_t end = len;
         if (!eof_) {
-            end = last_record_start(buf, buf.size());
+            end = last_record_start(buf, len);
             if (end == 0) {                              /* one record larger than the block: grow and retry */
-                carry_.assign(buf.begin(), buf.end()); block_ *= 2; return fill();
+                carry_.assign(buf, buf + len); block_ *= 2; return fill();
             }
-            carry_.assign(buf.begin() + (long)end, buf.end());
+            carry_.assign(buf + end, buf + len);
         }
         /* cut [0, end) into pieces at record starts, parse in parallel */
         std::vector<size_t> cut{0};
@@ -119,7 +116,7 @@ private:
         pending_pos_ = 0; pending_read_ = 0;
         std::vector<std::thread> th;
         for (size_t k = 0; k + 1 < cut.size(); k++)
-            th.emplace_back([&, k]() { parse(buf.data() + cut[k], buf.data() + cut[k + 1], pending_[k]); });
+            th.emplace_back([&, k]() { parse(buf + cut[k], buf + cut[k + 1], pending_[k]); });
         for (auto &t : th) t.join();
         return true;
     }
@@ -140,23 +137,23 @@ private:
         if (pending_pos_ == pending_.size()) { pending_.clear(); pending_pos_ = 0; }
     }
     static const char *line_end(const char *p, const char *e) { const char *q = (const char *)memchr(p, '\n', (size_t)(e - p)); return q ? q : e; }
-    bool is_record_start(const std::vector<char> &b, size_t p, size_t end) const {
+    bool is_record_start(const char *b, size_t p, size_t end) const {
         if (p >= end) return false;
         if (p > 0 && b[p - 1] != '\n') return false;
         if (format_ == 'a') return b[p] == '>';
         if (b[p] != '@') return false;                  /* '@' may also open a quality line: check the '+' two lines below */
-        const char *e = b.data() + end;
-        const char *l1 = line_end(b.data() + p, e); if (l1 >= e) return false;
+        const char *e = b + end;
+        const char *l1 = line_end(b + p, e); if (l1 >= e) return false;
         const char *l2 = line_end(l1 + 1, e); if (l2 >= e) return false;
         return l2 + 1 < e && l2[1] == '+';
     }
-    size_t next_record_start(const std::vector<char> &b, size_t from, size_t end) const {
-        const char *e = b.data() + end;
-        const char *p = b.data() + from;
+    size_t next_record_start(const char *b, size_t from, size_t end) const {
+        const char *e = b + end;
+        const char *p = b + from;
         while (p < e) {
             const char *nl = (const char *)memchr(p, '\n', (size_t)(e - p));
             if (!nl) return end;
-            size_t s = (size_t)(nl + 1 - b.data());
+            size_t s = (size_t)(nl + 1 - b);
             if (is_record_start(b, s, end)) {
                 /* a quality line that starts with '@' and is followed by a header line + '+' cannot be told apart
                  * locally only if the header's sequence line starts with '+': not a base, so the test is safe */
@@ -169,17 +166,17 @@ private:
     /* where the carried-over tail begins: the end of the last record that is certainly complete.  Walk the line
      * starts backwards to the last VERIFIED record start q (FASTQ: '@' with '+' two lines below); if four full lines
      * follow q the record is complete and the tail starts behind it, otherwise at q. */
-    size_t last_record_start(const std::vector<char> &b, size_t end) const {
+    size_t last_record_start(const char *b, size_t end) const {
         size_t p = end;
         for (int lines = 0; lines < 64 && p > 0; lines++) {
             size_t q = p - 1;                            /* start of the line that ends at p (p is one past its '\n' or the buffer end) */
             while (q > 0 && b[q - 1] != '\n') q--;
             if (is_record_start(b, q, end)) {
                 if (format_ == 'a') return q;
-                const char *e = b.data() + end, *l = b.data() + q;
+                const char *e = b + end, *l = b + q;
                 int nl = 0;
                 while (nl < 4) { const char *x = (const char *)memchr(l, '\n', (size_t)(e - l)); if (!x) break; l = x + 1; nl++; }
-                return nl == 4 ? (size_t)(l - b.data()) : q;
+                return nl == 4 ? (size_t)(l - b) : q;
             }
             p = q;
         }
@@ -225,8 +222,8 @@ private:
 
     gzFile gz_ = nullptr; int threads_; size_t block_;
     bool eof_ = false; char format_ = 0;
-    std::vector<char> carry_, buf_;
-    struct Raw { std::unique_ptr<char[]> p; size_t n = 0; size_t size() const { return n; } void reset(size_t m) { p.reset(new char[m]); n = m; } char *data() { return p.get(); } } raw_;
+    std::vector<char> carry_;
+    std::unique_ptr<char[]> raw_; size_t cap_ = 0;
     std::vector<FlatBatch> pending_; size_t pending_pos_ = 0, pending_read_ = 0;
 };
 
