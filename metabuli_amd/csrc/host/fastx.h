@@ -75,13 +75,19 @@ public:
         while (out.size() - before < max_reads) {
             if (pending_.size() == pending_pos_) {
                 if (!fill()) break;
-                /* grow the batch once for the whole block instead of doubling (and copying) on the way */
-                size_t nb = 0, nn = 0, nr = 0;
-                for (const FlatBatch &q : pending_) { nb += q.bases.size(); nn += q.names.size(); nr += q.size(); }
-                const size_t left = max_reads - (out.size() - before);
-                if (nr > left && nr) { nb = nb / nr * left + 4096; nn = nn / nr * left + 4096; nr = left; }
-                out.bases.reserve(out.bases.size() + nb + (out.bases.size() ? nb : 0)); out.names.reserve(out.names.size() + nn + (out.names.size() ? nn : 0));
-                out.offs.reserve(out.offs.size() + 2 * nr); out.name_offs.reserve(out.name_offs.size() + 2 * nr);
+                /* size the batch ONCE from the first block's averages (growing block by block re-copies everything each time) */
+                if (out.size() == before) {
+                    size_t nb = 0, nn = 0, nr = 0;
+                    for (const FlatBatch &q : pending_) { nb += q.bases.size(); nn += q.names.size(); nr += q.size(); }
+                    if (nr) {
+                        const double f = 1.05 * (double)max_reads / (double)nr;
+                        const size_t cap_b = (size_t)((double)nb * f) + 4096, cap_n = (size_t)((double)nn * f) + 4096;
+                        if (cap_b < ((size_t)8 << 30)) {            /* absurd --max-reads: let the vectors grow instead */
+                            out.bases.reserve(out.bases.size() + cap_b); out.names.reserve(out.names.size() + cap_n);
+                            out.offs.reserve(out.offs.size() + max_reads + 1); out.name_offs.reserve(out.name_offs.size() + max_reads + 1);
+                        }
+                    }
+                }
             }
             size_t want = max_reads - (out.size() - before);
             drain(want, out);
