@@ -44,3 +44,12 @@ def test_no_gpu_means_a_loud_error_not_a_fallback():
         assert e.status == M.MTB_ERR_DEVICE
     else:
         raise AssertionError("Context creation must fail without a GPU")
+
+
+def test_headers_compile_as_c99_and_cxx17(tmp_path):
+    """include/mtb.h is a plain C header (the drop-in boundary), include/mtb.hpp a header-only C++17 shim over it"""
+    import subprocess
+    c = tmp_path / "t.c"; c.write_text('#include "mtb.h"\nint main(void) { mtb_params p; mtb_default_params(&p); return (int)sizeof(mtb_match) - 24; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(c)])
+    cc = tmp_path / "t.cpp"; cc.write_text('#include "mtb.hpp"\nint main() { return sizeof(mtb::Kmer) == 16 ? 0 : 1; }\n')
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(cc)])
