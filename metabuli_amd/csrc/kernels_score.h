@@ -291,6 +291,9 @@ __device__ __forceinline__ void score_read_par(const REC *src, int32_t n, mtb_sw
     score_sync<IDX>();
     MTB_PHASE_MARK(4);
     int32_t maxrank = 0;
+    if (ng == n) {      /* every position group is one match (the usual read): neighbours are the adjacent slots */
+        for (int32_t i = lane; i < n; i += 64) { mtb_ph_links_unit(w, i, &sp); int32_t rr = w.rk[i]; maxrank = rr > maxrank ? rr : maxrank; }
+    } else
     for (int32_t i = lane; i < n; i += 64) { mtb_ph_links(w, i, &tx, &sp, ng, nbk); int32_t rr = w.rk[i]; maxrank = rr > maxrank ? rr : maxrank; }
     for (int d = 32; d > 0; d >>= 1) { int32_t o = __shfl_xor(maxrank, d, 64); maxrank = o > maxrank ? o : maxrank; }
     score_sync<IDX>();

@@ -156,6 +156,40 @@ MTB_HD void mtb_ph_links(const mtb_sws<IDX> &w, int32_t i, const mtb_tax_view *t
     w.rk[i] = (IDX)rank;
     w.bid[i] = (IDX)pl;            /* own slot only: bid[i] is read by nobody else */
 }
+/* ---- links when every position group holds exactly one match (n_groups == n: the usual read) ----
+ * group g == match g: its block neighbours are the slots before and after it, so the group / block start tables
+ * are not consulted (about a third of the LDS reads of mtb_ph_links).  Writes exactly what mtb_ph_links writes. */
+template <typename IDX>
+MTB_HD void mtb_ph_links_unit(const mtb_sws<IDX> &w, int32_t i, const mtb_score_params *sp) {
+    const mtb_match *m = w.m;
+    const int32_t n = w.n;
+    const uint32_t fl = w.flag[i];
+    const bool has_prev = !(fl & MTB_F_BHEAD);                               /* same block as slot i-1 */
+    const bool has_next = i + 1 < n && !(w.flag[i + 1] & MTB_F_BHEAD);
+    const uint64_t qi = m[i].qinfo;
+    const bool fwd = mtb_q_frame(qi) < 3;
+    const uint32_t pos = mtb_q_pos(qi), dna = m[i].dna;
+    uint32_t f = fl & (MTB_F_GHEAD | MTB_F_BHEAD | MTB_F_SHEAD);
+    if (has_prev || has_next) f |= MTB_F_MULTI;
+    if (w.acc[w.sid[i]]) f |= MTB_F_EUK;
+    uint32_t sh = 0, cm = 0; int32_t pl = 0;
+    if (has_prev) {
+        pl = i - 1;
+        int32_t s = (int32_t)(pos - mtb_q_pos(m[pl].qinfo)) / 3;
+        if (s > 0 && s <= sp->max_codon_shift) { sh = (uint32_t)s; if (mtb_consecutive(m[pl].dna, dna, s, fwd, sp->kmer_format)) cm = 1u; }
+    }
+    if (has_next) {
+        int32_t s = (int32_t)(mtb_q_pos(m[i + 1].qinfo) - pos) / 3;
+        if (s > 0 && s <= sp->max_codon_shift && mtb_consecutive(dna, m[i + 1].dna, s, fwd, sp->kmer_format)) f |= MTB_F_CONN;
+    }
+    mtb_path p;
+    p.start = (int32_t)pos; p.end = (int32_t)pos + 23; p.score = mtb_part_score(m[i].right_end_hamming, 8, false);
+    p.ham = m[i].hamming; p.depth = 1; p.start_idx = i;
+    w.path[i] = p;
+    w.flag[i] = (uint8_t)f; w.shift[i] = (uint8_t)sh; w.cmask[i] = (uint8_t)cm;
+    w.rk[i] = (IDX)(i - (int32_t)w.blk_start[w.bid[i]]);                    /* rank of the group inside its block */
+    w.bid[i] = (IDX)pl;
+}
 /* ---- one DP round (Taxonomer.cpp:528-560) ---- */
 template <typename IDX>
 MTB_HD void mtb_ph_round(const mtb_sws<IDX> &w, int32_t i, int32_t r, const mtb_score_params *sp) {

@@ -172,6 +172,14 @@ size_t emu_score_par(const uint8_t *acc_leaf, const int32_t *canon, const int32_
         // links: every element reads shared arrays written by EARLIER phases only, except its own slots
         {
             // emulate "all lanes read, then write" per chunk is unnecessary: reads touch gid/grp_start/blk_start/acc/sid/m, writes touch path/flag/shift/cmask/rk/bid[own]
+            if (ng == n) {      // every position group is a single match: the kernel's shortcut must write the same workspace
+                std::vector<uint8_t> slab2(slab);
+                mtb_sws<IDX> w2; mtb_sws_carve<IDX>(&w2, slab2.data(), (uint64_t)n); w2.n = n;
+                for (int32_t i = 0; i < n; i++) mtb_ph_links_unit(w2, i, &sp);
+                for (int32_t i = 0; i < n; i++) { mtb_ph_links(w, i, &tx, &sp, ng, nbk); }
+                // padding bytes of mtb_path (none) / untouched fields are identical by construction
+                if (memcmp(slab.data(), slab2.data(), slab.size()) != 0) { fprintf(stderr, "emu: links_unit mismatch\n"); abort(); }
+            } else
             for (int32_t i = 0; i < n; i++) { mtb_ph_links(w, i, &tx, &sp, ng, nbk); }
             for (int32_t i = 0; i < n; i++) maxrank = std::max<int32_t>(maxrank, w.rk[i]);
         }
