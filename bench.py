@@ -108,10 +108,38 @@ def gen_reads(torch, dev, world, n_reads, read_len, frac_random, err, seed, pair
     return out, offs
 
 
-def cpu_baseline(ctx, M, torch, dev, world, real_v, real_t, params, taxdir, d_bases, read_len, n_sample, n_filler_small, seed):
-    """Oracle (CPU restatement of the reference algorithm, 1 thread) on a bounded
-    sample: the first n_sample reads of this rank against an index built by the
-    same generator with fewer filler metamers."""
+def compare_with_oracle(M, res, tt, tc, R):
+    """GPU per-read results (compacted taxcnt lists) against the oracle's answer R for the same reads: taxon, classified
+    flag, score on the fp32 bit pattern, query lengths, and the taxID:match_count lists.  Reads the oracle flags as
+    std::sort-ambiguous (SURVEY Appendix B.13) are excluded and counted.  Returns a dict for the JSON line."""
+    ro = R["results"]
+    amb = ro["flag"] != 0
+    bad = (res["classification"] != ro["classification"]) | (res["is_classified"] != ro["is_classified"]) | \
+          (res["score"].view(np.uint32) != ro["score"].view(np.uint32)) | (res["qlen"] != ro["qlen"]) | (res["qlen2"] != ro["qlen2"]) | \
+          (res["n_taxcnt"] != ro["n_taxcnt"])
+    bad &= ~amb
+    # taxID:match_count lists of the reads that agree so far (equal lengths there): gather both sides by their offsets
+    ok = np.flatnonzero(~amb & ~bad)
+    n = ro["n_taxcnt"][ok].astype(np.int64)
+    tot = int(n.sum())
+    first = np.zeros(len(ok) + 1, np.int64); np.cumsum(n, out=first[1:])
+    within = np.arange(tot, dtype=np.int64) - np.repeat(first[:-1], n)
+    ig = np.repeat(res["taxcnt_off"][ok].astype(np.int64), n) + within
+    io = np.repeat(ro["taxcnt_off"][ok].astype(np.int64), n) + within
+    diff = (tt[ig] != R["tc_tax"][io]) | (tc[ig] != R["tc_cnt"][io])
+    list_bad = int(len(np.unique(np.repeat(np.arange(len(ok)), n)[diff])))
+    return dict(reads=int(len(ro)), mismatches=int(bad.sum()) + list_bad, ambiguous_excluded=int(amb.sum()),
+                classified=int((ro["is_classified"] != 0).sum()),
+                checked="classification, is_classified, score (fp32 bits), query lengths, taxID:match_count lists")
+
+
+def cpu_baseline_and_parity(ctx, M, torch, dev, world, real_v, real_t, params, taxdir, d_bases, d_bases2, read_len, n_sample, n_filler_small, seed,
+                            run_cpu=True):
+    """(a) cpu_baseline: the oracle (CPU restatement of the reference algorithm) on a bounded sample -- the first
+    n_sample reads of this rank against an index built by the same generator with fewer filler metamers -- on all host
+    cores and on one.  (b) parity_sample: the SAME reads against the SAME small index through the benchmarked entry
+    points (mtb_synth_index -> mtb_index_from_device -> mtb_classify_batch_device, device-resident inputs), compared
+    with the oracle's answer read by read.  Outside the timed region."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import Oracle, default_params as odp
     orc = Oracle()
@@ -119,21 +147,65 @@ def cpu_baseline(ctx, M, torch, dev, world, real_v, real_t, params, taxdir, d_ba
     dv = torch.empty(T, dtype=torch.int64, device=dev); di = torch.empty(T, dtype=torch.int32, device=dev)
     n = ctx.synth_index(seed, n_filler_small, world.filler_tax_lo, world.filler_tax_hi, real_v, real_t, dv.data_ptr(), di.data_ptr())
     vals = dv[:n].cpu().numpy().view(np.uint64); tids = di[:n].cpu().numpy()
-    del dv, di
     d = tempfile.mkdtemp(prefix="mtb_cpu_")
     op = odp(seq_mode=params.seq_mode, syncmer=params.syncmer, smer_len=params.smer_len)
     orc.write_db(d, vals, tids, op)
     tax = orc.load_taxonomy(taxdir)
     db = orc.open_db(d, tax, op)
+    paired = params.seq_mode == 2
     bases = d_bases[: n_sample * read_len].cpu().numpy()
     offs = (np.arange(n_sample + 1, dtype=np.uint64) * np.uint64(read_len))
+    bases2 = d_bases2[: n_sample * read_len].cpu().numpy() if paired else None
+    offs2 = offs if paired else None
+    ncores = os.cpu_count() or 1
     t0 = time.perf_counter()
-    R = orc.classify(db, tax, op, bases, offs)
+    R = orc.classify_batch(db, tax, op, bases, offs, bases2, offs2, threads=ncores)
     dt = time.perf_counter() - t0
-    cls = int((R["results"]["is_classified"] != 0).sum())
-    return dict(value=n_sample / dt / 1e6, unit="Mreads/s", cores=1, kind="port",
-                sample=f"{n_sample} x {read_len} bp reads vs {n} target metamers ({len(real_v)} genome-derived + {n_filler_small} filler), "
-                       f"oracle/liboracle.so single thread, {dt:.1f} s, {cls} classified", seconds=dt), R
+    stage_s = dict(orc.last_stage_s); oracle_counts = dict(orc.last_counts)
+    cpu = None
+    if run_cpu:
+        # the single-thread figure on a quarter of the sample (same code, threads=1)
+        n1 = max(1, n_sample // 4)
+        t1 = time.perf_counter()
+        orc.classify_batch(db, tax, op, bases[: n1 * read_len], offs[: n1 + 1], bases2[: n1 * read_len] if paired else None, offs[: n1 + 1] if paired else None, threads=1)
+        dt1 = time.perf_counter() - t1
+        cls = int((R["results"]["is_classified"] != 0).sum())
+        cpu = dict(value=n_sample / dt / 1e6, unit="Mreads/s", cores=ncores, kind="port", cpu_model=cpu_model(),
+                   single_thread_value=n1 / dt1 / 1e6, stage_seconds={k: round(v, 3) for k, v in stage_s.items()},
+                   sample=f"{n_sample} x {'2 x ' if paired else ''}{read_len} bp reads vs {n} target metamers ({len(real_v)} genome-derived + {n_filler_small} filler; "
+                          f"{n * 12 / 2**20:.0f} MiB flat), oracle/liboracle.so with OpenMP on {ncores} threads, {dt:.1f} s "
+                          f"(1 thread on {n1} reads: {dt1:.1f} s), {cls} classified")
+    # ---- the same sample through the benchmarked GPU path ----
+    taxid_list = np.concatenate([np.unique(real_t), np.arange(world.filler_tax_lo, world.filler_tax_hi + 1, dtype=np.int32)])
+    small = ctx.index_from_device(dv.data_ptr(), di.data_ptr(), n, taxdir, taxid_list, params)
+    s_res = torch.empty(n_sample * 24, dtype=torch.uint8, device=dev)
+    s_cap = n_sample * (20 + read_len // 9) * (2 if paired else 1) + 1024
+    s_tt = torch.empty(s_cap, dtype=torch.int32, device=dev); s_tc = torch.empty(s_cap, dtype=torch.int32, device=dev)
+    s_offs = torch.arange(n_sample + 1, device=dev, dtype=torch.int64) * read_len
+    ntc = ctx.classify_batch_device(small, params, d_bases.data_ptr(), s_offs.data_ptr(), d_bases2.data_ptr() if paired else 0,
+                                    s_offs.data_ptr() if paired else 0, n_sample, n_sample * read_len * (2 if paired else 1),
+                                    s_res.data_ptr(), s_tt.data_ptr(), s_tc.data_ptr(), s_cap)
+    torch.cuda.synchronize()
+    res = np.frombuffer(s_res.cpu().numpy().tobytes(), dtype=M.result_dt)
+    g_res, g_tt, g_tc = M.compact_taxcnt(res, s_tt[:ntc].cpu().numpy(), s_tc[:ntc].cpu().numpy().view(np.uint32))
+    par = compare_with_oracle(M, g_res, g_tt, g_tc, R)
+    par["index"] = f"{n} target metamers via mtb_synth_index -> mtb_index_from_device; reads via mtb_classify_batch_device (device-resident)"
+    par["matches"] = int(ctx.last_stats().n_matches); par["oracle_matches"] = int(oracle_counts["matches"])
+    if par["matches"] != par["oracle_matches"]:
+        par["mismatches"] += 1
+    small.close()
+    del dv, di
+    return cpu, par
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def main():
@@ -149,7 +221,8 @@ def main():
     ap.add_argument("--filler-species", type=int, default=130_000)
     ap.add_argument("--cpu-reads", type=int, default=400_000)
     ap.add_argument("--cpu-targets", type=float, default=16e6)
-    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the timed CPU baseline (the parity sample still runs the oracle)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle comparison of the benchmarked path (and the CPU baseline)")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams a batch is pipelined over inside the library")
     ap.add_argument("--seq-mode", type=int, default=1, choices=[1, 2, 3],
                     help="1 = short single-end (configs[1]); 2 = paired-end, --reads pairs of 2 x --read-len (configs[3] shape); 3 = long reads (configs[2])")
@@ -313,11 +386,13 @@ def main():
     if frac_cls < 0.5:   # 90 % of the reads come from genomes that are in the index
         raise SystemExit(f"sanity check failed: only {frac_cls:.4f} of the reads were classified")
 
-    cpu = None
-    if rank == 0 and not args.no_cpu and world_size == 1 and args.seq_mode != 2:
-        cpu, R = cpu_baseline(ctx, M, torch, dev, world, real_v, real_t, params, taxdir, d_bases, args.read_len,
-                              min(args.cpu_reads, args.reads), int(args.cpu_targets), args.seed)
-        cpu.pop("seconds", None)
+    cpu, parity = None, None
+    if rank == 0 and world_size == 1 and not args.no_parity:
+        cpu, parity = cpu_baseline_and_parity(ctx, M, torch, dev, world, real_v, real_t, params, taxdir, d_bases, d_bases2, args.read_len,
+                                              min(args.cpu_reads, args.reads), int(args.cpu_targets), args.seed, run_cpu=not args.no_cpu)
+        log(f"[rank 0] parity sample: {parity}")
+        if parity["mismatches"]:
+            raise SystemExit(f"parity check failed: {parity}")
 
     if rank == 0:
         total_reads = args.reads * world_size * args.steps
@@ -326,15 +401,16 @@ def main():
                    value=value, unit="Mreads/s", n_gpus=world_size, steps=args.steps, warmup=args.warmup,
                    ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None,
                    dtype="u64", data="synthetic",
-                   config=dict(workload=f"{args.reads/1e6:g}M x {'2 x ' if args.seq_mode == 2 else ''}{args.read_len} bp synthetic {'paired-end' if args.seq_mode == 2 else 'single-end'} reads per GPU vs synthetic "
+                   config=dict(workload=f"{args.reads/1e6:g}M x {'2 x ' if args.seq_mode == 2 else ''}{args.read_len} bp synthetic "
+                                        f"{ {1: 'single-end', 2: 'paired-end', 3: 'long'}[args.seq_mode] } reads per GPU vs synthetic "
                                         f"GTDB-scale index of {T/1e9:.2f} G metamers ({T*12/2**30:.0f} GiB flat, replicated per GPU), "
-                                        f"syncmer s=5, kmer_format 2 (BASELINE.json configs[1])",
+                                        f"syncmer s=5, kmer_format 2 ({ {1: 'BASELINE.json configs[1]', 2: 'BASELINE.json configs[3] shape: paired-end, index replicated, reads sharded', 3: 'BASELINE.json configs[2] shape: long reads'}[args.seq_mode] })",
                                reads_per_gpu=args.reads, read_len=args.read_len, targets=int(T), seq_mode=args.seq_mode,
                                gbp_per_s=value * args.read_len * (2 if args.seq_mode == 2 else 1) / 1e3, query_metamers=int(st.n_kmers), matches=int(st.n_matches),
                                classified_fraction=frac_cls, parallelism=f"reads sharded x{world_size}, index replicated", streams_per_gpu=args.streams),
                    stage_ms=dict(extract=st.ms_extract, sort=st.ms_sort, join=st.ms_join, regroup=st.ms_regroup,
                                  segsort=st.ms_segsort, score=st.ms_score, total=st.ms_total),
-                   kernel_ms=kern, roofline=roofline, cpu_baseline=cpu)
+                   kernel_ms=kern, roofline=roofline, cpu_baseline=cpu, parity_sample=parity)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -58,7 +58,7 @@ typedef struct {
     int32_t seq_mode;          /* 1 single-end, 2 paired-end, 3 long read     */
     int32_t syncmer;           /* 0/1                                         */
     int32_t smer_len;          /* 5                                           */
-    int32_t kmer_format;       /* 2 (only format implemented)                 */
+    int32_t kmer_format;       /* 1 (legacy, the CLI default) or 2 (db.parameters) */
     int32_t min_cons_cnt;      /* 4                                           */
     int32_t min_cons_cnt_euk;  /* 9                                           */
     float   min_score;         /* 0                                           */

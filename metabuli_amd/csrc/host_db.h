@@ -23,7 +23,7 @@ namespace mtbhost {
 inline bool file_exists(const std::string &p) { FILE *f = fopen(p.c_str(), "rb"); if (!f) return false; fclose(f); return true; }
 
 /* loadDbParameters (common.cpp:88-133): the DB overrides the flags */
-inline bool load_db_parameters(const std::string &dbdir, mtb_params *p) {
+inline bool load_db_parameters(const std::string &dbdir, mtb_params *p, int *reduced_aa = nullptr) {
     std::ifstream in(dbdir + "/db.parameters");
     if (!in) return false;
     std::string line;
@@ -39,6 +39,7 @@ inline bool load_db_parameters(const std::string &dbdir, mtb_params *p) {
         else if (k == "Syncmer") { if (v == "1" && p->syncmer == 0) p->syncmer = 1; }
         else if (k == "S-mer_len") p->smer_len = atoi(v.c_str());
         else if (k == "Kmer_format") p->kmer_format = atoi(v.c_str());
+        else if (k == "Reduced_alphabet") { if (reduced_aa) *reduced_aa = atoi(v.c_str()); }
     }
     return true;
 }

@@ -125,8 +125,8 @@ extern "C" {
 const char *mtb_version(void) { return "metabuli_amd 0.1 (gfx950)"; }
 const char *mtb_last_error(void) { return g_err.c_str(); }
 
-void mtb_default_params(mtb_params *p) {   /* classify.cpp:10-37 */
-    p->seq_mode = 2; p->syncmer = 0; p->smer_len = 5; p->kmer_format = 2; p->min_cons_cnt = 4; p->min_cons_cnt_euk = 9;
+void mtb_default_params(mtb_params *p) {   /* setClassifyDefaults, classify.cpp:10-37: kmerFormat 1 unless db.parameters says otherwise */
+    p->seq_mode = 2; p->syncmer = 0; p->smer_len = 5; p->kmer_format = 1; p->min_cons_cnt = 4; p->min_cons_cnt_euk = 9;
     p->min_score = 0.0f; p->min_sp_score = 0.0f; p->tie_ratio = 0.95f; p->accession_level = 0; p->skip_redundancy = 0;
 }
 
@@ -437,9 +437,11 @@ static mtb_status dev_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, uint
     STCHK(d2h(c, &tot, d_tcoff + n_reads, 8));
     *n_tc = tot;
     if (tot > tc_cap) return fail(MTB_ERR_CAPACITY, "taxcnt buffers too small");
+    if (tc_base + tot >= (1ull << 32)) return fail(MTB_ERR_ARG, "more than 2^32-1 taxcnt slots in one batch (mtb_result.taxcnt_off is 32 bits); split the batch");
     /* single-word sort key when taxids < 2^22 and positions < 2^11 (hamming of a match is <= 7) */
     const bool key64 = ix->tax.max_id < (1 << 22) && max_len + 3 < (1u << 11);
     const uint32_t max_nb = (uint32_t)mtb_num_buckets((int32_t)max_len, sp.dna_shift);
+    if (max_nb > 65535u) return fail(MTB_ERR_ARG, "read too long for mtb_result.n_taxcnt (16 bits): more than 65535 position buckets");
     ScoreSrc second_src;
     for (int pass = 0; pass < 2; pass++) {
         const ScoreSrc *S = &first;
@@ -579,7 +581,9 @@ static mtb_status open_impl(mtb_ctx *c, const char *dbdir, const char *taxonomy_
     if (n_parts == 0 || part >= n_parts) return fail(MTB_ERR_ARG, "partition index out of range");
     HIPCHK(hipSetDevice(c->device));
     std::string d(dbdir);
-    mtbhost::load_db_parameters(d, params);
+    int reduced_aa = 0;
+    mtbhost::load_db_parameters(d, params, &reduced_aa);
+    if (reduced_aa) return fail(MTB_ERR_UNSUPPORTED, "database was built with the reduced amino-acid alphabet (Reduced_alphabet 1 in db.parameters); not implemented");
     if (params->kmer_format != 1 && params->kmer_format != 2) return fail(MTB_ERR_UNSUPPORTED, "database uses a k-mer format other than 1 or 2");
     std::string taxdir = taxonomy_dir && *taxonomy_dir ? std::string(taxonomy_dir) : d + "/taxonomy";
     if (!mtbhost::file_exists(taxdir + "/nodes.dmp")) {

@@ -8,6 +8,8 @@
 #include "oracle.h"
 
 #include <algorithm>
+#include <parallel/algorithm>      /* __gnu_parallel::sort = the reference's SORT_PARALLEL (FastSort.h of MMseqs2) under OpenMP */
+#include <omp.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -17,6 +19,13 @@
 #include <string>
 #include <unordered_map>
 #include <vector>
+
+/* Host threads of the OpenMP layer (the reference parallelises the same four places with `#pragma omp`:
+ * KmerExtractor.cpp:83-160 per read chunk, SORT_PARALLEL, KmerMatcher.cpp:206-470 per query split,
+ * Classifier.cpp:187-203 per read block).  1 = the plain serial restatement. */
+static int g_orc_threads = 1;
+extern "C" void orc_set_threads(int n) { g_orc_threads = n < 1 ? 1 : n; omp_set_num_threads(g_orc_threads); }
+extern "C" int orc_get_threads(void) { return g_orc_threads; }
 
 namespace {
 
@@ -409,13 +418,12 @@ size_t orc_extract_read(const char *seq, int len, const orc_params *p, uint32_t 
     return fill_query_kmers(seq, len, *p, seq_id, offset, out, cap);
 }
 
-// loadChunkOfReads + processSequence (KmerExtractor.cpp:292-340, 429-481)
-size_t orc_extract_batch(const char *bases, const uint64_t *offs, const char *bases2,
-                         const uint64_t *offs2, size_t n_reads, const orc_params *p,
-                         orc_kmer *out, size_t cap, int32_t *qlen, int32_t *qlen2) {
+// loadChunkOfReads + processSequence (KmerExtractor.cpp:292-340, 429-481) for reads [lo, hi)
+static size_t extract_range(const char *bases, const uint64_t *offs, const char *bases2, const uint64_t *offs2, size_t lo, size_t hi,
+                            const orc_params *p, orc_kmer *out, size_t cap, int32_t *qlen, int32_t *qlen2) {
     size_t n = 0;
     std::string buf;
-    for (size_t i = 0; i < n_reads; i++) {
+    for (size_t i = lo; i < hi; i++) {
         int len1 = (int)(offs[i + 1] - offs[i]);
         qlen[i] = max_covered_length(len1);
         qlen2[i] = 0;
@@ -437,12 +445,36 @@ size_t orc_extract_batch(const char *bases, const uint64_t *offs, const char *ba
     }
     return n;
 }
+size_t orc_extract_batch(const char *bases, const uint64_t *offs, const char *bases2,
+                         const uint64_t *offs2, size_t n_reads, const orc_params *p,
+                         orc_kmer *out, size_t cap, int32_t *qlen, int32_t *qlen2) {
+    const int T = g_orc_threads;
+    if (T <= 1 || n_reads < (size_t)T * 64) return extract_range(bases, offs, bases2, offs2, 0, n_reads, p, out, cap, qlen, qlen2);
+    /* read chunks in parallel into private buffers (2 metamers per base bound), concatenated in read order */
+    std::vector<std::vector<orc_kmer>> part((size_t)T);
+    std::vector<size_t> cnt((size_t)T, 0);
+#pragma omp parallel for schedule(static, 1) num_threads(T)
+    for (int t = 0; t < T; t++) {
+        size_t lo = n_reads * (size_t)t / (size_t)T, hi = n_reads * (size_t)(t + 1) / (size_t)T;
+        size_t nb = (size_t)(offs[hi] - offs[lo]) + (offs2 ? (size_t)(offs2[hi] - offs2[lo]) : 0);
+        part[(size_t)t].resize(2 * nb + 64);
+        cnt[(size_t)t] = extract_range(bases, offs, bases2, offs2, lo, hi, p, part[(size_t)t].data(), part[(size_t)t].size(), qlen, qlen2);
+    }
+    size_t n = 0;
+    for (int t = 0; t < T; t++) {
+        size_t c = cnt[(size_t)t];
+        if (n < cap) memcpy(out + n, part[(size_t)t].data(), std::min(c, cap - n) * sizeof(orc_kmer));
+        n += c;
+    }
+    return n;
+}
 
 void orc_sort_kmers(orc_kmer *k, size_t n) {
-    std::sort(k, k + n, [](const orc_kmer &a, const orc_kmer &b) {
+    auto cmp = [](const orc_kmer &a, const orc_kmer &b) {
         if (a.value != b.value) return a.value < b.value;
         return qi_seq(a.qinfo) < qi_seq(b.qinfo);
-    });
+    };
+    if (g_orc_threads > 1) __gnu_parallel::sort(k, k + n, cmp); else std::sort(k, k + n, cmp);
 }
 
 // IndexCreator::getDiffIdx (IndexCreator.cpp:874-892)
@@ -659,21 +691,19 @@ orc_db *orc_db_open(const char *dir, const orc_taxonomy *tax, const orc_params *
 void orc_db_close(orc_db *db) { delete db; }
 size_t orc_db_num_kmers(const orc_db *db) { return db->info.size(); }
 
-// KmerMatcher::matchKmers with threads = 1 (KmerMatcher.cpp:123-481)
-size_t orc_match_kmers(orc_db *db, const orc_kmer *q, size_t queryKmerNum, orc_match *out, size_t cap) {
+} // extern "C"
+
+// The per-thread body of KmerMatcher::matchKmers (KmerMatcher.cpp:206-470) for the query split [startIdx, endIdx]:
+// the thread finds its start checkpoint in `split` and streams diffIdx/info from there.
+static size_t match_split(orc_db *db, const orc_kmer *q, size_t startIdx, size_t endIdx, orc_match *out, size_t cap) {
     const uint64_t AAMASK = ~0xFFFFFFull;
     const size_t numOfDiffIdx = db->diff.size();
-    size_t blank = 0;
-    for (size_t i = 0; i < queryKmerNum; i++) { if (qi_seq(q[i].qinfo) == 0) blank++; else break; }
-    queryKmerNum -= blank;
-    if (queryKmerNum == 0) return 0;
     // usable splits (:157-164)
     std::vector<orc_db::Split> sp = db->splits;
     size_t use = sp.size();
     for (size_t i = 1; i < sp.size(); i++) {
         if (sp[i].ad == 0 || sp[i].ad == UINT64_MAX) { sp[i] = {UINT64_MAX, UINT64_MAX, UINT64_MAX}; use--; }
     }
-    size_t startIdx = blank, endIdx = blank + queryKmerNum - 1;
     orc_db::Split start = sp[0];
     {
         uint64_t queryAA = q[startIdx].value & AAMASK;
@@ -743,16 +773,59 @@ size_t orc_match_kmers(orc_db *db, const orc_kmer *q, size_t queryKmerNum, orc_m
     return m;
 }
 
+extern "C" {
+
+// KmerMatcher::matchKmers (KmerMatcher.cpp:123-481).  One thread: the whole list is one split.  T threads: the sorted
+// list is cut into T query splits at amino-acid-part changes (:157-193 cut at the `split` checkpoints' amino-acid
+// parts; any amino-acid boundary gives the same matches since a query's candidates depend on its own amino-acid run
+// only), each thread fills a private buffer, the buffers are concatenated (the reference's threads reserve slices of
+// one shared buffer; match order is unspecified either way).
+size_t orc_match_kmers(orc_db *db, const orc_kmer *q, size_t queryKmerNum, orc_match *out, size_t cap) {
+    const uint64_t AAMASK = ~0xFFFFFFull;
+    size_t blank = 0;
+    for (size_t i = 0; i < queryKmerNum; i++) { if (qi_seq(q[i].qinfo) == 0) blank++; else break; }
+    queryKmerNum -= blank;
+    if (queryKmerNum == 0) return 0;
+    const int T = g_orc_threads;
+    if (T <= 1 || queryKmerNum < (size_t)T * 1024) return match_split(db, q, blank, blank + queryKmerNum - 1, out, cap);
+    std::vector<size_t> cut;
+    cut.push_back(blank);
+    for (int t = 1; t < T; t++) {
+        size_t c = blank + queryKmerNum * (size_t)t / (size_t)T;
+        while (c < blank + queryKmerNum && (q[c].value & AAMASK) == (q[c - 1].value & AAMASK)) c++;
+        if (c > cut.back() && c < blank + queryKmerNum) cut.push_back(c);
+    }
+    cut.push_back(blank + queryKmerNum);
+    const int S = (int)cut.size() - 1;
+    std::vector<std::vector<orc_match>> part((size_t)S);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(T)
+    for (int t = 0; t < S; t++) {
+        std::vector<orc_match> &v = part[(size_t)t];
+        v.resize((cut[(size_t)t + 1] - cut[(size_t)t]) * 2 + 1024);
+        size_t m = match_split(db, q, cut[(size_t)t], cut[(size_t)t + 1] - 1, v.data(), v.size());
+        if (m > v.size()) { v.resize(m); m = match_split(db, q, cut[(size_t)t], cut[(size_t)t + 1] - 1, v.data(), v.size()); }
+        v.resize(m);
+    }
+    size_t n = 0;
+    for (int t = 0; t < S; t++) {
+        size_t c = part[(size_t)t].size();
+        if (n < cap) memcpy(out + n, part[(size_t)t].data(), std::min(c, cap - n) * sizeof(orc_match));
+        n += c;
+    }
+    return n;
+}
+
 // KmerMatcher::compareMatches / sortMatches (KmerMatcher.cpp:1071-1078, 1149-1166)
 void orc_sort_matches(orc_match *m, size_t n) {
-    std::sort(m, m + n, [](const orc_match &a, const orc_match &b) {
+    auto cmp = [](const orc_match &a, const orc_match &b) {
         if (qi_seq(a.qinfo) != qi_seq(b.qinfo)) return qi_seq(a.qinfo) < qi_seq(b.qinfo);
         if (a.species_id != b.species_id) return a.species_id < b.species_id;
         if (qi_frame(a.qinfo) != qi_frame(b.qinfo)) return qi_frame(a.qinfo) < qi_frame(b.qinfo);
         if (qi_pos(a.qinfo) != qi_pos(b.qinfo)) return qi_pos(a.qinfo) < qi_pos(b.qinfo);
         if (a.hamming != b.hamming) return a.hamming < b.hamming;
         return a.dna < b.dna;
-    });
+    };
+    if (g_orc_threads > 1) __gnu_parallel::sort(m, m + n, cmp); else std::sort(m, m + n, cmp);
 }
 
 } // extern "C"
@@ -1035,20 +1108,66 @@ extern "C" size_t orc_score(const orc_db *db, const orc_taxonomy *tax, const orc
         res[i].classification = 0; res[i].score = 0; res[i].query_length = qlen[i]; res[i].query_length2 = qlen2 ? qlen2[i] : 0;
         res[i].is_classified = 0; res[i].ambiguous = 0; res[i].n_taxcnt = 0; res[i].taxcnt_off = 0;
     }
-    Taxonomer tx(*p, tax);
-    size_t w = 0, idx = 0;
     // Classifier::assignTaxonomy block cutting (Classifier.cpp:166-186)
+    struct Block { size_t s, e; uint32_t id; };
+    std::vector<Block> blocks;
+    size_t idx = 0;
     while (idx < nM) {
         uint32_t cur = qi_seq(ml[idx].qinfo);
         size_t s = idx;
         while (idx < nM && qi_seq(ml[idx].qinfo) == cur) ++idx;
-        size_t e = idx - 1;
-        size_t rIdx = (size_t)cur - 1;
-        std::map<int, unsigned> taxCnt;
-        tx.chooseBestTaxon(s, e, ml, qlen[rIdx], qlen2 ? qlen2[rIdx] : 0, res[rIdx], taxCnt);
-        res[rIdx].taxcnt_off = (uint32_t)w; res[rIdx].n_taxcnt = (uint16_t)std::min<size_t>(taxCnt.size(), 65535);
-        for (auto &kv : taxCnt) { if (w < cap) { tcTax[w] = kv.first; tcCnt[w] = kv.second; } w++; }
+        blocks.push_back({s, idx - 1, cur});
     }
+    // blocks are independent (Classifier.cpp:187-203: omp for schedule(dynamic, 1), one Taxonomer per thread)
+    const int T = std::max(1, std::min<int>(g_orc_threads, (int)(blocks.size() / 64 + 1)));
+    std::vector<std::vector<std::pair<int, unsigned>>> tcs(blocks.size());
+#pragma omp parallel num_threads(T)
+    {
+        Taxonomer tx(*p, tax);
+#pragma omp for schedule(dynamic, 64)
+        for (size_t b = 0; b < blocks.size(); b++) {
+            size_t rIdx = (size_t)blocks[b].id - 1;
+            std::map<int, unsigned> taxCnt;
+            tx.chooseBestTaxon(blocks[b].s, blocks[b].e, ml, qlen[rIdx], qlen2 ? qlen2[rIdx] : 0, res[rIdx], taxCnt);
+            tcs[b].assign(taxCnt.begin(), taxCnt.end());
+        }
+    }
+    size_t w = 0;
+    for (size_t b = 0; b < blocks.size(); b++) {
+        size_t rIdx = (size_t)blocks[b].id - 1;
+        res[rIdx].taxcnt_off = (uint32_t)w; res[rIdx].n_taxcnt = (uint16_t)std::min<size_t>(tcs[b].size(), 65535);
+        for (auto &kv : tcs[b]) { if (w < cap) { tcTax[w] = kv.first; tcCnt[w] = kv.second; } w++; }
+    }
+    return w;
+}
+
+/* The whole loop body of Classifier::startClassify (Classifier.cpp:81-125) for one batch, buffers kept inside (what
+ * bench.py's cpu_baseline times: no Python copies between the stages).  stage_s[5] = seconds of extract, sort, match,
+ * sortMatches, assignTaxonomy.  Returns the number of taxcnt entries (needed size if > cap). */
+#include <chrono>
+extern "C" size_t orc_classify_batch(orc_db *db, const orc_taxonomy *tax, const orc_params *p, const char *bases, const uint64_t *offs,
+                                     const char *bases2, const uint64_t *offs2, size_t n_reads, orc_result *res, int32_t *tcTax,
+                                     uint32_t *tcCnt, size_t cap, double *stage_s, size_t *n_kmers, size_t *n_matches) {
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = now();
+    size_t nb = (size_t)offs[n_reads] + (offs2 ? (size_t)offs2[n_reads] : 0);
+    std::vector<orc_kmer> k(2 * nb + 64);
+    std::vector<int32_t> ql(n_reads), ql2(n_reads);
+    size_t nk = orc_extract_batch(bases, offs, bases2, offs2, n_reads, p, k.data(), k.size(), ql.data(), ql2.data());
+    double t1 = now();
+    orc_sort_kmers(k.data(), nk);
+    double t2 = now();
+    std::vector<orc_match> m(nk + nk / 2 + 1024);
+    size_t nm = orc_match_kmers(db, k.data(), nk, m.data(), m.size());
+    if (nm > m.size()) { m.resize(nm); nm = orc_match_kmers(db, k.data(), nk, m.data(), m.size()); }   // Classifier.cpp:127-131 retry
+    double t3 = now();
+    orc_sort_matches(m.data(), nm);
+    double t4 = now();
+    size_t w = orc_score(db, tax, p, m.data(), nm, n_reads, ql.data(), ql2.data(), res, tcTax, tcCnt, cap);
+    double t5 = now();
+    if (stage_s) { stage_s[0] = t1 - t0; stage_s[1] = t2 - t1; stage_s[2] = t3 - t2; stage_s[3] = t4 - t3; stage_s[4] = t5 - t4; }
+    if (n_kmers) *n_kmers = nk;
+    if (n_matches) *n_matches = nm;
     return w;
 }
 

@@ -13,6 +13,42 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _hip_device_count():
+    """number of HIP devices, probed in a child process (this process must not load a HIP runtime before torch / libmtb
+    pick theirs); 0 when there is no runtime / GPU"""
+    import subprocess
+    code = ("import ctypes\n"
+            "n = ctypes.c_int(0)\n"
+            "for name in ('libamdhip64.so', 'libamdhip64.so.7', '/opt/rocm/lib/libamdhip64.so'):\n"
+            "    try:\n"
+            "        lib = ctypes.CDLL(name)\n"
+            "    except OSError:\n"
+            "        continue\n"
+            "    rc = lib.hipGetDeviceCount(ctypes.byref(n))\n"
+            "    print(n.value if rc == 0 else 0)\n"
+            "    break\n"
+            "else:\n"
+            "    print(0)\n")
+    try:
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120).stdout.strip().split("\n")[-1]
+        return int(out)
+    except Exception:
+        return 0
+
+
+def pytest_collection_modifyitems(config, items):
+    """a bare `pytest` on a box without a GPU skips the gpu-marked tests instead of erroring in their fixtures;
+    with `-m gpu` on such a box they are still skipped loudly (the driver runs them on an MI355X)."""
+    if not any("gpu" in it.keywords for it in items):
+        return
+    if os.path.exists("/dev/kfd") or _hip_device_count() > 0:       # /dev/kfd: the ROCm compute device node
+        return
+    skip = pytest.mark.skip(reason="no HIP device on this machine (libmtb has no CPU path)")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def orc():
     from helpers import Oracle
@@ -29,13 +65,13 @@ class Toy:
     """A toy database + reads + the oracle's full answer, built once per mode."""
 
     def __init__(self, orc, tmpdir, syncmer, paired, seed, n_reads=400, length=150, seq_mode=None, err=0.01,
-                 lognormal=False, genome_len=30000, with_n=0.1, kmer_format=2, accession_level=0, strain_rank="no rank"):
+                 lognormal=False, genome_len=30000, with_n=0.1, kmer_format=2, accession_level=0, strain_rank="no rank", genus_div=0.15):
         from helpers import build_toy_db, default_params
         from metabuli_amd import synth
         self.p = default_params(seq_mode=seq_mode or (2 if paired else 1), syncmer=syncmer, kmer_format=kmer_format,
                                 accession_level=accession_level)
         self.world = synth.make_world(seed=seed, n_genera=4, species_per_genus=3, strains_per_species=2, genome_len=genome_len,
-                                      strain_rank=strain_rank)
+                                      strain_rank=strain_rank, genus_div=genus_div)
         self.dbdir = str(tmpdir)
         self.values, self.taxids = build_toy_db(orc, self.world, self.p, self.dbdir)
         self.tax = orc.load_taxonomy(os.path.join(self.dbdir, "taxonomy"))

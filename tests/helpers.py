@@ -172,11 +172,46 @@ class Oracle:
         assert n <= cap
         return res, tt[:n].copy(), tc[:n].copy()
 
-    def classify(self, db, tax, p, bases, offs, bases2=None, offs2=None):
-        k, ql, ql2 = self.extract_batch(p, bases, offs, bases2, offs2)
-        ks = self.sort_kmers(k)
-        m = self.sort_matches(self.match(db, ks))
-        res, tt, tc = self.score(db, tax, p, m, len(offs) - 1, ql, ql2)
+    def classify_batch(self, db, tax, p, bases, offs, bases2=None, offs2=None, threads=1):
+        """the whole batch inside the library (no Python copies between the stages; bench.py's cpu_baseline).  Returns the
+        per-read results + taxcnt lists, per-stage seconds in last_stage_s, counts in last_counts."""
+        n = len(offs) - 1
+        res = np.zeros(n, result_dt)
+        cap = max(1024, 64 * n)
+        self.lib.orc_classify_batch.restype = C.c_size_t
+        self.set_threads(threads)
+        try:
+            while True:
+                tt = np.zeros(cap, np.int32); tc = np.zeros(cap, np.uint32)
+                st = (C.c_double * 5)(); nk = C.c_size_t(); nm = C.c_size_t()
+                w = self.lib.orc_classify_batch(db, tax, C.byref(p), _ptr(bases), _ptr(offs), _ptr(bases2), _ptr(offs2), C.c_size_t(n),
+                                                _ptr(res), _ptr(tt), _ptr(tc), C.c_size_t(cap), st, C.byref(nk), C.byref(nm))
+                if w <= cap:
+                    break
+                cap = w
+        finally:
+            self.set_threads(1)
+        self.last_stage_s = dict(zip(("extract", "sort_kmers", "match", "sort_matches", "score"), list(st)))
+        self.last_counts = dict(kmers=nk.value, matches=nm.value)
+        return dict(results=res, tc_tax=tt[:w].copy(), tc_cnt=tc[:w].copy())
+
+    def set_threads(self, n):
+        """host threads of the oracle's OpenMP layer (1 = the serial restatement)"""
+        self.lib.orc_set_threads(C.c_int(int(n)))
+
+    def classify(self, db, tax, p, bases, offs, bases2=None, offs2=None, threads=1):
+        import time
+        self.set_threads(threads)
+        try:
+            t = [time.perf_counter()]
+            k, ql, ql2 = self.extract_batch(p, bases, offs, bases2, offs2); t.append(time.perf_counter())
+            ks = self.sort_kmers(k); t.append(time.perf_counter())
+            m = self.match(db, ks); t.append(time.perf_counter())
+            m = self.sort_matches(m); t.append(time.perf_counter())
+            res, tt, tc = self.score(db, tax, p, m, len(offs) - 1, ql, ql2); t.append(time.perf_counter())
+        finally:
+            self.set_threads(1)
+        self.last_stage_s = dict(zip(("extract", "sort_kmers", "match", "sort_matches", "score"), np.diff(t).tolist()))
         return dict(kmers=ks, matches=m, results=res, tc_tax=tt, tc_cnt=tc, qlen=ql, qlen2=ql2)
 
 

@@ -111,10 +111,12 @@ def test_score_parallel_phases_equal_oracle(toy, orc, emu):
 
 
 @pytest.mark.parametrize("kw", [dict(min_score=0.2), dict(min_sp_score=0.9), dict(tie_ratio=0.5), dict(min_cons_cnt=2, min_cons_cnt_euk=3),
-                                dict(min_cons_cnt=1)])
-def test_score_parameter_variants(orc, emu, tmp_path, kw):
+                                dict(min_cons_cnt=1), dict(min_score=0.35, min_sp_score=0.6, tie_ratio=0.8), dict(tie_ratio=0.7)])
+@pytest.mark.parametrize("regime", ["clean", "noisy"])
+def test_score_parameter_variants(orc, emu, tmp_path, kw, regime):
     from conftest import Toy
-    t = Toy(orc, tmp_path, syncmer=1, paired=False, seed=8, n_reads=150)
+    # "noisy": species of a genus 4 % apart, 6 % read errors -> low scores and near-ties, so min_score / tie_ratio bite
+    t = Toy(orc, tmp_path, syncmer=1, paired=False, seed=8, n_reads=150, **(dict(err=0.06, genus_div=0.04) if regime == "noisy" else {}))
     for k, v in kw.items():
         setattr(t.p, k, v)
     ref = orc.classify(t.db, t.tax, t.p, t.b1, t.o1)
@@ -177,3 +179,23 @@ def test_slot16_roundtrip(toy, emu):
         rc = emu.lib.emu_slot_roundtrip(m.ctypes.data_as(C.c_void_p), C.c_size_t(len(m)), C.c_uint32(epoch), out.ctypes.data_as(C.c_void_p))
         assert rc == 0
         assert (out == m).all()
+
+
+def test_oracle_openmp_layer_equals_the_serial_restatement(orc, tmp_path):
+    """bench.py times the oracle on all host cores: read chunks, query splits and read blocks in parallel,
+    __gnu_parallel::sort for the two sorts.  Same answers as with one thread (match / metamer lists as sorted sets)."""
+    from conftest import Toy
+    t = Toy(orc, tmp_path, syncmer=1, paired=True, seed=21, n_reads=1500)
+    a = t.ref
+    b = orc.classify(t.db, t.tax, t.p, t.b1, t.o1, t.b2, t.o2, threads=4)
+    assert (np.sort(a["kmers"], order=["value", "qinfo"]) == np.sort(b["kmers"], order=["value", "qinfo"])).all()
+    assert (a["matches"] == b["matches"]).all()
+    assert (a["results"] == b["results"]).all() and (a["tc_tax"] == b["tc_tax"]).all() and (a["tc_cnt"] == b["tc_cnt"]).all()
+    assert orc.lib.orc_get_threads() == 1
+
+
+def test_oracle_whole_batch_call_equals_the_staged_calls(toy, orc):
+    """orc_classify_batch (what bench.py times) = the five staged oracle calls"""
+    r = orc.classify_batch(toy.db, toy.tax, toy.p, toy.b1, toy.o1, toy.b2, toy.o2, threads=3)
+    assert (r["results"] == toy.ref["results"]).all() and (r["tc_tax"] == toy.ref["tc_tax"]).all() and (r["tc_cnt"] == toy.ref["tc_cnt"]).all()
+    assert orc.last_counts["matches"] == len(toy.ref["matches"]) and orc.last_counts["kmers"] == len(toy.ref["kmers"])

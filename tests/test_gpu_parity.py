@@ -397,3 +397,126 @@ def test_golden_vectors_through_the_c_abi(ctx, orc, tmp_path, name):
     if not amb.any():
         assert (tt == g["tc_tax"]).all() and (tc == g["tc_cnt"]).all()
     ix.close()
+
+
+VARIANTS = [dict(min_score=0.3), dict(min_sp_score=0.5), dict(tie_ratio=0.7), dict(min_cons_cnt=2, min_cons_cnt_euk=3), dict(min_cons_cnt=1),
+            dict(min_score=0.35, min_sp_score=0.6, tie_ratio=0.8), dict(min_cons_cnt=6, min_cons_cnt_euk=12)]
+
+
+@pytest.mark.parametrize("kw", VARIANTS, ids=lambda kw: ",".join(f"{k}={v}" for k, v in kw.items()))
+@pytest.mark.parametrize("paired", [False, True], ids=["se", "pe"])
+def test_non_default_scoring_parameters_on_the_hip_path(ctx, orc, tmp_path, kw, paired):
+    """--min-score / --min-sp-score / --tie-ratio / --min-cons-cnt(-euk) away from their defaults, through mtb_score (exact
+    segments) and the fused batch (slot segments): the min_sp_score branch (Taxonomer.cpp:178-185), the min_score skip
+    (:357), tie -> LCA at other ratios, the Eukaryota MIN_DEPTH."""
+    from conftest import Toy
+    import metabuli_amd as M
+    # species of a genus 4 % apart and 6 % read errors: scores spread over 0..0.85 and near-ties between species are common,
+    # so every one of these switches changes answers (asserted)
+    t = Toy(orc, tmp_path, syncmer=1, paired=paired, seed=8, n_reads=300, err=0.06, genus_div=0.04)
+    base = t.ref["results"][["classification", "score", "is_classified"]].copy()
+    for k, v in kw.items():
+        setattr(t.p, k, v)
+    t.ref = orc.classify(t.db, t.tax, t.p, t.b1, t.o1, t.b2, t.o2)
+    assert (t.ref["results"][["classification", "score", "is_classified"]] != base).any()
+    p = M.default_params(seq_mode=t.p.seq_mode, syncmer=1, **kw)
+    ix = ctx.open_index(t.dbdir, p)
+    res, tt, tc = ctx.score(ix, p, t.ref["matches"], t.n_reads, t.ref["qlen"], t.ref["qlen2"])
+    _check_results(t, res, tt, tc)
+    res, tt, tc = ctx.classify_batch(ix, p, t.b1, t.o1, t.b2, t.o2)
+    _check_results(t, res, tt, tc)
+    ix.close()
+
+
+def test_redundancy_bit_of_legacy_databases(ctx, orc, tmp_path):
+    """Databases written before `Skip_redundancy 1` keep a redundancy flag in bit 31 of every `info` entry; the matcher
+    masks it (KmerMatcher.cpp:204-205, 381).  A toy database with the bit set on a third of the entries and
+    `Skip_redundancy 0` must classify exactly like its clean twin; without the mask the taxonomy ids would be garbage."""
+    from conftest import Toy
+    import metabuli_amd as M
+    t = Toy(orc, tmp_path / "clean", syncmer=1, paired=False, seed=12, n_reads=300)
+    d = str(tmp_path / "legacy"); os.makedirs(d)
+    for name in ("diffIdx", "split", "taxID_list"):
+        open(os.path.join(d, name), "wb").write(open(os.path.join(t.dbdir, name), "rb").read())
+    t.world.tax.write(os.path.join(d, "taxonomy"))
+    info = np.fromfile(os.path.join(t.dbdir, "info"), dtype=np.uint32)
+    rng = np.random.default_rng(5)
+    flagged = rng.random(len(info)) < 0.33
+    (info | (flagged.astype(np.uint32) << np.uint32(31))).astype(np.uint32).tofile(os.path.join(d, "info"))
+    txt = open(os.path.join(t.dbdir, "db.parameters")).read().replace("Skip_redundancy\t1", "Skip_redundancy\t0")
+    assert "Skip_redundancy\t0" in txt
+    open(os.path.join(d, "db.parameters"), "w").write(txt)
+    # the oracle on the legacy files (skip_redundancy 0 -> mask on) equals the clean run
+    from helpers import default_params
+    op = default_params(seq_mode=1, syncmer=1, skip_redundancy=0)
+    tax = orc.load_taxonomy(os.path.join(d, "taxonomy"))
+    ref = orc.classify(orc.open_db(d, tax, op), tax, op, t.b1, t.o1)
+    assert (ref["matches"] == t.ref["matches"]).all() and (ref["results"] == t.ref["results"]).all()
+    p = M.default_params(seq_mode=1, syncmer=1, skip_redundancy=0)
+    ix = ctx.open_index(d, p)
+    assert p.skip_redundancy == 0
+    _, dl_info = ix.download()
+    assert (dl_info >> 31).sum() == flagged.sum()                 # the resident index keeps the raw entries ...
+    m = ctx.sort_matches(ctx.match(ix, t.ref["kmers"]), t.n_reads)
+    assert (m == t.ref["matches"]).all()                          # ... and the join masks them
+    res, tt, tc = ctx.classify_batch(ix, p, t.b1, t.o1)
+    _check_results(t, res, tt, tc)
+    ix.close()
+
+
+def test_bench_path_matches_the_oracle(tmp_path):
+    """bench.py's own configuration in small: synthetic filler index (mtb_synth_index), borrowed device arrays
+    (mtb_index_from_device), device-resident reads (mtb_classify_batch_device) -- the entry points the headline number is
+    measured on -- compared with the oracle read by read inside bench.py (`parity_sample`).  A filler-dominated index
+    is a different join / scorer regime from the toy genomes: amino-acid runs full of foreign candidates."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for mode in (1, 2):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--reads", "20000", "--targets", "1.5e6",
+                              "--cpu-reads", "20000", "--cpu-targets", "1.5e6", "--species", "8", "--genome-len", "150000", "--filler-species", "3000",
+                              "--seq-mode", str(mode)], capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = json.loads(out.stdout.strip().split("\n")[-1])
+        ps = line["parity_sample"]
+        assert ps["reads"] == 20000 and ps["mismatches"] == 0 and ps["classified"] > 10000, ps
+        assert ps["matches"] == ps["oracle_matches"] > 0
+        assert line["cpu_baseline"]["cores"] >= 1 and line["cpu_baseline"]["kind"] == "port"
+
+
+def test_format1_database_without_kmer_format_line(ctx, orc, tmp_path):
+    """setClassifyDefaults (classify.cpp:12) leaves kmerFormat at 1: a legacy database whose db.parameters has no
+    Kmer_format line is read as format 1.  mtb_default_params must agree, else such a database is silently extracted
+    and joined as format 2."""
+    import ctypes as C
+    from conftest import Toy
+    import metabuli_amd as M
+    t = Toy(orc, tmp_path, syncmer=0, paired=False, seed=6, n_reads=200, kmer_format=1)
+    path = os.path.join(t.dbdir, "db.parameters")
+    lines = [l for l in open(path).read().split("\n") if not l.startswith("Kmer_format")]
+    open(path, "w").write("\n".join(lines))
+    p = M.Params()
+    M.lib().mtb_default_params(C.byref(p))
+    assert p.kmer_format == 1 and p.seq_mode == 2 and p.syncmer == 0
+    p.seq_mode = 1
+    ix = ctx.open_index(t.dbdir, p)
+    assert p.kmer_format == 1
+    res, tt, tc = ctx.classify_batch(ix, p, t.b1, t.o1)
+    _check_results(t, res, tt, tc)
+    assert (res["is_classified"] != 0).sum() > 100
+    ix.close()
+
+
+def test_reduced_alphabet_database_is_rejected(ctx, toy, tmp_path):
+    """Reduced_alphabet 1 switches the reference to ReducedKmerMatcher and 4-bit codon fields; not implemented here, so
+    such a database must be refused instead of being classified with the 24-bit DNA arithmetic"""
+    import shutil
+    import metabuli_amd as M
+    d = str(tmp_path / "red")
+    shutil.copytree(toy.dbdir, d)
+    path = os.path.join(d, "db.parameters")
+    open(path, "w").write(open(path).read().replace("Reduced_alphabet\t0", "Reduced_alphabet\t1"))
+    with pytest.raises(M.MtbError) as e:
+        ctx.open_index(d, _params(toy))
+    assert e.value.status == M.MTB_ERR_UNSUPPORTED
