@@ -26,6 +26,15 @@
 static int g_orc_threads = 1;
 extern "C" void orc_set_threads(int n) { g_orc_threads = n < 1 ? 1 : n; omp_set_num_threads(g_orc_threads); }
 extern "C" int orc_get_threads(void) { return g_orc_threads; }
+/* uninitialised storage: big scratch arrays must not be zero-filled by one thread before the parallel stages touch them */
+template <class T> struct RawBuf {
+    T *p = nullptr; size_t n = 0;
+    explicit RawBuf(size_t n_ = 0) { if (n_) resize(n_); }
+    ~RawBuf() { free(p); }
+    RawBuf(const RawBuf &) = delete; RawBuf &operator=(const RawBuf &) = delete;
+    void resize(size_t n_) { free(p); p = (T *)malloc(std::max<size_t>(n_, 1) * sizeof(T)); n = p ? n_ : 0; }
+    T *data() { return p; } size_t size() const { return n; }
+};
 
 namespace {
 
@@ -450,23 +459,26 @@ size_t orc_extract_batch(const char *bases, const uint64_t *offs, const char *ba
                          orc_kmer *out, size_t cap, int32_t *qlen, int32_t *qlen2) {
     const int T = g_orc_threads;
     if (T <= 1 || n_reads < (size_t)T * 64) return extract_range(bases, offs, bases2, offs2, 0, n_reads, p, out, cap, qlen, qlen2);
-    /* read chunks in parallel into private buffers (2 metamers per base bound), concatenated in read order */
-    std::vector<std::vector<orc_kmer>> part((size_t)T);
-    std::vector<size_t> cnt((size_t)T, 0);
-#pragma omp parallel for schedule(static, 1) num_threads(T)
-    for (int t = 0; t < T; t++) {
-        size_t lo = n_reads * (size_t)t / (size_t)T, hi = n_reads * (size_t)(t + 1) / (size_t)T;
-        size_t nb = (size_t)(offs[hi] - offs[lo]) + (offs2 ? (size_t)(offs2[hi] - offs2[lo]) : 0);
-        part[(size_t)t].resize(2 * nb + 64);
-        cnt[(size_t)t] = extract_range(bases, offs, bases2, offs2, lo, hi, p, part[(size_t)t].data(), part[(size_t)t].size(), qlen, qlen2);
+    /* KmerExtractor.cpp:117-200: every thread extracts a chunk of reads into a private buffer and reserves its slice of the
+     * shared buffer with one atomic add (kmerBuffer.reserveMemory); the order of the slices is arbitrary there too */
+    const size_t CH = 1024, n_chunks = (n_reads + CH - 1) / CH;
+    size_t total = 0;
+#pragma omp parallel num_threads(T)
+    {
+        std::vector<orc_kmer> buf;
+#pragma omp for schedule(dynamic, 1)
+        for (size_t c = 0; c < n_chunks; c++) {
+            size_t lo = c * CH, hi = std::min(n_reads, lo + CH);
+            size_t nb = (size_t)(offs[hi] - offs[lo]) + (offs2 ? (size_t)(offs2[hi] - offs2[lo]) : 0);
+            if (buf.size() < 2 * nb + 64) buf.resize(2 * nb + 64);
+            size_t cnt = extract_range(bases, offs, bases2, offs2, lo, hi, p, buf.data(), buf.size(), qlen, qlen2);
+            size_t at;
+#pragma omp atomic capture
+            { at = total; total += cnt; }
+            if (at < cap) memcpy(out + at, buf.data(), std::min(cnt, cap - at) * sizeof(orc_kmer));
+        }
     }
-    size_t n = 0;
-    for (int t = 0; t < T; t++) {
-        size_t c = cnt[(size_t)t];
-        if (n < cap) memcpy(out + n, part[(size_t)t].data(), std::min(c, cap - n) * sizeof(orc_kmer));
-        n += c;
-    }
-    return n;
+    return total;
 }
 
 void orc_sort_kmers(orc_kmer *k, size_t n) {
@@ -797,22 +809,23 @@ size_t orc_match_kmers(orc_db *db, const orc_kmer *q, size_t queryKmerNum, orc_m
     }
     cut.push_back(blank + queryKmerNum);
     const int S = (int)cut.size() - 1;
-    std::vector<std::vector<orc_match>> part((size_t)S);
+    std::vector<RawBuf<orc_match>> part((size_t)S);
+    std::vector<size_t> cnt((size_t)S, 0), first((size_t)S + 1, 0);
 #pragma omp parallel for schedule(dynamic, 1) num_threads(T)
     for (int t = 0; t < S; t++) {
-        std::vector<orc_match> &v = part[(size_t)t];
+        RawBuf<orc_match> &v = part[(size_t)t];
         v.resize((cut[(size_t)t + 1] - cut[(size_t)t]) * 2 + 1024);
         size_t m = match_split(db, q, cut[(size_t)t], cut[(size_t)t + 1] - 1, v.data(), v.size());
         if (m > v.size()) { v.resize(m); m = match_split(db, q, cut[(size_t)t], cut[(size_t)t + 1] - 1, v.data(), v.size()); }
-        v.resize(m);
+        cnt[(size_t)t] = m;
     }
-    size_t n = 0;
+    for (int t = 0; t < S; t++) first[(size_t)t + 1] = first[(size_t)t] + cnt[(size_t)t];
+#pragma omp parallel for schedule(static, 1) num_threads(T)
     for (int t = 0; t < S; t++) {
-        size_t c = part[(size_t)t].size();
+        size_t n = first[(size_t)t], c = cnt[(size_t)t];
         if (n < cap) memcpy(out + n, part[(size_t)t].data(), std::min(c, cap - n) * sizeof(orc_match));
-        n += c;
     }
-    return n;
+    return first[(size_t)S];
 }
 
 // KmerMatcher::compareMatches / sortMatches (KmerMatcher.cpp:1071-1078, 1149-1166)
@@ -1151,13 +1164,13 @@ extern "C" size_t orc_classify_batch(orc_db *db, const orc_taxonomy *tax, const 
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t0 = now();
     size_t nb = (size_t)offs[n_reads] + (offs2 ? (size_t)offs2[n_reads] : 0);
-    std::vector<orc_kmer> k(2 * nb + 64);
+    RawBuf<orc_kmer> k(2 * nb + 64);
     std::vector<int32_t> ql(n_reads), ql2(n_reads);
     size_t nk = orc_extract_batch(bases, offs, bases2, offs2, n_reads, p, k.data(), k.size(), ql.data(), ql2.data());
     double t1 = now();
     orc_sort_kmers(k.data(), nk);
     double t2 = now();
-    std::vector<orc_match> m(nk + nk / 2 + 1024);
+    RawBuf<orc_match> m(nk + nk / 2 + 1024);
     size_t nm = orc_match_kmers(db, k.data(), nk, m.data(), m.size());
     if (nm > m.size()) { m.resize(nm); nm = orc_match_kmers(db, k.data(), nk, m.data(), m.size()); }   // Classifier.cpp:127-131 retry
     double t3 = now();

@@ -516,7 +516,9 @@ def test_reduced_alphabet_database_is_rejected(ctx, toy, tmp_path):
     d = str(tmp_path / "red")
     shutil.copytree(toy.dbdir, d)
     path = os.path.join(d, "db.parameters")
-    open(path, "w").write(open(path).read().replace("Reduced_alphabet\t0", "Reduced_alphabet\t1"))
+    txt = open(path).read().replace("Reduced_alphabet\t0", "Reduced_alphabet\t1")
+    assert "Reduced_alphabet\t1" in txt
+    open(path, "w").write(txt)
     with pytest.raises(M.MtbError) as e:
         ctx.open_index(d, _params(toy))
     assert e.value.status == M.MTB_ERR_UNSUPPORTED
