@@ -199,3 +199,26 @@ def test_oracle_whole_batch_call_equals_the_staged_calls(toy, orc):
     r = orc.classify_batch(toy.db, toy.tax, toy.p, toy.b1, toy.o1, toy.b2, toy.o2, threads=3)
     assert (r["results"] == toy.ref["results"]).all() and (r["tc_tax"] == toy.ref["tc_tax"]).all() and (r["tc_cnt"] == toy.ref["tc_cnt"]).all()
     assert orc.last_counts["matches"] == len(toy.ref["matches"]) and orc.last_counts["kmers"] == len(toy.ref["kmers"])
+
+
+def test_reporter_restatements_agree(toy, orc, tmp_path):
+    """tests/reporter_spec.py (Python, from Reporter.cpp) and the oracle's C++ writer produce the same files"""
+    import ctypes as C
+    import reporter_spec as rs
+    ref = toy.ref
+    names = [f"r{i}" for i in range(toy.n_reads)]
+    tv = rs.TaxView(toy.world.tax.parent, toy.world.tax.rank, toy.world.tax.name)
+    nm = ("\n".join(names) + "\n").encode()
+    for lin in (0, 1):
+        a = str(tmp_path / f"a{lin}.tsv"); b = str(tmp_path / f"b{lin}.tsv")
+        assert orc.lib.orc_write_classifications2(a.encode(), toy.tax, nm, C.c_size_t(toy.n_reads), ref["results"].ctypes.data_as(C.c_void_p),
+                                                  ref["tc_tax"].ctypes.data_as(C.c_void_p), ref["tc_cnt"].ctypes.data_as(C.c_void_p), C.c_int(lin)) == 0
+        rs.write_classifications(b, tv, names, ref["results"], ref["tc_tax"], ref["tc_cnt"], lineage=bool(lin))
+        assert open(a).read() == open(b).read()
+    a = str(tmp_path / "ra.tsv"); b = str(tmp_path / "rb.tsv")
+    assert orc.lib.orc_write_report(a.encode(), toy.tax, C.c_size_t(toy.n_reads), ref["results"].ctypes.data_as(C.c_void_p)) == 0
+    counts = {}
+    for c in ref["results"]["classification"].tolist():
+        counts[c] = counts.get(c, 0) + 1
+    rs.write_report(b, tv, counts, toy.n_reads)
+    assert sorted(open(a).read().split("\n")) == sorted(open(b).read().split("\n"))

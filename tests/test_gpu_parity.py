@@ -191,9 +191,28 @@ def test_classify_driver_tsv_outputs(toy, orc, tmp_path):
     assert orc.lib.orc_write_classifications(cpath.encode(), toy.tax, nm, C.c_size_t(toy.n_reads), ref["results"].ctypes.data_as(C.c_void_p),
                                              ref["tc_tax"].ctypes.data_as(C.c_void_p), ref["tc_cnt"].ctypes.data_as(C.c_void_p)) == 0
     assert orc.lib.orc_write_report(rpath.encode(), toy.tax, C.c_size_t(toy.n_reads), ref["results"].ctypes.data_as(C.c_void_p)) == 0
+    # the Python restatement of Reporter.cpp (tests/reporter_spec.py) is the primary comparison; the oracle's C++ writer second
+    import reporter_spec as rs
+    tv = rs.TaxView(toy.world.tax.parent, toy.world.tax.rank, toy.world.tax.name)
+    spath = str(tmp_path / "spec_classifications.tsv"); srpath = str(tmp_path / "spec_report.tsv")
+    rs.write_classifications(spath, tv, names, ref["results"], ref["tc_tax"], ref["tc_cnt"])
+    counts = {}
+    for c in ref["results"]["classification"].tolist():
+        counts[c] = counts.get(c, 0) + 1
+    rs.write_report(srpath, tv, counts, toy.n_reads)
     if not (ref["results"]["flag"] != 0).any():
-        assert open(str(tmp_path / "job_classifications.tsv")).read() == open(cpath).read()
-        assert sorted(open(str(tmp_path / "job_report.tsv")).read().split("\n")) == sorted(open(rpath).read().split("\n"))
+        got_c = open(str(tmp_path / "job_classifications.tsv")).read(); got_r = open(str(tmp_path / "job_report.tsv")).read()
+        assert got_c == open(spath).read()
+        assert sorted(got_r.split("\n")) == sorted(open(srpath).read().split("\n"))      # order among equal clade counts is unspecified
+        assert got_r.split("\n")[0] == open(srpath).read().split("\n")[0]
+        assert got_c == open(cpath).read()
+        assert sorted(got_r.split("\n")) == sorted(open(rpath).read().split("\n"))
+        krona = open(str(tmp_path / "job_krona.html")).read()
+        nodes = rs.krona_nodes(tv, counts, toy.n_reads)
+        assert krona.endswith("</krona></div></body></html>") and "<krona" in krona
+        body = krona[krona.index('<node name="all">'):-len("</krona></div></body></html>")]
+        assert sorted(body.split("<node ")) == sorted(nodes.split("<node "))                 # same nodes; sibling order among ties free
+        assert body.count("</node>") == nodes.count("</node>")
     # --lineage 1 adds the lineage column (Reporter.cpp:38-40, 57-59, 74-76)
     args_l = args[:1] + ["--lineage", "1"] + args[1:-1] + ["jobl"]
     subprocess.check_call(args_l, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
@@ -202,6 +221,8 @@ def test_classify_driver_tsv_outputs(toy, orc, tmp_path):
                                               ref["tc_tax"].ctypes.data_as(C.c_void_p), ref["tc_cnt"].ctypes.data_as(C.c_void_p), C.c_int(1)) == 0
     if not (ref["results"]["flag"] != 0).any():
         got = open(str(tmp_path / "jobl_classifications.tsv")).read()
+        rs.write_classifications(spath, tv, names, ref["results"], ref["tc_tax"], ref["tc_cnt"], lineage=True)
+        assert got == open(spath).read()
         assert got == open(lpath).read()
         assert "\tlineage\t" in got.split("\n")[0] and ";s_" in got
 
