@@ -217,7 +217,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step")
     ap.add_argument("--read-len", type=int, default=150)
-    ap.add_argument("--targets", type=float, default=8e9, help="filler metamers in the synthetic index (per GPU, replicated)")
+    ap.add_argument("--targets", type=float, default=16e9,
+                    help="filler metamers in the synthetic index (per GPU, replicated); 16 G = SURVEY 8(d)'s GTDB-scale planning size, 192 GB flat")
     ap.add_argument("--species", type=int, default=24)
     ap.add_argument("--genome-len", type=int, default=1_000_000)
     ap.add_argument("--filler-species", type=int, default=130_000)
@@ -359,8 +360,9 @@ def main():
     # algorithmic bytes of one whole step per kernel (SURVEY.md 8(d) per-stage split);
     # a step launches every kernel once per stream (and per radix pass): bytes per launch = total / launches
     alg_step = {"extract_count": L, "extract_emit": L + 16 * Kq, "radix_hist": 16 * Kq, "radix_scatter": 32 * Kq,
-                "join": 16 * Kq + 12 * ps.n_targets + 24 * Mm, "regroup": 48 * Mm, "score": 24 * Mm + 16 * N}
+                "join": 16 * Kq + 24 * Mm, "regroup": 48 * Mm, "score": 24 * Mm + 16 * N}
     alg = {k: v / max(1, kern[k]["launches"]) for k, v in alg_step.items()}
+    alg["join"] += 12 * ps.n_targets          # the 12*T_span term is paid by every launch (one per HBM-budgeted sub-batch): each spans the whole index
     dom = max((k for k in alg), key=lambda k: kern[k]["ms"])
     avg_ms = kern[dom]["ms"] / max(1, kern[dom]["launches"])
     achieved = alg[dom] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -409,7 +411,8 @@ def main():
                                         f"syncmer s=5, kmer_format 2 ({ {1: 'BASELINE.json configs[1]', 2: 'BASELINE.json configs[3] shape: paired-end, index replicated, reads sharded', 3: 'BASELINE.json configs[2] shape: long reads'}[args.seq_mode] })",
                                reads_per_gpu=args.reads, read_len=args.read_len, targets=int(T), seq_mode=args.seq_mode,
                                gbp_per_s=value * args.read_len * (2 if args.seq_mode == 2 else 1) / 1e3, query_metamers=int(st.n_kmers), matches=int(st.n_matches),
-                               classified_fraction=frac_cls, parallelism=f"reads sharded x{world_size}, index replicated", streams_per_gpu=args.streams),
+                               classified_fraction=frac_cls, parallelism=f"reads sharded x{world_size}, index replicated", streams_per_gpu=args.streams,
+                               sub_batches_per_step=ctx.last_sub_batches),
                    stage_ms=dict(extract=st.ms_extract, sort=st.ms_sort, join=st.ms_join, regroup=st.ms_regroup,
                                  segsort=st.ms_segsort, score=st.ms_score, total=st.ms_total),
                    kernel_ms=kern, roofline=roofline, cpu_baseline=cpu, parity_sample=parity)

@@ -121,6 +121,13 @@ mtb_status mtb_ctx_set_profiling(mtb_ctx *, int on);
  * latency-bound kernels of one range overlap bandwidth-bound kernels of another.  Results are
  * identical; per-read taxcnt slots of range i live in the i-th n-th of the taxcnt arrays.   */
 mtb_status mtb_ctx_set_streams(mtb_ctx *, int n);
+/* HBM-budgeted batching (replaces QueryIndexer's --max-ram split rule, QueryIndexer.cpp:62,132, and the
+ * matchPerKmer += 4 redo, Classifier.cpp:92-99,127-131): mtb_classify_batch* cut a batch into contiguous read ranges
+ * whose workspace (metamer buffers, slot segments, match buffers) fits the budget and run them one after another;
+ * results are those of the undivided batch.  bytes = 0 (default): the budget is what hipMemGetInfo reports free plus
+ * what the context already holds.  mtb_ctx_last_sub_batches: how many ranges the last call used.               */
+mtb_status mtb_ctx_set_workspace_limit(mtb_ctx *, uint64_t bytes);
+uint32_t   mtb_ctx_last_sub_batches(const mtb_ctx *);
 
 /* ---- index residency ---------------------------------------------------
  * Replaces the per-call fopen/fread/mmap of diffIdx, info, split inside

@@ -147,6 +147,15 @@ class Context:
     def set_profiling(self, on):
         _chk(self.L.mtb_ctx_set_profiling(self.h, C.c_int(1 if on else 0)))
 
+    def set_workspace_limit(self, nbytes):
+        """workspace budget of a batch in bytes (0 = automatic from hipMemGetInfo): forces sub-batches in tests"""
+        _chk(self.L.mtb_ctx_set_workspace_limit(self.h, C.c_uint64(int(nbytes))))
+
+    @property
+    def last_sub_batches(self):
+        self.L.mtb_ctx_last_sub_batches.restype = C.c_uint32
+        return int(self.L.mtb_ctx_last_sub_batches(self.h))
+
     def set_streams(self, n):
         _chk(self.L.mtb_ctx_set_streams(self.h, C.c_int(n)))
 

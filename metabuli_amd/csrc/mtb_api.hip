@@ -53,7 +53,13 @@ struct mtb_ctx {
     uint32_t seg_epoch = 0;          /* tag of the live slots in the "segm" buffer (1..MTB_SLOT_EPOCHS) */
     double extract_yield = 0.0;      /* metamers per base of the previous batch (single-pass extraction buffer sizing) */
     uint64_t part_n_reads = 0; uint32_t part_max_len = 0;   /* batch state between mtb_part_extract and mtb_part_score */
+    uint64_t ws_limit = 0;           /* workspace budget of a batch in bytes; 0 = what hipMemGetInfo reports free (+ what the context holds) */
+    double ws_per_base = 0.0;        /* workspace bytes per base measured on the last sub-batch (HBM-budgeted batching) */
+    uint32_t last_sub_batches = 0;
 };
+/* buffers that carry a call's inputs / outputs (host-buffer entry points) are not workspace */
+static bool is_io_buf(const std::string &n) { return n == "bases" || n == "offs" || n == "bases2" || n == "offs2" || n == "results" || n == "tctax" || n == "tccnt"; }
+static size_t held_bytes(const mtb_ctx *c) { size_t b = 0; for (auto &kv : c->bufs) if (!is_io_buf(kv.first)) b += kv.second.cap; return b; }
 
 /* RAII bracket around one kernel launch (only when profiling is on) */
 struct KTimer {
@@ -171,6 +177,13 @@ mtb_status mtb_ctx_set_profiling(mtb_ctx *c, int on) {
     for (mtb_ctx *l : c->lanes) l->profiling = on;
     return MTB_OK;
 }
+mtb_status mtb_ctx_set_workspace_limit(mtb_ctx *c, uint64_t bytes) {
+    if (!c) return fail(MTB_ERR_ARG, "NULL ctx");
+    c->ws_limit = bytes;
+    for (mtb_ctx *l : c->lanes) l->ws_limit = bytes;
+    return MTB_OK;
+}
+uint32_t mtb_ctx_last_sub_batches(const mtb_ctx *c) { return c ? c->last_sub_batches : 0; }
 mtb_status mtb_ctx_set_streams(mtb_ctx *c, int n) {
     if (!c || n < 1 || n > 8) return fail(MTB_ERR_ARG, "streams must be 1..8");
     HIPCHK(hipSetDevice(c->device));
@@ -1090,6 +1103,71 @@ static void merge_stats(mtb_batch_stats &S, const mtb_batch_stats &L) {
     for (int i = 0; i < MTB_NUM_KERNELS; i++) { S.ms_kernel[i] += L.ms_kernel[i]; S.n_launch[i] += L.n_launch[i]; }
 }
 
+/* HBM-budgeted batching (the reference sizes a QuerySplit from --max-ram, QueryIndexer.cpp:62,132, and redoes
+ * it with a bigger match buffer on overflow, Classifier.cpp:127-131).  Here the budget is HBM: what hipMemGetInfo
+ * reports free plus what the context's own buffers already hold (or mtb_ctx_set_workspace_limit), and the per-base
+ * workspace is known -- two 16-byte metamer buffers + two 2-byte digit arrays per extracted metamer, one 16-byte slot per
+ * metamer plus the tail for short reads (24-byte match records twice for long reads), ~100 bytes of per-read tables -- and
+ * is re-measured on every sub-batch.  The batch is cut into contiguous read ranges of equal size that fit; a range that
+ * still runs out of memory is halved and redone.  Results land at their final places (d_results + lo, taxcnt slots
+ * appended), so the caller sees one batch. */
+static mtb_status classify_budgeted(mtb_ctx *c, mtb_index *ix, const mtb_params *p, const char *d_bases, const uint64_t *d_offs,
+                                    const char *d_bases2, const uint64_t *d_offs2, uint64_t n_reads, uint64_t n_bases_total,
+                                    mtb_result *d_results, int32_t *d_taxcnt_tax, uint32_t *d_taxcnt_cnt, uint64_t taxcnt_cap,
+                                    uint64_t *n_taxcnt, uint64_t tc_base0) {
+    HIPCHK(hipSetDevice(c->device));
+    *n_taxcnt = 0;
+    c->last_sub_batches = 0;
+    if (n_reads == 0) { memset(&c->stats, 0, sizeof(c->stats)); return MTB_OK; }
+    size_t fr = 0, tot = 0;
+    HIPCHK(hipMemGetInfo(&fr, &tot));
+    const size_t held = held_bytes(c);
+    uint64_t budget = c->ws_limit ? c->ws_limit : (uint64_t)fr + held;
+    if (!c->ws_limit) budget -= std::min<uint64_t>(budget / 16, 2ull << 30);          /* allocator granularity, other users of the device */
+    const double mean_len = (double)n_bases_total / (double)n_reads;
+    double per_base = c->ws_per_base;
+    if (per_base <= 0.0) {
+        const double yield = (c->extract_yield > 0.0 ? c->extract_yield : (p->syncmer ? 1.0 : 2.0)) * 1.15;
+        per_base = yield * (16 + 16 + 2 + 2) + (p->seq_mode == 3 ? yield * 1.5 * 48 : yield * 1.2 * 16 + 24.0 * 16 / std::max(mean_len, 1.0)) + 100.0 / std::max(mean_len, 1.0);
+    }
+    uint64_t fit = (uint64_t)((double)budget / (per_base * 1.08 * mean_len));          /* reads per sub-batch */
+    fit = std::max<uint64_t>(fit, 1);
+    uint64_t n_sub = (n_reads + fit - 1) / fit;
+    mtb_batch_stats S; memset(&S, 0, sizeof(S));
+    uint64_t tc_used = 0, lo = 0;
+    uint32_t done = 0;
+    while (lo < n_reads) {
+        const uint64_t left_sub = std::max<uint64_t>(1, n_sub > done ? n_sub - done : 1);
+        uint64_t cnt = (n_reads - lo + left_sub - 1) / left_sub;
+        uint64_t n_tc = 0;
+        mtb_status st;
+        for (;;) {
+            st = classify_one(c, ix, p, d_bases, d_offs + lo, d_bases2, d_offs2 ? d_offs2 + lo : nullptr, cnt,
+                              (uint64_t)(mean_len * (double)cnt), d_results + lo, d_taxcnt_tax + tc_used, d_taxcnt_cnt + tc_used,
+                              taxcnt_cap - std::min(taxcnt_cap, tc_used), &n_tc, tc_base0 + tc_used);
+            if (st != MTB_ERR_OOM || cnt <= 1024) break;
+            /* the estimate was too optimistic for this range: give the memory back, halve, redo */
+            HIPCHK(hipStreamSynchronize(c->stream));
+            for (auto &kv : c->bufs) if (kv.second.p && !is_io_buf(kv.first)) { hipError_t e = hipFree(kv.second.p); (void)e; kv.second.p = nullptr; kv.second.cap = 0; }
+            cnt = (cnt + 1) / 2; n_sub *= 2; done *= 2;
+        }
+        if (st == MTB_ERR_CAPACITY) {
+            /* taxcnt arrays too small: report what the whole batch needs (slots of the ranges done + this one + the rest pro rata) */
+            const uint64_t rest = n_reads - lo - cnt;
+            *n_taxcnt = std::max<uint64_t>(taxcnt_cap + 1, tc_used + n_tc + (uint64_t)((double)n_tc / (double)cnt * (double)rest * 1.05) + 64);
+            return st;
+        }
+        if (st != MTB_OK) return st;
+        if (c->stats.n_bases) c->ws_per_base = (double)held_bytes(c) / (double)c->stats.n_bases;
+        merge_stats(S, c->stats); S.ms_total += c->stats.ms_total;
+        tc_used += n_tc; lo += cnt; done++;
+    }
+    c->stats = S;
+    c->last_sub_batches = done;
+    *n_taxcnt = tc_used;
+    return MTB_OK;
+}
+
 extern "C" {
 
 mtb_status mtb_classify_batch_device(mtb_ctx *c, mtb_index *ix, const mtb_params *p, const char *d_bases, const uint64_t *d_offs,
@@ -1099,8 +1177,8 @@ mtb_status mtb_classify_batch_device(mtb_ctx *c, mtb_index *ix, const mtb_params
     if (!c || !ix || !p || !n_taxcnt) return fail(MTB_ERR_ARG, "NULL argument");
     const size_t L = c->lanes.size();
     if (L < 2 || n_reads < 4096 * L)
-        return classify_one(c, ix, p, d_bases, d_offs, d_bases2, d_offs2, n_reads, n_bases_total, d_results, d_taxcnt_tax, d_taxcnt_cnt,
-                            taxcnt_cap, n_taxcnt, 0);
+        return classify_budgeted(c, ix, p, d_bases, d_offs, d_bases2, d_offs2, n_reads, n_bases_total, d_results, d_taxcnt_tax, d_taxcnt_cnt,
+                                 taxcnt_cap, n_taxcnt, 0);
     /* L contiguous read ranges, one host thread + one non-blocking stream each */
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));          /* inputs produced on the caller's stream are complete */

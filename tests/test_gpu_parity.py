@@ -543,3 +543,24 @@ def test_reduced_alphabet_database_is_rejected(ctx, toy, tmp_path):
     with pytest.raises(M.MtbError) as e:
         ctx.open_index(d, _params(toy))
     assert e.value.status == M.MTB_ERR_UNSUPPORTED
+
+
+def test_hbm_budgeted_sub_batches(toy):
+    """a21: with a tiny workspace budget the library cuts the batch into >= 3 contiguous read ranges, runs them one after
+    another and still returns the undivided batch's results (per-read rows at their places, taxcnt slots appended)."""
+    import metabuli_amd as M
+    c = M.Context(0)
+    p = _params(toy)
+    ix = c.open_index(toy.dbdir, p)
+    n_bases = int(toy.o1[-1]) + (int(toy.o2[-1]) if toy.o2 is not None else 0)
+    c.set_workspace_limit(max(n_bases * 20, 200_000))          # ~a quarter of what the batch needs at once
+    res, tt, tc = c.classify_batch(ix, p, toy.b1, toy.o1, toy.b2, toy.o2)
+    assert c.last_sub_batches >= 3, c.last_sub_batches
+    _check_results(toy, res, tt, tc)
+    st = c.last_stats()
+    assert st.n_reads == toy.n_reads and st.n_kmers == len(toy.ref["kmers"]) and st.n_matches == len(toy.ref["matches"])
+    c.set_workspace_limit(0)
+    res2, tt2, tc2 = c.classify_batch(ix, p, toy.b1, toy.o1, toy.b2, toy.o2)
+    assert c.last_sub_batches == 1
+    assert (res2 == res).all() and (tt2 == tt).all() and (tc2 == tc).all()
+    ix.close(); c.close()
