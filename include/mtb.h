@@ -135,7 +135,8 @@ uint32_t   mtb_ctx_last_sub_batches(const mtb_ctx *);
  * KmerMatcher::loadTaxIdList (KmerMatcher.cpp:56-120) plus loadTaxonomy /
  * loadDbParameters (common.cpp:50-133): the delta-coded index is decoded
  * once on the GPU into a flat {u64 value[T]; u32 info[T]} held in HBM.
- * `taxonomy_dir` may be NULL (then DBDIR/taxonomy/{names,nodes,merged}.dmp).
+ * Taxonomy as loadTaxonomy picks it (common.cpp:50-86): DBDIR/taxonomyDB (binary, internal ids) if present, else
+ * `taxonomy_dir`, else (NULL) DBDIR/taxonomy/{names,nodes,merged}.dmp.
  * `params` is in/out: db.parameters overrides are written back.             */
 mtb_status mtb_index_open(mtb_ctx *, const char *dbdir, const char *taxonomy_dir,
                           mtb_params *params, mtb_index **out);
@@ -156,6 +157,13 @@ int32_t    mtb_tax_lca(const mtb_index *, int32_t a, int32_t b);
 int32_t    mtb_tax_species(const mtb_index *, int32_t taxid);  /* taxId2speciesId */
 int32_t    mtb_tax_parent(const mtb_index *, int32_t taxid);
 int32_t    mtb_tax_max_id(const mtb_index *);
+/* TaxonomyWrapper::getOriginalTaxID (TaxonomyWrapper.h:70-79): databases written by `build` number their taxa
+ * internally (1..maxTaxID in order of appearance) and keep the map in taxonomyDB; every id the reference prints goes
+ * through it (Reporter.cpp:52,62,69,181).  Identity for dump-file taxonomies.                               */
+int32_t    mtb_tax_original_id(const mtb_index *, int32_t taxid);
+/* children of a node in node order (NcbiTaxonomy::getParentToChildren, used by Reporter::writeReportFile, Reporter.cpp:121) */
+int32_t    mtb_tax_num_children(const mtb_index *, int32_t taxid);
+int32_t    mtb_tax_child(const mtb_index *, int32_t taxid, int32_t k);
 /* rank / scientific name of a node ("" if unknown); pointers stay valid while the index is open
  * (TaxonomyWrapper::getString(taxonNode(t)->rankIdx / nameIdx), used by Reporter.cpp:35-193) */
 const char *mtb_tax_rank(const mtb_index *, int32_t taxid);

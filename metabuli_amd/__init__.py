@@ -81,6 +81,8 @@ def lib():
     L.mtb_tax_species.argtypes = [C.c_void_p, C.c_int32]
     L.mtb_tax_parent.argtypes = [C.c_void_p, C.c_int32]
     L.mtb_tax_max_id.argtypes = [C.c_void_p]
+    L.mtb_tax_original_id.restype = C.c_int32
+    L.mtb_tax_original_id.argtypes = [C.c_void_p, C.c_int32]
     for f in ("mtb_tax_rank", "mtb_tax_name"):
         getattr(L, f).restype = C.c_char_p
         getattr(L, f).argtypes = [C.c_void_p, C.c_int32]
@@ -304,6 +306,10 @@ class Index:
     @property
     def num_targets(self):
         return self.ctx.L.mtb_index_num_targets(self.h)
+
+    def original_id(self, taxid):
+        """TaxonomyWrapper::getOriginalTaxID: internal id (what results carry) -> the id the reports print"""
+        return int(self.ctx.L.mtb_tax_original_id(self.h, C.c_int32(int(taxid))))
 
     def slice(self, lo_value, hi_value, is_last):
         """device view of the value range [lo, hi) (mtb_index_slice); close it before the parent"""

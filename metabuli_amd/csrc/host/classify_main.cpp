@@ -11,10 +11,15 @@
  * thread formats batch k-1 with --threads workers and appends it in order.
  *
  *   mtb_classify [flags] <FASTA/Q> [<FASTA/Q mate>] <DBDIR> <OUTDIR> <JobID>
- *   flags: --seq-mode 1|2|3  --min-score F  --min-sp-score F  --min-cons-cnt N
- *          --min-cons-cnt-euk N  --tie-ratio F  --taxonomy-path DIR
- *          --syncmer 0|1  --smer-len N  --kmer-format 1|2  --accession-level 0|1|2
- *          --max-reads N (batch size)  --device N  --threads N (host parsing / formatting)  --lineage 0|1
+ *   flags read on the path: --seq-mode 1|2|3  --min-score F  --min-sp-score F  --min-cons-cnt N  --min-cons-cnt-euk N
+ *          --tie-ratio F  --taxonomy-path DIR  --syncmer 0|1  --smer-len N  --kmer-format 1|2  --accession-level 0|1|2
+ *          --lineage 0|1  --threads N (host parsing / formatting)
+ *   accepted for command-line compatibility, no effect here (one warning each): --max-ram (batches are bounded by HBM inside
+ *          the library; the host batch is --max-reads), --match-per-kmer (exact-size retry), --hamming-margin, --mask,
+ *          --mask-prob, --validate-input, --validate-db, --print-log, -v   (LocalParameters.cpp:631-654)
+ *   own flags: --max-reads N (host batch)  --device N | --devices 0,1,... (one engine per GPU: every host batch is cut into
+ *          contiguous read ranges, one per device, classified concurrently, results concatenated in input order and
+ *          the per-taxon counts summed -- reads are independent, Classifier.cpp:187-203)
  */
 #include <cstdio>
 #include <cstring>
@@ -88,13 +93,13 @@ void format_reads(const Job &j, size_t lo, size_t hi, const mtb_index *ix, bool 
         const mtb_result &r = j.res[i];
         out += r.is_classified ? '1' : '0'; out += '\t';
         out.append(j.r1.names.data() + j.r1.name_offs[i], j.r1.names.data() + j.r1.name_offs[i + 1]); out += '\t';
-        int n = snprintf(num, sizeof(num), "%d\t%d\t%g\t", r.classification, r.query_length + r.query_length2, (double)r.score);
+        int n = snprintf(num, sizeof(num), "%d\t%d\t%g\t", mtb_tax_original_id(ix, r.classification), r.query_length + r.query_length2, (double)r.score);
         out.append(num, (size_t)n);
         if (r.is_classified) {
             out += mtb_tax_rank(ix, r.classification); out += '\t';
             if (lineage) { append_lineage(ix, r.classification, out); out += '\t'; }
             for (uint32_t k = 0; k < r.n_taxcnt; k++) {
-                n = snprintf(num, sizeof(num), "%d:%u ", j.tt[r.taxcnt_off + k], j.tc[r.taxcnt_off + k]);
+                n = snprintf(num, sizeof(num), "%d:%u ", mtb_tax_original_id(ix, j.tt[r.taxcnt_off + k]), j.tc[r.taxcnt_off + k]);
                 out.append(num, (size_t)n);
             }
             out += '\n';
@@ -102,46 +107,85 @@ void format_reads(const Job &j, size_t lo, size_t hi, const mtb_index *ix, bool 
     }
 }
 
-/* Reporter::writeReportFile / writeReport (Reporter.cpp:115-193); clade counts as in
- * NcbiTaxonomy::getCladeCounts (every ancestor of a counted taxon accumulates it).
- * Children are ordered by clade count (descending), ties by taxid: the reference's
- * order among equal counts is unspecified (unstable sort). */
-void write_report(FILE *fp, const std::map<int, unsigned> &taxCounts, const mtb_index *ix, unsigned long total) {
+/* Reporter::writeReportFile / writeReport / kronaReport (Reporter.cpp:86-193): clade counts as NcbiTaxonomy::getCladeCounts
+ * builds them (every counted taxon adds its count to itself and to all of its ancestors; a node's children are the
+ * taxonomy's children), the report as a depth-first walk with the children ordered by clade count, descending -- the
+ * reference's order among equal counts is unspecified (unstable sort); here ties go by taxon id.
+ * Printed ids are the original ones (getOriginalTaxID, Reporter.cpp:181). */
+struct CladeTable {
     std::unordered_map<int, unsigned> clade, own;
-    std::unordered_map<int, std::vector<int>> children;
-    for (const auto &kv : taxCounts) {
-        own[kv.first] = kv.second;
-        if (kv.first == 0) { clade[0] += kv.second; continue; }
-        int t = kv.first;
-        for (int guard = 0; guard < 1000; guard++) {
-            bool fresh = clade.find(t) == clade.end();
-            clade[t] += kv.second;
-            int p = mtb_tax_parent(ix, t);
-            if (p < 0 || p == t) break;
-            if (fresh) children[p].push_back(t);
-            t = p;
+    const mtb_index *ix;
+    CladeTable(const std::map<int, unsigned> &taxCounts, const mtb_index *ix_) : ix(ix_) {
+        for (const auto &kv : taxCounts) {
+            own[kv.first] = kv.second;
+            clade[kv.first] += kv.second;
+            if (kv.first == 0) continue;
+            int t = kv.first;
+            for (int guard = 0; guard < 1000; guard++) {
+                int p = mtb_tax_parent(ix, t);
+                if (p < 0 || p == t) break;
+                clade[p] += kv.second;
+                t = p;
+            }
         }
     }
+    unsigned clade_of(int t) const { auto it = clade.find(t); return it == clade.end() ? 0u : it->second; }
+    unsigned own_of(int t) const { auto it = own.find(t); return it == own.end() ? 0u : it->second; }
+    std::vector<int> children(int t) const {                 /* counted children, by clade count */
+        std::vector<int> ch;
+        const int n = mtb_tax_num_children(ix, t);
+        for (int k = 0; k < n; k++) { int c = mtb_tax_child(ix, t, k); if (clade_of(c)) ch.push_back(c); }
+        std::sort(ch.begin(), ch.end(), [&](int a, int b) { unsigned ca = clade_of(a), cb = clade_of(b); return ca != cb ? ca > cb : a < b; });
+        return ch;
+    }
+};
+
+void write_report(FILE *fp, const CladeTable &ct, unsigned long total) {
     fprintf(fp, "#clade_proportion\tclade_count\ttaxon_count\trank\ttaxID\tname\n");
-    if (clade.count(0) && clade[0] > 0)
-        fprintf(fp, "%.4f\t%i\t%i\tno rank\t0\tunclassified\n", 100 * clade[0] / double(total), (int)clade[0], (int)own[0]);
+    if (ct.clade_of(0) > 0)
+        fprintf(fp, "%.4f\t%i\t%i\tno rank\t0\tunclassified\n", 100 * ct.clade_of(0) / double(total), (int)ct.clade_of(0), (int)ct.own_of(0));
     std::function<void(int, int)> rec = [&](int t, int depth) {
-        auto it = clade.find(t);
-        if (it == clade.end() || it->second == 0) return;
-        fprintf(fp, "%.4f\t%i\t%i\t%s\t%i\t%s%s\n", 100 * it->second / double(total), (int)it->second, (int)(own.count(t) ? own[t] : 0),
-                mtb_tax_rank(ix, t), t, std::string(2 * (size_t)depth, ' ').c_str(), mtb_tax_name(ix, t));
-        std::vector<int> ch = children[t];
-        std::sort(ch.begin(), ch.end(), [&](int a, int b) { return clade[a] != clade[b] ? clade[a] > clade[b] : a < b; });
-        for (int c : ch) rec(c, depth + 1);
+        const unsigned c = ct.clade_of(t);
+        if (c == 0) return;
+        fprintf(fp, "%.4f\t%i\t%i\t%s\t%i\t%s%s\n", 100 * c / double(total), (int)c, (int)ct.own_of(t), mtb_tax_rank(ct.ix, t),
+                mtb_tax_original_id(ct.ix, t), std::string(2 * (size_t)depth, ' ').c_str(), mtb_tax_name(ct.ix, t));
+        for (int ch : ct.children(t)) rec(ch, depth + 1);
     };
     rec(1, 0);
+}
+
+std::string escape_attribute(const char *s) {
+    std::string o;
+    for (; *s; s++) switch (*s) {
+        case '&': o += "&amp;"; break; case '"': o += "&quot;"; break; case '\'': o += "&apos;"; break;
+        case '<': o += "&lt;"; break; case '>': o += "&gt;"; break; default: o += *s;
+    }
+    return o;
+}
+/* <JobID>_krona.html (Reporter.cpp:143-158).  The <node> tree is kronaReport's (:86-113).  The HTML prelude of the reference
+ * is MMseqs2's generated resource krona_prelude_html, absent from the snapshot: a minimal prelude with the same
+ * <krona> data island stands in, so the file opens in KronaTools' importer / any XML reader but not as the interactive chart. */
+void write_krona(FILE *fp, const CladeTable &ct, unsigned long total) {
+    fputs("<!DOCTYPE html><html><head><meta charset=\"utf-8\"/><title>Krona</title></head><body><div style=\"display:none\">"
+          "<krona collapse=\"false\" key=\"true\"><attributes magnitude=\"magnitude\"><attribute display=\"Count\">magnitude</attribute></attributes>", fp);
+    fprintf(fp, "<node name=\"all\"><magnitude><val>%zu</val></magnitude>", (size_t)total);
+    if (ct.clade_of(0) > 0) fprintf(fp, "<node name=\"unclassified\"><magnitude><val>%d</val></magnitude></node>", (int)ct.clade_of(0));
+    std::function<void(int)> rec = [&](int t) {
+        const unsigned c = ct.clade_of(t);
+        if (c == 0) return;
+        fprintf(fp, "<node name=\"%s\"><magnitude><val>%d</val></magnitude>", escape_attribute(mtb_tax_name(ct.ix, t)).c_str(), (int)c);
+        for (int ch : ct.children(t)) rec(ch);
+        fputs("</node>", fp);
+    };
+    rec(1);
+    fputs("</node></krona></div></body></html>", fp);
 }
 
 } // namespace
 
 int main(int argc, char **argv) {
     mtb_params par; mtb_default_params(&par);
-    std::string taxdir; int device = 0; size_t max_reads = 2000000;
+    std::string taxdir; std::vector<int> devices(1, 0); size_t max_reads = 2000000;
     int threads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     bool lineage = false;
     std::vector<std::string> pos;
@@ -160,10 +204,17 @@ int main(int argc, char **argv) {
         else if (a == "--syncmer") par.syncmer = atoi(val().c_str());
         else if (a == "--smer-len") par.smer_len = atoi(val().c_str());
         else if (a == "--max-reads") max_reads = (size_t)atoll(val().c_str());
-        else if (a == "--device") device = atoi(val().c_str());
+        else if (a == "--device") { devices.assign(1, atoi(val().c_str())); }
+        else if (a == "--devices") { devices.clear(); std::stringstream ss(val()); std::string tok; while (std::getline(ss, tok, ',')) if (!tok.empty()) devices.push_back(atoi(tok.c_str())); }
+        else if (a == "--reduced-aa") { if (atoi(val().c_str()) != 0) { fprintf(stderr, "mtb_classify: --reduced-aa 1 is not implemented\n"); return 1; } }
+        else if (a == "--max-ram" || a == "--match-per-kmer" || a == "--hamming-margin" || a == "--mask" || a == "--mask-prob" ||
+                 a == "--validate-input" || a == "--validate-db" || a == "--print-log" || a == "-v" || a == "--max-gap") {
+            std::string v = val();
+            fprintf(stderr, "mtb_classify: %s %s accepted for compatibility with `metabuli classify`, it has no effect here\n", a.c_str(), v.c_str());
+        }
         else if (a == "--threads") threads = std::max(1, atoi(val().c_str()));
         else if (a == "--lineage") lineage = atoi(val().c_str()) != 0;
-        else if (a.rfind("--", 0) == 0) { fprintf(stderr, "unsupported flag %s\n", a.c_str()); return 1; }
+        else if (a.rfind("--", 0) == 0) { fprintf(stderr, "mtb_classify: unknown flag %s\n", a.c_str()); return 1; }
         else pos.push_back(a);
     }
     size_t need = par.seq_mode == 2 ? 5 : 4;
@@ -176,7 +227,15 @@ int main(int argc, char **argv) {
     try {
         auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         const double t_start = now();
-        mtb::Engine eng(device, dbdir, taxdir, par);          /* db.parameters overrides the flags (common.cpp:88-133) */
+        if (devices.empty()) throw std::runtime_error("--devices: empty list");
+        /* one engine (context + resident copy of the index) per GPU; db.parameters overrides the flags (common.cpp:88-133) */
+        std::vector<std::unique_ptr<mtb::Engine>> engs;
+        for (size_t d = 0; d < devices.size(); d++) {
+            mtb_params pd = par;
+            engs.emplace_back(new mtb::Engine(devices[d], dbdir, taxdir, d == 0 ? par : pd));
+        }
+        mtb::Engine &eng = *engs[0];                          /* taxonomy services for formatting */
+        const size_t ND = engs.size();
         const double t_open = now() - t_start;
         double t_parse = 0, t_gpu = 0, t_write = 0;           /* busy time of the three stages */
         FILE *out = fopen((outdir + "/" + job + "_classifications.tsv").c_str(), "w");
@@ -225,8 +284,10 @@ int main(int argc, char **argv) {
                 std::cout << "The number of processed sequences: " << total << std::endl;
             }
         });
-        /* stage 2: the GPU */
+        /* stage 2: the GPUs.  A host batch is cut into ND contiguous read ranges; range d runs on engine d from its own host
+         * thread (one thread per mtb_ctx); rows land at their places in j->res, the taxcnt lists are appended range by range */
         std::string gpu_err;
+        struct Range { std::vector<uint64_t> offs, offs2; std::vector<int32_t> tt; std::vector<uint32_t> tc; uint64_t ntc = 0; std::string err; };
         for (;;) {
             std::unique_ptr<Job> j = parsed.get();
             if (j->last) { scored.put(std::move(j)); break; }
@@ -234,14 +295,46 @@ int main(int argc, char **argv) {
             const double t0 = now();
             const size_t n = j->r1.size();
             j->res.resize(n);
-            size_t cap = 64 * n + 1024; uint64_t ntc = 0;
-            for (;;) {
-                j->tt.resize(cap); j->tc.resize(cap);
-                mtb_status s = mtb_classify_batch(eng.ctx, eng.index, &par, j->r1.bases.data(), j->r1.offs.data(), paired ? j->r2.bases.data() : nullptr,
-                                                  paired ? j->r2.offs.data() : nullptr, n, j->res.data(), j->tt.data(), j->tc.data(), cap, &ntc);
-                if (s == MTB_ERR_CAPACITY && ntc > cap) { cap = ntc; continue; }
-                if (s != MTB_OK) gpu_err = mtb_last_error();
-                break;
+            std::vector<Range> rg(ND);
+            auto run = [&](size_t d) {
+                Range &R = rg[d];
+                const size_t lo = n * d / ND, hi = n * (d + 1) / ND, m = hi - lo;
+                if (m == 0) return;
+                const uint64_t b0 = j->r1.offs[lo];
+                R.offs.resize(m + 1);
+                for (size_t i = 0; i <= m; i++) R.offs[i] = j->r1.offs[lo + i] - b0;
+                uint64_t c0 = 0;
+                if (paired) { c0 = j->r2.offs[lo]; R.offs2.resize(m + 1); for (size_t i = 0; i <= m; i++) R.offs2[i] = j->r2.offs[lo + i] - c0; }
+                mtb_params pd = par;
+                size_t cap = 64 * m + 1024;
+                for (;;) {
+                    R.tt.resize(cap); R.tc.resize(cap);
+                    mtb_status st = mtb_classify_batch(engs[d]->ctx, engs[d]->index, &pd, j->r1.bases.data() + b0, R.offs.data(),
+                                                       paired ? j->r2.bases.data() + c0 : nullptr, paired ? R.offs2.data() : nullptr, m,
+                                                       j->res.data() + lo, R.tt.data(), R.tc.data(), cap, &R.ntc);
+                    if (st == MTB_ERR_CAPACITY && R.ntc > cap) { cap = R.ntc; continue; }
+                    if (st != MTB_OK) R.err = mtb_last_error();
+                    break;
+                }
+            };
+            if (ND == 1) run(0);
+            else { std::vector<std::thread> th; for (size_t d = 0; d < ND; d++) th.emplace_back(run, d); for (auto &x : th) x.join(); }
+            uint64_t tot_tc = 0;
+            for (size_t d = 0; d < ND; d++) { if (!rg[d].err.empty() && gpu_err.empty()) gpu_err = rg[d].err; tot_tc += rg[d].ntc; }
+            if (gpu_err.empty()) {
+                if (tot_tc >= (1ull << 32)) gpu_err = "taxcnt lists of one host batch exceed 2^32 entries; lower --max-reads";
+                else if (ND == 1) { j->tt.swap(rg[0].tt); j->tc.swap(rg[0].tc); }
+                else {
+                    j->tt.resize(tot_tc); j->tc.resize(tot_tc);
+                    uint64_t base = 0;
+                    for (size_t d = 0; d < ND; d++) {
+                        const size_t lo = n * d / ND, hi = n * (d + 1) / ND;
+                        std::copy(rg[d].tt.begin(), rg[d].tt.begin() + (ptrdiff_t)rg[d].ntc, j->tt.begin() + (ptrdiff_t)base);
+                        std::copy(rg[d].tc.begin(), rg[d].tc.begin() + (ptrdiff_t)rg[d].ntc, j->tc.begin() + (ptrdiff_t)base);
+                        for (size_t i = lo; i < hi; i++) j->res[i].taxcnt_off += (uint32_t)base;
+                        base += rg[d].ntc;
+                    }
+                }
             }
             t_gpu += now() - t0;
             if (gpu_err.empty()) scored.put(std::move(j));
@@ -253,12 +346,17 @@ int main(int argc, char **argv) {
         if (!writer_err.empty()) throw std::runtime_error(writer_err);
         std::map<int, unsigned> counts;
         for (size_t t = 0; t < tax_counts.size(); t++) if (tax_counts[t]) counts[(int)t] = (unsigned)tax_counts[t];
+        CladeTable ct(counts, eng.index);
         FILE *fp = fopen((outdir + "/" + job + "_report.tsv").c_str(), "w");
         if (!fp) throw std::runtime_error("cannot write the report");
-        write_report(fp, counts, eng.index, total);
+        write_report(fp, ct, total);
         fclose(fp);
-        fprintf(stderr, "mtb_classify: %lu reads in %.2f s (index open %.2f s; stage busy time: parse %.2f s, GPU incl. PCIe %.2f s, format+write %.2f s; %d host threads)\n",
-                total, now() - t_start, t_open, t_parse, t_gpu, t_write, threads);
+        fp = fopen((outdir + "/" + job + "_krona.html").c_str(), "w");
+        if (!fp) throw std::runtime_error("cannot write the krona file");
+        write_krona(fp, ct, total);
+        fclose(fp);
+        fprintf(stderr, "mtb_classify: %lu reads in %.2f s on %zu GPU(s) (index open %.2f s; stage busy time: parse %.2f s, GPU incl. PCIe %.2f s, format+write %.2f s; %d host threads)\n",
+                total, now() - t_start, ND, t_open, t_parse, t_gpu, t_write, threads);
     } catch (const std::exception &e) {
         fprintf(stderr, "mtb_classify: %s\n", e.what());
         return 1;

@@ -598,12 +598,12 @@ static mtb_status open_impl(mtb_ctx *c, const char *dbdir, const char *taxonomy_
     mtbhost::load_db_parameters(d, params, &reduced_aa);
     if (reduced_aa) return fail(MTB_ERR_UNSUPPORTED, "database was built with the reduced amino-acid alphabet (Reduced_alphabet 1 in db.parameters); not implemented");
     if (params->kmer_format != 1 && params->kmer_format != 2) return fail(MTB_ERR_UNSUPPORTED, "database uses a k-mer format other than 1 or 2");
+    /* loadTaxonomy (common.cpp:50-86): DBDIR/taxonomyDB wins when it is there and readable; else --taxonomy-path; else
+     * DBDIR/taxonomy/.  (A taxonomyDB with an outdated serialization version makes the reference fall back to DBDIR/taxonomy.) */
     std::string taxdir = taxonomy_dir && *taxonomy_dir ? std::string(taxonomy_dir) : d + "/taxonomy";
-    if (!mtbhost::file_exists(taxdir + "/nodes.dmp")) {
-        if (mtbhost::file_exists(d + "/taxonomyDB"))
-            return fail(MTB_ERR_UNSUPPORTED, "binary taxonomyDB is not supported yet; pass a taxonomy directory with names/nodes/merged.dmp");
-        return fail(MTB_ERR_IO, "taxonomy dump files not found in " + taxdir);
-    }
+    const bool have_bin = mtbhost::file_exists(d + "/taxonomyDB");
+    if (!have_bin && !mtbhost::file_exists(taxdir + "/nodes.dmp"))
+        return fail(MTB_ERR_IO, "no taxonomy: neither " + d + "/taxonomyDB nor dump files in " + taxdir);
     PartPlan plan;
     STCHK(plan_parts(d, n_parts, &plan));
     const PartPlan::P &P = plan.parts[part];
@@ -611,7 +611,16 @@ static mtb_status open_impl(mtb_ctx *c, const char *dbdir, const char *taxonomy_
     ix->ctx = c; ix->params = *params; ix->own = true;
     for (uint32_t q = part + 1; q < n_parts; q++) if (!plan.parts[q].empty) ix->match_last = true;
     std::string err;
-    if (!mtbhost::load_taxonomy(taxdir, &ix->tax, &err)) { delete ix; return fail(MTB_ERR_IO, err); }
+    bool tax_ok = false;
+    if (have_bin) {
+        tax_ok = mtbhost::load_taxonomy_db(d + "/taxonomyDB", &ix->tax, &err);
+        if (!tax_ok) {
+            const std::string fb = d + "/taxonomy";
+            if (!mtbhost::file_exists(fb + "/nodes.dmp")) { delete ix; return fail(MTB_ERR_IO, err); }
+            taxdir = fb; err.clear();
+        }
+    }
+    if (!tax_ok && !mtbhost::load_taxonomy(taxdir, &ix->tax, &err)) { delete ix; return fail(MTB_ERR_IO, err); }
     std::vector<int32_t> ids;
     if (!mtbhost::read_taxid_list(d + "/taxID_list", &ids)) { delete ix; return fail(MTB_ERR_IO, "cannot open " + d + "/taxID_list"); }
     mtbhost::build_tax2species(&ix->tax, ids.data(), ids.size());
@@ -787,6 +796,13 @@ int32_t mtb_tax_lca(const mtb_index *ix, int32_t a, int32_t b) { return ix->tax.
 int32_t mtb_tax_species(const mtb_index *ix, int32_t t) { return (t >= 0 && t <= ix->tax.max_id) ? ix->tax.tax2species[(size_t)t] : 0; }
 int32_t mtb_tax_parent(const mtb_index *ix, int32_t t) { int32_t c = ix->tax.cn(t); return c < 0 ? -1 : ix->tax.parent[(size_t)c]; }
 int32_t mtb_tax_max_id(const mtb_index *ix) { return ix->tax.max_id; }
+int32_t mtb_tax_original_id(const mtb_index *ix, int32_t t) { return (t >= 0 && t <= ix->tax.max_id) ? ix->tax.orig[(size_t)t] : t; }
+int32_t mtb_tax_num_children(const mtb_index *ix, int32_t t) { int32_t c = ix->tax.cn(t); return c < 0 ? 0 : (int32_t)ix->tax.children_of(c).size(); }
+int32_t mtb_tax_child(const mtb_index *ix, int32_t t, int32_t k) {
+    int32_t c = ix->tax.cn(t); if (c < 0) return -1;
+    const std::vector<int32_t> &v = ix->tax.children_of(c);
+    return (k >= 0 && (size_t)k < v.size()) ? v[(size_t)k] : -1;
+}
 const char *mtb_tax_rank(const mtb_index *ix, int32_t t) { int32_t c = ix->tax.cn(t); return c < 0 ? "" : ix->tax.rank[(size_t)c].c_str(); }
 const char *mtb_tax_name(const mtb_index *ix, int32_t t) { int32_t c = ix->tax.cn(t); return c < 0 ? "" : ix->tax.name[(size_t)c].c_str(); }
 

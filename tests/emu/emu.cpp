@@ -276,6 +276,21 @@ int emu_load_taxonomy(const char *dir, const int32_t *taxid_list, size_t n_ids, 
     memcpy(acc_leaf, t.acc_leaf.data(), n); memcpy(under_euk, t.under_euk.data(), n); memcpy(sp_parent, t.sp_parent.data(), n * 4); memcpy(tax2species, t.tax2species.data(), n * 4);
     return 0;
 }
+/* host_db.h::load_taxonomy_db: the same arrays from a binary taxonomyDB file, plus the internal -> original id map */
+int emu_load_taxonomy_db(const char *path, const int32_t *taxid_list, size_t n_ids, int32_t cap, int32_t *max_id, int32_t *canon, int32_t *parent,
+                         int32_t *depth, uint8_t *under_euk, int32_t *sp_parent, int32_t *tax2species, uint8_t *acc_leaf, int32_t *orig,
+                         int32_t *eukaryota, char *err_out, size_t err_cap) {
+    mtbhost::Taxonomy t; std::string err;
+    if (!mtbhost::load_taxonomy_db(path, &t, &err)) { if (err_out && err_cap) { strncpy(err_out, err.c_str(), err_cap - 1); err_out[err_cap - 1] = 0; } return 1; }
+    mtbhost::build_tax2species(&t, taxid_list, n_ids);
+    *max_id = t.max_id; *eukaryota = t.eukaryota;
+    if (t.max_id + 1 > cap) return 2;
+    size_t n = (size_t)t.max_id + 1;
+    memcpy(canon, t.canon.data(), n * 4); memcpy(parent, t.parent.data(), n * 4); memcpy(depth, t.depth.data(), n * 4);
+    memcpy(acc_leaf, t.acc_leaf.data(), n); memcpy(under_euk, t.under_euk.data(), n); memcpy(sp_parent, t.sp_parent.data(), n * 4); memcpy(tax2species, t.tax2species.data(), n * 4);
+    memcpy(orig, t.orig.data(), n * 4);
+    return 0;
+}
 int emu_load_db_parameters(const char *dir, mtb_params *p) { return mtbhost::load_db_parameters(dir, p) ? 0 : 1; }
 
 } // extern "C"

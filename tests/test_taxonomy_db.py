@@ -1,0 +1,106 @@
+"""Binary `taxonomyDB`: the reader libmtb uses at index-open time (host_db.h::load_taxonomy_db, built for
+the host in tests/emu) against the dump-file loader on the same taxonomy, through fixtures written by tests/taxdb_writer.py
+(TaxonomyWrapper::serialize restated).  Layout of the MMseqs2 parts: restated from published sources, unpinned."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import taxdb_writer as tw
+from helpers import _ptr
+
+
+def _world(seed=5):
+    from metabuli_amd import synth
+    w = synth.make_world(seed=seed, n_genera=3, species_per_genus=2, strains_per_species=2, genome_len=2000)
+    return w
+
+
+def _orig_id(t):
+    return 1 if t == 1 else 1000 + 7 * t          # original ids far from the dense internal ones; the root stays 1
+
+
+def _write_dmp(d, w, merged=()):
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, "nodes.dmp"), "w") as f:
+        for t in sorted(w.tax.parent):
+            f.write(f"{_orig_id(t)}\t|\t{_orig_id(w.tax.parent[t])}\t|\t{w.tax.rank[t]}\t|\t\t|\n")
+    with open(os.path.join(d, "names.dmp"), "w") as f:
+        for t in sorted(w.tax.parent):
+            f.write(f"{_orig_id(t)}\t|\t{w.tax.name[t]}\t|\t\t|\tscientific name\t|\n")
+    with open(os.path.join(d, "merged.dmp"), "w") as f:
+        for a, b in merged:
+            f.write(f"{a}\t|\t{b}\t|\n")
+
+
+def _lines(w):
+    return [(_orig_id(t), _orig_id(w.tax.parent[t]), w.tax.rank[t]) for t in sorted(w.tax.parent)], {_orig_id(t): w.tax.name[t] for t in w.tax.parent}
+
+
+def _load_db(emu, path, ids):
+    cap = 1 << 20
+    a = [np.zeros(cap, np.int32) for _ in range(3)]
+    under = np.zeros(cap, np.uint8); spp = np.zeros(cap, np.int32); t2s = np.zeros(cap, np.int32); acc = np.zeros(cap, np.uint8); orig = np.zeros(cap, np.int32)
+    mx = C.c_int32(); euk = C.c_int32()
+    err = C.create_string_buffer(512)
+    ids = np.ascontiguousarray(ids, np.int32)
+    rc = emu.lib.emu_load_taxonomy_db(path.encode(), _ptr(ids), C.c_size_t(len(ids)), C.c_int32(cap), C.byref(mx), _ptr(a[0]), _ptr(a[1]), _ptr(a[2]),
+                                      _ptr(under), _ptr(spp), _ptr(t2s), _ptr(acc), _ptr(orig), C.byref(euk), err, C.c_size_t(512))
+    if rc:
+        return rc, err.value.decode()
+    n = mx.value + 1
+    return 0, dict(canon=a[0][:n].copy(), parent=a[1][:n].copy(), depth=a[2][:n].copy(), under=under[:n].copy(), spp=spp[:n].copy(), t2s=t2s[:n].copy(),
+                   acc=acc[:n].copy(), orig=orig[:n].copy(), euk=euk.value)
+
+
+@pytest.mark.parametrize("k_extra", [0, 1])
+def test_taxonomy_db_equals_dump_files(emu, tmp_path, k_extra):
+    w = _world()
+    merged = [(900001, _orig_id(5)), (900002, _orig_id(9))]
+    d = str(tmp_path / "tax")
+    _write_dmp(d, w, merged)
+    lines, names = _lines(w)
+    path = str(tmp_path / "taxonomyDB")
+    o2i = tw.write_taxonomy_db(path, lines, names, merged, use_internal=True, k_extra=k_extra)
+    strains = [t for t, r in w.tax.rank.items() if r == "no rank" and t > 3]
+    ids_orig = np.array([_orig_id(t) for t in strains], np.int32)
+    (canon, parent, depth, under, spp, acc), t2s = emu.load_taxonomy(d, ids_orig)
+    rc, db = _load_db(emu, path, np.array([o2i[int(o)] for o in ids_orig], np.int32))
+    assert rc == 0, db
+    assert db["orig"][0] == 0 and db["euk"] == o2i[_orig_id(3)]
+    assert len(db["canon"]) == len(o2i) + 1                      # internal ids are dense: 1..maxTaxID
+    for o, i in o2i.items():
+        assert db["orig"][i] == o
+        co = canon[o]
+        if co < 0:
+            assert db["canon"][i] < 0
+            continue
+        ci = db["canon"][i]
+        assert db["orig"][ci] == co                                # merged ids resolve to the same node
+        if co != o:
+            continue
+        assert db["orig"][db["parent"][i]] == parent[o] and db["depth"][i] == depth[o] and db["under"][i] == under[o] and db["acc"][i] == acc[o]
+        assert db["orig"][db["spp"][i]] == spp[o] if spp[o] else db["spp"][i] == 0
+        assert (db["orig"][db["t2s"][i]] if db["t2s"][i] else 0) == t2s[o]
+    assert db["canon"][o2i[900001]] == o2i[_orig_id(5)]
+
+
+def test_taxonomy_db_without_internal_ids_and_bad_version(emu, tmp_path):
+    w = _world(7)
+    lines, names = _lines(w)
+    path = str(tmp_path / "plain")
+    tw.write_taxonomy_db(path, lines, names, use_internal=False)
+    rc, db = _load_db(emu, path, np.zeros(0, np.int32))
+    assert rc == 0, db
+    present = np.flatnonzero(db["canon"] >= 0)
+    assert set(present.tolist()) == {o for o, _, _ in lines}
+    assert (db["orig"] == np.arange(len(db["orig"]))).all()      # getOriginalTaxID is the identity without internal ids
+    bad = str(tmp_path / "old")
+    tw.write_taxonomy_db(bad, lines, names, version=1)
+    rc, msg = _load_db(emu, bad, np.zeros(0, np.int32))
+    assert rc == 1 and "version" in msg
+    trunc = str(tmp_path / "trunc")
+    open(trunc, "wb").write(open(path, "rb").read()[:-7])
+    rc, msg = _load_db(emu, trunc, np.zeros(0, np.int32))
+    assert rc == 1
