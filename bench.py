@@ -360,7 +360,7 @@ def main():
     # algorithmic bytes of one whole step per kernel (SURVEY.md 8(d) per-stage split);
     # a step launches every kernel once per stream (and per radix pass): bytes per launch = total / launches
     alg_step = {"extract_count": L, "extract_emit": L + 16 * Kq, "radix_hist": 16 * Kq, "radix_scatter": 32 * Kq,
-                "join": 16 * Kq + 24 * Mm, "regroup": 48 * Mm, "score": 24 * Mm + 16 * N}
+                "join": 16 * Kq + 24 * Mm, "regroup": 48 * Mm, "score": 24 * Mm + 16 * N, "score_fast": 24 * Mm + 16 * N}
     alg = {k: v / max(1, kern[k]["launches"]) for k, v in alg_step.items()}
     alg["join"] += 12 * ps.n_targets          # the 12*T_span term is paid by every launch (one per HBM-budgeted sub-batch): each spans the whole index
     dom = max((k for k in alg), key=lambda k: kern[k]["ms"])
@@ -412,7 +412,7 @@ def main():
                                reads_per_gpu=args.reads, read_len=args.read_len, targets=int(T), seq_mode=args.seq_mode,
                                gbp_per_s=value * args.read_len * (2 if args.seq_mode == 2 else 1) / 1e3, query_metamers=int(st.n_kmers), matches=int(st.n_matches),
                                classified_fraction=frac_cls, parallelism=f"reads sharded x{world_size}, index replicated", streams_per_gpu=args.streams,
-                               sub_batches_per_step=ctx.last_sub_batches),
+                               sub_batches_per_step=ctx.last_sub_batches, reads_scored_by_generic_kernel=int(ps.n_generic_reads)),
                    stage_ms=dict(extract=st.ms_extract, sort=st.ms_sort, join=st.ms_join, regroup=st.ms_regroup,
                                  segsort=st.ms_segsort, score=st.ms_score, total=st.ms_total),
                    kernel_ms=kern, roofline=roofline, cpu_baseline=cpu, parity_sample=parity)

@@ -87,8 +87,8 @@ typedef struct mtb_index mtb_index;
 /* kernel ids for mtb_batch_stats.ms_kernel / n_launch */
 enum {
     MTB_K_EXTRACT_COUNT = 0, MTB_K_EXTRACT_EMIT = 1, MTB_K_RADIX_HIST = 2, MTB_K_RADIX_SCATTER = 3,
-    MTB_K_JOIN = 4, MTB_K_REGROUP = 5, MTB_K_SEGSORT = 6, MTB_K_SCORE = 7, MTB_K_SCAN = 8,
-    MTB_NUM_KERNELS = 9
+    MTB_K_JOIN = 4, MTB_K_REGROUP = 5, MTB_K_SEGSORT = 6, MTB_K_SCORE = 7, MTB_K_SCAN = 8, MTB_K_SCORE_FAST = 9,
+    MTB_NUM_KERNELS = 10
 };
 
 /* Per-stage device time of the last mtb_classify_batch* call (HIP events on
@@ -101,6 +101,7 @@ typedef struct {
      * immediately before and after every launch of that kernel.            */
     float    ms_kernel[MTB_NUM_KERNELS];
     uint32_t n_launch[MTB_NUM_KERNELS];
+    uint64_t n_generic_reads;   /* reads the register-resident scorer (k_score_fast) handed to the generic k_score */
 } mtb_batch_stats;
 
 const char *mtb_version(void);

@@ -65,6 +65,14 @@ __global__ __launch_bounds__(64) void k_taxcnt_bound(const uint64_t *__restrict_
     bound[r] = (uint32_t)(n < nb ? n : nb);
 }
 
+/* number of set bytes (reads k_score_fast left to the generic kernel; statistics) */
+__global__ __launch_bounds__(256) void k_count_flags(const uint8_t *__restrict__ f, uint64_t n, unsigned long long *__restrict__ out) {
+    uint32_t c = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) c += f[i] ? 1u : 0u;
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, (unsigned long long)c);
+}
+
 /* list the reads whose segment does not fit the LDS staging of k_score; they
  * are sorted in HBM by k_segsort_large and scored out of per-workgroup slabs */
 __global__ __launch_bounds__(256) void k_list_large(const uint64_t *__restrict__ seg_start, uint64_t n_reads, uint32_t threshold,
@@ -658,7 +666,8 @@ __global__ __launch_bounds__(64, (CAP > MTB_SCORE_LDS ? 2 : MTB_SCORE_MINWAVES))
                                                const uint32_t *__restrict__ list, const uint32_t *__restrict__ n_list,
                                                const uint32_t *__restrict__ cursor, uint32_t stride, int seg_by_list,
                                                uint32_t direct, uint32_t epoch, uint32_t *__restrict__ big_list, uint32_t *__restrict__ n_big_out,
-                                               uint32_t *__restrict__ cnt_out, unsigned long long *__restrict__ work) {
+                                               uint32_t *__restrict__ cnt_out, unsigned long long *__restrict__ work,
+                                               const uint8_t *__restrict__ only_flagged) {
     __shared__ __attribute__((aligned(16))) uint8_t s_ws[MTB_SCORE_WS_BYTES_(CAP)];
     __shared__ uint32_t s_pf[64];                 /* landing zone of the slot prefetch (never read) */
     /* bucket / taxCnt / chain arrays of the decide phase live in the path storage,
@@ -677,7 +686,8 @@ __global__ __launch_bounds__(64, (CAP > MTB_SCORE_LDS ? 2 : MTB_SCORE_MINWAVES))
         unsigned long long kt0_ = __builtin_readcyclecounter();
 #endif
         const uint64_t r = list ? (uint64_t)list[it] : it;
-        if (SLOT && !DYN && !list && it + gridDim.x < n_iter) {
+        if (SLOT && only_flagged && !only_flagged[r]) continue;            /* already scored by k_score_fast */
+        if (SLOT && !DYN && !list && !only_flagged && it + gridDim.x < n_iter) {
             /* slot mode: start pulling the NEXT read's slots towards L2 now (one dword per 128-byte line, delivered
              * straight into a dummy LDS area: no register, nothing waits for it) -- the slot loads are one dependent
              * HBM round trip per read with nothing to overlap otherwise */

@@ -17,6 +17,7 @@
 #include "kernels_join.h"
 #include "kernels_scan.h"
 #include "kernels_score.h"
+#include "kernels_score_fast.h"
 #include "kernels_sort.h"
 #include "mtb_core.h"
 
@@ -56,6 +57,7 @@ struct mtb_ctx {
     uint64_t ws_limit = 0;           /* workspace budget of a batch in bytes; 0 = what hipMemGetInfo reports free (+ what the context holds) */
     double ws_per_base = 0.0;        /* workspace bytes per base measured on the last sub-batch (HBM-budgeted batching) */
     uint32_t last_sub_batches = 0;
+    bool fast_used = false;          /* the last dev_score call launched k_score_fast (its slow-list count sits in d_scal[6]) */
 };
 /* buffers that carry a call's inputs / outputs (host-buffer entry points) are not workspace */
 static bool is_io_buf(const std::string &n) { return n == "bases" || n == "offs" || n == "bases2" || n == "offs2" || n == "results" || n == "tctax" || n == "tccnt"; }
@@ -429,6 +431,7 @@ struct ScoreSrc {
     bool sort = false;                    /* segments arrive unordered: rank sort in the kernel */
     uint32_t max_seg = 0;                 /* largest segment this launch can meet */
     uint32_t grid = 0;                    /* 0 = default */
+    const uint8_t *only_flagged = nullptr; /* slot mode after k_score_fast: score only the reads it flagged */
 };
 
 /* d_results/d_tc_* are device outputs; *n_tc = sum of per-read bounds.  `second` (optional) runs after the launch
@@ -485,7 +488,24 @@ static mtb_status dev_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, uint
         KTimer kt(c, pass == 0 ? MTB_K_SCORE : MTB_K_SEGSORT);      /* the deferred reads' launch is booked with the large-segment path */
 #define MTB_LAUNCH_SCORE(SRT, K, CAPV, DYNV, SLOTV) hipLaunchKernelGGL((k_score<SRT, K, mtb_match, CAPV, DYNV, SLOTV>), dim3(grid), dim3(64), 0, c->stream, S->m, S->seg, n_reads, d_qlen, \
         d_qlen2, tax_view(ix), sp, (const uint64_t *)d_tcoff, d_res, d_tc_tax, d_tc_cnt, tc_cap, d_slabs, slab_bytes, slab_n, slab_nb, (mtb_match *)nullptr,  \
-        tc_base, S->list, S->n_list, S->cursor, S->stride, S->seg_by_list, S->direct, S->epoch, S->big_list, S->n_big, S->cnt_out, d_work)
+        tc_base, S->list, S->n_list, S->cursor, S->stride, S->seg_by_list, S->direct, S->epoch, S->big_list, S->n_big, S->cnt_out, d_work, S->only_flagged)
+        ScoreSrc S_rest;
+        if (S->cursor && pass == 0 && key64 && p->seq_mode != 2 && S->stride <= 192 && !getenv("MTB_NO_FAST_SCORER")) {
+            /* slot mode, single reads: the register-resident scorer takes every read with the common structure (slots already in
+             * compareMatches order, one match per position group) and lists the others for the generic kernel below */
+            uint8_t *d_slow;
+            STCHK(ensure(c, "slowflag", n_reads, &d_slow));
+            HIPCHK(hipMemsetAsync(d_slow, 0, n_reads, c->stream));
+            HIPCHK(hipMemsetAsync(c->d_scal + 6, 0, 8, c->stream));
+#define MTB_LAUNCH_FAST(KV) hipLaunchKernelGGL((k_score_fast<KV>), dim3(grid), dim3(64), 0, c->stream, (const mtb_slot16 *)S->m, n_reads, d_qlen, d_qlen2, tax_view(ix), sp, \
+            (const uint64_t *)d_tcoff, d_res, d_tc_tax, d_tc_cnt, tc_cap, tc_base, S->cursor, S->stride, S->direct, S->epoch, d_slow, S->cnt_out)
+            { KTimer ktf(c, MTB_K_SCORE_FAST); if (S->stride <= 128) MTB_LAUNCH_FAST(2); else MTB_LAUNCH_FAST(3); }
+#undef MTB_LAUNCH_FAST
+            hipLaunchKernelGGL(k_count_flags, dim3(256), dim3(256), 0, c->stream, (const uint8_t *)d_slow, n_reads, (unsigned long long *)(c->d_scal + 6));
+            c->fast_used = true;
+            S_rest = *S; S_rest.only_flagged = d_slow;
+            S = &S_rest;
+        }
         if (S->cursor) {              /* slot mode (always sorts in the kernel); LDS staging capacity chosen by the caller */
 #define MTB_LAUNCH_SLOT(CAPV) do { if (key64) MTB_LAUNCH_SCORE(true, true, CAPV, false, true); else MTB_LAUNCH_SCORE(true, false, CAPV, false, true); } while (0)
             if (S->cap <= 144) MTB_LAUNCH_SLOT(144);
@@ -1109,6 +1129,8 @@ static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, c
     HIPCHK(hipEventElapsedTime(&S.ms_total, c->ev[0], c->ev[6]));
     collect_kernel_times(c);
     S.n_reads = n_reads; S.n_bases = n_bases_total; S.n_kmers = nk_real; S.n_matches = nm; S.n_targets = ix->T;
+    if (c->fast_used) { uint64_t ns = 0; STCHK(d2h(c, &ns, c->d_scal + 6, 8)); S.n_generic_reads = ns & 0xFFFFFFFFull; c->fast_used = false; }
+    else S.n_generic_reads = n_reads;
     return MTB_OK;
 }
 
@@ -1116,6 +1138,7 @@ static void merge_stats(mtb_batch_stats &S, const mtb_batch_stats &L) {
     S.ms_extract += L.ms_extract; S.ms_sort += L.ms_sort; S.ms_join += L.ms_join; S.ms_regroup += L.ms_regroup;
     S.ms_segsort += L.ms_segsort; S.ms_score += L.ms_score;
     S.n_reads += L.n_reads; S.n_bases += L.n_bases; S.n_kmers += L.n_kmers; S.n_matches += L.n_matches; S.n_targets = L.n_targets;
+    S.n_generic_reads += L.n_generic_reads;
     for (int i = 0; i < MTB_NUM_KERNELS; i++) { S.ms_kernel[i] += L.ms_kernel[i]; S.n_launch[i] += L.n_launch[i]; }
 }
 
@@ -1355,6 +1378,17 @@ mtb_status mtb_debug_phase_cycles(mtb_ctx *c, unsigned long long *out4) {
     /* join phases ride in out4[16..23] */
     HIPCHK(hipMemcpyFromSymbol(out4 + MTB_NPHASE, HIP_SYMBOL(mtb_join_cycles), 64));
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(mtb_join_cycles), z, 64));
+    return MTB_OK;
+}
+#endif
+
+#ifdef MTB_FAST_DEBUG
+/* debugging build only: read and reset the k_score_fast exit counters */
+mtb_status mtb_debug_fast_reasons(mtb_ctx *c, unsigned long long *out8) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpyFromSymbol(out8, HIP_SYMBOL(mtb_fast_reasons), 64));
+    unsigned long long z[8] = {0};
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(mtb_fast_reasons), z, 64));
     return MTB_OK;
 }
 #endif

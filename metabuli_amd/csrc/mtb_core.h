@@ -427,15 +427,28 @@ MTB_HD int32_t mtb_lca(const mtb_tax_view *t, int32_t a, int32_t b) {
 /* Match.h:32-44 / Taxonomer.cpp:650-661: score of the `n` codons starting at
  * 2-bit field `first`, walking up (dir=+1) or down (dir=-1) */
 MTB_HD float mtb_codon_score(uint32_t h) { return h == 0 ? 3.0f : 2.0f - 0.5f * (float)h; }
-MTB_HD float mtb_part_score(uint32_t reh, int n, bool left) {
-    float s = 0.0f;
-    for (int c = 0; c < n; c++) s += mtb_codon_score((reh >> (left ? 14 - 2 * c : 2 * c)) & 3u);
-    return s;
+/* the n 2-bit fields a partial score covers, packed into the low 2n bits: the n right-end codons (fields 0..n-1) or the
+ * n left-end ones (fields 7, 6, ...).  0 <= n <= 8. */
+MTB_HD uint32_t mtb_part_fields(uint32_t reh, int n, bool left) {
+    if (n <= 0) return 0u;
+    if (n > 8) n = 8;
+    return left ? ((reh & 0xFFFFu) >> (16 - 2 * n)) : (reh & ((1u << (2 * n)) - 1u));
 }
+/* Sum of the per-codon hamming fields / scores in closed form (popcounts) instead of a loop per codon: a codon scores
+ * 3 if its field is 0, else 2 - 0.5 h, so n codons score 2 n + #zero fields - 0.5 sum(h).  All terms are multiples of
+ * 0.5 far below 2^24: exact in fp32 in any association, i.e. bit-identical to the reference's running sum
+ * (Match.h:32-87, Taxonomer.cpp:650-669). */
 MTB_HD int32_t mtb_part_ham(uint32_t reh, int n, bool left) {
-    int32_t s = 0;
-    for (int c = 0; c < n; c++) s += (int32_t)((reh >> (left ? 14 - 2 * c : 2 * c)) & 3u);
-    return s;
+    const uint32_t f = mtb_part_fields(reh, n, left);
+    return (int32_t)(__builtin_popcount(f & 0x5555u) + 2 * __builtin_popcount(f & 0xAAAAu));
+}
+MTB_HD float mtb_part_score(uint32_t reh, int n, bool left) {
+    if (n <= 0) return 0.0f;
+    if (n > 8) n = 8;
+    const uint32_t f = mtb_part_fields(reh, n, left);
+    const int32_t ham = __builtin_popcount(f & 0x5555u) + 2 * __builtin_popcount(f & 0xAAAAu);
+    const int32_t zeros = n - __builtin_popcount((f | (f >> 1)) & 0x5555u);
+    return (float)(4 * n + 2 * zeros - ham) * 0.5f;
 }
 
 typedef struct {           /* MatchPath (Taxonomer.h:34-57); endMatch = own slot */
