@@ -1,0 +1,215 @@
+/* kernels_dir.h -- amino-acid prefix directory over the resident target array, and the join that uses it.
+ *
+ * The reference finds a query's candidates by streaming the delta-coded target list from a `split` checkpoint
+ * (KmerMatcher.cpp:157-205, 363-371).  With the list flat in HBM the first version of this engine searched a tile's target
+ * window by bisection: ~13 dependent loads per query plus the run scan (k_join, kernels_join.h) -- latency, not bandwidth,
+ * bounds that kernel (82 % of its wave cycles parked in s_waitcnt, rocprofv3 SQ counters).  Here the targets are bucketed by
+ * the base-21 number of their first L amino-acid letters (L <= 7, chosen so that a bucket holds a handful of targets):
+ *     dir[b]      = start of bucket b, as u32 relative to base[b >> 16]           ((21^L + 1) x 4 B: 7.2 GB at L = 7)
+ *     base[g]     = absolute start of bucket g * 65536                              (u64)
+ * so a query reads two adjacent directory words and finishes with <= 3-4 bisection steps inside one or two cache lines.
+ * Sorted queries (top 30 bits) walk the directory and the target array front to back: both streams are L2-friendly.
+ * The directory exists only when every 5-bit letter of the index is < 21 (kmer_format 2) and no bucket group spans 2^32
+ * targets; otherwise k_join is used.
+ *
+ * k_join_dir (fused short-read path, slot segments): no LDS, no barrier, no output reservation.  Per query: bucket ->
+ * bisection for the amino-acid part -> the run of equal amino-acid parts is scanned once for the minimum hamming sum and
+ * once to emit (compareDna, KmerMatcher.cpp:1117-1146): the first selected candidate goes to the query's ordinal slot, the
+ * others to the read's tail (one atomic each, rare), beyond that to the overflow list -- same contract as k_join<SEG>.    */
+#ifndef MTB_KERNELS_DIR_H
+#define MTB_KERNELS_DIR_H
+#include "dev_util.h"
+#include "kernels_join.h"
+#include "mtb_core.h"
+
+struct mtb_dir_view { const uint32_t *dir; const uint64_t *base; int32_t L; int32_t kmer_format; uint32_t n_buckets; };
+
+MTB_HD uint32_t mtb_pow21(int e) { uint32_t p = 1; for (int i = 0; i < e; i++) p *= 21u; return p; }
+
+/* bucket of a metamer value: base-21 number of its first L amino-acid letters (monotone in the value while all letters < 21) */
+MTB_HD uint32_t mtb_dir_bucket(uint64_t value, int L, int kmer_format) {
+    const uint64_t aa = value >> 24;
+    if (kmer_format == 1) {                       /* the amino-acid part already is the base-21 number of the 8 letters */
+        switch (L) {
+            case 1: return (uint32_t)(aa / 1801088541ull); case 2: return (uint32_t)(aa / 85766121ull); case 3: return (uint32_t)(aa / 4084101ull);
+            case 4: return (uint32_t)(aa / 194481ull); case 5: return (uint32_t)(aa / 9261ull); case 6: return (uint32_t)(aa / 441ull);
+            default: return (uint32_t)(aa / 21ull);
+        }
+    }
+    uint32_t b = 0;
+    for (int j = 0; j < L; j++) b = b * 21u + (uint32_t)((aa >> (35 - 5 * j)) & 31u);
+    return b;
+}
+
+/* base[g] = first target whose bucket is >= g * 65536 (g = 0 .. n_groups, the last one = T) */
+__global__ __launch_bounds__(256) void k_dir_base(const uint64_t *__restrict__ values, uint64_t T, int L, int fmt, uint32_t n_groups, uint64_t *__restrict__ base) {
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    if (g > n_groups) return;
+    const uint64_t gb = (uint64_t)g << 16;
+    uint64_t lo = 0, hi = T;
+    while (lo < hi) { const uint64_t mid = lo + ((hi - lo) >> 1); if ((uint64_t)mtb_dir_bucket(values[mid], L, fmt) < gb) lo = mid + 1; else hi = mid; }
+    base[g] = lo;
+}
+/* dir[x] for every bucket that starts at target i (and the empty buckets before it); flags: [0] a letter >= 21, [1] a group of
+ * 65536 buckets spans >= 2^32 targets */
+__global__ __launch_bounds__(256) void k_dir_fill(const uint64_t *__restrict__ values, uint64_t T, int L, int fmt, uint32_t n_buckets,
+                                                   const uint64_t *__restrict__ base, uint32_t *__restrict__ dir, uint32_t *__restrict__ flags) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < T; i += (uint64_t)gridDim.x * 256) {
+        const uint64_t v = values[i];
+        if (fmt != 1) {
+            bool bad = false;
+            for (int j = 0; j < 8; j++) bad |= ((v >> (59 - 5 * j)) & 31u) > 20u;
+            if (bad) { flags[0] = 1; continue; }
+        }
+        const uint32_t b = mtb_dir_bucket(v, L, fmt);
+        if (b >= n_buckets) { flags[0] = 1; continue; }
+        int64_t pb = -1;
+        if (i > 0) { const uint32_t p = mtb_dir_bucket(values[i - 1], L, fmt); if (p == b) continue; pb = (int64_t)p; if (p > b) { flags[0] = 1; continue; } }
+        for (int64_t x = pb + 1; x <= (int64_t)b; x++) {
+            const uint64_t rel = i - base[(uint64_t)x >> 16];
+            if (rel >> 32) flags[1] = 1;
+            dir[x] = (uint32_t)rel;
+        }
+    }
+}
+/* the empty buckets behind the last target, and the end sentinel dir[n_buckets] */
+__global__ __launch_bounds__(256) void k_dir_tail(const uint64_t *__restrict__ values, uint64_t T, int L, int fmt, uint32_t n_buckets,
+                                                   const uint64_t *__restrict__ base, uint32_t *__restrict__ dir, uint32_t *__restrict__ flags) {
+    const uint64_t first = T ? (uint64_t)mtb_dir_bucket(values[T - 1], L, fmt) + 1 : 0;
+    for (uint64_t x = first + (uint64_t)blockIdx.x * 256 + threadIdx.x; x <= n_buckets; x += (uint64_t)gridDim.x * 256) {
+        const uint64_t rel = T - base[x >> 16];
+        if (rel >> 32) flags[1] = 1;
+        dir[x] = (uint32_t)rel;
+    }
+}
+
+/* ---- packed state of the target array (directory depth 7 only) ------------------------------------------------------------
+ * Inside a bucket of the depth-7 directory all targets share their first seven amino-acid letters, so a target is told apart by
+ * 29 bits: its eighth letter (5 bits; format 1: the last base-21 digit) and its 24 DNA bits.  The other 35 bits of the 64-bit
+ * word carry the `info` entry (taxonomy id, incl. the legacy redundancy bit): one 8-byte load gives the join everything the
+ * reference reads from diffIdx AND info (KmerMatcher.cpp:378-381) -- the separate info[] fetch, a random 64-byte HBM sector per
+ * match (70 GB per 10 M reads at 16 G targets), disappears.  The conversion is in place (values[] is rewritten, info[] stays
+ * allocated as the unpack destination) and reversible: everything that needs the flat arrays unpacks first.            */
+#define MTB_PACK_LOW 29
+MTB_HD uint64_t mtb_pack_word(uint64_t value, uint32_t info, int fmt) {
+    const uint64_t low = fmt == 1 ? ((((value >> 24) % 21ull) << 24) | (value & 0xFFFFFFull)) : (value & ((1ull << MTB_PACK_LOW) - 1));
+    return ((uint64_t)info << MTB_PACK_LOW) | low;
+}
+MTB_HD uint64_t mtb_unpack_value(uint64_t w, uint32_t bucket, int fmt) {
+    const uint64_t low = w & ((1ull << MTB_PACK_LOW) - 1);
+    if (fmt == 1) return ((((uint64_t)bucket * 21ull) + (low >> 24)) << 24) | (low & 0xFFFFFFull);
+    uint64_t pre = 0; uint32_t b = bucket;
+    for (int j = 6; j >= 0; j--) { pre |= (uint64_t)(b % 21u) << (5 * (6 - j)); b /= 21u; }       /* letter j at bits 5*(6-j) of the 35-bit prefix */
+    return (pre << MTB_PACK_LOW) | low;
+}
+__global__ __launch_bounds__(256) void k_index_pack(uint64_t *__restrict__ values, const uint32_t *__restrict__ info, uint64_t T, int fmt) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < T; i += (uint64_t)gridDim.x * 256) values[i] = mtb_pack_word(values[i], info[i], fmt);
+}
+/* one thread per bucket: its targets get their prefix back, info[] is rewritten from the upper bits */
+__global__ __launch_bounds__(256) void k_index_unpack(uint64_t *__restrict__ values, uint32_t *__restrict__ info, mtb_dir_view dv) {
+    for (uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x; b < dv.n_buckets; b += (uint64_t)gridDim.x * 256) {
+        const uint64_t lo = dv.base[b >> 16] + dv.dir[b], hi = dv.base[(b + 1) >> 16] + dv.dir[b + 1];
+        for (uint64_t t = lo; t < hi; t++) { const uint64_t w = values[t]; info[t] = (uint32_t)(w >> MTB_PACK_LOW); values[t] = mtb_unpack_value(w, (uint32_t)b, dv.kmer_format); }
+    }
+}
+
+#ifndef MTB_JOIN_DIR_QPT
+#define MTB_JOIN_DIR_QPT 2
+#endif
+
+template <bool PACKED>
+__global__ __launch_bounds__(256) void k_join_dir(const mtb_kmer *__restrict__ q, uint64_t n, mtb_index_view ix, uint64_t limit, mtb_dir_view dv,
+                                                   const mtb_tables *__restrict__ tabs, JoinSegArgs sa, uint32_t *__restrict__ overflow) {
+    constexpr int Q = MTB_JOIN_DIR_QPT;
+    const uint64_t AAM = ~0xFFFFFFull;
+    __shared__ uint32_t s_hr[8];                    /* hammingLookup rows as nibble words: the only table the join arithmetic reads */
+    if (threadIdx.x < 8) s_hr[threadIdx.x] = tabs->hamrow[threadIdx.x];
+    const uint64_t base_q = (uint64_t)blockIdx.x * (256 * Q);
+    mtb_kmer k[Q]; bool valid[Q]; uint64_t lo[Q], hi[Q];
+#pragma unroll
+    for (int u = 0; u < Q; u++) {
+        const uint64_t j = base_q + (uint64_t)u * 256 + threadIdx.x;
+        valid[u] = j < n;
+        k[u].value = 0; k[u].qinfo = 0;
+        if (valid[u]) { k[u] = q[j]; valid[u] = mtb_q_seq(k[u].qinfo) != 0; }        /* blank slots carry sequenceID 0 */
+    }
+#pragma unroll
+    for (int u = 0; u < Q; u++) {
+        lo[u] = 0; hi[u] = 0;
+        if (valid[u]) {
+            const uint32_t b = mtb_dir_bucket(k[u].value, dv.L, dv.kmer_format);
+            if (b < dv.n_buckets) {
+                lo[u] = dv.base[b >> 16] + dv.dir[b];
+                hi[u] = dv.base[(b + 1) >> 16] + dv.dir[b + 1];
+                if (hi[u] > limit) hi[u] = limit;           /* the last entry of the (whole) index is never a candidate */
+                if (lo[u] > hi[u]) lo[u] = hi[u];
+            }
+        }
+    }
+    __syncthreads();                                 /* s_hr; the query and directory loads above are in flight meanwhile */
+    /* what tells targets of one bucket apart: the whole amino-acid part (flat state) or the packed word's eighth letter */
+    auto tkey = [&](uint64_t w) -> uint64_t { return PACKED ? (w & 0x1F000000ull) : (w & AAM); };
+    auto qkey = [&](uint64_t v) -> uint64_t {
+        if (!PACKED) return v & AAM;
+        return dv.kmer_format == 1 ? (((v >> 24) % 21ull) << 24) : (v & 0x1F000000ull);
+    };
+    /* first target of the bucket with the query's amino-acid part (bisection inside the bucket: a cache line or two) */
+    bool more = true;
+    uint64_t e_hi[Q];
+#pragma unroll
+    for (int u = 0; u < Q; u++) e_hi[u] = hi[u];
+    while (more) {
+        more = false;
+#pragma unroll
+        for (int u = 0; u < Q; u++) {
+            if (lo[u] < hi[u]) {
+                const uint64_t mid = lo[u] + ((hi[u] - lo[u]) >> 1);
+                if (tkey(ix.values[mid]) < qkey(k[u].value)) lo[u] = mid + 1; else hi[u] = mid;
+                more |= lo[u] < hi[u];
+            }
+        }
+    }
+    const uint32_t tail_cap = sa.stride - sa.direct;
+#pragma unroll
+    for (int u = 0; u < Q; u++) {
+        if (!valid[u]) continue;
+        const uint64_t s = lo[u], end = e_hi[u];
+        const uint64_t aa = qkey(k[u].value);
+        if (s >= end) continue;
+        uint64_t v0 = ix.values[s];
+        if (tkey(v0) != aa) continue;
+        const uint32_t info0 = PACKED ? (uint32_t)(v0 >> MTB_PACK_LOW) : ix.info[s];      /* flat state: issued now, the first candidate is selected more often than not */
+        mtb_qrows qr; mtb_prepare_query_rows(s_hr, k[u].value, &qr);
+        uint32_t mn = mtb_ham_sum(&qr, (uint32_t)v0 & 0xFFFFFFu);
+        uint64_t e = s + 1;
+        while (e < end) { const uint64_t v = ix.values[e]; if (tkey(v) != aa) break; const uint32_t h = mtb_ham_sum(&qr, (uint32_t)v & 0xFFFFFFu); mn = h < mn ? h : mn; e++; }
+        const uint32_t thr = mtb_ham_threshold(mn);
+        const uint32_t r = mtb_q_seq(k[u].qinfo) - 1;
+        const uint32_t ord = mtb_q_pos(k[u].qinfo) >> 16;
+        const uint64_t qinfo = k[u].qinfo & ~0xFFFF0000ull;      /* the record carries the reference's qinfo */
+        const bool rev = mtb_hammings_reversed(mtb_q_frame(qinfo), ix.kmer_format);
+        mtb_slot16 *seg = sa.seg + (uint64_t)r * sa.stride;
+        bool first = ord < sa.direct;
+        for (uint64_t t = s; t < e; t++) {
+            const uint64_t v = t == s ? v0 : ix.values[t];
+            const uint32_t td = (uint32_t)v & 0xFFFFFFu;
+            const uint32_t h = mtb_ham_sum(&qr, td);
+            if (h > thr) continue;
+            const int32_t tid = (int32_t)((t == s ? info0 : (PACKED ? (uint32_t)(v >> MTB_PACK_LOW) : ix.info[t])) & ix.info_mask);
+            const int32_t sp = (tid >= 0 && tid <= ix.max_taxid) ? ix.tax2species[tid] : 0;
+            const uint16_t reh = mtb_hammings(&qr, td, rev);
+            if (first) { seg[ord] = mtb_slot_pack(qinfo, tid, sp, td, reh, h, sa.epoch); first = false; continue; }
+            const uint32_t at = atomicAdd(&sa.cursor[r], 1u);
+            if (at < tail_cap) seg[sa.direct + at] = mtb_slot_pack(qinfo, tid, sp, td, reh, h, sa.epoch);
+            else {
+                const unsigned long long o = atomicAdd(sa.ovf_counter, 1ull);
+                if (o < sa.ovf_cap) {
+                    mtb_match m; m.qinfo = qinfo; m.target_id = tid; m.species_id = sp; m.dna = td; m.right_end_hamming = reh; m.hamming = (uint8_t)h; m.pad = 0;
+                    sa.ovf[o] = m;
+                } else *overflow = 1;
+            }
+        }
+    }
+}
+
+#endif

@@ -15,6 +15,7 @@
 #include "kernels_extract.h"
 #include "kernels_index.h"
 #include "kernels_join.h"
+#include "kernels_dir.h"
 #include "kernels_scan.h"
 #include "kernels_score.h"
 #include "kernels_score_fast.h"
@@ -103,6 +104,9 @@ struct mtb_index {
     uint8_t *d_under = nullptr, *d_accleaf = nullptr;
     mtb_params params;
     uint32_t info_mask = 0xFFFFFFFFu;
+    /* amino-acid prefix directory (kernels_dir.h); absent for views and for indices it cannot describe */
+    uint32_t *d_dir = nullptr; uint64_t *d_dirbase = nullptr; int32_t dir_L = 0; uint32_t dir_buckets = 0;
+    bool packed = false;             /* d_values holds packed words (kernels_dir.h): the fused join's state; everything else unpacks first */
 };
 
 template <typename T>
@@ -339,6 +343,9 @@ static mtb_status dev_sort(mtb_ctx *c, mtb_kmer *d_a, uint64_t n, int first_bit,
     return MTB_OK;
 }
 
+static mtb_status ensure_flat(mtb_index *ix);
+static mtb_status ensure_packed(mtb_index *ix);
+static mtb_dir_view dir_view(const mtb_index *ix);
 static mtb_index_view index_view(const mtb_index *ix) {
     mtb_index_view v;
     v.values = ix->d_values; v.info = ix->d_info; v.n_targets = ix->T; v.tax2species = ix->d_tax2species;
@@ -364,7 +371,16 @@ static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint6
     uint64_t *d_bounds;
     STCHK(ensure(c, "jbounds", 2ull * grid, &d_bounds));
     uint64_t limit = ix->T ? ix->T - (ix->match_last ? 0 : 1) : 0;          /* the last entry of the (whole) index is never a candidate */
-    { KTimer kt(c, MTB_K_JOIN);
+    if (seg && ix->d_dir) {
+        STCHK(ensure_packed(ix));
+        KTimer kt(c, MTB_K_JOIN);
+        JoinSegArgs sa = *seg; sa.ovf_counter = (unsigned long long *)c->d_scal;
+        const uint32_t g2 = (uint32_t)((n + 256 * MTB_JOIN_DIR_QPT - 1) / (256 * MTB_JOIN_DIR_QPT));
+        if (ix->packed) hipLaunchKernelGGL((k_join_dir<true>), dim3(g2), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1));
+        else hipLaunchKernelGGL((k_join_dir<false>), dim3(g2), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1));
+    } else
+    { STCHK(ensure_flat(ix));
+    KTimer kt(c, MTB_K_JOIN);
     hipLaunchKernelGGL(k_join_bounds, dim3((grid + 255) / 256), dim3(256), 0, c->stream, d_q, n, (const uint64_t *)ix->d_values, limit,
                        (uint64_t)grid, d_bounds, sort_low_bits);
     if (seg) {
@@ -558,9 +574,59 @@ static mtb_status upload_taxonomy(mtb_index *ix) {
     return MTB_OK;
 }
 
-extern "C" {
+/* The amino-acid prefix directory of an index that owns (or borrows) a complete flat array: L letters with 21^L >= T / 8, at most
+ * 7 (7.2 GB).  Not built (k_join is used) when the index holds a 5-bit letter >= 21 or a directory group spans 2^32 targets.
+ * MTB_NO_DIR=1 disables it (A/B measurements). */
+static mtb_status build_directory(mtb_ctx *c, mtb_index *ix) {
+    if (ix->T < 2 || getenv("MTB_NO_DIR")) return MTB_OK;
+    int L = 1;
+    while (L < 7 && (uint64_t)mtb_pow21(L) < ix->T / 8) L++;
+    if (getenv("MTB_DIR_DEPTH")) L = std::max(1, std::min(7, atoi(getenv("MTB_DIR_DEPTH"))));       /* tests force depth 7 (packed state) on toy indices */
+    const uint32_t nbk = mtb_pow21(L);
+    const uint32_t n_groups = (nbk >> 16) + 1;
+    size_t fr = 0, tot = 0;
+    HIPCHK(hipMemGetInfo(&fr, &tot));
+    if (((size_t)nbk + 1) * 4 + ((size_t)n_groups + 2) * 8 + (64u << 20) > fr) return MTB_OK;       /* no room: the bisection join still works */
+    uint32_t *d_flags = (uint32_t *)(c->d_scal + 6);
+    HIPCHK(hipMalloc((void **)&ix->d_dir, ((size_t)nbk + 1) * 4));
+    HIPCHK(hipMalloc((void **)&ix->d_dirbase, ((size_t)n_groups + 2) * 8));
+    HIPCHK(hipMemsetAsync(d_flags, 0, 8, c->stream));
+    const int fmt = ix->params.kmer_format;
+    hipLaunchKernelGGL(k_dir_base, dim3((n_groups + 1 + 255) / 256), dim3(256), 0, c->stream, (const uint64_t *)ix->d_values, ix->T, L, fmt, n_groups, ix->d_dirbase);
+    hipLaunchKernelGGL(k_dir_fill, dim3((uint32_t)std::min<uint64_t>((ix->T + 255) / 256, 1u << 20)), dim3(256), 0, c->stream, (const uint64_t *)ix->d_values, ix->T, L, fmt,
+                       nbk, (const uint64_t *)ix->d_dirbase, ix->d_dir, d_flags);
+    hipLaunchKernelGGL(k_dir_tail, dim3(4096), dim3(256), 0, c->stream, (const uint64_t *)ix->d_values, ix->T, L, fmt, nbk, (const uint64_t *)ix->d_dirbase, ix->d_dir, d_flags);
+    HIPCHK(hipGetLastError());
+    uint32_t fl[2] = {0, 0};
+    STCHK(d2h(c, fl, d_flags, 8));
+    if (fl[0] || fl[1]) { hipError_t e = hipFree(ix->d_dir); e = hipFree(ix->d_dirbase); (void)e; ix->d_dir = nullptr; ix->d_dirbase = nullptr; return MTB_OK; }
+    ix->dir_L = L; ix->dir_buckets = nbk;
+    return MTB_OK;
+}
 
-} // extern "C"
+static mtb_dir_view dir_view(const mtb_index *ix) {
+    mtb_dir_view dv; dv.dir = ix->d_dir; dv.base = ix->d_dirbase; dv.L = ix->dir_L; dv.kmer_format = ix->params.kmer_format; dv.n_buckets = ix->dir_buckets;
+    return dv;
+}
+/* the two states of the target array: flat {value[T], info[T]} (every stage-level entry point, download / write / slices) and packed
+ * (the fused join; depth-7 directory only).  Conversions are in place, ~25 ms each at 16 G targets, and happen only on a change of use. */
+static mtb_status ensure_flat(mtb_index *ix) {
+    if (!ix || !ix->packed) return MTB_OK;
+    mtb_ctx *c = ix->ctx;
+    hipLaunchKernelGGL(k_index_unpack, dim3((uint32_t)std::min<uint64_t>(((uint64_t)ix->dir_buckets + 255) / 256, 1u << 20)), dim3(256), 0, c->stream, ix->d_values, ix->d_info, dir_view(ix));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    ix->packed = false;
+    return MTB_OK;
+}
+static mtb_status ensure_packed(mtb_index *ix) {
+    if (ix->packed || !ix->d_dir || ix->dir_L != 7 || !ix->own_tax || getenv("MTB_NO_PACK")) return MTB_OK;
+    mtb_ctx *c = ix->ctx;
+    hipLaunchKernelGGL(k_index_pack, dim3((uint32_t)std::min<uint64_t>((ix->T + 255) / 256, 1u << 20)), dim3(256), 0, c->stream, ix->d_values, (const uint32_t *)ix->d_info, ix->T, ix->params.kmer_format);
+    HIPCHK(hipGetLastError());
+    ix->packed = true;
+    return MTB_OK;
+}
 
 /* How a database directory is cut into n_parts value ranges at `split` checkpoints (IndexCreator.cpp:848-857: a
  * checkpoint {value, diffIdx offset after it, info index + 1} sits on the first metamer of an amino-acid group).  */
@@ -678,6 +744,7 @@ static mtb_status open_impl(mtb_ctx *c, const char *dbdir, const char *taxonomy_
     HIPCHK(hipStreamSynchronize(c->stream));
     release(c, "diffraw"); release(c, "difftc"); release(c, "difftoff");
     ix->T = T;
+    if ((st = build_directory(c, ix)) != MTB_OK) { mtb_index_close(ix); return st; }
     *out = ix;
     return MTB_OK;
 }
@@ -712,6 +779,7 @@ mtb_status mtb_index_from_device(mtb_ctx *c, const uint64_t *d_values, const uin
     ix->d_values = (uint64_t *)d_values; ix->d_info = (uint32_t *)d_info; ix->T = n_targets;
     mtb_status st = upload_taxonomy(ix);
     if (st != MTB_OK) { mtb_index_close(ix); return st; }
+    if ((st = build_directory(c, ix)) != MTB_OK) { mtb_index_close(ix); return st; }
     *out = ix;
     return MTB_OK;
 }
@@ -720,6 +788,7 @@ void mtb_index_close(mtb_index *ix) {
     if (!ix) return;
     hipError_t e = hipSuccess;
     if (ix->own) { if (ix->d_values) e = hipFree(ix->d_values); if (ix->d_info) e = hipFree(ix->d_info); }
+    if (ix->own_tax) { if (ix->d_dir) e = hipFree(ix->d_dir); if (ix->d_dirbase) e = hipFree(ix->d_dirbase); }     /* views never own a directory */
     if (!ix->own_tax) { (void)e; delete ix; return; }
     if (ix->d_canon) e = hipFree(ix->d_canon);
     if (ix->d_parent) e = hipFree(ix->d_parent);
@@ -737,6 +806,7 @@ mtb_status mtb_index_download(mtb_index *ix, uint64_t *values, uint32_t *info, u
     if (!ix) return fail(MTB_ERR_ARG, "NULL index");
     if (cap < ix->T) return fail(MTB_ERR_CAPACITY, "output too small");
     if (ix->T == 0) return MTB_OK;
+    STCHK(ensure_flat(ix));
     if (values) HIPCHK(hipMemcpy(values, ix->d_values, ix->T * 8, hipMemcpyDeviceToHost));
     if (info) HIPCHK(hipMemcpy(info, ix->d_info, ix->T * 4, hipMemcpyDeviceToHost));
     return MTB_OK;
@@ -748,6 +818,7 @@ mtb_status mtb_index_write(const mtb_index *ix, const char *dbdir, int split_num
     if (!ix || !dbdir || split_num < 2) return fail(MTB_ERR_ARG, "NULL argument / split_num < 2");
     mtb_ctx *c = ix->ctx;
     HIPCHK(hipSetDevice(c->device));
+    STCHK(ensure_flat(const_cast<mtb_index *>(ix)));
     const std::string d(dbdir);
     FILE *fd = fopen((d + "/diffIdx").c_str(), "wb"), *fi = fopen((d + "/info").c_str(), "wb");
     if (!fd || !fi) { if (fd) fclose(fd); if (fi) fclose(fi); return fail(MTB_ERR_IO, "cannot create diffIdx/info in " + d); }
@@ -1307,10 +1378,11 @@ mtb_status mtb_index_slice(mtb_index *ix, uint64_t lo_value, uint64_t hi_value, 
     mtb_ctx *c = ix->ctx;
     HIPCHK(hipSetDevice(c->device));
     uint64_t b[2] = {lo_value, hi_value}, pos[2] = {0, 0};
+    STCHK(ensure_flat(ix));                 /* a view shares the parent's arrays: the parent must stay flat while the view is used */
     if (ix->T) STCHK(lower_bounds(c, ix->d_values, ix->T, 1, b, 2, pos));
     if (hi_value == UINT64_MAX) pos[1] = ix->T;
     mtb_index *sl = new mtb_index(*ix);
-    sl->own = false; sl->own_tax = false;
+    sl->own = false; sl->own_tax = false; sl->d_dir = nullptr; sl->d_dirbase = nullptr; sl->dir_L = 0;
     sl->d_values = ix->d_values + pos[0]; sl->d_info = ix->d_info + pos[0]; sl->T = pos[1] - pos[0];
     sl->match_last = !is_last || ix->match_last;
     *out = sl;

@@ -227,12 +227,13 @@ MTB_HD bool mtb_window_metamer(const uint8_t *cod, int syncmer, int smer_len, ui
 /* ------------------------------------------------------------------ */
 typedef struct { uint32_t row[8]; uint32_t qdna; } mtb_qrows;   /* row[i]: hamming row of query codon i (i=0 is the LSB codon) */
 
-MTB_HD void mtb_prepare_query(const mtb_tables *t, uint64_t qvalue, mtb_qrows *q) {
+MTB_HD void mtb_prepare_query_rows(const uint32_t *hamrow, uint64_t qvalue, mtb_qrows *q) {
     uint32_t d = (uint32_t)qvalue & 0xFFFFFFu;
     q->qdna = d;
 MTB_UNROLL
-    for (int i = 0; i < 8; i++) q->row[i] = t->hamrow[(d >> (3 * i)) & 7u];
+    for (int i = 0; i < 8; i++) q->row[i] = hamrow[(d >> (3 * i)) & 7u];
 }
+MTB_HD void mtb_prepare_query(const mtb_tables *t, uint64_t qvalue, mtb_qrows *q) { mtb_prepare_query_rows(t->hamrow, qvalue, q); }
 /* getHammingDistanceSum (KmerMatcher.h:348-360) */
 MTB_HD uint32_t mtb_ham_sum(const mtb_qrows *q, uint32_t tdna) {
     uint32_t s = 0;

@@ -564,3 +564,33 @@ def test_hbm_budgeted_sub_batches(toy):
     assert c.last_sub_batches == 1
     assert (res2 == res).all() and (tt2 == tt).all() and (tc2 == tc).all()
     ix.close(); c.close()
+
+
+def test_packed_index_state_round_trips(toy, monkeypatch, tmp_path):
+    """Depth-7 directory + packed target words (kernels_dir.h): the fused join rewrites values[] in place as
+    (info << 29 | eighth letter | dna) and reads no info[]; every flat-array user unpacks first.  Forced on a toy index (the
+    depth is normally chosen from the index size): fused results == oracle, download == the database's arrays, the stage
+    join after a fused batch, the writer after a fused batch, and a second fused batch after all that."""
+    import metabuli_amd as M
+    if toy.p.seq_mode == 3:
+        pytest.skip("long reads use exact segments (k_join), not the slot path")
+    monkeypatch.setenv("MTB_DIR_DEPTH", "7")
+    c = M.Context(0)
+    p = _params(toy)
+    ix = c.open_index(toy.dbdir, p)
+    monkeypatch.delenv("MTB_DIR_DEPTH")
+    res, tt, tc = c.classify_batch(ix, p, toy.b1, toy.o1, toy.b2, toy.o2)          # packs
+    _check_results(toy, res, tt, tc)
+    v, info = ix.download()                                                          # unpacks
+    assert (v == toy.values).all() and (info.astype(np.int32) == toy.taxids).all()
+    res, tt, tc = c.classify_batch(ix, p, toy.b1, toy.o1, toy.b2, toy.o2)          # packs again
+    _check_results(toy, res, tt, tc)
+    m = c.sort_matches(c.match(ix, toy.ref["kmers"]), toy.n_reads)                  # stage join: unpacks
+    assert (m == toy.ref["matches"]).all()
+    res, tt, tc = c.classify_batch(ix, p, toy.b1, toy.o1, toy.b2, toy.o2)
+    _check_results(toy, res, tt, tc)
+    out = tmp_path / "copy"; out.mkdir()
+    ix.write(str(out))                                                               # unpacks
+    for name in ("diffIdx", "info"):
+        assert (out / name).read_bytes() == open(os.path.join(toy.dbdir, name), "rb").read(), name
+    ix.close(); c.close()
