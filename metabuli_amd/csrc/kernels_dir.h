@@ -153,11 +153,44 @@ __global__ __launch_bounds__(256) void k_join_dir(const mtb_kmer *__restrict__ q
         if (!PACKED) return v & AAM;
         return dv.kmer_format == 1 ? (((v >> 24) % 21ull) << 24) : (v & 0x1F000000ull);
     };
-    /* first target of the bucket with the query's amino-acid part (bisection inside the bucket: a cache line or two) */
-    bool more = true;
+    /* first target of the bucket with the query's amino-acid part.  The first eight words of the bucket (one or two 64-byte
+     * sectors; most buckets hold fewer) are fetched with four independent 16-byte loads and counted in registers: one memory
+     * round trip instead of a 3-4 step bisection chain; larger buckets finish by bisection behind the window. */
     uint64_t e_hi[Q];
 #pragma unroll
     for (int u = 0; u < Q; u++) e_hi[u] = hi[u];
+#ifdef MTB_JOIN_DIR_WINDOW       /* measured: no gain over the plain bisection (44-54 ms either way; the kernel is bound by its scattered slot stores) */
+    {
+        ulonglong2 w[Q][4];
+#pragma unroll
+        for (int u = 0; u < Q; u++) {
+            const uint64_t a0 = lo[u] & ~1ull;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                w[u][j] = make_ulonglong2(~0ull, ~0ull);
+                if (lo[u] < hi[u] && a0 + 2 * j < hi[u]) w[u][j] = *(const ulonglong2 *)(ix.values + a0 + 2 * j);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < Q; u++) {
+            if (lo[u] >= hi[u]) continue;
+            const uint64_t a0 = lo[u] & ~1ull, qk = qkey(k[u].value);
+            uint32_t less = 0, seen = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint64_t idx = a0 + j, word = (j & 1) ? w[u][j >> 1].y : w[u][j >> 1].x;
+                const bool in = idx >= lo[u] && idx < hi[u];
+                seen += in ? 1u : 0u;
+                less += (in && tkey(word) < qk) ? 1u : 0u;
+            }
+            if (less < seen || lo[u] + seen >= hi[u]) { lo[u] += less; hi[u] = lo[u]; }        /* answer inside the window (or the bucket ends in it) */
+            else lo[u] += seen;                                                                   /* everything seen is smaller: continue behind the window */
+        }
+    }
+#endif
+    bool more = false;
+#pragma unroll
+    for (int u = 0; u < Q; u++) more |= lo[u] < hi[u];
     while (more) {
         more = false;
 #pragma unroll
@@ -198,9 +231,14 @@ __global__ __launch_bounds__(256) void k_join_dir(const mtb_kmer *__restrict__ q
             const int32_t tid = (int32_t)((t == s ? info0 : (PACKED ? (uint32_t)(v >> MTB_PACK_LOW) : ix.info[t])) & ix.info_mask);
             const int32_t sp = (tid >= 0 && tid <= ix.max_taxid) ? ix.tax2species[tid] : 0;
             const uint16_t reh = mtb_hammings(&qr, td, rev);
-            if (first) { seg[ord] = mtb_slot_pack(qinfo, tid, sp, td, reh, h, sa.epoch); first = false; continue; }
+            /* non-temporal stores: a slot line is written ~5 times at unrelated moments of the kernel and never read by it; keeping
+             * those lines out of the L2's way measured 47.5 ms against 50-58 ms (and steadier) for the kernel -- which is bound by
+             * these 1.1 G scattered 16-byte stores: 20.5 ms without them, 29 ms with dense stores (profiles/r02_notes.md) */
+            if (first) { const mtb_slot16 sl = mtb_slot_pack(qinfo, tid, sp, td, reh, h, sa.epoch);
+                         __builtin_nontemporal_store(sl.a, &seg[ord].a); __builtin_nontemporal_store(sl.b, &seg[ord].b); first = false; continue; }
             const uint32_t at = atomicAdd(&sa.cursor[r], 1u);
-            if (at < tail_cap) seg[sa.direct + at] = mtb_slot_pack(qinfo, tid, sp, td, reh, h, sa.epoch);
+            if (at < tail_cap) { const mtb_slot16 sl = mtb_slot_pack(qinfo, tid, sp, td, reh, h, sa.epoch);
+                                 __builtin_nontemporal_store(sl.a, &seg[sa.direct + at].a); __builtin_nontemporal_store(sl.b, &seg[sa.direct + at].b); }
             else {
                 const unsigned long long o = atomicAdd(sa.ovf_counter, 1ull);
                 if (o < sa.ovf_cap) {

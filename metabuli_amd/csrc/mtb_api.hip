@@ -307,7 +307,7 @@ static mtb_status dev_extract(mtb_ctx *c, const mtb_params *p, const char *d_bas
 /* first_bit >= 0: binary LSD passes over bits [first_bit, 64).  first_bit == MTB_SORT_AA6 (kmer_format 2): three
  * passes on amino-acid letter pairs = order by bits [34, 64) (kernels_sort.h). */
 #define MTB_SORT_AA6 (-6)
-static mtb_status dev_sort(mtb_ctx *c, mtb_kmer *d_a, uint64_t n, int first_bit, mtb_kmer **sorted, uint16_t *d_dig = nullptr) {
+static mtb_status dev_sort(mtb_ctx *c, mtb_kmer *d_a, uint64_t n, int first_bit, mtb_kmer **sorted, uint16_t *d_dig = nullptr, int aa_first_shift = 34) {
     *sorted = d_a;
     if (n == 0) return MTB_OK;
     const bool aa = first_bit == MTB_SORT_AA6;
@@ -324,7 +324,9 @@ static mtb_status dev_sort(mtb_ctx *c, mtb_kmer *d_a, uint64_t n, int first_bit,
          * scatter writes the next pass's in output order) instead of the 16-byte records */
         uint16_t *dig_src = aa ? d_dig : nullptr, *dig_dst = nullptr;
         if (dig_src) STCHK(ensure(c, "digB", n, &dig_dst));
-        for (int shift = aa ? 34 : first_bit; shift < 64; shift += aa ? 10 : 8) {
+        /* the directory join (kernels_dir.h) looks every query up on its own: the sort only buys locality of the directory /
+         * target accesses, so the fused path may stop after fewer letter pairs (aa_first_shift: 34 = six letters, 44 = four, 54 = two) */
+        for (int shift = aa ? aa_first_shift : first_bit; shift < 64; shift += aa ? 10 : 8) {
             { KTimer kt(c, MTB_K_RADIX_HIST);
               if (aa && dig_src) hipLaunchKernelGGL((k_radix_hist_dig<512, 512>), dim3((tiles + MTB_HIST_GROUP - 1) / MTB_HIST_GROUP), dim3(512), 0, c->stream, (const uint16_t *)dig_src, n, d_hist, tiles);
               else if (aa) hipLaunchKernelGGL((k_radix_hist<512, 1, 512>), dim3(tiles), dim3(512), 0, c->stream, (const mtb_kmer *)src, n, shift, d_hist, tiles);
@@ -1090,7 +1092,9 @@ static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, c
      * comes from k_join_bounds */
     mtb_kmer *d_s;
     const int low_bits = aa6 ? 34 : 32;
-    STCHK(dev_sort(c, d_k, nk, aa6 ? MTB_SORT_AA6 : 32, &d_s, d_dig));
+    int aa_first_shift = 34;
+    if (aa6 && fixed && ix->d_dir && getenv("MTB_SORT_PAIRS")) aa_first_shift = 64 - 10 * std::max(1, std::min(3, atoi(getenv("MTB_SORT_PAIRS"))));
+    STCHK(dev_sort(c, d_k, nk, aa6 ? MTB_SORT_AA6 : 32, &d_s, aa_first_shift == 34 ? d_dig : nullptr, aa_first_shift));
     HIPCHK(hipEventRecord(c->ev[2], st));
     uint32_t *d_rc;
     STCHK(ensure(c, "readcnt", n_reads, &d_rc));

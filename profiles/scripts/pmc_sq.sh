@@ -12,5 +12,9 @@ run() { d=$1; shift; c="$1"; shift
 run a "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU" "$@"
 run b "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA" "$@"
 run c "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_FLAT SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE GRBM_COUNT" "$@"
+if [ -z "$MTB_PMC_NO_TCC" ]; then
+run d "FETCH_SIZE" "$@"
+run e "WRITE_SIZE" "$@"
+fi
 find $R/gpurun_out -name "*counter_collection.csv" -size +60M -delete
 ls -la $R/gpurun_out/pmc_${tag}_* | head -40
