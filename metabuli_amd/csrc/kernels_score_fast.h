@@ -35,10 +35,14 @@
 /* debugging build only (-DMTB_FAST_DEBUG): why reads leave the fast path: 0 tail overflow / buckets, 1 > 8 species, 2 not sorted
  * (S1), 3 position group with two matches (S2), 4 > 64 paths (S3), 5 handled; 6 sum of emitted paths, 7 sum of species */
 #ifdef MTB_FAST_DEBUG
-__device__ unsigned long long mtb_fast_reasons[8];
+__device__ unsigned long long mtb_fast_reasons[32];          /* [8..]: cycles per phase (wave 0 of every workgroup = every wave) */
 #define MTB_FAST_COUNT(k, v) do { if (threadIdx.x == 0) atomicAdd(&mtb_fast_reasons[k], (unsigned long long)(v)); } while (0)
+#define MTB_FAST_T0() unsigned long long ft_ = __builtin_readcyclecounter()
+#define MTB_FAST_MARK(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) s_ph[k] += t_ - ft_; ft_ = t_; } while (0)
 #else
 #define MTB_FAST_COUNT(k, v) do {} while (0)
+#define MTB_FAST_T0() do {} while (0)
+#define MTB_FAST_MARK(k) do {} while (0)
 #endif
 
 __device__ __forceinline__ int32_t rl_i(int32_t v, int32_t l) { return __builtin_amdgcn_readlane(v, l); }
@@ -83,6 +87,10 @@ __global__ __launch_bounds__(64, 4) void k_score_fast(const mtb_slot16 *__restri
     __shared__ uint32_t s_pf[64];
     __shared__ uint32_t s_hcnt[256];            /* matches per species hash: lonely matches are dropped up front */
     const int32_t lane = (int32_t)threadIdx.x;
+#ifdef MTB_FAST_DEBUG
+    __shared__ unsigned long long s_ph[16];
+    if (threadIdx.x < 16) s_ph[threadIdx.x] = 0;
+#endif
     const uint64_t lt = lanemask_lt();
     const uint64_t le = lt | (1ull << lane);
     const uint32_t tail_cap = stride - direct;
@@ -94,6 +102,7 @@ __global__ __launch_bounds__(64, 4) void k_score_fast(const mtb_slot16 *__restri
             const uint8_t *pf = (const uint8_t *)(slots_all + (r + gridDim.x) * (uint64_t)stride) + (uint64_t)lane * 128u;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)pf, (__attribute__((address_space(3))) void *)s_pf, 4, 0, 0);
         }
+        MTB_FAST_T0();
         const int32_t ql1 = qlen[r], ql2 = qlen2[r];
         const int32_t read_len = ql1 + ql2;
         const int32_t nb = mtb_num_buckets(read_len, sp.dna_shift);
@@ -104,6 +113,7 @@ __global__ __launch_bounds__(64, 4) void k_score_fast(const mtb_slot16 *__restri
         for (int k = 0; k < K; k++) { const uint32_t i = (uint32_t)lane + 64u * k; x[k].a = 0; x[k].b = 0; if (i < stride) x[k] = slots[i]; }
         bool slow = cur > tail_cap || nb > MTB_FAST_BKT;
         wave_fence();                                   /* previous read's LDS traffic is complete */
+        MTB_FAST_MARK(0);       /* setup + slot loads issued */
         /* ---- compaction of the live slots -> keys / aux in LDS, ordered by (species, slot order).  A stray match of a foreign
          * species (a filler hit of a metamer that carries a read error) is what usually breaks the slot order: the species are
          * taken one after another in ascending order (a wave minimum per species, 1-3 of them), each species' matches keep their
@@ -116,8 +126,7 @@ __global__ __launch_bounds__(64, 4) void k_score_fast(const mtb_slot16 *__restri
          * at again: it is dropped here.  With an index full of foreign species most stray hits are of this kind (every hit of a
          * read of an unknown organism, typically), and they are what breaks the slot order.  Lonely = alone in its bucket of a
          * 256-entry species hash (a collision only keeps a droppable match). */
-        for (int32_t q = lane; q < 256; q += 64) s_hcnt[q] = 0;
-        wave_fence();
+        uint32_t smin = 0xFFFFFFFFu, smax = 0u;
 #pragma unroll
         for (int k = 0; k < K; k++) {
             const uint32_t i = (uint32_t)lane + 64u * k;
@@ -125,15 +134,25 @@ __global__ __launch_bounds__(64, 4) void k_score_fast(const mtb_slot16 *__restri
             spc[k] = live[k] ? (uint32_t)(x[k].a >> 32) : 0xFFFFFFFFu;
             dst[k] = 0;
             n_live += (int32_t)__popcll(__ballot(live[k]));
-            if (live[k]) atomicAdd(&s_hcnt[(spc[k] * 0x9E3779B1u) >> 24], 1u);
+            smin = spc[k] < smin ? spc[k] : smin;
+            if (live[k]) smax = spc[k] > smax ? spc[k] : smax;
         }
-        wave_fence();
+        smin = wave_min_u32(smin); smax = wave_max_u32(smax);
         uint32_t todo_min = 0xFFFFFFFFu;
+        if (smin != smax) {                         /* a read of one species (about half of them) needs neither the hash nor more than one round */
+            for (int32_t q = lane; q < 256; q += 64) s_hcnt[q] = 0;
+            wave_fence();
 #pragma unroll
-        for (int k = 0; k < K; k++) {
-            if (live[k] && s_hcnt[(spc[k] * 0x9E3779B1u) >> 24] < 2u) { live[k] = false; spc[k] = 0xFFFFFFFFu; }
-            todo_min = spc[k] < todo_min ? spc[k] : todo_min;
+            for (int k = 0; k < K; k++) if (live[k]) atomicAdd(&s_hcnt[(spc[k] * 0x9E3779B1u) >> 24], 1u);
+            wave_fence();
+#pragma unroll
+            for (int k = 0; k < K; k++) if (live[k] && s_hcnt[(spc[k] * 0x9E3779B1u) >> 24] < 2u) { live[k] = false; spc[k] = 0xFFFFFFFFu; }
+        } else if (n_live < 2) {
+#pragma unroll
+            for (int k = 0; k < K; k++) { live[k] = false; spc[k] = 0xFFFFFFFFu; }        /* a single match is lonely too */
         }
+#pragma unroll
+        for (int k = 0; k < K; k++) todo_min = spc[k] < todo_min ? spc[k] : todo_min;
         for (int round = 0; ; round++) {
             const uint32_t m = wave_min_u32(todo_min);
             if (m == 0xFFFFFFFFu) break;
@@ -156,12 +175,15 @@ __global__ __launch_bounds__(64, 4) void k_score_fast(const mtb_slot16 *__restri
                 s_aux[dst[k]] = (x[k].a & 0xFFFFFFFFull) | (((b >> 24) & 0xFFFFull) << 32);
             }
         }
+        MTB_FAST_MARK(1);       /* species order + keys to LDS (includes the wait for the slot loads) */
         mtb_result R;
         R.classification = 0; R.score = 0.0f; R.query_length = ql1; R.query_length2 = ql2; R.is_classified = 0; R.reserved = 0; R.n_taxcnt = 0; R.taxcnt_off = (uint32_t)tc_base;
         if (!slow && n == 0) { if (lane == 0) { cnt_out[r] = (uint32_t)n_live; results[r] = R; } continue; }
         wave_fence();
         /* ---- own elements, neighbours, structure checks ---- */
         uint64_t key[K]; uint32_t tid[K], reh[K];
+        int32_t tcanon[K]; uint8_t euk[K];
+        const mtb_tax_node *nodes = (const mtb_tax_node *)tx.node;
         bool bhead[K], linked[K];
         int32_t shv[K];
         uint64_t bmask[K + 1], lmask[K + 1], rmask[K];
@@ -173,11 +195,22 @@ __global__ __launch_bounds__(64, 4) void k_score_fast(const mtb_slot16 *__restri
 #pragma unroll
         for (int k = 0; k < K; k++) {
             const int32_t i = lane + 64 * k;
-            key[k] = 0; tid[k] = 0; reh[k] = 0; bhead[k] = true; linked[k] = false; shv[k] = 0;
+            key[k] = 0; tid[k] = 0; reh[k] = 0; bhead[k] = true; linked[k] = false; shv[k] = 0; tcanon[k] = -1; euk[k] = 0;
             bmask[k] = ~0ull; lmask[k] = 0; rmask[k] = 0;
             if (k < nslot && !slow) {
                 uint64_t pk = 0;
-                if (i < n) { key[k] = s_key[i]; const uint64_t a = s_aux[i]; tid[k] = (uint32_t)a; reh[k] = (uint32_t)(a >> 32); if (i > 0) pk = s_key[i - 1]; }
+                if (i < n) {
+                    key[k] = s_key[i]; const uint64_t a = s_aux[i]; tid[k] = (uint32_t)a; reh[k] = (uint32_t)(a >> 32); if (i > 0) pk = s_key[i - 1];
+                    /* taxonomy lookups this match may need later, issued now and all at once: its target's canonical id (redundancy
+                     * filter) and whether its species sits under Eukaryota (minimum path depth) -- the scorer's wall time is L2
+                     * round trips of such lookups, so they must not queue up behind each other */
+                }
+                {   /* unconditional loads from clamped indices (a load under a branch is waited for at the branch's end) */
+                    const int32_t t_ = (int32_t)tid[k], s_ = (int32_t)(key[k] >> 41);
+                    const bool tv = i < n && t_ >= 0 && t_ <= tx.max_taxid, sv = i < n && s_ >= 0 && s_ <= tx.max_taxid;
+                    const int32_t tc_ = nodes[tv ? t_ : 0].canon; const uint8_t eu_ = tx.under_euk[sv ? s_ : 0];
+                    tcanon[k] = tv ? tc_ : -1; euk[k] = sv ? eu_ : 0;
+                }
                 const uint64_t xr = key[k] ^ pk;
                 const bool first = i == 0;
                 if (i < n && !first) {
@@ -206,6 +239,7 @@ __global__ __launch_bounds__(64, 4) void k_score_fast(const mtb_slot16 *__restri
         slow = slow || __any(bad || bad2);
         if (slow) { if (lane == 0) slow_flag[r] = 1; continue; }        /* no shared counter: millions of returning atomics on one address cost tens of ms */
         if (lane == 0) cnt_out[r] = (uint32_t)n_live;
+        MTB_FAST_MARK(2);       /* own elements, flags, links */
         /* ---- chain DP as one segmented prefix sum; candidates for emission ---- */
         float ps[K]; int32_t phd[K]; int32_t root[K];
         bool cand[K];
@@ -235,6 +269,7 @@ __global__ __launch_bounds__(64, 4) void k_score_fast(const mtb_slot16 *__restri
             }
         }
         wave_fence();
+        MTB_FAST_MARK(3);       /* chain prefix sums */
         /* ---- emitted paths -> one per lane ---- */
         int32_t ne = 0;
         bool too_many = false;
@@ -245,8 +280,7 @@ __global__ __launch_bounds__(64, 4) void k_score_fast(const mtb_slot16 *__restri
                 FastPath P; P.start = 0; P.end = 0; P.score = 0.0f; P.ham = 0; P.rehs = 0; P.species = 0;
                 if (cand[k]) {
                     const int32_t spc = (int32_t)(key[k] >> 41);
-                    const bool euk = spc >= 0 && spc <= tx.max_taxid && tx.under_euk[spc];        /* IsAncestor(eukaryota, species), Taxonomer.cpp:497-500 */
-                    const int32_t md = euk ? sp.min_cons_cnt_euk : sp.min_cons_cnt;
+                    const int32_t md = euk[k] ? sp.min_cons_cnt_euk : sp.min_cons_cnt;                  /* IsAncestor(eukaryota, species), Taxonomer.cpp:497-500 */
                     const int32_t rt = root[k];
                     const uint64_t pr = s_pp[rt], rkey = s_key[rt];
                     const uint32_t rreh = (uint32_t)(s_aux[rt] >> 32);
@@ -273,6 +307,7 @@ __global__ __launch_bounds__(64, 4) void k_score_fast(const mtb_slot16 *__restri
         if (too_many) { if (lane == 0) slow_flag[r] = 1; continue; }       /* S3 (cnt_out is rewritten by k_score) */
         if (ne == 0) { if (lane == 0) results[r] = R; continue; }           /* no species produced a path: unclassified, score 0 (:372-375) */
         wave_fence();
+        MTB_FAST_MARK(4);       /* emission */
         /* ---- combination: lane e owns emitted path e ---- */
         FastPath P = s_path[lane < ne ? lane : 0];
         const bool have = lane < ne;
@@ -344,6 +379,7 @@ __global__ __launch_bounds__(64, 4) void k_score_fast(const mtb_slot16 *__restri
             const int32_t spid = rl_i(P.species, slo);
             if (lane == s_idx) { sp_score = sc; sp_id = spid; }
         }
+        MTB_FAST_MARK(5);       /* combination */
         /* ---- species decision (getBestSpeciesMatches second half, chooseBestTaxon early exits) ---- */
         const bool valid = lane < nsp && !(sp_score < sp.min_score);
         const uint64_t vmask = __ballot(valid);
@@ -373,6 +409,10 @@ __global__ __launch_bounds__(64, 4) void k_score_fast(const mtb_slot16 *__restri
         if (n_max > 1) { R.is_classified = 1; R.classification = lca < 0 ? 0 : lca; if (lane == 0) results[r] = R; continue; }
         R.is_classified = 1;
         const int32_t species = only;
+        const bool sp_ok = species >= 0 && species <= tx.max_taxid;
+        mtb_tax_node rs = nodes[sp_ok ? species : 0];                              /* needed by the descent: in flight during the filter */
+        if (!sp_ok) { rs.canon = -1; rs.depth = 0; rs.parent = -1; rs.flags = 0; }
+        MTB_FAST_MARK(6);       /* decision */
         /* ---- redundancy filter over the best species' matches (filterRedundantMatches, :205-241) ---- */
         for (int32_t q = lane; q < nb; q += 64) { s_hmin[q] = 255u; s_btax[q] = -1; }
         wave_fence();
@@ -395,7 +435,7 @@ __global__ __launch_bounds__(64, 4) void k_score_fast(const mtb_slot16 *__restri
                 const int32_t t = (int32_t)tid[k];
                 int32_t old = atomicCAS(&s_btax[bq[k]], -1, t);              /* the first id of a bucket stays raw */
                 while (old != -1) {
-                    const int32_t merged = mtb_lca(&tx, old, t);
+                    const int32_t merged = old == t ? (tcanon[k] < 0 ? t : tcanon[k]) : mtb_lca(&tx, old, t);      /* LCA(a, a) = canon(a), already here */
                     if (merged == old) break;
                     const int32_t seen = atomicCAS(&s_btax[bq[k]], old, merged);
                     if (seen == old) break;
@@ -405,6 +445,7 @@ __global__ __launch_bounds__(64, 4) void k_score_fast(const mtb_slot16 *__restri
         }
         wave_fence();
         const uint64_t off = tc_off[r], room = tc_off[r + 1] - off;
+        MTB_FAST_MARK(7);       /* filter */
         /* Query::taxCnt: distinct bucket taxa in ascending order with their bucket counts (std::map order); the buckets sit two per
          * lane, one wave minimum per distinct taxon (1-2 for most reads).  Taxonomy ids are < 2^22 here. */
         int32_t ntc = 0;
@@ -423,11 +464,28 @@ __global__ __launch_bounds__(64, 4) void k_score_fast(const mtb_slot16 *__restri
             }
         }
         wave_fence();
+        MTB_FAST_MARK(8);       /* gather */
         /* ---- sub-species descent (lowerRankClassification, :252-314) ---- */
         int32_t slow_lr = ntc > MTB_LR_MAXE ? 1 : 0;
         if (!slow_lr && lane < ntc) {
+            /* mtb_lr_climb on the per-taxon record: canon, depth and parent of the entry arrive with one load */
+            const int32_t tax = s_otax[lane];
+            const bool t_ok = tax >= 0 && tax <= tx.max_taxid;
+            mtb_tax_node rt = nodes[t_ok ? tax : 0];
+            if (!t_ok) { rt.canon = -1; rt.depth = 0; rt.parent = -1; rt.flags = 0; }
             int32_t lv;
-            mtb_lr_climb(&tx, s_otax[lane], species, &lv, s_anc + lane * MTB_LR_K);
+            const int32_t cs = rs.canon, c = rt.canon;
+            if (cs < 0 || c < 0) lv = -1;
+            else {
+                const int32_t L = rt.depth - rs.depth;
+                if (L < 0) lv = -1;
+                else if (L > MTB_LR_K) lv = MTB_LR_K + 1;
+                else {
+                    int32_t a = c;
+                    for (int32_t k = L - 1; k >= 0; k--) { s_anc[lane * MTB_LR_K + k] = a; a = (k == L - 1) ? rt.parent : tx.parent[a]; }
+                    lv = (a == cs) ? L : -1;
+                }
+            }
             s_lev[lane] = lv;
             if (lv > MTB_LR_K) slow_lr = 1;
         }
@@ -435,7 +493,7 @@ __global__ __launch_bounds__(64, 4) void k_score_fast(const mtb_slot16 *__restri
         wave_fence();
         if (lane == 0) {
             R.n_taxcnt = (uint16_t)ntc;
-            const int32_t cs = mtb_tax_canon(&tx, species);
+            const int32_t cs = rs.canon;
             if (R.score < sp.min_sp_score) R.classification = (species >= 0 && species <= tx.max_taxid) ? tx.sp_parent[species] : 0;
             else if (slow_lr || cs < 0) R.classification = mtb_lower_rank(&tx, s_otax, s_ocnt, ntc, species, read_len, sp.denominator, sp.accession_level);
             else R.classification = mtb_lr_bfs(s_lev, s_anc, s_ocnt, ntc, cs, read_len, sp.denominator, &tx, sp.accession_level);
@@ -444,7 +502,12 @@ __global__ __launch_bounds__(64, 4) void k_score_fast(const mtb_slot16 *__restri
                 if (off + k < tc_cap) { tc_tax[off + k] = s_otax[k]; tc_cnt[off + k] = s_ocnt[k]; }
             results[r] = R;
         }
+        MTB_FAST_MARK(9);       /* descent + output */
     }
+#ifdef MTB_FAST_DEBUG
+    __syncthreads();
+    if (threadIdx.x < 16) atomicAdd(&mtb_fast_reasons[8 + threadIdx.x], s_ph[threadIdx.x]);
+#endif
 }
 
 #endif

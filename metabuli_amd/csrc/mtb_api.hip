@@ -102,6 +102,7 @@ struct mtb_index {
     mtbhost::Taxonomy tax;
     int32_t *d_canon = nullptr, *d_parent = nullptr, *d_depth = nullptr, *d_spparent = nullptr, *d_tax2species = nullptr;
     uint8_t *d_under = nullptr, *d_accleaf = nullptr;
+    mtb_tax_node *d_node = nullptr;
     mtb_params params;
     uint32_t info_mask = 0xFFFFFFFFu;
     /* amino-acid prefix directory (kernels_dir.h); absent for views and for indices it cannot describe */
@@ -358,6 +359,7 @@ static mtb_tax_view tax_view(const mtb_index *ix) {
     mtb_tax_view v;
     v.acc_leaf = ix->d_accleaf; v.canon = ix->d_canon; v.parent = ix->d_parent; v.depth = ix->d_depth; v.under_euk = ix->d_under; v.sp_parent = ix->d_spparent;
     v.max_taxid = ix->tax.max_id;
+    v.node = ix->d_node;
     return v;
 }
 
@@ -573,6 +575,18 @@ static mtb_status upload_taxonomy(mtb_index *ix) {
     HIPCHK(hipMemcpy(ix->d_tax2species, t.tax2species.data(), n * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ix->d_under, t.under_euk.data(), n, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ix->d_accleaf, t.acc_leaf.data(), n, hipMemcpyHostToDevice));
+    {   /* the same per taxid in one record (k_score_fast) */
+        std::vector<mtb_tax_node> nodes(n);
+        for (size_t i = 0; i < n; i++) {
+            const int32_t c = t.canon[i];
+            nodes[i].canon = c;
+            nodes[i].depth = c >= 0 ? t.depth[(size_t)c] : 0;
+            nodes[i].parent = c >= 0 ? t.parent[(size_t)c] : -1;
+            nodes[i].flags = c >= 0 ? ((t.under_euk[(size_t)c] ? 1u : 0u) | (t.acc_leaf[(size_t)c] ? 2u : 0u)) : 0u;
+        }
+        HIPCHK(hipMalloc((void **)&ix->d_node, n * sizeof(mtb_tax_node)));
+        HIPCHK(hipMemcpy(ix->d_node, nodes.data(), n * sizeof(mtb_tax_node), hipMemcpyHostToDevice));
+    }
     return MTB_OK;
 }
 
@@ -799,6 +813,7 @@ void mtb_index_close(mtb_index *ix) {
     if (ix->d_tax2species) e = hipFree(ix->d_tax2species);
     if (ix->d_under) e = hipFree(ix->d_under);
     if (ix->d_accleaf) e = hipFree(ix->d_accleaf);
+    if (ix->d_node) e = hipFree(ix->d_node);
     (void)e;
     delete ix;
 }
@@ -1462,9 +1477,9 @@ mtb_status mtb_debug_phase_cycles(mtb_ctx *c, unsigned long long *out4) {
 /* debugging build only: read and reset the k_score_fast exit counters */
 mtb_status mtb_debug_fast_reasons(mtb_ctx *c, unsigned long long *out8) {
     HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipMemcpyFromSymbol(out8, HIP_SYMBOL(mtb_fast_reasons), 64));
-    unsigned long long z[8] = {0};
-    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(mtb_fast_reasons), z, 64));
+    HIPCHK(hipMemcpyFromSymbol(out8, HIP_SYMBOL(mtb_fast_reasons), 256));      /* 32 counters */
+    unsigned long long z[32] = {0};
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(mtb_fast_reasons), z, 256));
     return MTB_OK;
 }
 #endif

@@ -391,7 +391,12 @@ typedef struct {
     const uint8_t *under_euk;   /* IsAncestor(eukaryota, taxid)  (Taxonomer.cpp:497-500)       */
     const int32_t *sp_parent;   /* parent(getTaxIdAtRank(taxid,"species")) (Taxonomer.cpp:178-185) */
     int32_t max_taxid;
+    const void *node;           /* optional: mtb_tax_node[max_taxid + 1], the fields above gathered per taxid (one 16-byte load) */
 } mtb_tax_view;
+
+/* canon / depth / parent of a taxid behind ONE load: the scorer's taxonomy walks are chains of dependent lookups in
+ * separate arrays (canon -> depth -> parent ...), each an L2 round trip; with the record a strain-under-species climb needs one. */
+typedef struct { int32_t canon; int32_t depth; int32_t parent; uint32_t flags; } mtb_tax_node;      /* flags: 1 = under Eukaryota, 2 = accession-level leaf; of the canonical node */
 
 typedef struct {
     int32_t max_codon_shift, dna_shift, denominator;  /* Taxonomer.cpp:34-48 */

@@ -109,41 +109,48 @@ class GpuStages:
         return self.ctx.part_score(self.index, self.params, matches.data_ptr(), int(matches.shape[0]), self.n_reads)
 
 
-# rows of one all_to_all_single call are bounded: torch 2.10 + RCCL 2.26 return corrupt data for variable-split
-# exchanges beyond ~1 GiB per call (measured on MI355X, world_size 1: 1.0 GiB intact, 1.5 GiB not); 512 MiB
-# per call still means >= 64 MiB per peer at 8 GPUs, far above the xGMI latency regime
+# One message is bounded: torch 2.10 + RCCL 2.26 returned corrupt data for variable-split all_to_all_single calls beyond
+# ~1 GiB per call (measured on MI355X at world_size 1 only -- no multi-GPU node was available to the builder: 1.0 GiB
+# intact, 1.5 GiB not; to be re-tested at world_size >= 2).  512 MiB per peer and round is far above the xGMI latency regime.
 _XCHG_BYTES = 512 << 20
 
 
 def _exchange(torch, dist, send, send_counts, width, xdev):
-    """all-to-all(v) of [n, width] int64 rows; returns (received rows, per-source row counts)."""
-    world = dist.get_world_size()
-    sc = torch.tensor(send_counts, dtype=torch.int64, device=xdev)
-    rc = torch.empty(world, dtype=torch.int64, device=xdev)
-    dist.all_to_all_single(rc, sc)
-    mx = torch.tensor([max(send_counts) if send_counts else 0], dtype=torch.int64, device=xdev)
-    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-    recv_counts = [int(x) for x in rc.cpu().tolist()]
+    """all-to-all(v) of [n, width] int64 rows; returns (received rows, per-source row counts).
+
+    One small collective for the counts: every rank all-gathers its send-count vector, so each rank reads its receive
+    counts (a column of the matrix) and the global maximum (number of rounds) from ONE host copy -- no second collective,
+    no second sync.  The payload moves as point-to-point messages between views of the send / receive buffers
+    (batch_isend_irecv = one ncclGroup per round on RCCL): nothing is concatenated or copied back, the own share is a
+    device-to-device copy, and a peer's share is cut into rounds of at most _XCHG_BYTES."""
+    world, me = dist.get_world_size(), dist.get_rank()
+    sc = torch.tensor([int(x) for x in send_counts], dtype=torch.int64, device=xdev)
+    allc = torch.empty(world * world, dtype=torch.int64, device=xdev)
+    dist.all_gather_into_tensor(allc, sc)
+    mat = allc.cpu().view(world, world)                       # mat[src][dst]
+    recv_counts = [int(x) for x in mat[:, me].tolist()]
     send_counts = [int(x) for x in send_counts]
-    send = send.to(xdev)
+    send = send.to(xdev).contiguous()
     recv = torch.empty((sum(recv_counts), width), dtype=torch.int64, device=xdev)
-    chunk = max(1, _XCHG_BYTES // (8 * width * world))           # rows per peer per call
-    rounds = (int(mx.item()) + chunk - 1) // chunk
     s_off = np.concatenate([[0], np.cumsum(send_counts)]).astype(np.int64)
     r_off = np.concatenate([[0], np.cumsum(recv_counts)]).astype(np.int64)
-    for k in range(rounds):
-        s_n = [max(0, min(chunk, c - k * chunk)) for c in send_counts]
-        r_n = [max(0, min(chunk, c - k * chunk)) for c in recv_counts]
-        if rounds == 1:
-            dist.all_to_all_single(recv, send.contiguous(), r_n, s_n)
-            break
-        part = torch.cat([send[int(s_off[p]) + k * chunk: int(s_off[p]) + k * chunk + s_n[p]] for p in range(world)])
-        got = torch.empty((sum(r_n), width), dtype=torch.int64, device=xdev)
-        dist.all_to_all_single(got, part, r_n, s_n)
-        o = 0
-        for p in range(world):
-            recv[int(r_off[p]) + k * chunk: int(r_off[p]) + k * chunk + r_n[p]] = got[o:o + r_n[p]]
-            o += r_n[p]
+    if send_counts[me]:
+        recv[int(r_off[me]): int(r_off[me]) + send_counts[me]] = send[int(s_off[me]): int(s_off[me]) + send_counts[me]]
+    chunk = max(1, _XCHG_BYTES // (8 * width))                 # rows per peer per round
+    mx = int(mat.max().item()) if world > 1 else 0
+    for k in range((mx + chunk - 1) // chunk):
+        ops = []
+        for d in range(1, world):                              # peer order staggered by rank: no hot spot on the point-to-point links
+            to, frm = (me + d) % world, (me - d) % world
+            s_n = max(0, min(chunk, send_counts[to] - k * chunk))
+            r_n = max(0, min(chunk, recv_counts[frm] - k * chunk))
+            if s_n:
+                ops.append(dist.P2POp(dist.isend, send[int(s_off[to]) + k * chunk: int(s_off[to]) + k * chunk + s_n], to))
+            if r_n:
+                ops.append(dist.P2POp(dist.irecv, recv[int(r_off[frm]) + k * chunk: int(r_off[frm]) + k * chunk + r_n], frm))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
     return recv, recv_counts
 
 
@@ -151,8 +158,8 @@ def classify_partitioned(stages, bounds, dist):
     """One batch on one rank of a range-partitioned index.  `stages` provides extract_sorted(bounds) ->
     (metamers [n,2] sorted by value, count per range), join(run) -> matches [m,3], score(matches) -> results;
     `bounds[p]` is the lower amino-acid-part bound of rank p's range.  Returns what score() returns for this
-    rank's reads.  Collectives: 2 x (counts + payload) all-to-all; with backend "gloo" (CPU tests) the payload
-    is staged through host memory."""
+    rank's reads.  Communication: 2 x (count all-gather + point-to-point payload exchange); with backend "gloo" (CPU tests)
+    the payload is staged through host memory."""
     import torch
     world = dist.get_world_size()
     assert len(bounds) == world, "one value range per rank"

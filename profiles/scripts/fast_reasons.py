@@ -24,7 +24,7 @@ b, o = bench.gen_reads(torch, dev, world, reads, 150, 0.10, 0.005, 1234 + 17)
 res = torch.empty(reads * 24, dtype=torch.uint8, device=dev)
 cap = reads * 40 + 1024
 tt = torch.empty(cap, dtype=torch.int32, device=dev); tc = torch.empty(cap, dtype=torch.int32, device=dev)
-out = (C.c_ulonglong * 8)()
+out = (C.c_ulonglong * 32)()
 for it in range(2):
     ctx.classify_batch_device(ix, params, b.data_ptr(), o.data_ptr(), 0, 0, reads, reads * 150, res.data_ptr(), tt.data_ptr(), tc.data_ptr(), cap)
     M.lib().mtb_debug_fast_reasons(ctx.h, out)
@@ -33,3 +33,7 @@ names = ["tail overflow / buckets", "> 8 species", "S1 not sorted", "S2 group of
 for n, x in zip(names, v):
     print(f"{n:28s} {x:12d}  {x / reads:.4f} per read")
 print("generic:", ctx.last_stats().n_generic_reads)
+ph = ["setup+issue loads", "order+keys", "flags+links", "chain", "emission", "combination", "decision", "filter", "gather", "descent+output"]
+tot = sum(v[8:18])
+for n, x in zip(ph, v[8:18]):
+    print(f"phase {n:22s} {x / reads:10.0f} cycles/read  {100 * x / max(tot, 1):5.1f} %")

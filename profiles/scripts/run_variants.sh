@@ -1,5 +1,5 @@
-# A/B runs of bench.py with environment knobs / library variants; prints stage times from stderr
-for v in "MTB_LIB=metabuli_amd/csrc/libmtb.so" "MTB_LIB=metabuli_amd/csrc/libmtb_vA.so" "MTB_LIB=metabuli_amd/csrc/libmtb.so" "MTB_LIB=metabuli_amd/csrc/libmtb_vA.so"; do
-  env $v timeout 300 python bench.py --steps 2 --warmup 1 --no-parity > gpurun_out/var.json 2> gpurun_out/var.err
-  echo "$v: $(grep 'stage ms' gpurun_out/var.err | cut -c1-160)"
+# A/B runs of bench.py with environment knobs / flags; prints ms per step and stage times
+for v in "--streams 1" "--streams 1"; do
+  timeout 400 python bench.py --steps 6 --warmup 3 --cpu-reads 400000 --no-cpu $v > gpurun_out/var.json 2> gpurun_out/var.err
+  echo "$v: $(python -c "import json; j=json.load(open('gpurun_out/var.json')); print(round(j['ms_per_step'],1), round(j['value'],1), j['parity_sample']['mismatches'], j['config']['reads_scored_by_generic_kernel'], {k: round(x['ms'],1) for k,x in j['kernel_ms'].items() if x['ms']>1})") $(grep 'stage ms' gpurun_out/var.err | cut -c1-150)"
 done
