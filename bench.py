@@ -232,6 +232,7 @@ def main():
     ap.add_argument("--partitioned", action="store_true",
                     help="SURVEY 8(e) row 2: every rank owns one value range of the index; metamers and matches travel by all-to-all "
                          "(functional/perf check of that path; the default is the replicated index)")
+    ap.add_argument("--no-seal", action="store_true", help="keep the flat {value, info} arrays next to the packed state (mtb_index_seal not called)")
     ap.add_argument("--seed", type=int, default=1234)
     args = ap.parse_args()
 
@@ -270,6 +271,16 @@ def main():
     T = ctx.synth_index(args.seed, n_filler, world.filler_tax_lo, world.filler_tax_hi, real_v, real_t, d_values.data_ptr(), d_info.data_ptr())
     taxid_list = np.concatenate([np.unique(real_t), np.arange(world.filler_tax_lo, world.filler_tax_hi + 1, dtype=np.int32)])
     index = ctx.index_from_device(d_values.data_ptr(), d_info.data_ptr(), T, taxdir, taxid_list, params)
+    sealed = False
+    if not args.partitioned and not args.no_seal:
+        # dedicate the index to the fused path: packed 8-byte target words under the amino-acid directory; the info array lent to
+        # the library is no longer needed by it and is freed here (64 GB at 16 G targets)
+        try:
+            index.seal(); sealed = True
+            del d_info
+            torch.cuda.empty_cache()
+        except M.MtbError as e:
+            log(f"[rank {rank}] index not sealed: {e}")
     d_bases2 = None
     if args.seq_mode == 2:
         d_bases, d_offs, d_bases2 = gen_reads(torch, dev, world, args.reads, args.read_len, 0.10, 0.005, args.seed + 17 * (rank + 1), paired=True)
@@ -412,7 +423,8 @@ def main():
                                reads_per_gpu=args.reads, read_len=args.read_len, targets=int(T), seq_mode=args.seq_mode,
                                gbp_per_s=value * args.read_len * (2 if args.seq_mode == 2 else 1) / 1e3, query_metamers=int(st.n_kmers), matches=int(st.n_matches),
                                classified_fraction=frac_cls, parallelism=f"reads sharded x{world_size}, index replicated", streams_per_gpu=args.streams,
-                               sub_batches_per_step=ctx.last_sub_batches, reads_scored_by_generic_kernel=int(ps.n_generic_reads)),
+                               sub_batches_per_step=ctx.last_sub_batches, index_sealed=sealed,
+                               index_bytes=int(T * 8 + 4 * (1801088541 + 1)) if sealed else int(T * 12 + 4 * (1801088541 + 1)), reads_scored_by_generic_kernel=int(ps.n_generic_reads)),
                    stage_ms=dict(extract=st.ms_extract, sort=st.ms_sort, join=st.ms_join, regroup=st.ms_regroup,
                                  segsort=st.ms_segsort, score=st.ms_score, total=st.ms_total),
                    kernel_ms=kern, roofline=roofline, cpu_baseline=cpu, parity_sample=parity)

@@ -149,6 +149,13 @@ mtb_status mtb_index_from_device(mtb_ctx *, const uint64_t *d_values, const uint
                                  uint64_t n_targets, const char *taxonomy_dir,
                                  const int32_t *taxid_list, size_t n_taxids,
                                  const mtb_params *params, mtb_index **out);
+/* Dedicate an index to the fused path (mtb_classify_batch*): its target array goes to the packed state -- one 8-byte word per
+ * target carrying the eighth amino-acid letter, the DNA bits and the info entry under the depth-7 amino-acid directory,
+ * kernels_dir.h -- and info[] is let go of: freed if the library owns it, else the caller may free the array it lent
+ * (mtb_index_from_device).  12 -> 8.4 bytes per target: a 16 G-metamer index takes 135 GB instead of 199 GB.  Entry points
+ * that need the flat arrays (stage calls, download, write, slices) still work: they re-allocate info[] and unpack.
+ * MTB_ERR_UNSUPPORTED if the index is too small for a depth-7 directory or is a view.                            */
+mtb_status mtb_index_seal(mtb_index *);
 void       mtb_index_close(mtb_index *);
 uint64_t   mtb_index_num_targets(const mtb_index *);
 /* Copy the decoded flat index back to the host (parity seam for the codec). */

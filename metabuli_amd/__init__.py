@@ -307,6 +307,10 @@ class Index:
     def num_targets(self):
         return self.ctx.L.mtb_index_num_targets(self.h)
 
+    def seal(self):
+        """mtb_index_seal: packed state + info[] released (the lender of a borrowed info array may free it afterwards)"""
+        _chk(self.ctx.L.mtb_index_seal(self.h))
+
     def original_id(self, taxid):
         """TaxonomyWrapper::getOriginalTaxID: internal id (what results carry) -> the id the reports print"""
         return int(self.ctx.L.mtb_tax_original_id(self.h, C.c_int32(int(taxid))))

@@ -108,6 +108,7 @@ struct mtb_index {
     /* amino-acid prefix directory (kernels_dir.h); absent for views and for indices it cannot describe */
     uint32_t *d_dir = nullptr; uint64_t *d_dirbase = nullptr; int32_t dir_L = 0; uint32_t dir_buckets = 0;
     bool packed = false;             /* d_values holds packed words (kernels_dir.h): the fused join's state; everything else unpacks first */
+    bool info_owned = false;         /* d_info was (re)allocated by the library although the value array is borrowed (after mtb_index_seal) */
 };
 
 template <typename T>
@@ -629,6 +630,11 @@ static mtb_dir_view dir_view(const mtb_index *ix) {
 static mtb_status ensure_flat(mtb_index *ix) {
     if (!ix || !ix->packed) return MTB_OK;
     mtb_ctx *c = ix->ctx;
+    if (!ix->d_info) {                                  /* sealed: info[] was let go of; the flat state needs it back */
+        hipError_t e = hipMalloc((void **)&ix->d_info, std::max<uint64_t>(ix->T, 1) * 4);
+        if (e != hipSuccess) { ix->d_info = nullptr; return fail(MTB_ERR_OOM, "no HBM to restore info[] of a sealed index"); }
+        ix->info_owned = true;
+    }
     hipLaunchKernelGGL(k_index_unpack, dim3((uint32_t)std::min<uint64_t>(((uint64_t)ix->dir_buckets + 255) / 256, 1u << 20)), dim3(256), 0, c->stream, ix->d_values, ix->d_info, dir_view(ix));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -804,6 +810,7 @@ void mtb_index_close(mtb_index *ix) {
     if (!ix) return;
     hipError_t e = hipSuccess;
     if (ix->own) { if (ix->d_values) e = hipFree(ix->d_values); if (ix->d_info) e = hipFree(ix->d_info); }
+    else if (ix->info_owned && ix->d_info) e = hipFree(ix->d_info);
     if (ix->own_tax) { if (ix->d_dir) e = hipFree(ix->d_dir); if (ix->d_dirbase) e = hipFree(ix->d_dirbase); }     /* views never own a directory */
     if (!ix->own_tax) { (void)e; delete ix; return; }
     if (ix->d_canon) e = hipFree(ix->d_canon);
@@ -818,6 +825,19 @@ void mtb_index_close(mtb_index *ix) {
     delete ix;
 }
 uint64_t mtb_index_num_targets(const mtb_index *ix) { return ix ? ix->T : 0; }
+
+mtb_status mtb_index_seal(mtb_index *ix) {
+    if (!ix) return fail(MTB_ERR_ARG, "NULL index");
+    mtb_ctx *c = ix->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    if (!ix->d_dir || ix->dir_L != 7 || !ix->own_tax) return fail(MTB_ERR_UNSUPPORTED, "index has no depth-7 directory (too small, or a view): nothing to seal");
+    STCHK(ensure_packed(ix));
+    if (!ix->packed) return fail(MTB_ERR_UNSUPPORTED, "packing is disabled");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (ix->d_info && (ix->own || ix->info_owned)) { hipError_t e = hipFree(ix->d_info); (void)e; }
+    ix->d_info = nullptr; ix->info_owned = false;       /* a borrowed info[] now belongs to the caller alone */
+    return MTB_OK;
+}
 
 mtb_status mtb_index_download(mtb_index *ix, uint64_t *values, uint32_t *info, uint64_t cap) {
     if (!ix) return fail(MTB_ERR_ARG, "NULL index");
@@ -1259,7 +1279,8 @@ static mtb_status classify_budgeted(mtb_ctx *c, mtb_index *ix, const mtb_params 
         const double yield = (c->extract_yield > 0.0 ? c->extract_yield : (p->syncmer ? 1.0 : 2.0)) * 1.15;
         per_base = yield * (16 + 16 + 2 + 2) + (p->seq_mode == 3 ? yield * 1.5 * 48 : yield * 1.2 * 16 + 24.0 * 16 / std::max(mean_len, 1.0)) + 100.0 / std::max(mean_len, 1.0);
     }
-    uint64_t fit = (uint64_t)((double)budget / (per_base * 1.08 * mean_len));          /* reads per sub-batch */
+    const double safety = c->ws_per_base > 0.0 ? 1.02 : 1.08;                           /* measured on the previous batch / first-call estimate */
+    uint64_t fit = (uint64_t)((double)budget / (per_base * safety * mean_len));        /* reads per sub-batch */
     fit = std::max<uint64_t>(fit, 1);
     uint64_t n_sub = (n_reads + fit - 1) / fit;
     mtb_batch_stats S; memset(&S, 0, sizeof(S));

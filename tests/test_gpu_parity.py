@@ -581,7 +581,10 @@ def test_packed_index_state_round_trips(toy, monkeypatch, tmp_path):
     monkeypatch.delenv("MTB_DIR_DEPTH")
     res, tt, tc = c.classify_batch(ix, p, toy.b1, toy.o1, toy.b2, toy.o2)          # packs
     _check_results(toy, res, tt, tc)
-    v, info = ix.download()                                                          # unpacks
+    ix.seal()                                                                        # info[] released: 8 bytes per target + directory
+    res, tt, tc = c.classify_batch(ix, p, toy.b1, toy.o1, toy.b2, toy.o2)
+    _check_results(toy, res, tt, tc)
+    v, info = ix.download()                                                          # info[] re-allocated, unpacks
     assert (v == toy.values).all() and (info.astype(np.int32) == toy.taxids).all()
     res, tt, tc = c.classify_batch(ix, p, toy.b1, toy.o1, toy.b2, toy.o2)          # packs again
     _check_results(toy, res, tt, tc)
