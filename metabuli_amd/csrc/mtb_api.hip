@@ -123,7 +123,11 @@ static mtb_status ensure(mtb_ctx *c, const char *name, size_t elems, T **out) {
         HIPCHK(hipMemGetInfo(&fr, &tot));
         if (want > fr) { want = bytes; if (want > fr) return fail(MTB_ERR_OOM, std::string("not enough HBM for buffer ") + name); }
         hipError_t e = hipMalloc(&b.p, want);
-        if (e != hipSuccess) { b.p = nullptr; return fail(MTB_ERR_OOM, std::string("hipMalloc failed for ") + name + ": " + hipGetErrorString(e)); }
+        if (e != hipSuccess) {
+            b.p = nullptr;
+            (void)hipGetLastError();          /* the failure is reported here: do not leave it in the runtime's sticky slot for the next hipGetLastError() check */
+            return fail(MTB_ERR_OOM, std::string("hipMalloc failed for ") + name + ": " + hipGetErrorString(e));
+        }
         b.cap = want;
     }
     *out = (T *)b.p;
@@ -506,7 +510,6 @@ static mtb_status dev_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, uint
         }
         unsigned long long *d_work = nullptr;
         if (dynamic) { d_work = (unsigned long long *)(c->d_xscal + 4 + pass); HIPCHK(hipMemsetAsync(d_work, 0, 8, c->stream)); }
-        KTimer kt(c, pass == 0 ? MTB_K_SCORE : MTB_K_SEGSORT);      /* the deferred reads' launch is booked with the large-segment path */
 #define MTB_LAUNCH_SCORE(SRT, K, CAPV, DYNV, SLOTV) hipLaunchKernelGGL((k_score<SRT, K, mtb_match, CAPV, DYNV, SLOTV>), dim3(grid), dim3(64), 0, c->stream, S->m, S->seg, n_reads, d_qlen, \
         d_qlen2, tax_view(ix), sp, (const uint64_t *)d_tcoff, d_res, d_tc_tax, d_tc_cnt, tc_cap, d_slabs, slab_bytes, slab_n, slab_nb, (mtb_match *)nullptr,  \
         tc_base, S->list, S->n_list, S->cursor, S->stride, S->seg_by_list, S->direct, S->epoch, S->big_list, S->n_big, S->cnt_out, d_work, S->only_flagged)
@@ -527,6 +530,7 @@ static mtb_status dev_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, uint
             S_rest = *S; S_rest.only_flagged = d_slow;
             S = &S_rest;
         }
+        KTimer kt(c, pass == 0 ? MTB_K_SCORE : MTB_K_SEGSORT);      /* the deferred reads' launch is booked with the large-segment path */
         if (S->cursor) {              /* slot mode (always sorts in the kernel); LDS staging capacity chosen by the caller */
 #define MTB_LAUNCH_SLOT(CAPV) do { if (key64) MTB_LAUNCH_SCORE(true, true, CAPV, false, true); else MTB_LAUNCH_SCORE(true, false, CAPV, false, true); } while (0)
             if (S->cap <= 144) MTB_LAUNCH_SLOT(144);
@@ -1272,7 +1276,7 @@ static mtb_status classify_budgeted(mtb_ctx *c, mtb_index *ix, const mtb_params 
     HIPCHK(hipMemGetInfo(&fr, &tot));
     const size_t held = held_bytes(c);
     uint64_t budget = c->ws_limit ? c->ws_limit : (uint64_t)fr + held;
-    if (!c->ws_limit) budget -= std::min<uint64_t>(budget / 16, 2ull << 30);          /* allocator granularity, other users of the device */
+    if (!c->ws_limit) budget -= std::min<uint64_t>(budget / 16, 4ull << 30);          /* allocator granularity, kernel scratch, other users of the device */
     const double mean_len = (double)n_bases_total / (double)n_reads;
     double per_base = c->ws_per_base;
     if (per_base <= 0.0) {
