@@ -272,7 +272,7 @@ def main():
     taxid_list = np.concatenate([np.unique(real_t), np.arange(world.filler_tax_lo, world.filler_tax_hi + 1, dtype=np.int32)])
     index = ctx.index_from_device(d_values.data_ptr(), d_info.data_ptr(), T, taxdir, taxid_list, params)
     sealed = False
-    if not args.partitioned and not args.no_seal:
+    if not args.partitioned and not args.no_seal and args.seq_mode != 3:       # long reads take the exact-segment join, which works on the flat arrays
         # dedicate the index to the fused path: packed 8-byte target words under the amino-acid directory; the info array lent to
         # the library is no longer needed by it and is freed here (64 GB at 16 G targets)
         try:

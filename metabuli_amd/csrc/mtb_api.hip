@@ -1277,6 +1277,7 @@ static mtb_status classify_budgeted(mtb_ctx *c, mtb_index *ix, const mtb_params 
     const size_t held = held_bytes(c);
     uint64_t budget = c->ws_limit ? c->ws_limit : (uint64_t)fr + held;
     if (!c->ws_limit) budget -= std::min<uint64_t>(budget / 16, 4ull << 30);          /* allocator granularity, kernel scratch, other users of the device */
+    if (p->seq_mode == 3 && !c->ws_limit) budget -= std::min<uint64_t>(budget / 3, 48ull << 30);     /* the slab pool of the large-segment scorer does not scale with the batch */
     const double mean_len = (double)n_bases_total / (double)n_reads;
     double per_base = c->ws_per_base;
     if (per_base <= 0.0) {
