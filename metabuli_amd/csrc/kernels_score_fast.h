@@ -64,6 +64,16 @@ __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_A
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) { MTB_DPP_RED(v, MTB_MINU); return (uint32_t)__builtin_amdgcn_readlane((int)v, 63); }
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { MTB_DPP_RED(v, MTB_MAXU); return (uint32_t)__builtin_amdgcn_readlane((int)v, 63); }
 
+/* The compareMatches key of a match as two 32-bit words (all arithmetic on it is 32-bit: the kernel is VALU bound):
+ *   hi = species[10..31] frame[7..9] position >> 4 [0..6]        lo = position & 15 [27..30] hamming[24..26] dna[0..23]
+ * (hi, lo) compared lexicographically = (species, frame, position, hamming, dna).  Needs species < 2^22, positions < 2^11. */
+struct FKey { uint32_t lo, hi; };
+__device__ __forceinline__ uint32_t fk_species(const FKey &k) { return k.hi >> 10; }
+__device__ __forceinline__ uint32_t fk_frame(const FKey &k) { return (k.hi >> 7) & 7u; }
+__device__ __forceinline__ uint32_t fk_pos(const FKey &k) { return ((k.hi & 127u) << 4) | (k.lo >> 27); }
+__device__ __forceinline__ uint32_t fk_ham(const FKey &k) { return (k.lo >> 24) & 7u; }
+__device__ __forceinline__ uint32_t fk_dna(const FKey &k) { return k.lo & 0xFFFFFFu; }
+
 /* emitted path, one per lane during the combination */
 struct FastPath { int32_t start, end; float score; int32_t ham; uint32_t rehs; /* start_reh | end_reh << 16 */ int32_t species; };
 
@@ -75,7 +85,7 @@ __global__ __launch_bounds__(64, 4) void k_score_fast(const mtb_slot16 *__restri
                                                        const uint32_t *__restrict__ cursor, uint32_t stride, uint32_t direct, uint32_t epoch,
                                                        uint8_t *__restrict__ slow_flag, uint32_t *__restrict__ cnt_out) {
     constexpr int NMAX = 64 * K;
-    __shared__ uint64_t s_key[NMAX];            /* sort keys of the compacted slots                     */
+    __shared__ FKey s_key[NMAX];                /* sort keys of the compacted slots                     */
     __shared__ uint64_t s_aux[NMAX];            /* target id | right_end_hamming << 32                  */
     __shared__ uint64_t s_pp[NMAX];             /* prefix sums of the chain increments: score | hd << 32 */
     __shared__ FastPath s_path[64];
@@ -171,7 +181,10 @@ __global__ __launch_bounds__(64, 4) void k_score_fast(const mtb_slot16 *__restri
         for (int k = 0; k < K; k++) {
             if (live[k] && !slow) {
                 const uint64_t b = x[k].b;
-                s_key[dst[k]] = ((x[k].a >> 32) << 41) | (((b >> 52) & 7ull) << 38) | (((b >> 40) & 0x7FFull) << 27) | (((b >> 55) & 7ull) << 24) | (b & 0xFFFFFFull);
+                const uint32_t bh = (uint32_t)(b >> 32), ps_ = (bh >> 8) & 0x7FFu;          /* slot word b: epoch ham[23..26] frame[20..22] pos[8..19] | reh dna */
+                FKey fk; fk.hi = ((uint32_t)(x[k].a >> 32) << 10) | (((bh >> 20) & 7u) << 7) | (ps_ >> 4);
+                fk.lo = ((ps_ & 15u) << 27) | (((bh >> 23) & 7u) << 24) | ((uint32_t)b & 0xFFFFFFu);
+                s_key[dst[k]] = fk;
                 s_aux[dst[k]] = (x[k].a & 0xFFFFFFFFull) | (((b >> 24) & 0xFFFFull) << 32);
             }
         }
@@ -181,7 +194,7 @@ __global__ __launch_bounds__(64, 4) void k_score_fast(const mtb_slot16 *__restri
         if (!slow && n == 0) { if (lane == 0) { cnt_out[r] = (uint32_t)n_live; results[r] = R; } continue; }
         wave_fence();
         /* ---- own elements, neighbours, structure checks ---- */
-        uint64_t key[K]; uint32_t tid[K], reh[K];
+        FKey key[K]; uint32_t tid[K], reh[K];
         int32_t tcanon[K]; uint8_t euk[K];
         const mtb_tax_node *nodes = (const mtb_tax_node *)tx.node;
         bool bhead[K], linked[K];
@@ -195,10 +208,10 @@ __global__ __launch_bounds__(64, 4) void k_score_fast(const mtb_slot16 *__restri
 #pragma unroll
         for (int k = 0; k < K; k++) {
             const int32_t i = lane + 64 * k;
-            key[k] = 0; tid[k] = 0; reh[k] = 0; bhead[k] = true; linked[k] = false; shv[k] = 0; tcanon[k] = -1; euk[k] = 0;
+            key[k].lo = 0; key[k].hi = 0; tid[k] = 0; reh[k] = 0; bhead[k] = true; linked[k] = false; shv[k] = 0; tcanon[k] = -1; euk[k] = 0;
             bmask[k] = ~0ull; lmask[k] = 0; rmask[k] = 0;
             if (k < nslot && !slow) {
-                uint64_t pk = 0;
+                FKey pk; pk.lo = 0; pk.hi = 0;
                 if (i < n) {
                     key[k] = s_key[i]; const uint64_t a = s_aux[i]; tid[k] = (uint32_t)a; reh[k] = (uint32_t)(a >> 32); if (i > 0) pk = s_key[i - 1];
                     /* taxonomy lookups this match may need later, issued now and all at once: its target's canonical id (redundancy
@@ -206,25 +219,24 @@ __global__ __launch_bounds__(64, 4) void k_score_fast(const mtb_slot16 *__restri
                      * round trips of such lookups, so they must not queue up behind each other */
                 }
                 {   /* unconditional loads from clamped indices (a load under a branch is waited for at the branch's end) */
-                    const int32_t t_ = (int32_t)tid[k], s_ = (int32_t)(key[k] >> 41);
+                    const int32_t t_ = (int32_t)tid[k], s_ = (int32_t)fk_species(key[k]);
                     const bool tv = i < n && t_ >= 0 && t_ <= tx.max_taxid, sv = i < n && s_ >= 0 && s_ <= tx.max_taxid;
                     const int32_t tc_ = nodes[tv ? t_ : 0].canon; const uint8_t eu_ = tx.under_euk[sv ? s_ : 0];
                     tcanon[k] = tv ? tc_ : -1; euk[k] = sv ? eu_ : 0;
                 }
-                const uint64_t xr = key[k] ^ pk;
                 const bool first = i == 0;
                 if (i < n && !first) {
-                    if (pk > key[k]) bad = true;                        /* S1: not in compareMatches order */
-                    if ((xr >> 27) == 0) bad2 = true;                   /* S2: two matches in one position group */
+                    if (pk.hi > key[k].hi || (pk.hi == key[k].hi && pk.lo > key[k].lo)) bad = true;      /* S1: not in compareMatches order */
+                    if (pk.hi == key[k].hi && ((pk.lo ^ key[k].lo) >> 27) == 0) bad2 = true;              /* S2: two matches in one position group */
                 }
-                bhead[k] = i >= n || first || (xr >> 38) != 0;
+                bhead[k] = i >= n || first || ((pk.hi ^ key[k].hi) >> 7) != 0;
                 if (i < n && !bhead[k]) {
-                    const int32_t pos = (int32_t)((key[k] >> 27) & 0x7FFu), ppos = (int32_t)((pk >> 27) & 0x7FFu);
+                    const int32_t pos = (int32_t)fk_pos(key[k]), ppos = (int32_t)fk_pos(pk);
                     const int32_t s = (pos - ppos) / 3;
                     if (s > 0 && s <= sp.max_codon_shift) {
                         shv[k] = s;
-                        const bool fwd = ((key[k] >> 38) & 7u) < 3u;
-                        linked[k] = mtb_consecutive((uint32_t)pk & 0xFFFFFFu, (uint32_t)key[k] & 0xFFFFFFu, s, fwd, sp.kmer_format);
+                        const bool fwd = fk_frame(key[k]) < 3u;
+                        linked[k] = mtb_consecutive(fk_dna(pk), fk_dna(key[k]), s, fwd, sp.kmer_format);
                     }
                 }
                 bmask[k] = __ballot(bhead[k]);
@@ -279,19 +291,19 @@ __global__ __launch_bounds__(64, 4) void k_score_fast(const mtb_slot16 *__restri
                 bool e = false;
                 FastPath P; P.start = 0; P.end = 0; P.score = 0.0f; P.ham = 0; P.rehs = 0; P.species = 0;
                 if (cand[k]) {
-                    const int32_t spc = (int32_t)(key[k] >> 41);
+                    const int32_t spc = (int32_t)fk_species(key[k]);
                     const int32_t md = euk[k] ? sp.min_cons_cnt_euk : sp.min_cons_cnt;                  /* IsAncestor(eukaryota, species), Taxonomer.cpp:497-500 */
                     const int32_t rt = root[k];
-                    const uint64_t pr = s_pp[rt], rkey = s_key[rt];
+                    const uint64_t pr = s_pp[rt]; const FKey rkey = s_key[rt];
                     const uint32_t rreh = (uint32_t)(s_aux[rt] >> 32);
                     const int32_t dhd = phd[k] - (int32_t)(uint32_t)(pr >> 32);
                     const int32_t depth = 1 + (dhd & 0xFFFF);
                     if (depth >= md) {
                         e = true;
-                        P.start = (int32_t)((rkey >> 27) & 0x7FFu);
-                        P.end = (int32_t)((key[k] >> 27) & 0x7FFu) + 23;
+                        P.start = (int32_t)fk_pos(rkey);
+                        P.end = (int32_t)fk_pos(key[k]) + 23;
                         P.score = mtb_part_score(rreh, 8, false) + (rt == lane + 64 * k ? 0.0f : ps[k] - __uint_as_float((uint32_t)pr));
-                        P.ham = (int32_t)((rkey >> 24) & 7u) + (rt == lane + 64 * k ? 0 : (dhd >> 16));
+                        P.ham = (int32_t)fk_ham(rkey) + (rt == lane + 64 * k ? 0 : (dhd >> 16));
                         P.rehs = rreh | (reh[k] << 16);
                         P.species = spc;
                     }
@@ -422,16 +434,16 @@ __global__ __launch_bounds__(64, 4) void k_score_fast(const mtb_slot16 *__restri
             bq[k] = -1;
             if (k < nslot) {
                 const int32_t i = lane + 64 * k;
-                if (i < n && (int32_t)(key[k] >> 41) == species) {
-                    const int32_t q = (int32_t)((((uint32_t)(key[k] >> 27) & 0x7FFu) * div_m) >> 16);
-                    if (q < nb) { bq[k] = q; atomicMin(&s_hmin[q], (uint32_t)((key[k] >> 24) & 7u)); }
+                if (i < n && (int32_t)fk_species(key[k]) == species) {
+                    const int32_t q = (int32_t)((fk_pos(key[k]) * div_m) >> 16);
+                    if (q < nb) { bq[k] = q; atomicMin(&s_hmin[q], fk_ham(key[k])); }
                 }
             }
         }
         wave_fence();
 #pragma unroll
         for (int k = 0; k < K; k++) {
-            if (k < nslot && bq[k] >= 0 && (uint32_t)((key[k] >> 24) & 7u) == s_hmin[bq[k]]) {
+            if (k < nslot && bq[k] >= 0 && fk_ham(key[k]) == s_hmin[bq[k]]) {
                 const int32_t t = (int32_t)tid[k];
                 int32_t old = atomicCAS(&s_btax[bq[k]], -1, t);              /* the first id of a bucket stays raw */
                 while (old != -1) {
