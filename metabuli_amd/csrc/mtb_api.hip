@@ -693,12 +693,31 @@ static mtb_status plan_parts(const std::string &d, uint32_t n_parts, PartPlan *p
     return MTB_OK;
 }
 
-template <class T> static bool read_range(const std::string &path, uint64_t lo, uint64_t hi, std::vector<T> *v) {
-    FILE *f = fopen(path.c_str(), "rb"); if (!f) return false;
-    v->resize((size_t)(hi - lo));
-    bool ok = fseek(f, (long)(lo * sizeof(T)), SEEK_SET) == 0 && fread(v->data(), sizeof(T), v->size(), f) == v->size();
+/* bytes [off, off + len) of a file -> device memory, double-buffered through pinned host memory */
+static mtb_status stream_file_to_device(mtb_ctx *c, const std::string &path, uint64_t off, uint64_t len, void *d_dst) {
+    if (len == 0) return MTB_OK;
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return fail(MTB_ERR_IO, "cannot open " + path);
+    if (fseeko(f, (off_t)off, SEEK_SET) != 0) { fclose(f); return fail(MTB_ERR_IO, "cannot seek in " + path); }
+    const size_t CH = 64u << 20;
+    void *buf[2] = {nullptr, nullptr}; hipEvent_t ev[2]; bool used[2] = {false, false};
+    mtb_status st = MTB_OK;
+    if (hipHostMalloc(&buf[0], CH, hipHostMallocDefault) != hipSuccess || hipHostMalloc(&buf[1], CH, hipHostMallocDefault) != hipSuccess ||
+        hipEventCreate(&ev[0]) != hipSuccess || hipEventCreate(&ev[1]) != hipSuccess) { (void)hipGetLastError(); st = fail(MTB_ERR_OOM, "no pinned host memory for the index upload"); }
+    uint64_t done = 0; int k = 0;
+    while (st == MTB_OK && done < len) {
+        const size_t n = (size_t)std::min<uint64_t>(CH, len - done);
+        if (used[k] && hipEventSynchronize(ev[k]) != hipSuccess) { st = fail(MTB_ERR_DEVICE, "hipEventSynchronize failed during the index upload"); break; }
+        if (fread(buf[k], 1, n, f) != n) { st = fail(MTB_ERR_IO, "short read from " + path); break; }
+        if (hipMemcpyAsync((char *)d_dst + done, buf[k], n, hipMemcpyHostToDevice, c->stream) != hipSuccess || hipEventRecord(ev[k], c->stream) != hipSuccess) {
+            st = fail(MTB_ERR_DEVICE, "H2D copy failed during the index upload"); break; }
+        used[k] = true; done += n; k ^= 1;
+    }
+    hipError_t e = hipStreamSynchronize(c->stream); (void)e;
     fclose(f);
-    return ok;
+    for (int i = 0; i < 2; i++) { if (buf[i]) e = hipHostFree(buf[i]); }
+    e = hipEventDestroy(ev[0]); e = hipEventDestroy(ev[1]); (void)e;
+    return st;
 }
 
 static mtb_status open_impl(mtb_ctx *c, const char *dbdir, const char *taxonomy_dir, mtb_params *params, uint32_t part, uint32_t n_parts, mtb_index **out) {
@@ -740,11 +759,9 @@ static mtb_status open_impl(mtb_ctx *c, const char *dbdir, const char *taxonomy_
     mtb_status st = upload_taxonomy(ix);
     if (st != MTB_OK) { mtb_index_close(ix); return st; }
     if (P.empty) { ix->T = 0; *out = ix; return MTB_OK; }
-    /* only this partition's byte ranges are read from the files */
-    std::vector<uint16_t> diff; std::vector<uint32_t> info;
-    if (!read_range(d + "/diffIdx", P.diff_lo, P.diff_hi, &diff) || !read_range(d + "/info", P.info_lo, P.info_hi, &info)) {
-        mtb_index_close(ix); return fail(MTB_ERR_IO, "cannot read diffIdx/info in " + d); }
-    const uint64_t n16 = diff.size(), T = info.size();
+    /* only this partition's byte ranges are read from the files, streamed through two pinned 64 MiB buffers straight into HBM
+     * (fread of chunk k+1 overlaps the H2D copy of chunk k): no whole-file copy in host memory, whatever the database size */
+    const uint64_t n16 = P.diff_hi - P.diff_lo, T = P.info_hi - P.info_lo;
     const uint64_t expect = T - (P.explicit_first ? 1 : 0) + (P.drop_last ? 1 : 0);     /* metamers coded in the byte range */
     /* decode on the GPU: terminators per tile -> offsets -> deltas -> inclusive scan */
     uint16_t *d_diff; uint32_t *d_tc; uint64_t *d_toff; uint64_t *d_ws;
@@ -753,7 +770,8 @@ static mtb_status open_impl(mtb_ctx *c, const char *dbdir, const char *taxonomy_
         (st = ensure(c, "difftoff", tiles + 1, &d_toff)) != MTB_OK ||
         (st = ensure(c, "scanws", scan_ws_elems(std::max<uint64_t>(tiles + 1, T + 1)), &d_ws)) != MTB_OK) { mtb_index_close(ix); return st; }
     HIPCHK(hipMalloc((void **)&ix->d_values, (T + 1) * 8)); HIPCHK(hipMalloc((void **)&ix->d_info, T * 4));
-    if ((st = h2d(c, d_diff, diff.data(), n16 * 2)) != MTB_OK || (st = h2d(c, ix->d_info, info.data(), T * 4)) != MTB_OK) { mtb_index_close(ix); return st; }
+    if ((st = stream_file_to_device(c, d + "/diffIdx", P.diff_lo * 2, n16 * 2, d_diff)) != MTB_OK ||
+        (st = stream_file_to_device(c, d + "/info", P.info_lo * 4, T * 4, ix->d_info)) != MTB_OK) { mtb_index_close(ix); return st; }
     hipLaunchKernelGGL(k_diff_tile_count, dim3((uint32_t)tiles), dim3(256), 0, c->stream, (const uint16_t *)d_diff, n16, d_tc);
     scan_launch<uint32_t, uint64_t, false>(c->stream, d_tc, tiles, true, d_toff, d_ws);
     uint64_t found = 0;

@@ -144,6 +144,21 @@ def test_empty_and_ragged_inputs(ctx, orc):
     # zero reads
     k, _, _ = ctx.extract(M.default_params(), np.zeros(0, np.uint8), np.zeros(1, np.uint64))
     assert len(k) == 0
+    # pairs: a pair is skipped entirely when EITHER mate is too short (KmerExtractor.cpp:443-446, 450-453), the query
+    # lengths are still reported; mate-2 positions are shifted by used(L1) + 3
+    long_ = b"ACGTTTGACCATGGCATTAGCCGATTACAGGCATCGAGGCTAGCTAGGATCGATCGGGATCTAGCTAGCAACGTTTGACCATGGCATTAGCC"
+    m1 = [long_, b"ACGTACGTACGT", long_, long_[:26], long_, b""]
+    m2 = [long_[::-1], long_, b"ACGTACGTACGTACGTACGTACGTA", long_, long_[:40], long_]
+    def cat(seqs):
+        o = np.zeros(len(seqs) + 1, np.uint64); o[1:] = np.cumsum([len(x) for x in seqs])
+        return np.frombuffer(b"".join(seqs), dtype=np.uint8).copy(), o
+    b1, o1 = cat(m1); b2, o2 = cat(m2)
+    for sync in (0, 1):
+        k, ql, ql2 = ctx.extract(M.default_params(seq_mode=2, syncmer=sync), b1, o1, b2, o2)
+        ko, qlo, ql2o = orc.extract_batch(default_params(seq_mode=2, syncmer=sync), b1, o1, b2, o2)
+        assert (ql == qlo).all() and (ql2 == ql2o).all() and len(k) == len(ko) and (k == ko).all()
+        seqs = set(((k["qinfo"] >> np.uint64(32)) & np.uint64(0x1FFFFFFF)).tolist())
+        assert seqs == {1, 4, 5}                              # pairs 2, 3, 6 have a mate below 26 bases
 
 
 def test_large_properties(ctx):
