@@ -186,7 +186,7 @@ void write_krona(FILE *fp, const CladeTable &ct, unsigned long total) {
 int main(int argc, char **argv) {
     mtb_params par; mtb_default_params(&par);
     std::string taxdir; std::vector<int> devices(1, 0); size_t max_reads = 2000000;
-    int threads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    int threads = (int)std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
     bool lineage = false;
     std::vector<std::string> pos;
     for (int i = 1; i < argc; i++) {

@@ -3,8 +3,11 @@
  * The reference parses reads with one kseq producer per file (KmerExtractor.cpp:122-171, KSeqWrapper); at
  * GPU rates the parser is the bottleneck, so this reader works on large blocks:
  * a block is cut at record boundaries into one piece per worker thread, every worker scans its piece
- * with memchr and appends bases / names to its own flat buffers, and the pieces are concatenated in
- * order.  Output is the layout the C ABI takes: concatenated bases + u64 offsets, names likewise.
+ * with memchr and appends bases / names to its own flat buffers, and the pieces are copied into the batch
+ * in parallel (uninitialised batch buffers: nothing is zero-filled or copied by one thread).  Plain files are
+ * mapped and parsed in place; gzip streams are inflated one block ahead on their own thread (a single gzip
+ * stream inflates serially: ~0.4 GB/s of text is the ceiling there).  Output is the layout the C ABI
+ * takes: concatenated bases + u64 offsets, names likewise.
  *
  * Formats: FASTQ with four lines per record (what sequencers and the reference's test data use;
  * multi-line FASTQ is not supported), FASTA with sequences over any number of lines.  Names end at the
@@ -12,10 +15,16 @@
  */
 #ifndef MTB_FASTX_H
 #define MTB_FASTX_H
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -25,22 +34,42 @@
 
 namespace mtbhost {
 
-struct FlatBatch {
-    std::vector<char> bases; std::vector<uint64_t> offs{0};
-    std::vector<char> names; std::vector<uint64_t> name_offs{0};
-    size_t size() const { return offs.size() - 1; }
-    void clear() { bases.clear(); offs.assign(1, 0); names.clear(); name_offs.assign(1, 0); }
-    void add(const char *name, size_t name_len, const char *seq, size_t seq_len) {
-        names.insert(names.end(), name, name + name_len); name_offs.push_back(names.size());
-        bases.insert(bases.end(), seq, seq + seq_len); offs.push_back(bases.size());
+/* growable array of a trivially copyable type WITHOUT value-initialisation: batch buffers are filled by parallel copies, a
+ * std::vector would zero every byte first from one thread */
+template <class T> class PodVec {
+public:
+    PodVec() = default;
+    ~PodVec() { free(p_); }
+    PodVec(const PodVec &) = delete; PodVec &operator=(const PodVec &) = delete;
+    PodVec(PodVec &&o) noexcept : p_(o.p_), n_(o.n_), cap_(o.cap_) { o.p_ = nullptr; o.n_ = o.cap_ = 0; }
+    PodVec &operator=(PodVec &&o) noexcept { if (this != &o) { free(p_); p_ = o.p_; n_ = o.n_; cap_ = o.cap_; o.p_ = nullptr; o.n_ = o.cap_ = 0; } return *this; }
+    T *data() { return p_; } const T *data() const { return p_; }
+    size_t size() const { return n_; } bool empty() const { return n_ == 0; }
+    T &operator[](size_t i) { return p_[i]; } const T &operator[](size_t i) const { return p_[i]; }
+    void clear() { n_ = 0; }
+    void reserve(size_t c) {
+        if (c <= cap_) return;
+        T *q = (T *)realloc(p_, c * sizeof(T));
+        if (!q) throw std::bad_alloc();
+        p_ = q; cap_ = c;
     }
-    void append(const FlatBatch &o) {
-        const uint64_t b0 = bases.size(), n0 = names.size();
-        offs.reserve(offs.size() + o.offs.size()); name_offs.reserve(name_offs.size() + o.name_offs.size());
-        bases.insert(bases.end(), o.bases.begin(), o.bases.end());
-        names.insert(names.end(), o.names.begin(), o.names.end());
-        for (size_t i = 1; i < o.offs.size(); i++) offs.push_back(b0 + o.offs[i]);
-        for (size_t i = 1; i < o.name_offs.size(); i++) name_offs.push_back(n0 + o.name_offs[i]);
+    void resize_uninit(size_t n) { if (n > cap_) reserve(n + n / 8 + 16); n_ = n; }
+    void push_back(const T &v) { if (n_ == cap_) reserve(cap_ ? cap_ * 2 : 64); p_[n_++] = v; }
+    void append(const T *a, const T *b) { const size_t k = (size_t)(b - a); if (n_ + k > cap_) reserve(std::max(cap_ * 2, n_ + k)); if (k) memcpy(p_ + n_, a, k * sizeof(T)); n_ += k; }
+private:
+    T *p_ = nullptr; size_t n_ = 0, cap_ = 0;
+};
+
+struct FlatBatch {
+    PodVec<char> bases; PodVec<uint64_t> offs;
+    PodVec<char> names; PodVec<uint64_t> name_offs;
+    FlatBatch() { offs.push_back(0); name_offs.push_back(0); }
+    FlatBatch(FlatBatch &&) = default; FlatBatch &operator=(FlatBatch &&) = default;
+    size_t size() const { return offs.size() - 1; }
+    void clear() { bases.clear(); offs.clear(); offs.push_back(0); names.clear(); name_offs.clear(); name_offs.push_back(0); }
+    void add(const char *name, size_t name_len, const char *seq, size_t seq_len) {
+        names.append(name, name + name_len); name_offs.push_back(names.size());
+        bases.append(seq, seq + seq_len); offs.push_back(bases.size());
     }
     std::string name(size_t i) const { return std::string(names.data() + name_offs[i], names.data() + name_offs[i + 1]); }
 };
@@ -48,120 +77,161 @@ struct FlatBatch {
 class FastxReader {
 public:
     FastxReader(const std::string &path, int threads, size_t block_bytes = 64u << 20)
-        : threads_(threads < 1 ? 1 : threads), block_(block_bytes) {
-        /* gzip (magic 1f 8b) goes through zlib; plain files are read directly -- zlib's transparent mode copies through its
-         * own buffer at ~1.5 GB/s, which was most of the parse stage */
-        FILE *f = fopen(path.c_str(), "rb");
-        if (!f) throw std::runtime_error("cannot open " + path);
+        : threads_(threads < 1 ? 1 : threads), block_(block_bytes < 16 ? 16 : block_bytes) {
+        int fd = open(path.c_str(), O_RDONLY);
+        if (fd < 0) throw std::runtime_error("cannot open " + path);
         unsigned char magic[2] = {0, 0};
-        size_t got = fread(magic, 1, 2, f);
+        ssize_t got = pread(fd, magic, 2, 0);
         if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
-            fclose(f);
+            close(fd);
             gz_ = gzopen(path.c_str(), "rb");
             if (!gz_) throw std::runtime_error("cannot open " + path);
             gzbuffer(gz_, 1u << 20);
         } else {
-            rewind(f);
-            setvbuf(f, nullptr, _IONBF, 0);
-            plain_ = f;
+            struct stat sb;
+            if (fstat(fd, &sb) != 0) { close(fd); throw std::runtime_error("cannot stat " + path); }
+            map_len_ = (size_t)sb.st_size;
+            if (map_len_) {
+                void *m = mmap(nullptr, map_len_, PROT_READ, MAP_PRIVATE, fd, 0);
+                if (m == MAP_FAILED) { close(fd); throw std::runtime_error("cannot map " + path); }
+                map_ = (const char *)m;
+                madvise(m, map_len_, MADV_SEQUENTIAL);
+            }
+            close(fd);
         }
     }
-    ~FastxReader() { if (gz_) gzclose(gz_); if (plain_) fclose(plain_); }
+    ~FastxReader() {
+        if (prefetch_.joinable()) prefetch_.join();
+        if (gz_) gzclose(gz_);
+        free(gz_buf_[0]); free(gz_buf_[1]);
+        if (map_) munmap((void *)map_, map_len_);
+    }
     FastxReader(const FastxReader &) = delete;
 
     /* appends up to max_reads records to `out`; returns false when the file is exhausted and nothing was added */
     bool next_batch(size_t max_reads, FlatBatch &out) {
         size_t before = out.size();
         while (out.size() - before < max_reads) {
-            if (pending_.size() == pending_pos_) {
-                if (!fill()) break;
-                /* size the batch ONCE from the first block's averages (growing block by block re-copies everything each time) */
-                if (out.size() == before) {
-                    size_t nb = 0, nn = 0, nr = 0;
-                    for (const FlatBatch &q : pending_) { nb += q.bases.size(); nn += q.names.size(); nr += q.size(); }
-                    if (nr) {
-                        const double f = 1.05 * (double)max_reads / (double)nr;
-                        const size_t cap_b = (size_t)((double)nb * f) + 4096, cap_n = (size_t)((double)nn * f) + 4096;
-                        if (cap_b < ((size_t)8 << 30)) {            /* absurd --max-reads: let the vectors grow instead */
-                            out.bases.reserve(out.bases.size() + cap_b); out.names.reserve(out.names.size() + cap_n);
-                            out.offs.reserve(out.offs.size() + max_reads + 1); out.name_offs.reserve(out.name_offs.size() + max_reads + 1);
-                        }
-                    }
-                }
-            }
-            size_t want = max_reads - (out.size() - before);
-            drain(want, out);
+            if (pending_.size() == pending_pos_ && !fill()) break;
+            drain(max_reads - (out.size() - before), out);
         }
         return out.size() > before;
     }
 
 private:
-    /* one parsed block waits in pending_ (FlatBatch pieces in order) until batches have consumed it */
-    bool fill() {
-        if (eof_ && carry_.empty()) return false;
-        /* one persistent, never zero-filled block buffer; the file is read straight behind the carried-over tail */
-        const size_t keep = carry_.size();
-        if (cap_ < keep + block_ + 1) { cap_ = keep + block_ + 1; raw_.reset(new char[cap_]); }
-        char *const buf = raw_.get();
-        if (keep) memcpy(buf, carry_.data(), keep);
-        carry_.clear();
-        size_t len = keep;
-        if (!eof_) {
+    /* gzip: inflate up to block_ bytes into buffer `k`, behind its first `keep` bytes (the record carried over) */
+    void read_gz_block(int k, size_t keep) {
+        try {
+            gz_reserve(k, keep + block_ + 1);
             size_t got = 0;
-            while (got < block_) {                      /* gzread takes an unsigned length */
-                long r;
-                if (plain_) { r = (long)fread(buf + keep + got, 1, block_ - got, plain_); if (r == 0 && ferror(plain_)) throw std::runtime_error("read error"); }
-                else { r = gzread(gz_, buf + keep + got, (unsigned)std::min<size_t>(block_ - got, 1u << 30)); if (r < 0) throw std::runtime_error("read error (corrupt gzip stream?)"); }
-                if (r == 0) { eof_ = true; break; }
+            while (!gz_eof_ && got < block_) {                      /* gzread takes an unsigned length */
+                int r = gzread(gz_, gz_buf_[k] + keep + got, (unsigned)std::min<size_t>(block_ - got, 1u << 30));
+                if (r < 0) throw std::runtime_error("read error (corrupt gzip stream?)");
+                if (r == 0) { gz_eof_ = true; break; }
                 got += (size_t)r;
             }
-            len += got;
+            gz_len_[k] = keep + got;
+        } catch (const std::exception &e) { gz_err_ = e.what(); gz_len_[k] = keep; gz_eof_ = true; }
+    }
+    void gz_reserve(int k, size_t n) {
+        if (gz_cap_[k] >= n) return;
+        char *nb = (char *)realloc(gz_buf_[k], n); if (!nb) throw std::bad_alloc();
+        gz_buf_[k] = nb; gz_cap_[k] = n;
+    }
+    /* one parsed block waits in pending_ (FlatBatch pieces in order) until batches have consumed it */
+    bool fill() {
+        const char *buf; size_t len; bool at_eof; int cur = 0;
+        if (!gz_) {
+            if (map_pos_ >= map_len_) return false;
+            buf = map_ + map_pos_;
+            len = std::min(block_, map_len_ - map_pos_);
+            at_eof = map_pos_ + len >= map_len_;
+        } else {
+            if (prefetch_.joinable()) { prefetch_.join(); cur = gz_next_; }
+            else if (!gz_started_) { gz_started_ = true; read_gz_block(0, 0); cur = 0; }
+            else return false;                                        /* the last block has been handed out */
+            if (!gz_err_.empty()) throw std::runtime_error(gz_err_);
+            buf = gz_buf_[cur]; len = gz_len_[cur];
+            at_eof = gz_eof_;
         }
         if (len == 0) return false;
         if (format_ == 0) {
             size_t p = 0; while (p < len && (buf[p] == '\n' || buf[p] == '\r')) p++;
-            if (p == len) return false;
-            format_ = buf[p] == '@' ? 'q' : (buf[p] == '>' ? 'a' : 0);
-            if (!format_) throw std::runtime_error("input is neither FASTA nor FASTQ");
+            if (p < len) {
+                format_ = buf[p] == '@' ? 'q' : (buf[p] == '>' ? 'a' : 0);
+                if (!format_) throw std::runtime_error("input is neither FASTA nor FASTQ");
+            } else if (at_eof) return false;                          /* nothing but blank lines */
         }
-        /* the block ends inside a record unless the file ended: keep the incomplete tail for the next block */
+        /* the block ends inside a record unless the input ended: the incomplete tail opens the next block */
         size_t end = len;
-        if (!eof_) {
+        while (!at_eof && format_) {
             end = last_record_start(buf, len);
-            if (end == 0) {                              /* one record larger than the block: grow and retry */
-                carry_.assign(buf, buf + len); block_ *= 2; return fill();
-            }
-            carry_.assign(buf + end, buf + len);
+            if (end) break;
+            block_ *= 2;                                              /* one record larger than the block: take more */
+            if (!gz_) { len = std::min(block_, map_len_ - map_pos_); at_eof = map_pos_ + len >= map_len_; }
+            else { read_gz_block(cur, len); if (!gz_err_.empty()) throw std::runtime_error(gz_err_); buf = gz_buf_[cur]; len = gz_len_[cur]; at_eof = gz_eof_; }
+            end = len;
+        }
+        if (!format_) end = len;                                      /* a block of blank lines */
+        if (!gz_) map_pos_ += end;
+        else if (!at_eof) {
+            /* start inflating the next block right away (behind the carried-over tail), parse this one meanwhile */
+            const int k = cur ^ 1; const size_t keep = len - end;
+            gz_reserve(k, keep + block_ + 1);
+            if (keep) memcpy(gz_buf_[k], buf + end, keep);
+            gz_next_ = k;
+            prefetch_ = std::thread([this, k, keep] { read_gz_block(k, keep); });
         }
         /* cut [0, end) into pieces at record starts, parse in parallel */
         std::vector<size_t> cut{0};
-        for (int t = 1; t < threads_; t++) {
+        for (int t = 1; t < threads_ && format_; t++) {
             size_t guess = end / (size_t)threads_ * (size_t)t;
             size_t s = next_record_start(buf, guess, end);
             if (s > cut.back() && s < end) cut.push_back(s);
         }
         cut.push_back(end);
-        pending_.assign(cut.size() - 1, FlatBatch());
+        pending_.clear(); pending_.resize(cut.size() - 1);
         pending_pos_ = 0; pending_read_ = 0;
-        std::vector<std::thread> th;
-        for (size_t k = 0; k + 1 < cut.size(); k++)
-            th.emplace_back([&, k]() { parse(buf + cut[k], buf + cut[k + 1], pending_[k]); });
-        for (auto &t : th) t.join();
+        if (format_) run_parallel(cut.size() - 1, [&](size_t k) { parse(buf + cut[k], buf + cut[k + 1], pending_[k]); });
         return true;
     }
+    template <class F> void run_parallel(size_t n, F f) {
+        if (n <= 1) { if (n) f(0); return; }
+        std::vector<std::thread> th;
+        for (size_t k = 1; k < n; k++) th.emplace_back([&f, k] { f(k); });
+        f(0);
+        for (auto &t : th) t.join();
+    }
+    /* whole pieces are copied into the batch by one thread each (offsets rebased); a piece that straddles the batch limit is
+     * split record by record */
     void drain(size_t want, FlatBatch &out) {
-        while (want && pending_pos_ < pending_.size()) {
+        size_t first = pending_pos_, last = pending_pos_, take = 0;
+        if (pending_read_ == 0)
+            while (last < pending_.size() && take + pending_[last].size() <= want) { take += pending_[last].size(); last++; }
+        if (last > first) {
+            const size_t np = last - first;
+            std::vector<size_t> b0(np + 1), n0(np + 1), r0(np + 1);
+            b0[0] = out.bases.size(); n0[0] = out.names.size(); r0[0] = out.size();
+            for (size_t k = 0; k < np; k++) { const FlatBatch &p = pending_[first + k]; b0[k + 1] = b0[k] + p.bases.size(); n0[k + 1] = n0[k] + p.names.size(); r0[k + 1] = r0[k] + p.size(); }
+            out.bases.resize_uninit(b0[np]); out.names.resize_uninit(n0[np]);
+            out.offs.resize_uninit(r0[np] + 1); out.name_offs.resize_uninit(r0[np] + 1);
+            run_parallel(np, [&](size_t k) {
+                const FlatBatch &p = pending_[first + k];
+                if (p.bases.size()) memcpy(out.bases.data() + b0[k], p.bases.data(), p.bases.size());
+                if (p.names.size()) memcpy(out.names.data() + n0[k], p.names.data(), p.names.size());
+                uint64_t *o = out.offs.data() + r0[k], *no = out.name_offs.data() + r0[k];
+                for (size_t i = 1; i <= p.size(); i++) { o[i] = b0[k] + p.offs[i]; no[i] = n0[k] + p.name_offs[i]; }
+            });
+            for (size_t k = first; k < last; k++) { FlatBatch e; pending_[k] = std::move(e); }
+            pending_pos_ = last; want -= take;
+        }
+        if (want && pending_pos_ < pending_.size()) {
             FlatBatch &p = pending_[pending_pos_];
-            size_t avail = p.size() - pending_read_;
-            if (pending_read_ == 0 && avail <= want) { out.append(p); want -= avail; }
-            else {
-                size_t take = std::min(avail, want);
-                for (size_t i = pending_read_; i < pending_read_ + take; i++)
-                    out.add(p.names.data() + p.name_offs[i], p.name_offs[i + 1] - p.name_offs[i], p.bases.data() + p.offs[i], p.offs[i + 1] - p.offs[i]);
-                want -= take; pending_read_ += take;
-                if (pending_read_ < p.size()) return;
-            }
-            p.clear(); pending_pos_++; pending_read_ = 0;
+            const size_t avail = p.size() - pending_read_, n = std::min(avail, want);
+            for (size_t i = pending_read_; i < pending_read_ + n; i++)
+                out.add(p.names.data() + p.name_offs[i], p.name_offs[i + 1] - p.name_offs[i], p.bases.data() + p.offs[i], p.offs[i + 1] - p.offs[i]);
+            pending_read_ += n;
+            if (pending_read_ == p.size()) { FlatBatch e; p = std::move(e); pending_pos_++; pending_read_ = 0; }
         }
         if (pending_pos_ == pending_.size()) { pending_.clear(); pending_pos_ = 0; }
     }
@@ -233,26 +303,26 @@ private:
                 const char *q_end = plus_end < e ? line_end(plus_end + 1, e) : e;
                 p = q_end < e ? q_end + 1 : e;
             } else {
-                size_t n0 = out.bases.size();
                 const char *s = h_end < e ? h_end + 1 : e;
                 while (s < e && *s != '>') {
                     const char *le = line_end(s, e);
                     const char *se = le; if (se > s && se[-1] == '\r') se--;
-                    out.bases.insert(out.bases.end(), s, se);
+                    out.bases.append(s, se);
                     s = le < e ? le + 1 : e;
                 }
-                out.names.insert(out.names.end(), name, ne); out.name_offs.push_back(out.names.size());
+                out.names.append(name, ne); out.name_offs.push_back(out.names.size());
                 out.offs.push_back(out.bases.size());
-                (void)n0;
                 p = s;
             }
         }
     }
 
-    gzFile gz_ = nullptr; FILE *plain_ = nullptr; int threads_; size_t block_;
-    bool eof_ = false; char format_ = 0;
-    std::vector<char> carry_;
-    std::unique_ptr<char[]> raw_; size_t cap_ = 0;
+    gzFile gz_ = nullptr; int threads_; size_t block_;
+    char format_ = 0;
+    const char *map_ = nullptr; size_t map_len_ = 0, map_pos_ = 0;                 /* plain files */
+    char *gz_buf_[2] = {nullptr, nullptr}; size_t gz_cap_[2] = {0, 0}, gz_len_[2] = {0, 0};   /* gzip: two blocks */
+    int gz_next_ = 0; bool gz_eof_ = false, gz_started_ = false;
+    std::string gz_err_; std::thread prefetch_;
     std::vector<FlatBatch> pending_; size_t pending_pos_ = 0, pending_read_ = 0;
 };
 
