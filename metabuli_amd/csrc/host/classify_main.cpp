@@ -44,7 +44,7 @@ namespace {
 /* one batch travelling through the pipeline */
 struct Job {
     mtbhost::FlatBatch r1, r2;
-    std::vector<mtb_result> res; std::vector<int32_t> tt; std::vector<uint32_t> tc;
+    std::vector<mtb_result> res; mtbhost::PodVec<int32_t> tt; mtbhost::PodVec<uint32_t> tc;      /* taxcnt lists: never zero-filled */
     bool last = false;
 };
 
@@ -237,7 +237,7 @@ int main(int argc, char **argv) {
         mtb::Engine &eng = *engs[0];                          /* taxonomy services for formatting */
         const size_t ND = engs.size();
         const double t_open = now() - t_start;
-        double t_parse = 0, t_gpu = 0, t_write = 0;           /* busy time of the three stages */
+        double t_parse = 0, t_gpu = 0, t_write = 0, t_dev = 0;  /* busy time of the three stages; device time inside the GPU stage */
         FILE *out = fopen((outdir + "/" + job + "_classifications.tsv").c_str(), "w");
         if (!out) throw std::runtime_error("cannot write to " + outdir);
         fputs(lineage ? "#is_classified\tname\ttaxID\tquery_length\tscore\trank\tlineage\ttaxID:match_count\n"
@@ -287,7 +287,7 @@ int main(int argc, char **argv) {
         /* stage 2: the GPUs.  A host batch is cut into ND contiguous read ranges; range d runs on engine d from its own host
          * thread (one thread per mtb_ctx); rows land at their places in j->res, the taxcnt lists are appended range by range */
         std::string gpu_err;
-        struct Range { std::vector<uint64_t> offs, offs2; std::vector<int32_t> tt; std::vector<uint32_t> tc; uint64_t ntc = 0; std::string err; };
+        struct Range { std::vector<uint64_t> offs, offs2; mtbhost::PodVec<int32_t> tt; mtbhost::PodVec<uint32_t> tc; uint64_t ntc = 0; std::string err; double dev_ms = 0; };
         for (;;) {
             std::unique_ptr<Job> j = parsed.get();
             if (j->last) { scored.put(std::move(j)); break; }
@@ -306,14 +306,15 @@ int main(int argc, char **argv) {
                 uint64_t c0 = 0;
                 if (paired) { c0 = j->r2.offs[lo]; R.offs2.resize(m + 1); for (size_t i = 0; i <= m; i++) R.offs2[i] = j->r2.offs[lo + i] - c0; }
                 mtb_params pd = par;
-                size_t cap = 64 * m + 1024;
+                size_t cap = 24 * m + 4096;                  /* the device side needs one slot per position bucket (18 for 150 bp reads); more -> exact retry */
                 for (;;) {
-                    R.tt.resize(cap); R.tc.resize(cap);
+                    R.tt.resize_uninit(cap); R.tc.resize_uninit(cap);
                     mtb_status st = mtb_classify_batch(engs[d]->ctx, engs[d]->index, &pd, j->r1.bases.data() + b0, R.offs.data(),
                                                        paired ? j->r2.bases.data() + c0 : nullptr, paired ? R.offs2.data() : nullptr, m,
                                                        j->res.data() + lo, R.tt.data(), R.tc.data(), cap, &R.ntc);
                     if (st == MTB_ERR_CAPACITY && R.ntc > cap) { cap = R.ntc; continue; }
                     if (st != MTB_OK) R.err = mtb_last_error();
+                    else { mtb_batch_stats bs; if (mtb_last_batch_stats(engs[d]->ctx, &bs) == MTB_OK) R.dev_ms = bs.ms_total; }
                     break;
                 }
             };
@@ -323,20 +324,20 @@ int main(int argc, char **argv) {
             for (size_t d = 0; d < ND; d++) { if (!rg[d].err.empty() && gpu_err.empty()) gpu_err = rg[d].err; tot_tc += rg[d].ntc; }
             if (gpu_err.empty()) {
                 if (tot_tc >= (1ull << 32)) gpu_err = "taxcnt lists of one host batch exceed 2^32 entries; lower --max-reads";
-                else if (ND == 1) { j->tt.swap(rg[0].tt); j->tc.swap(rg[0].tc); }
+                else if (ND == 1) { j->tt = std::move(rg[0].tt); j->tc = std::move(rg[0].tc); }
                 else {
-                    j->tt.resize(tot_tc); j->tc.resize(tot_tc);
+                    j->tt.resize_uninit(tot_tc); j->tc.resize_uninit(tot_tc);
                     uint64_t base = 0;
                     for (size_t d = 0; d < ND; d++) {
                         const size_t lo = n * d / ND, hi = n * (d + 1) / ND;
-                        std::copy(rg[d].tt.begin(), rg[d].tt.begin() + (ptrdiff_t)rg[d].ntc, j->tt.begin() + (ptrdiff_t)base);
-                        std::copy(rg[d].tc.begin(), rg[d].tc.begin() + (ptrdiff_t)rg[d].ntc, j->tc.begin() + (ptrdiff_t)base);
+                        if (rg[d].ntc) { memcpy(j->tt.data() + base, rg[d].tt.data(), rg[d].ntc * 4); memcpy(j->tc.data() + base, rg[d].tc.data(), rg[d].ntc * 4); }
                         for (size_t i = lo; i < hi; i++) j->res[i].taxcnt_off += (uint32_t)base;
                         base += rg[d].ntc;
                     }
                 }
             }
             t_gpu += now() - t0;
+            { double mx = 0; for (size_t d = 0; d < ND; d++) mx = std::max(mx, rg[d].dev_ms); t_dev += mx * 1e-3; }
             if (gpu_err.empty()) scored.put(std::move(j));
         }
         reader.join(); writer.join();
@@ -355,8 +356,8 @@ int main(int argc, char **argv) {
         if (!fp) throw std::runtime_error("cannot write the krona file");
         write_krona(fp, ct, total);
         fclose(fp);
-        fprintf(stderr, "mtb_classify: %lu reads in %.2f s on %zu GPU(s) (index open %.2f s; stage busy time: parse %.2f s, GPU incl. PCIe %.2f s, format+write %.2f s; %d host threads)\n",
-                total, now() - t_start, ND, t_open, t_parse, t_gpu, t_write, threads);
+        fprintf(stderr, "mtb_classify: %lu reads in %.2f s on %zu GPU(s) (index open %.2f s; stage busy time: parse %.2f s, GPU incl. PCIe %.2f s (kernels %.2f s), format+write %.2f s; %d host threads)\n",
+                total, now() - t_start, ND, t_open, t_parse, t_gpu, t_dev, t_write, threads);
     } catch (const std::exception &e) {
         fprintf(stderr, "mtb_classify: %s\n", e.what());
         return 1;
