@@ -232,6 +232,7 @@ def main():
     ap.add_argument("--partitioned", action="store_true",
                     help="SURVEY 8(e) row 2: every rank owns one value range of the index; metamers and matches travel by all-to-all "
                          "(functional/perf check of that path; the default is the replicated index)")
+    ap.add_argument("--prealloc", action="store_true", help="experiment: grow the context's workspace on a tiny index BEFORE the big index is allocated")
     ap.add_argument("--no-seal", action="store_true", help="keep the flat {value, info} arrays next to the packed state (mtb_index_seal not called)")
     ap.add_argument("--seed", type=int, default=1234)
     args = ap.parse_args()
@@ -262,6 +263,21 @@ def main():
     real_v, real_t = extract_targets(ctx, M, world, params)
     n_filler = int(args.targets)
     T_cap = n_filler + len(real_v)
+    if args.prealloc:
+        nf0 = 1_000_000
+        v0 = torch.empty(nf0 + len(real_v), dtype=torch.int64, device=dev); i0 = torch.empty(nf0 + len(real_v), dtype=torch.int32, device=dev)
+        T0 = ctx.synth_index(args.seed, nf0, world.filler_tax_lo, world.filler_tax_hi, real_v, real_t, v0.data_ptr(), i0.data_ptr())
+        tl0 = np.concatenate([np.unique(real_t), np.arange(world.filler_tax_lo, world.filler_tax_hi + 1, dtype=np.int32)])
+        ix0 = ctx.index_from_device(v0.data_ptr(), i0.data_ptr(), T0, taxdir, tl0, params)
+        b0, o0 = gen_reads(torch, dev, world, args.reads, args.read_len, 0.10, 0.005, args.seed + 17 * (rank + 1))
+        r0 = torch.empty(args.reads * 24, dtype=torch.uint8, device=dev)
+        cap0 = args.reads * (20 + args.read_len // 9) + 1024
+        t0_ = torch.empty(cap0, dtype=torch.int32, device=dev); c0_ = torch.empty(cap0, dtype=torch.int32, device=dev)
+        for _ in range(2):
+            ctx.classify_batch_device(ix0, params, b0.data_ptr(), o0.data_ptr(), 0, 0, args.reads, args.reads * args.read_len, r0.data_ptr(), t0_.data_ptr(), c0_.data_ptr(), cap0)
+        torch.cuda.synchronize()
+        del ix0, v0, i0, b0, o0, r0, t0_, c0_
+        torch.cuda.empty_cache()
     free, total = torch.cuda.mem_get_info(dev)
     need = T_cap * 12 + args.reads * (args.read_len + 8)
     if need > free * 0.9:

@@ -17,6 +17,12 @@
  *   accepted for command-line compatibility, no effect here (one warning each): --max-ram (batches are bounded by HBM inside
  *          the library; the host batch is --max-reads), --match-per-kmer (exact-size retry), --hamming-margin, --mask,
  *          --mask-prob, --validate-input, --validate-db, --print-log, -v   (LocalParameters.cpp:631-654)
+ *   filter mode (`metabuli filter`, src/workflow/filter.cpp:5-45, QueryFilter.cpp:75-186): --filter 1 [--print-mode 1|2] <FASTA/Q> [<mate>] <DBDIR>
+ *          classifies with the filter command's defaults (--min-score 0.5 unless given) and writes, next to the input,
+ *          <base>_filtered.fna (reads NOT classified = not contamination), with --print-mode 2 also <base>_removed.fna (classified
+ *          reads), and <base>_classifications.tsv / <base>_report.tsv; <base> = LocalUtil::getQueryBaseName (LocalUtil.cpp:5-20).
+ *          (In the reference snapshot the match loop of filterReads is stubbed out, QueryFilter.cpp:172-175, so it keeps every
+ *          read; this implements the documented behaviour of the command.)
  *   own flags: --max-reads N (host batch)  --device N | --devices 0,1,... (one engine per GPU: every host batch is cut into
  *          contiguous read ranges, one per device, classified concurrently, results concatenated in input order and
  *          the per-taxon counts summed -- reads are independent, Classifier.cpp:187-203)
@@ -107,6 +113,27 @@ void format_reads(const Job &j, size_t lo, size_t hi, const mtb_index *ix, bool 
     }
 }
 
+/* QueryFilter::printFilteredReads (QueryFilter.cpp:102-118): ">name\nsequence\n" of the reads [lo, hi) whose is_classified flag equals `classified` */
+void format_fasta(const mtbhost::FlatBatch &r, const std::vector<mtb_result> &res, size_t lo, size_t hi, bool classified, std::string &out) {
+    out.clear();
+    for (size_t i = lo; i < hi; i++) {
+        if ((res[i].is_classified != 0) != classified) continue;
+        out += '>'; out.append(r.names.data() + r.name_offs[i], r.names.data() + r.name_offs[i + 1]); out += '\n';
+        out.append(r.bases.data() + r.offs[i], r.bases.data() + r.offs[i + 1]); out += '\n';
+    }
+}
+
+/* LocalUtil::getQueryBaseName (LocalUtil.cpp:5-20): the path without its last extension (without the last two for .gz) */
+std::string query_base_name(const std::string &path) {
+    std::vector<std::string> parts;
+    size_t a = 0;
+    for (;;) { size_t b = path.find('.', a); if (b == std::string::npos) { parts.push_back(path.substr(a)); break; } parts.push_back(path.substr(a, b - a)); a = b + 1; }
+    const size_t drop = path.size() >= 3 && path.compare(path.size() - 3, 3, ".gz") == 0 ? 2 : 1;
+    std::string base;
+    for (size_t i = 0; i + drop < parts.size(); i++) { if (i) base += '.'; base += parts[i]; }
+    return base;
+}
+
 /* Reporter::writeReportFile / writeReport / kronaReport (Reporter.cpp:86-193): clade counts as NcbiTaxonomy::getCladeCounts
  * builds them (every counted taxon adds its count to itself and to all of its ancestors; a node's children are the
  * taxonomy's children), the report as a depth-first walk with the children ordered by clade count, descending -- the
@@ -187,13 +214,15 @@ int main(int argc, char **argv) {
     mtb_params par; mtb_default_params(&par);
     std::string taxdir; std::vector<int> devices(1, 0); size_t max_reads = 2000000;
     int threads = (int)std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
-    bool lineage = false;
+    bool lineage = false, filter = false, min_score_given = false; int print_mode = 1;
     std::vector<std::string> pos;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto val = [&]() { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(1); } return std::string(argv[++i]); };
         if (a == "--seq-mode") par.seq_mode = atoi(val().c_str());
-        else if (a == "--min-score") par.min_score = (float)atof(val().c_str());
+        else if (a == "--min-score") { par.min_score = (float)atof(val().c_str()); min_score_given = true; }
+        else if (a == "--filter") filter = atoi(val().c_str()) != 0;
+        else if (a == "--print-mode") print_mode = atoi(val().c_str());
         else if (a == "--min-sp-score") par.min_sp_score = (float)atof(val().c_str());
         else if (a == "--min-cons-cnt") par.min_cons_cnt = atoi(val().c_str());
         else if (a == "--min-cons-cnt-euk") par.min_cons_cnt_euk = atoi(val().c_str());
@@ -217,13 +246,17 @@ int main(int argc, char **argv) {
         else if (a.rfind("--", 0) == 0) { fprintf(stderr, "mtb_classify: unknown flag %s\n", a.c_str()); return 1; }
         else pos.push_back(a);
     }
-    size_t need = par.seq_mode == 2 ? 5 : 4;
+    const bool paired = par.seq_mode == 2;
+    size_t need = (paired ? 5 : 4) - (filter ? 2 : 0);
     if (pos.size() != need) {
-        fprintf(stderr, "usage: mtb_classify [flags] <FASTA/Q>%s <DBDIR> <OUTDIR> <JobID>\n", par.seq_mode == 2 ? " <FASTA/Q>" : "");
+        fprintf(stderr, filter ? "usage: mtb_classify --filter 1 [flags] <FASTA/Q>%s <DBDIR>\n" : "usage: mtb_classify [flags] <FASTA/Q>%s <DBDIR> <OUTDIR> <JobID>\n", paired ? " <FASTA/Q>" : "");
         return 1;
     }
-    const bool paired = par.seq_mode == 2;
-    const std::string dbdir = pos[paired ? 2 : 1], outdir = pos[paired ? 3 : 2], job = pos[paired ? 4 : 3];
+    if (filter && !min_score_given) par.min_score = 0.5f;     /* setFilterDefaults, filter.cpp:8 */
+    const std::string dbdir = pos[paired ? 2 : 1];
+    /* classify: <OUTDIR>/<JobID>_*; filter: <base of the first input>_* (QueryFilter.cpp:75-93) */
+    const std::string base1 = filter ? query_base_name(pos[0]) : std::string(), base2 = filter && paired ? query_base_name(pos[1]) : std::string();
+    const std::string prefix = filter ? base1 : pos[paired ? 3 : 2] + "/" + pos[paired ? 4 : 3];
     try {
         auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         const double t_start = now();
@@ -238,8 +271,14 @@ int main(int argc, char **argv) {
         const size_t ND = engs.size();
         const double t_open = now() - t_start;
         double t_parse = 0, t_gpu = 0, t_write = 0, t_dev = 0;  /* busy time of the three stages; device time inside the GPU stage */
-        FILE *out = fopen((outdir + "/" + job + "_classifications.tsv").c_str(), "w");
-        if (!out) throw std::runtime_error("cannot write to " + outdir);
+        FILE *out = fopen((prefix + "_classifications.tsv").c_str(), "w");
+        if (!out) throw std::runtime_error("cannot write " + prefix + "_classifications.tsv");
+        FILE *flt[2] = {nullptr, nullptr}, *rmv[2] = {nullptr, nullptr};
+        if (filter) {
+            auto open_w = [](const std::string &p) { FILE *f = fopen(p.c_str(), "w"); if (!f) throw std::runtime_error("cannot write " + p); return f; };
+            flt[0] = open_w(base1 + "_filtered.fna"); if (paired) flt[1] = open_w(base2 + "_filtered.fna");
+            if (print_mode == 2) { rmv[0] = open_w(base1 + "_removed.fna"); if (paired) rmv[1] = open_w(base2 + "_removed.fna"); }
+        }
         fputs(lineage ? "#is_classified\tname\ttaxID\tquery_length\tscore\trank\tlineage\ttaxID:match_count\n"
                       : "#is_classified\tname\ttaxID\tquery_length\tscore\trank\ttaxID:match_count\n", out);
         Channel<Job> parsed(2), scored(2);
@@ -278,6 +317,16 @@ int main(int argc, char **argv) {
                     th.emplace_back([&, t] { format_reads(*j, n * (size_t)t / (size_t)threads, n * (size_t)(t + 1) / (size_t)threads, eng.index, lineage, parts[(size_t)t]); });
                 for (auto &x : th) x.join();
                 for (auto &p : parts) if (fwrite(p.data(), 1, p.size(), out) != p.size()) writer_err = "short write";
+                for (int mate = 0; mate < 2; mate++) for (int cls = 0; cls < 2; cls++) {
+                    FILE *f = cls ? rmv[mate] : flt[mate];
+                    if (!f) continue;
+                    const mtbhost::FlatBatch &rb = mate ? j->r2 : j->r1;
+                    std::vector<std::thread> t2;
+                    for (int t = 0; t < threads; t++)
+                        t2.emplace_back([&, t] { format_fasta(rb, j->res, n * (size_t)t / (size_t)threads, n * (size_t)(t + 1) / (size_t)threads, cls != 0, parts[(size_t)t]); });
+                    for (auto &x : t2) x.join();
+                    for (auto &p : parts) if (fwrite(p.data(), 1, p.size(), f) != p.size()) writer_err = "short write";
+                }
                 for (size_t i = 0; i < n; i++) { int32_t c = j->res[i].classification; if (c >= 0 && (size_t)c < tax_counts.size()) tax_counts[(size_t)c]++; }
                 total += n;
                 t_write += now() - t0;
@@ -342,20 +391,23 @@ int main(int argc, char **argv) {
         }
         reader.join(); writer.join();
         fclose(out);
+        for (int k = 0; k < 2; k++) { if (flt[k]) fclose(flt[k]); if (rmv[k]) fclose(rmv[k]); }
         if (!reader_err.empty()) throw std::runtime_error(reader_err);
         if (!gpu_err.empty()) throw std::runtime_error("mtb: " + gpu_err);
         if (!writer_err.empty()) throw std::runtime_error(writer_err);
         std::map<int, unsigned> counts;
         for (size_t t = 0; t < tax_counts.size(); t++) if (tax_counts[t]) counts[(int)t] = (unsigned)tax_counts[t];
         CladeTable ct(counts, eng.index);
-        FILE *fp = fopen((outdir + "/" + job + "_report.tsv").c_str(), "w");
+        FILE *fp = fopen((prefix + "_report.tsv").c_str(), "w");
         if (!fp) throw std::runtime_error("cannot write the report");
         write_report(fp, ct, total);
         fclose(fp);
-        fp = fopen((outdir + "/" + job + "_krona.html").c_str(), "w");
-        if (!fp) throw std::runtime_error("cannot write the krona file");
-        write_krona(fp, ct, total);
-        fclose(fp);
+        if (!filter) {                                        /* the filter command writes the default report only (QueryFilter.cpp:198) */
+            fp = fopen((prefix + "_krona.html").c_str(), "w");
+            if (!fp) throw std::runtime_error("cannot write the krona file");
+            write_krona(fp, ct, total);
+            fclose(fp);
+        }
         fprintf(stderr, "mtb_classify: %lu reads in %.2f s on %zu GPU(s) (index open %.2f s; stage busy time: parse %.2f s, GPU incl. PCIe %.2f s (kernels %.2f s), format+write %.2f s; %d host threads)\n",
                 total, now() - t_start, ND, t_open, t_parse, t_gpu, t_dev, t_write, threads);
     } catch (const std::exception &e) {

@@ -16,7 +16,9 @@
 #include "mtb_core.h"
 
 #define MTB_SORT_TILE 2048
+#ifndef MTB_SORT_ITEMS
 #define MTB_SORT_ITEMS 8
+#endif
 
 /* Digit of one pass.  MODE 0: 8 binary bits at `shift` (256 bins).  MODE 1 (kmer_format 2 only): the two 5-bit
  * amino-acid letters at `shift` as one base-21 digit, letter codes are 0..20 -> 441 of 512 bins; three such passes
@@ -56,7 +58,7 @@ __global__ __launch_bounds__(THREADS) void k_radix_hist(const mtb_kmer *__restri
  * run of the digit-major table (one bin per thread): writing tile by tile put a lone 4-byte word into every sector,
  * 5 GB of HBM writes for a 0.64 GB table (PMC WRITE_SIZE). */
 #define MTB_HIST_GROUP 16
-template <int NB, int THREADS>
+template <int NB, int THREADS, int TILE = THREADS * MTB_SORT_ITEMS>
 __global__ __launch_bounds__(THREADS) void k_radix_hist_dig(const uint16_t *__restrict__ dig, uint64_t n, uint32_t *__restrict__ hist, uint32_t num_tiles) {
     static_assert(NB == THREADS, "one bin per thread");
     __shared__ uint32_t s_h[MTB_HIST_GROUP][NB];
@@ -65,10 +67,22 @@ __global__ __launch_bounds__(THREADS) void k_radix_hist_dig(const uint16_t *__re
     for (int g = 0; g < MTB_HIST_GROUP; g++) s_h[g][threadIdx.x] = 0;
     __syncthreads();
     for (int g = 0; g < MTB_HIST_GROUP; g++) {
-        const uint64_t base = (uint64_t)(tile0 + g) * (THREADS * MTB_SORT_ITEMS);
+        const uint64_t base = (uint64_t)(tile0 + g) * TILE;
         if (base >= n) break;
+        if (TILE == THREADS * 8 && base + TILE <= n) {
+            /* whole tile: eight digits per thread in one 16-byte load (the side arrays are hipMalloc'ed and TILE * 2 bytes is a multiple of 16) */
+            const uint4 q = *(const uint4 *)(dig + base + 8u * threadIdx.x);
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-        for (int r = 0; r < MTB_SORT_ITEMS; r++) {
+            for (int k = 0; k < 4; k++) {
+                const uint32_t d0 = w[k] & 0xFFFFu, d1 = w[k] >> 16;
+                atomicAdd(&s_h[g][d0 < NB ? d0 : NB - 1], 1u);
+                atomicAdd(&s_h[g][d1 < NB ? d1 : NB - 1], 1u);
+            }
+            continue;
+        }
+#pragma unroll
+        for (int r = 0; r < TILE / THREADS; r++) {
             uint64_t i = base + (uint64_t)r * THREADS + threadIdx.x;
             if (i < n) { uint32_t d = dig[i]; atomicAdd(&s_h[g][d < NB ? d : NB - 1], 1u); }
         }
@@ -94,21 +108,31 @@ __global__ __launch_bounds__(THREADS) void k_radix_hist_dig(const uint16_t *__re
 template <int NB, int MODE, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_radix_scatter(const mtb_kmer *__restrict__ in, mtb_kmer *__restrict__ out,
                                                             uint64_t n, int shift, const uint32_t *__restrict__ tile_off,
-                                                            uint32_t num_tiles, uint16_t *__restrict__ dig_out = nullptr, int next_shift = 0) {
+                                                            uint32_t num_tiles, uint16_t *__restrict__ dig_out = nullptr, int next_shift = 0, int xcd_map = 1) {
     constexpr int BITS = NB == 256 ? 8 : 9;
     constexpr int NW = THREADS / 64;
     constexpr int TILE = THREADS * MTB_SORT_ITEMS;
-    static_assert(NB == THREADS, "one bin per thread");
+    static_assert(NB <= THREADS, "at least one thread per bin");
     __shared__ uint16_t s_cnt[NW][NB];             /* per wave: records of the digit so far; later: start of the wave's run */
     __shared__ uint16_t s_start[NB];
     __shared__ uint32_t s_tmp[NW];
     __shared__ mtb_kmer s_buf[TILE];
+    __shared__ uint32_t s_goff[NB];
     const uint32_t t = threadIdx.x, w = t >> 6, lane = t & 63u;
-    const uint64_t base = (uint64_t)blockIdx.x * TILE;
+    /* workgroups go to the 8 XCDs round-robin: XCD x takes the x-th eighth of the tiles in order, so that the runs of one bin
+     * written by neighbouring tiles (adjacent in memory) meet in ONE L2 and leave it as whole lines, and the tile_off
+     * sectors are fetched once per 16 tiles instead of once per tile */
+    const uint32_t per_xcd = (num_tiles + 7u) >> 3;
+    const uint32_t tile = xcd_map ? (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
+    if (tile >= num_tiles) return;
+    const uint64_t base = (uint64_t)tile * TILE;
+    const uint32_t my_off = t < NB ? tile_off[(uint64_t)t * num_tiles + tile] : 0u;          /* bin t of this tile: global start */
     mtb_kmer e[MTB_SORT_ITEMS];
     uint32_t lrank[MTB_SORT_ITEMS];
+    if (t < NB) {
 #pragma unroll
-    for (int k = 0; k < NW; k++) s_cnt[k][t] = 0;
+        for (int k = 0; k < NW; k++) s_cnt[k][t] = 0;
+    }
     /* all loads of the thread in flight: wave w owns records [w*64*ITEMS, (w+1)*64*ITEMS) of the tile */
 #pragma unroll
     for (int r = 0; r < MTB_SORT_ITEMS; r++) {
@@ -138,11 +162,16 @@ __global__ __launch_bounds__(THREADS) void k_radix_scatter(const mtb_kmer *__res
     __syncthreads();
     /* bin t: exclusive offsets of the waves' runs inside the bin, bin total -> exclusive scan over bins */
     uint32_t run = 0;
+    if (t < NB) {
 #pragma unroll
-    for (int k = 0; k < NW; k++) { uint32_t c = s_cnt[k][t]; s_cnt[k][t] = (uint16_t)run; run += c; }
+        for (int k = 0; k < NW; k++) { uint32_t c = s_cnt[k][t]; s_cnt[k][t] = (uint16_t)run; run += c; }
+    }
     uint32_t tot;
     uint32_t ex = block_exclusive_scan<uint32_t, NW>(run, s_tmp, &tot);
-    s_start[t] = (uint16_t)ex;
+    if (t < NB) {
+        s_start[t] = (uint16_t)ex;
+        s_goff[t] = my_off - ex;                                        /* destination of record i of bin t = s_goff[t] + i */
+    }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < MTB_SORT_ITEMS; r++) {
@@ -157,7 +186,7 @@ __global__ __launch_bounds__(THREADS) void k_radix_scatter(const mtb_kmer *__res
     for (uint32_t i = t; i < cnt; i += THREADS) {
         mtb_kmer x = s_buf[i];
         uint32_t d = radix_digit<MODE>(x.value, shift);
-        const uint64_t dst = (uint64_t)tile_off[(uint64_t)d * num_tiles + blockIdx.x] + (i - s_start[d]);
+        const uint64_t dst = (uint64_t)(s_goff[d] + i);
         out[dst] = x;
         if (dig_out) dig_out[dst] = (uint16_t)radix_digit<MODE>(x.value, next_shift);      /* next pass's histogram input */
     }
@@ -176,7 +205,7 @@ static mtb_kmer *radix_sort_kmers(hipStream_t st, mtb_kmer *a, mtb_kmer *b, uint
     for (int shift = first_bit; shift < 64; shift += 8) {
         hipLaunchKernelGGL((k_radix_hist<256, 0, 256>), dim3(tiles), dim3(256), 0, st, src, n, shift, hist, tiles);
         scan_launch<uint32_t, uint32_t, false>(st, hist, 256ull * tiles, false, hist, ws);
-        hipLaunchKernelGGL((k_radix_scatter<256, 0, 256>), dim3(tiles), dim3(256), 0, st, src, dst, n, shift, hist, tiles);
+        hipLaunchKernelGGL((k_radix_scatter<256, 0, 256>), dim3((tiles + 7u) / 8u * 8u), dim3(256), 0, st, src, dst, n, shift, hist, tiles);
         mtb_kmer *tmp = src; src = dst; dst = tmp;
     }
     return src;

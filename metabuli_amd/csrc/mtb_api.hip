@@ -340,7 +340,9 @@ static mtb_status dev_sort(mtb_ctx *c, mtb_kmer *d_a, uint64_t n, int first_bit,
     STCHK(ensure(c, "hist", radix_hist_elems(n, bins), &d_hist));
     STCHK(ensure(c, "scanws", scan_ws_elems(radix_hist_elems(n, bins)), &d_ws));
     {
-        const uint64_t tile = (uint64_t)bins * MTB_SORT_ITEMS;        /* one bin per thread, 8 records per thread */
+        static const int xcd_map = getenv("MTB_SORT_NO_XCD") ? 0 : 1;
+        const uint32_t sc_threads = aa ? 512u : 256u;
+        const uint64_t tile = (uint64_t)sc_threads * MTB_SORT_ITEMS;  /* MTB_SORT_ITEMS records per scatter thread */
         uint32_t tiles = (uint32_t)((n + tile - 1) / tile);
         mtb_kmer *src = d_a, *dst = d_b;
         /* AA6 with a digit side array: every histogram reads 2-byte digits (the extractor wrote the first pass's, each
@@ -351,14 +353,16 @@ static mtb_status dev_sort(mtb_ctx *c, mtb_kmer *d_a, uint64_t n, int first_bit,
          * target accesses, so the fused path may stop after fewer letter pairs (aa_first_shift: 34 = six letters, 44 = four, 54 = two) */
         for (int shift = aa ? aa_first_shift : first_bit; shift < 64; shift += aa ? 10 : 8) {
             { KTimer kt(c, MTB_K_RADIX_HIST);
-              if (aa && dig_src) hipLaunchKernelGGL((k_radix_hist_dig<512, 512>), dim3((tiles + MTB_HIST_GROUP - 1) / MTB_HIST_GROUP), dim3(512), 0, c->stream, (const uint16_t *)dig_src, n, d_hist, tiles);
+              const dim3 hg((tiles + MTB_HIST_GROUP - 1) / MTB_HIST_GROUP);
+              if (aa && dig_src) hipLaunchKernelGGL((k_radix_hist_dig<512, 512>), hg, dim3(512), 0, c->stream, (const uint16_t *)dig_src, n, d_hist, tiles);
               else if (aa) hipLaunchKernelGGL((k_radix_hist<512, 1, 512>), dim3(tiles), dim3(512), 0, c->stream, (const mtb_kmer *)src, n, shift, d_hist, tiles);
               else hipLaunchKernelGGL((k_radix_hist<256, 0, 256>), dim3(tiles), dim3(256), 0, c->stream, (const mtb_kmer *)src, n, shift, d_hist, tiles); }
             { KTimer kt(c, MTB_K_SCAN); scan_launch<uint32_t, uint32_t, false>(c->stream, d_hist, (uint64_t)bins * tiles, false, d_hist, (uint32_t *)d_ws); }
             { KTimer kt(c, MTB_K_RADIX_SCATTER);
-              if (aa) hipLaunchKernelGGL((k_radix_scatter<512, 1, 512>), dim3(tiles), dim3(512), 0, c->stream, (const mtb_kmer *)src, dst, n, shift, (const uint32_t *)d_hist, tiles,
-                                         (dig_src && shift + 10 < 64) ? dig_dst : (uint16_t *)nullptr, shift + 10);
-              else hipLaunchKernelGGL((k_radix_scatter<256, 0, 256>), dim3(tiles), dim3(256), 0, c->stream, (const mtb_kmer *)src, dst, n, shift, (const uint32_t *)d_hist, tiles); }
+              const dim3 sg((tiles + 7u) / 8u * 8u);
+              uint16_t *dnext = (dig_src && shift + 10 < 64) ? dig_dst : (uint16_t *)nullptr;
+              if (aa) hipLaunchKernelGGL((k_radix_scatter<512, 1, 512>), sg, dim3(512), 0, c->stream, (const mtb_kmer *)src, dst, n, shift, (const uint32_t *)d_hist, tiles, dnext, shift + 10, xcd_map);
+              else hipLaunchKernelGGL((k_radix_scatter<256, 0, 256>), sg, dim3(256), 0, c->stream, (const mtb_kmer *)src, dst, n, shift, (const uint32_t *)d_hist, tiles); }
             mtb_kmer *tmp = src; src = dst; dst = tmp;
             if (dig_src) { uint16_t *t2 = dig_src; dig_src = dig_dst; dig_dst = t2; }
         }

@@ -210,3 +210,38 @@ def test_mtb_hpp_stage_classes_execute(orc, tmp_path, mode):
         if amb[i]:
             continue
         assert nm == f"r{i}" and int(cls) == ro["classification"][i] and np.float32(float(sc)).view(np.uint32) == ro["score"][i].view(np.uint32)
+
+
+@pytest.mark.parametrize("mode", ["sync_se", "sync_pe"])
+def test_filter_mode_splits_the_reads(orc, tmp_path, mode):
+    """`mtb_classify --filter 1 --print-mode 2` (the `filter` command over the same seam, QueryFilter.cpp:75-118, filter.cpp:5-45):
+    classified reads (at the command's default --min-score 0.5) go to <base>_removed.fna, the others to <base>_filtered.fna, as
+    ">name\\nsequence\\n" in input order, mates split alike; <base> drops the last extension (two for .gz)."""
+    import gzip
+    from conftest import Toy, TOY_MODES
+    t = Toy(orc, tmp_path / "db", **TOY_MODES[mode])
+    names = [f"read{i}" for i in range(t.n_reads)]
+    fq1 = str(tmp_path / "sample.R1.fq"); _write_fastq(fq1, names, t.b1, t.o1)
+    files = [fq1]
+    if t.b2 is not None:
+        plain = str(tmp_path / "sample.R2.fq"); _write_fastq(plain, names, t.b2, t.o2)
+        fq2 = plain + ".gz"
+        with open(plain, "rb") as f, gzip.open(fq2, "wb") as g:
+            g.write(f.read())
+        os.remove(plain)
+        files.append(fq2)
+    subprocess.check_call([_exe(), "--filter", "1", "--print-mode", "2", "--seq-mode", str(t.p.seq_mode), "--max-reads", "170"] + files + [t.dbdir],
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    p = type(t.p).from_buffer_copy(t.p); p.min_score = 0.5           # filter.cpp:8
+    ref = orc.classify(t.db, t.tax, p, t.b1, t.o1, t.b2, t.o2)["results"]
+    cls = ref["is_classified"] != 0
+    assert 0 < cls.sum() < t.n_reads                      # both files get reads
+    for k, (b, o, path) in enumerate([(t.b1, t.o1, files[0])] + ([(t.b2, t.o2, files[1])] if t.b2 is not None else [])):
+        base = str(tmp_path / ("sample.R1" if k == 0 else "sample.R2"))
+        def fasta(sel):
+            return "".join(f">{names[i]}\n{bytes(b[int(o[i]):int(o[i + 1])]).decode()}\n" for i in range(t.n_reads) if sel[i])
+        assert open(base + "_filtered.fna").read() == fasta(~cls)
+        assert open(base + "_removed.fna").read() == fasta(cls)
+    rows = open(str(tmp_path / "sample.R1_classifications.tsv")).read().split("\n")[1:-1]
+    assert [r[0] == "1" for r in rows] == cls.tolist()
+    assert os.path.exists(str(tmp_path / "sample.R1_report.tsv")) and not os.path.exists(str(tmp_path / "sample.R1_krona.html"))
