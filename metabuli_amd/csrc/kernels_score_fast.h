@@ -77,8 +77,11 @@ __device__ __forceinline__ uint32_t fk_dna(const FKey &k) { return k.lo & 0xFFFF
 /* emitted path, one per lane during the combination */
 struct FastPath { int32_t start, end; float score; int32_t ham; uint32_t rehs; /* start_reh | end_reh << 16 */ int32_t species; };
 
-template <int K>
-__global__ __launch_bounds__(64, 4) void k_score_fast(const mtb_slot16 *__restrict__ slots_all, uint64_t n_reads, const int32_t *__restrict__ qlen,
+/* K = elements per lane after the compaction (n <= 64 K matches), KL = slots loaded per lane (stride <= 64 KL).  BYFRAME: pairs.
+ * The slot order of a pair is (mate, frame, position), compareMatches order is (species, frame, position) with the second mate's
+ * positions behind the first mate's: the compaction then takes one (species, frame) after another instead of one species. */
+template <int K, int KL = K, bool BYFRAME = false>
+__global__ __launch_bounds__(64, K <= 3 ? 4 : 2) void k_score_fast(const mtb_slot16 *__restrict__ slots_all, uint64_t n_reads, const int32_t *__restrict__ qlen,
                                                        const int32_t *__restrict__ qlen2, mtb_tax_view tx, mtb_score_params sp,
                                                        const uint64_t *__restrict__ tc_off, mtb_result *__restrict__ results,
                                                        int32_t *__restrict__ tc_tax, uint32_t *__restrict__ tc_cnt, uint64_t tc_cap, uint64_t tc_base,
@@ -118,9 +121,9 @@ __global__ __launch_bounds__(64, 4) void k_score_fast(const mtb_slot16 *__restri
         const int32_t nb = mtb_num_buckets(read_len, sp.dna_shift);
         const uint32_t cur = cursor[r];
         const mtb_slot16 *slots = slots_all + r * (uint64_t)stride;
-        mtb_slot16 x[K];
+        mtb_slot16 x[KL];
 #pragma unroll
-        for (int k = 0; k < K; k++) { const uint32_t i = (uint32_t)lane + 64u * k; x[k].a = 0; x[k].b = 0; if (i < stride) x[k] = slots[i]; }
+        for (int k = 0; k < KL; k++) { const uint32_t i = (uint32_t)lane + 64u * k; x[k].a = 0; x[k].b = 0; if (i < stride) x[k] = slots[i]; }
         bool slow = cur > tail_cap || nb > MTB_FAST_BKT;
         wave_fence();                                   /* previous read's LDS traffic is complete */
         MTB_FAST_MARK(0);       /* setup + slot loads issued */
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(64, 4) void k_score_fast(const mtb_slot16 *__restri
          * slot order -- which is (frame, position) order when the read has one match per metamer and species.  Whether the result
          * really is compareMatches order is checked on the keys below (S1). ---- */
         int32_t n = 0, n_live = 0;
-        uint32_t spc[K]; bool live[K]; int32_t dst[K];
+        uint32_t spc[KL]; bool live[KL]; int32_t dst[KL];
         /* A match whose species has no other match in the read cannot be part of a path (a (species, frame) block needs two position
          * groups, Taxonomer.cpp:342 and the walk of getMatchPaths), so its species never gets a score and the match is never looked
          * at again: it is dropped here.  With an index full of foreign species most stray hits are of this kind (every hit of a
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(64, 4) void k_score_fast(const mtb_slot16 *__restri
          * 256-entry species hash (a collision only keeps a droppable match). */
         uint32_t smin = 0xFFFFFFFFu, smax = 0u;
 #pragma unroll
-        for (int k = 0; k < K; k++) {
+        for (int k = 0; k < KL; k++) {
             const uint32_t i = (uint32_t)lane + 64u * k;
             live[k] = i < stride && mtb_slot_epoch(x[k]) == epoch && (i < direct || i - direct < cur);
             spc[k] = live[k] ? (uint32_t)(x[k].a >> 32) : 0xFFFFFFFFu;
@@ -153,23 +156,27 @@ __global__ __launch_bounds__(64, 4) void k_score_fast(const mtb_slot16 *__restri
             for (int32_t q = lane; q < 256; q += 64) s_hcnt[q] = 0;
             wave_fence();
 #pragma unroll
-            for (int k = 0; k < K; k++) if (live[k]) atomicAdd(&s_hcnt[(spc[k] * 0x9E3779B1u) >> 24], 1u);
+            for (int k = 0; k < KL; k++) if (live[k]) atomicAdd(&s_hcnt[(spc[k] * 0x9E3779B1u) >> 24], 1u);
             wave_fence();
 #pragma unroll
-            for (int k = 0; k < K; k++) if (live[k] && s_hcnt[(spc[k] * 0x9E3779B1u) >> 24] < 2u) { live[k] = false; spc[k] = 0xFFFFFFFFu; }
+            for (int k = 0; k < KL; k++) if (live[k] && s_hcnt[(spc[k] * 0x9E3779B1u) >> 24] < 2u) { live[k] = false; spc[k] = 0xFFFFFFFFu; }
         } else if (n_live < 2) {
 #pragma unroll
-            for (int k = 0; k < K; k++) { live[k] = false; spc[k] = 0xFFFFFFFFu; }        /* a single match is lonely too */
+            for (int k = 0; k < KL; k++) { live[k] = false; spc[k] = 0xFFFFFFFFu; }        /* a single match is lonely too */
+        }
+        if (BYFRAME) {                              /* round key: species, frame (species < 2^22 on this path) */
+#pragma unroll
+            for (int k = 0; k < KL; k++) if (live[k]) spc[k] = (spc[k] << 3) | ((uint32_t)(x[k].b >> 52) & 7u);
         }
 #pragma unroll
-        for (int k = 0; k < K; k++) todo_min = spc[k] < todo_min ? spc[k] : todo_min;
+        for (int k = 0; k < KL; k++) todo_min = spc[k] < todo_min ? spc[k] : todo_min;
         for (int round = 0; ; round++) {
             const uint32_t m = wave_min_u32(todo_min);
             if (m == 0xFFFFFFFFu) break;
-            if (round == 8) { slow = true; break; }                    /* many species: the generic kernel sorts */
+            if (round == (BYFRAME ? 24 : 8)) { slow = true; break; }   /* many species: the generic kernel sorts */
             todo_min = 0xFFFFFFFFu;
 #pragma unroll
-            for (int k = 0; k < K; k++) {
+            for (int k = 0; k < KL; k++) {
                 const bool mine = spc[k] == m;
                 const uint64_t mask = __ballot(mine);
                 if (mine) { dst[k] = n + (int32_t)__popcll(mask & lt); spc[k] = 0xFFFFFFFFu; }
@@ -177,8 +184,9 @@ __global__ __launch_bounds__(64, 4) void k_score_fast(const mtb_slot16 *__restri
                 todo_min = spc[k] < todo_min ? spc[k] : todo_min;
             }
         }
+        if (KL > K && n > NMAX) slow = true;        /* more matches than the register-resident part holds */
 #pragma unroll
-        for (int k = 0; k < K; k++) {
+        for (int k = 0; k < KL; k++) {
             if (live[k] && !slow) {
                 const uint64_t b = x[k].b;
                 const uint32_t bh = (uint32_t)(b >> 32), ps_ = (bh >> 8) & 0x7FFu;          /* slot word b: epoch ham[23..26] frame[20..22] pos[8..19] | reh dna */
