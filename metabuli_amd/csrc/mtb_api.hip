@@ -536,7 +536,7 @@ static mtb_status dev_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, uint
         tc_base, S->list, S->n_list, S->cursor, S->stride, S->seg_by_list, S->direct, S->epoch, S->big_list, S->n_big, S->cnt_out, d_work, S->only_flagged)
         ScoreSrc S_rest;
         const bool pairs = p->seq_mode == 2;
-        if (S->cursor && pass == 0 && key64 && S->stride <= (pairs ? 384u : 256u) && !getenv("MTB_NO_FAST_SCORER") && !(pairs && getenv("MTB_NO_FAST_PAIRS"))) {
+        if (S->cursor && pass == 0 && key64 && S->stride <= 384u && !getenv("MTB_NO_FAST_SCORER") && !(pairs && getenv("MTB_NO_FAST_PAIRS"))) {
             /* slot mode: the register-resident scorer takes every read with the common structure (slots in compareMatches order
              * once the species -- for pairs the (species, frame) runs -- are laid one after another, one match per position
              * group) and lists the others for the generic kernel below */
@@ -548,7 +548,7 @@ static mtb_status dev_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, uint
             (const uint64_t *)d_tcoff, d_res, d_tc_tax, d_tc_cnt, tc_cap, tc_base, S->cursor, S->stride, S->direct, S->epoch, d_slow, S->cnt_out)
             { KTimer ktf(c, MTB_K_SCORE_FAST);
               if (pairs) { if (S->stride <= 192) MTB_LAUNCH_FAST(3, 3, true); else if (S->stride <= 256) MTB_LAUNCH_FAST(4, 4, true); else MTB_LAUNCH_FAST(5, 6, true); }
-              else if (S->stride <= 128) MTB_LAUNCH_FAST(2); else if (S->stride <= 192) MTB_LAUNCH_FAST(3); else MTB_LAUNCH_FAST(4); }
+              else if (S->stride <= 128) MTB_LAUNCH_FAST(2); else if (S->stride <= 192) MTB_LAUNCH_FAST(3); else if (S->stride <= 256) MTB_LAUNCH_FAST(4); else MTB_LAUNCH_FAST(5, 6, false); }
 #undef MTB_LAUNCH_FAST
             hipLaunchKernelGGL(k_count_flags, dim3(256), dim3(256), 0, c->stream, (const uint8_t *)d_slow, n_reads, (unsigned long long *)(c->d_scal + 6));
             c->fast_used = true;

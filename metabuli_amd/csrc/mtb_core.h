@@ -207,6 +207,12 @@ MTB_HD bool mtb_window_metamer_words(uint32_t w0, uint32_t w1, int syncmer, int 
     const uint64_t aa = ((uint64_t)a0 << 20) | a1;
     *value = (aa << 24) | dna;
     if (!syncmer) return true;
+    if (smer_len == 5) {            /* the default: the four 25-bit s-mers from the two 20-bit halves, 32-bit arithmetic only */
+        const uint32_t s0 = (a0 << 5) | (a1 >> 15), s1 = ((a0 & 0x7FFFu) << 10) | (a1 >> 10);
+        const uint32_t s2 = ((a0 & 0x3FFu) << 15) | (a1 >> 5), s3 = ((a0 & 0x1Fu) << 20) | a1;
+        const uint32_t mid = s1 < s2 ? s1 : s2;
+        return (s0 <= mid && s0 <= s3) || (s3 < s0 && s3 < mid);      /* leftmost minimum at the first or the last position */
+    }
     int ns = 8 - smer_len + 1;
     uint64_t mask = (1ull << (5 * smer_len)) - 1;
     uint64_t best = ~0ull; int arg = 0;

@@ -612,3 +612,38 @@ def test_packed_index_state_round_trips(toy, monkeypatch, tmp_path):
     for name in ("diffIdx", "info"):
         assert (out / name).read_bytes() == open(os.path.join(toy.dbdir, name), "rb").read(), name
     ix.close(); c.close()
+
+
+@pytest.mark.parametrize("paired,length", [(False, 100), (False, 250), (True, 75), (True, 110), (True, 150)])
+def test_register_resident_scorer_variants(ctx, orc, tmp_path, paired, length):
+    """k_score_fast instantiations by slot stride: single reads 2 / 3 / 4 elements per lane (<= 128 / 192 / 256 slots), pairs
+    3 / 4 / 5 with the (species, frame) runs re-ordered (the slot order of a pair is mate-major, compareMatches order is
+    frame-major).  genus_div 0.3 and one strain per species keep most reads on the fast kernel (checked through the
+    statistics); every row still has to equal the oracle's."""
+    import metabuli_amd as M
+    from conftest import Toy
+    from helpers import default_params
+    from metabuli_amd import synth
+    t = Toy.__new__(Toy)
+    t.p = default_params(seq_mode=2 if paired else 1, syncmer=1)
+    t.world = synth.make_world(seed=40 + length, n_genera=3, species_per_genus=2, strains_per_species=1, genome_len=30000, genus_div=0.3)
+    t.dbdir = str(tmp_path)
+    from helpers import build_toy_db
+    t.values, t.taxids = build_toy_db(orc, t.world, t.p, t.dbdir)
+    t.tax = orc.load_taxonomy(os.path.join(t.dbdir, "taxonomy"))
+    t.db = orc.open_db(t.dbdir, t.tax, t.p)
+    out = synth.sample_reads(np.random.default_rng(length), t.world, 600, length=length, err=0.01, with_n=0.05, paired=paired, lognormal=False)
+    if paired:
+        t.b1, t.o1, t.b2, t.o2, _ = out
+    else:
+        (t.b1, t.o1, _), t.b2, t.o2 = out, None, None
+    t.n_reads = 600
+    t.ref = orc.classify(t.db, t.tax, t.p, t.b1, t.o1, t.b2, t.o2)
+    p = M.default_params(seq_mode=t.p.seq_mode, syncmer=1)
+    ix = ctx.open_index(t.dbdir, p)
+    res, tt, tc = ctx.classify_batch(ix, p, t.b1, t.o1, t.b2, t.o2)
+    _check_results(t, res, tt, tc)
+    st = ctx.last_stats()
+    assert st.n_generic_reads < 0.5 * t.n_reads, st.n_generic_reads          # the fast kernel really took most of them
+    assert (res["is_classified"] != 0).sum() > 0.6 * t.n_reads
+    ix.close()
