@@ -15,8 +15,9 @@
  *          --tie-ratio F  --taxonomy-path DIR  --syncmer 0|1  --smer-len N  --kmer-format 1|2  --accession-level 0|1|2
  *          --lineage 0|1  --threads N (host parsing / formatting)
  *   accepted for command-line compatibility, no effect here (one warning each): --max-ram (batches are bounded by HBM inside
- *          the library; the host batch is --max-reads), --match-per-kmer (exact-size retry), --hamming-margin, --mask,
- *          --mask-prob, --validate-input, --validate-db, --print-log, -v   (LocalParameters.cpp:631-654)
+ *          the library; the host batch is --max-reads), --match-per-kmer (exact-size retry), --hamming-margin and --max-gap (stored
+ *          but never read by the reference's classify path either), --mask 0, --mask-prob, --validate-input, --validate-db,
+ *          --print-log, -v   (LocalParameters.cpp:631-654).  Refused: --mask 1, --reduced-aa 1 (they change the answers)
  *   filter mode (`metabuli filter`, src/workflow/filter.cpp:5-45, QueryFilter.cpp:75-186): --filter 1 [--print-mode 1|2] <FASTA/Q> [<mate>] <DBDIR>
  *          classifies with the filter command's defaults (--min-score 0.5 unless given) and writes, next to the input,
  *          <base>_filtered.fna (reads NOT classified = not contamination), with --print-mode 2 also <base>_removed.fna (classified
@@ -236,7 +237,9 @@ int main(int argc, char **argv) {
         else if (a == "--device") { devices.assign(1, atoi(val().c_str())); }
         else if (a == "--devices") { devices.clear(); std::stringstream ss(val()); std::string tok; while (std::getline(ss, tok, ',')) if (!tok.empty()) devices.push_back(atoi(tok.c_str())); }
         else if (a == "--reduced-aa") { if (atoi(val().c_str()) != 0) { fprintf(stderr, "mtb_classify: --reduced-aa 1 is not implemented\n"); return 1; } }
-        else if (a == "--max-ram" || a == "--match-per-kmer" || a == "--hamming-margin" || a == "--mask" || a == "--mask-prob" ||
+        else if (a == "--mask") {       /* tantan masking of the reads before extraction (KmerExtractor.cpp:308-314) changes the answers: refuse it rather than ignore it */
+            if (atoi(val().c_str()) != 0) { fprintf(stderr, "mtb_classify: --mask 1 (low-complexity masking of the reads) is not implemented\n"); return 1; } }
+        else if (a == "--max-ram" || a == "--match-per-kmer" || a == "--hamming-margin" || a == "--mask-prob" ||
                  a == "--validate-input" || a == "--validate-db" || a == "--print-log" || a == "-v" || a == "--max-gap") {
             std::string v = val();
             fprintf(stderr, "mtb_classify: %s %s accepted for compatibility with `metabuli classify`, it has no effect here\n", a.c_str(), v.c_str());
