@@ -388,6 +388,9 @@ def main():
     # a step launches every kernel once per stream (and per radix pass): bytes per launch = total / launches
     alg_step = {"extract_count": L, "extract_emit": L + 16 * Kq, "radix_hist": 16 * Kq, "radix_scatter": 32 * Kq,
                 "join": 16 * Kq + 24 * Mm, "regroup": 48 * Mm, "score": 24 * Mm + 16 * N, "score_fast": 24 * Mm + 16 * N}
+    if params.kmer_format == 2 and kern["radix_hist"]["launches"]:
+        # the fused path's histograms read the 2-byte digit side arrays and write the 4-byte tile table, not the 16-byte records
+        alg_step["radix_hist"] = kern["radix_hist"]["launches"] * (2 * Kq + 4 * 512 * ((Kq + 4095) // 4096))
     alg = {k: v / max(1, kern[k]["launches"]) for k, v in alg_step.items()}
     if kern.get("score_fast", {}).get("launches"):         # the two scoring kernels share the reads
         gfrac = ps.n_generic_reads / max(1, N)
