@@ -210,6 +210,22 @@ def cpu_model():
     return "unknown"
 
 
+def finish(dist, line):
+    """Rank 0's JSON line is the LAST thing on stdout: collectives are torn down first and whatever C libraries (RCCL prints its
+    library path through C stdio, which is block-buffered on a pipe) left in the C-level buffer is flushed before it."""
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    if line is not None:
+        print(line, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -235,19 +251,28 @@ def main():
     ap.add_argument("--prealloc", action="store_true", help="experiment: grow the context's workspace on a tiny index BEFORE the big index is allocated")
     ap.add_argument("--no-seal", action="store_true", help="keep the flat {value, info} arrays next to the packed state (mtb_index_seal not called)")
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--dist-backend", default="nccl", help="testing only: gloo lets several ranks share one GPU (RCCL refuses duplicate devices)")
+    ap.add_argument("--shared-gpu", action="store_true", help="testing only: every rank uses cuda:0")
     args = ap.parse_args()
 
     import torch  # before libmtb: both must share one HIP runtime (libamdhip64.so.7)
     rank = int(os.environ.get("RANK", "0")); world_size = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if rank != 0:       # torch.distributed.run interleaves every rank's stdout: only rank 0 may write there (C libraries included)
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
     if world_size != args.gpus:
         log(f"warning: WORLD_SIZE={world_size} but --gpus {args.gpus}")
+    if args.shared_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world_size > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world_size)
     elif args.partitioned:
         import torch.distributed as dist
         dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{29400 + os.getpid() % 500}", rank=0, world_size=1, device_id=dev)
@@ -360,7 +385,7 @@ def main():
         log(f"[rank {rank}] partitioned step: classified {frac_cls:.4f}")
         if rank == 0:
             value = args.reads * world_size * args.steps / dt / 1e6
-            print(json.dumps(dict(metric="Mreads/s classified (metabuli classify hot path, reads + index resident in HBM)",
+            line = json.dumps(dict(metric="Mreads/s classified (metabuli classify hot path, reads + index resident in HBM)",
                                   value=value, unit="Mreads/s", n_gpus=world_size, steps=args.steps, warmup=args.warmup,
                                   ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None,
                                   dtype="u64", data="synthetic",
@@ -369,9 +394,8 @@ def main():
                                               reads_per_gpu=args.reads, read_len=args.read_len, targets=int(T), seq_mode=args.seq_mode,
                                               classified_fraction=frac_cls,
                                               parallelism=f"index range-partitioned x{world_size}, 2 all-to-all per batch; results to host"),
-                                  roofline=None, cpu_baseline=None)), flush=True)
-        dist.barrier()
-        dist.destroy_process_group()
+                                  roofline=None, cpu_baseline=None))
+        finish(dist, line if rank == 0 else None)
         return
 
     # one extra, untimed, profiled step on ONE stream (kernels not overlapped, full-batch launches):
@@ -455,10 +479,9 @@ def main():
                    stage_ms=dict(extract=st.ms_extract, sort=st.ms_sort, join=st.ms_join, regroup=st.ms_regroup,
                                  segsort=st.ms_segsort, score=st.ms_score, total=st.ms_total),
                    kernel_ms=kern, roofline=roofline, roofline_all=roofline_all, cpu_baseline=cpu, parity_sample=parity)
-        print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        finish(dist, json.dumps(out))
+    else:
+        finish(dist, None)
 
 
 if __name__ == "__main__":
