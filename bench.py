@@ -373,6 +373,7 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
+    sub_batches_timed = ctx.last_sub_batches if part is None else 0      # of the last timed step (the profiled step and the parity sample overwrite the counter)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -474,7 +475,7 @@ def main():
                                reads_per_gpu=args.reads, read_len=args.read_len, targets=int(T), seq_mode=args.seq_mode,
                                gbp_per_s=value * args.read_len * (2 if args.seq_mode == 2 else 1) / 1e3, query_metamers=int(st.n_kmers), matches=int(st.n_matches),
                                classified_fraction=frac_cls, parallelism=f"reads sharded x{world_size}, index replicated", streams_per_gpu=args.streams,
-                               sub_batches_per_step=ctx.last_sub_batches, index_sealed=sealed,
+                               sub_batches_per_step=sub_batches_timed, index_sealed=sealed,
                                index_bytes=int(T * 8 + 4 * (1801088541 + 1)) if sealed else int(T * 12 + 4 * (1801088541 + 1)), reads_scored_by_generic_kernel=int(ps.n_generic_reads)),
                    stage_ms=dict(extract=st.ms_extract, sort=st.ms_sort, join=st.ms_join, regroup=st.ms_regroup,
                                  segsort=st.ms_segsort, score=st.ms_score, total=st.ms_total),

@@ -73,13 +73,21 @@ struct mtb_ctx {
     double extract_yield = 0.0;      /* metamers per base of the previous batch (single-pass extraction buffer sizing) */
     uint64_t part_n_reads = 0; uint32_t part_max_len = 0;   /* batch state between mtb_part_extract and mtb_part_score */
     uint64_t ws_limit = 0;           /* workspace budget of a batch in bytes; 0 = what hipMemGetInfo reports free (+ what the context holds) */
-    double ws_per_base = 0.0;        /* workspace bytes per base measured on the last sub-batch (HBM-budgeted batching) */
+    double ws_per_base = 0.0;        /* workspace bytes per base: what the buffers hold / the largest sub-batch they were grown for (HBM-budgeted batching) */
+    uint64_t ws_max_sub_bases = 0;   /* bases of the largest sub-batch since the workspace was last released */
+    int ws_seq_mode = 0;             /* the buffer sets of short and long reads differ: a change of mode releases the workspace */
     uint32_t last_sub_batches = 0;
     bool fast_used = false;          /* the last dev_score call launched k_score_fast (its slow-list count sits in d_scal[6]) */
 };
 /* buffers that carry a call's inputs / outputs (host-buffer entry points) are not workspace */
 static bool is_io_buf(const std::string &n) { return n == "bases" || n == "offs" || n == "bases2" || n == "offs2" || n == "results" || n == "tctax" || n == "tccnt"; }
 static size_t held_bytes(const mtb_ctx *c) { size_t b = 0; for (auto &kv : c->bufs) if (!is_io_buf(kv.first)) b += kv.second.cap; return b; }
+/* the part of it that grows with the sub-batch (the slab pool of the large-segment scorer is bounded on its own) */
+static size_t scaling_bytes(const mtb_ctx *c) { size_t b = 0; for (auto &kv : c->bufs) if (!is_io_buf(kv.first) && kv.first != "slabs") b += kv.second.cap; return b; }
+static void release_workspace(mtb_ctx *c) {
+    for (auto &kv : c->bufs) if (kv.second.p && !is_io_buf(kv.first)) { hipError_t e = hipFree(kv.second.p); (void)e; kv.second.p = nullptr; kv.second.cap = 0; }
+    c->ws_per_base = 0.0; c->ws_max_sub_bases = 0;
+}
 
 /* RAII bracket around one kernel launch (only when profiling is on) */
 struct KTimer {
@@ -1315,6 +1323,10 @@ static mtb_status classify_budgeted(mtb_ctx *c, mtb_index *ix, const mtb_params 
     *n_taxcnt = 0;
     c->last_sub_batches = 0;
     if (n_reads == 0) { memset(&c->stats, 0, sizeof(c->stats)); return MTB_OK; }
+    if (c->ws_seq_mode != p->seq_mode) {             /* other buffer set: what the previous mode grew would only sit in the way */
+        if (c->ws_seq_mode) { HIPCHK(hipStreamSynchronize(c->stream)); release_workspace(c); }
+        c->ws_seq_mode = p->seq_mode;
+    }
     size_t fr = 0, tot = 0;
     HIPCHK(hipMemGetInfo(&fr, &tot));
     const size_t held = held_bytes(c);
@@ -1346,7 +1358,7 @@ static mtb_status classify_budgeted(mtb_ctx *c, mtb_index *ix, const mtb_params 
             if (st != MTB_ERR_OOM || cnt <= 1024) break;
             /* the estimate was too optimistic for this range: give the memory back, halve, redo */
             HIPCHK(hipStreamSynchronize(c->stream));
-            for (auto &kv : c->bufs) if (kv.second.p && !is_io_buf(kv.first)) { hipError_t e = hipFree(kv.second.p); (void)e; kv.second.p = nullptr; kv.second.cap = 0; }
+            release_workspace(c);
             cnt = (cnt + 1) / 2; n_sub *= 2; done *= 2;
         }
         if (st == MTB_ERR_CAPACITY) {
@@ -1356,7 +1368,10 @@ static mtb_status classify_budgeted(mtb_ctx *c, mtb_index *ix, const mtb_params 
             return st;
         }
         if (st != MTB_OK) return st;
-        if (c->stats.n_bases) c->ws_per_base = (double)held_bytes(c) / (double)c->stats.n_bases;
+        /* the buffers only grow: what they hold belongs to the largest sub-batch they have seen, not to this one (dividing by a
+         * smaller one inflates the figure, more sub-batches follow, and the next measurement is worse still) */
+        c->ws_max_sub_bases = std::max<uint64_t>(c->ws_max_sub_bases, c->stats.n_bases);
+        if (c->ws_max_sub_bases) c->ws_per_base = (double)scaling_bytes(c) / (double)c->ws_max_sub_bases;
         merge_stats(S, c->stats); S.ms_total += c->stats.ms_total;
         tc_used += n_tc; lo += cnt; done++;
     }
