@@ -3,12 +3,17 @@
  * src/commons/KmerExtractor.cpp:79; equal values keep extraction order, which
  * is ascending sequenceID, so the result is a valid (value, seqID) order).
  *
- * 8-bit digits; per pass: histogram kernel (tile counts, digit-major), device
- * scan, scatter kernel.  The scatter ranks a 2048-element tile stably with
- * wave64 ballot matching, reorders it through LDS so that every digit's
- * elements leave the CU as one contiguous run (full 128-byte lines instead of
- * scattered 16-byte writes), and adds the scanned tile offsets.
- * Algorithmic HBM bytes per pass: 16 (hist read) + 16 (read) + 16 (write).   */
+ * Per pass: histogram kernel (counts per tile, digit-major table), device scan,
+ * scatter kernel.  Stage API (mtb_sort_kmers): 8-bit digits over all 64 bits,
+ * 2048-record tiles.  Fused path: three passes whose digit is a PAIR of
+ * amino-acid letters (441 of 512 bins), 4096-record tiles, histograms from
+ * 2-byte digit side arrays.  The scatter ranks a tile stably with wave64 ballot
+ * matching, reorders it through LDS so that every digit's records leave the CU
+ * as one contiguous run, and adds the scanned tile offsets; tiles are handed
+ * out in XCD-contiguous order so that the adjacent runs of neighbouring tiles
+ * merge in one L2.
+ * Algorithmic HBM bytes per pass: 16 (read) + 16 (write) per record, + 2 + 2
+ * for the digit side arrays (16 instead of 2 where the histogram reads records). */
 #ifndef MTB_KERNELS_SORT_H
 #define MTB_KERNELS_SORT_H
 #include "dev_util.h"
