@@ -173,7 +173,7 @@ __global__ __launch_bounds__(64, K <= 3 ? 4 : 2) void k_score_fast(const mtb_slo
         for (int round = 0; ; round++) {
             const uint32_t m = wave_min_u32(todo_min);
             if (m == 0xFFFFFFFFu) break;
-            if (round == (BYFRAME ? 24 : 8)) { slow = true; break; }   /* many species: the generic kernel sorts */
+            if (round == 24) { slow = true; break; }   /* many species: the generic kernel sorts */
             todo_min = 0xFFFFFFFFu;
 #pragma unroll
             for (int k = 0; k < KL; k++) {
