@@ -210,6 +210,12 @@ def cpu_model():
     return "unknown"
 
 
+def silence_other_ranks(rank):
+    """torch.distributed.run interleaves every rank's stdout: only rank 0 may write there (C libraries included)"""
+    if rank != 0:
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
+
+
 def finish(dist, line):
     """Rank 0's JSON line is the LAST thing on stdout: collectives are torn down first and whatever C libraries (RCCL prints its
     library path through C stdio, which is block-buffered on a pipe) left in the C-level buffer is flushed before it."""
@@ -258,8 +264,7 @@ def main():
     import torch  # before libmtb: both must share one HIP runtime (libamdhip64.so.7)
     rank = int(os.environ.get("RANK", "0")); world_size = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if rank != 0:       # torch.distributed.run interleaves every rank's stdout: only rank 0 may write there (C libraries included)
-        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
+    silence_other_ranks(rank)
     if world_size != args.gpus:
         log(f"warning: WORLD_SIZE={world_size} but --gpus {args.gpus}")
     if args.shared_gpu:

@@ -62,3 +62,35 @@ def test_shard_range_partition():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
             assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+def test_bench_json_line_is_the_last_line_of_the_combined_stdout(tmp_path):
+    """bench.py under torch.distributed.run: every rank shares one stdout, and C libraries (RCCL prints its path through C stdio,
+    block-buffered on a pipe) flush at process exit -- after a JSON line printed earlier.  bench.silence_other_ranks + bench.finish
+    must leave rank 0's JSON line as the LAST line and the only JSON line.  Two gloo ranks, a C-level printf on every rank."""
+    import json
+    import subprocess
+    script = tmp_path / "two_ranks.py"
+    script.write_text(f"""
+import ctypes, os, sys
+sys.path.insert(0, {ROOT!r})
+import torch.distributed as dist
+import bench
+rank = int(os.environ["RANK"])
+bench.silence_other_ranks(rank)
+dist.init_process_group("gloo", rank=rank, world_size=int(os.environ["WORLD_SIZE"]))
+libc = ctypes.CDLL(None)
+libc.printf(b"C-level chatter of rank %d (buffered until exit on a pipe)\\n", rank)
+print("python-level chatter of rank", rank, flush=True)
+bench.finish(dist, '{{"value": 1.5, "n_gpus": 2}}' if rank == 0 else None)
+""")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    port = 29600 + os.getpid() % 300
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), str(script)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert json.loads(lines[-1]) == {"value": 1.5, "n_gpus": 2}
+    assert sum(1 for l in lines if l.lstrip().startswith("{")) == 1
+    assert not any("rank 1" in l for l in lines)              # nothing of the other rank reaches the shared stdout
+    assert any("C-level chatter of rank 0" in l for l in lines[:-1])
