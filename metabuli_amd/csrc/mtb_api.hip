@@ -154,6 +154,9 @@ static mtb_status ensure(mtb_ctx *c, const char *name, size_t elems, T **out) {
             return fail(MTB_ERR_OOM, std::string("hipMalloc failed for ") + name + ": " + hipGetErrorString(e));
         }
         b.cap = want;
+#ifdef MTB_POISON_ALLOC     /* robustness build (make libmtb_xpoison.so X=-DMTB_POISON_ALLOC): no kernel may rely on fresh device memory being zero */
+        HIPCHK(hipMemsetAsync(b.p, 0xA5, want, c->stream));         /* on the library's stream: it must not overtake or trail the kernels that use the buffer */
+#endif
     }
     *out = (T *)b.p;
     return MTB_OK;
