@@ -647,3 +647,42 @@ def test_register_resident_scorer_variants(ctx, orc, tmp_path, paired, length):
     assert st.n_generic_reads < 0.5 * t.n_reads, st.n_generic_reads          # the fast kernel really took most of them
     assert (res["is_classified"] != 0).sum() > 0.6 * t.n_reads
     ix.close()
+
+
+def test_no_kernel_relies_on_zeroed_device_memory(orc, tmp_path):
+    """hipMalloc happens to hand out cleared VRAM; nothing may depend on it.  libmtb_xpoison.so (-DMTB_POISON_ALLOC) fills every new
+    workspace buffer with 0xA5 on the library's stream before its first use; a single-end and a paired toy batch through the fused
+    path (slot segments, register-resident and generic scorer, taxID:count lists) must still equal the oracle."""
+    import subprocess
+    import sys
+    import metabuli_amd as M
+    from conftest import Toy, TOY_MODES
+    csrc = os.path.dirname(M.LIB_PATH)
+    subprocess.check_call(["make", "-C", csrc, "libmtb_xpoison.so", "X=-DMTB_POISON_ALLOC"], stdout=subprocess.DEVNULL)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for mode in ("sync_se", "sync_pe"):
+        t = Toy(orc, tmp_path / mode, **TOY_MODES[mode])
+        ref = t.ref["results"]
+        exp = str(tmp_path / f"{mode}_expected.npz"); inp = str(tmp_path / f"{mode}_reads.npz")
+        np.savez(exp, cls=ref["classification"], score=ref["score"], flag=ref["flag"], tt=t.ref["tc_tax"], tc=t.ref["tc_cnt"])
+        np.savez(inp, b1=t.b1, o1=t.o1, **({"b2": t.b2, "o2": t.o2} if t.b2 is not None else {}))
+        code = f"""
+import sys, numpy as np
+sys.path.insert(0, {root!r})
+import metabuli_amd as M
+assert M.LIB_PATH.endswith("libmtb_xpoison.so"), M.LIB_PATH
+r = np.load({inp!r}); e = np.load({exp!r})
+c = M.Context(0)
+p = M.default_params(seq_mode={int(t.p.seq_mode)}, syncmer=1)
+ix = c.open_index({t.dbdir!r}, p)
+for _ in range(2):
+    res, tt, tc = c.classify_batch(ix, p, r["b1"], r["o1"], r["b2"] if "b2" in r else None, r["o2"] if "o2" in r else None)
+    amb = e["flag"] != 0
+    assert ((res["classification"] == e["cls"]) | amb).all()
+    assert ((res["score"].view(np.uint32) == e["score"].view(np.uint32)) | amb).all()
+    assert not amb.any() and (tt == e["tt"]).all() and (tc == e["tc"]).all()
+print("poisoned run ok", len(res))
+"""
+        env = dict(os.environ, MTB_LIB=os.path.join(csrc, "libmtb_xpoison.so"))
+        p = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        assert p.returncode == 0 and "poisoned run ok" in p.stdout, (p.stdout[-500:], p.stderr[-1500:])
