@@ -36,35 +36,134 @@ def build_world(seed, n_species, genome_len, n_filler_species):
                             genome_len=genome_len, n_filler_species=n_filler_species)
 
 
-def extract_targets(ctx, M, world, params):
-    """Six-frame (sync)metamers of every genome, on the GPU, via the public
-    extraction entry point (long-read geometry, overlapping 20 kb pieces)."""
+def build_world_fast(torch, dev, seed, n_species, genome_len, n_filler_species):
+    """Same shape as synth.make_world (root -> {Bacteria, Eukaryota} -> genus -> 4 species -> 1 strain, genus divergence 15 %,
+    strain divergence 1 %) for THOUSANDS of genomes: sequences are drawn and mutated on the device (Bernoulli substitutions) instead
+    of numpy's choice-without-replacement per genome.  Used for the genome-diversity runs (--species >= 200)."""
+    from metabuli_amd import synth
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    tax = synth.Taxonomy()
+    tax.add(1, 1, "no rank", "root"); tax.add(2, 1, "superkingdom", "Bacteria"); tax.add(3, 1, "superkingdom", "Eukaryota")
+    nxt = 4
+    n_genera = max(1, n_species // 4)
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+
+    def mutate(x, rate):
+        m = torch.rand(x.shape, generator=g, device=dev) < rate
+        sub = (x + torch.randint(1, 4, x.shape, generator=g, device=dev, dtype=torch.uint8)) & 3       # a DIFFERENT base
+        return torch.where(m, sub, x)
+    genomes, species = [], []
+    for gi in range(n_genera):
+        dom = 3 if gi == n_genera - 1 else 2
+        gid = nxt; nxt += 1
+        tax.add(gid, dom, "genus", f"Genus{gi}")
+        anc = torch.randint(0, 4, (genome_len,), generator=g, device=dev, dtype=torch.uint8)
+        for sidx in range(4):
+            sid = nxt; nxt += 1
+            tax.add(sid, gid, "species", f"Genus{gi} species{sidx}")
+            species.append(sid)
+            tid = nxt; nxt += 1
+            tax.add(tid, sid, "no rank", f"Genus{gi} species{sidx} strain0")
+            genomes.append((tid, acgt[mutate(mutate(anc, 0.15), 0.01).long()].cpu().numpy()))
+    lo = nxt
+    for i in range(n_filler_species):
+        tax.add(nxt, 2, "species", f"filler{i}"); nxt += 1
+    return synth.World(tax, genomes, species, lo, nxt - 1)
+
+
+def extract_targets(ctx, M, world, params, torch=None, dev=None, genomes_per_call=48):
+    """Six-frame (sync)metamers of every genome, on the GPU, via the public extraction entry point (long-read geometry,
+    overlapping 20 kb pieces), a few dozen genomes per call; per-genome de-duplication and the final (value, taxid) order on the
+    device when torch is given (thousands of genomes), else numpy."""
     piece, ov = 20000, 32
-    seqs, owner = [], []
-    for gi, (tid, g) in enumerate(world.genomes):
-        for st in range(0, len(g), piece - ov):
-            seqs.append(g[st:st + piece])
-            owner.append(gi)
-            if st + piece >= len(g):
-                break
-    offs = np.zeros(len(seqs) + 1, np.uint64)
-    offs[1:] = np.cumsum([len(s) for s in seqs])
-    bases = np.concatenate(seqs).astype(np.uint8)
     p = M.default_params(seq_mode=3, syncmer=params.syncmer, smer_len=params.smer_len)
-    k, _, _ = ctx.extract(p, bases, offs)
-    owner = np.asarray(owner, dtype=np.int64)
-    seq = ((k["qinfo"] >> np.uint64(32)) & np.uint64(0x1FFFFFFF)).astype(np.int64) - 1
-    g_of = owner[seq]
     vals, tids = [], []
-    for gi, (tid, g) in enumerate(world.genomes):
-        v = np.unique(k["value"][g_of == gi])
-        vals.append(v)
-        tids.append(np.full(len(v), tid, np.int32))
+    for g0 in range(0, len(world.genomes), genomes_per_call):
+        chunk = world.genomes[g0:g0 + genomes_per_call]
+        seqs, owner = [], []
+        for gi, (tid, g) in enumerate(chunk):
+            for st in range(0, len(g), piece - ov):
+                seqs.append(g[st:st + piece])
+                owner.append(gi)
+                if st + piece >= len(g):
+                    break
+        offs = np.zeros(len(seqs) + 1, np.uint64)
+        offs[1:] = np.cumsum([len(x) for x in seqs])
+        bases = np.concatenate(seqs).astype(np.uint8)
+        k, _, _ = ctx.extract(p, bases, offs)
+        owner = np.asarray(owner, dtype=np.int64)
+        seq = ((k["qinfo"] >> np.uint64(32)) & np.uint64(0x1FFFFFFF)).astype(np.int64) - 1       # emission order = piece order = genome order
+        first = np.searchsorted(owner[seq], np.arange(len(chunk) + 1))
+        if torch is not None:
+            kv = torch.from_numpy(np.ascontiguousarray(k["value"]).view(np.int64)).to(dev)
+        for gi, (tid, g) in enumerate(chunk):
+            if torch is not None:
+                v = torch.unique(kv[first[gi]:first[gi + 1]])                                   # (signed order inside a genome; the global order is made below)
+                vals.append(v); tids.append(torch.full((len(v),), tid, dtype=torch.int32, device=dev))
+            else:
+                v = np.unique(k["value"][first[gi]:first[gi + 1]])
+                vals.append(v); tids.append(np.full(len(v), tid, np.int32))
+    # one strain per species here, so (value, species) pairs are already unique; strain ids rise with the genome order,
+    # so a STABLE sort by value of the genome-major concatenation is (value, taxid) order
+    if torch is not None:
+        v = torch.cat(vals); t = torch.cat(tids)
+        del vals, tids
+        # unsigned 64-bit order = the non-negative int64 values ascending, then the negative ones ascending; the halves are
+        # sorted separately (torch.sort takes < 2^31 elements per call)
+        out_v, out_t = [], []
+        for half in (v >= 0, v < 0):
+            hv, ht = v[half], t[half]
+            order = torch.sort(hv, stable=True).indices
+            out_v.append(hv[order].cpu().numpy().view(np.uint64)); out_t.append(ht[order].cpu().numpy())
+            del hv, ht, order
+        del v, t
+        torch.cuda.empty_cache()
+        return np.concatenate(out_v), np.concatenate(out_t)
     vals = np.concatenate(vals); tids = np.concatenate(tids)
-    # one strain per species here, so (value, species) pairs are already unique;
-    # strain ids are allocated right after their species id, so taxid order = species order
     order = np.lexsort((tids, vals))
     return vals[order], tids[order]
+
+
+def candidate_closure(torch, d_values, d_info, T, q_values):
+    """Every target of the flat device index whose amino-acid part equals that of a query metamer, plus the index's true last
+    entry -- computed with torch.searchsorted on the flat arrays, i.e. by nothing of the library under test.  Matches(q) depends on
+    no other target (C(q) = {t < T-1 : AA(t) = AA(q)}), so the oracle on this sub-database must give every read of
+    the sample the answer the GPU gives against the whole index.  Returns (values u64, taxids i32) as numpy arrays."""
+    dev = d_values.device
+    aa = np.unique(np.asarray(q_values, dtype=np.uint64) >> np.uint64(24))
+    v = d_values[:T]
+    # the array is sorted as UNSIGNED 64-bit; as int64 it is [non-negative ascending | negative ascending]: find the split by
+    # bisection on single elements and search each half with the queries of its sign
+    lo, hi = 0, T
+    while lo < hi:
+        mid = (lo + hi) // 2
+        if int(v[mid].item()) >= 0:
+            lo = mid + 1
+        else:
+            hi = mid
+    n_pos = lo
+    lo_key = (aa << np.uint64(24)).view(np.int64)
+    hi_key = (((aa + np.uint64(1)) << np.uint64(24)) - np.uint64(1)).view(np.int64)       # last value of the amino-acid part (no wrap at the top)
+    neg = lo_key < 0
+    starts = np.empty(len(aa), np.int64); ends = np.empty(len(aa), np.int64)
+    for sel, base, seg in ((~neg, 0, v[:n_pos]), (neg, n_pos, v[n_pos:])):
+        if not sel.any():
+            continue
+        a = torch.searchsorted(seg, torch.from_numpy(lo_key[sel]).to(dev), right=False) + base
+        b = torch.searchsorted(seg, torch.from_numpy(hi_key[sel]).to(dev), right=True) + base
+        starts[sel] = a.cpu().numpy(); ends[sel] = b.cpu().numpy()
+    cnt = ends - starts
+    keep = cnt > 0
+    starts, cnt = starts[keep], cnt[keep]
+    tot = int(cnt.sum())
+    first = np.zeros(len(cnt) + 1, np.int64); np.cumsum(cnt, out=first[1:])
+    idx = np.repeat(starts - first[:-1], cnt) + np.arange(tot, dtype=np.int64)
+    if tot == 0 or idx[-1] != T - 1:
+        idx = np.append(idx, T - 1)                      # the entry the `t < T-1` rule excludes must be the sub-database's last one too
+    di = torch.from_numpy(idx).to(dev)
+    cv = d_values[di].cpu().numpy().view(np.uint64); ct = d_info[di].cpu().numpy().view(np.int32) & np.int32(0x7FFFFFFF)
+    assert (cv[1:] >= cv[:-1]).all()
+    return cv, ct
 
 
 def gen_reads(torch, dev, world, n_reads, read_len, frac_random, err, seed, paired=False, frag_len=400):
@@ -200,6 +299,51 @@ def cpu_baseline_and_parity(ctx, M, torch, dev, world, real_v, real_t, params, t
     return cpu, par
 
 
+def parity_full_index(ctx, M, torch, dev, index, params, taxdir, d_bases, d_bases2, read_len, n_s, closure, T):
+    """The first n_s reads of the timed batch through the benchmarked entry point against THE TIMED INDEX ITSELF (sealed, packed
+    words, depth-7 directory, > 2^32 targets), compared read by read with the oracle run on the candidate closure of those reads
+    (candidate_closure above, taken from the flat arrays before they were packed).  Outside the timed region."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import Oracle, default_params as odp
+    orc = Oracle()
+    cv, ct = closure
+    d = tempfile.mkdtemp(prefix="mtb_closure_")
+    op = odp(seq_mode=params.seq_mode, syncmer=params.syncmer, smer_len=params.smer_len)
+    orc.write_db(d, cv, ct, op)
+    tax = orc.load_taxonomy(taxdir)
+    db = orc.open_db(d, tax, op)
+    paired = params.seq_mode == 2
+    offs_all = d_bases_offsets(torch, dev, n_s, read_len)
+    bases = d_bases[: n_s * read_len].cpu().numpy()
+    offs = np.arange(n_s + 1, dtype=np.uint64) * np.uint64(read_len)
+    bases2 = d_bases2[: n_s * read_len].cpu().numpy() if paired else None
+    R = orc.classify_batch(db, tax, op, bases, offs, bases2, offs if paired else None, threads=os.cpu_count() or 1)
+    oracle_counts = dict(orc.last_counts)
+    s_res = torch.empty(n_s * 24, dtype=torch.uint8, device=dev)
+    s_cap = n_s * (20 + read_len // 9) * (2 if paired else 1) + 1024
+    s_tt = torch.empty(s_cap, dtype=torch.int32, device=dev); s_tc = torch.empty(s_cap, dtype=torch.int32, device=dev)
+    ntc = ctx.classify_batch_device(index, params, d_bases.data_ptr(), offs_all.data_ptr(), d_bases2.data_ptr() if paired else 0,
+                                    offs_all.data_ptr() if paired else 0, n_s, n_s * read_len * (2 if paired else 1),
+                                    s_res.data_ptr(), s_tt.data_ptr(), s_tc.data_ptr(), s_cap)
+    torch.cuda.synchronize()
+    res = np.frombuffer(s_res.cpu().numpy().tobytes(), dtype=M.result_dt)
+    g_res, g_tt, g_tc = M.compact_taxcnt(res, s_tt[:ntc].cpu().numpy(), s_tc[:ntc].cpu().numpy().view(np.uint32))
+    par = compare_with_oracle(M, g_res, g_tt, g_tc, R)
+    par["matches"] = int(ctx.last_stats().n_matches); par["oracle_matches"] = int(oracle_counts["matches"])
+    if par["matches"] != par["oracle_matches"]:
+        par["mismatches"] += 1
+    stt = index.state()
+    par["index"] = (f"the timed index itself: {T} targets, directory depth {stt['dir_depth']}, {'packed 8-byte words' if stt['packed'] else 'flat {value, info}'}"
+                    f"{', sealed' if stt['sealed'] else ''}; oracle on the candidate closure of the sample's metamers ({len(cv)} targets incl. the index's last entry, "
+                    "gathered with torch.searchsorted from the flat arrays before packing)")
+    par["closure_targets"] = int(len(cv))
+    return par
+
+
+def d_bases_offsets(torch, dev, n, read_len):
+    return torch.arange(n + 1, device=dev, dtype=torch.int64) * read_len
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -241,7 +385,11 @@ def main():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--targets", type=float, default=16e9,
                     help="filler metamers in the synthetic index (per GPU, replicated); 16 G = SURVEY 8(d)'s GTDB-scale planning size, 192 GB flat")
-    ap.add_argument("--species", type=int, default=24)
+    ap.add_argument("--species", type=int, default=24,
+                    help="genomes the reads are drawn from (and whose metamers are in the index); >= 200 takes the device-side generator: "
+                         "the genome-diversity run is --species 2400 --fixed-total (0.6 x coverage instead of 62 x)")
+    ap.add_argument("--fixed-total", action="store_true", help="--targets is the TOTAL number of target metamers (filler = total - genome-derived)")
+    ap.add_argument("--full-parity-reads", type=int, default=32768, help="reads of the parity check against the timed index itself (0 = off)")
     ap.add_argument("--genome-len", type=int, default=1_000_000)
     ap.add_argument("--filler-species", type=int, default=130_000)
     ap.add_argument("--cpu-reads", type=int, default=2_000_000, help="reads of the CPU-baseline / parity sample (the first reads of rank 0's batch)")
@@ -287,11 +435,14 @@ def main():
     params = M.default_params(seq_mode=args.seq_mode, syncmer=1, smer_len=5)
 
     t_setup = time.perf_counter()
-    world = build_world(args.seed, args.species, args.genome_len, args.filler_species)
+    big_world = args.species >= 200
+    world = build_world_fast(torch, dev, args.seed, args.species, args.genome_len, args.filler_species) if big_world else \
+        build_world(args.seed, args.species, args.genome_len, args.filler_species)
     taxdir = tempfile.mkdtemp(prefix="mtb_tax_")
     world.tax.write(taxdir)
-    real_v, real_t = extract_targets(ctx, M, world, params)
-    n_filler = int(args.targets)
+    real_v, real_t = extract_targets(ctx, M, world, params, torch if big_world else None, dev)
+    n_filler = int(args.targets) - (len(real_v) if args.fixed_total else 0)
+    log(f"[rank {rank}] world: {len(world.genomes)} genomes x {args.genome_len} bp, {len(real_v)} genome-derived target metamers ({time.perf_counter()-t_setup:.1f}s)")
     T_cap = n_filler + len(real_v)
     if args.prealloc:
         nf0 = 1_000_000
@@ -317,6 +468,22 @@ def main():
     T = ctx.synth_index(args.seed, n_filler, world.filler_tax_lo, world.filler_tax_hi, real_v, real_t, d_values.data_ptr(), d_info.data_ptr())
     taxid_list = np.concatenate([np.unique(real_t), np.arange(world.filler_tax_lo, world.filler_tax_hi + 1, dtype=np.int32)])
     index = ctx.index_from_device(d_values.data_ptr(), d_info.data_ptr(), T, taxdir, taxid_list, params)
+    d_bases2 = None
+    if args.seq_mode == 2:
+        d_bases, d_offs, d_bases2 = gen_reads(torch, dev, world, args.reads, args.read_len, 0.10, 0.005, args.seed + 17 * (rank + 1), paired=True)
+    else:
+        d_bases, d_offs = gen_reads(torch, dev, world, args.reads, args.read_len, 0.10, 0.005, args.seed + 17 * (rank + 1))
+    # candidate closure of the parity sample, from the flat arrays and before anything packs them (parity_full_index below)
+    closure, n_full = None, 0
+    if rank == 0 and world_size == 1 and not args.no_parity and not args.partitioned and args.full_parity_reads > 0:
+        n_full = min(args.reads, args.full_parity_reads if args.seq_mode != 3 else max(1, args.full_parity_reads * 150 // args.read_len))
+        sb = d_bases[: n_full * args.read_len].cpu().numpy()
+        so = np.arange(n_full + 1, dtype=np.uint64) * np.uint64(args.read_len)
+        sk, _, _ = ctx.extract(params, sb, so, d_bases2[: n_full * args.read_len].cpu().numpy() if d_bases2 is not None else None, so if d_bases2 is not None else None)
+        t_c = time.perf_counter()
+        closure = candidate_closure(torch, d_values, d_info, T, sk["value"])
+        log(f"[rank 0] candidate closure of {n_full} reads ({len(sk)} metamers): {len(closure[0])} targets ({time.perf_counter()-t_c:.1f}s)")
+        del sk
     sealed = False
     if not args.partitioned and not args.no_seal and args.seq_mode != 3:       # long reads take the exact-segment join, which works on the flat arrays
         # dedicate the index to the fused path: packed 8-byte target words under the amino-acid directory; the info array lent to
@@ -327,11 +494,6 @@ def main():
             torch.cuda.empty_cache()
         except M.MtbError as e:
             log(f"[rank {rank}] index not sealed: {e}")
-    d_bases2 = None
-    if args.seq_mode == 2:
-        d_bases, d_offs, d_bases2 = gen_reads(torch, dev, world, args.reads, args.read_len, 0.10, 0.005, args.seed + 17 * (rank + 1), paired=True)
-    else:
-        d_bases, d_offs = gen_reads(torch, dev, world, args.reads, args.read_len, 0.10, 0.005, args.seed + 17 * (rank + 1))
     n_bases_step = args.reads * args.read_len * (2 if args.seq_mode == 2 else 1)
     d_res = torch.empty(args.reads * 24, dtype=torch.uint8, device=dev)
     tc_cap = args.reads * (20 + args.read_len // 9) * (2 if args.seq_mode == 2 else 1) + 1024
@@ -413,6 +575,19 @@ def main():
     ctx.set_profiling(False)
     ctx.set_streams(args.streams)
     kern = {M.KERNEL_NAMES[i]: dict(ms=float(ps.ms_kernel[i]), launches=int(ps.n_launch[i])) for i in range(len(M.KERNEL_NAMES))}
+    # index-side working set of that step's directory join (diagnostic kernel over the step's sorted metamers)
+    footprint = None
+    try:
+        fp = ctx.join_footprint(index)
+        least = fp.target_sectors * 64 + fp.dir_sectors * 64 + 16 * fp.n_queries
+        footprint = dict(query_metamers=int(fp.n_queries), distinct_buckets=int(fp.distinct_buckets), buckets=int(fp.n_buckets),
+                         directory_sectors_64B=int(fp.dir_sectors), target_sectors_64B=int(fp.target_sectors),
+                         target_sectors_total=int(fp.n_targets * 8 // 64), target_fraction_touched=fp.target_sectors * 64 / max(1, fp.n_targets * 8),
+                         least_fetch_bytes=int(least),
+                         note="distinct 64-byte sectors the batch's queries address (bucket spans of the target array, directory words) + 16 B per query: "
+                              "the least k_join_dir can fetch for this batch; 12 x T of the contract formula is a streaming-merge figure this kernel never pays")
+    except M.MtbError as e:
+        log(f"[rank {rank}] no join footprint: {e}")
     Kq, Mm, N, L = ps.n_kmers, ps.n_matches, ps.n_reads, ps.n_bases
     # algorithmic bytes of one whole step per kernel (SURVEY.md 8(d) per-stage split);
     # a step launches every kernel once per stream (and per radix pass): bytes per launch = total / launches
@@ -446,9 +621,14 @@ def main():
                             achieved_gb_s=round(alg[k] / (kern[k]["ms"] / max(1, kern[k]["launches"]) * 1e-3) / 1e9, 1),
                             frac=round(alg[k] / (kern[k]["ms"] / max(1, kern[k]["launches"]) * 1e-3) / 1e9 / 8000.0, 4))
                     for k in alg if kern[k]["ms"] > 0}
+    effective = (traffic / (avg_ms * 1e-3) / 1e9 / 8000.0) if (traffic and avg_ms > 0) else None
     roofline = dict(bound="hbm", kernel=dom, achieved=achieved, peak=8000.0, unit="GB/s", frac=achieved / 8000.0, traffic=traffic, traffic_note=traffic_note,
+                    effective=effective,
+                    effective_note="traffic / avg_launch_ms / peak: the fraction of HBM bandwidth the kernel really moves (PMC bytes, not the contract's algorithmic bytes)",
                     avg_launch_ms=avg_ms, launches=kern[dom]["launches"], algorithmic_bytes_per_launch=alg[dom],
-                    note="per-kernel durations from HIP events around every launch of one extra step; traffic = HBM bytes per launch from the PMC passes")
+                    footprint=footprint if dom == "join" else None,
+                    note="per-kernel durations from HIP events around every launch of one extra step; traffic = HBM bytes per launch from the PMC passes; "
+                         "`frac` follows SURVEY 8(d)'s formula (16 Kq + 12 T + 24 M for the join) and is NOT a bandwidth fraction for the directory join: see `effective` and `footprint`")
 
     # sanity of the timed output: fraction of reads classified
     res = np.frombuffer(d_res.cpu().numpy().tobytes(), dtype=M.result_dt)
@@ -465,6 +645,12 @@ def main():
         log(f"[rank 0] parity sample: {parity}")
         if parity["mismatches"]:
             raise SystemExit(f"parity check failed: {parity}")
+    parity_full = None
+    if closure is not None:
+        parity_full = parity_full_index(ctx, M, torch, dev, index, params, taxdir, d_bases, d_bases2, args.read_len, n_full, closure, T)
+        log(f"[rank 0] parity against the timed index: {parity_full}")
+        if parity_full["mismatches"]:
+            raise SystemExit(f"parity check against the timed index failed: {parity_full}")
 
     if rank == 0:
         total_reads = args.reads * world_size * args.steps
@@ -481,10 +667,11 @@ def main():
                                gbp_per_s=value * args.read_len * (2 if args.seq_mode == 2 else 1) / 1e3, query_metamers=int(st.n_kmers), matches=int(st.n_matches),
                                classified_fraction=frac_cls, parallelism=f"reads sharded x{world_size}, index replicated", streams_per_gpu=args.streams,
                                sub_batches_per_step=sub_batches_timed, index_sealed=sealed,
-                               index_bytes=int(T * 8 + 4 * (1801088541 + 1)) if sealed else int(T * 12 + 4 * (1801088541 + 1)), reads_scored_by_generic_kernel=int(ps.n_generic_reads)),
+                               index_bytes=int(T * (8 if sealed else 12) + 4 * (21 ** index.state()["dir_depth"] + 1)), species=args.species, genome_len=args.genome_len, reads_scored_by_generic_kernel=int(ps.n_generic_reads)),
                    stage_ms=dict(extract=st.ms_extract, sort=st.ms_sort, join=st.ms_join, regroup=st.ms_regroup,
                                  segsort=st.ms_segsort, score=st.ms_score, total=st.ms_total),
-                   kernel_ms=kern, roofline=roofline, roofline_all=roofline_all, cpu_baseline=cpu, parity_sample=parity)
+                   kernel_ms=kern, roofline=roofline, roofline_all=roofline_all, join_footprint=footprint, cpu_baseline=cpu, parity_sample=parity,
+                   parity_full_index=parity_full)
         finish(dist, json.dumps(out))
     else:
         finish(dist, None)

@@ -143,9 +143,13 @@ mtb_status mtb_index_open(mtb_ctx *, const char *dbdir, const char *taxonomy_dir
                           mtb_params *params, mtb_index **out);
 /* Same, from an already flat index resident on the device (synthetic-index
  * benchmark path).  The arrays are borrowed, not copied: they must outlive
- * the index.  taxonomy_dir must hold the *.dmp files; taxid_list (host) is
- * the content of DBDIR/taxID_list.                                          */
-mtb_status mtb_index_from_device(mtb_ctx *, const uint64_t *d_values, const uint32_t *d_info,
+ * the index -- and they are NOT read-only: while the index lives the fused
+ * path (mtb_classify_batch*, mtb_index_seal) may rewrite d_values in place to
+ * packed words (kernels_dir.h) and back, so the lender must not read them in
+ * between; mtb_index_close hands d_values back in the flat state it was lent
+ * in (d_info too, unless the index was sealed).  taxonomy_dir must hold the
+ * *.dmp files; taxid_list (host) is the content of DBDIR/taxID_list.        */
+mtb_status mtb_index_from_device(mtb_ctx *, uint64_t *d_values, uint32_t *d_info,
                                  uint64_t n_targets, const char *taxonomy_dir,
                                  const int32_t *taxid_list, size_t n_taxids,
                                  const mtb_params *params, mtb_index **out);
@@ -158,6 +162,9 @@ mtb_status mtb_index_from_device(mtb_ctx *, const uint64_t *d_values, const uint
 mtb_status mtb_index_seal(mtb_index *);
 void       mtb_index_close(mtb_index *);
 uint64_t   mtb_index_num_targets(const mtb_index *);
+/* How the target array is held right now: depth of the amino-acid directory (0 = none: the bisection join is used), whether the
+ * array is in the packed state of the fused join, whether the index is sealed (info[] released).  Reporting only.          */
+mtb_status mtb_index_state(const mtb_index *, int32_t *dir_depth, int32_t *packed, int32_t *sealed);
 /* Copy the decoded flat index back to the host (parity seam for the codec). */
 mtb_status mtb_index_download(mtb_index *, uint64_t *values, uint32_t *info, uint64_t cap);
 /* Taxonomy services (TaxonomyWrapper / NcbiTaxonomy) for the host side.     */
@@ -225,6 +232,13 @@ mtb_status mtb_classify_batch_device(mtb_ctx *, mtb_index *, const mtb_params *,
                                      uint32_t *d_taxcnt_cnt, uint64_t taxcnt_cap,
                                      uint64_t *n_taxcnt);
 mtb_status mtb_last_batch_stats(mtb_ctx *, mtb_batch_stats *out);
+/* Diagnostic, outside any timed region: the index-side working set of the LAST mtb_classify_batch* call of this context
+ * when it took the directory join (short reads, index with a directory): distinct directory buckets its query metamers fall
+ * into, distinct 64-byte sectors of the directory they read, distinct 64-byte sectors of the target array spanned by those
+ * buckets.  target_sectors x 64 + dir_sectors x 64 + 16 x n_queries is the least the join can fetch for that batch.
+ * MTB_ERR_UNSUPPORTED if the last call did not leave its sorted metamers behind (no call yet, long reads, sub-batches > 1).  */
+typedef struct { uint64_t n_queries, distinct_buckets, dir_sectors, target_sectors, n_buckets, n_targets; } mtb_join_footprint;
+mtb_status mtb_ctx_join_footprint(mtb_ctx *, mtb_index *, mtb_join_footprint *out);
 
 /* Writes the resident index in the reference's on-disk format -- diffIdx
  * (IndexCreator::getDiffIdx, IndexCreator.cpp:874-892), info, split

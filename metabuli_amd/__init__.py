@@ -42,6 +42,11 @@ class BatchStats(C.Structure):
                 ("ms_kernel", C.c_float * 10), ("n_launch", C.c_uint32 * 10), ("n_generic_reads", C.c_uint64)]
 
 
+class JoinFootprint(C.Structure):
+    _fields_ = [("n_queries", C.c_uint64), ("distinct_buckets", C.c_uint64), ("dir_sectors", C.c_uint64),
+                ("target_sectors", C.c_uint64), ("n_buckets", C.c_uint64), ("n_targets", C.c_uint64)]
+
+
 KERNEL_NAMES = ["extract_count", "extract_emit", "radix_hist", "radix_scatter", "join", "regroup", "segsort", "score", "scan", "score_fast"]
 
 
@@ -292,6 +297,12 @@ class Context:
             _chk(st)
             return compact_taxcnt(res, tt, tc)
 
+    def join_footprint(self, index):
+        """index-side working set of the last fused batch's directory join (mtb_ctx_join_footprint; diagnostic)"""
+        f = JoinFootprint()
+        _chk(self.L.mtb_ctx_join_footprint(self.h, index.h, C.byref(f)))
+        return f
+
     def last_stats(self):
         s = BatchStats()
         _chk(self.L.mtb_last_batch_stats(self.h, C.byref(s)))
@@ -310,6 +321,12 @@ class Index:
     def seal(self):
         """mtb_index_seal: packed state + info[] released (the lender of a borrowed info array may free it afterwards)"""
         _chk(self.ctx.L.mtb_index_seal(self.h))
+
+    def state(self):
+        """directory depth (0 = none), packed / sealed flags of the resident target array (mtb_index_state)"""
+        d = C.c_int32(); pk = C.c_int32(); sl = C.c_int32()
+        _chk(self.ctx.L.mtb_index_state(self.h, C.byref(d), C.byref(pk), C.byref(sl)))
+        return dict(dir_depth=d.value, packed=bool(pk.value), sealed=bool(sl.value))
 
     def original_id(self, taxid):
         """TaxonomyWrapper::getOriginalTaxID: internal id (what results carry) -> the id the reports print"""

@@ -254,7 +254,11 @@ inline bool load_taxonomy_db(const std::string &path, Taxonomy *t, std::string *
         if (at + 24 > N) continue;
         const uint64_t bc = rd64(at), ec = rd64(at + 8), en = rd64(at + 16);
         if (bc > N || ec > N / 4 + 1 || en > ec) continue;
-        if (at + 24 + bc + ec * 4 != N) continue;
+        /* serialize() always reserves (maxTaxID + 1) ints for internal2orgTaxId in memSize and writes the whole buffer
+         * (TaxonomyWrapper.cpp:296-310), but only fills them in when internal ids are used (:341-344): a file written with
+         * useInternalTaxID == false ends in that many unused bytes */
+        const size_t slack = internal ? 0 : ((size_t)max_taxid + 1) * 4;
+        if (at + 24 + bc + ec * 4 != N && at + 24 + bc + ec * 4 + slack != N) continue;
         block_at = at; byte_cap = bc; entry_cap = ec; entry_cnt = en;
         break;
     }

@@ -105,14 +105,19 @@ MTB_HD uint64_t mtb_unpack_value(uint64_t w, uint32_t bucket, int fmt) {
 __global__ __launch_bounds__(256) void k_index_pack(uint64_t *__restrict__ values, const uint32_t *__restrict__ info, uint64_t T, int fmt) {
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < T; i += (uint64_t)gridDim.x * 256) values[i] = mtb_pack_word(values[i], info[i], fmt);
 }
-/* one thread per bucket: its targets get their prefix back, info[] is rewritten from the upper bits */
+/* one thread per bucket: its targets get their prefix back, info[] (if given) is rewritten from the upper bits */
 __global__ __launch_bounds__(256) void k_index_unpack(uint64_t *__restrict__ values, uint32_t *__restrict__ info, mtb_dir_view dv) {
     for (uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x; b < dv.n_buckets; b += (uint64_t)gridDim.x * 256) {
         const uint64_t lo = dv.base[b >> 16] + dv.dir[b], hi = dv.base[(b + 1) >> 16] + dv.dir[b + 1];
-        for (uint64_t t = lo; t < hi; t++) { const uint64_t w = values[t]; info[t] = (uint32_t)(w >> MTB_PACK_LOW); values[t] = mtb_unpack_value(w, (uint32_t)b, dv.kmer_format); }
+        for (uint64_t t = lo; t < hi; t++) { const uint64_t w = values[t]; if (info) info[t] = (uint32_t)(w >> MTB_PACK_LOW); values[t] = mtb_unpack_value(w, (uint32_t)b, dv.kmer_format); }
     }
 }
 
+#ifdef MTB_NO_NT_STORES          /* experiment build: plain stores */
+#define MTB_SLOT_STORE(sl, p) do { *(p) = (sl); } while (0)
+#else
+#define MTB_SLOT_STORE(sl, p) do { __builtin_nontemporal_store((sl).a, &(p)->a); __builtin_nontemporal_store((sl).b, &(p)->b); } while (0)
+#endif
 #ifndef MTB_JOIN_DIR_QPT
 #define MTB_JOIN_DIR_QPT 2
 #endif
@@ -235,10 +240,10 @@ __global__ __launch_bounds__(256) void k_join_dir(const mtb_kmer *__restrict__ q
              * those lines out of the L2's way measured 47.5 ms against 50-58 ms (and steadier) for the kernel -- which is bound by
              * these 1.1 G scattered 16-byte stores: 20.5 ms without them, 29 ms with dense stores (profiles/r02_notes.md) */
             if (first) { const mtb_slot16 sl = mtb_slot_pack(qinfo, tid, sp, td, reh, h, sa.epoch);
-                         __builtin_nontemporal_store(sl.a, &seg[ord].a); __builtin_nontemporal_store(sl.b, &seg[ord].b); first = false; continue; }
+                         MTB_SLOT_STORE(sl, &seg[ord]); first = false; continue; }
             const uint32_t at = atomicAdd(&sa.cursor[r], 1u);
             if (at < tail_cap) { const mtb_slot16 sl = mtb_slot_pack(qinfo, tid, sp, td, reh, h, sa.epoch);
-                                 __builtin_nontemporal_store(sl.a, &seg[sa.direct + at].a); __builtin_nontemporal_store(sl.b, &seg[sa.direct + at].b); }
+                                 MTB_SLOT_STORE(sl, &seg[sa.direct + at]); }
             else {
                 const unsigned long long o = atomicAdd(sa.ovf_counter, 1ull);
                 if (o < sa.ovf_cap) {
@@ -248,6 +253,36 @@ __global__ __launch_bounds__(256) void k_join_dir(const mtb_kmer *__restrict__ q
             }
         }
     }
+}
+
+/* ---- diagnostic (not on the timed path): what the directory join addresses on the index side --------------------------------
+ * One thread per query of the last batch: its bucket, the 64-byte sectors of the two directory words it reads and the 64-byte
+ * sectors of the bucket's span in the target array are marked in bitmaps; k_popcount_words counts them.  This is the batch's
+ * distinct index-side working set -- the lower bound of what k_join_dir has to fetch whatever the caches do (bench.py reports it
+ * next to the PMC traffic: `footprint`). */
+__global__ __launch_bounds__(256) void k_join_footprint(const mtb_kmer *__restrict__ q, uint64_t n, mtb_dir_view dv, uint64_t T,
+                                                         uint32_t *__restrict__ bm_bucket, uint32_t *__restrict__ bm_dirsec, uint32_t *__restrict__ bm_tgtsec,
+                                                         unsigned long long *__restrict__ n_valid) {
+    const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const mtb_kmer k = q[j];
+    if (mtb_q_seq(k.qinfo) == 0) return;
+    const uint32_t b = mtb_dir_bucket(k.value, dv.L, dv.kmer_format);
+    if (b >= dv.n_buckets) return;
+    atomicAdd(n_valid, 1ull);
+    atomicOr(&bm_bucket[b >> 5], 1u << (b & 31u));
+    const uint64_t ds0 = ((uint64_t)b * 4) >> 6, ds1 = ((uint64_t)(b + 1) * 4) >> 6;
+    atomicOr(&bm_dirsec[ds0 >> 5], 1u << (ds0 & 31u));
+    if (ds1 != ds0) atomicOr(&bm_dirsec[ds1 >> 5], 1u << (ds1 & 31u));
+    uint64_t lo = dv.base[b >> 16] + dv.dir[b], hi = dv.base[(b + 1) >> 16] + dv.dir[b + 1];
+    if (hi > T) hi = T;
+    for (uint64_t sct = (lo * 8) >> 6; lo < hi && sct <= ((hi * 8 - 1) >> 6); sct++) atomicOr(&bm_tgtsec[sct >> 5], 1u << (sct & 31u));
+}
+__global__ __launch_bounds__(256) void k_popcount_words(const uint32_t *__restrict__ w, uint64_t n_words, unsigned long long *__restrict__ out) {
+    unsigned long long acc = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * 256) acc += (unsigned long long)__popc(w[i]);
+    for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
 }
 
 #endif

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <functional>
 #include <map>
 #include <string>
@@ -78,6 +80,7 @@ struct mtb_ctx {
     int ws_seq_mode = 0;             /* the buffer sets of short and long reads differ: a change of mode releases the workspace */
     uint32_t last_sub_batches = 0;
     bool fast_used = false;          /* the last dev_score call launched k_score_fast (its slow-list count sits in d_scal[6]) */
+    const mtb_kmer *last_sorted = nullptr; uint64_t last_sorted_n = 0;       /* the last fused slot-path batch's sorted metamers (mtb_ctx_join_footprint) */
 };
 /* buffers that carry a call's inputs / outputs (host-buffer entry points) are not workspace */
 static bool is_io_buf(const std::string &n) { return n == "bases" || n == "offs" || n == "bases2" || n == "offs2" || n == "results" || n == "tctax" || n == "tccnt"; }
@@ -134,6 +137,12 @@ struct mtb_index {
     uint32_t *d_dir = nullptr; uint64_t *d_dirbase = nullptr; int32_t dir_L = 0; uint32_t dir_buckets = 0;
     bool packed = false;             /* d_values holds packed words (kernels_dir.h): the fused join's state; everything else unpacks first */
     bool info_owned = false;         /* d_info was (re)allocated by the library although the value array is borrowed (after mtb_index_seal) */
+    /* The flat <-> packed conversion rewrites the target array in place and is not idempotent: it happens under `state_mu`, only
+     * while no kernel that reads the array is in flight (`users` = join launches between acquire and the end of their stream
+     * sync, whatever context or stream they run on), and is complete (stream-synchronised) before the lock is released. */
+    std::mutex state_mu; std::condition_variable state_cv; int users = 0;
+    int views = 0;                   /* live mtb_index_slice views: they read the parent's flat arrays, so the parent stays flat */
+    mtb_index *parent = nullptr;     /* of a view */
 };
 
 template <typename T>
@@ -176,9 +185,25 @@ __global__ __launch_bounds__(256) void k_probe_scatter(mtb_slot16 *buf, uint64_t
         __builtin_nontemporal_store((uint64_t)0, &p->a); __builtin_nontemporal_store((uint64_t)0, &p->b);      /* epoch 0 = not live */
     }
 }
+__global__ __launch_bounds__(256) void k_clear_words(uint64_t *p, uint64_t n_words) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * 256) p[i] = 0;
+}
 static mtb_status ensure_placed(mtb_ctx *c, const char *name, size_t elems, mtb_slot16 **out) {
     DevBuf &b = c->bufs[name];
     const size_t bytes = std::max<size_t>(elems * sizeof(mtb_slot16), 64);
+    /* experiment switch (tests/test_gpu_contig.py, profiles/r03_notes.md): the slot buffer -- of ANY size -- from physically
+     * contiguous VRAM, the configuration in which round 2 saw pair scores differ from the oracle's */
+    static const char *contig = getenv("MTB_SEGM_CONTIG");
+    if (contig) {
+        if (b.cap >= bytes) { *out = (mtb_slot16 *)b.p; return MTB_OK; }
+        if (b.p) { hipError_t e = hipFree(b.p); (void)e; b.p = nullptr; b.cap = 0; }
+        const size_t want = bytes + bytes / 16 + 256 + (getenv("MTB_SEGM_PAD") ? (1u << 20) : 0);
+        hipError_t e = hipExtMallocWithFlags(&b.p, want, hipDeviceMallocContiguous);
+        if (e != hipSuccess) { b.p = nullptr; (void)hipGetLastError(); return fail(MTB_ERR_OOM, std::string("contiguous allocation failed for ") + name + ": " + hipGetErrorString(e)); }
+        b.cap = want;
+        *out = (mtb_slot16 *)b.p;
+        return MTB_OK;
+    }
     static const bool no_probe = getenv("MTB_NO_PLACEMENT_PROBE") != nullptr;
     if (b.cap >= bytes || bytes < (8ull << 30) || no_probe) return ensure(c, name, elems, out);      /* small batches: an allocation of this size takes 0.3 - 1 s, not worth it */
     if (b.p) { hipError_t e = hipFree(b.p); (void)e; b.p = nullptr; b.cap = 0; }
@@ -459,8 +484,7 @@ static mtb_status dev_sort(mtb_ctx *c, mtb_kmer *d_a, uint64_t n, int first_bit,
     return MTB_OK;
 }
 
-static mtb_status ensure_flat(mtb_index *ix);
-static mtb_status ensure_packed(mtb_index *ix);
+struct IndexUse;
 static mtb_dir_view dir_view(const mtb_index *ix);
 static mtb_index_view index_view(const mtb_index *ix) {
     mtb_index_view v;
@@ -476,6 +500,66 @@ static mtb_tax_view tax_view(const mtb_index *ix) {
     return v;
 }
 
+static mtb_status ensure_flat_locked(mtb_index *ix) {       /* caller holds state_mu and has seen users == 0 */
+    if (!ix || !ix->packed) return MTB_OK;
+    mtb_ctx *c = ix->ctx;
+    if (!ix->d_info) {                                  /* sealed: info[] was let go of; the flat state needs it back */
+        hipError_t e = hipMalloc((void **)&ix->d_info, std::max<uint64_t>(ix->T, 1) * 4);
+        if (e != hipSuccess) { ix->d_info = nullptr; (void)hipGetLastError(); return fail(MTB_ERR_OOM, "no HBM to restore info[] of a sealed index"); }
+        ix->info_owned = true;
+    }
+    hipLaunchKernelGGL(k_index_unpack, dim3((uint32_t)std::min<uint64_t>(((uint64_t)ix->dir_buckets + 255) / 256, 1u << 20)), dim3(256), 0, c->stream, ix->d_values, ix->d_info, dir_view(ix));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    ix->packed = false;
+    return MTB_OK;
+}
+static bool can_pack(const mtb_index *ix) {
+    return ix->d_dir && ix->dir_L == 7 && ix->own_tax && ix->views == 0 && !getenv("MTB_NO_PACK");
+}
+static mtb_status ensure_packed_locked(mtb_index *ix) {
+    if (ix->packed || !can_pack(ix)) return MTB_OK;
+    mtb_ctx *c = ix->ctx;
+    hipLaunchKernelGGL(k_index_pack, dim3((uint32_t)std::min<uint64_t>((ix->T + 255) / 256, 1u << 20)), dim3(256), 0, c->stream, ix->d_values, (const uint32_t *)ix->d_info, ix->T, ix->params.kmer_format);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));            /* complete before any other stream's join may read the array */
+    ix->packed = true;
+    return MTB_OK;
+}
+/* A view's arrays are its parent's: the state (and the lock) live there. */
+static mtb_index *state_owner(mtb_index *ix) { return ix && ix->parent ? ix->parent : ix; }
+/* Exclusive change of state for the synchronous entry points (download, write, seal, slice): waits for the joins in flight. */
+static mtb_status ensure_flat(mtb_index *ix) {
+    mtb_index *o = state_owner(ix);
+    if (!o) return MTB_OK;
+    std::unique_lock<std::mutex> lk(o->state_mu);
+    o->state_cv.wait(lk, [&] { return o->users == 0; });
+    return ensure_flat_locked(o);
+}
+static mtb_status ensure_packed(mtb_index *ix) {
+    mtb_index *o = state_owner(ix);
+    std::unique_lock<std::mutex> lk(o->state_mu);
+    o->state_cv.wait(lk, [&] { return o->users == 0; });
+    return ensure_packed_locked(o);
+}
+/* A join's hold on the state it was launched for: taken before the launch, released after the launching stream has been
+ * synchronised.  Several lanes (mtb_ctx_set_streams) or contexts may hold the same state at once; a lane that needs the other
+ * state waits until the holders are gone, converts, and holds in turn. */
+struct IndexUse {
+    mtb_index *o = nullptr;
+    mtb_status acquire(mtb_index *ix, bool want_packed) {
+        mtb_index *own = state_owner(ix);
+        std::unique_lock<std::mutex> lk(own->state_mu);
+        const bool target = want_packed && can_pack(own);
+        own->state_cv.wait(lk, [&] { return own->users == 0 || own->packed == target; });
+        if (own->packed != target) { mtb_status st = target ? ensure_packed_locked(own) : ensure_flat_locked(own); if (st != MTB_OK) return st; }
+        own->users++; o = own;
+        return MTB_OK;
+    }
+    void release() { if (!o) return; { std::lock_guard<std::mutex> lk(o->state_mu); o->users--; } o->state_cv.notify_all(); o = nullptr; }
+    ~IndexUse() { release(); }
+};
+
 /* join into d_out (cap entries); *count = matches found (may exceed cap -> MTB_ERR_CAPACITY).
  * With `seg` (per-read slot segments, k_join<SEG>) matches go to seg->seg and the overflow list instead; *count is then
  * the number of overflow entries needed and MTB_ERR_CAPACITY refers to the overflow list.                     */
@@ -488,15 +572,16 @@ static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint6
     uint64_t *d_bounds;
     STCHK(ensure(c, "jbounds", 2ull * grid, &d_bounds));
     uint64_t limit = ix->T ? ix->T - (ix->match_last ? 0 : 1) : 0;          /* the last entry of the (whole) index is never a candidate */
+    IndexUse use;                     /* released after the stream sync below (the d2h of the counters) */
     if (seg && ix->d_dir) {
-        STCHK(ensure_packed(ix));
+        STCHK(use.acquire(ix, true));
         KTimer kt(c, MTB_K_JOIN);
         JoinSegArgs sa = *seg; sa.ovf_counter = (unsigned long long *)c->d_scal;
         const uint32_t g2 = (uint32_t)((n + 256 * MTB_JOIN_DIR_QPT - 1) / (256 * MTB_JOIN_DIR_QPT));
-        if (ix->packed) hipLaunchKernelGGL((k_join_dir<true>), dim3(g2), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1));
+        if (state_owner(ix)->packed) hipLaunchKernelGGL((k_join_dir<true>), dim3(g2), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1));
         else hipLaunchKernelGGL((k_join_dir<false>), dim3(g2), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1));
     } else
-    { STCHK(ensure_flat(ix));
+    { STCHK(use.acquire(ix, false));
     KTimer kt(c, MTB_K_JOIN);
     hipLaunchKernelGGL(k_join_bounds, dim3((grid + 255) / 256), dim3(256), 0, c->stream, d_q, n, (const uint64_t *)ix->d_values, limit,
                        (uint64_t)grid, d_bounds, sort_low_bits);
@@ -743,29 +828,6 @@ static mtb_dir_view dir_view(const mtb_index *ix) {
 }
 /* the two states of the target array: flat {value[T], info[T]} (every stage-level entry point, download / write / slices) and packed
  * (the fused join; depth-7 directory only).  Conversions are in place, ~25 ms each at 16 G targets, and happen only on a change of use. */
-static mtb_status ensure_flat(mtb_index *ix) {
-    if (!ix || !ix->packed) return MTB_OK;
-    mtb_ctx *c = ix->ctx;
-    if (!ix->d_info) {                                  /* sealed: info[] was let go of; the flat state needs it back */
-        hipError_t e = hipMalloc((void **)&ix->d_info, std::max<uint64_t>(ix->T, 1) * 4);
-        if (e != hipSuccess) { ix->d_info = nullptr; return fail(MTB_ERR_OOM, "no HBM to restore info[] of a sealed index"); }
-        ix->info_owned = true;
-    }
-    hipLaunchKernelGGL(k_index_unpack, dim3((uint32_t)std::min<uint64_t>(((uint64_t)ix->dir_buckets + 255) / 256, 1u << 20)), dim3(256), 0, c->stream, ix->d_values, ix->d_info, dir_view(ix));
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(c->stream));
-    ix->packed = false;
-    return MTB_OK;
-}
-static mtb_status ensure_packed(mtb_index *ix) {
-    if (ix->packed || !ix->d_dir || ix->dir_L != 7 || !ix->own_tax || getenv("MTB_NO_PACK")) return MTB_OK;
-    mtb_ctx *c = ix->ctx;
-    hipLaunchKernelGGL(k_index_pack, dim3((uint32_t)std::min<uint64_t>((ix->T + 255) / 256, 1u << 20)), dim3(256), 0, c->stream, ix->d_values, (const uint32_t *)ix->d_info, ix->T, ix->params.kmer_format);
-    HIPCHK(hipGetLastError());
-    ix->packed = true;
-    return MTB_OK;
-}
-
 /* How a database directory is cut into n_parts value ranges at `split` checkpoints (IndexCreator.cpp:848-857: a
  * checkpoint {value, diffIdx offset after it, info index + 1} sits on the first metamer of an amino-acid group).  */
 struct PartPlan {
@@ -922,7 +984,7 @@ mtb_status mtb_index_part_bounds(const char *dbdir, uint32_t n_parts, uint64_t *
     return MTB_OK;
 }
 
-mtb_status mtb_index_from_device(mtb_ctx *c, const uint64_t *d_values, const uint32_t *d_info, uint64_t n_targets, const char *taxonomy_dir,
+mtb_status mtb_index_from_device(mtb_ctx *c, uint64_t *d_values, uint32_t *d_info, uint64_t n_targets, const char *taxonomy_dir,
                                  const int32_t *taxid_list, size_t n_taxids, const mtb_params *params, mtb_index **out) {
     if (!c || !taxonomy_dir || !params || !out) return fail(MTB_ERR_ARG, "NULL argument");
     HIPCHK(hipSetDevice(c->device));
@@ -932,7 +994,7 @@ mtb_status mtb_index_from_device(mtb_ctx *c, const uint64_t *d_values, const uin
     if (!mtbhost::load_taxonomy(taxonomy_dir, &ix->tax, &err)) { delete ix; return fail(MTB_ERR_IO, err); }
     mtbhost::build_tax2species(&ix->tax, taxid_list, n_taxids);
     ix->info_mask = ~((uint32_t)(params->skip_redundancy == 0) << 31);
-    ix->d_values = (uint64_t *)d_values; ix->d_info = (uint32_t *)d_info; ix->T = n_targets;
+    ix->d_values = d_values; ix->d_info = d_info; ix->T = n_targets;
     mtb_status st = upload_taxonomy(ix);
     if (st != MTB_OK) { mtb_index_close(ix); return st; }
     if ((st = build_directory(c, ix)) != MTB_OK) { mtb_index_close(ix); return st; }
@@ -943,10 +1005,26 @@ mtb_status mtb_index_from_device(mtb_ctx *c, const uint64_t *d_values, const uin
 void mtb_index_close(mtb_index *ix) {
     if (!ix) return;
     hipError_t e = hipSuccess;
+    if (ix->parent) {                /* a view: the parent may be packed again once the last view is gone */
+        { std::lock_guard<std::mutex> lk(ix->parent->state_mu); ix->parent->views--; }
+        delete ix; return;
+    }
+    if (!ix->own && ix->packed && ix->d_values) {
+        /* a borrowed target array (mtb_index_from_device) is handed back the way it was lent: flat.  A sealed index has let go of
+         * info[] (the lender was told so and may have freed it): only the values are restored then. */
+        std::unique_lock<std::mutex> lk(ix->state_mu);
+        ix->state_cv.wait(lk, [&] { return ix->users == 0; });
+        if (hipSetDevice(ix->ctx->device) == hipSuccess) {
+            hipLaunchKernelGGL(k_index_unpack, dim3((uint32_t)std::min<uint64_t>(((uint64_t)ix->dir_buckets + 255) / 256, 1u << 20)), dim3(256), 0, ix->ctx->stream,
+                               ix->d_values, ix->d_info, dir_view(ix));
+            e = hipStreamSynchronize(ix->ctx->stream);
+        }
+        ix->packed = false;
+    }
     if (ix->own) { if (ix->d_values) e = hipFree(ix->d_values); if (ix->d_info) e = hipFree(ix->d_info); }
     else if (ix->info_owned && ix->d_info) e = hipFree(ix->d_info);
-    if (ix->own_tax) { if (ix->d_dir) e = hipFree(ix->d_dir); if (ix->d_dirbase) e = hipFree(ix->d_dirbase); }     /* views never own a directory */
-    if (!ix->own_tax) { (void)e; delete ix; return; }
+    if (ix->d_dir) e = hipFree(ix->d_dir);
+    if (ix->d_dirbase) e = hipFree(ix->d_dirbase);
     if (ix->d_canon) e = hipFree(ix->d_canon);
     if (ix->d_parent) e = hipFree(ix->d_parent);
     if (ix->d_depth) e = hipFree(ix->d_depth);
@@ -959,15 +1037,25 @@ void mtb_index_close(mtb_index *ix) {
     delete ix;
 }
 uint64_t mtb_index_num_targets(const mtb_index *ix) { return ix ? ix->T : 0; }
+mtb_status mtb_index_state(const mtb_index *ix, int32_t *dir_depth, int32_t *packed, int32_t *sealed) {
+    if (!ix) return fail(MTB_ERR_ARG, "NULL index");
+    const mtb_index *o = ix->parent ? ix->parent : ix;
+    if (dir_depth) *dir_depth = ix->d_dir ? ix->dir_L : 0;
+    if (packed) *packed = o->packed ? 1 : 0;
+    if (sealed) *sealed = (o->packed && !o->d_info) ? 1 : 0;
+    return MTB_OK;
+}
 
 mtb_status mtb_index_seal(mtb_index *ix) {
     if (!ix) return fail(MTB_ERR_ARG, "NULL index");
     mtb_ctx *c = ix->ctx;
     HIPCHK(hipSetDevice(c->device));
     if (!ix->d_dir || ix->dir_L != 7 || !ix->own_tax) return fail(MTB_ERR_UNSUPPORTED, "index has no depth-7 directory (too small, or a view): nothing to seal");
-    STCHK(ensure_packed(ix));
+    std::unique_lock<std::mutex> lk(ix->state_mu);
+    ix->state_cv.wait(lk, [&] { return ix->users == 0; });
+    if (ix->views) return fail(MTB_ERR_UNSUPPORTED, "index has live views (mtb_index_slice): close them before sealing");
+    STCHK(ensure_packed_locked(ix));
     if (!ix->packed) return fail(MTB_ERR_UNSUPPORTED, "packing is disabled");
-    HIPCHK(hipStreamSynchronize(c->stream));
     if (ix->d_info && (ix->own || ix->info_owned)) { hipError_t e = hipFree(ix->d_info); (void)e; }
     ix->d_info = nullptr; ix->info_owned = false;       /* a borrowed info[] now belongs to the caller alone */
     return MTB_OK;
@@ -1265,6 +1353,7 @@ static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, c
     if (aa6 && fixed && ix->d_dir && getenv("MTB_SORT_PAIRS")) aa_first_shift = 64 - 10 * std::max(1, std::min(3, atoi(getenv("MTB_SORT_PAIRS"))));
     STCHK(dev_sort(c, d_k, nk, aa6 ? MTB_SORT_AA6 : 32, &d_s, aa_first_shift == 34 ? d_dig : nullptr, aa_first_shift));
     HIPCHK(hipEventRecord(c->ev[2], st));
+    c->last_sorted = (fixed && ix->d_dir) ? d_s : nullptr; c->last_sorted_n = nk;
     uint32_t *d_rc;
     STCHK(ensure(c, "readcnt", n_reads, &d_rc));
     HIPCHK(hipMemsetAsync(d_rc, 0, n_reads * 4, st));
@@ -1278,7 +1367,14 @@ static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, c
             DevBuf &sb = c->bufs["segm"];
             void *before = sb.p; size_t cap_before = sb.cap;
             STCHK(ensure_placed(c, "segm", n_reads * (uint64_t)stride, &d_segm));
-            if (sb.p != before || sb.cap != cap_before || c->seg_epoch >= MTB_SLOT_EPOCHS) { HIPCHK(hipMemsetAsync(sb.p, 0, sb.cap, st)); c->seg_epoch = 0; }
+            static const char *clear_mode = getenv("MTB_SEGM_CLEAR");      /* experiment switch: kernel | sync | always (default: hipMemsetAsync when new / on epoch wrap) */
+            const bool always = clear_mode && !strcmp(clear_mode, "always");
+            if (sb.p != before || sb.cap != cap_before || c->seg_epoch >= MTB_SLOT_EPOCHS || always) {
+                if (clear_mode && !strcmp(clear_mode, "kernel")) hipLaunchKernelGGL(k_clear_words, dim3(2048), dim3(256), 0, st, (uint64_t *)sb.p, (uint64_t)(sb.cap / 8));
+                else HIPCHK(hipMemsetAsync(sb.p, 0, sb.cap, st));
+                if (clear_mode && !strcmp(clear_mode, "sync")) HIPCHK(hipDeviceSynchronize());
+                c->seg_epoch = 0;
+            }
             c->seg_epoch++;
         }
         const uint32_t epoch = c->seg_epoch;
@@ -1577,10 +1673,23 @@ mtb_status mtb_index_slice(mtb_index *ix, uint64_t lo_value, uint64_t hi_value, 
     mtb_ctx *c = ix->ctx;
     HIPCHK(hipSetDevice(c->device));
     uint64_t b[2] = {lo_value, hi_value}, pos[2] = {0, 0};
-    STCHK(ensure_flat(ix));                 /* a view shares the parent's arrays: the parent must stay flat while the view is used */
-    if (ix->T) STCHK(lower_bounds(c, ix->d_values, ix->T, 1, b, 2, pos));
+    if (ix->parent) return fail(MTB_ERR_ARG, "a view of a view: slice the parent instead");
+    {   /* a view reads the parent's flat arrays: the parent goes flat now and stays flat while views are alive (ensure_packed /
+           mtb_index_seal refuse, the fused join takes its flat-state kernel) */
+        std::unique_lock<std::mutex> lk(ix->state_mu);
+        ix->state_cv.wait(lk, [&] { return ix->users == 0; });
+        STCHK(ensure_flat_locked(ix));
+        ix->views++;
+    }
+    mtb_status st_lb = MTB_OK;
+    if (ix->T) st_lb = lower_bounds(c, ix->d_values, ix->T, 1, b, 2, pos);
+    if (st_lb != MTB_OK) { std::lock_guard<std::mutex> lk(ix->state_mu); ix->views--; return st_lb; }
     if (hi_value == UINT64_MAX) pos[1] = ix->T;
-    mtb_index *sl = new mtb_index(*ix);
+    mtb_index *sl = new mtb_index();
+    sl->ctx = ix->ctx; sl->tax = ix->tax; sl->params = ix->params; sl->info_mask = ix->info_mask;
+    sl->d_canon = ix->d_canon; sl->d_parent = ix->d_parent; sl->d_depth = ix->d_depth; sl->d_spparent = ix->d_spparent; sl->d_tax2species = ix->d_tax2species;
+    sl->d_under = ix->d_under; sl->d_accleaf = ix->d_accleaf; sl->d_node = ix->d_node;
+    sl->parent = ix;
     sl->own = false; sl->own_tax = false; sl->d_dir = nullptr; sl->d_dirbase = nullptr; sl->dir_L = 0;
     sl->d_values = ix->d_values + pos[0]; sl->d_info = ix->d_info + pos[0]; sl->T = pos[1] - pos[0];
     sl->match_last = !is_last || ix->match_last;
@@ -1679,6 +1788,36 @@ mtb_status mtb_debug_move_buffer(mtb_ctx *c, const char *name, unsigned long lon
     return MTB_OK;
 }
 #endif
+
+mtb_status mtb_ctx_join_footprint(mtb_ctx *c, mtb_index *ix, mtb_join_footprint *out) {
+    if (!c || !ix || !out) return fail(MTB_ERR_ARG, "NULL argument");
+    memset(out, 0, sizeof(*out));
+    if (!c->last_sorted || !ix->d_dir || c->last_sub_batches != 1) return fail(MTB_ERR_UNSUPPORTED, "no directory join of a single sub-batch to look at");
+    HIPCHK(hipSetDevice(c->device));
+    const uint64_t nb = ix->dir_buckets, T = ix->T;
+    const uint64_t w_b = (nb >> 5) + 1, w_d = (((nb + 1) * 4) >> 11) + 1, w_t = ((T * 8) >> 11) + 1;
+    uint32_t *bm = nullptr; unsigned long long *d_cnt = nullptr;
+    if (hipMalloc((void **)&bm, (w_b + w_d + w_t) * 4) != hipSuccess) { (void)hipGetLastError(); return fail(MTB_ERR_OOM, "no HBM for the footprint bitmaps"); }
+    if (hipMalloc((void **)&d_cnt, 32) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(bm); return fail(MTB_ERR_OOM, "no HBM for the footprint counters"); }
+    mtb_status st = MTB_OK;
+    hipError_t e = hipMemsetAsync(bm, 0, (w_b + w_d + w_t) * 4, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_cnt, 0, 32, c->stream);
+    if (e == hipSuccess && c->last_sorted_n) {
+        hipLaunchKernelGGL(k_join_footprint, dim3((uint32_t)((c->last_sorted_n + 255) / 256)), dim3(256), 0, c->stream, c->last_sorted, c->last_sorted_n, dir_view(ix), T,
+                           bm, bm + w_b, bm + w_b + w_d, d_cnt);
+        hipLaunchKernelGGL(k_popcount_words, dim3(2048), dim3(256), 0, c->stream, (const uint32_t *)bm, w_b, d_cnt + 1);
+        hipLaunchKernelGGL(k_popcount_words, dim3(2048), dim3(256), 0, c->stream, (const uint32_t *)(bm + w_b), w_d, d_cnt + 2);
+        hipLaunchKernelGGL(k_popcount_words, dim3(2048), dim3(256), 0, c->stream, (const uint32_t *)(bm + w_b + w_d), w_t, d_cnt + 3);
+        e = hipGetLastError();
+    }
+    unsigned long long h[4] = {0, 0, 0, 0};
+    if (e == hipSuccess) e = hipMemcpyAsync(h, d_cnt, 32, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) st = fail(MTB_ERR_DEVICE, std::string("join footprint: ") + hipGetErrorString(e));
+    (void)hipFree(bm); (void)hipFree(d_cnt);
+    out->n_queries = h[0]; out->distinct_buckets = h[1]; out->dir_sectors = h[2]; out->target_sectors = h[3]; out->n_buckets = nb; out->n_targets = T;
+    return st;
+}
 
 mtb_status mtb_last_batch_stats(mtb_ctx *c, mtb_batch_stats *out) {
     if (!c || !out) return fail(MTB_ERR_ARG, "NULL argument");

@@ -42,7 +42,7 @@ def flog2_k(dim):
     return int(math.floor(math.log2(dim))) + 1
 
 
-def write_taxonomy_db(path, node_lines, names: dict, merged_lines=(), use_internal=True, version=2, k_extra=0):
+def write_taxonomy_db(path, node_lines, names: dict, merged_lines=(), use_internal=True, version=2, k_extra=0, slack=True):
     """names: orig id -> scientific name.  Returns org2internal (identity dict when use_internal is False)."""
     if use_internal:
         nodes, dm, int2org, org2int = internal_numbering(node_lines, merged_lines)
@@ -95,6 +95,10 @@ def write_taxonomy_db(path, node_lines, names: dict, merged_lines=(), use_intern
     out += struct.pack("<QQQ", len(data), len(offsets), len(offsets))
     out += bytes(data)
     out += struct.pack(f"<{len(offsets)}I", *offsets)
+    if not use_internal and slack:
+        # serialize() counts (maxTaxID + 1) ints for internal2orgTaxId into memSize whether or not it writes them
+        # (TaxonomyWrapper.cpp:296-310 vs :341-344) and dumps the whole malloc'ed buffer: such files end in unused bytes
+        out += b"\xCD" * (4 * (max_taxid + 1))
     with open(path, "wb") as f:
         f.write(out)
     return org2int

@@ -299,6 +299,108 @@ def test_two_streams_give_identical_results(toy):
     ix.close(); c.close()
 
 
+def test_streams_on_an_unsealed_depth7_index(toy, monkeypatch):
+    """with mtb_ctx_set_streams(n >= 2) every lane thread used to see an unpacked depth-7 index and launch the
+    in-place, non-idempotent pack itself (pack(pack(v)) loses the value) on the index's stream while its join ran on the lane's.
+    The conversion now happens once under the index's state lock, complete before any lane's join may read the array; a lane that
+    needs the other state waits for the joins in flight.  Two lanes on a freshly opened (flat) depth-7 toy index, then a stage
+    join (unpacks), then two lanes again (re-pack): every result equals the single-stream run and the oracle, and the index still
+    downloads as the database's arrays."""
+    import metabuli_amd as M
+    if toy.p.seq_mode == 3:
+        pytest.skip("long reads use exact segments (k_join), not the slot path")
+    monkeypatch.setenv("MTB_DIR_DEPTH", "7")
+    c = M.Context(0)
+    p = _params(toy)
+    ix = c.open_index(toy.dbdir, p)
+    monkeypatch.delenv("MTB_DIR_DEPTH")
+    assert ix.state() == dict(dir_depth=7, packed=False, sealed=False)
+    big = 8192 // toy.n_reads + 1
+    b1 = np.tile(toy.b1, big); o1 = np.concatenate([[0], np.cumsum(np.tile(np.diff(toy.o1.astype(np.int64)), big))]).astype(np.uint64)
+    b2 = o2 = None
+    if toy.b2 is not None:
+        b2 = np.tile(toy.b2, big); o2 = np.concatenate([[0], np.cumsum(np.tile(np.diff(toy.o2.astype(np.int64)), big))]).astype(np.uint64)
+    if len(o1) - 1 < 8192:
+        ix.close(); c.close(); pytest.skip("batch too small to be split")
+    ro = toy.ref["results"]
+    amb = np.tile(ro["flag"] != 0, big)
+    c.set_streams(2)
+    r2, t2, c2 = c.classify_batch(ix, p, b1, o1, b2, o2)              # both lanes arrive at a flat index: one of them packs, once
+    assert ix.state()["packed"]
+    assert ((r2["classification"] == np.tile(ro["classification"], big)) | amb).all()
+    assert ((r2["score"].view(np.uint32) == np.tile(ro["score"].view(np.uint32), big)) | amb).all()
+    m = c.sort_matches(c.match(ix, toy.ref["kmers"]), toy.n_reads)     # stage join: unpacks
+    assert (m == toy.ref["matches"]).all() and not ix.state()["packed"]
+    r3, t3, c3 = c.classify_batch(ix, p, b1, o1, b2, o2)              # two lanes again: packs again
+    assert (r3 == r2).all() and (t3 == t2).all() and (c3 == c2).all()
+    c.set_streams(1)
+    r1, t1, c1 = c.classify_batch(ix, p, b1, o1, b2, o2)
+    assert (r1["classification"] == r2["classification"]).all() and (r1["score"].view(np.uint32) == r2["score"].view(np.uint32)).all()
+    v, info = ix.download()
+    assert (v == toy.values).all() and (info.astype(np.int32) == toy.taxids).all()
+    ix.close(); c.close()
+
+
+def test_views_keep_their_parent_flat(toy, monkeypatch):
+    """a view (mtb_index_slice) reads the parent's flat arrays; while one is alive the parent is not packed (the
+    fused join takes its flat-state kernel) and cannot be sealed; after the last view is closed it packs again."""
+    import metabuli_amd as M
+    if toy.p.seq_mode == 3:
+        pytest.skip("long reads use exact segments (k_join), not the slot path")
+    monkeypatch.setenv("MTB_DIR_DEPTH", "7")
+    c = M.Context(0)
+    p = _params(toy)
+    ix = c.open_index(toy.dbdir, p)
+    monkeypatch.delenv("MTB_DIR_DEPTH")
+    res, tt, tc = c.classify_batch(ix, p, toy.b1, toy.o1, toy.b2, toy.o2)
+    _check_results(toy, res, tt, tc)
+    assert ix.state()["packed"]
+    mid = int(toy.values[len(toy.values) // 2]) & ~0xFFFFFF
+    view = ix.slice(0, mid, False)
+    assert not ix.state()["packed"]
+    res, tt, tc = c.classify_batch(ix, p, toy.b1, toy.o1, toy.b2, toy.o2)          # parent stays flat: k_join_dir<false>
+    _check_results(toy, res, tt, tc)
+    assert not ix.state()["packed"]
+    with pytest.raises(M.MtbError) as e:
+        ix.seal()
+    assert e.value.status == M.MTB_ERR_UNSUPPORTED
+    ks = toy.ref["kmers"]
+    lo_part = ks[ks["value"] < np.uint64(mid)]
+    m = c.sort_matches(c.match(view, lo_part), toy.n_reads)                          # the view's arrays are still values, not packed words
+    m_parent = c.sort_matches(c.match(ix, lo_part), toy.n_reads)
+    assert len(m) > 0 and (m == m_parent).all()
+    view.close()
+    res, tt, tc = c.classify_batch(ix, p, toy.b1, toy.o1, toy.b2, toy.o2)
+    _check_results(toy, res, tt, tc)
+    assert ix.state()["packed"]
+    ix.close(); c.close()
+
+
+def test_borrowed_arrays_are_handed_back_flat(ctx, toy):
+    """mtb_index_from_device borrows the caller's arrays and the fused path packs d_values in place; closing the
+    index restores them (values and, unless the index was sealed, info)."""
+    torch = pytest.importorskip("torch")
+    import metabuli_amd as M
+    if toy.p.seq_mode == 3:
+        pytest.skip("long reads use exact segments (k_join), not the slot path")
+    os.environ["MTB_DIR_DEPTH"] = "7"
+    try:
+        p = _params(toy)
+        dv = torch.from_numpy(toy.values.view(np.int64).copy()).cuda(); di = torch.from_numpy(toy.taxids.astype(np.int32).copy()).cuda()
+        taxid_list = np.unique(toy.taxids).astype(np.int32)
+        ix = ctx.index_from_device(dv.data_ptr(), di.data_ptr(), len(toy.values), os.path.join(toy.dbdir, "taxonomy"), taxid_list, p)
+    finally:
+        del os.environ["MTB_DIR_DEPTH"]
+    res, tt, tc = ctx.classify_batch(ix, p, toy.b1, toy.o1, toy.b2, toy.o2)
+    _check_results(toy, res, tt, tc)
+    assert ix.state()["packed"]
+    torch.cuda.synchronize()
+    assert not (dv.cpu().numpy().view(np.uint64) == toy.values).all()              # the lender's array holds packed words now
+    ix.close()
+    torch.cuda.synchronize()
+    assert (dv.cpu().numpy().view(np.uint64) == toy.values).all() and (di.cpu().numpy() == toy.taxids).all()
+
+
 def test_foreign_sequence_ids_are_rejected(ctx):
     """caller-supplied match records whose sequenceID lies outside the batch are an argument error, not a wild write"""
     import metabuli_amd as M

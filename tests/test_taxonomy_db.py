@@ -90,9 +90,13 @@ def test_taxonomy_db_without_internal_ids_and_bad_version(emu, tmp_path):
     w = _world(7)
     lines, names = _lines(w)
     path = str(tmp_path / "plain")
-    tw.write_taxonomy_db(path, lines, names, use_internal=False)
+    tw.write_taxonomy_db(path, lines, names, use_internal=False)          # ends in the unused id-map bytes, as the reference's files do
     rc, db = _load_db(emu, path, np.zeros(0, np.int32))
     assert rc == 0, db
+    tight = str(tmp_path / "plain_tight")
+    tw.write_taxonomy_db(tight, lines, names, use_internal=False, slack=False)
+    rc, db2 = _load_db(emu, tight, np.zeros(0, np.int32))
+    assert rc == 0 and (db2["canon"] == db["canon"]).all() and (db2["parent"] == db["parent"]).all()
     present = np.flatnonzero(db["canon"] >= 0)
     assert set(present.tolist()) == {o for o, _, _ in lines}
     assert (db["orig"] == np.arange(len(db["orig"]))).all()      # getOriginalTaxID is the identity without internal ids
