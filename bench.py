@@ -98,25 +98,27 @@ def extract_targets(ctx, M, world, params, torch=None, dev=None, genomes_per_cal
             kv = torch.from_numpy(np.ascontiguousarray(k["value"]).view(np.int64)).to(dev)
         for gi, (tid, g) in enumerate(chunk):
             if torch is not None:
-                v = torch.unique(kv[first[gi]:first[gi + 1]])                                   # (signed order inside a genome; the global order is made below)
-                vals.append(v); tids.append(torch.full((len(v),), tid, dtype=torch.int32, device=dev))
+                v = torch.unique(kv[first[gi]:first[gi + 1]])                                   # signed ascending: [negative values | non-negative values]
+                n_neg = int((v < 0).sum().item())
+                vals.append((v[n_neg:], v[:n_neg])); tids.append(tid)
             else:
                 v = np.unique(k["value"][first[gi]:first[gi + 1]])
                 vals.append(v); tids.append(np.full(len(v), tid, np.int32))
     # one strain per species here, so (value, species) pairs are already unique; strain ids rise with the genome order,
     # so a STABLE sort by value of the genome-major concatenation is (value, taxid) order
     if torch is not None:
-        v = torch.cat(vals); t = torch.cat(tids)
-        del vals, tids
         # unsigned 64-bit order = the non-negative int64 values ascending, then the negative ones ascending; the halves are
-        # sorted separately (torch.sort takes < 2^31 elements per call)
+        # sorted separately (torch.sort and boolean masks take < 2^31 elements per call)
         out_v, out_t = [], []
-        for half in (v >= 0, v < 0):
-            hv, ht = v[half], t[half]
+        for half in (0, 1):
+            hv = torch.cat([x[half] for x in vals])
+            ht = torch.cat([torch.full((len(x[half]),), tid, dtype=torch.int32, device=dev) for x, tid in zip(vals, tids)])
+            if len(hv) >= 2**31:
+                raise SystemExit(f"{len(hv)} genome-derived metamers in one sign half: more than one torch.sort call takes")
             order = torch.sort(hv, stable=True).indices
             out_v.append(hv[order].cpu().numpy().view(np.uint64)); out_t.append(ht[order].cpu().numpy())
             del hv, ht, order
-        del v, t
+        del vals
         torch.cuda.empty_cache()
         return np.concatenate(out_v), np.concatenate(out_t)
     vals = np.concatenate(vals); tids = np.concatenate(tids)
@@ -639,7 +641,7 @@ def main():
         raise SystemExit(f"sanity check failed: only {frac_cls:.4f} of the reads were classified")
 
     cpu, parity = None, None
-    if rank == 0 and world_size == 1 and not args.no_parity:
+    if rank == 0 and world_size == 1 and not args.no_parity and not big_world:       # (the small-index sample would need all 2.4 G genome-derived entries: the diversity run keeps the check against the timed index only)
         cpu, parity = cpu_baseline_and_parity(ctx, M, torch, dev, world, real_v, real_t, params, taxdir, d_bases, d_bases2, args.read_len,
                                               min(args.cpu_reads, args.reads), int(args.cpu_targets), args.seed, run_cpu=not args.no_cpu)
         log(f"[rank 0] parity sample: {parity}")

@@ -71,4 +71,15 @@ __device__ __forceinline__ T block_exclusive_scan(T v, T *s_tmp, T *total) {
     return pre + inc - v;
 }
 
+/* experiment build (-DMTB_SYS_FENCES, profiles/scripts/contig_diag.py): system-scope release at the end of the kernels that write
+ * the slot buffer and system-scope acquire at the start of those that read it -- on gfx950 these emit the L2 write-back /
+ * invalidate that a kernel boundary normally implies for ordinary device memory */
+#ifdef MTB_SYS_FENCES          /* 1: both, 2: release only, 3: acquire only */
+#define MTB_END_RELEASE() do { if (MTB_SYS_FENCES != 3) __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); } while (0)
+#define MTB_BEGIN_ACQUIRE() do { if (MTB_SYS_FENCES != 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); } while (0)
+#else
+#define MTB_END_RELEASE() do {} while (0)
+#define MTB_BEGIN_ACQUIRE() do {} while (0)
+#endif
+
 #endif

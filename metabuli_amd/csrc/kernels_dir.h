@@ -253,6 +253,7 @@ __global__ __launch_bounds__(256) void k_join_dir(const mtb_kmer *__restrict__ q
             }
         }
     }
+    MTB_END_RELEASE();
 }
 
 /* ---- diagnostic (not on the timed path): what the directory join addresses on the index side --------------------------------

@@ -674,6 +674,7 @@ __global__ __launch_bounds__(64, (CAP > MTB_SCORE_LDS ? 2 : MTB_SCORE_MINWAVES))
      * which is dead once the species scores exist (keeps LDS per wave small -> occupancy) */
     static_assert(CAP * sizeof(mtb_path) >= MTB_SCORE_BKT * 13 + (MTB_LR_MAXE + MTB_LR_MAXE * MTB_LR_K) * 4, "decide arrays must fit the path area");
     const uint32_t lane = threadIdx.x;
+    MTB_BEGIN_ACQUIRE();
     MTB_PHASE_KERNEL_BEGIN();
     const uint64_t n_iter = list ? (uint64_t)*n_list : n_reads;      /* optional: only the listed reads */
     /* DYN (slab launches: long reads, each worth milliseconds): the workgroups claim reads one by one from the counter

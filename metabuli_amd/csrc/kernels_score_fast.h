@@ -100,6 +100,7 @@ __global__ __launch_bounds__(64, K <= 3 ? 4 : 2) void k_score_fast(const mtb_slo
     __shared__ uint32_t s_pf[64];
     __shared__ uint32_t s_hcnt[256];            /* matches per species hash: lonely matches are dropped up front */
     const int32_t lane = (int32_t)threadIdx.x;
+    MTB_BEGIN_ACQUIRE();
 #ifdef MTB_FAST_DEBUG
     __shared__ unsigned long long s_ph[16];
     if (threadIdx.x < 16) s_ph[threadIdx.x] = 0;

@@ -187,6 +187,7 @@ __global__ __launch_bounds__(256) void k_probe_scatter(mtb_slot16 *buf, uint64_t
 }
 __global__ __launch_bounds__(256) void k_clear_words(uint64_t *p, uint64_t n_words) {
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * 256) p[i] = 0;
+    MTB_END_RELEASE();
 }
 static mtb_status ensure_placed(mtb_ctx *c, const char *name, size_t elems, mtb_slot16 **out) {
     DevBuf &b = c->bufs[name];

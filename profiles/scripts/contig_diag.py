@@ -79,8 +79,16 @@ def main():
         ("contig + plain slot stores", {"MTB_SEGM_CONTIG": "1", "MTB_LIB": os.path.join(csrc, "libmtb_xnont.so")}),
         ("contig + poisoned buffers", {"MTB_SEGM_CONTIG": "1", "MTB_LIB": os.path.join(csrc, "libmtb_xpoison.so")}),
         ("contig, every batch twice", {"MTB_SEGM_CONTIG": "1", "DIAG_REPS": "2"}),
+        ("contig + system-scope release after the slot writers / acquire before the readers", {"MTB_SEGM_CONTIG": "1", "MTB_LIB": os.path.join(csrc, "libmtb_xfence.so")}),
+        ("contig + fences + clear by kernel", {"MTB_SEGM_CONTIG": "1", "MTB_SEGM_CLEAR": "kernel", "MTB_LIB": os.path.join(csrc, "libmtb_xfence.so")}),
+        ("hipMalloc + fences (control)", {"MTB_LIB": os.path.join(csrc, "libmtb_xfence.so")}),
+        ("contig + release fences only", {"MTB_SEGM_CONTIG": "1", "MTB_SEGM_CLEAR": "kernel", "MTB_LIB": os.path.join(csrc, "libmtb_xfencerel.so")}),
+        ("contig + acquire fences only", {"MTB_SEGM_CONTIG": "1", "MTB_SEGM_CLEAR": "kernel", "MTB_LIB": os.path.join(csrc, "libmtb_xfenceacq.so")}),
     ]
+    only = [a for a in sys.argv[1:] if not a.startswith("--")]
     for name, env in variants:
+        if only and not any(o in name for o in only):
+            continue
         if "MTB_LIB" in env and not os.path.exists(env["MTB_LIB"]):
             print(f"== {name}: {env['MTB_LIB']} not built, skipped"); continue
         p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
