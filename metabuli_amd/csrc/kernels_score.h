@@ -687,7 +687,7 @@ __global__ __launch_bounds__(64, (CAP > MTB_SCORE_LDS ? 2 : MTB_SCORE_MINWAVES))
         unsigned long long kt0_ = __builtin_readcyclecounter();
 #endif
         const uint64_t r = list ? (uint64_t)list[it] : it;
-        if (SLOT && only_flagged && !only_flagged[r]) continue;            /* already scored by k_score_fast */
+        if ((SLOT || DYN) && only_flagged && !only_flagged[r]) continue;   /* already scored by k_score_fast (slot mode) / by k_score_long (slab launches) */
         if (SLOT && !DYN && !list && !only_flagged && it + gridDim.x < n_iter) {
             /* slot mode: start pulling the NEXT read's slots towards L2 now (one dword per 128-byte line, delivered
              * straight into a dummy LDS area: no register, nothing waits for it) -- the slot loads are one dependent

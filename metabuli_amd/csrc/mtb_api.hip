@@ -21,6 +21,7 @@
 #include "kernels_scan.h"
 #include "kernels_score.h"
 #include "kernels_score_fast.h"
+#include "kernels_score_long.h"
 #include "kernels_sort.h"
 #include "mtb_core.h"
 
@@ -749,6 +750,49 @@ static mtb_status dev_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, uint
     return MTB_OK;
 }
 
+/* Long reads (seq_mode 3): exact segments in compareMatches order -> k_score_long, one workgroup per read (kernels_score_long.h).
+ * Reads it cannot take (LDS budgets) are flagged and scored by the generic slab launch of dev_score afterwards. */
+static mtb_status dev_score_long(mtb_ctx *c, mtb_index *ix, const mtb_params *p, uint64_t n_reads, const int32_t *d_qlen, const int32_t *d_qlen2,
+                                 uint32_t max_len, mtb_result *d_res, int32_t *d_tc_tax, uint32_t *d_tc_cnt, uint64_t tc_cap, uint64_t *n_tc,
+                                 uint64_t tc_base, const mtb_match *d_m, const uint64_t *d_seg, uint32_t max_seg) {
+    mtb_score_params sp; mtb_make_score_params(p, &sp);
+    uint32_t *d_bound; uint64_t *d_tcoff; uint64_t *d_ws; uint8_t *d_todo;
+    STCHK(ensure(c, "bound", n_reads, &d_bound));
+    STCHK(ensure(c, "tcoff", n_reads + 1, &d_tcoff));
+    STCHK(ensure(c, "scanws", scan_ws_elems(n_reads + 1), &d_ws));
+    STCHK(ensure(c, "slowflag", n_reads, &d_todo));
+    hipLaunchKernelGGL(k_taxcnt_bound, dim3((uint32_t)((n_reads + 63) / 64)), dim3(64), 0, c->stream, d_seg, (const uint32_t *)nullptr, d_qlen, d_qlen2,
+                       n_reads, sp.dna_shift, d_bound);
+    { KTimer kt(c, MTB_K_SCAN); scan_launch<uint32_t, uint64_t, false>(c->stream, d_bound, n_reads, true, d_tcoff, d_ws); }
+    uint64_t tot = 0;
+    STCHK(d2h(c, &tot, d_tcoff + n_reads, 8));
+    *n_tc = tot;
+    if (tot > tc_cap) return fail(MTB_ERR_CAPACITY, "taxcnt buffers too small");
+    if (tc_base + tot >= (1ull << 32)) return fail(MTB_ERR_ARG, "more than 2^32-1 taxcnt slots in one batch (mtb_result.taxcnt_off is 32 bits); split the batch");
+    const uint32_t max_nb = (uint32_t)mtb_num_buckets((int32_t)max_len, sp.dna_shift);
+    if (max_nb > 65535u) return fail(MTB_ERR_ARG, "read too long for mtb_result.n_taxcnt (16 bits): more than 65535 position buckets");
+    HIPCHK(hipMemsetAsync(d_todo, 0, n_reads, c->stream));
+    unsigned long long *d_work = (unsigned long long *)(c->d_xscal + 6);
+    HIPCHK(hipMemsetAsync(d_work, 0, 8, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_scal + 6, 0, 8, c->stream));
+    {   KTimer kt(c, MTB_K_SCORE_FAST);       /* booked with the register-resident scorer's id: the workgroup-per-read kernel of long reads */
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(n_reads, 256ull * 3);
+        hipLaunchKernelGGL(k_score_long, dim3(grid), dim3(MTB_LONG_NT), 0, c->stream, d_m, d_seg, n_reads, d_qlen, d_qlen2, tax_view(ix), sp, (const uint64_t *)d_tcoff,
+                           d_res, d_tc_tax, d_tc_cnt, tc_cap, tc_base, d_todo, d_work); }
+    hipLaunchKernelGGL(k_count_flags, dim3(256), dim3(256), 0, c->stream, (const uint8_t *)d_todo, n_reads, (unsigned long long *)(c->d_scal + 6));
+    HIPCHK(hipGetLastError());
+    uint64_t n_left = 0;
+    STCHK(d2h(c, &n_left, c->d_scal + 6, 8));
+    c->fast_used = true;                      /* statistics: d_scal[6] = reads the generic kernel scores */
+    if (n_left == 0) return MTB_OK;
+    ScoreSrc a; a.m = d_m; a.seg = d_seg; a.sort = false; a.max_seg = std::max<uint32_t>(max_seg, MTB_SCORE_LDS + 1); a.only_flagged = d_todo;
+    uint64_t n_tc2 = 0;
+    STCHK(dev_score(c, ix, p, n_reads, d_qlen, d_qlen2, max_len, d_res, d_tc_tax, d_tc_cnt, tc_cap, &n_tc2, tc_base, a, nullptr));
+    HIPCHK(hipMemsetAsync(c->d_scal + 6, 0, 8, c->stream));         /* dev_score's statistics slot: put the count back */
+    hipLaunchKernelGGL(k_count_flags, dim3(256), dim3(256), 0, c->stream, (const uint8_t *)d_todo, n_reads, (unsigned long long *)(c->d_scal + 6));
+    return MTB_OK;
+}
+
 /* ------------------------------------------------------------------ */
 /* index                                                               */
 /* ------------------------------------------------------------------ */
@@ -1266,7 +1310,9 @@ mtb_status mtb_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, const mtb_m
     mtb_result *d_res; int32_t *d_tt; uint32_t *d_tc;
     STCHK(ensure(c, "results", n_reads, &d_res)); STCHK(ensure(c, "tctax", taxcnt_cap, &d_tt)); STCHK(ensure(c, "tccnt", taxcnt_cap, &d_tc));
     ScoreSrc src; src.m = d_m; src.seg = d_seg; src.sort = false; src.max_seg = max_seg;
-    mtb_status st = dev_score(c, ix, p, n_reads, d_ql, d_ql2, max_len, d_res, d_tt, d_tc, taxcnt_cap, n_taxcnt, 0, src, nullptr);
+    mtb_status st = (p->seq_mode == 3 && !getenv("MTB_NO_LONG_SCORER"))
+        ? dev_score_long(c, ix, p, n_reads, d_ql, d_ql2, max_len, d_res, d_tt, d_tc, taxcnt_cap, n_taxcnt, 0, d_m, d_seg, max_seg)
+        : dev_score(c, ix, p, n_reads, d_ql, d_ql2, max_len, d_res, d_tt, d_tc, taxcnt_cap, n_taxcnt, 0, src, nullptr);
     if (st != MTB_OK) return st;
     STCHK(d2h(c, results, d_res, n_reads * sizeof(mtb_result)));
     if (*n_taxcnt) { STCHK(d2h(c, taxcnt_tax, d_tt, *n_taxcnt * 4)); STCHK(d2h(c, taxcnt_cnt, d_tc, *n_taxcnt * 4)); }
@@ -1289,7 +1335,9 @@ static mtb_status score_join_order(mtb_ctx *c, mtb_index *ix, const mtb_params *
     STCHK(ensure(c, "matches", nm, &d_m));
     STCHK(dev_regroup(c, d_tmp, nm, n_reads, d_rc, &d_seg, d_m));
     HIPCHK(hipEventRecord(c->ev[4], st));
-    /* segments that fit LDS are sorted inside k_score; only the big ones are sorted here */
+    /* segments that fit LDS are sorted inside k_score; only the big ones are sorted here.  Long reads: k_score_long streams sorted
+     * segments, so every segment of two or more matches is sorted here */
+    const bool long_scorer = p->seq_mode == 3 && !getenv("MTB_NO_LONG_SCORER");
     uint32_t max_seg = 0;
     {
         uint32_t *d_large;
@@ -1297,7 +1345,7 @@ static mtb_status score_join_order(mtb_ctx *c, mtb_index *ix, const mtb_params *
         HIPCHK(hipMemsetAsync(c->d_scal + 2, 0, 16, st));
         { KTimer kt(c, MTB_K_SEGSORT);
         hipLaunchKernelGGL(k_list_large, dim3((uint32_t)((n_reads + 255) / 256)), dim3(256), 0, st, (const uint64_t *)d_seg, n_reads,
-                           (uint32_t)MTB_SCORE_LDS, d_large, (uint32_t *)(c->d_scal + 2), (uint32_t *)(c->d_scal + 3)); }
+                           long_scorer ? 1u : (uint32_t)MTB_SCORE_LDS, d_large, (uint32_t *)(c->d_scal + 2), (uint32_t *)(c->d_scal + 3)); }
         uint64_t sc[2];
         STCHK(d2h(c, sc, c->d_scal + 2, 16));
         max_seg = (uint32_t)sc[1];
@@ -1311,6 +1359,7 @@ static mtb_status score_join_order(mtb_ctx *c, mtb_index *ix, const mtb_params *
         }
     }
     HIPCHK(hipEventRecord(c->ev[5], st));
+    if (long_scorer) return dev_score_long(c, ix, p, n_reads, d_ql, d_ql2, max_len, d_results, d_taxcnt_tax, d_taxcnt_cnt, taxcnt_cap, n_taxcnt, tc_base, d_m, d_seg, max_seg);
     ScoreSrc a; a.m = d_m; a.seg = d_seg; a.sort = true; a.max_seg = max_seg;
     return dev_score(c, ix, p, n_reads, d_ql, d_ql2, max_len, d_results, d_taxcnt_tax, d_taxcnt_cnt, taxcnt_cap, n_taxcnt, tc_base, a, nullptr);
 }
