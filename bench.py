@@ -487,7 +487,7 @@ def main():
         log(f"[rank 0] candidate closure of {n_full} reads ({len(sk)} metamers): {len(closure[0])} targets ({time.perf_counter()-t_c:.1f}s)")
         del sk
     sealed = False
-    if not args.partitioned and not args.no_seal and args.seq_mode != 3:       # long reads take the exact-segment join, which works on the flat arrays
+    if not args.partitioned and not args.no_seal:
         # dedicate the index to the fused path: packed 8-byte target words under the amino-acid directory; the info array lent to
         # the library is no longer needed by it and is freed here (64 GB at 16 G targets)
         try:
@@ -669,7 +669,7 @@ def main():
                                gbp_per_s=value * args.read_len * (2 if args.seq_mode == 2 else 1) / 1e3, query_metamers=int(st.n_kmers), matches=int(st.n_matches),
                                classified_fraction=frac_cls, parallelism=f"reads sharded x{world_size}, index replicated", streams_per_gpu=args.streams,
                                sub_batches_per_step=sub_batches_timed, index_sealed=sealed,
-                               index_bytes=int(T * (8 if sealed else 12) + 4 * (21 ** index.state()["dir_depth"] + 1)), species=args.species, genome_len=args.genome_len, reads_scored_by_generic_kernel=int(ps.n_generic_reads)),
+                               index_bytes=int(T * (8 if sealed else 12) + 4 * (21 ** index.state()["dir_depth"] + 1)), species=args.species, genome_len=args.genome_len, reads_scored_by_generic_kernel=int(ps.n_generic_reads), reads_on_ordinal_slots=int(ps.n_slot_reads)),
                    stage_ms=dict(extract=st.ms_extract, sort=st.ms_sort, join=st.ms_join, regroup=st.ms_regroup,
                                  segsort=st.ms_segsort, score=st.ms_score, total=st.ms_total),
                    kernel_ms=kern, roofline=roofline, roofline_all=roofline_all, join_footprint=footprint, cpu_baseline=cpu, parity_sample=parity,

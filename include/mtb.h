@@ -101,7 +101,9 @@ typedef struct {
      * immediately before and after every launch of that kernel.            */
     float    ms_kernel[MTB_NUM_KERNELS];
     uint32_t n_launch[MTB_NUM_KERNELS];
-    uint64_t n_generic_reads;   /* reads the register-resident scorer (k_score_fast) handed to the generic k_score */
+    uint64_t n_generic_reads;   /* reads the register-resident scorer (k_score_fast) / the workgroup-per-read scorer of long reads (k_score_long) handed to the generic k_score */
+    uint64_t n_slot_reads;      /* reads whose matches went through per-read ordinal slots (short reads: fixed segments; long reads: per-read
+                                 * ranges ordered by k_seg_order) instead of regroup + segment sort */
 } mtb_batch_stats;
 
 const char *mtb_version(void);

@@ -39,7 +39,7 @@ class BatchStats(C.Structure):
                 ("ms_segsort", C.c_float), ("ms_score", C.c_float), ("ms_total", C.c_float),
                 ("n_reads", C.c_uint64), ("n_bases", C.c_uint64), ("n_kmers", C.c_uint64),
                 ("n_matches", C.c_uint64), ("n_targets", C.c_uint64),
-                ("ms_kernel", C.c_float * 10), ("n_launch", C.c_uint32 * 10), ("n_generic_reads", C.c_uint64)]
+                ("ms_kernel", C.c_float * 10), ("n_launch", C.c_uint32 * 10), ("n_generic_reads", C.c_uint64), ("n_slot_reads", C.c_uint64)]
 
 
 class JoinFootprint(C.Structure):

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void k_index_unpack(uint64_t *__restrict__ val
 #define MTB_JOIN_DIR_QPT 2
 #endif
 
-template <bool PACKED>
+template <bool PACKED, bool LONG = false>
 __global__ __launch_bounds__(256) void k_join_dir(const mtb_kmer *__restrict__ q, uint64_t n, mtb_index_view ix, uint64_t limit, mtb_dir_view dv,
                                                    const mtb_tables *__restrict__ tabs, JoinSegArgs sa, uint32_t *__restrict__ overflow) {
     constexpr int Q = MTB_JOIN_DIR_QPT;
@@ -226,8 +226,11 @@ __global__ __launch_bounds__(256) void k_join_dir(const mtb_kmer *__restrict__ q
         const uint32_t ord = mtb_q_pos(k[u].qinfo) >> 16;
         const uint64_t qinfo = k[u].qinfo & ~0xFFFF0000ull;      /* the record carries the reference's qinfo */
         const bool rev = mtb_hammings_reversed(mtb_q_frame(qinfo), ix.kmer_format);
-        mtb_slot16 *seg = sa.seg + (uint64_t)r * sa.stride;
-        bool first = ord < sa.direct;
+        uint32_t direct = sa.direct, tcap = tail_cap;
+        mtb_slot16 *seg;
+        if (LONG) { direct = sa.dcnt[r]; tcap = mtb_lslot_tail(direct, sa.tf); seg = sa.seg + sa.rb[r]; }
+        else seg = sa.seg + (uint64_t)r * sa.stride;
+        bool first = ord < direct;
         for (uint64_t t = s; t < e; t++) {
             const uint64_t v = t == s ? v0 : ix.values[t];
             const uint32_t td = (uint32_t)v & 0xFFFFFFu;
@@ -239,14 +242,15 @@ __global__ __launch_bounds__(256) void k_join_dir(const mtb_kmer *__restrict__ q
             /* non-temporal stores: a slot line is written ~5 times at unrelated moments of the kernel and never read by it; keeping
              * those lines out of the L2's way measured 47.5 ms against 50-58 ms (and steadier) for the kernel -- which is bound by
              * these 1.1 G scattered 16-byte stores: 20.5 ms without them, 29 ms with dense stores (profiles/r02_notes.md) */
-            if (first) { const mtb_slot16 sl = mtb_slot_pack(qinfo, tid, sp, td, reh, h, sa.epoch);
+            if (first) { const mtb_slot16 sl = LONG ? mtb_lslot_pack(qinfo, tid, sp, td, reh, h) : mtb_slot_pack(qinfo, tid, sp, td, reh, h, sa.epoch);
                          MTB_SLOT_STORE(sl, &seg[ord]); first = false; continue; }
             const uint32_t at = atomicAdd(&sa.cursor[r], 1u);
-            if (at < tail_cap) { const mtb_slot16 sl = mtb_slot_pack(qinfo, tid, sp, td, reh, h, sa.epoch);
-                                 MTB_SLOT_STORE(sl, &seg[sa.direct + at]); }
+            if (at < tcap) { const mtb_slot16 sl = LONG ? mtb_lslot_pack(qinfo, tid, sp, td, reh, h) : mtb_slot_pack(qinfo, tid, sp, td, reh, h, sa.epoch);
+                             MTB_SLOT_STORE(sl, &seg[direct + at]); }
             else {
                 const unsigned long long o = atomicAdd(sa.ovf_counter, 1ull);
-                if (o < sa.ovf_cap) {
+                if (LONG) { }                      /* counted only: the caller retries the join with a larger tail */
+                else if (o < sa.ovf_cap) {
                     mtb_match m; m.qinfo = qinfo; m.target_id = tid; m.species_id = sp; m.dna = td; m.right_end_hamming = reh; m.hamming = (uint8_t)h; m.pad = 0;
                     sa.ovf[o] = m;
                 } else *overflow = 1;

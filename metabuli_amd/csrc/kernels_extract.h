@@ -108,7 +108,7 @@ __global__ __launch_bounds__(64) void k_extract(ExtractArgs a, const mtb_tables 
         }
         /* pair skipped if either mate is too short (KmerExtractor.cpp:443-453) */
         const bool skip = mtb_read_too_short(len1) || (paired && mtb_read_too_short(len2));
-        if (skip) { if (MODE == 0 && lane == 0) counts[r] = 0; continue; }
+        if (skip) { if ((MODE == 0 || (MODE == 2 && counts)) && lane == 0) counts[r] = 0; continue; }
         uint64_t wpos = MODE == 1 ? out_offs[r] : 0;
         uint32_t total = 0;
         for (int mate = 0; mate < (paired ? 2 : 1); mate++) {
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(64) void k_extract(ExtractArgs a, const mtb_tables 
                 }
             }
         }
-        if (MODE == 0 && lane == 0) counts[r] = total;
+        if ((MODE == 0 || (MODE == 2 && counts)) && lane == 0) counts[r] = total;      /* single pass: only the long-read slot path asks for them */
         my_maxq = total > my_maxq ? total : my_maxq;
     }
     flush();

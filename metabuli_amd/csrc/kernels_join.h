@@ -68,6 +68,9 @@ struct JoinSegArgs {
     mtb_slot16 *seg; uint32_t stride, direct; uint32_t *cursor;
     mtb_match *ovf; uint64_t ovf_cap; unsigned long long *ovf_counter;
     uint32_t epoch;
+    /* long reads (k_join_dir<.., LONG>): read r owns slots [rb[r], rb[r + 1]) = dcnt[r] direct ones (one per metamer, by ordinal)
+     * + mtb_lslot_tail(dcnt[r], tf) tail slots; matches beyond the tail are only counted (the caller retries with a larger tail) */
+    const uint64_t *rb; const uint32_t *dcnt; uint32_t tf;
 };
 
 #ifdef MTB_SCORE_PHASE_CYCLES

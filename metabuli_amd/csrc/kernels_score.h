@@ -667,7 +667,7 @@ __global__ __launch_bounds__(64, (CAP > MTB_SCORE_LDS ? 2 : MTB_SCORE_MINWAVES))
                                                const uint32_t *__restrict__ cursor, uint32_t stride, int seg_by_list,
                                                uint32_t direct, uint32_t epoch, uint32_t *__restrict__ big_list, uint32_t *__restrict__ n_big_out,
                                                uint32_t *__restrict__ cnt_out, unsigned long long *__restrict__ work,
-                                               const uint8_t *__restrict__ only_flagged) {
+                                               const uint8_t *__restrict__ only_flagged, const uint32_t *__restrict__ seg_cnt = nullptr) {
     __shared__ __attribute__((aligned(16))) uint8_t s_ws[MTB_SCORE_WS_BYTES_(CAP)];
     __shared__ uint32_t s_pf[64];                 /* landing zone of the slot prefetch (never read) */
     /* bucket / taxCnt / chain arrays of the decide phase live in the path storage,
@@ -703,7 +703,7 @@ __global__ __launch_bounds__(64, (CAP > MTB_SCORE_LDS ? 2 : MTB_SCORE_MINWAVES))
         uint64_t s0 = 0; int32_t n = 0;
         if (!SLOT) {
             const uint64_t si = seg_by_list ? it : r;
-            s0 = seg_start[si]; n = (int32_t)(seg_start[si + 1] - s0);
+            s0 = seg_start[si]; n = (DYN && seg_cnt) ? (int32_t)seg_cnt[si] : (int32_t)(seg_start[si + 1] - s0);
         }
         const int32_t ql1 = qlen[r], ql2 = qlen2[r];
         const int32_t read_len = ql1 + ql2;

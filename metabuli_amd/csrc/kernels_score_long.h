@@ -58,7 +58,8 @@ __global__ __launch_bounds__(MTB_LONG_NT) void k_score_long(const mtb_match *__r
                                                              const int32_t *__restrict__ qlen, const int32_t *__restrict__ qlen2, mtb_tax_view tx, mtb_score_params sp,
                                                              const uint64_t *__restrict__ tc_off, mtb_result *__restrict__ results, int32_t *__restrict__ tc_tax,
                                                              uint32_t *__restrict__ tc_cnt, uint64_t tc_cap, uint64_t tc_base, uint8_t *__restrict__ todo,
-                                                             unsigned long long *__restrict__ work) {
+                                                             unsigned long long *__restrict__ work, const uint32_t *__restrict__ seg_cnt = nullptr,
+                                                             const uint32_t *__restrict__ list = nullptr, uint32_t n_list = 0) {
     __shared__ __attribute__((aligned(16))) mtb_lpath s_path[MTB_LONG_MAXP];
     __shared__ uint16_t s_sidx[MTB_LONG_MAXP], s_acc[MTB_LONG_MAXP];
     __shared__ uint32_t s_blk[MTB_LONG_MAXBLK];
@@ -80,10 +81,11 @@ __global__ __launch_bounds__(MTB_LONG_NT) void k_score_long(const mtb_match *__r
         __syncthreads();
         if (tid == 0) { s_r = atomicAdd(work, 1ull); s_nblk = 0; s_next = 0; s_npath = 0; s_fail = 0; s_nsp = 0; s_go = 0; }
         __syncthreads();
-        const uint64_t r = s_r;
-        if (r >= n_reads) break;
-        const uint64_t s0 = seg_start[r];
-        const int32_t n = (int32_t)(seg_start[r + 1] - s0);
+        const uint64_t it = s_r;
+        if (it >= (list ? (uint64_t)n_list : n_reads)) break;
+        const uint64_t r = list ? (uint64_t)list[it] : it;           /* optional: only the listed reads, their segments indexed by the list slot */
+        const uint64_t s0 = seg_start[it];
+        const int32_t n = seg_cnt ? (int32_t)seg_cnt[it] : (int32_t)(seg_start[it + 1] - s0);      /* (ordered slot segments: the read's records fill the front of its slot range) */
         const mtb_match *m = matches + s0;
         const int32_t ql1 = qlen[r], ql2 = qlen2[r], read_len = ql1 + ql2;
         const int32_t nb = mtb_num_buckets(read_len, sp.dna_shift);

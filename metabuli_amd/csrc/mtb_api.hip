@@ -22,6 +22,7 @@
 #include "kernels_score.h"
 #include "kernels_score_fast.h"
 #include "kernels_score_long.h"
+#include "kernels_seg_order.h"
 #include "kernels_sort.h"
 #include "mtb_core.h"
 
@@ -81,6 +82,7 @@ struct mtb_ctx {
     int ws_seq_mode = 0;             /* the buffer sets of short and long reads differ: a change of mode releases the workspace */
     uint32_t last_sub_batches = 0;
     bool fast_used = false;          /* the last dev_score call launched k_score_fast (its slow-list count sits in d_scal[6]) */
+    bool no_lslot = false;           /* classify_one is redoing a long-read range on the exact-segment path */
     const mtb_kmer *last_sorted = nullptr; uint64_t last_sorted_n = 0;       /* the last fused slot-path batch's sorted metamers (mtb_ctx_join_footprint) */
 };
 /* buffers that carry a call's inputs / outputs (host-buffer entry points) are not workspace */
@@ -367,7 +369,8 @@ static mtb_status h2d(mtb_ctx *c, void *dst, const void *src, size_t bytes) {
 static mtb_status dev_extract(mtb_ctx *c, const mtb_params *p, const char *d_bases, const uint64_t *d_offs, const char *d_bases2,
                               const uint64_t *d_offs2, uint64_t n_reads, mtb_kmer **out, uint64_t *count, int32_t *d_qlen,
                               int32_t *d_qlen2, uint32_t *max_len, bool single_pass = false, uint64_t n_bases = 0,
-                              uint64_t *real_count = nullptr, bool tag_ord = false, uint32_t *max_q = nullptr, uint16_t **dig = nullptr) {
+                              uint64_t *real_count = nullptr, bool tag_ord = false, uint32_t *max_q = nullptr, uint16_t **dig = nullptr,
+                              uint32_t *d_counts = nullptr /* single pass: metamers per read (long-read slot path) */) {
     if (n_reads >= (1ull << 29)) return fail(MTB_ERR_ARG, "more than 2^29-1 reads per batch (sequenceID is 29 bits, Kmer.h:13)");
     if (p->kmer_format != 1 && p->kmer_format != 2) return fail(MTB_ERR_UNSUPPORTED, "only kmer_format 1 and 2 are implemented");
     if (p->syncmer && (p->smer_len < 1 || p->smer_len > 8)) return fail(MTB_ERR_ARG, "smer_len out of range");
@@ -399,7 +402,7 @@ static mtb_status dev_extract(mtb_ctx *c, const mtb_params *p, const char *d_bas
             if (dig) { STCHK(ensure(c, "digA", cap, &d_dig)); *dig = d_dig; }
             HIPCHK(hipMemsetAsync(c->d_xscal, 0, 32, c->stream));
             { KTimer kt(c, MTB_K_EXTRACT_EMIT);
-            hipLaunchKernelGGL((k_extract<2>), dim3(grid), dim3(64), 0, c->stream, a, c->d_tabs, (uint32_t *)nullptr, (const uint64_t *)nullptr,
+            hipLaunchKernelGGL((k_extract<2>), dim3(grid), dim3(64), 0, c->stream, a, c->d_tabs, d_counts, (const uint64_t *)nullptr,
                                d_k, d_qlen, d_qlen2, (uint32_t *)(c->d_scal + 4), (unsigned long long *)c->d_xscal, cap, d_dig); }
             HIPCHK(hipGetLastError());
             uint64_t sc[4];
@@ -580,6 +583,10 @@ static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint6
         KTimer kt(c, MTB_K_JOIN);
         JoinSegArgs sa = *seg; sa.ovf_counter = (unsigned long long *)c->d_scal;
         const uint32_t g2 = (uint32_t)((n + 256 * MTB_JOIN_DIR_QPT - 1) / (256 * MTB_JOIN_DIR_QPT));
+        if (sa.rb) {        /* long reads: per-read slot ranges */
+            if (state_owner(ix)->packed) hipLaunchKernelGGL((k_join_dir<true, true>), dim3(g2), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1));
+            else hipLaunchKernelGGL((k_join_dir<false, true>), dim3(g2), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1));
+        } else
         if (state_owner(ix)->packed) hipLaunchKernelGGL((k_join_dir<true>), dim3(g2), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1));
         else hipLaunchKernelGGL((k_join_dir<false>), dim3(g2), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1));
     } else
@@ -652,6 +659,8 @@ struct ScoreSrc {
     uint32_t max_seg = 0;                 /* largest segment this launch can meet */
     uint32_t grid = 0;                    /* 0 = default */
     const uint8_t *only_flagged = nullptr; /* slot mode after k_score_fast: score only the reads it flagged */
+    const uint32_t *seg_cnt = nullptr;     /* slab launches: matches per read when the segment does not fill [seg[r], seg[r + 1]) */
+    const void *bound_by_buckets = nullptr; /* non-NULL: every read gets one taxcnt slot per position bucket (its match count is not in seg[]) */
 };
 
 /* d_results/d_tc_* are device outputs; *n_tc = sum of per-read bounds.  `second` (optional) runs after the launch
@@ -666,8 +675,8 @@ static mtb_status dev_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, uint
     STCHK(ensure(c, "bound", n_reads, &d_bound));
     STCHK(ensure(c, "tcoff", n_reads + 1, &d_tcoff));
     STCHK(ensure(c, "scanws", scan_ws_elems(n_reads + 1), &d_ws));
-    hipLaunchKernelGGL(k_taxcnt_bound, dim3((uint32_t)((n_reads + 63) / 64)), dim3(64), 0, c->stream, first.seg, first.cursor, d_qlen, d_qlen2,
-                       n_reads, sp.dna_shift, d_bound);
+    hipLaunchKernelGGL(k_taxcnt_bound, dim3((uint32_t)((n_reads + 63) / 64)), dim3(64), 0, c->stream, first.seg, first.cursor ? first.cursor : (const uint32_t *)first.bound_by_buckets,
+                       d_qlen, d_qlen2, n_reads, sp.dna_shift, d_bound);
     { KTimer kt(c, MTB_K_SCAN); scan_launch<uint32_t, uint64_t, false>(c->stream, d_bound, n_reads, true, d_tcoff, d_ws); }
     uint64_t tot = 0;
     STCHK(d2h(c, &tot, d_tcoff + n_reads, 8));
@@ -707,7 +716,7 @@ static mtb_status dev_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, uint
         if (dynamic) { d_work = (unsigned long long *)(c->d_xscal + 4 + pass); HIPCHK(hipMemsetAsync(d_work, 0, 8, c->stream)); }
 #define MTB_LAUNCH_SCORE(SRT, K, CAPV, DYNV, SLOTV) hipLaunchKernelGGL((k_score<SRT, K, mtb_match, CAPV, DYNV, SLOTV>), dim3(grid), dim3(64), 0, c->stream, S->m, S->seg, n_reads, d_qlen, \
         d_qlen2, tax_view(ix), sp, (const uint64_t *)d_tcoff, d_res, d_tc_tax, d_tc_cnt, tc_cap, d_slabs, slab_bytes, slab_n, slab_nb, (mtb_match *)nullptr,  \
-        tc_base, S->list, S->n_list, S->cursor, S->stride, S->seg_by_list, S->direct, S->epoch, S->big_list, S->n_big, S->cnt_out, d_work, S->only_flagged)
+        tc_base, S->list, S->n_list, S->cursor, S->stride, S->seg_by_list, S->direct, S->epoch, S->big_list, S->n_big, S->cnt_out, d_work, S->only_flagged, S->seg_cnt)
         ScoreSrc S_rest;
         const bool pairs = p->seq_mode == 2;
         if (S->cursor && pass == 0 && key64 && S->stride <= 384u && !getenv("MTB_NO_FAST_SCORER") && !(pairs && getenv("MTB_NO_FAST_PAIRS"))) {
@@ -754,38 +763,45 @@ static mtb_status dev_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, uint
  * Reads it cannot take (LDS budgets) are flagged and scored by the generic slab launch of dev_score afterwards. */
 static mtb_status dev_score_long(mtb_ctx *c, mtb_index *ix, const mtb_params *p, uint64_t n_reads, const int32_t *d_qlen, const int32_t *d_qlen2,
                                  uint32_t max_len, mtb_result *d_res, int32_t *d_tc_tax, uint32_t *d_tc_cnt, uint64_t tc_cap, uint64_t *n_tc,
-                                 uint64_t tc_base, const mtb_match *d_m, const uint64_t *d_seg, uint32_t max_seg) {
+                                 uint64_t tc_base, const mtb_match *d_m, const uint64_t *d_seg, uint32_t max_seg, const uint32_t *d_segcnt = nullptr,
+                                 const uint32_t *d_list = nullptr, uint32_t n_list = 0 /* only these reads; segments indexed by the list slot; taxcnt slots as laid out by a previous call */) {
     mtb_score_params sp; mtb_make_score_params(p, &sp);
     uint32_t *d_bound; uint64_t *d_tcoff; uint64_t *d_ws; uint8_t *d_todo;
     STCHK(ensure(c, "bound", n_reads, &d_bound));
     STCHK(ensure(c, "tcoff", n_reads + 1, &d_tcoff));
     STCHK(ensure(c, "scanws", scan_ws_elems(n_reads + 1), &d_ws));
     STCHK(ensure(c, "slowflag", n_reads, &d_todo));
-    hipLaunchKernelGGL(k_taxcnt_bound, dim3((uint32_t)((n_reads + 63) / 64)), dim3(64), 0, c->stream, d_seg, (const uint32_t *)nullptr, d_qlen, d_qlen2,
-                       n_reads, sp.dna_shift, d_bound);
-    { KTimer kt(c, MTB_K_SCAN); scan_launch<uint32_t, uint64_t, false>(c->stream, d_bound, n_reads, true, d_tcoff, d_ws); }
-    uint64_t tot = 0;
-    STCHK(d2h(c, &tot, d_tcoff + n_reads, 8));
-    *n_tc = tot;
-    if (tot > tc_cap) return fail(MTB_ERR_CAPACITY, "taxcnt buffers too small");
-    if (tc_base + tot >= (1ull << 32)) return fail(MTB_ERR_ARG, "more than 2^32-1 taxcnt slots in one batch (mtb_result.taxcnt_off is 32 bits); split the batch");
-    const uint32_t max_nb = (uint32_t)mtb_num_buckets((int32_t)max_len, sp.dna_shift);
-    if (max_nb > 65535u) return fail(MTB_ERR_ARG, "read too long for mtb_result.n_taxcnt (16 bits): more than 65535 position buckets");
+    if (!d_list) {
+        /* per-read taxcnt slots: one per position bucket (slot ranges: the match count is not known yet), else min(matches, buckets) */
+        hipLaunchKernelGGL(k_taxcnt_bound, dim3((uint32_t)((n_reads + 63) / 64)), dim3(64), 0, c->stream, d_seg, d_segcnt, d_qlen, d_qlen2,
+                           n_reads, sp.dna_shift, d_bound);
+        { KTimer kt(c, MTB_K_SCAN); scan_launch<uint32_t, uint64_t, false>(c->stream, d_bound, n_reads, true, d_tcoff, d_ws); }
+        uint64_t tot = 0;
+        STCHK(d2h(c, &tot, d_tcoff + n_reads, 8));
+        *n_tc = tot;
+        if (tot > tc_cap) return fail(MTB_ERR_CAPACITY, "taxcnt buffers too small");
+        if (tc_base + tot >= (1ull << 32)) return fail(MTB_ERR_ARG, "more than 2^32-1 taxcnt slots in one batch (mtb_result.taxcnt_off is 32 bits); split the batch");
+        const uint32_t max_nb = (uint32_t)mtb_num_buckets((int32_t)max_len, sp.dna_shift);
+        if (max_nb > 65535u) return fail(MTB_ERR_ARG, "read too long for mtb_result.n_taxcnt (16 bits): more than 65535 position buckets");
+    }
     HIPCHK(hipMemsetAsync(d_todo, 0, n_reads, c->stream));
     unsigned long long *d_work = (unsigned long long *)(c->d_xscal + 6);
     HIPCHK(hipMemsetAsync(d_work, 0, 8, c->stream));
     HIPCHK(hipMemsetAsync(c->d_scal + 6, 0, 8, c->stream));
     {   KTimer kt(c, MTB_K_SCORE_FAST);       /* booked with the register-resident scorer's id: the workgroup-per-read kernel of long reads */
-        const uint32_t grid = (uint32_t)std::min<uint64_t>(n_reads, 256ull * 3);
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(d_list ? n_list : n_reads, 256ull * 3);
         hipLaunchKernelGGL(k_score_long, dim3(grid), dim3(MTB_LONG_NT), 0, c->stream, d_m, d_seg, n_reads, d_qlen, d_qlen2, tax_view(ix), sp, (const uint64_t *)d_tcoff,
-                           d_res, d_tc_tax, d_tc_cnt, tc_cap, tc_base, d_todo, d_work); }
+                           d_res, d_tc_tax, d_tc_cnt, tc_cap, tc_base, d_todo, d_work, d_segcnt, d_list, n_list); }
     hipLaunchKernelGGL(k_count_flags, dim3(256), dim3(256), 0, c->stream, (const uint8_t *)d_todo, n_reads, (unsigned long long *)(c->d_scal + 6));
     HIPCHK(hipGetLastError());
     uint64_t n_left = 0;
     STCHK(d2h(c, &n_left, c->d_scal + 6, 8));
     c->fast_used = true;                      /* statistics: d_scal[6] = reads the generic kernel scores */
     if (n_left == 0) return MTB_OK;
-    ScoreSrc a; a.m = d_m; a.seg = d_seg; a.sort = false; a.max_seg = std::max<uint32_t>(max_seg, MTB_SCORE_LDS + 1); a.only_flagged = d_todo;
+    ScoreSrc a; a.m = d_m; a.seg = d_seg; a.sort = false; a.max_seg = std::max<uint32_t>(max_seg, MTB_SCORE_LDS + 1); a.only_flagged = d_todo; a.seg_cnt = d_segcnt;
+    a.bound_by_buckets = d_segcnt ? (const void *)d_segcnt : (const void *)d_list;      /* the same taxcnt layout as above */
+    uint32_t *d_nl = nullptr;
+    if (d_list) { STCHK(ensure(c, "lnlist", 2, &d_nl)); STCHK(h2d(c, d_nl, &n_list, 4)); a.list = d_list; a.n_list = d_nl; a.seg_by_list = 1; }
     uint64_t n_tc2 = 0;
     STCHK(dev_score(c, ix, p, n_reads, d_qlen, d_qlen2, max_len, d_res, d_tc_tax, d_tc_cnt, tc_cap, &n_tc2, tc_base, a, nullptr));
     HIPCHK(hipMemsetAsync(c->d_scal + 6, 0, 8, c->stream));         /* dev_score's statistics slot: put the count back */
@@ -1385,11 +1401,16 @@ static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, c
      * first match.  Needs positions < 2^12 (16-byte slot records) and a moderate number of metamers per read; otherwise
      * exact segments. */
     bool fixed = p->seq_mode != 3;
+    /* long reads: ordinal slots too, with per-read slot ranges (k_join_dir<.., LONG>, kernels_seg_order.h) -- needs the directory join,
+     * positions and ordinals below 2^16; otherwise (and after a failed attempt) exact segments via regroup + segment sort */
+    bool lslot = p->seq_mode == 3 && ix->d_dir && !c->no_lslot && !getenv("MTB_NO_LONG_SLOTS");
+    uint32_t *d_dcnt = nullptr;
+    if (lslot) { STCHK(ensure(c, "dcnt", n_reads, &d_dcnt)); HIPCHK(hipMemsetAsync(d_dcnt, 0, n_reads * 4, st)); }
     uint16_t *d_dig = nullptr;               /* first radix pass's digits, written by the single-pass extractor */
     const bool aa6 = p->kmer_format == 2;           /* 5-bit amino-acid letters: three base-21 pair passes order bits [34,64) */
-    STCHK(dev_extract(c, p, d_bases, d_offs, d_bases2, d_offs2, n_reads, &d_k, &nk, d_ql, d_ql2, &max_len, true, n_bases_total, &nk_real, fixed, &max_q, aa6 ? &d_dig : nullptr));
-    if (fixed && (max_len + 3 >= MTB_SLOT_MAX_POS || max_q > 384)) {
-        fixed = false;                     /* tags would collide with positions / segments would be huge: extract again untagged */
+    STCHK(dev_extract(c, p, d_bases, d_offs, d_bases2, d_offs2, n_reads, &d_k, &nk, d_ql, d_ql2, &max_len, true, n_bases_total, &nk_real, fixed || lslot, &max_q, aa6 ? &d_dig : nullptr, d_dcnt));
+    if ((fixed && (max_len + 3 >= MTB_SLOT_MAX_POS || max_q > 384)) || (lslot && (max_len + 3 >= 65536u || max_q >= 65535u))) {
+        fixed = false; lslot = false;      /* tags would collide with positions / segments would be huge: extract again untagged */
         STCHK(dev_extract(c, p, d_bases, d_offs, d_bases2, d_offs2, n_reads, &d_k, &nk, d_ql, d_ql2, &max_len, true, n_bases_total, &nk_real, false, &max_q, aa6 ? &d_dig : nullptr));
     }
     HIPCHK(hipEventRecord(c->ev[1], st));
@@ -1491,6 +1512,93 @@ static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, c
         { KTimer kt(c, MTB_K_SCAN); scan_launch<uint32_t, uint64_t, false>(st, d_cnt, n_reads, true, d_tot, d_ws2); }
         STCHK(d2h(c, &nm, d_tot + n_reads, 8));
         nm += big_total;
+    } else if (lslot) {
+        /* ---- long reads on ordinal slots: join into per-read slot ranges, order every range by a stable species partition, score ---- */
+        uint32_t *d_sizes; uint64_t *d_rb, *d_ws2; uint32_t *d_live;
+        STCHK(ensure(c, "lsizes", n_reads, &d_sizes)); STCHK(ensure(c, "lrb", n_reads + 1, &d_rb)); STCHK(ensure(c, "scanws", scan_ws_elems(n_reads + 1), &d_ws2));
+        STCHK(ensure(c, "livecnt", n_reads, &d_live));
+        uint32_t *d_fail;
+        STCHK(ensure(c, "lfail", n_reads, &d_fail));
+        bool done = false;
+        for (uint32_t tf = 1; tf <= 4 && !done; tf *= 4) {            /* tail = a quarter of the read's metamers, then all of them */
+            hipLaunchKernelGGL(k_lslot_sizes, dim3((uint32_t)((n_reads + 255) / 256)), dim3(256), 0, st, (const uint32_t *)d_dcnt, n_reads, tf, d_sizes);
+            { KTimer kt(c, MTB_K_SCAN); scan_launch<uint32_t, uint64_t, false>(st, d_sizes, n_reads, true, d_rb, d_ws2); }
+            uint64_t n_slots = 0;
+            STCHK(d2h(c, &n_slots, d_rb + n_reads, 8));
+            mtb_slot16 *d_segm; mtb_match *d_m;
+            STCHK(ensure(c, "segm", n_slots, &d_segm));
+            c->seg_epoch = MTB_SLOT_EPOCHS;                           /* (a later short-read batch starts from a cleared buffer) */
+            HIPCHK(hipMemsetAsync(d_segm, 0, n_slots * sizeof(mtb_slot16), st));
+            HIPCHK(hipMemsetAsync(d_rc, 0, n_reads * 4, st));
+            JoinSegArgs sa; memset(&sa, 0, sizeof(sa));
+            sa.seg = d_segm; sa.cursor = d_rc; sa.rb = d_rb; sa.dcnt = d_dcnt; sa.tf = tf; sa.ovf = nullptr; sa.ovf_cap = 0;
+            uint64_t n_ovf = 0;
+            mtb_status s2 = dev_join(c, ix, d_s, nk, nullptr, 0, nullptr, &n_ovf, &sa, low_bits);
+            if (s2 == MTB_ERR_CAPACITY) {                              /* some read's tail overran: larger tails */
+                if (getenv("MTB_LSLOT_VERBOSE")) fprintf(stderr, "mtb: long-read slot path: %llu matches beyond the tails at tail factor %u/4\n", (unsigned long long)n_ovf, tf);
+                continue;
+            }
+            if (s2 != MTB_OK) return s2;
+            HIPCHK(hipEventRecord(c->ev[3], st));
+            STCHK(ensure(c, "matches", n_slots, &d_m));
+            HIPCHK(hipMemsetAsync(c->d_scal + 2, 0, 16, st));         /* [2] reads beyond the LDS tables, [3] matches of the range (incl. the dropped lonely ones) */
+            unsigned long long *d_work = (unsigned long long *)(c->d_xscal + 7);
+            HIPCHK(hipMemsetAsync(d_work, 0, 8, st));
+            { KTimer kt(c, MTB_K_SEGSORT);
+              hipLaunchKernelGGL(k_seg_order, dim3((uint32_t)std::min<uint64_t>(n_reads, 256ull * 2)), dim3(MTB_SO_NT), 0, st, (const mtb_slot16 *)d_segm, (const uint64_t *)d_rb,
+                                 (const uint32_t *)d_dcnt, (const uint32_t *)d_rc, tf, n_reads, d_m, d_live, (uint32_t *)(c->d_scal + 2), d_fail, d_work,
+                                 (unsigned long long *)(c->d_scal + 3)); }
+            HIPCHK(hipGetLastError());
+            uint64_t sc2[2] = {0, 0};
+            STCHK(d2h(c, sc2, c->d_scal + 2, 16));
+            if (getenv("MTB_LSLOT_VERBOSE")) fprintf(stderr, "mtb: long-read slot path: %llu reads, tail factor %u/4, %llu slots, %llu matches, %llu reads beyond the LDS tables (sorted the general way)\n",
+                                                     (unsigned long long)n_reads, tf, (unsigned long long)n_slots, (unsigned long long)sc2[1], (unsigned long long)(sc2[0] & 0xFFFFFFFFull));
+            const uint32_t n_failed = (uint32_t)(sc2[0] & 0xFFFFFFFFull);
+            /* reads beyond k_seg_order's LDS tables: their live slots -> exact segments, sorted the general way */
+            mtb_match *d_big = nullptr; uint64_t *d_bigstart = nullptr; uint32_t big_max = 0; uint64_t big_total = 0;
+            if (n_failed) {
+                uint32_t *d_bigcnt; mtb_match *d_scr; uint64_t mx = 0;
+                STCHK(ensure(c, "bigcnt", n_failed, &d_bigcnt)); STCHK(ensure(c, "bigstart", (uint64_t)n_failed + 1, &d_bigstart));
+                HIPCHK(hipMemsetAsync(c->d_scal + 4, 0, 8, st));
+                hipLaunchKernelGGL(k_lbig_count, dim3(std::min<uint32_t>(n_failed, 4096)), dim3(64), 0, st, (const mtb_slot16 *)d_segm, (const uint64_t *)d_rb, (const uint32_t *)d_dcnt,
+                                   (const uint32_t *)d_rc, tf, (const uint32_t *)d_fail, n_failed, d_bigcnt, (uint32_t *)(c->d_scal + 4));
+                scan_launch<uint32_t, uint64_t, false>(st, d_bigcnt, n_failed, true, d_bigstart, d_ws2);
+                STCHK(d2h(c, &big_total, d_bigstart + n_failed, 8));
+                STCHK(d2h(c, &mx, c->d_scal + 4, 8));
+                big_max = (uint32_t)mx;
+                STCHK(ensure(c, "bigm", big_total, &d_big)); STCHK(ensure(c, "jtemp", big_total, &d_scr));
+                hipLaunchKernelGGL(k_lbig_copy, dim3(std::min<uint32_t>(n_failed, 4096)), dim3(64), 0, st, (const mtb_slot16 *)d_segm, (const uint64_t *)d_rb, (const uint32_t *)d_dcnt,
+                                   (const uint32_t *)d_rc, tf, (const uint32_t *)d_fail, n_failed, (const uint64_t *)d_bigstart, d_big);
+                const size_t lds = (size_t)MTB_SEGLDS_CHUNK * 14;
+                HIPCHK(hipFuncSetAttribute((const void *)k_segsort_lds<mtb_match>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                { KTimer kt(c, MTB_K_SEGSORT);
+                  hipLaunchKernelGGL((k_segsort_lds<mtb_match>), dim3(std::min<uint32_t>(n_failed, 2048)), dim3(MTB_SEGLDS_THREADS), lds, st, d_big, (const uint64_t *)d_bigstart,
+                                     (const uint32_t *)nullptr, (const uint32_t *)(c->d_scal + 2), d_scr); }
+                HIPCHK(hipGetLastError());
+            }
+            HIPCHK(hipEventRecord(c->ev[4], st));
+            HIPCHK(hipEventRecord(c->ev[5], st));
+            STCHK(dev_score_long(c, ix, p, n_reads, d_ql, d_ql2, max_len, d_results, d_taxcnt_tax, d_taxcnt_cnt, taxcnt_cap, n_taxcnt, tc_base, d_m, d_rb, max_q + mtb_lslot_tail(max_q, tf), d_live));
+            uint64_t n_generic = 0;
+            if (n_failed) {
+                STCHK(d2h(c, &n_generic, c->d_scal + 6, 8));        /* reads the first launch left to the generic kernel */
+                uint64_t n_tc2 = 0;
+                STCHK(dev_score_long(c, ix, p, n_reads, d_ql, d_ql2, max_len, d_results, d_taxcnt_tax, d_taxcnt_cnt, taxcnt_cap, &n_tc2, tc_base, d_big, d_bigstart, big_max, nullptr, d_fail, n_failed));
+                uint64_t g2 = 0;
+                STCHK(d2h(c, &g2, c->d_scal + 6, 8));
+                n_generic = (n_generic & 0xFFFFFFFFull) + (g2 & 0xFFFFFFFFull);
+                STCHK(h2d(c, c->d_scal + 6, &n_generic, 8));
+            }
+            nm = sc2[1] + big_total;
+            done = true;
+        }
+        if (!done) {
+            /* redo this range without ordinal slots (tags stripped by a fresh extraction) */
+            c->no_lslot = true;
+            mtb_status s3 = classify_one(c, ix, p, d_bases, d_offs, d_bases2, d_offs2, n_reads, n_bases_total, d_results, d_taxcnt_tax, d_taxcnt_cnt, taxcnt_cap, n_taxcnt, tc_base);
+            c->no_lslot = false;
+            return s3;
+        }
     } else {
         /* ---- long reads: exact segments (temp buffer, per-read counters, scan, regroup) ---- */
         mtb_match *d_tmp;
@@ -1521,6 +1629,7 @@ static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, c
     S.n_reads = n_reads; S.n_bases = n_bases_total; S.n_kmers = nk_real; S.n_matches = nm; S.n_targets = ix->T;
     if (c->fast_used) { uint64_t ns = 0; STCHK(d2h(c, &ns, c->d_scal + 6, 8)); S.n_generic_reads = ns & 0xFFFFFFFFull; c->fast_used = false; }
     else S.n_generic_reads = n_reads;
+    S.n_slot_reads = (fixed || lslot) ? n_reads : 0;
     return MTB_OK;
 }
 
@@ -1528,7 +1637,7 @@ static void merge_stats(mtb_batch_stats &S, const mtb_batch_stats &L) {
     S.ms_extract += L.ms_extract; S.ms_sort += L.ms_sort; S.ms_join += L.ms_join; S.ms_regroup += L.ms_regroup;
     S.ms_segsort += L.ms_segsort; S.ms_score += L.ms_score;
     S.n_reads += L.n_reads; S.n_bases += L.n_bases; S.n_kmers += L.n_kmers; S.n_matches += L.n_matches; S.n_targets = L.n_targets;
-    S.n_generic_reads += L.n_generic_reads;
+    S.n_generic_reads += L.n_generic_reads; S.n_slot_reads += L.n_slot_reads;
     for (int i = 0; i < MTB_NUM_KERNELS; i++) { S.ms_kernel[i] += L.ms_kernel[i]; S.n_launch[i] += L.n_launch[i]; }
 }
 

@@ -315,6 +315,31 @@ MTB_HD mtb_slot16 mtb_slot_pack(uint64_t qinfo, int32_t target_id, int32_t speci
     return s;
 }
 MTB_HD uint32_t mtb_slot_epoch(const mtb_slot16 &s) { return (uint32_t)(s.b >> 59); }
+/* Long reads (positions < 2^16): the buffer is cleared for every batch and a written slot carries bit 63 of word a instead of an epoch.
+ *   a = 1[63] species[32..62] | target id[0..31]      b = hamming[59..62] frame[56..58] position[40..55] right_end_hamming[24..39] dna[0..23] */
+MTB_HD mtb_slot16 mtb_lslot_pack(uint64_t qinfo, int32_t target_id, int32_t species_id, uint32_t dna, uint32_t reh, uint32_t ham) {
+    mtb_slot16 s;
+    s.a = (1ull << 63) | ((uint64_t)((uint32_t)species_id & 0x7FFFFFFFu) << 32) | (uint32_t)target_id;
+    s.b = ((uint64_t)(ham & 15u) << 59) | ((uint64_t)(mtb_q_frame(qinfo) & 7u) << 56) | ((uint64_t)(mtb_q_pos(qinfo) & 0xFFFFu) << 40) |
+          ((uint64_t)(reh & 0xFFFFu) << 24) | (uint64_t)(dna & 0xFFFFFFu);
+    return s;
+}
+MTB_HD bool mtb_lslot_live(const mtb_slot16 &s) { return (s.a >> 63) != 0; }
+MTB_HD int32_t mtb_lslot_species(const mtb_slot16 &s) { return (int32_t)((s.a >> 32) & 0x7FFFFFFFu); }
+/* (frame, position, hamming, dna): compareMatches' order inside one species, 46 bits */
+MTB_HD uint64_t mtb_lslot_key(const mtb_slot16 &s) {
+    return (((s.b >> 56) & 7u) << 43) | (((s.b >> 40) & 0xFFFFu) << 27) | (((s.b >> 59) & 7u) << 24) | (s.b & 0xFFFFFFull);
+}
+MTB_HD mtb_match mtb_lslot_unpack(const mtb_slot16 &s, uint32_t seq_id) {
+    mtb_match m;
+    m.qinfo = mtb_qinfo(seq_id, (uint32_t)(s.b >> 40) & 0xFFFFu, (uint32_t)(s.b >> 56) & 7u);
+    m.target_id = (int32_t)(uint32_t)s.a; m.species_id = mtb_lslot_species(s);
+    m.dna = (uint32_t)s.b & 0xFFFFFFu; m.right_end_hamming = (uint16_t)((s.b >> 24) & 0xFFFFu);
+    m.hamming = (uint8_t)((s.b >> 59) & 15u); m.pad = 0;
+    return m;
+}
+/* slots of a long read with d metamers: d direct ones + a tail for the further matches of its queries (tf quarters of d, + 16) */
+MTB_HD uint32_t mtb_lslot_tail(uint32_t d, uint32_t tf) { return d ? (uint32_t)(((uint64_t)d * tf) >> 2) + 16u : 0u; }
 MTB_HD mtb_match mtb_slot_unpack(const mtb_slot16 &s, uint32_t seq_id) {
     mtb_match m;
     m.qinfo = mtb_qinfo(seq_id, (uint32_t)(s.b >> 40) & 0xFFFu, (uint32_t)(s.b >> 52) & 7u);

@@ -426,6 +426,32 @@ def test_borrowed_arrays_are_handed_back_flat(ctx, toy, monkeypatch):
     hip.free(dv); hip.free(di)
 
 
+def test_long_reads_on_ordinal_slots_and_on_exact_segments(toy, monkeypatch):
+    """Long reads (seq_mode 3): the directory join writes the first match of a read's ord-th metamer to slot ord of the read's own
+    slot range, k_seg_order turns the range into the read's segment in compareMatches order by a stable species partition + a rank
+    merge of the tail matches (matches that are alone in their species are dropped: they can never be part of a path), k_score_long
+    scores it.  With MTB_NO_LONG_SLOTS the same reads take regroup + segment sort.  Both must equal the oracle; the statistics say
+    which way the reads went."""
+    import metabuli_amd as M
+    if toy.p.seq_mode != 3:
+        pytest.skip("long-read modes only")
+    c = M.Context(0)
+    p = _params(toy)
+    ix = c.open_index(toy.dbdir, p)
+    res, tt, tc = c.classify_batch(ix, p, toy.b1, toy.o1, toy.b2, toy.o2)
+    _check_results(toy, res, tt, tc)
+    st = c.last_stats()
+    assert st.n_slot_reads == toy.n_reads and st.n_matches == len(toy.ref["matches"])
+    assert st.n_generic_reads <= toy.n_reads // 2          # (reads with more position buckets than k_score_long's LDS table take the generic kernel)
+    monkeypatch.setenv("MTB_NO_LONG_SLOTS", "1")
+    res2, tt2, tc2 = c.classify_batch(ix, p, toy.b1, toy.o1, toy.b2, toy.o2)
+    _check_results(toy, res2, tt2, tc2)
+    st = c.last_stats()
+    assert st.n_slot_reads == 0 and st.n_matches == len(toy.ref["matches"])
+    assert (res2["classification"] == res["classification"]).all() and (res2["score"].view(np.uint32) == res["score"].view(np.uint32)).all()
+    ix.close(); c.close()
+
+
 def test_foreign_sequence_ids_are_rejected(ctx):
     """caller-supplied match records whose sequenceID lies outside the batch are an argument error, not a wild write"""
     import metabuli_amd as M
