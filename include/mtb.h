@@ -278,21 +278,48 @@ mtb_status mtb_index_open_part(mtb_ctx *, const char *dbdir, const char *taxonom
 mtb_status mtb_index_slice(mtb_index *, uint64_t lo_value, uint64_t hi_value, int is_last,
                            mtb_index **out);
 /* *d_sorted (owned by the context, valid until its next call) = the batch's
- * metamers sorted by value; part_counts[p] = how many fall into range p
- * (consecutive runs).  Query lengths stay in the context for mtb_part_score. */
+ * metamers, sorted; run p = d_sorted[part_starts[p] .. + part_counts[p]) goes
+ * to the owner of range p.  part_starts == NULL: the runs are consecutive and
+ * the list is sorted on bits [24, 64) (five binary radix passes), matches come
+ * home through regroup + segment sort.  part_starts != NULL (what the host
+ * layers use): short reads take the product path of the fused batch -- ordinal
+ * tags in qinfo, three letter-pair passes, runs cut at prefix granularity so
+ * that NEIGHBOURING RUNS MAY OVERLAP by the metamers that share their prefix
+ * with a bound (the owner that does not hold their amino-acid group emits
+ * nothing for them); the owners join through their range's directory
+ * (k_join_dir, matches as a dense list with the ordinal kept in qinfo and
+ * pad = 1 on a query's first match) and mtb_part_score places the matches
+ * into this rank's slot segments and runs the slot scorers (k_score_fast ...).
+ * Query lengths / the batch's mode stay in the context for mtb_part_score.  */
 mtb_status mtb_part_extract(mtb_ctx *, const mtb_params *, const char *d_bases,
                             const uint64_t *d_offs, const char *d_bases2, const uint64_t *d_offs2,
                             uint64_t n_reads, const uint64_t *bounds, uint32_t n_parts,
-                            const mtb_kmer **d_sorted, uint64_t *n_kmers, uint64_t *part_counts);
+                            const mtb_kmer **d_sorted, uint64_t *n_kmers, uint64_t *part_counts,
+                            uint64_t *part_starts);
 /* one sorted run of metamers (from any rank) against this rank's range */
 mtb_status mtb_part_join(mtb_ctx *, mtb_index *, const mtb_kmer *d_kmers, uint64_t n,
                          mtb_match *d_out, uint64_t cap, uint64_t *count);
 /* all matches of this rank's reads, any order (d_matches is clobbered: it
- * becomes sort scratch); results / taxcnt arrays are host buffers.          */
+ * becomes sort scratch); results / taxcnt arrays are host buffers; the
+ * taxID:count lists arrive packed (taxcnt_off = running total), *n_taxcnt =
+ * entries written.  taxcnt_cap must hold one entry per position bucket of
+ * every read on the device side (MTB_ERR_CAPACITY + required size otherwise). */
 mtb_status mtb_part_score(mtb_ctx *, mtb_index *, const mtb_params *, mtb_match *d_matches,
                           uint64_t n_matches, uint64_t n_reads, mtb_result *results,
                           int32_t *taxcnt_tax, uint32_t *taxcnt_cnt, uint64_t taxcnt_cap,
                           uint64_t *n_taxcnt);
+
+/* The partitioned batch for a host that drives several GPUs from one process (mtb_classify --devices a,b,.. --partitioned 1):
+ * ctxs[k] / parts[k] = context and range k of n (mtb_index_open_part(ctxs[k], .., k, n, &parts[k])), bounds from
+ * mtb_index_part_bounds.  Host buffers in and out like mtb_classify_batch; the reads are cut into n contiguous shares, the
+ * two exchanges are device-to-device peer copies (KmerMatcher.cpp:157-205 lets threads start mid-stream from `split`
+ * checkpoints in one address space; here the ranges live in different HBMs).  Results in input order, every read's
+ * taxID:count entries at taxcnt_off, packed.  MTB_ERR_CAPACITY with *n_taxcnt = required entries if taxcnt_cap is too small. */
+mtb_status mtb_classify_batch_partitioned(mtb_ctx **ctxs, mtb_index **parts, uint32_t n, const uint64_t *bounds,
+                                          const mtb_params *, const char *bases, const uint64_t *offs,
+                                          const char *bases2, const uint64_t *offs2, uint64_t n_reads,
+                                          mtb_result *results, int32_t *taxcnt_tax, uint32_t *taxcnt_cnt,
+                                          uint64_t taxcnt_cap, uint64_t *n_taxcnt);
 
 /* ---- synthetic data on the device (bench / tests) ------
  * Builds a flat sorted target index of `n_filler` pseudo-random valid

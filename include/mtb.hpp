@@ -69,6 +69,11 @@ public:
         check(mtb_ctx_create(device, nullptr, &ctx));
         check(mtb_index_open(ctx, dbDir.c_str(), taxonomyDir.empty() ? nullptr : taxonomyDir.c_str(), &par, &index));
     }
+    /* range `part` of `n_parts` of a database larger than one HBM (mtb_index_open_part) */
+    Engine(int device, const std::string &dbDir, const std::string &taxonomyDir, LocalParameters &par, uint32_t part, uint32_t n_parts) {
+        check(mtb_ctx_create(device, nullptr, &ctx));
+        check(mtb_index_open_part(ctx, dbDir.c_str(), taxonomyDir.empty() ? nullptr : taxonomyDir.c_str(), &par, part, n_parts, &index));
+    }
     ~Engine() { mtb_index_close(index); mtb_ctx_destroy(ctx); }
     mtb_ctx *ctx = nullptr;
     mtb_index *index = nullptr;

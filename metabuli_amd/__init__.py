@@ -265,15 +265,19 @@ class Context:
                                         C.byref(params), C.c_uint32(part), C.c_uint32(n_parts), C.byref(h)))
         return Index(self, h)
 
-    def part_extract(self, params, d_bases, d_offs, d_bases2, d_offs2, n_reads, bounds):
-        """-> (device pointer of the sorted metamers (owned by the context), n_kmers, counts per partition)"""
+    def part_extract(self, params, d_bases, d_offs, d_bases2, d_offs2, n_reads, bounds, overlapping=True):
+        """-> (device pointer of the sorted metamers (owned by the context), n_kmers, counts per partition, starts per partition).
+        overlapping=False: the legacy consecutive runs (full sort on bits [24, 64), exact-segment scoring at home)."""
         b = np.ascontiguousarray(bounds, dtype=np.uint64)
         ptr = C.c_void_p(); nk = C.c_uint64()
-        counts = np.zeros(len(b), np.uint64)
+        counts = np.zeros(len(b), np.uint64); starts = np.zeros(len(b), np.uint64)
         _chk(self.L.mtb_part_extract(self.h, C.byref(params), C.c_void_p(d_bases), C.c_void_p(d_offs),
                                      C.c_void_p(d_bases2) if d_bases2 else None, C.c_void_p(d_offs2) if d_offs2 else None,
-                                     C.c_uint64(n_reads), _p(b), C.c_uint32(len(b)), C.byref(ptr), C.byref(nk), _p(counts)))
-        return ptr.value or 0, nk.value, counts
+                                     C.c_uint64(n_reads), _p(b), C.c_uint32(len(b)), C.byref(ptr), C.byref(nk), _p(counts),
+                                     _p(starts) if overlapping else None))
+        if not overlapping:
+            starts[1:] = np.cumsum(counts)[:-1]
+        return ptr.value or 0, nk.value, counts, starts
 
     def part_join(self, index, d_kmers, n, d_out, cap):
         """-> (status, count); status MTB_ERR_CAPACITY means `count` entries are needed"""
@@ -284,10 +288,10 @@ class Context:
         return st, cnt.value
 
     def part_score(self, index, params, d_matches, n_matches, n_reads):
-        res = np.zeros(n_reads, result_dt)
-        cap = max(1024, 64 * n_reads)
+        res = np.empty(n_reads, result_dt)
+        cap = max(1024, 24 * n_reads + 4096)        # one slot per position bucket (18 for a 150 bp read); more -> exact retry
         while True:
-            tt = np.zeros(cap, np.int32); tc = np.zeros(cap, np.uint32)
+            tt = np.empty(cap, np.int32); tc = np.empty(cap, np.uint32)      # (never zero-filled: 64 slots x 8 bytes x 2 M reads were 1 GB of memset per call)
             n = C.c_uint64()
             st = self.L.mtb_part_score(self.h, index.h, C.byref(params), C.c_void_p(d_matches), C.c_uint64(n_matches),
                                        C.c_uint64(n_reads), _p(res), _p(tt), _p(tc), C.c_uint64(cap), C.byref(n))
@@ -295,7 +299,7 @@ class Context:
                 cap = n.value
                 continue
             _chk(st)
-            return compact_taxcnt(res, tt, tc)
+            return res, tt[:n.value], tc[:n.value]          # the library packs the lists on the device (taxcnt_off = running total)
 
     def join_footprint(self, index):
         """index-side working set of the last fused batch's directory join (mtb_ctx_join_footprint; diagnostic)"""

@@ -24,7 +24,9 @@
  *          reads), and <base>_classifications.tsv / <base>_report.tsv; <base> = LocalUtil::getQueryBaseName (LocalUtil.cpp:5-20).
  *          (In the reference snapshot the match loop of filterReads is stubbed out, QueryFilter.cpp:172-175, so it keeps every
  *          read; this implements the documented behaviour of the command.)
- *   own flags: --max-reads N (host batch)  --device N | --devices 0,1,... (one engine per GPU: every host batch is cut into
+ *   own flags: --max-reads N (host batch)  --partitioned 1 (with --devices: engine d holds value range d of the database -- for
+ *          databases larger than one GPU's HBM; metamers and matches are exchanged between the GPUs)
+ *          --device N | --devices 0,1,... (one engine per GPU: every host batch is cut into
  *          contiguous read ranges, one per device, classified concurrently, results concatenated in input order and
  *          the per-taxon counts summed -- reads are independent, Classifier.cpp:187-203)
  */
@@ -215,7 +217,7 @@ int main(int argc, char **argv) {
     mtb_params par; mtb_default_params(&par);
     std::string taxdir; std::vector<int> devices(1, 0); size_t max_reads = 2000000;
     int threads = (int)std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
-    bool lineage = false, filter = false, min_score_given = false; int print_mode = 1;
+    bool lineage = false, filter = false, min_score_given = false, partitioned = false; int print_mode = 1;
     std::vector<std::string> pos;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -235,6 +237,7 @@ int main(int argc, char **argv) {
         else if (a == "--smer-len") par.smer_len = atoi(val().c_str());
         else if (a == "--max-reads") max_reads = (size_t)atoll(val().c_str());
         else if (a == "--device") { devices.assign(1, atoi(val().c_str())); }
+        else if (a == "--partitioned") partitioned = atoi(val().c_str()) != 0;
         else if (a == "--devices") { devices.clear(); std::stringstream ss(val()); std::string tok; while (std::getline(ss, tok, ',')) if (!tok.empty()) devices.push_back(atoi(tok.c_str())); }
         else if (a == "--reduced-aa") { if (atoi(val().c_str()) != 0) { fprintf(stderr, "mtb_classify: --reduced-aa 1 is not implemented\n"); return 1; } }
         else if (a == "--mask") {       /* tantan masking of the reads before extraction (KmerExtractor.cpp:308-314) changes the answers: refuse it rather than ignore it */
@@ -266,9 +269,13 @@ int main(int argc, char **argv) {
         if (devices.empty()) throw std::runtime_error("--devices: empty list");
         /* one engine (context + resident copy of the index) per GPU; db.parameters overrides the flags (common.cpp:88-133) */
         std::vector<std::unique_ptr<mtb::Engine>> engs;
+        std::vector<uint64_t> bounds(devices.size(), 0);
+        if (partitioned) mtb::check(mtb_index_part_bounds(dbdir.c_str(), (uint32_t)devices.size(), bounds.data()));
         for (size_t d = 0; d < devices.size(); d++) {
             mtb_params pd = par;
-            engs.emplace_back(new mtb::Engine(devices[d], dbdir, taxdir, d == 0 ? par : pd));
+            /* --partitioned 1: engine d holds range d of the database (databases larger than one HBM) */
+            if (partitioned) engs.emplace_back(new mtb::Engine(devices[d], dbdir, taxdir, d == 0 ? par : pd, (uint32_t)d, (uint32_t)devices.size()));
+            else engs.emplace_back(new mtb::Engine(devices[d], dbdir, taxdir, d == 0 ? par : pd));
         }
         mtb::Engine &eng = *engs[0];                          /* taxonomy services for formatting */
         const size_t ND = engs.size();
@@ -370,6 +377,30 @@ int main(int argc, char **argv) {
                     break;
                 }
             };
+            if (partitioned) {
+                /* every engine owns a value range: its share of the reads is extracted there, the sorted metamers travel to the range
+                 * owners and the matches back (peer copies inside the library), rows come back in input order */
+                std::vector<mtb_ctx *> cs(ND); std::vector<mtb_index *> is(ND);
+                for (size_t d = 0; d < ND; d++) { cs[d] = engs[d]->ctx; is[d] = engs[d]->index; }
+                Range &R = rg[0];
+                mtb_params pd = par;
+                size_t cap = 8 * n + 4096;
+                for (;;) {
+                    R.tt.resize_uninit(cap); R.tc.resize_uninit(cap);
+                    mtb_status st = mtb_classify_batch_partitioned(cs.data(), is.data(), (uint32_t)ND, bounds.data(), &pd, j->r1.bases.data(), j->r1.offs.data(),
+                                                                   paired ? j->r2.bases.data() : nullptr, paired ? j->r2.offs.data() : nullptr, n,
+                                                                   j->res.data(), R.tt.data(), R.tc.data(), cap, &R.ntc);
+                    if (st == MTB_ERR_CAPACITY && R.ntc > cap) { cap = R.ntc; continue; }
+                    if (st != MTB_OK) R.err = mtb_last_error();
+                    break;
+                }
+                if (R.err.empty()) { j->tt = std::move(R.tt); j->tc = std::move(R.tc); }
+                for (size_t d = 1; d < ND; d++) rg[d].ntc = 0;
+                if (!R.err.empty()) gpu_err = R.err;
+                t_gpu += now() - t0;
+                if (gpu_err.empty()) scored.put(std::move(j));
+                continue;
+            }
             if (ND == 1) run(0);
             else { std::vector<std::thread> th; for (size_t d = 0; d < ND; d++) th.emplace_back(run, d); for (auto &x : th) x.join(); }
             uint64_t tot_tc = 0;

@@ -122,10 +122,13 @@ __global__ __launch_bounds__(256) void k_index_unpack(uint64_t *__restrict__ val
 #define MTB_JOIN_DIR_QPT 2
 #endif
 
-template <bool PACKED, bool LONG = false>
+/* MODE 0: slot segments of fixed stride (short reads); 1: per-read slot ranges (long reads); 2: dense list of Match records
+ * (owner side of the range-partitioned index: the home rank of the read places them into ITS slot segments, k_slot_place) */
+template <bool PACKED, int MODE = 0>
 __global__ __launch_bounds__(256) void k_join_dir(const mtb_kmer *__restrict__ q, uint64_t n, mtb_index_view ix, uint64_t limit, mtb_dir_view dv,
                                                    const mtb_tables *__restrict__ tabs, JoinSegArgs sa, uint32_t *__restrict__ overflow) {
     constexpr int Q = MTB_JOIN_DIR_QPT;
+    constexpr bool LONG = MODE == 1, LIST = MODE == 2;
     const uint64_t AAM = ~0xFFFFFFull;
     __shared__ uint32_t s_hr[8];                    /* hammingLookup rows as nibble words: the only table the join arithmetic reads */
     if (threadIdx.x < 8) s_hr[threadIdx.x] = tabs->hamrow[threadIdx.x];
@@ -206,6 +209,58 @@ __global__ __launch_bounds__(256) void k_join_dir(const mtb_kmer *__restrict__ q
                 more |= lo[u] < hi[u];
             }
         }
+    }
+    if (LIST) {
+        /* dense list (owner side of the partitioned index): count the selected candidates of the thread's queries, one workgroup
+         * scan, ONE atomic per workgroup for the output range, then emit (a per-match atomic on the list's single counter cost
+         * 65 ms per 217 M matches, measured).  A record keeps its query's qinfo (ordinal tag included); pad = 1 on the query's
+         * first match = the one that owns the ordinal slot at the read's home rank. */
+        __shared__ uint32_t s_scan[8]; __shared__ unsigned long long s_base;
+        uint64_t rs[Q], re[Q]; uint32_t thr_[Q], cnt[Q]; uint32_t tot_c = 0;
+#pragma unroll
+        for (int u = 0; u < Q; u++) {
+            rs[u] = 0; re[u] = 0; thr_[u] = 0; cnt[u] = 0;
+            if (!valid[u]) continue;
+            const uint64_t s0 = lo[u], end = e_hi[u];
+            const uint64_t aa = qkey(k[u].value);
+            if (s0 >= end) continue;
+            const uint64_t v0 = ix.values[s0];
+            if (tkey(v0) != aa) continue;
+            mtb_qrows qr; mtb_prepare_query_rows(s_hr, k[u].value, &qr);
+            uint32_t mn = mtb_ham_sum(&qr, (uint32_t)v0 & 0xFFFFFFu);
+            uint64_t e = s0 + 1;
+            while (e < end) { const uint64_t v = ix.values[e]; if (tkey(v) != aa) break; const uint32_t h = mtb_ham_sum(&qr, (uint32_t)v & 0xFFFFFFu); mn = h < mn ? h : mn; e++; }
+            const uint32_t thr = mtb_ham_threshold(mn);
+            uint32_t c = 0;
+            for (uint64_t t = s0; t < e; t++) { const uint64_t v = t == s0 ? v0 : ix.values[t]; c += mtb_ham_sum(&qr, (uint32_t)v & 0xFFFFFFu) <= thr ? 1u : 0u; }
+            rs[u] = s0; re[u] = e; thr_[u] = thr; cnt[u] = c; tot_c += c;
+        }
+        uint32_t tot;
+        const uint32_t off = block256_exclusive_scan<uint32_t>(tot_c, s_scan, &tot);
+        if (threadIdx.x == 0) s_base = tot ? atomicAdd(sa.ovf_counter, (unsigned long long)tot) : 0ull;
+        __syncthreads();
+        unsigned long long o = s_base + off;
+#pragma unroll
+        for (int u = 0; u < Q; u++) {
+            if (cnt[u] == 0) continue;
+            mtb_qrows qr; mtb_prepare_query_rows(s_hr, k[u].value, &qr);
+            const bool rev = mtb_hammings_reversed(mtb_q_frame(k[u].qinfo), ix.kmer_format);
+            bool first = true;
+            for (uint64_t t = rs[u]; t < re[u]; t++) {
+                const uint64_t v = ix.values[t];
+                const uint32_t td = (uint32_t)v & 0xFFFFFFu;
+                const uint32_t h = mtb_ham_sum(&qr, td);
+                if (h > thr_[u]) continue;
+                if (o < sa.ovf_cap) {
+                    const int32_t tid = (int32_t)((PACKED ? (uint32_t)(v >> MTB_PACK_LOW) : ix.info[t]) & ix.info_mask);
+                    mtb_match m; m.qinfo = k[u].qinfo; m.target_id = tid; m.species_id = (tid >= 0 && tid <= ix.max_taxid) ? ix.tax2species[tid] : 0;
+                    m.dna = td; m.right_end_hamming = mtb_hammings(&qr, td, rev); m.hamming = (uint8_t)h; m.pad = first ? 1 : 0;
+                    sa.ovf[o] = m;
+                }
+                o++; first = false;
+            }
+        }
+        return;
     }
     const uint32_t tail_cap = sa.stride - sa.direct;
 #pragma unroll

@@ -71,6 +71,7 @@ struct JoinSegArgs {
     /* long reads (k_join_dir<.., LONG>): read r owns slots [rb[r], rb[r + 1]) = dcnt[r] direct ones (one per metamer, by ordinal)
      * + mtb_lslot_tail(dcnt[r], tf) tail slots; matches beyond the tail are only counted (the caller retries with a larger tail) */
     const uint64_t *rb; const uint32_t *dcnt; uint32_t tf;
+    uint32_t list;      /* k_join_dir<.., 2>: matches go to the dense list ovf[0 .. ovf_cap) (owner side of the partitioned index) */
 };
 
 #ifdef MTB_SCORE_PHASE_CYCLES
@@ -265,6 +266,34 @@ __global__ __launch_bounds__(256) void k_big_ovf(const mtb_match *__restrict__ o
     uint32_t b = bigidx[mtb_q_seq(m.qinfo) - 1];
     uint32_t slot = atomicAdd(&bigcur[b], 1u);
     big[big_start[b] + slot] = m;
+}
+
+/* Home side of the range-partitioned index: matches that came back from the range owners (k_join_dir<.., 2>: qinfo still carries the
+ * query's ordinal, pad = 1 for the query's first match) -> this rank's slot segments, exactly as the fused join fills them:
+ * first match to slot `ord`, the others to the read's tail (returning atomic on its cursor), beyond that to the overflow list. */
+__global__ __launch_bounds__(256) void k_slot_place(const mtb_match *__restrict__ in, uint64_t n, JoinSegArgs sa, uint64_t n_reads, uint32_t *__restrict__ bad) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const mtb_match m = in[i];
+    const uint32_t seq = mtb_q_seq(m.qinfo);
+    if (seq == 0 || seq > n_reads) { *bad = 1; return; }
+    const uint32_t r = seq - 1, ord = mtb_q_pos(m.qinfo) >> 16;
+    const uint64_t qinfo = m.qinfo & ~0xFFFF0000ull;
+    mtb_slot16 *seg = sa.seg + (uint64_t)r * sa.stride;
+    if ((m.pad & 1u) && ord < sa.direct) {
+        const mtb_slot16 sl = mtb_slot_pack(qinfo, m.target_id, m.species_id, m.dna, m.right_end_hamming, m.hamming, sa.epoch);
+        __builtin_nontemporal_store(sl.a, &seg[ord].a); __builtin_nontemporal_store(sl.b, &seg[ord].b);
+        return;
+    }
+    const uint32_t tail_cap = sa.stride - sa.direct;
+    const uint32_t at = atomicAdd(&sa.cursor[r], 1u);
+    if (at < tail_cap) {
+        const mtb_slot16 sl = mtb_slot_pack(qinfo, m.target_id, m.species_id, m.dna, m.right_end_hamming, m.hamming, sa.epoch);
+        __builtin_nontemporal_store(sl.a, &seg[sa.direct + at].a); __builtin_nontemporal_store(sl.b, &seg[sa.direct + at].b);
+    } else {
+        const unsigned long long o = atomicAdd(sa.ovf_counter, 1ull);
+        if (o < sa.ovf_cap) { mtb_match x = m; x.qinfo = qinfo; x.pad = 0; sa.ovf[o] = x; }
+    }
 }
 
 /* Move every match into its read's segment (seg_start from a scan of the

@@ -76,6 +76,7 @@ struct mtb_ctx {
     uint32_t seg_epoch = 0;          /* tag of the live slots in the "segm" buffer (1..MTB_SLOT_EPOCHS) */
     double extract_yield = 0.0;      /* metamers per base of the previous batch (single-pass extraction buffer sizing) */
     uint64_t part_n_reads = 0; uint32_t part_max_len = 0;   /* batch state between mtb_part_extract and mtb_part_score */
+    int part_mode = 0; uint32_t part_max_q = 0; uint64_t part_nk_real = 0;      /* part_mode 1: the batch's metamers carry ordinals, the matches come home into slot segments */
     uint64_t ws_limit = 0;           /* workspace budget of a batch in bytes; 0 = what hipMemGetInfo reports free (+ what the context holds) */
     double ws_per_base = 0.0;        /* workspace bytes per base: what the buffers hold / the largest sub-batch they were grown for (HBM-budgeted batching) */
     uint64_t ws_max_sub_bases = 0;   /* bases of the largest sub-batch since the workspace was last released */
@@ -216,7 +217,12 @@ static mtb_status ensure_placed(mtb_ctx *c, const char *name, size_t elems, mtb_
     struct Cand { void *p; float ms; size_t bytes; };
     std::vector<Cand> held;                 /* the best candidate so far + rejected ones kept allocated so that the next one lands elsewhere */
     std::vector<float> seen; std::vector<void *> seen_p, pads; std::vector<size_t> sizes;
-    hipEvent_t e0, e1;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    struct Guard {                          /* every early return (a failing HIP call below) hands the candidates, the pads and the events back */
+        std::vector<Cand> &held; std::vector<void *> &pads; hipEvent_t &e0, &e1; bool armed = true;
+        ~Guard() { if (!armed) return; for (auto &h : held) { hipError_t e = hipFree(h.p); (void)e; } for (void *q : pads) { hipError_t e = hipFree(q); (void)e; }
+                   if (e0) { hipError_t e = hipEventDestroy(e0); (void)e; } if (e1) { hipError_t e = hipEventDestroy(e1); (void)e; } }
+    } guard{held, pads, e0, e1};
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     for (int attempt = 0; attempt < 8; attempt++) {
         if (attempt >= 2 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() > 2.0) break;      /* one-time cost, bounded */
@@ -254,6 +260,7 @@ static mtb_status ensure_placed(mtb_ctx *c, const char *name, size_t elems, mtb_
         float hi = 0.0f; for (float v : seen) hi = std::max(hi, v);
         if (seen.size() >= 4 && near >= 2 && lo <= 0.9f * hi) break;   /* ... and clearly better than the worst one seen */
     }
+    guard.armed = false;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     for (void *q : pads) { hipError_t e = hipFree(q); (void)e; }
     if (held.empty()) return ensure(c, name, elems, out);              /* not even one candidate fitted: the plain path reports the error */
@@ -370,7 +377,8 @@ static mtb_status dev_extract(mtb_ctx *c, const mtb_params *p, const char *d_bas
                               const uint64_t *d_offs2, uint64_t n_reads, mtb_kmer **out, uint64_t *count, int32_t *d_qlen,
                               int32_t *d_qlen2, uint32_t *max_len, bool single_pass = false, uint64_t n_bases = 0,
                               uint64_t *real_count = nullptr, bool tag_ord = false, uint32_t *max_q = nullptr, uint16_t **dig = nullptr,
-                              uint32_t *d_counts = nullptr /* single pass: metamers per read (long-read slot path) */) {
+                              uint32_t *d_counts = nullptr /* single pass: metamers per read (long-read slot path) */,
+                              uint64_t *n_bases_exact = nullptr /* single pass: bases of the read range, from its offsets */) {
     if (n_reads >= (1ull << 29)) return fail(MTB_ERR_ARG, "more than 2^29-1 reads per batch (sequenceID is 29 bits, Kmer.h:13)");
     if (p->kmer_format != 1 && p->kmer_format != 2) return fail(MTB_ERR_UNSUPPORTED, "only kmer_format 1 and 2 are implemented");
     if (p->syncmer && (p->smer_len < 1 || p->smer_len > 8)) return fail(MTB_ERR_ARG, "smer_len out of range");
@@ -387,6 +395,7 @@ static mtb_status dev_extract(mtb_ctx *c, const mtb_params *p, const char *d_bas
         STCHK(d2h(c, &o[0], d_offs, 8)); STCHK(d2h(c, &o[1], d_offs + n_reads, 8));
         n_bases = o[1] - o[0];
         if (p->seq_mode == 2 && d_offs2) { STCHK(d2h(c, &o[0], d_offs2, 8)); STCHK(d2h(c, &o[1], d_offs2 + n_reads, 8)); n_bases += o[1] - o[0]; }
+        if (n_bases_exact) *n_bases_exact = n_bases;
     }
     if (single_pass && n_bases) {
         /* six frames x L/3 windows bound the output by 2 metamers per base; syncmer selection keeps about half of them:
@@ -583,9 +592,13 @@ static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint6
         KTimer kt(c, MTB_K_JOIN);
         JoinSegArgs sa = *seg; sa.ovf_counter = (unsigned long long *)c->d_scal;
         const uint32_t g2 = (uint32_t)((n + 256 * MTB_JOIN_DIR_QPT - 1) / (256 * MTB_JOIN_DIR_QPT));
+        if (sa.list) {      /* owner side of the partitioned index: a dense list of Match records */
+            if (state_owner(ix)->packed) hipLaunchKernelGGL((k_join_dir<true, 2>), dim3(g2), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1));
+            else hipLaunchKernelGGL((k_join_dir<false, 2>), dim3(g2), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1));
+        } else
         if (sa.rb) {        /* long reads: per-read slot ranges */
-            if (state_owner(ix)->packed) hipLaunchKernelGGL((k_join_dir<true, true>), dim3(g2), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1));
-            else hipLaunchKernelGGL((k_join_dir<false, true>), dim3(g2), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1));
+            if (state_owner(ix)->packed) hipLaunchKernelGGL((k_join_dir<true, 1>), dim3(g2), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1));
+            else hipLaunchKernelGGL((k_join_dir<false, 1>), dim3(g2), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1));
         } else
         if (state_owner(ix)->packed) hipLaunchKernelGGL((k_join_dir<true>), dim3(g2), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1));
         else hipLaunchKernelGGL((k_join_dir<false>), dim3(g2), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1));
@@ -1068,6 +1081,9 @@ void mtb_index_close(mtb_index *ix) {
     hipError_t e = hipSuccess;
     if (ix->parent) {                /* a view: the parent may be packed again once the last view is gone */
         { std::lock_guard<std::mutex> lk(ix->parent->state_mu); ix->parent->views--; }
+        if (ix->d_dir) e = hipFree(ix->d_dir);
+        if (ix->d_dirbase) e = hipFree(ix->d_dirbase);
+        (void)e;
         delete ix; return;
     }
     if (!ix->own && ix->packed && ix->d_values) {
@@ -1380,6 +1396,109 @@ static mtb_status score_join_order(mtb_ctx *c, mtb_index *ix, const mtb_params *
     return dev_score(c, ix, p, n_reads, d_ql, d_ql2, max_len, d_results, d_taxcnt_tax, d_taxcnt_cnt, taxcnt_cap, n_taxcnt, tc_base, a, nullptr);
 }
 
+/* The slot segments of a short-read batch: n_reads x stride 16-byte slots in buffer "segm".  Live slots carry the batch's epoch tag;
+ * the buffer is cleared only when it is new or the tag wraps. */
+static mtb_status prepare_slots(mtb_ctx *c, uint64_t n_reads, uint32_t stride, mtb_slot16 **out, uint32_t *epoch_out) {
+    hipStream_t st = c->stream;
+    mtb_slot16 *d_segm;
+    DevBuf &sb = c->bufs["segm"];
+    void *before = sb.p; size_t cap_before = sb.cap;
+    STCHK(ensure_placed(c, "segm", n_reads * (uint64_t)stride, &d_segm));
+    static const char *clear_mode = getenv("MTB_SEGM_CLEAR");      /* experiment switch: kernel | sync | always (default: hipMemsetAsync when new / on epoch wrap) */
+    const bool always = clear_mode && !strcmp(clear_mode, "always");
+    if (sb.p != before || sb.cap != cap_before || c->seg_epoch >= MTB_SLOT_EPOCHS || always) {
+        if (clear_mode && !strcmp(clear_mode, "kernel")) hipLaunchKernelGGL(k_clear_words, dim3(2048), dim3(256), 0, st, (uint64_t *)sb.p, (uint64_t)(sb.cap / 8));
+        else HIPCHK(hipMemsetAsync(sb.p, 0, sb.cap, st));
+        if (clear_mode && !strcmp(clear_mode, "sync")) HIPCHK(hipDeviceSynchronize());
+        c->seg_epoch = 0;
+    }
+    c->seg_epoch++;
+    *out = d_segm; *epoch_out = c->seg_epoch;
+    return MTB_OK;
+}
+static void slot_geometry(uint32_t max_q, uint32_t *direct, uint32_t *stride) {
+    *direct = std::max<uint32_t>(8, (max_q + 7) & ~7u);
+    *stride = *direct + std::max<uint32_t>(16, (*direct / 8 + 7) & ~7u);
+}
+
+/* Scoring out of filled slot segments (fused path after the join; partitioned path after the matches came home): the
+ * register-resident scorer, the generic one for the reads it flags, exact segments for the reads neither can take from their slots.
+ * d_rc = per-read tail cursors, d_ovf / n_ovf = the overflow list.  *nm = matches seen (statistics). */
+static mtb_status score_fixed_slots(mtb_ctx *c, mtb_index *ix, const mtb_params *p, uint64_t n_reads, const int32_t *d_ql, const int32_t *d_ql2, uint32_t max_len,
+                                    uint64_t nk_real, mtb_slot16 *d_segm, uint32_t *d_rc, uint32_t stride, uint32_t direct, uint32_t epoch, mtb_match *d_ovf, uint64_t n_ovf,
+                                    mtb_result *d_results, int32_t *d_taxcnt_tax, uint32_t *d_taxcnt_cnt, uint64_t taxcnt_cap, uint64_t *n_taxcnt, uint64_t tc_base, uint64_t *nm_out) {
+    hipStream_t st = c->stream;
+    uint64_t nm = 0;
+    uint32_t *d_biglist, *d_bigcnt, *d_bigidx, *d_bigcur, *d_cnt; uint64_t *d_bigstart = nullptr, *d_ws2, *d_tot; mtb_match *d_big = nullptr;
+    STCHK(ensure(c, "biglist", n_reads, &d_biglist)); STCHK(ensure(c, "bigidx", n_reads, &d_bigidx)); STCHK(ensure(c, "livecnt", n_reads, &d_cnt));
+    STCHK(ensure(c, "segstart", n_reads + 1, &d_tot)); STCHK(ensure(c, "scanws", scan_ws_elems(n_reads + 1), &d_ws2));
+    HIPCHK(hipMemsetAsync(d_cnt, 0, n_reads * 4, st));
+    HIPCHK(hipMemsetAsync(c->d_scal + 2, 0, 32, st));            /* [2] unused, [3] max big segment, [5] reads deferred by the first launch */
+    uint64_t big_total = 0;
+    ScoreSrc a; a.m = (const mtb_match *)d_segm; a.cursor = d_rc;       /* slot mode: 16-byte slot records behind the pointer */ a.stride = stride; a.direct = direct; a.epoch = epoch; a.sort = true;
+    /* LDS staging of the scorer = smallest instantiation that holds one match for every metamer of the longest read
+     * (144 records: 16 waves per CU, 160: 14, 224: 10, 288: 8, 320: 7); reads with more live records are deferred */
+    {   /* sized for the typical read (mean metamer count + 12 %), not the longest: the few reads beyond it take the deferred
+           path, and 144 instead of 160 records is worth 10 % of the kernel on 150 bp reads (47.1 vs 52.3 ms) */
+        const uint32_t want = std::min<uint32_t>(direct, (uint32_t)((double)nk_real / (double)n_reads * 1.12) + 1);
+        a.cap = want <= 144 ? 144 : want <= 160 ? 160 : want <= 224 ? 224 : want <= 288 ? 288 : 320;
+    }
+    a.max_seg = a.cap;
+    a.big_list = d_biglist; a.n_big = (uint32_t *)(c->d_scal + 5); a.cnt_out = d_cnt;
+    /* reads the first launch could not take from their slots: exact segments (live slots + overflow list), sorted in HBM */
+    ScoreSecond second = [&](ScoreSrc *b, bool *go) -> mtb_status {
+        uint64_t sc = 0;
+        STCHK(d2h(c, &sc, c->d_scal + 5, 8));
+        const uint32_t n_big = (uint32_t)sc;
+        *go = n_big != 0;
+        if (!n_big) return MTB_OK;
+        KTimer kt(c, MTB_K_SEGSORT);
+        STCHK(ensure(c, "bigcnt", n_big, &d_bigcnt)); STCHK(ensure(c, "bigstart", (uint64_t)n_big + 1, &d_bigstart)); STCHK(ensure(c, "bigcur", n_big, &d_bigcur));
+        hipLaunchKernelGGL(k_big_count, dim3(std::min<uint32_t>(n_big, 4096)), dim3(64), 0, st, (const mtb_slot16 *)d_segm, stride, direct, epoch,
+                           (const uint32_t *)d_rc, (const uint32_t *)d_biglist, n_big, d_bigcnt, d_bigidx, (uint32_t *)(c->d_scal + 3));
+        scan_launch<uint32_t, uint64_t, false>(st, d_bigcnt, n_big, true, d_bigstart, d_ws2);
+        uint64_t mx = 0;
+        STCHK(d2h(c, &big_total, d_bigstart + n_big, 8));
+        STCHK(d2h(c, &mx, c->d_scal + 3, 8));
+        STCHK(ensure(c, "bigm", big_total, &d_big));
+        hipLaunchKernelGGL(k_big_copy, dim3(std::min<uint32_t>(n_big, 4096)), dim3(64), 0, st, (const mtb_slot16 *)d_segm, stride, direct, epoch,
+                           (const uint32_t *)d_rc, (const uint32_t *)d_biglist, (const uint64_t *)d_bigstart, n_big, d_bigcur, d_big);
+        if (n_ovf) hipLaunchKernelGGL(k_big_ovf, dim3((uint32_t)((n_ovf + 255) / 256)), dim3(256), 0, st, (const mtb_match *)d_ovf, n_ovf,
+                                      (const uint32_t *)d_bigidx, (const uint64_t *)d_bigstart, d_bigcur, d_big);
+        hipLaunchKernelGGL((k_segsort_large<mtb_match>), dim3(std::min<uint32_t>(n_big, 1024)), dim3(256), 0, st, d_big, (const uint64_t *)d_bigstart,
+                           (const uint32_t *)nullptr, (const uint32_t *)(c->d_scal + 5));
+        HIPCHK(hipGetLastError());
+        b->m = d_big; b->seg = d_bigstart; b->list = d_biglist; b->n_list = (const uint32_t *)(c->d_scal + 5); b->seg_by_list = 1;
+        b->sort = false; b->max_seg = (uint32_t)mx; b->grid = std::min<uint32_t>(n_big, 1024);
+        return MTB_OK;
+    };
+    STCHK(dev_score(c, ix, p, n_reads, d_ql, d_ql2, max_len, d_results, d_taxcnt_tax, d_taxcnt_cnt, taxcnt_cap, n_taxcnt, tc_base, a, &second));
+    /* number of matches (statistics): live records seen by the first launch + the deferred reads' segments */
+    { KTimer kt(c, MTB_K_SCAN); scan_launch<uint32_t, uint64_t, false>(st, d_cnt, n_reads, true, d_tot, d_ws2); }
+    STCHK(d2h(c, &nm, d_tot + n_reads, 8));
+    nm += big_total;
+    *nm_out = nm;
+    return MTB_OK;
+}
+
+/* results of a batch to the host with the taxID:count lists packed on the device first: only what they hold crosses PCIe */
+static mtb_status download_packed(mtb_ctx *c, mtb_result *d_res, const int32_t *d_tt, const uint32_t *d_tc, uint64_t n_reads, mtb_result *results,
+                                  int32_t *taxcnt_tax, uint32_t *taxcnt_cnt, uint64_t *n_taxcnt) {
+    uint32_t *d_n; uint64_t *d_off, *d_ws; int32_t *d_tt2; uint32_t *d_tc2;
+    STCHK(ensure(c, "tcn", n_reads, &d_n)); STCHK(ensure(c, "tcnewoff", n_reads + 1, &d_off)); STCHK(ensure(c, "scanws", scan_ws_elems(n_reads + 1), &d_ws));
+    hipLaunchKernelGGL(k_taxcnt_n, dim3((uint32_t)((n_reads + 255) / 256)), dim3(256), 0, c->stream, (const mtb_result *)d_res, n_reads, d_n);
+    scan_launch<uint32_t, uint64_t, false>(c->stream, d_n, n_reads, true, d_off, d_ws);
+    uint64_t total = 0;
+    STCHK(d2h(c, &total, d_off + n_reads, 8));
+    STCHK(ensure(c, "tctax2", total, &d_tt2)); STCHK(ensure(c, "tccnt2", total, &d_tc2));
+    hipLaunchKernelGGL(k_taxcnt_pack, dim3((uint32_t)((n_reads + 255) / 256)), dim3(256), 0, c->stream, d_res, n_reads, (const uint64_t *)d_off, d_tt, d_tc, d_tt2, d_tc2);
+    HIPCHK(hipGetLastError());
+    STCHK(d2h(c, results, d_res, n_reads * sizeof(mtb_result)));
+    if (total) { STCHK(d2h(c, taxcnt_tax, d_tt2, total * 4)); STCHK(d2h(c, taxcnt_cnt, d_tc2, total * 4)); }
+    *n_taxcnt = total;
+    return MTB_OK;
+}
+
 /* one read range on one stream; taxcnt slots of this range start at tc_base of the caller's arrays */
 static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, const char *d_bases, const uint64_t *d_offs,
                                const char *d_bases2, const uint64_t *d_offs2, uint64_t n_reads, uint64_t n_bases_total,
@@ -1408,7 +1527,8 @@ static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, c
     if (lslot) { STCHK(ensure(c, "dcnt", n_reads, &d_dcnt)); HIPCHK(hipMemsetAsync(d_dcnt, 0, n_reads * 4, st)); }
     uint16_t *d_dig = nullptr;               /* first radix pass's digits, written by the single-pass extractor */
     const bool aa6 = p->kmer_format == 2;           /* 5-bit amino-acid letters: three base-21 pair passes order bits [34,64) */
-    STCHK(dev_extract(c, p, d_bases, d_offs, d_bases2, d_offs2, n_reads, &d_k, &nk, d_ql, d_ql2, &max_len, true, n_bases_total, &nk_real, fixed || lslot, &max_q, aa6 ? &d_dig : nullptr, d_dcnt));
+    uint64_t n_bases_exact = n_bases_total;      /* the caller's figure is an estimate for a sub-batch of variable-length reads: the budget is kept on the exact one */
+    STCHK(dev_extract(c, p, d_bases, d_offs, d_bases2, d_offs2, n_reads, &d_k, &nk, d_ql, d_ql2, &max_len, true, n_bases_total, &nk_real, fixed || lslot, &max_q, aa6 ? &d_dig : nullptr, d_dcnt, &n_bases_exact));
     if ((fixed && (max_len + 3 >= MTB_SLOT_MAX_POS || max_q > 384)) || (lslot && (max_len + 3 >= 65536u || max_q >= 65535u))) {
         fixed = false; lslot = false;      /* tags would collide with positions / segments would be huge: extract again untagged */
         STCHK(dev_extract(c, p, d_bases, d_offs, d_bases2, d_offs2, n_reads, &d_k, &nk, d_ql, d_ql2, &max_len, true, n_bases_total, &nk_real, false, &max_q, aa6 ? &d_dig : nullptr));
@@ -1431,29 +1551,16 @@ static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, c
     uint64_t nm = 0;
     if (fixed) {
         /* ---- join straight into per-read slot segments (d_rc = per-read tail cursor) ---- */
-        const uint32_t direct = std::max<uint32_t>(8, (max_q + 7) & ~7u);
-        const uint32_t stride = direct + std::max<uint32_t>(16, (direct / 8 + 7) & ~7u);
-        mtb_slot16 *d_segm; mtb_match *d_ovf; uint64_t n_ovf = 0;
-        {   /* live slots carry the batch's epoch tag; the buffer is cleared only when it is new or the tag wraps */
-            DevBuf &sb = c->bufs["segm"];
-            void *before = sb.p; size_t cap_before = sb.cap;
-            STCHK(ensure_placed(c, "segm", n_reads * (uint64_t)stride, &d_segm));
-            static const char *clear_mode = getenv("MTB_SEGM_CLEAR");      /* experiment switch: kernel | sync | always (default: hipMemsetAsync when new / on epoch wrap) */
-            const bool always = clear_mode && !strcmp(clear_mode, "always");
-            if (sb.p != before || sb.cap != cap_before || c->seg_epoch >= MTB_SLOT_EPOCHS || always) {
-                if (clear_mode && !strcmp(clear_mode, "kernel")) hipLaunchKernelGGL(k_clear_words, dim3(2048), dim3(256), 0, st, (uint64_t *)sb.p, (uint64_t)(sb.cap / 8));
-                else HIPCHK(hipMemsetAsync(sb.p, 0, sb.cap, st));
-                if (clear_mode && !strcmp(clear_mode, "sync")) HIPCHK(hipDeviceSynchronize());
-                c->seg_epoch = 0;
-            }
-            c->seg_epoch++;
-        }
-        const uint32_t epoch = c->seg_epoch;
+        uint32_t direct, stride;
+        slot_geometry(max_q, &direct, &stride);
+        mtb_slot16 *d_segm; mtb_match *d_ovf; uint64_t n_ovf = 0; uint32_t epoch = 0;
+        STCHK(prepare_slots(c, n_reads, stride, &d_segm, &epoch));
         DevBuf &ob = c->bufs["ovf"];
         uint64_t ovf_cap = std::max<uint64_t>(ob.cap / sizeof(mtb_match), nk / 64 + 4096);
         for (int attempt = 0; attempt < 3; attempt++) {
             STCHK(ensure(c, "ovf", ovf_cap, &d_ovf));
-            JoinSegArgs sa; sa.seg = d_segm; sa.stride = stride; sa.direct = direct; sa.cursor = d_rc; sa.ovf = d_ovf; sa.ovf_cap = ovf_cap;
+            JoinSegArgs sa; memset(&sa, 0, sizeof(sa));
+            sa.seg = d_segm; sa.stride = stride; sa.direct = direct; sa.cursor = d_rc; sa.ovf = d_ovf; sa.ovf_cap = ovf_cap;
             sa.ovf_counter = nullptr; sa.epoch = epoch;
             mtb_status s2 = dev_join(c, ix, d_s, nk, nullptr, 0, nullptr, &n_ovf, &sa, low_bits);
             if (s2 == MTB_OK) break;
@@ -1464,54 +1571,8 @@ static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, c
         HIPCHK(hipEventRecord(c->ev[3], st));
         HIPCHK(hipEventRecord(c->ev[4], st));
         HIPCHK(hipEventRecord(c->ev[5], st));
-        uint32_t *d_biglist, *d_bigcnt, *d_bigidx, *d_bigcur, *d_cnt; uint64_t *d_bigstart = nullptr, *d_ws2, *d_tot; mtb_match *d_big = nullptr;
-        STCHK(ensure(c, "biglist", n_reads, &d_biglist)); STCHK(ensure(c, "bigidx", n_reads, &d_bigidx)); STCHK(ensure(c, "livecnt", n_reads, &d_cnt));
-        STCHK(ensure(c, "segstart", n_reads + 1, &d_tot)); STCHK(ensure(c, "scanws", scan_ws_elems(n_reads + 1), &d_ws2));
-        HIPCHK(hipMemsetAsync(d_cnt, 0, n_reads * 4, st));
-        HIPCHK(hipMemsetAsync(c->d_scal + 2, 0, 32, st));            /* [2] unused, [3] max big segment, [5] reads deferred by the first launch */
-        uint64_t big_total = 0;
-        ScoreSrc a; a.m = (const mtb_match *)d_segm; a.cursor = d_rc;       /* slot mode: 16-byte slot records behind the pointer */ a.stride = stride; a.direct = direct; a.epoch = epoch; a.sort = true;
-        /* LDS staging of the scorer = smallest instantiation that holds one match for every metamer of the longest read
-         * (144 records: 16 waves per CU, 160: 14, 224: 10, 288: 8, 320: 7); reads with more live records are deferred */
-        {   /* sized for the typical read (mean metamer count + 12 %), not the longest: the few reads beyond it take the deferred
-               path, and 144 instead of 160 records is worth 10 % of the kernel on 150 bp reads (47.1 vs 52.3 ms) */
-            const uint32_t want = std::min<uint32_t>(direct, (uint32_t)((double)nk_real / (double)n_reads * 1.12) + 1);
-            a.cap = want <= 144 ? 144 : want <= 160 ? 160 : want <= 224 ? 224 : want <= 288 ? 288 : 320;
-        }
-        a.max_seg = a.cap;
-        a.big_list = d_biglist; a.n_big = (uint32_t *)(c->d_scal + 5); a.cnt_out = d_cnt;
-        /* reads the first launch could not take from their slots: exact segments (live slots + overflow list), sorted in HBM */
-        ScoreSecond second = [&](ScoreSrc *b, bool *go) -> mtb_status {
-            uint64_t sc = 0;
-            STCHK(d2h(c, &sc, c->d_scal + 5, 8));
-            const uint32_t n_big = (uint32_t)sc;
-            *go = n_big != 0;
-            if (!n_big) return MTB_OK;
-            KTimer kt(c, MTB_K_SEGSORT);
-            STCHK(ensure(c, "bigcnt", n_big, &d_bigcnt)); STCHK(ensure(c, "bigstart", (uint64_t)n_big + 1, &d_bigstart)); STCHK(ensure(c, "bigcur", n_big, &d_bigcur));
-            hipLaunchKernelGGL(k_big_count, dim3(std::min<uint32_t>(n_big, 4096)), dim3(64), 0, st, (const mtb_slot16 *)d_segm, stride, direct, epoch,
-                               (const uint32_t *)d_rc, (const uint32_t *)d_biglist, n_big, d_bigcnt, d_bigidx, (uint32_t *)(c->d_scal + 3));
-            scan_launch<uint32_t, uint64_t, false>(st, d_bigcnt, n_big, true, d_bigstart, d_ws2);
-            uint64_t mx = 0;
-            STCHK(d2h(c, &big_total, d_bigstart + n_big, 8));
-            STCHK(d2h(c, &mx, c->d_scal + 3, 8));
-            STCHK(ensure(c, "bigm", big_total, &d_big));
-            hipLaunchKernelGGL(k_big_copy, dim3(std::min<uint32_t>(n_big, 4096)), dim3(64), 0, st, (const mtb_slot16 *)d_segm, stride, direct, epoch,
-                               (const uint32_t *)d_rc, (const uint32_t *)d_biglist, (const uint64_t *)d_bigstart, n_big, d_bigcur, d_big);
-            if (n_ovf) hipLaunchKernelGGL(k_big_ovf, dim3((uint32_t)((n_ovf + 255) / 256)), dim3(256), 0, st, (const mtb_match *)d_ovf, n_ovf,
-                                          (const uint32_t *)d_bigidx, (const uint64_t *)d_bigstart, d_bigcur, d_big);
-            hipLaunchKernelGGL((k_segsort_large<mtb_match>), dim3(std::min<uint32_t>(n_big, 1024)), dim3(256), 0, st, d_big, (const uint64_t *)d_bigstart,
-                               (const uint32_t *)nullptr, (const uint32_t *)(c->d_scal + 5));
-            HIPCHK(hipGetLastError());
-            b->m = d_big; b->seg = d_bigstart; b->list = d_biglist; b->n_list = (const uint32_t *)(c->d_scal + 5); b->seg_by_list = 1;
-            b->sort = false; b->max_seg = (uint32_t)mx; b->grid = std::min<uint32_t>(n_big, 1024);
-            return MTB_OK;
-        };
-        STCHK(dev_score(c, ix, p, n_reads, d_ql, d_ql2, max_len, d_results, d_taxcnt_tax, d_taxcnt_cnt, taxcnt_cap, n_taxcnt, tc_base, a, &second));
-        /* number of matches (statistics): live records seen by the first launch + the deferred reads' segments */
-        { KTimer kt(c, MTB_K_SCAN); scan_launch<uint32_t, uint64_t, false>(st, d_cnt, n_reads, true, d_tot, d_ws2); }
-        STCHK(d2h(c, &nm, d_tot + n_reads, 8));
-        nm += big_total;
+        STCHK(score_fixed_slots(c, ix, p, n_reads, d_ql, d_ql2, max_len, nk_real, d_segm, d_rc, stride, direct, epoch, d_ovf, n_ovf,
+                                d_results, d_taxcnt_tax, d_taxcnt_cnt, taxcnt_cap, n_taxcnt, tc_base, &nm));
     } else if (lslot) {
         /* ---- long reads on ordinal slots: join into per-read slot ranges, order every range by a stable species partition, score ---- */
         uint32_t *d_sizes; uint64_t *d_rb, *d_ws2; uint32_t *d_live;
@@ -1626,7 +1687,7 @@ static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, c
     HIPCHK(hipEventElapsedTime(&S.ms_score, c->ev[5], c->ev[6]));
     HIPCHK(hipEventElapsedTime(&S.ms_total, c->ev[0], c->ev[6]));
     collect_kernel_times(c);
-    S.n_reads = n_reads; S.n_bases = n_bases_total; S.n_kmers = nk_real; S.n_matches = nm; S.n_targets = ix->T;
+    S.n_reads = n_reads; S.n_bases = n_bases_exact; S.n_kmers = nk_real; S.n_matches = nm; S.n_targets = ix->T;
     if (c->fast_used) { uint64_t ns = 0; STCHK(d2h(c, &ns, c->d_scal + 6, 8)); S.n_generic_reads = ns & 0xFFFFFFFFull; c->fast_used = false; }
     else S.n_generic_reads = n_reads;
     S.n_slot_reads = (fixed || lslot) ? n_reads : 0;
@@ -1779,23 +1840,7 @@ mtb_status mtb_classify_batch(mtb_ctx *c, mtb_index *ix, const mtb_params *p, co
     STCHK(ensure(c, "results", n_reads, &d_res)); STCHK(ensure(c, "tctax", taxcnt_cap, &d_tt)); STCHK(ensure(c, "tccnt", taxcnt_cap, &d_tc));
     mtb_status st = mtb_classify_batch_device(c, ix, p, d_b, d_o, d_b2, d_o2, n_reads, nb, d_res, d_tt, d_tc, taxcnt_cap, n_taxcnt);
     if (st != MTB_OK) return st;
-    if (c->lanes.size() < 2 && *n_taxcnt) {
-        /* pack the lists on the device, copy only what they hold */
-        uint32_t *d_n; uint64_t *d_off, *d_ws; int32_t *d_tt2; uint32_t *d_tc2;
-        STCHK(ensure(c, "tcn", n_reads, &d_n)); STCHK(ensure(c, "tcnewoff", n_reads + 1, &d_off)); STCHK(ensure(c, "scanws", scan_ws_elems(n_reads + 1), &d_ws));
-        hipLaunchKernelGGL(k_taxcnt_n, dim3((uint32_t)((n_reads + 255) / 256)), dim3(256), 0, c->stream, (const mtb_result *)d_res, n_reads, d_n);
-        scan_launch<uint32_t, uint64_t, false>(c->stream, d_n, n_reads, true, d_off, d_ws);
-        uint64_t total = 0;
-        STCHK(d2h(c, &total, d_off + n_reads, 8));
-        STCHK(ensure(c, "tctax2", total, &d_tt2)); STCHK(ensure(c, "tccnt2", total, &d_tc2));
-        hipLaunchKernelGGL(k_taxcnt_pack, dim3((uint32_t)((n_reads + 255) / 256)), dim3(256), 0, c->stream, d_res, n_reads, (const uint64_t *)d_off, (const int32_t *)d_tt,
-                           (const uint32_t *)d_tc, d_tt2, d_tc2);
-        HIPCHK(hipGetLastError());
-        STCHK(d2h(c, results, d_res, n_reads * sizeof(mtb_result)));
-        if (total) { STCHK(d2h(c, taxcnt_tax, d_tt2, total * 4)); STCHK(d2h(c, taxcnt_cnt, d_tc2, total * 4)); }
-        *n_taxcnt = total;
-        return MTB_OK;
-    }
+    if (c->lanes.size() < 2 && *n_taxcnt) return download_packed(c, d_res, d_tt, d_tc, n_reads, results, taxcnt_tax, taxcnt_cnt, n_taxcnt);
     STCHK(d2h(c, results, d_res, n_reads * sizeof(mtb_result)));
     if (*n_taxcnt) { STCHK(d2h(c, taxcnt_tax, d_tt, *n_taxcnt * 4)); STCHK(d2h(c, taxcnt_cnt, d_tc, *n_taxcnt * 4)); }
     return MTB_OK;
@@ -1852,29 +1897,61 @@ mtb_status mtb_index_slice(mtb_index *ix, uint64_t lo_value, uint64_t hi_value, 
     sl->own = false; sl->own_tax = false; sl->d_dir = nullptr; sl->d_dirbase = nullptr; sl->dir_L = 0;
     sl->d_values = ix->d_values + pos[0]; sl->d_info = ix->d_info + pos[0]; sl->T = pos[1] - pos[0];
     sl->match_last = !is_last || ix->match_last;
+    {   /* a view gets a directory of its own (over its part of the parent's flat array): the owner side of the partitioned path joins through it */
+        mtb_status sd = build_directory(c, sl);
+        if (sd != MTB_OK) { mtb_index_close(sl); return sd; }
+    }
     *out = sl;
     return MTB_OK;
 }
 
 mtb_status mtb_part_extract(mtb_ctx *c, const mtb_params *p, const char *d_bases, const uint64_t *d_offs, const char *d_bases2,
                             const uint64_t *d_offs2, uint64_t n_reads, const uint64_t *bounds, uint32_t n_parts, const mtb_kmer **d_sorted,
-                            uint64_t *n_kmers, uint64_t *part_counts) {
+                            uint64_t *n_kmers, uint64_t *part_counts, uint64_t *part_starts) {
     if (!c || !p || !d_offs || !bounds || !d_sorted || !n_kmers || !part_counts || n_parts == 0) return fail(MTB_ERR_ARG, "NULL argument");
     HIPCHK(hipSetDevice(c->device));
     *d_sorted = nullptr; *n_kmers = 0;
-    for (uint32_t q = 0; q < n_parts; q++) part_counts[q] = 0;
-    c->part_n_reads = n_reads; c->part_max_len = 0;
+    for (uint32_t q = 0; q < n_parts; q++) { part_counts[q] = 0; if (part_starts) part_starts[q] = 0; }
+    c->part_n_reads = n_reads; c->part_max_len = 0; c->part_mode = 0; c->part_max_q = 0; c->part_nk_real = 0;
     if (n_reads == 0) return MTB_OK;
     int32_t *d_ql, *d_ql2;
     STCHK(ensure(c, "qlen", n_reads, &d_ql)); STCHK(ensure(c, "qlen2", n_reads, &d_ql2));
     mtb_kmer *d_k, *d_s; uint64_t nk; uint32_t max_len = 0;
+    if (part_starts && p->seq_mode != 3 && !getenv("MTB_PART_EXACT")) {
+        /* the product path of short reads: single-pass extraction with ordinals, the sort on the leading amino-acid letters only (it is
+         * there for the locality of the owners' directory joins) -- so a run is cut at PREFIX granularity and the metamers that share
+         * their prefix with a bound go to both neighbours: a query finds candidates only in the range that holds its amino-acid
+         * group (no group straddles a cut), the other owner emits nothing for it */
+        uint32_t max_q = 0; uint64_t nk_real = 0; uint16_t *d_dig = nullptr;
+        const bool aa6 = p->kmer_format == 2;
+        STCHK(dev_extract(c, p, d_bases, d_offs, d_bases2, d_offs2, n_reads, &d_k, &nk, d_ql, d_ql2, &max_len, true, 0, &nk_real, true, &max_q, aa6 ? &d_dig : nullptr));
+        if (max_len + 3 < MTB_SLOT_MAX_POS && max_q <= 384) {
+            const int low_bits = aa6 ? 34 : 32;
+            STCHK(dev_sort(c, d_k, nk, aa6 ? MTB_SORT_AA6 : 32, &d_s, d_dig));
+            c->part_max_len = max_len; c->part_mode = 1; c->part_max_q = max_q; c->part_nk_real = nk_real;
+            std::vector<uint64_t> key(2 * n_parts), pos(2 * n_parts);
+            for (uint32_t q = 0; q < n_parts; q++) {
+                const uint64_t pre = bounds[q] >> low_bits;
+                key[2 * q] = pre << low_bits;                                                       /* first record whose prefix is >= the bound's */
+                key[2 * q + 1] = pre + 1 >= (1ull << (64 - low_bits)) ? UINT64_MAX : (pre + 1) << low_bits;      /* first record behind the bound's prefix group */
+            }
+            if (nk) STCHK(lower_bounds(c, (const uint64_t *)d_s, nk, 2, key.data(), 2 * n_parts, pos.data()));
+            for (uint32_t q = 0; q < n_parts; q++) {
+                const uint64_t lo = q == 0 ? 0 : pos[2 * q];
+                const uint64_t hi = q + 1 < n_parts ? (key[2 * (q + 1) + 1] == UINT64_MAX ? nk : pos[2 * (q + 1) + 1]) : nk;
+                part_starts[q] = lo; part_counts[q] = hi > lo ? hi - lo : 0;
+            }
+            *d_sorted = d_s; *n_kmers = nk;
+            return MTB_OK;
+        }
+    }
     STCHK(dev_extract(c, p, d_bases, d_offs, d_bases2, d_offs2, n_reads, &d_k, &nk, d_ql, d_ql2, &max_len));
     /* partition boundaries are amino-acid-part boundaries (bit 24), finer than the 32-bit tiles of the fused path: 5 passes */
     STCHK(dev_sort(c, d_k, nk, 24, &d_s));
     c->part_max_len = max_len;
     std::vector<uint64_t> pos(n_parts);
     if (nk) STCHK(lower_bounds(c, (const uint64_t *)d_s, nk, 2, bounds, n_parts, pos.data()));
-    for (uint32_t q = 0; q < n_parts; q++) { uint64_t hi = q + 1 < n_parts ? pos[q + 1] : nk; part_counts[q] = hi >= pos[q] ? hi - pos[q] : 0; }
+    for (uint32_t q = 0; q < n_parts; q++) { uint64_t hi = q + 1 < n_parts ? pos[q + 1] : nk; part_counts[q] = hi >= pos[q] ? hi - pos[q] : 0; if (part_starts) part_starts[q] = pos[q]; }
     if (nk && pos[0] != 0) return fail(MTB_ERR_ARG, "bounds[0] must be 0");
     *d_sorted = d_s; *n_kmers = nk;
     return MTB_OK;
@@ -1885,6 +1962,13 @@ mtb_status mtb_part_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_kmers, uin
     HIPCHK(hipSetDevice(c->device));
     *count = 0;
     if (n == 0 || ix->T == 0) return MTB_OK;
+    if (ix->d_dir && !getenv("MTB_PART_EXACT")) {
+        /* the directory join, matches to a dense list: every record keeps its query's qinfo (with the ordinal tag of a slot-mode
+         * batch) and says in `pad` whether it is the query's first match */
+        JoinSegArgs sa; memset(&sa, 0, sizeof(sa));
+        sa.list = 1; sa.ovf = d_out; sa.ovf_cap = cap;
+        return dev_join(c, ix, d_kmers, n, nullptr, 0, nullptr, count, &sa);
+    }
     return dev_join(c, ix, d_kmers, n, d_out, cap, nullptr, count);
 }
 
@@ -1900,10 +1984,178 @@ mtb_status mtb_part_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, mtb_ma
     STCHK(ensure(c, "qlen", n_reads, &d_ql)); STCHK(ensure(c, "qlen2", n_reads, &d_ql2));
     STCHK(ensure(c, "readcnt", n_reads, &d_rc));
     STCHK(ensure(c, "results", n_reads, &d_res)); STCHK(ensure(c, "tctax", taxcnt_cap, &d_tt)); STCHK(ensure(c, "tccnt", taxcnt_cap, &d_tc));
+    if (c->part_mode == 1) {
+        /* slot mode: the matches are placed into this rank's slot segments by their ordinal (what the fused join does at once),
+         * then the slot scorers run */
+        hipStream_t st = c->stream;
+        uint32_t direct, stride;
+        slot_geometry(c->part_max_q, &direct, &stride);
+        mtb_slot16 *d_segm; mtb_match *d_ovf; uint32_t epoch = 0; uint64_t n_ovf = 0;
+        STCHK(prepare_slots(c, n_reads, stride, &d_segm, &epoch));
+        DevBuf &ob = c->bufs["ovf"];
+        uint64_t ovf_cap = std::max<uint64_t>(ob.cap / sizeof(mtb_match), n_matches / 64 + 4096);
+        for (int attempt = 0; attempt < 3; attempt++) {
+            STCHK(ensure(c, "ovf", ovf_cap, &d_ovf));
+            HIPCHK(hipMemsetAsync(d_rc, 0, n_reads * 4, st));
+            HIPCHK(hipMemsetAsync(c->d_scal, 0, 16, st));
+            JoinSegArgs sa; memset(&sa, 0, sizeof(sa));
+            sa.seg = d_segm; sa.stride = stride; sa.direct = direct; sa.cursor = d_rc; sa.ovf = d_ovf; sa.ovf_cap = ovf_cap; sa.ovf_counter = (unsigned long long *)c->d_scal; sa.epoch = epoch;
+            if (n_matches) hipLaunchKernelGGL(k_slot_place, dim3((uint32_t)((n_matches + 255) / 256)), dim3(256), 0, st, (const mtb_match *)d_matches, n_matches, sa, n_reads, (uint32_t *)(c->d_scal + 1));
+            HIPCHK(hipGetLastError());
+            uint64_t sc[2];
+            STCHK(d2h(c, sc, c->d_scal, 16));
+            if (sc[1] & 0xFFFFFFFFull) return fail(MTB_ERR_ARG, "match records with a sequenceID outside 1..n_reads");
+            n_ovf = sc[0];
+            if (n_ovf <= ovf_cap) break;
+            if (attempt == 2) return fail(MTB_ERR_CAPACITY, "overflow list too small");
+            ovf_cap = n_ovf + n_ovf / 16 + 1024;          /* slots written by the failed attempt are rewritten identically */
+        }
+        uint64_t nm = 0;
+        memset(&c->stats, 0, sizeof(c->stats));
+        STCHK(score_fixed_slots(c, ix, p, n_reads, d_ql, d_ql2, c->part_max_len, c->part_nk_real, d_segm, d_rc, stride, direct, epoch, d_ovf, n_ovf,
+                                d_res, d_tt, d_tc, taxcnt_cap, n_taxcnt, 0, &nm));
+        c->stats.n_reads = n_reads; c->stats.n_matches = nm; c->stats.n_slot_reads = n_reads; c->stats.n_kmers = c->part_nk_real;
+        if (c->fast_used) { uint64_t ns = 0; STCHK(d2h(c, &ns, c->d_scal + 6, 8)); c->stats.n_generic_reads = ns & 0xFFFFFFFFull; c->fast_used = false; }
+        return download_packed(c, d_res, d_tt, d_tc, n_reads, results, taxcnt_tax, taxcnt_cnt, n_taxcnt);
+    }
     STCHK(count_reads(c, d_matches, n_matches, n_reads, d_rc));
     STCHK(score_join_order(c, ix, p, d_matches, n_matches, n_reads, d_rc, d_ql, d_ql2, c->part_max_len, d_res, d_tt, d_tc, taxcnt_cap, n_taxcnt, 0));
-    STCHK(d2h(c, results, d_res, n_reads * sizeof(mtb_result)));
-    if (*n_taxcnt) { STCHK(d2h(c, taxcnt_tax, d_tt, *n_taxcnt * 4)); STCHK(d2h(c, taxcnt_cnt, d_tc, *n_taxcnt * 4)); }
+    return download_packed(c, d_res, d_tt, d_tc, n_reads, results, taxcnt_tax, taxcnt_cnt, n_taxcnt);
+}
+
+/* One batch on a group of contexts of THIS process, context k holding range k of the database (mtb_index_open_part(.., k, n)):
+ * the C++ host's form of SURVEY 8(e) row 2 (metabuli_amd/parallel.py is the torch.distributed form of the same steps).
+ *   1. every context: its contiguous share of the reads -> device, mtb_part_extract (ordinal tags, prefix-granular runs);
+ *   2. exchange #1: run p of every context -> the owner of range p (hipMemcpyPeerAsync, device to device over xGMI), which joins
+ *      every received run through its directory (mtb_part_join: runs stay sorted, no merge);
+ *   3. exchange #2: the matches of source k's reads -> context k, which places them into its slot segments and scores
+ *      (mtb_part_score);
+ *   4. rows in input order, the taxID:count lists packed back to back behind taxcnt_off.
+ * One host thread per context inside each step; the steps are separated by joins (the exchange needs every sender's counts). */
+static mtb_status run_parallel_status(uint32_t n, const std::function<mtb_status(uint32_t)> &f, std::string *err) {
+    std::vector<mtb_status> st(n, MTB_OK); std::vector<std::string> errs(n);
+    std::vector<std::thread> th;
+    for (uint32_t k = 0; k < n; k++) th.emplace_back([&, k] { st[k] = f(k); if (st[k] != MTB_OK) errs[k] = g_err; });
+    for (auto &t : th) t.join();
+    for (uint32_t k = 0; k < n; k++) if (st[k] != MTB_OK) { *err = errs[k]; return st[k]; }
+    return MTB_OK;
+}
+
+mtb_status mtb_classify_batch_partitioned(mtb_ctx **ctxs, mtb_index **parts, uint32_t n, const uint64_t *bounds, const mtb_params *p,
+                                          const char *bases, const uint64_t *offs, const char *bases2, const uint64_t *offs2, uint64_t n_reads,
+                                          mtb_result *results, int32_t *taxcnt_tax, uint32_t *taxcnt_cnt, uint64_t taxcnt_cap, uint64_t *n_taxcnt) {
+    if (!ctxs || !parts || !bounds || !p || !n_taxcnt || n == 0) return fail(MTB_ERR_ARG, "NULL argument");
+    *n_taxcnt = 0;
+    if (n_reads == 0) return MTB_OK;
+    if (!bases || !offs || !results) return fail(MTB_ERR_ARG, "NULL argument");
+    const bool paired = p->seq_mode == 2;
+    if (paired && (!bases2 || !offs2)) return fail(MTB_ERR_ARG, "seq_mode 2 needs bases2/offs2");
+    struct Rank {
+        uint64_t lo = 0, hi = 0;                          /* its reads */
+        const mtb_kmer *d_sorted = nullptr; uint64_t nk = 0;
+        std::vector<uint64_t> counts, starts;             /* runs by owner */
+        std::vector<uint64_t> m_count, m_start;           /* as an owner: matches per source, their start in its match buffer */
+        mtb_match *d_matches = nullptr;                   /* as an owner */
+        std::vector<mtb_result> res; std::vector<int32_t> tt; std::vector<uint32_t> tc; uint64_t ntc = 0;
+    };
+    std::vector<Rank> R(n);
+    for (uint32_t k = 0; k < n; k++) { R[k].lo = n_reads * k / n; R[k].hi = n_reads * (k + 1) / n; R[k].counts.assign(n, 0); R[k].starts.assign(n, 0); R[k].m_count.assign(n, 0); R[k].m_start.assign(n, 0); }
+    std::string err;
+    /* 1. reads to their device, extraction */
+    mtb_status st = run_parallel_status(n, [&](uint32_t k) -> mtb_status {
+        mtb_ctx *c = ctxs[k]; Rank &r = R[k];
+        const uint64_t m = r.hi - r.lo;
+        if (m == 0) return MTB_OK;
+        HIPCHK(hipSetDevice(c->device));
+        std::vector<uint64_t> o(m + 1), o2(paired ? m + 1 : 0);
+        for (uint64_t i = 0; i <= m; i++) o[i] = offs[r.lo + i] - offs[r.lo];
+        if (paired) for (uint64_t i = 0; i <= m; i++) o2[i] = offs2[r.lo + i] - offs2[r.lo];
+        char *d_b, *d_b2; uint64_t *d_o, *d_o2; uint64_t nb;
+        STCHK(upload_reads(c, p, bases + offs[r.lo], o.data(), paired ? bases2 + offs2[r.lo] : nullptr, paired ? o2.data() : nullptr, m, &d_b, &d_o, &d_b2, &d_o2, &nb));
+        return mtb_part_extract(c, p, d_b, d_o, d_b2, d_o2, m, bounds, n, &r.d_sorted, &r.nk, r.counts.data(), r.starts.data());
+    }, &err);
+    if (st != MTB_OK) return fail(st, err);
+    /* 2. runs to their owners, joins */
+    st = run_parallel_status(n, [&](uint32_t q) -> mtb_status {
+        mtb_ctx *c = ctxs[q]; Rank &own = R[q];
+        HIPCHK(hipSetDevice(c->device));
+        uint64_t n_in = 0;
+        for (uint32_t k = 0; k < n; k++) n_in += R[k].counts[q];
+        if (n_in == 0) return MTB_OK;
+        mtb_kmer *d_in;
+        STCHK(ensure(c, "xkmers", n_in, &d_in));
+        uint64_t at = 0;
+        for (uint32_t k = 0; k < n; k++) {
+            const uint64_t cnt = R[k].counts[q];
+            if (cnt) HIPCHK(hipMemcpyPeerAsync(d_in + at, c->device, R[k].d_sorted + R[k].starts[q], ctxs[k]->device, cnt * sizeof(mtb_kmer), c->stream));
+            at += cnt;
+        }
+        HIPCHK(hipStreamSynchronize(c->stream));
+        uint64_t cap = n_in + n_in / 4 + 1024;
+        for (int attempt = 0; attempt < 4; attempt++) {
+            STCHK(ensure(c, "xmatches", cap, &own.d_matches));
+            uint64_t used = 0, need = 0; bool again = false;
+            at = 0;
+            for (uint32_t k = 0; k < n && !again; k++) {
+                const uint64_t cnt = R[k].counts[q];
+                uint64_t got = 0;
+                own.m_start[k] = used;
+                if (cnt) {
+                    mtb_status sj = mtb_part_join(c, parts[q], d_in + at, cnt, own.d_matches + used, cap - used, &got);
+                    if (sj == MTB_ERR_CAPACITY) { again = true; need = used + got; }
+                    else if (sj != MTB_OK) return sj;
+                }
+                own.m_count[k] = got; used += got; at += cnt;
+            }
+            if (!again) return MTB_OK;
+            cap = need + need / 2 + 1024;                 /* (the runs behind the one that did not fit are not counted yet) */
+        }
+        return fail(MTB_ERR_CAPACITY, "match buffer of a range owner too small");
+    }, &err);
+    if (st != MTB_OK) return fail(st, err);
+    /* 3. matches home, scoring */
+    st = run_parallel_status(n, [&](uint32_t k) -> mtb_status {
+        mtb_ctx *c = ctxs[k]; Rank &r = R[k];
+        const uint64_t m = r.hi - r.lo;
+        if (m == 0) return MTB_OK;
+        HIPCHK(hipSetDevice(c->device));
+        uint64_t nm = 0;
+        for (uint32_t q = 0; q < n; q++) nm += R[q].m_count[k];
+        mtb_match *d_home;
+        STCHK(ensure(c, "xhome", nm, &d_home));
+        uint64_t at = 0;
+        for (uint32_t q = 0; q < n; q++) {
+            const uint64_t cnt = R[q].m_count[k];
+            if (cnt) HIPCHK(hipMemcpyPeerAsync(d_home + at, c->device, R[q].d_matches + R[q].m_start[k], ctxs[q]->device, cnt * sizeof(mtb_match), c->stream));
+            at += cnt;
+        }
+        HIPCHK(hipStreamSynchronize(c->stream));
+        r.res.resize(m);
+        uint64_t cap = 24 * m + 4096;
+        for (;;) {
+            r.tt.resize(cap); r.tc.resize(cap);
+            mtb_status ss = mtb_part_score(c, parts[k], p, d_home, nm, m, r.res.data(), r.tt.data(), r.tc.data(), cap, &r.ntc);
+            if (ss == MTB_ERR_CAPACITY && r.ntc > cap) { cap = r.ntc; continue; }
+            return ss;
+        }
+    }, &err);
+    if (st != MTB_OK) return fail(st, err);
+    /* 4. rows in input order, lists packed */
+    uint64_t used = 0;
+    for (uint32_t k = 0; k < n; k++) for (uint64_t i = 0; i < R[k].res.size(); i++) used += R[k].res[i].n_taxcnt;
+    *n_taxcnt = used;
+    if (used > taxcnt_cap) return fail(MTB_ERR_CAPACITY, "taxcnt buffers too small");
+    if (used >= (1ull << 32)) return fail(MTB_ERR_ARG, "more than 2^32-1 taxcnt entries in one batch; split the batch");
+    uint64_t at = 0;
+    for (uint32_t k = 0; k < n; k++) {
+        Rank &r = R[k];
+        for (uint64_t i = 0; i < r.res.size(); i++) {
+            mtb_result x = r.res[i];
+            for (uint32_t j = 0; j < x.n_taxcnt; j++) { taxcnt_tax[at + j] = r.tt[x.taxcnt_off + j]; taxcnt_cnt[at + j] = r.tc[x.taxcnt_off + j]; }
+            x.taxcnt_off = (uint32_t)at; at += x.n_taxcnt;
+            results[r.lo + i] = x;
+        }
+    }
     return MTB_OK;
 }
 

@@ -13,8 +13,9 @@ Row 2 (index larger than one HBM): `classify_partitioned` below.  The flat
 target array is range-partitioned by value at amino-acid-part boundaries, one
 range per GPU; per batch the sorted query metamers travel to the owner of their
 range (all-to-all #1, 16-byte records), are joined there, and the 24-byte
-matches travel back to the read's home GPU (all-to-all #2), which sorts and
-scores them.  Two exchange steps, no all-reduce on the data path.
+matches travel back to the read's home GPU (all-to-all #2), which places them into
+its per-read slot segments by the metamer's ordinal and runs the slot scorers -- the kernels of the
+replicated path (k_join_dir, k_score_fast, k_score) on both sides.  Two exchange steps, no all-reduce on the data path.
 """
 from __future__ import annotations
 
@@ -64,6 +65,7 @@ class GpuStages:
         self.ctx, self.index, self.params, self.torch = ctx, index, params, torch
         self.device = torch.device(device)
         self.n_reads = 0
+        self.overlapping = True     # the product path: ordinal tags, prefix-granular (overlapping) runs, slot scoring at home
 
     def set_reads(self, d_bases, d_offs, n_reads, d_bases2=None, d_offs2=None):
         """device tensors: bases uint8, offs int64 (n_reads + 1); mates for seq_mode 2"""
@@ -79,14 +81,14 @@ class GpuStages:
         torch = self.torch
         b, o, b2, o2 = self.reads
         self._fence()
-        ptr, nk, counts = self.ctx.part_extract(self.params, b.data_ptr(), o.data_ptr(), b2.data_ptr() if b2 is not None else 0,
-                                                o2.data_ptr() if o2 is not None else 0, self.n_reads, bounds)
+        ptr, nk, counts, starts = self.ctx.part_extract(self.params, b.data_ptr(), o.data_ptr(), b2.data_ptr() if b2 is not None else 0,
+                                                        o2.data_ptr() if o2 is not None else 0, self.n_reads, bounds, overlapping=self.overlapping)
         if nk == 0:
-            return torch.empty((0, 2), dtype=torch.int64, device=self.device), [0] * len(counts)
+            return torch.empty((0, 2), dtype=torch.int64, device=self.device), [0] * len(counts), [0] * len(counts)
 
         class _View:            # zero-copy view of the context-owned buffer (valid until the next stage call)
             __cuda_array_interface__ = {"shape": (int(nk), 2), "typestr": "<i8", "data": (int(ptr), False), "version": 2}
-        return torch.as_tensor(_View(), device=self.device), [int(c) for c in counts]
+        return torch.as_tensor(_View(), device=self.device), [int(c) for c in counts], [int(x) for x in starts]
 
     def join(self, run):
         torch = self.torch
@@ -115,7 +117,7 @@ class GpuStages:
 _XCHG_BYTES = 512 << 20
 
 
-def _exchange(torch, dist, send, send_counts, width, xdev):
+def _exchange(torch, dist, send, send_counts, width, xdev, send_starts=None):
     """all-to-all(v) of [n, width] int64 rows; returns (received rows, per-source row counts).
 
     One small collective for the counts: every rank all-gathers its send-count vector, so each rank reads its receive
@@ -132,7 +134,8 @@ def _exchange(torch, dist, send, send_counts, width, xdev):
     send_counts = [int(x) for x in send_counts]
     send = send.to(xdev).contiguous()
     recv = torch.empty((sum(recv_counts), width), dtype=torch.int64, device=xdev)
-    s_off = np.concatenate([[0], np.cumsum(send_counts)]).astype(np.int64)
+    # the runs of a sender are consecutive unless it says otherwise (prefix-granular cuts let neighbouring runs overlap)
+    s_off = np.asarray(send_starts, dtype=np.int64) if send_starts is not None else np.concatenate([[0], np.cumsum(send_counts)]).astype(np.int64)
     r_off = np.concatenate([[0], np.cumsum(recv_counts)]).astype(np.int64)
     if send_counts[me]:
         recv[int(r_off[me]): int(r_off[me]) + send_counts[me]] = send[int(s_off[me]): int(s_off[me]) + send_counts[me]]
@@ -156,22 +159,44 @@ def _exchange(torch, dist, send, send_counts, width, xdev):
 
 def classify_partitioned(stages, bounds, dist):
     """One batch on one rank of a range-partitioned index.  `stages` provides extract_sorted(bounds) ->
-    (metamers [n,2] sorted by value, count per range), join(run) -> matches [m,3], score(matches) -> results;
+    (metamers [n,2] sorted, count per range[, start per range: neighbouring runs may overlap]), join(run) -> matches [m,3], score(matches) -> results;
     `bounds[p]` is the lower amino-acid-part bound of rank p's range.  Returns what score() returns for this
     rank's reads.  Communication: 2 x (count all-gather + point-to-point payload exchange); with backend "gloo" (CPU tests)
     the payload is staged through host memory."""
+    import os
+    import time
     import torch
     world = dist.get_world_size()
     assert len(bounds) == world, "one value range per rank"
-    kmers, counts = stages.extract_sorted(bounds)
+    timing = os.environ.get("MTB_PART_TIMING")
+    t = [time.perf_counter()]
+
+    def mark():
+        if timing:
+            torch.cuda.synchronize() if torch.cuda.is_available() else None
+            t.append(time.perf_counter())
+    ext = stages.extract_sorted(bounds)
+    mark()
+    kmers, counts, starts = ext if len(ext) == 3 else (ext[0], ext[1], None)
     xdev = kmers.device if dist.get_backend() == "nccl" else torch.device("cpu")
     home = kmers.device
-    recv, recv_counts = _exchange(torch, dist, kmers, counts, 2, xdev)           # all-to-all #1: metamers to range owners
+    recv, recv_counts = _exchange(torch, dist, kmers, counts, 2, xdev, starts)   # all-to-all #1: metamers to range owners
     recv = recv.to(home)
+    mark()
     runs, o = [], 0
     for n in recv_counts:                                                         # runs arrive sorted: one join per source, no merge
         runs.append(stages.join(recv[o:o + n])); o += n
     m_counts = [int(r.shape[0]) for r in runs]
     m_send = torch.cat(runs) if runs else torch.empty((0, 3), dtype=torch.int64, device=home)
+    mark()
     m_recv, _ = _exchange(torch, dist, m_send, m_counts, 3, xdev)                 # all-to-all #2: matches back to the read's home
-    return stages.score(m_recv.to(home))
+    m_recv = m_recv.to(home)
+    mark()
+    out = stages.score(m_recv)
+    mark()
+    if timing and dist.get_rank() == 0:
+        import sys
+        names = ("extract+sort", "exchange 1", "join", "exchange 2", "place+score+results")
+        print("[partitioned] " + ", ".join(f"{n} {1e3 * (b - a):.1f} ms" for n, a, b in zip(names, t[:-1], t[1:])) +
+              f"; {int(kmers.shape[0])} metamers out, {int(m_recv.shape[0])} matches home", file=sys.stderr, flush=True)
+    return out

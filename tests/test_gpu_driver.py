@@ -140,6 +140,29 @@ def test_driver_on_two_engines_equals_one(orc, tmp_path, mode):
     assert outs["one"]["classifications.tsv"].count("\n") == t.n_reads + 1
 
 
+@pytest.mark.parametrize("mode", ["sync_se", "sync_pe"])
+def test_driver_on_a_range_partitioned_index_equals_one_engine(orc, tmp_path, mode):
+    """mtb_classify --devices 0,0[,0] --partitioned 1: engine d opens only value range d of the database (split checkpoints), every
+    host batch goes through mtb_classify_batch_partitioned -- extraction per engine, metamer runs to the range owners and matches
+    home as device-to-device peer copies, directory join at the owners, slot scorers at home (SURVEY 8(e) row 2 in the C++ host).
+    The files must equal the single-engine run on the whole index byte for byte."""
+    from conftest import Toy, TOY_MODES
+    t = Toy(orc, tmp_path / "db", **TOY_MODES[mode])
+    names = [f"read{i}" for i in range(t.n_reads)]
+    fq1 = str(tmp_path / "r1.fq"); _write_fastq(fq1, names, t.b1, t.o1)
+    files = [fq1]
+    if t.b2 is not None:
+        fq2 = str(tmp_path / "r2.fq"); _write_fastq(fq2, names, t.b2, t.o2); files.append(fq2)
+    outs = {}
+    for tag, extra in (("one", ["--devices", "0"]), ("two", ["--devices", "0,0", "--partitioned", "1"]), ("three", ["--devices", "0,0,0", "--partitioned", "1"])):
+        od = tmp_path / tag; od.mkdir()
+        p = subprocess.run([_exe(), "--seq-mode", str(t.p.seq_mode), "--max-reads", "150"] + extra + files + [t.dbdir, str(od), "j"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs[tag] = {f: open(str(od / f"j_{f}")).read() for f in ("classifications.tsv", "report.tsv", "krona.html")}
+    assert outs["one"] == outs["two"] == outs["three"]
+    assert outs["one"]["classifications.tsv"].count("\n") == t.n_reads + 1
+
+
 STAGE_PROGRAM = r"""
 // the reference's loop body (Classifier.cpp:105-119) written against include/mtb.hpp's stage classes, compared with classifyBatch
 #include <cstdio>

@@ -32,9 +32,18 @@ class EmuStages:
     def extract_sorted(self, bounds):
         k, self.ql, self.ql2 = self.orc.extract_batch(self.p, self.bases, self.offs)
         k = self.orc.sort_kmers(k)
-        pos = np.searchsorted(k["value"], np.asarray(bounds, np.uint64))
+        b = np.asarray(bounds, np.uint64)
+        kt = self.torch.from_numpy(k.view(np.int64).reshape(-1, 2).copy())
+        if os.environ.get("MTB_TEST_OVERLAP"):
+            # what libmtb's product path does: runs cut at the granularity of the 30-bit amino-acid prefix, so a run also carries the
+            # metamers that share their prefix with its upper bound (the neighbour gets them too and finds nothing for the foreign ones)
+            pre = b >> np.uint64(34)
+            lo = np.searchsorted(k["value"], pre << np.uint64(34)); lo[0] = 0
+            hi = np.append(np.searchsorted(k["value"], (pre[1:] + np.uint64(1)) << np.uint64(34)), len(k))
+            return kt, [int(max(0, h - l)) for l, h in zip(lo, hi)], [int(x) for x in lo]
+        pos = np.searchsorted(k["value"], b)
         counts = np.diff(np.append(pos, len(k)))
-        return self.torch.from_numpy(k.view(np.int64).reshape(-1, 2).copy()), [int(c) for c in counts]
+        return kt, [int(c) for c in counts]
 
     def join(self, run):
         from helpers import kmer_dt
@@ -107,14 +116,16 @@ def test_part_bounds_are_amino_acid_boundaries(orc, tmp_path):
                 assert (t.values[c - 1] & AAMASK) != (t.values[c] & AAMASK)
 
 
-@pytest.mark.parametrize("xchg_bytes", [None, 20000])
-def test_two_rank_partitioned_index_matches_single_process(orc, tmp_path, xchg_bytes, monkeypatch):
+@pytest.mark.parametrize("xchg_bytes,overlap", [(None, False), (20000, False), (None, True), (20000, True)])
+def test_two_rank_partitioned_index_matches_single_process(orc, tmp_path, xchg_bytes, overlap, monkeypatch):
     from conftest import Toy
     t = Toy(orc, tmp_path / "db", syncmer=1, paired=False, seed=22, n_reads=90)
     npz = str(tmp_path / "in.npz"); out = str(tmp_path / "out.npz")
     np.savez(npz, bases=t.b1, offs=t.o1, values=t.values, taxids=t.taxids)
     if xchg_bytes:
         monkeypatch.setenv("MTB_TEST_XCHG", str(xchg_bytes))
+    if overlap:
+        monkeypatch.setenv("MTB_TEST_OVERLAP", "1")
     mp.spawn(_cpu_worker, args=(2, 30100 + os.getpid() % 500, t.dbdir, npz, out), nprocs=2, join=True)
     _check(out, t.ref)
 
@@ -136,31 +147,39 @@ def _gpu_worker(rank, world, port, dbdir, npz, out, seq_mode):
     b, o, lo, hi = parallel.shard_reads(g["bases"], g["offs"], rank, world)
     dev = torch.device("cuda:0")
     st = parallel.GpuStages(ctx, ix, p, dev)
+    st.overlapping = not os.environ.get("MTB_TEST_PART_LEGACY")
     st.set_reads(torch.from_numpy(b.copy()).to(dev), torch.from_numpy(o.astype(np.int64)).to(dev), hi - lo)
     res, tt, tc = parallel.classify_partitioned(st, bounds, dist)
+    slot_reads = int(ctx.last_stats().n_slot_reads) if st.overlapping else -1
     gathered = [None] * world
-    dist.all_gather_object(gathered, (lo, hi, res["classification"].tolist(), res["score"].tolist(), tt.tolist(), tc.tolist(), ix.num_targets))
+    dist.all_gather_object(gathered, (lo, hi, res["classification"].tolist(), res["score"].tolist(), tt.tolist(), tc.tolist(), ix.num_targets, slot_reads))
     if rank == 0:
         n = len(g["offs"]) - 1
         cls = np.zeros(n, np.int32); sc = np.zeros(n, np.float32); att, atc = [], []; T = 0
-        for lo_, hi_, c, s, t1, t2, tn in gathered:
+        slot_ok = True
+        for lo_, hi_, c, s, t1, t2, tn, sr in gathered:
             cls[lo_:hi_] = c; sc[lo_:hi_] = s; att += t1; atc += t2; T += tn
-        np.savez(out, cls=cls, score=sc, tt=np.array(att, np.int32), tc=np.array(atc, np.uint32), T=T)
+            slot_ok = slot_ok and (sr == -1 or sr == hi_ - lo_)      # the product path really took the slot segments
+        np.savez(out, cls=cls, score=sc, tt=np.array(att, np.int32), tc=np.array(atc, np.uint32), T=T, slot_ok=slot_ok)
     dist.barrier()
     ix.close(); ctx.close()
     dist.destroy_process_group()
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 3])
-def test_gpu_partitioned_two_processes(orc, tmp_path, world):
+@pytest.mark.parametrize("world,legacy", [(2, False), (3, False), (2, True)])
+def test_gpu_partitioned_two_processes(orc, tmp_path, world, legacy, monkeypatch):
+    """legacy = False: the product path (ordinal tags, prefix-granular overlapping runs, directory join at the owners, matches placed
+    into the home rank's slot segments, slot scorers); True: consecutive runs, regroup + segment sort at home"""
     from conftest import Toy
     t = Toy(orc, tmp_path / "db", syncmer=1, paired=False, seed=23, n_reads=200)
     npz = str(tmp_path / "in.npz"); out = str(tmp_path / "out.npz")
     np.savez(npz, bases=t.b1, offs=t.o1)
+    if legacy:
+        monkeypatch.setenv("MTB_TEST_PART_LEGACY", "1")
     mp.spawn(_gpu_worker, args=(world, 30700 + os.getpid() % 500, t.dbdir, npz, out, 1), nprocs=world, join=True)
     _check(out, t.ref)
-    assert int(np.load(out)["T"]) == len(t.values)
+    assert int(np.load(out)["T"]) == len(t.values) and bool(np.load(out)["slot_ok"])
 
 
 @pytest.mark.gpu
