@@ -233,6 +233,20 @@ mtb_status mtb_classify_batch_device(mtb_ctx *, mtb_index *, const mtb_params *,
                                      mtb_result *d_results, int32_t *d_taxcnt_tax,
                                      uint32_t *d_taxcnt_cnt, uint64_t taxcnt_cap,
                                      uint64_t *n_taxcnt);
+/* Host ingest at device rate (the reference has a single kseq producer per file, KmerExtractor.cpp:122-171).
+ * mtb_host_alloc / mtb_host_free: pinned host memory for the caller's batch buffers (H2D / D2H copies of pageable memory run at
+ * a fraction of the link rate).
+ * mtb_classify_batch_packed: mtb_classify_batch with the bases as 2-bit codes -- packed2 holds 2 bits per base (A 0, C 1, T 2,
+ * G 3 = GeneticCode's nuc2int order; IUPAC codes mapped as the reference's atcg table maps them), nmask 1 bit per base (set =
+ * not a base: N, '.', ...), lens[r] the bases of read r; every read starts at a fresh group of 8 bases in both arrays (read r
+ * at group sum_{q<r} ceil(lens[q] / 8)).  0.375 bytes per base cross PCIe instead of 1; a device kernel rebuilds the text
+ * (invalid bases as 'N') for the extractor, so the results equal those of the text entry point.  Mates likewise (seq_mode 2). */
+void      *mtb_host_alloc(size_t bytes);
+void       mtb_host_free(void *);
+mtb_status mtb_classify_batch_packed(mtb_ctx *, mtb_index *, const mtb_params *, const uint8_t *packed2, const uint8_t *nmask,
+                                     const uint32_t *lens, const uint8_t *packed2_mate, const uint8_t *nmask_mate,
+                                     const uint32_t *lens_mate, uint64_t n_reads, mtb_result *results, int32_t *taxcnt_tax,
+                                     uint32_t *taxcnt_cnt, uint64_t taxcnt_cap, uint64_t *n_taxcnt);
 mtb_status mtb_last_batch_stats(mtb_ctx *, mtb_batch_stats *out);
 /* Diagnostic, outside any timed region: the index-side working set of the LAST mtb_classify_batch* call of this context
  * when it took the directory join (short reads, index with a directory): distinct directory buckets its query metamers fall

@@ -24,13 +24,16 @@
  *          reads), and <base>_classifications.tsv / <base>_report.tsv; <base> = LocalUtil::getQueryBaseName (LocalUtil.cpp:5-20).
  *          (In the reference snapshot the match loop of filterReads is stubbed out, QueryFilter.cpp:172-175, so it keeps every
  *          read; this implements the documented behaviour of the command.)
- *   own flags: --max-reads N (host batch)  --partitioned 1 (with --devices: engine d holds value range d of the database -- for
+ *   own flags: --max-reads N (host batch)  --pack-reads 0|1 (default 1: the reads cross PCIe as 2-bit codes + invalid mask out of
+ *          pinned buffers, mtb_classify_batch_packed; 0: as text)  --partitioned 1 (with --devices: engine d holds value range d of the database -- for
  *          databases larger than one GPU's HBM; metamers and matches are exchanged between the GPUs)
  *          --device N | --devices 0,1,... (one engine per GPU: every host batch is cut into
  *          contiguous read ranges, one per device, classified concurrently, results concatenated in input order and
  *          the per-taxon counts summed -- reads are independent, Classifier.cpp:187-203)
  */
 #include <cstdio>
+#include <sys/mman.h>
+#include <unistd.h>
 #include <cstring>
 #include <fstream>
 #include <algorithm>
@@ -40,12 +43,14 @@
 #include <sstream>
 #include <unordered_map>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
 
 #include "../../../include/mtb.hpp"
+#include "../mtb_core.h"         /* mtb_build_tables: the extractor's base classes, for the 2-bit packing of the reads */
 #include "fastx.h"
 
 namespace {
@@ -53,9 +58,24 @@ namespace {
 /* one batch travelling through the pipeline */
 struct Job {
     mtbhost::FlatBatch r1, r2;
-    std::vector<mtb_result> res; mtbhost::PodVec<int32_t> tt; mtbhost::PodVec<uint32_t> tc;      /* taxcnt lists: never zero-filled */
+    mtbhost::PodVec<mtb_result> res; mtbhost::PodVec<int32_t> tt; mtbhost::PodVec<uint32_t> tc;      /* never zero-filled */
     bool last = false;
+    /* what crosses PCIe lives in pinned host memory (mtb_host_alloc): 2-bit reads up, results and taxID:count lists down */
+    void pin() {
+        for (mtbhost::FlatBatch *b : {&r1, &r2}) { b->packed2.set_allocator(mtb_host_alloc, mtb_host_free); b->nmask.set_allocator(mtb_host_alloc, mtb_host_free); b->lens.set_allocator(mtb_host_alloc, mtb_host_free); }
+        res.set_allocator(mtb_host_alloc, mtb_host_free); tt.set_allocator(mtb_host_alloc, mtb_host_free); tc.set_allocator(mtb_host_alloc, mtb_host_free);
+    }
+    void reset() { r1.clear(); r2.clear(); res.clear(); tt.clear(); tc.clear(); last = false; }
 };
+
+/* small non-negative / signed integers without snprintf (the formatter printed three numbers per read through it) */
+inline void append_int(std::string &out, long long v) {
+    char buf[24]; int n = 0;
+    unsigned long long u = v < 0 ? (unsigned long long)(-v) : (unsigned long long)v;
+    do { buf[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+    if (v < 0) out += '-';
+    while (n) out += buf[--n];
+}
 
 /* bounded single-producer / single-consumer hand-over */
 template <class T> class Channel {
@@ -102,22 +122,53 @@ void format_reads(const Job &j, size_t lo, size_t hi, const mtb_index *ix, bool 
         const mtb_result &r = j.res[i];
         out += r.is_classified ? '1' : '0'; out += '\t';
         out.append(j.r1.names.data() + j.r1.name_offs[i], j.r1.names.data() + j.r1.name_offs[i + 1]); out += '\t';
-        int n = snprintf(num, sizeof(num), "%d\t%d\t%g\t", mtb_tax_original_id(ix, r.classification), r.query_length + r.query_length2, (double)r.score);
-        out.append(num, (size_t)n);
+        append_int(out, mtb_tax_original_id(ix, r.classification)); out += '\t';
+        append_int(out, r.query_length + r.query_length2); out += '\t';
+        if (r.score == 0.0f) out += '0'; else if (r.score == 1.0f) out += '1';
+        else { const int n = snprintf(num, sizeof(num), "%g", (double)r.score); out.append(num, (size_t)n); }       /* an ostream's float: 6 significant digits */
+        out += '\t';
         if (r.is_classified) {
             out += mtb_tax_rank(ix, r.classification); out += '\t';
             if (lineage) { append_lineage(ix, r.classification, out); out += '\t'; }
             for (uint32_t k = 0; k < r.n_taxcnt; k++) {
-                n = snprintf(num, sizeof(num), "%d:%u ", mtb_tax_original_id(ix, j.tt[r.taxcnt_off + k]), j.tc[r.taxcnt_off + k]);
-                out.append(num, (size_t)n);
+                append_int(out, mtb_tax_original_id(ix, j.tt[r.taxcnt_off + k])); out += ':';
+                append_int(out, j.tc[r.taxcnt_off + k]); out += ' ';
             }
             out += '\n';
         } else out += lineage ? "-\t-\t-\t\n" : "-\t-\t\n";
     }
 }
 
+/* The rows of a batch (one string per formatting piece) appended to `out`.  One thread writing 60 bytes per read through
+ * write(2) tops out near 2 GB/s (35 M reads/s); parallel pwrite()s into one file serialise on the inode lock (measured: slower).
+ * So the file is grown by the batch's size, that range is mapped, and the pieces are copied into the mapping in parallel -- the page
+ * cache fills through page faults, which do not take the inode's write lock.  Falls back to fwrite if the mapping fails. */
+void append_parts(FILE *out, const std::vector<std::string> &parts, mtbhost::WorkerPool &pool, std::string &err) {
+    size_t total = 0;
+    for (auto &p : parts) total += p.size();
+    if (total == 0) return;
+    fflush(out);
+    const off_t at = ftello(out);
+    const int fd = fileno(out);
+    const long page = sysconf(_SC_PAGESIZE);
+    const off_t map_at = at / page * page;
+    const size_t lead = (size_t)(at - map_at);
+    void *m = MAP_FAILED;
+    if (total >= (1u << 20) && ftruncate(fd, at + (off_t)total) == 0) m = mmap(nullptr, lead + total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, map_at);
+    if (m == MAP_FAILED) {
+        for (auto &p : parts) if (fwrite(p.data(), 1, p.size(), out) != p.size()) err = "short write";
+        return;
+    }
+    std::vector<size_t> off(parts.size() + 1, 0);
+    for (size_t t = 0; t < parts.size(); t++) off[t + 1] = off[t] + parts[t].size();
+    char *dst = (char *)m + lead;
+    pool.run(parts.size(), [&](size_t t) { if (!parts[t].empty()) memcpy(dst + off[t], parts[t].data(), parts[t].size()); });
+    munmap(m, lead + total);
+    fseeko(out, at + (off_t)total, SEEK_SET);
+}
+
 /* QueryFilter::printFilteredReads (QueryFilter.cpp:102-118): ">name\nsequence\n" of the reads [lo, hi) whose is_classified flag equals `classified` */
-void format_fasta(const mtbhost::FlatBatch &r, const std::vector<mtb_result> &res, size_t lo, size_t hi, bool classified, std::string &out) {
+void format_fasta(const mtbhost::FlatBatch &r, const mtbhost::PodVec<mtb_result> &res, size_t lo, size_t hi, bool classified, std::string &out) {
     out.clear();
     for (size_t i = lo; i < hi; i++) {
         if ((res[i].is_classified != 0) != classified) continue;
@@ -216,8 +267,8 @@ void write_krona(FILE *fp, const CladeTable &ct, unsigned long total) {
 int main(int argc, char **argv) {
     mtb_params par; mtb_default_params(&par);
     std::string taxdir; std::vector<int> devices(1, 0); size_t max_reads = 2000000;
-    int threads = (int)std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
-    bool lineage = false, filter = false, min_score_given = false, partitioned = false; int print_mode = 1;
+    int threads = (int)std::max(1u, std::min(128u, std::thread::hardware_concurrency()));
+    bool lineage = false, filter = false, min_score_given = false, partitioned = false, pack = true; int print_mode = 1;
     std::vector<std::string> pos;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -238,6 +289,7 @@ int main(int argc, char **argv) {
         else if (a == "--max-reads") max_reads = (size_t)atoll(val().c_str());
         else if (a == "--device") { devices.assign(1, atoi(val().c_str())); }
         else if (a == "--partitioned") partitioned = atoi(val().c_str()) != 0;
+        else if (a == "--pack-reads") pack = atoi(val().c_str()) != 0;
         else if (a == "--devices") { devices.clear(); std::stringstream ss(val()); std::string tok; while (std::getline(ss, tok, ',')) if (!tok.empty()) devices.push_back(atoi(tok.c_str())); }
         else if (a == "--reduced-aa") { if (atoi(val().c_str()) != 0) { fprintf(stderr, "mtb_classify: --reduced-aa 1 is not implemented\n"); return 1; } }
         else if (a == "--mask") {       /* tantan masking of the reads before extraction (KmerExtractor.cpp:308-314) changes the answers: refuse it rather than ignore it */
@@ -259,6 +311,7 @@ int main(int argc, char **argv) {
         return 1;
     }
     if (filter && !min_score_given) par.min_score = 0.5f;     /* setFilterDefaults, filter.cpp:8 */
+    if (partitioned) pack = false;                             /* (the partitioned batch takes the text) */
     const std::string dbdir = pos[paired ? 2 : 1];
     /* classify: <OUTDIR>/<JobID>_*; filter: <base of the first input>_* (QueryFilter.cpp:75-93) */
     const std::string base1 = filter ? query_base_name(pos[0]) : std::string(), base2 = filter && paired ? query_base_name(pos[1]) : std::string();
@@ -291,16 +344,24 @@ int main(int argc, char **argv) {
         }
         fputs(lineage ? "#is_classified\tname\ttaxID\tquery_length\tscore\trank\tlineage\ttaxID:match_count\n"
                       : "#is_classified\tname\ttaxID\tquery_length\tscore\trank\ttaxID:match_count\n", out);
-        Channel<Job> parsed(2), scored(2);
+        Channel<Job> parsed(2), scored(2), idle(4);
+        /* three batches are in flight (parse / GPU / format); their buffers are recycled, so that after the first round no stage
+         * touches fresh pages, and what crosses PCIe sits in pinned memory */
+        for (int k = 0; k < 3; k++) { std::unique_ptr<Job> j(new Job()); if (pack) j->pin(); idle.put(std::move(j)); }
+        mtbhost::WorkerPool parse_pool(threads), format_pool(threads);
+        mtbhost::PackTable pack_table;
+        { static mtb_tables tabs; mtb_build_tables(&tabs); for (int c = 0; c < 256; c++) pack_table.code[c] = tabs.base[c] < 4 ? tabs.base[c] : 0xFF; }
         std::string reader_err, writer_err;
         /* stage 1: parse */
         std::thread reader([&] {
             try {
-                mtbhost::FastxReader r1(pos[0], threads);
+                mtbhost::FastxReader r1(pos[0], threads, 64u << 20, &parse_pool);
                 std::unique_ptr<mtbhost::FastxReader> r2;
-                if (paired) r2.reset(new mtbhost::FastxReader(pos[1], threads));
+                if (paired) r2.reset(new mtbhost::FastxReader(pos[1], threads, 64u << 20, &parse_pool));
+                if (pack) { r1.set_pack(&pack_table, filter); if (r2) r2->set_pack(&pack_table, filter); }      /* the text is only kept for the filter command's FASTA output */
                 for (;;) {
-                    std::unique_ptr<Job> j(new Job());
+                    std::unique_ptr<Job> j = idle.get();
+                    j->reset();
                     const double t0 = now();
                     r1.next_batch(max_reads, j->r1);
                     if (paired) { r2->next_batch(j->r1.size(), j->r2); if (j->r2.size() != j->r1.size()) throw std::runtime_error("mate file is shorter"); }
@@ -316,31 +377,27 @@ int main(int argc, char **argv) {
         std::vector<uint64_t> tax_counts((size_t)mtb_tax_max_id(eng.index) + 2, 0);
         unsigned long total = 0;
         std::thread writer([&] {
-            std::vector<std::string> parts((size_t)threads);
+            const size_t NP = (size_t)threads * 2;                       /* pieces: a few per worker, reads differ in their row length */
+            std::vector<std::string> parts(NP);
             for (;;) {
                 std::unique_ptr<Job> j = scored.get();
                 if (j->last) break;
                 const double t0 = now();
                 const size_t n = j->r1.size();
-                std::vector<std::thread> th;
-                for (int t = 0; t < threads; t++)
-                    th.emplace_back([&, t] { format_reads(*j, n * (size_t)t / (size_t)threads, n * (size_t)(t + 1) / (size_t)threads, eng.index, lineage, parts[(size_t)t]); });
-                for (auto &x : th) x.join();
-                for (auto &p : parts) if (fwrite(p.data(), 1, p.size(), out) != p.size()) writer_err = "short write";
+                format_pool.run(NP, [&](size_t t) { format_reads(*j, n * t / NP, n * (t + 1) / NP, eng.index, lineage, parts[t]); });
+                append_parts(out, parts, format_pool, writer_err);
                 for (int mate = 0; mate < 2; mate++) for (int cls = 0; cls < 2; cls++) {
                     FILE *f = cls ? rmv[mate] : flt[mate];
                     if (!f) continue;
                     const mtbhost::FlatBatch &rb = mate ? j->r2 : j->r1;
-                    std::vector<std::thread> t2;
-                    for (int t = 0; t < threads; t++)
-                        t2.emplace_back([&, t] { format_fasta(rb, j->res, n * (size_t)t / (size_t)threads, n * (size_t)(t + 1) / (size_t)threads, cls != 0, parts[(size_t)t]); });
-                    for (auto &x : t2) x.join();
+                    format_pool.run(NP, [&](size_t t) { format_fasta(rb, j->res, n * t / NP, n * (t + 1) / NP, cls != 0, parts[t]); });
                     for (auto &p : parts) if (fwrite(p.data(), 1, p.size(), f) != p.size()) writer_err = "short write";
                 }
                 for (size_t i = 0; i < n; i++) { int32_t c = j->res[i].classification; if (c >= 0 && (size_t)c < tax_counts.size()) tax_counts[(size_t)c]++; }
                 total += n;
                 t_write += now() - t0;
                 std::cout << "The number of processed sequences: " << total << std::endl;
+                idle.put(std::move(j));                                  /* its buffers serve the next batch */
             }
         });
         /* stage 2: the GPUs.  A host batch is cut into ND contiguous read ranges; range d runs on engine d from its own host
@@ -353,8 +410,17 @@ int main(int argc, char **argv) {
             if (!gpu_err.empty()) continue;                  /* drain the reader after a failure */
             const double t0 = now();
             const size_t n = j->r1.size();
-            j->res.resize(n);
+            j->res.resize_uninit(n);
             std::vector<Range> rg(ND);
+            /* 2-bit reads: the group (8 bases) at which every engine's read range starts in the packed arrays */
+            std::vector<uint64_t> slot_lo(ND + 1, 0), slot2_lo(ND + 1, 0);
+            if (pack && ND > 1) {
+                size_t d = 1; uint64_t a1 = 0, a2 = 0;
+                for (size_t i = 0; i < n && d <= ND; i++) {
+                    while (d <= ND && i == n * d / ND) { slot_lo[d] = a1; slot2_lo[d] = a2; d++; }
+                    a1 += (j->r1.lens[i] + 7u) >> 3; if (paired) a2 += (j->r2.lens[i] + 7u) >> 3;
+                }
+            }
             auto run = [&](size_t d) {
                 Range &R = rg[d];
                 const size_t lo = n * d / ND, hi = n * (d + 1) / ND, m = hi - lo;
@@ -366,11 +432,16 @@ int main(int argc, char **argv) {
                 if (paired) { c0 = j->r2.offs[lo]; R.offs2.resize(m + 1); for (size_t i = 0; i <= m; i++) R.offs2[i] = j->r2.offs[lo + i] - c0; }
                 mtb_params pd = par;
                 size_t cap = 24 * m + 4096;                  /* the device side needs one slot per position bucket (18 for 150 bp reads); more -> exact retry */
+                if (ND == 1) { R.tt = std::move(j->tt); R.tc = std::move(j->tc); }       /* the job's own (pinned, recycled) buffers */
                 for (;;) {
                     R.tt.resize_uninit(cap); R.tc.resize_uninit(cap);
-                    mtb_status st = mtb_classify_batch(engs[d]->ctx, engs[d]->index, &pd, j->r1.bases.data() + b0, R.offs.data(),
-                                                       paired ? j->r2.bases.data() + c0 : nullptr, paired ? R.offs2.data() : nullptr, m,
-                                                       j->res.data() + lo, R.tt.data(), R.tc.data(), cap, &R.ntc);
+                    mtb_status st = pack
+                        ? mtb_classify_batch_packed(engs[d]->ctx, engs[d]->index, &pd, j->r1.packed2.data() + 2 * slot_lo[d], j->r1.nmask.data() + slot_lo[d], j->r1.lens.data() + lo,
+                                                    paired ? j->r2.packed2.data() + 2 * slot2_lo[d] : nullptr, paired ? j->r2.nmask.data() + slot2_lo[d] : nullptr,
+                                                    paired ? j->r2.lens.data() + lo : nullptr, m, j->res.data() + lo, R.tt.data(), R.tc.data(), cap, &R.ntc)
+                        : mtb_classify_batch(engs[d]->ctx, engs[d]->index, &pd, j->r1.bases.data() + b0, R.offs.data(),
+                                             paired ? j->r2.bases.data() + c0 : nullptr, paired ? R.offs2.data() : nullptr, m,
+                                             j->res.data() + lo, R.tt.data(), R.tc.data(), cap, &R.ntc);
                     if (st == MTB_ERR_CAPACITY && R.ntc > cap) { cap = R.ntc; continue; }
                     if (st != MTB_OK) R.err = mtb_last_error();
                     else { mtb_batch_stats bs; if (mtb_last_batch_stats(engs[d]->ctx, &bs) == MTB_OK) R.dev_ms = bs.ms_total; }

@@ -55,6 +55,26 @@ __global__ __launch_bounds__(256) void k_taxcnt_pack(mtb_result *__restrict__ re
     res[i].taxcnt_off = (uint32_t)dst;
 }
 
+/* 2-bit reads (mtb_classify_batch_packed): slots of 8 bases a read needs; bases of read r written as text behind offs[r] */
+__global__ __launch_bounds__(256) void k_pack_slots(const uint32_t *__restrict__ lens, uint64_t n, uint32_t *__restrict__ slots) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) slots[i] = (lens[i] + 7u) >> 3;
+}
+__global__ __launch_bounds__(64) void k_unpack_reads(const uint8_t *__restrict__ packed2, const uint8_t *__restrict__ nmask, const uint64_t *__restrict__ offs,
+                                                     const uint64_t *__restrict__ slot_off, uint64_t n, char *__restrict__ bases) {
+    for (uint64_t r = blockIdx.x; r < n; r += gridDim.x) {
+        const uint64_t o = offs[r], s0 = slot_off[r];
+        const uint32_t L = (uint32_t)(offs[r + 1] - o);
+        for (uint32_t k = threadIdx.x; k < L; k += 64) {            /* one base per lane: a wave writes 64 consecutive bytes */
+            const uint64_t g = s0 + (k >> 3); const uint32_t j = k & 7u;
+            const uint32_t w = (uint32_t)packed2[2 * g] | ((uint32_t)packed2[2 * g + 1] << 8);
+            const bool bad = (nmask[g] >> j) & 1u;
+            const uint32_t c = (w >> (2 * j)) & 3u;
+            bases[o + k] = bad ? 'N' : (char)((0x47544341u >> (8 * c)) & 0xFFu);       /* "ACTG": GeneticCode's nuc2int order */
+        }
+    }
+}
+
 struct DevBuf { void *p = nullptr; size_t cap = 0; };
 
 struct mtb_ctx {
@@ -87,7 +107,7 @@ struct mtb_ctx {
     const mtb_kmer *last_sorted = nullptr; uint64_t last_sorted_n = 0;       /* the last fused slot-path batch's sorted metamers (mtb_ctx_join_footprint) */
 };
 /* buffers that carry a call's inputs / outputs (host-buffer entry points) are not workspace */
-static bool is_io_buf(const std::string &n) { return n == "bases" || n == "offs" || n == "bases2" || n == "offs2" || n == "results" || n == "tctax" || n == "tccnt"; }
+static bool is_io_buf(const std::string &n) { return n == "bases" || n == "offs" || n == "bases2" || n == "offs2" || n == "results" || n == "tctax" || n == "tccnt" || n.compare(0, 2, "pk") == 0; }
 static size_t held_bytes(const mtb_ctx *c) { size_t b = 0; for (auto &kv : c->bufs) if (!is_io_buf(kv.first)) b += kv.second.cap; return b; }
 /* the part of it that grows with the sub-batch (the slab pool of the large-segment scorer is bounded on its own) */
 static size_t scaling_bytes(const mtb_ctx *c) { size_t b = 0; for (auto &kv : c->bufs) if (!is_io_buf(kv.first) && kv.first != "slabs") b += kv.second.cap; return b; }
@@ -1839,6 +1859,63 @@ mtb_status mtb_classify_batch(mtb_ctx *c, mtb_index *ix, const mtb_params *p, co
     mtb_result *d_res; int32_t *d_tt; uint32_t *d_tc;
     STCHK(ensure(c, "results", n_reads, &d_res)); STCHK(ensure(c, "tctax", taxcnt_cap, &d_tt)); STCHK(ensure(c, "tccnt", taxcnt_cap, &d_tc));
     mtb_status st = mtb_classify_batch_device(c, ix, p, d_b, d_o, d_b2, d_o2, n_reads, nb, d_res, d_tt, d_tc, taxcnt_cap, n_taxcnt);
+    if (st != MTB_OK) return st;
+    if (c->lanes.size() < 2 && *n_taxcnt) return download_packed(c, d_res, d_tt, d_tc, n_reads, results, taxcnt_tax, taxcnt_cnt, n_taxcnt);
+    STCHK(d2h(c, results, d_res, n_reads * sizeof(mtb_result)));
+    if (*n_taxcnt) { STCHK(d2h(c, taxcnt_tax, d_tt, *n_taxcnt * 4)); STCHK(d2h(c, taxcnt_cnt, d_tc, *n_taxcnt * 4)); }
+    return MTB_OK;
+}
+
+/* Host ingest at device rate: pinned host memory for the batch buffers, and the bases as 2-bit codes. */
+void *mtb_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+void mtb_host_free(void *p) { if (p) { hipError_t e = hipHostFree(p); (void)e; } }
+
+static mtb_status upload_packed(mtb_ctx *c, const char *tag, const uint8_t *packed2, const uint8_t *nmask, const uint32_t *lens, uint64_t n_reads,
+                                char **d_bases, uint64_t **d_offs, uint64_t *n_bases) {
+    const std::string t(tag);
+    uint64_t slots = 0;
+    for (uint64_t i = 0; i < n_reads; i++) slots += (lens[i] + 7u) >> 3;
+    uint8_t *d_p2, *d_nm; uint32_t *d_len, *d_sl; uint64_t *d_so, *d_ws;
+    STCHK(ensure(c, ("pk2" + t).c_str(), slots * 2 + 8, &d_p2)); STCHK(ensure(c, ("pkm" + t).c_str(), slots + 8, &d_nm));
+    STCHK(ensure(c, ("pklen" + t).c_str(), n_reads, &d_len)); STCHK(ensure(c, ("pksl" + t).c_str(), n_reads, &d_sl)); STCHK(ensure(c, ("pkso" + t).c_str(), n_reads + 1, &d_so));
+    STCHK(ensure(c, ("offs" + t).c_str(), n_reads + 1, d_offs)); STCHK(ensure(c, "scanws", scan_ws_elems(n_reads + 1), &d_ws));
+    HIPCHK(hipMemcpyAsync(d_p2, packed2, slots * 2, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d_nm, nmask, slots, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d_len, lens, n_reads * 4, hipMemcpyHostToDevice, c->stream));
+    scan_launch<uint32_t, uint64_t, false>(c->stream, d_len, n_reads, true, *d_offs, d_ws);
+    hipLaunchKernelGGL(k_pack_slots, dim3((uint32_t)((n_reads + 255) / 256)), dim3(256), 0, c->stream, (const uint32_t *)d_len, n_reads, d_sl);
+    scan_launch<uint32_t, uint64_t, false>(c->stream, d_sl, n_reads, true, d_so, d_ws);
+    uint64_t nb = 0;
+    STCHK(d2h(c, &nb, *d_offs + n_reads, 8));
+    STCHK(ensure(c, ("bases" + t).c_str(), nb + 8, d_bases));
+    hipLaunchKernelGGL(k_unpack_reads, dim3((uint32_t)std::min<uint64_t>(n_reads, 256ull * 64)), dim3(64), 0, c->stream, (const uint8_t *)d_p2, (const uint8_t *)d_nm,
+                       (const uint64_t *)*d_offs, (const uint64_t *)d_so, n_reads, *d_bases);
+    HIPCHK(hipGetLastError());
+    *n_bases = nb;
+    return MTB_OK;
+}
+
+mtb_status mtb_classify_batch_packed(mtb_ctx *c, mtb_index *ix, const mtb_params *p, const uint8_t *packed2, const uint8_t *nmask, const uint32_t *lens,
+                                     const uint8_t *packed2_mate, const uint8_t *nmask_mate, const uint32_t *lens_mate, uint64_t n_reads,
+                                     mtb_result *results, int32_t *taxcnt_tax, uint32_t *taxcnt_cnt, uint64_t taxcnt_cap, uint64_t *n_taxcnt) {
+    if (!c || !ix || !p || !n_taxcnt) return fail(MTB_ERR_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(c->device));
+    *n_taxcnt = 0;
+    if (n_reads == 0) return MTB_OK;
+    if (!packed2 || !nmask || !lens) return fail(MTB_ERR_ARG, "packed2/nmask/lens NULL");
+    char *d_b = nullptr, *d_b2 = nullptr; uint64_t *d_o = nullptr, *d_o2 = nullptr; uint64_t nb = 0, nb2 = 0;
+    STCHK(upload_packed(c, "", packed2, nmask, lens, n_reads, &d_b, &d_o, &nb));
+    if (p->seq_mode == 2) {
+        if (!packed2_mate || !nmask_mate || !lens_mate) return fail(MTB_ERR_ARG, "seq_mode 2 needs the mates");
+        STCHK(upload_packed(c, "2", packed2_mate, nmask_mate, lens_mate, n_reads, &d_b2, &d_o2, &nb2));
+    }
+    mtb_result *d_res; int32_t *d_tt; uint32_t *d_tc;
+    STCHK(ensure(c, "results", n_reads, &d_res)); STCHK(ensure(c, "tctax", taxcnt_cap, &d_tt)); STCHK(ensure(c, "tccnt", taxcnt_cap, &d_tc));
+    mtb_status st = mtb_classify_batch_device(c, ix, p, d_b, d_o, d_b2, d_o2, n_reads, nb + nb2, d_res, d_tt, d_tc, taxcnt_cap, n_taxcnt);
     if (st != MTB_OK) return st;
     if (c->lanes.size() < 2 && *n_taxcnt) return download_packed(c, d_res, d_tt, d_tc, n_reads, results, taxcnt_tax, taxcnt_cnt, n_taxcnt);
     STCHK(d2h(c, results, d_res, n_reads * sizeof(mtb_result)));

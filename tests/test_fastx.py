@@ -17,8 +17,8 @@ def dump(tmp_path_factory):
     return exe
 
 
-def _run(dump, path, threads, block, batch):
-    out = subprocess.run([dump, path, str(threads), str(block), str(batch)], capture_output=True, check=True).stdout.decode()
+def _run(dump, path, threads, block, batch, *extra):
+    out = subprocess.run([dump, path, str(threads), str(block), str(batch)] + list(extra), capture_output=True, check=True).stdout.decode()
     return [tuple(l.split("\t")) for l in out.split("\n") if l]
 
 
@@ -69,3 +69,39 @@ def test_empty_and_garbage_inputs(dump, tmp_path):
     p.write_bytes(b"hello\n")
     r = subprocess.run([dump, str(p), "2", "1000", "10"], capture_output=True)
     assert r.returncode != 0 and b"neither FASTA nor FASTQ" in r.stderr
+
+
+def _bgzf(data: bytes, block=5000) -> bytes:
+    """blocked gzip as bgzip writes it (SAM specification 4.1): independent deflate blocks with their size in the 'BC' extra field"""
+    import struct
+    import zlib
+    out = bytearray()
+    for o in list(range(0, len(data), block)) + [None]:
+        chunk = b"" if o is None else data[o:o + block]           # the last, empty block is the end-of-file marker
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        comp = c.compress(chunk) + c.flush()
+        bsize = 12 + 6 + len(comp) + 8
+        out += struct.pack("<BBBBIBBH", 0x1F, 0x8B, 8, 4, 0, 0, 0xFF, 6) + b"BC" + struct.pack("<HH", 2, bsize - 1)
+        out += comp + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk))
+    return bytes(out)
+
+
+def test_bgzf_is_inflated_block_parallel_and_two_bit_packing(dump, tmp_path):
+    rng = np.random.default_rng(99)
+    recs, text = _records(rng, 900, True)
+    pz = tmp_path / "b.fq.gz"
+    pz.write_bytes(_bgzf(text.encode()))
+    assert gzip.decompress(pz.read_bytes()).decode() == text                # a valid multi-member gzip file as well
+    for threads, block, batch in ((4, 3000, 128), (8, 1 << 20, 10**6), (2, 64, 33)):
+        assert _run(dump, str(pz), threads, block, batch) == recs, (threads, block, batch)
+    # 2-bit codes + invalid mask (what crosses PCIe): the extractor's base classes (SURVEY Appendix A) -- A R W -> A, C M S -> C,
+    # H T Y -> T, B D G K U -> G, everything else invalid
+    cls = {}
+    for k, v in (("ARWarw", "A"), ("CMScms", "C"), ("HTYhty", "T"), ("BDGKUbdgku", "G")):
+        for ch in k:
+            cls[ch] = v
+    exp = [(n, "".join(cls.get(ch, "N") for ch in s)) for n, s in recs]
+    p = tmp_path / "x.fq"
+    p.write_bytes(text.encode())
+    assert _run(dump, str(p), 4, 3000, 100, "pack") == exp
+    assert _run(dump, str(pz), 3, 2000, 77, "pack") == exp
