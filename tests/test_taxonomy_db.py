@@ -108,3 +108,30 @@ def test_taxonomy_db_without_internal_ids_and_bad_version(emu, tmp_path):
     open(trunc, "wb").write(open(path, "rb").read()[:-7])
     rc, msg = _load_db(emu, trunc, np.zeros(0, np.int32))
     assert rc == 1
+
+
+@pytest.mark.parametrize("use_internal", [True, False])
+def test_two_independent_writers_read_alike(emu, tmp_path, use_internal):
+    """tests/taxdb_writer2.py restates the constructor + serialize() a second time without sharing code with the first writer:
+    compacted StringBlock (shared offsets), real Euler tour / sparse table, trailing unused bytes without internal ids, a wider M
+    matrix.  The reader must produce the same taxonomy from both files (and both must agree with the dump-file loader, above)."""
+    import taxdb_writer2 as tw2
+    w = _world(11)
+    merged = [(900001, _orig_id(5)), (900007, _orig_id(8))]
+    lines, names = _lines(w)
+    p1 = str(tmp_path / "w1"); p2 = str(tmp_path / "w2"); p3 = str(tmp_path / "w3")
+    o2i_1 = tw.write_taxonomy_db(p1, lines, names, merged, use_internal=use_internal)
+    o2i_2 = tw2.write(p2, lines, sorted(names.items()), merged, use_internal=use_internal)
+    tw2.write(p3, lines, sorted(names.items()), merged, use_internal=use_internal, flog2_bias=1, seed=3)
+    if use_internal:
+        assert o2i_1 == o2i_2
+    strains = [t for t, r in w.tax.rank.items() if r == "no rank" and t > 3]
+    ids = np.array([o2i_2[_orig_id(t)] for t in strains], np.int32)
+    rc1, a = _load_db(emu, p1, ids)
+    rc2, b = _load_db(emu, p2, ids)
+    rc3, c = _load_db(emu, p3, ids)
+    assert rc1 == 0 and rc2 == 0 and rc3 == 0, (a, b, c)
+    for key in ("canon", "parent", "depth", "under", "spp", "t2s", "acc", "orig"):
+        assert (a[key] == b[key]).all() and (a[key] == c[key]).all(), key
+    assert a["euk"] == b["euk"] == c["euk"] != 0
+    assert open(p1, "rb").read() != open(p2, "rb").read()          # (different bytes: string block and tour tables)
