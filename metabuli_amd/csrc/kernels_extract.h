@@ -24,6 +24,7 @@ struct ExtractArgs {
     uint64_t n_reads;
     int32_t seq_mode, syncmer, smer_len, kmer_format;
     int32_t tag_ord;      /* MODE 2: bits 16-31 of qinfo's position field carry the metamer's ordinal within its read */
+    int32_t dig_shift;    /* MODE 2 with dig_out: the letter pair whose base-21 digit is written next to every record (54 = the top pair: first pass of the bucket-local sort; 34 = LSD) */
 };
 
 /* MODE 0 = count pass, 1 = emit pass (deterministic reference order: the stage API), 2 = single pass for the fused
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(64) void k_extract(ExtractArgs a, const mtb_tables 
                 const mtb_kmer x = s_out[done + i];
                 out[chunk_pos + i] = x;
                 if (dig_out) {          /* first radix pass's digit (amino-acid letters 4,5 as a base-21 pair, kernels_sort.h) */
-                    uint32_t two = (uint32_t)(x.value >> 34) & 1023u, d = (two >> 5) * 21u + (two & 31u);
+                    uint32_t two = (uint32_t)(x.value >> a.dig_shift) & 1023u, d = (two >> 5) * 21u + (two & 31u);
                     dig_out[chunk_pos + i] = (uint16_t)(d < 511u ? d : 511u);
                 }
             }

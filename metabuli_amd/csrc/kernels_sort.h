@@ -105,6 +105,14 @@ __global__ __launch_bounds__(THREADS) void k_radix_hist_dig(const uint16_t *__re
     }
 }
 
+#define MTB_SORT_NBKT 512
+/* bucket of a tile: last b with first_tile[b] <= t */
+__device__ __forceinline__ uint32_t sort_tile_bucket(const uint32_t *__restrict__ first_tile, uint32_t t) {
+    uint32_t lo = 0, hi = MTB_SORT_NBKT;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (first_tile[mid] <= t) lo = mid; else hi = mid; }
+    return lo;
+}
+
 /* Scatter of one pass.  Every wavefront owns a contiguous eighth (THREADS/64-th) of the tile and ranks its records
  * on its own: per round the lanes with equal digits find each other with ballots, the first of them bumps the wave's
  * private counter of that digit and all take "counter before + rank among peers" -- LDS operations of one wave
@@ -113,7 +121,8 @@ __global__ __launch_bounds__(THREADS) void k_radix_hist_dig(const uint16_t *__re
 template <int NB, int MODE, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_radix_scatter(const mtb_kmer *__restrict__ in, mtb_kmer *__restrict__ out,
                                                             uint64_t n, int shift, const uint32_t *__restrict__ tile_off,
-                                                            uint32_t num_tiles, uint16_t *__restrict__ dig_out = nullptr, int next_shift = 0, int xcd_map = 1) {
+                                                            uint32_t num_tiles, uint16_t *__restrict__ dig_out = nullptr, int next_shift = 0, int xcd_map = 1,
+                                                            const uint32_t *__restrict__ plan = nullptr /* bucket-local pass: tiles and table are bucket-major */) {
     constexpr int BITS = NB == 256 ? 8 : 9;
     constexpr int NW = THREADS / 64;
     constexpr int TILE = THREADS * MTB_SORT_ITEMS;
@@ -127,11 +136,21 @@ __global__ __launch_bounds__(THREADS) void k_radix_scatter(const mtb_kmer *__res
     /* workgroups go to the 8 XCDs round-robin: XCD x takes the x-th eighth of the tiles in order, so that the runs of one bin
      * written by neighbouring tiles (adjacent in memory) meet in ONE L2 and leave it as whole lines, and the tile_off
      * sectors are fetched once per 16 tiles instead of once per tile */
+    if (plan) num_tiles = plan[513 + 512];
     const uint32_t per_xcd = (num_tiles + 7u) >> 3;
     const uint32_t tile = xcd_map ? (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
     if (tile >= num_tiles) return;
-    const uint64_t base = (uint64_t)tile * TILE;
-    const uint32_t my_off = t < NB ? tile_off[(uint64_t)t * num_tiles + tile] : 0u;          /* bin t of this tile: global start */
+    uint64_t base = (uint64_t)tile * TILE;
+    uint32_t my_off;
+    if (plan) {
+        const uint32_t *tfirst = plan + 513;
+        const uint32_t b = sort_tile_bucket(tfirst, tile);
+        const uint32_t j = tile - tfirst[b], ntb = tfirst[b + 1] - tfirst[b];
+        base = (uint64_t)plan[b] + (uint64_t)j * TILE;
+        n = plan[b + 1];                                                     /* the bucket's end bounds the (possibly partial) tile */
+        my_off = t < NB ? tile_off[(uint64_t)512 * tfirst[b] + (uint64_t)t * ntb + j] : 0u;
+    } else
+    my_off = t < NB ? tile_off[(uint64_t)t * num_tiles + tile] : 0u;          /* bin t of this tile: global start */
     mtb_kmer e[MTB_SORT_ITEMS];
     uint32_t lrank[MTB_SORT_ITEMS];
     if (t < NB) {
@@ -194,6 +213,78 @@ __global__ __launch_bounds__(THREADS) void k_radix_scatter(const mtb_kmer *__res
         const uint64_t dst = (uint64_t)(s_goff[d] + i);
         out[dst] = x;
         if (dig_out) dig_out[dst] = (uint16_t)radix_digit<MODE>(x.value, next_shift);      /* next pass's histogram input */
+    }
+}
+
+/* ---- bucket-local passes (fused path, kmer_format 2) -------------------------------------------------------------------------
+ * The three letter-pair passes used to be LSD: every pass scatters every tile's 441 runs over the whole 20 GB output, 441 open pages
+ * per tile, and the scatter is bound by address translation (UTCL2 busy 96 %, profiles/r02_notes.md).  Now the FIRST pass takes the
+ * TOP letter pair (the extractor knows it) and leaves 441 buckets of ~46 MB; the two lower pairs are then sorted INSIDE every bucket
+ * (low pair first, stable): same records moved, same final order (top, middle, low), but a tile's 441 runs of those two passes fall
+ * into one bucket = 23 pages.  A bucket is cut into tiles of its own (the last one partial); the tile list is bucket-major, and so is
+ * the histogram table (bucket, bin, tile-in-bucket) -- one global exclusive scan of it yields global destinations, because all
+ * records of bucket b precede those of bucket b + 1.
+ * plan[0 .. 512]   = first record of every bucket (plan[512] = n)        plan[513 .. 1025] = first tile of every bucket (last = tiles) */
+__global__ __launch_bounds__(512) void k_sort_plan(const uint32_t *__restrict__ scanned, uint32_t num_tiles, uint64_t n, uint32_t tile, uint32_t *__restrict__ plan) {
+    __shared__ uint32_t s_tmp[8];
+    const uint32_t b = threadIdx.x;
+    const uint32_t start = scanned[(uint64_t)b * num_tiles];               /* bin b of the first pass, tile 0: where the bucket begins */
+    const uint32_t next = b + 1 < MTB_SORT_NBKT ? scanned[(uint64_t)(b + 1) * num_tiles] : (uint32_t)n;
+    const uint32_t nt = (next - start + tile - 1) / tile;
+    uint32_t tot;
+    const uint32_t first = block_exclusive_scan<uint32_t, 8>(nt, s_tmp, &tot);
+    plan[b] = start; plan[513 + b] = first;
+    if (b == 0) { plan[512] = (uint32_t)n; plan[513 + 512] = tot; }
+}
+/* histogram of one bucket-local pass from the 2-byte digit side array; table entry of (bucket b, bin x, tile j of the bucket) =
+ * 512 * first_tile[b] + x * tiles_of(b) + j.  A workgroup takes MTB_HIST_GROUP consecutive tiles; inside one bucket it writes, per
+ * bin, their counts as one run (the common case), across a bucket boundary tile by tile. */
+template <int NB, int THREADS, int TILE = THREADS * MTB_SORT_ITEMS>
+__global__ __launch_bounds__(THREADS) void k_radix_hist_seg(const uint16_t *__restrict__ dig, const uint32_t *__restrict__ plan, uint32_t *__restrict__ hist) {
+    static_assert(NB == THREADS, "one bin per thread");
+    __shared__ uint32_t s_h[MTB_HIST_GROUP][NB];
+    const uint32_t *bstart = plan, *tfirst = plan + 513;
+    const uint32_t tiles = tfirst[512];
+    const uint32_t tile0 = blockIdx.x * MTB_HIST_GROUP;
+    if (tile0 >= tiles) return;
+#pragma unroll
+    for (int g = 0; g < MTB_HIST_GROUP; g++) s_h[g][threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t b0 = sort_tile_bucket(tfirst, tile0);
+    uint32_t b = b0;
+    for (int g = 0; g < MTB_HIST_GROUP; g++) {
+        const uint32_t t = tile0 + g;
+        if (t >= tiles) break;
+        while (tfirst[b + 1] <= t) b++;                                     /* (empty buckets own no tile) */
+        const uint32_t base = bstart[b] + (t - tfirst[b]) * TILE;
+        const uint32_t end = bstart[b + 1] < base + TILE ? bstart[b + 1] : base + TILE;
+        if (TILE == THREADS * 8 && end == base + TILE && (base & 7u) == 0) {
+            const uint4 q = *(const uint4 *)(dig + base + 8u * threadIdx.x);
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t d0 = w[k] & 0xFFFFu, d1 = w[k] >> 16;
+                atomicAdd(&s_h[g][d0 < NB ? d0 : NB - 1], 1u);
+                atomicAdd(&s_h[g][d1 < NB ? d1 : NB - 1], 1u);
+            }
+            continue;
+        }
+        for (uint32_t i = base + threadIdx.x; i < end; i += THREADS) { const uint32_t d = dig[i]; atomicAdd(&s_h[g][d < NB ? d : NB - 1], 1u); }
+    }
+    __syncthreads();
+    const uint32_t last = tile0 + MTB_HIST_GROUP <= tiles ? tile0 + MTB_HIST_GROUP - 1 : tiles - 1;
+    if (tfirst[b0 + 1] > last) {                                             /* all tiles of the group in bucket b0: one run per bin */
+        const uint32_t ntb = tfirst[b0 + 1] - tfirst[b0];
+        uint32_t *row = hist + (uint64_t)512 * tfirst[b0] + (uint64_t)threadIdx.x * ntb + (tile0 - tfirst[b0]);
+        for (uint32_t g = 0; g <= last - tile0; g++) row[g] = s_h[g][threadIdx.x];
+    } else {
+        uint32_t bb = b0;
+        for (uint32_t g = 0; g <= last - tile0; g++) {
+            const uint32_t t = tile0 + g;
+            while (tfirst[bb + 1] <= t) bb++;
+            const uint32_t ntb = tfirst[bb + 1] - tfirst[bb];
+            hist[(uint64_t)512 * tfirst[bb] + (uint64_t)threadIdx.x * ntb + (t - tfirst[bb])] = s_h[g][threadIdx.x];
+        }
     }
 }
 

@@ -390,6 +390,9 @@ static mtb_status h2d(mtb_ctx *c, void *dst, const void *src, size_t bytes) {
     return MTB_OK;
 }
 
+/* fused-path sort: first pass on the top letter pair, the two lower pairs bucket-local (kernels_sort.h); MTB_SORT_LSD=1: the three LSD passes of round 2 (A/B) */
+static bool sort_msd_first() { static const bool lsd = getenv("MTB_SORT_LSD") != nullptr; return !lsd; }
+
 /* extract.  Result in buffer "kmersA".  Two passes (counts -> offsets -> emit) give the reference's emission order
  * (stage API); `single_pass` (fused path, n_bases = bases of the batch) runs the arithmetic once and lets every
  * wave reserve its output with an atomic: run order arbitrary, which the radix sort does not mind. */
@@ -405,7 +408,7 @@ static mtb_status dev_extract(mtb_ctx *c, const mtb_params *p, const char *d_bas
     *count = 0; *out = nullptr;
     if (real_count) *real_count = 0;
     if (n_reads == 0) return MTB_OK;
-    ExtractArgs a{d_bases, d_offs, d_bases2, d_offs2, n_reads, p->seq_mode, p->syncmer, p->smer_len, p->kmer_format, (single_pass && tag_ord) ? 1 : 0};
+    ExtractArgs a{d_bases, d_offs, d_bases2, d_offs2, n_reads, p->seq_mode, p->syncmer, p->smer_len, p->kmer_format, (single_pass && tag_ord) ? 1 : 0, sort_msd_first() ? 54 : 34};
     /* grid sweep, 10 M reads: 7424 workgroups 23.5 ms, 16384 18.7, 65536 17.3, 262144 17.7 (and more blank tail records) */
     uint32_t grid = (uint32_t)std::min<uint64_t>(n_reads, 256ull * 256);
     HIPCHK(hipMemsetAsync(c->d_scal + 4, 0, 8, c->stream));
@@ -497,6 +500,36 @@ static mtb_status dev_sort(mtb_ctx *c, mtb_kmer *d_a, uint64_t n, int first_bit,
         if (dig_src) STCHK(ensure(c, "digB", n, &dig_dst));
         /* the directory join (kernels_dir.h) looks every query up on its own: the sort only buys locality of the directory /
          * target accesses, so the fused path may stop after fewer letter pairs (aa_first_shift: 34 = six letters, 44 = four, 54 = two) */
+        if (aa && dig_src && aa_first_shift == 34 && sort_msd_first()) {
+            /* pass A: the top letter pair, over the whole list (its digits came with the records); passes B, C: the low and the middle
+             * pair inside every bucket of pass A */
+            uint32_t *d_plan;
+            STCHK(ensure(c, "sortplan", 1026, &d_plan));
+            const uint32_t seg_tiles_max = tiles + MTB_SORT_NBKT;
+            STCHK(ensure(c, "hist", (uint64_t)bins * seg_tiles_max, &d_hist));
+            STCHK(ensure(c, "scanws", scan_ws_elems((uint64_t)bins * seg_tiles_max), &d_ws));
+            { KTimer kt(c, MTB_K_RADIX_HIST);
+              hipLaunchKernelGGL((k_radix_hist_dig<512, 512>), dim3((tiles + MTB_HIST_GROUP - 1) / MTB_HIST_GROUP), dim3(512), 0, c->stream, (const uint16_t *)dig_src, n, d_hist, tiles); }
+            { KTimer kt(c, MTB_K_SCAN); scan_launch<uint32_t, uint32_t, false>(c->stream, d_hist, (uint64_t)bins * tiles, false, d_hist, (uint32_t *)d_ws); }
+            hipLaunchKernelGGL(k_sort_plan, dim3(1), dim3(512), 0, c->stream, (const uint32_t *)d_hist, tiles, n, (uint32_t)tile, d_plan);
+            { KTimer kt(c, MTB_K_RADIX_SCATTER);
+              hipLaunchKernelGGL((k_radix_scatter<512, 1, 512>), dim3((tiles + 7u) / 8u * 8u), dim3(512), 0, c->stream, (const mtb_kmer *)src, dst, n, 54, (const uint32_t *)d_hist, tiles, dig_dst, 34, xcd_map); }
+            { mtb_kmer *tmp = src; src = dst; dst = tmp; uint16_t *t2 = dig_src; dig_src = dig_dst; dig_dst = t2; }
+            for (int shift = 34; shift <= 44; shift += 10) {
+                const dim3 hg((seg_tiles_max + MTB_HIST_GROUP - 1) / MTB_HIST_GROUP), sg((seg_tiles_max + 7u) / 8u * 8u);
+                { KTimer kt(c, MTB_K_RADIX_HIST);
+                  hipLaunchKernelGGL((k_radix_hist_seg<512, 512>), hg, dim3(512), 0, c->stream, (const uint16_t *)dig_src, (const uint32_t *)d_plan, d_hist); }
+                /* (the table's length is on the device: the scan covers the most it can be; entries behind the last tile are never read) */
+                { KTimer kt(c, MTB_K_SCAN); scan_launch<uint32_t, uint32_t, false>(c->stream, d_hist, (uint64_t)bins * seg_tiles_max, false, d_hist, (uint32_t *)d_ws); }
+                { KTimer kt(c, MTB_K_RADIX_SCATTER);
+                  hipLaunchKernelGGL((k_radix_scatter<512, 1, 512>), sg, dim3(512), 0, c->stream, (const mtb_kmer *)src, dst, n, shift, (const uint32_t *)d_hist, tiles,
+                                     shift == 34 ? dig_dst : (uint16_t *)nullptr, 44, xcd_map, (const uint32_t *)d_plan); }
+                { mtb_kmer *tmp = src; src = dst; dst = tmp; uint16_t *t2 = dig_src; dig_src = dig_dst; dig_dst = t2; }
+            }
+            *sorted = src;
+            HIPCHK(hipGetLastError());
+            return MTB_OK;
+        }
         for (int shift = aa ? aa_first_shift : first_bit; shift < 64; shift += aa ? 10 : 8) {
             { KTimer kt(c, MTB_K_RADIX_HIST);
               const dim3 hg((tiles + MTB_HIST_GROUP - 1) / MTB_HIST_GROUP);
