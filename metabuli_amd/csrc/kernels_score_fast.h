@@ -97,7 +97,8 @@ __global__ __launch_bounds__(64, K <= 3 ? 4 : 2) void k_score_fast(const mtb_slo
     __shared__ int32_t s_otax[MTB_FAST_BKT];
     __shared__ uint32_t s_ocnt[MTB_FAST_BKT];
     __shared__ int32_t s_lev[MTB_LR_MAXE], s_anc[MTB_LR_MAXE * MTB_LR_K];
-    __shared__ uint32_t s_pf[64];
+    __shared__ uint32_t s_pf[64];              /* landing zone of the slot prefetch (never read) */
+    __shared__ uint32_t s_tl[64];              /* tail matches of the read: their places in the compacted list */
     __shared__ uint32_t s_hcnt[256];            /* matches per species hash: lonely matches are dropped up front */
     const int32_t lane = (int32_t)threadIdx.x;
     MTB_BEGIN_ACQUIRE();
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(64, K <= 3 ? 4 : 2) void k_score_fast(const mtb_slo
                 FKey fk; fk.hi = ((uint32_t)(x[k].a >> 32) << 10) | (((bh >> 20) & 7u) << 7) | (ps_ >> 4);
                 fk.lo = ((ps_ & 15u) << 27) | (((bh >> 23) & 7u) << 24) | ((uint32_t)b & 0xFFFFFFu);
                 s_key[dst[k]] = fk;
-                s_aux[dst[k]] = (x[k].a & 0xFFFFFFFFull) | (((b >> 24) & 0xFFFFull) << 32);
+                s_aux[dst[k]] = (x[k].a & 0xFFFFFFFFull) | (((b >> 24) & 0xFFFFull) << 32) | ((uint32_t)lane + 64u * k >= direct ? (1ull << 63) : 0ull);      /* bit 63: from a tail slot */
             }
         }
         MTB_FAST_MARK(1);       /* species order + keys to LDS (includes the wait for the slot loads) */
@@ -202,6 +203,72 @@ __global__ __launch_bounds__(64, K <= 3 ? 4 : 2) void k_score_fast(const mtb_slo
         R.classification = 0; R.score = 0.0f; R.query_length = ql1; R.query_length2 = ql2; R.is_classified = 0; R.reserved = 0; R.n_taxcnt = 0; R.taxcnt_off = (uint32_t)tc_base;
         if (!slow && n == 0) { if (lane == 0) { cnt_out[r] = (uint32_t)n_live; results[r] = R; } continue; }
         wave_fence();
+        /* ---- tail matches into their places.  The further matches of a multi-match metamer sit in the read's tail slots, i.e. at the
+         * END of their run (species; for pairs species and frame) in the order above, whereas compareMatches wants them by (frame,)
+         * position among the run's direct matches -- which are in order among themselves.  So only the tail matches move: a direct
+         * match shifts behind the tail matches of its run with a smaller key, a tail match goes to (direct matches of its run with a
+         * smaller key) + (tail matches of its run with a smaller key).  A handful of tail matches per read at most (the tail's
+         * capacity); reads without any skip this.  Before, 5.2 % of the pairs left the fast path for this reason alone. ---- */
+        {
+            uint32_t nt = 0;
+            bool any_tail = false;
+#pragma unroll
+            for (int k = 0; k < KL; k++) any_tail |= live[k] && (uint32_t)lane + 64u * k >= direct;
+            /* pairs only: there the generic kernel costs 20 ns per read it takes over (320-record staging, 2 waves per SIMD), and the merge
+             * pays (12.5 M pairs: generic 21.5 -> 6.8 ms, this kernel 72 -> 77 ms); single reads lose (generic 2.9 -> 0.9 ms, this kernel
+             * 22.5 -> 26.5 ms: the merge costs about what the read's whole scoring does) and keep handing such reads over */
+            if (BYFRAME && !slow && __any(any_tail)) {
+                FKey ke[K]; uint64_t ax[K]; int32_t np[K]; bool tl[K];
+                const int32_t nsl = (n + 63) >> 6;
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    const int32_t i = lane + 64 * k;
+                    ke[k].lo = 0; ke[k].hi = 0; ax[k] = 0; np[k] = i; tl[k] = false;
+                    if (k < nsl && i < n) { ke[k] = s_key[i]; ax[k] = s_aux[i]; tl[k] = (ax[k] >> 63) != 0; }
+                    if (k < nsl) {
+                        const uint64_t tm = __ballot(tl[k]);
+                        if (tl[k]) { const uint32_t at = nt + (uint32_t)__popcll(tm & lt); if (at < 64u) s_tl[at] = (uint32_t)i; }
+                        nt += (uint32_t)__popcll(tm);
+                    }
+                }
+                if (nt > 64u) slow = true;
+                wave_fence();
+                if (!slow) {
+                    auto same_run = [&](const FKey &a, const FKey &b) { return BYFRAME ? ((a.hi ^ b.hi) >> 7) == 0 : ((a.hi ^ b.hi) >> 10) == 0; };
+                    auto less = [&](const FKey &a, const FKey &b) { return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); };
+                    for (uint32_t t = 0; t < nt; t++) {
+                        const int32_t ti = (int32_t)s_tl[t];
+                        const FKey kt = s_key[ti];
+                        /* direct matches of the run: those with a greater key move one place back; counts for the tail match itself */
+                        uint32_t n_dir_less = 0, n_dir_run = 0;
+#pragma unroll
+                        for (int k = 0; k < K; k++) {
+                            if (k < nsl) {
+                                const int32_t i = lane + 64 * k;
+                                const bool dir = i < n && !tl[k] && same_run(ke[k], kt);
+                                const bool smaller = dir && less(ke[k], kt);
+                                if (dir && !smaller) np[k]++;
+                                n_dir_run += (uint32_t)__popcll(__ballot(dir)); n_dir_less += (uint32_t)__popcll(__ballot(smaller));
+                            }
+                        }
+                        uint32_t n_tl_less = 0, n_tl_before = 0;
+                        for (uint32_t u = 0; u < nt; u++) {
+                            if (u == t) continue;
+                            const FKey ku = s_key[s_tl[u]];
+                            if (!same_run(ku, kt)) continue;
+                            n_tl_less += less(ku, kt) ? 1u : 0u; n_tl_before += u < t ? 1u : 0u;
+                        }
+                        const int32_t run_start = ti - (int32_t)n_dir_run - (int32_t)n_tl_before;
+#pragma unroll
+                        for (int k = 0; k < K; k++) if (lane + 64 * k == ti) np[k] = run_start + (int32_t)(n_dir_less + n_tl_less);
+                    }
+                    wave_fence();
+#pragma unroll
+                    for (int k = 0; k < K; k++) { const int32_t i = lane + 64 * k; if (k < nsl && i < n) { s_key[np[k]] = ke[k]; s_aux[np[k]] = ax[k] & ~(1ull << 63); } }
+                    wave_fence();
+                }
+            }
+        }
         /* ---- own elements, neighbours, structure checks ---- */
         FKey key[K]; uint32_t tid[K], reh[K];
         int32_t tcanon[K]; uint8_t euk[K];
@@ -222,7 +289,7 @@ __global__ __launch_bounds__(64, K <= 3 ? 4 : 2) void k_score_fast(const mtb_slo
             if (k < nslot && !slow) {
                 FKey pk; pk.lo = 0; pk.hi = 0;
                 if (i < n) {
-                    key[k] = s_key[i]; const uint64_t a = s_aux[i]; tid[k] = (uint32_t)a; reh[k] = (uint32_t)(a >> 32); if (i > 0) pk = s_key[i - 1];
+                    key[k] = s_key[i]; const uint64_t a = s_aux[i]; tid[k] = (uint32_t)a; reh[k] = (uint32_t)(a >> 32) & 0xFFFFu; if (i > 0) pk = s_key[i - 1];
                     /* taxonomy lookups this match may need later, issued now and all at once: its target's canonical id (redundancy
                      * filter) and whether its species sits under Eukaryota (minimum path depth) -- the scorer's wall time is L2
                      * round trips of such lookups, so they must not queue up behind each other */
