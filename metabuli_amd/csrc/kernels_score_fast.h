@@ -31,6 +31,9 @@
 #include "mtb_score_par.h"
 
 #define MTB_FAST_BKT 128          /* position buckets handled in LDS */
+#ifndef MTB_FAST_MERGE_SINGLES
+#define MTB_FAST_MERGE_SINGLES 0  /* A/B switch (make libmtb_xmerge.so X=-DMTB_FAST_MERGE_SINGLES=1): the tail merge for single reads too */
+#endif
 
 /* debugging build only (-DMTB_FAST_DEBUG): why reads leave the fast path: 0 tail overflow / buckets, 1 > 8 species, 2 not sorted
  * (S1), 3 position group with two matches (S2), 4 > 64 paths (S3), 5 handled; 6 sum of emitted paths, 7 sum of species */
@@ -81,7 +84,7 @@ struct FastPath { int32_t start, end; float score; int32_t ham; uint32_t rehs; /
  * The slot order of a pair is (mate, frame, position), compareMatches order is (species, frame, position) with the second mate's
  * positions behind the first mate's: the compaction then takes one (species, frame) after another instead of one species. */
 template <int K, int KL = K, bool BYFRAME = false>
-__global__ __launch_bounds__(64, K <= 3 ? 4 : 2) void k_score_fast(const mtb_slot16 *__restrict__ slots_all, uint64_t n_reads, const int32_t *__restrict__ qlen,
+__global__ __launch_bounds__(64, K <= 3 ? 5 : 4) void k_score_fast(const mtb_slot16 *__restrict__ slots_all, uint64_t n_reads, const int32_t *__restrict__ qlen,
                                                        const int32_t *__restrict__ qlen2, mtb_tax_view tx, mtb_score_params sp,
                                                        const uint64_t *__restrict__ tc_off, mtb_result *__restrict__ results,
                                                        int32_t *__restrict__ tc_tax, uint32_t *__restrict__ tc_cnt, uint64_t tc_cap, uint64_t tc_base,
@@ -92,14 +95,22 @@ __global__ __launch_bounds__(64, K <= 3 ? 4 : 2) void k_score_fast(const mtb_slo
     __shared__ uint64_t s_aux[NMAX];            /* target id | right_end_hamming << 32                  */
     __shared__ uint64_t s_pp[NMAX];             /* prefix sums of the chain increments: score | hd << 32 */
     __shared__ FastPath s_path[64];
-    __shared__ uint32_t s_hmin[MTB_FAST_BKT];
-    __shared__ int32_t s_btax[MTB_FAST_BKT];
-    __shared__ int32_t s_otax[MTB_FAST_BKT];
-    __shared__ uint32_t s_ocnt[MTB_FAST_BKT];
-    __shared__ int32_t s_lev[MTB_LR_MAXE], s_anc[MTB_LR_MAXE * MTB_LR_K];
     __shared__ uint32_t s_pf[64];              /* landing zone of the slot prefetch (never read) */
-    __shared__ uint32_t s_tl[64];              /* tail matches of the read: their places in the compacted list */
-    __shared__ uint32_t s_hcnt[256];            /* matches per species hash: lonely matches are dropped up front */
+    __shared__ uint32_t s_tl[(BYFRAME || MTB_FAST_MERGE_SINGLES) ? 64 : 1];     /* tail matches of the read: their places in the compacted list */
+    /* The wave's time is memory round trips (slot records, three rounds of taxonomy lookups): what bounds the kernel is the number of
+     * waves a CU holds, and LDS is what limited it (10.1 KB: 16 waves; 97 registers: 4 per SIMD).  The small tables of the phases
+     * before the keys exist and after the last path is emitted therefore live inside the big arrays (a wave fence separates every two
+     * phases; the arrays of one phase are distinct):
+     *   compaction:            s_hcnt (matches per species hash)                     in s_pp   (written by the chain prefix sums)
+     *   filter, gather:        s_hmin / s_btax (position buckets)                    in s_key  (last read by the emission)
+     *   gather .. output:      s_otax / s_ocnt (the read's taxID:count list)         in s_pp   (last read by the emission)
+     *   descent:               s_lev / s_anc                                         in s_aux  (last read by the emission)           */
+    typedef uint32_t __attribute__((may_alias)) u32a; typedef int32_t __attribute__((may_alias)) i32a;
+    static_assert(NMAX * 8 >= 2 * MTB_FAST_BKT * 4 && NMAX * 8 >= 256 * 4 && NMAX * 8 >= (MTB_LR_MAXE + MTB_LR_MAXE * MTB_LR_K) * 4, "tables fit the arrays they live in");
+    u32a *const s_hcnt = (u32a *)s_pp;
+    u32a *const s_hmin = (u32a *)s_key; i32a *const s_btax = (i32a *)s_key + MTB_FAST_BKT;
+    i32a *const s_otax = (i32a *)s_pp; u32a *const s_ocnt = (u32a *)s_pp + MTB_FAST_BKT;
+    i32a *const s_lev = (i32a *)s_aux; i32a *const s_anc = (i32a *)s_aux + MTB_LR_MAXE;
     const int32_t lane = (int32_t)threadIdx.x;
     MTB_BEGIN_ACQUIRE();
 #ifdef MTB_FAST_DEBUG
@@ -217,7 +228,7 @@ __global__ __launch_bounds__(64, K <= 3 ? 4 : 2) void k_score_fast(const mtb_slo
             /* pairs only: there the generic kernel costs 20 ns per read it takes over (320-record staging, 2 waves per SIMD), and the merge
              * pays (12.5 M pairs: generic 21.5 -> 6.8 ms, this kernel 72 -> 77 ms); single reads lose (generic 2.9 -> 0.9 ms, this kernel
              * 22.5 -> 26.5 ms: the merge costs about what the read's whole scoring does) and keep handing such reads over */
-            if (BYFRAME && !slow && __any(any_tail)) {
+            if ((BYFRAME || MTB_FAST_MERGE_SINGLES) && !slow && __any(any_tail)) {
                 FKey ke[K]; uint64_t ax[K]; int32_t np[K]; bool tl[K];
                 const int32_t nsl = (n + 63) >> 6;
 #pragma unroll
