@@ -468,6 +468,7 @@ def main():
     import metabuli_amd as M
     ctx = M.Context(local_rank)
     ctx.set_streams(args.streams)
+    ctx.set_placement_probe(True)      # this process has allocated and freed > 200 GB through torch by now: see mtb_ctx_set_placement_probe (include/mtb.h)
     params = M.default_params(seq_mode=args.seq_mode, syncmer=1, smer_len=5)
 
     t_setup = time.perf_counter()

@@ -130,6 +130,11 @@ mtb_status mtb_ctx_set_streams(mtb_ctx *, int n);
  * results are those of the undivided batch.  bytes = 0 (default): the budget is what hipMemGetInfo reports free plus
  * what the context already holds.  mtb_ctx_last_sub_batches: how many ranges the last call used.               */
 mtb_status mtb_ctx_set_workspace_limit(mtb_ctx *, uint64_t bytes);
+/* Placement search for the slot buffer of big batches (>= 8 GB): the join's scattered 16-byte stores run 42 - 57 ms per 10 M reads
+ * depending on where that buffer landed in a device whose free memory is fragmented by the process's earlier allocations; with the
+ * search on, a new buffer is picked among a few candidate allocations by a random-store probe (one-time 0.6 - 3.8 s).  Off by
+ * default: a process that allocates through this library only gets the good placement from the first hipMalloc. */
+mtb_status mtb_ctx_set_placement_probe(mtb_ctx *, int on);
 uint32_t   mtb_ctx_last_sub_batches(const mtb_ctx *);
 
 /* ---- index residency ---------------------------------------------------

@@ -154,6 +154,10 @@ class Context:
     def set_profiling(self, on):
         _chk(self.L.mtb_ctx_set_profiling(self.h, C.c_int(1 if on else 0)))
 
+    def set_placement_probe(self, on):
+        """slot buffers >= 8 GB are chosen among candidate allocations (for processes with a long device-allocation history of their own)"""
+        _chk(self.L.mtb_ctx_set_placement_probe(self.h, C.c_int(1 if on else 0)))
+
     def set_workspace_limit(self, nbytes):
         """workspace budget of a batch in bytes (0 = automatic from hipMemGetInfo): forces sub-batches in tests"""
         _chk(self.L.mtb_ctx_set_workspace_limit(self.h, C.c_uint64(int(nbytes))))

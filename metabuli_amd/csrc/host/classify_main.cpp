@@ -52,6 +52,7 @@
 #include "../../../include/mtb.hpp"
 #include "../mtb_core.h"         /* mtb_build_tables: the extractor's base classes, for the 2-bit packing of the reads */
 #include "fastx.h"
+#include "format.h"
 
 namespace {
 
@@ -67,15 +68,6 @@ struct Job {
     }
     void reset() { r1.clear(); r2.clear(); res.clear(); tt.clear(); tc.clear(); last = false; }
 };
-
-/* small non-negative / signed integers without snprintf (the formatter printed three numbers per read through it) */
-inline void append_int(std::string &out, long long v) {
-    char buf[24]; int n = 0;
-    unsigned long long u = v < 0 ? (unsigned long long)(-v) : (unsigned long long)v;
-    do { buf[n++] = (char)('0' + u % 10); u /= 10; } while (u);
-    if (v < 0) out += '-';
-    while (n) out += buf[--n];
-}
 
 /* bounded single-producer / single-consumer hand-over */
 template <class T> class Channel {
@@ -113,29 +105,39 @@ void append_lineage(const mtb_index *ix, int32_t taxid, std::string &out) {
 }
 
 /* Reporter::writeReadClassification (Reporter.cpp:35-80), one line per read, reads [lo, hi) of the job.  The score is
- * printed like an ostream prints a float (6 significant digits). */
-void format_reads(const Job &j, size_t lo, size_t hi, const mtb_index *ix, bool lineage, std::string &out) {
-    char num[64];
-    out.clear();
-    out.reserve((hi - lo) * 96);
+ * printed like an ostream prints a float (6 significant digits; format.h).  The piece's reads per classification (Classifier.cpp:201-203)
+ * are counted on the way: `counts` gets (taxon, reads) pairs, merged by the caller. */
+void format_reads(const Job &j, size_t lo, size_t hi, const mtb_index *ix, bool lineage, std::string &out, std::vector<std::pair<int32_t, uint32_t>> *counts = nullptr) {
+    mtbhost::RowBuf o(out, (hi - lo) * 96);
+    std::unordered_map<int32_t, uint32_t> cnt;
+    int32_t last_cls = -1; uint32_t last_run = 0;             /* reads of a sample often repeat the taxon of their neighbour */
+    const char *names = j.r1.names.data();
+    std::string lin;
     for (size_t i = lo; i < hi; i++) {
         const mtb_result &r = j.res[i];
-        out += r.is_classified ? '1' : '0'; out += '\t';
-        out.append(j.r1.names.data() + j.r1.name_offs[i], j.r1.names.data() + j.r1.name_offs[i + 1]); out += '\t';
-        append_int(out, mtb_tax_original_id(ix, r.classification)); out += '\t';
-        append_int(out, r.query_length + r.query_length2); out += '\t';
-        if (r.score == 0.0f) out += '0'; else if (r.score == 1.0f) out += '1';
-        else { const int n = snprintf(num, sizeof(num), "%g", (double)r.score); out.append(num, (size_t)n); }       /* an ostream's float: 6 significant digits */
-        out += '\t';
+        if (counts) { if (r.classification == last_cls) last_run++; else { if (last_run) cnt[last_cls] += last_run; last_cls = r.classification; last_run = 1; } }
+        const size_t nlen = (size_t)(j.r1.name_offs[i + 1] - j.r1.name_offs[i]);
+        o.need(nlen + 160 + (size_t)r.n_taxcnt * 24);
+        o.ch(r.is_classified ? '1' : '0'); o.ch('\t');
+        o.bytes(names + j.r1.name_offs[i], nlen); o.ch('\t');
+        o.p = mtbhost::put_int(o.p, mtb_tax_original_id(ix, r.classification)); o.ch('\t');
+        o.p = mtbhost::put_int(o.p, (long long)r.query_length + r.query_length2); o.ch('\t');
+        o.p = mtbhost::put_float_g6(o.p, r.score);
+        o.ch('\t');
         if (r.is_classified) {
-            out += mtb_tax_rank(ix, r.classification); out += '\t';
-            if (lineage) { append_lineage(ix, r.classification, out); out += '\t'; }
+            o.cstr(mtb_tax_rank(ix, r.classification)); o.ch('\t');
+            if (lineage) { lin.clear(); append_lineage(ix, r.classification, lin); o.need(lin.size() + 64 + (size_t)r.n_taxcnt * 24); o.bytes(lin.data(), lin.size()); o.ch('\t'); }
             for (uint32_t k = 0; k < r.n_taxcnt; k++) {
-                append_int(out, mtb_tax_original_id(ix, j.tt[r.taxcnt_off + k])); out += ':';
-                append_int(out, j.tc[r.taxcnt_off + k]); out += ' ';
+                o.p = mtbhost::put_int(o.p, mtb_tax_original_id(ix, j.tt[r.taxcnt_off + k])); o.ch(':');
+                o.p = mtbhost::put_uint(o.p, j.tc[r.taxcnt_off + k]); o.ch(' ');
             }
-            out += '\n';
-        } else out += lineage ? "-\t-\t-\t\n" : "-\t-\t\n";
+            o.ch('\n');
+        } else { if (lineage) o.bytes("-\t-\t-\t\n", 7); else o.bytes("-\t-\t\n", 5); }
+    }
+    o.finish();
+    if (counts) {
+        if (last_run) cnt[last_cls] += last_run;
+        counts->assign(cnt.begin(), cnt.end());
     }
 }
 
@@ -333,7 +335,7 @@ int main(int argc, char **argv) {
         mtb::Engine &eng = *engs[0];                          /* taxonomy services for formatting */
         const size_t ND = engs.size();
         const double t_open = now() - t_start;
-        double t_parse = 0, t_gpu = 0, t_write = 0, t_dev = 0;  /* busy time of the three stages; device time inside the GPU stage */
+        double t_parse = 0, t_gpu = 0, t_write = 0, t_dev = 0, t_fmt = 0, t_app = 0;  /* busy time of the three stages; device time inside the GPU stage */
         FILE *out = fopen((prefix + "_classifications.tsv").c_str(), "w");
         if (!out) throw std::runtime_error("cannot write " + prefix + "_classifications.tsv");
         FILE *flt[2] = {nullptr, nullptr}, *rmv[2] = {nullptr, nullptr};
@@ -379,13 +381,16 @@ int main(int argc, char **argv) {
         std::thread writer([&] {
             const size_t NP = (size_t)threads * 2;                       /* pieces: a few per worker, reads differ in their row length */
             std::vector<std::string> parts(NP);
+            std::vector<std::vector<std::pair<int32_t, uint32_t>>> piece_counts(NP);
             for (;;) {
                 std::unique_ptr<Job> j = scored.get();
                 if (j->last) break;
                 const double t0 = now();
                 const size_t n = j->r1.size();
-                format_pool.run(NP, [&](size_t t) { format_reads(*j, n * t / NP, n * (t + 1) / NP, eng.index, lineage, parts[t]); });
+                format_pool.run(NP, [&](size_t t) { format_reads(*j, n * t / NP, n * (t + 1) / NP, eng.index, lineage, parts[t], &piece_counts[t]); });
+                const double t1 = now();
                 append_parts(out, parts, format_pool, writer_err);
+                t_fmt += t1 - t0; t_app += now() - t1;
                 for (int mate = 0; mate < 2; mate++) for (int cls = 0; cls < 2; cls++) {
                     FILE *f = cls ? rmv[mate] : flt[mate];
                     if (!f) continue;
@@ -393,7 +398,7 @@ int main(int argc, char **argv) {
                     format_pool.run(NP, [&](size_t t) { format_fasta(rb, j->res, n * t / NP, n * (t + 1) / NP, cls != 0, parts[t]); });
                     for (auto &p : parts) if (fwrite(p.data(), 1, p.size(), f) != p.size()) writer_err = "short write";
                 }
-                for (size_t i = 0; i < n; i++) { int32_t c = j->res[i].classification; if (c >= 0 && (size_t)c < tax_counts.size()) tax_counts[(size_t)c]++; }
+                for (auto &pc : piece_counts) for (auto &kv : pc) if (kv.first >= 0 && (size_t)kv.first < tax_counts.size()) tax_counts[(size_t)kv.first] += kv.second;
                 total += n;
                 t_write += now() - t0;
                 std::cout << "The number of processed sequences: " << total << std::endl;
@@ -513,8 +518,8 @@ int main(int argc, char **argv) {
             write_krona(fp, ct, total);
             fclose(fp);
         }
-        fprintf(stderr, "mtb_classify: %lu reads in %.2f s on %zu GPU(s) (index open %.2f s; stage busy time: parse %.2f s, GPU incl. PCIe %.2f s (kernels %.2f s), format+write %.2f s; %d host threads)\n",
-                total, now() - t_start, ND, t_open, t_parse, t_gpu, t_dev, t_write, threads);
+        fprintf(stderr, "mtb_classify: %lu reads in %.2f s on %zu GPU(s) (index open %.2f s; stage busy time: parse %.2f s, GPU incl. PCIe %.2f s (kernels %.2f s), format+write %.2f s (rows %.2f s, file %.2f s); %d host threads)\n",
+                total, now() - t_start, ND, t_open, t_parse, t_gpu, t_dev, t_write, t_fmt, t_app, threads);
     } catch (const std::exception &e) {
         fprintf(stderr, "mtb_classify: %s\n", e.what());
         return 1;

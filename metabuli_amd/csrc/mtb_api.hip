@@ -97,6 +97,7 @@ struct mtb_ctx {
     double extract_yield = 0.0;      /* metamers per base of the previous batch (single-pass extraction buffer sizing) */
     uint64_t part_n_reads = 0; uint32_t part_max_len = 0;   /* batch state between mtb_part_extract and mtb_part_score */
     int part_mode = 0; uint32_t part_max_q = 0; uint64_t part_nk_real = 0;      /* part_mode 1: the batch's metamers carry ordinals, the matches come home into slot segments */
+    bool placement_probe = false;    /* mtb_ctx_set_placement_probe: a new big slot buffer is chosen among candidate allocations */
     uint64_t ws_limit = 0;           /* workspace budget of a batch in bytes; 0 = what hipMemGetInfo reports free (+ what the context holds) */
     double ws_per_base = 0.0;        /* workspace bytes per base: what the buffers hold / the largest sub-batch they were grown for (HBM-budgeted batching) */
     uint64_t ws_max_sub_bases = 0;   /* bases of the largest sub-batch since the workspace was last released */
@@ -229,8 +230,13 @@ static mtb_status ensure_placed(mtb_ctx *c, const char *name, size_t elems, mtb_
         *out = (mtb_slot16 *)b.p;
         return MTB_OK;
     }
-    static const bool no_probe = getenv("MTB_NO_PLACEMENT_PROBE") != nullptr;
-    if (b.cap >= bytes || bytes < (8ull << 30) || no_probe) return ensure(c, name, elems, out);      /* small batches: an allocation of this size takes 0.3 - 1 s, not worth it */
+    /* Off unless the caller asks for it (mtb_ctx_set_placement_probe, or MTB_PLACEMENT_PROBE=1): in a process whose only device
+     * allocations are the library's own (the stand-alone driver) a plain hipMalloc lands as well as any candidate
+     * (profiles/scripts/alloc_probe.hip, profiles/r03_notes.md section 3), and the search costs the first big batch 2.5 - 3.8 s
+     * (profiles/r03_e2e_driver_30Mreads.txt).  A process with a long allocation history of its own (bench.py under torch's caching
+     * allocator) turns it on. */
+    static const bool no_probe = getenv("MTB_NO_PLACEMENT_PROBE") != nullptr, env_probe = getenv("MTB_PLACEMENT_PROBE") != nullptr;
+    if (b.cap >= bytes || bytes < (8ull << 30) || no_probe || !(c->placement_probe || env_probe)) return ensure(c, name, elems, out);
     if (b.p) { hipError_t e = hipFree(b.p); (void)e; b.p = nullptr; b.cap = 0; }
     const size_t want = bytes + bytes / 16 + 256;
     const auto t_begin = std::chrono::steady_clock::now();
@@ -349,6 +355,12 @@ mtb_status mtb_ctx_set_profiling(mtb_ctx *c, int on) {
     for (mtb_ctx *l : c->lanes) l->profiling = on;
     return MTB_OK;
 }
+mtb_status mtb_ctx_set_placement_probe(mtb_ctx *c, int on) {
+    if (!c) return fail(MTB_ERR_ARG, "NULL ctx");
+    c->placement_probe = on != 0;
+    for (mtb_ctx *l : c->lanes) l->placement_probe = on != 0;
+    return MTB_OK;
+}
 mtb_status mtb_ctx_set_workspace_limit(mtb_ctx *c, uint64_t bytes) {
     if (!c) return fail(MTB_ERR_ARG, "NULL ctx");
     c->ws_limit = bytes;
@@ -362,7 +374,7 @@ mtb_status mtb_ctx_set_streams(mtb_ctx *c, int n) {
     while ((int)c->lanes.size() > (n == 1 ? 0 : n)) { mtb_ctx_destroy(c->lanes.back()); c->lanes.pop_back(); }
     while (n > 1 && (int)c->lanes.size() < n) {
         mtb_ctx *l = new mtb_ctx();
-        l->device = c->device; l->is_lane = true; l->d_tabs = c->d_tabs; l->h_tabs = c->h_tabs; l->profiling = c->profiling;
+        l->device = c->device; l->is_lane = true; l->d_tabs = c->d_tabs; l->h_tabs = c->h_tabs; l->profiling = c->profiling; l->placement_probe = c->placement_probe;
         HIPCHK(hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking));
         HIPCHK(hipMalloc((void **)&l->d_scal, 16 * sizeof(uint64_t)));
         l->d_xscal = l->d_scal + 8;
@@ -1941,6 +1953,9 @@ mtb_status mtb_classify_batch_packed(mtb_ctx *c, mtb_index *ix, const mtb_params
     if (n_reads == 0) return MTB_OK;
     if (!packed2 || !nmask || !lens) return fail(MTB_ERR_ARG, "packed2/nmask/lens NULL");
     char *d_b = nullptr, *d_b2 = nullptr; uint64_t *d_o = nullptr, *d_o2 = nullptr; uint64_t nb = 0, nb2 = 0;
+    static const bool timing = getenv("MTB_HOST_TIMING") != nullptr;      /* wall time of the call's three parts on stderr (the uploads are synchronised for it) */
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
     STCHK(upload_packed(c, "", packed2, nmask, lens, n_reads, &d_b, &d_o, &nb));
     if (p->seq_mode == 2) {
         if (!packed2_mate || !nmask_mate || !lens_mate) return fail(MTB_ERR_ARG, "seq_mode 2 needs the mates");
@@ -1948,9 +1963,17 @@ mtb_status mtb_classify_batch_packed(mtb_ctx *c, mtb_index *ix, const mtb_params
     }
     mtb_result *d_res; int32_t *d_tt; uint32_t *d_tc;
     STCHK(ensure(c, "results", n_reads, &d_res)); STCHK(ensure(c, "tctax", taxcnt_cap, &d_tt)); STCHK(ensure(c, "tccnt", taxcnt_cap, &d_tc));
+    if (timing) HIPCHK(hipStreamSynchronize(c->stream));
+    const double t1 = now();
     mtb_status st = mtb_classify_batch_device(c, ix, p, d_b, d_o, d_b2, d_o2, n_reads, nb + nb2, d_res, d_tt, d_tc, taxcnt_cap, n_taxcnt);
     if (st != MTB_OK) return st;
-    if (c->lanes.size() < 2 && *n_taxcnt) return download_packed(c, d_res, d_tt, d_tc, n_reads, results, taxcnt_tax, taxcnt_cnt, n_taxcnt);
+    const double t2 = now();
+    if (c->lanes.size() < 2 && *n_taxcnt) {
+        st = download_packed(c, d_res, d_tt, d_tc, n_reads, results, taxcnt_tax, taxcnt_cnt, n_taxcnt);
+        if (timing) fprintf(stderr, "mtb_classify_batch_packed: %llu reads: upload + unpack %.1f ms, classify %.1f ms (device %.1f ms), pack + download %.1f ms\n",
+                            (unsigned long long)n_reads, t1 - t0, t2 - t1, (double)c->stats.ms_total, now() - t2);
+        return st;
+    }
     STCHK(d2h(c, results, d_res, n_reads * sizeof(mtb_result)));
     if (*n_taxcnt) { STCHK(d2h(c, taxcnt_tax, d_tt, *n_taxcnt * 4)); STCHK(d2h(c, taxcnt_cnt, d_tc, *n_taxcnt * 4)); }
     return MTB_OK;
