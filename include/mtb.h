@@ -222,7 +222,12 @@ mtb_status mtb_score(mtb_ctx *, mtb_index *, const mtb_params *, const mtb_match
 
 /* ---- fused batch (the product path) ------------------------------------
  * One pass of Classifier::startClassify's loop body (Classifier.cpp:81-125)
- * for one batch.  Host-buffer variant copies inputs over PCIe first.        */
+ * for one batch.  Host-buffer variant copies inputs over PCIe first.
+ * taxcnt arrays of the host-buffer variants (one stream): the taxID:count lists arrive packed (taxcnt_off = running total),
+ * so taxcnt_cap only has to hold what the batch's lists contain (2-3 entries per short read is typical; the device-side
+ * arrays, one slot per position bucket of every read, are the library's).  MTB_ERR_CAPACITY: *n_taxcnt = entries needed,
+ * nothing was copied.  With mtb_ctx_set_streams(n > 1) the lists are spread over the arrays instead and taxcnt_cap must
+ * hold one entry per position bucket ((read length + 3) / dna shift + 2 per read).                                     */
 mtb_status mtb_classify_batch(mtb_ctx *, mtb_index *, const mtb_params *, const char *bases,
                               const uint64_t *offs, const char *bases2, const uint64_t *offs2,
                               uint64_t n_reads, mtb_result *results, int32_t *taxcnt_tax,

@@ -237,10 +237,13 @@ class Context:
         return compact_taxcnt(res, tt, tc)
 
     # ---- fused batch ----
-    def classify_batch(self, index, params, bases, offs, bases2=None, offs2=None):
+    def classify_batch(self, index, params, bases, offs, bases2=None, offs2=None, taxcnt_cap=None):
+        """taxcnt_cap: capacity of the host arrays for the packed taxID:count lists (default: ample); too small -> the call is
+        repeated with the size the library reports (self.last_capacity_retries counts those)"""
         n = len(offs) - 1
         res = np.zeros(n, result_dt)
-        cap = max(1024, 64 * n)
+        cap = max(1024, 64 * n) if taxcnt_cap is None else int(taxcnt_cap)
+        self.last_capacity_retries = 0
         while True:
             tt = np.zeros(cap, np.int32); tc = np.zeros(cap, np.uint32)
             cnt = C.c_uint64()
@@ -248,6 +251,7 @@ class Context:
                                            C.c_uint64(n), _p(res), _p(tt), _p(tc), C.c_uint64(cap), C.byref(cnt))
             if st == MTB_ERR_CAPACITY and cnt.value > cap:
                 cap = cnt.value
+                self.last_capacity_retries += 1
                 continue
             _chk(st)
             return compact_taxcnt(res, tt, tc)

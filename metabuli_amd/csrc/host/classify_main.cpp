@@ -24,7 +24,9 @@
  *          reads), and <base>_classifications.tsv / <base>_report.tsv; <base> = LocalUtil::getQueryBaseName (LocalUtil.cpp:5-20).
  *          (In the reference snapshot the match loop of filterReads is stubbed out, QueryFilter.cpp:172-175, so it keeps every
  *          read; this implements the documented behaviour of the command.)
- *   own flags: --max-reads N (host batch)  --pack-reads 0|1 (default 1: the reads cross PCIe as 2-bit codes + invalid mask out of
+ *   own flags: --max-reads N (host batch)  --gpu-workers W (default 1; W batches inside the GPU stage at once, each on contexts of its own, so that
+ *          one batch's PCIe transfers overlap another's kernels -- measured on one MI355X: no gain, the kernels of two batches slow each other
+ *          by what the overlap wins, profiles/r03_notes.md)  --pack-reads 0|1 (default 1: the reads cross PCIe as 2-bit codes + invalid mask out of
  *          pinned buffers, mtb_classify_batch_packed; 0: as text)  --partitioned 1 (with --devices: engine d holds value range d of the database -- for
  *          databases larger than one GPU's HBM; metamers and matches are exchanged between the GPUs)
  *          --device N | --devices 0,1,... (one engine per GPU: every host batch is cut into
@@ -270,7 +272,7 @@ int main(int argc, char **argv) {
     mtb_params par; mtb_default_params(&par);
     std::string taxdir; std::vector<int> devices(1, 0); size_t max_reads = 2000000;
     int threads = (int)std::max(1u, std::min(128u, std::thread::hardware_concurrency()));
-    bool lineage = false, filter = false, min_score_given = false, partitioned = false, pack = true; int print_mode = 1;
+    bool lineage = false, filter = false, min_score_given = false, partitioned = false, pack = true; int print_mode = 1, gpu_workers = 1;
     std::vector<std::string> pos;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -292,6 +294,7 @@ int main(int argc, char **argv) {
         else if (a == "--device") { devices.assign(1, atoi(val().c_str())); }
         else if (a == "--partitioned") partitioned = atoi(val().c_str()) != 0;
         else if (a == "--pack-reads") pack = atoi(val().c_str()) != 0;
+        else if (a == "--gpu-workers") gpu_workers = std::max(1, std::min(4, atoi(val().c_str())));
         else if (a == "--devices") { devices.clear(); std::stringstream ss(val()); std::string tok; while (std::getline(ss, tok, ',')) if (!tok.empty()) devices.push_back(atoi(tok.c_str())); }
         else if (a == "--reduced-aa") { if (atoi(val().c_str()) != 0) { fprintf(stderr, "mtb_classify: --reduced-aa 1 is not implemented\n"); return 1; } }
         else if (a == "--mask") {       /* tantan masking of the reads before extraction (KmerExtractor.cpp:308-314) changes the answers: refuse it rather than ignore it */
@@ -313,7 +316,7 @@ int main(int argc, char **argv) {
         return 1;
     }
     if (filter && !min_score_given) par.min_score = 0.5f;     /* setFilterDefaults, filter.cpp:8 */
-    if (partitioned) pack = false;                             /* (the partitioned batch takes the text) */
+    if (partitioned) { pack = false; gpu_workers = 1; }        /* (the partitioned batch takes the text; its engines work on one batch together) */
     const std::string dbdir = pos[paired ? 2 : 1];
     /* classify: <OUTDIR>/<JobID>_*; filter: <base of the first input>_* (QueryFilter.cpp:75-93) */
     const std::string base1 = filter ? query_base_name(pos[0]) : std::string(), base2 = filter && paired ? query_base_name(pos[1]) : std::string();
@@ -346,10 +349,10 @@ int main(int argc, char **argv) {
         }
         fputs(lineage ? "#is_classified\tname\ttaxID\tquery_length\tscore\trank\tlineage\ttaxID:match_count\n"
                       : "#is_classified\tname\ttaxID\tquery_length\tscore\trank\ttaxID:match_count\n", out);
-        Channel<Job> parsed(2), scored(2), idle(4);
-        /* three batches are in flight (parse / GPU / format); their buffers are recycled, so that after the first round no stage
+        Channel<Job> parsed(2), scored(2), idle((size_t)gpu_workers + 4);
+        /* a few batches are in flight (parse / GPU workers / format); their buffers are recycled, so that after the first round no stage
          * touches fresh pages, and what crosses PCIe sits in pinned memory */
-        for (int k = 0; k < 3; k++) { std::unique_ptr<Job> j(new Job()); if (pack) j->pin(); idle.put(std::move(j)); }
+        for (int k = 0; k < gpu_workers + 3; k++) { std::unique_ptr<Job> j(new Job()); if (pack) j->pin(); idle.put(std::move(j)); }
         mtbhost::WorkerPool parse_pool(threads), format_pool(threads);
         mtbhost::PackTable pack_table;
         { static mtb_tables tabs; mtb_build_tables(&tabs); for (int c = 0; c < 256; c++) pack_table.code[c] = tabs.base[c] < 4 ? tabs.base[c] : 0xFF; }
@@ -406,13 +409,18 @@ int main(int argc, char **argv) {
             }
         });
         /* stage 2: the GPUs.  A host batch is cut into ND contiguous read ranges; range d runs on engine d from its own host
-         * thread (one thread per mtb_ctx); rows land at their places in j->res, the taxcnt lists are appended range by range */
-        std::string gpu_err;
+         * thread (one thread per mtb_ctx); rows land at their places in j->res, the taxcnt lists are appended range by range.
+         * --gpu-workers W (default 1): W batches are in this stage at once, each on contexts of its own (same resident index), so
+         * that one batch's PCIe transfers and host-side bookkeeping overlap another's kernels; batches leave the stage in input order. */
+        std::string gpu_err; std::mutex gpu_err_mu;
         struct Range { std::vector<uint64_t> offs, offs2; mtbhost::PodVec<int32_t> tt; mtbhost::PodVec<uint32_t> tc; uint64_t ntc = 0; std::string err; double dev_ms = 0; };
-        for (;;) {
-            std::unique_ptr<Job> j = parsed.get();
-            if (j->last) { scored.put(std::move(j)); break; }
-            if (!gpu_err.empty()) continue;                  /* drain the reader after a failure */
+        const int W = gpu_workers;
+        std::atomic<double> tc_per_read{6.0};
+        std::vector<std::vector<mtb_ctx *>> wctx((size_t)W, std::vector<mtb_ctx *>(ND, nullptr));
+        for (int w = 0; w < W; w++) for (size_t d = 0; d < ND; d++) { if (w == 0) wctx[0][d] = engs[d]->ctx; else mtb::check(mtb_ctx_create(devices[d], nullptr, &wctx[(size_t)w][d])); }
+        std::vector<double> w_busy((size_t)W, 0.0), w_dev((size_t)W, 0.0);
+        auto process = [&](Job &job, int w) {
+            Job *j = &job;
             const double t0 = now();
             const size_t n = j->r1.size();
             j->res.resize_uninit(n);
@@ -428,31 +436,39 @@ int main(int argc, char **argv) {
             }
             auto run = [&](size_t d) {
                 Range &R = rg[d];
+                mtb_ctx *cx = wctx[(size_t)w][d];
                 const size_t lo = n * d / ND, hi = n * (d + 1) / ND, m = hi - lo;
                 if (m == 0) return;
-                const uint64_t b0 = j->r1.offs[lo];
-                R.offs.resize(m + 1);
-                for (size_t i = 0; i <= m; i++) R.offs[i] = j->r1.offs[lo + i] - b0;
-                uint64_t c0 = 0;
-                if (paired) { c0 = j->r2.offs[lo]; R.offs2.resize(m + 1); for (size_t i = 0; i <= m; i++) R.offs2[i] = j->r2.offs[lo + i] - c0; }
+                uint64_t b0 = 0, c0 = 0;
+                if (!pack) {
+                    b0 = j->r1.offs[lo];
+                    R.offs.resize(m + 1);
+                    for (size_t i = 0; i <= m; i++) R.offs[i] = j->r1.offs[lo + i] - b0;
+                    if (paired) { c0 = j->r2.offs[lo]; R.offs2.resize(m + 1); for (size_t i = 0; i <= m; i++) R.offs2[i] = j->r2.offs[lo + i] - c0; }
+                }
                 mtb_params pd = par;
-                size_t cap = 24 * m + 4096;                  /* the device side needs one slot per position bucket (18 for 150 bp reads); more -> exact retry */
+                /* the taxID:count lists arrive packed: a few entries per read (the factor follows what the batches so far needed; a
+                 * batch that needs more is redone with the exact size) -- these are pinned buffers, 24 entries per read cost the
+                 * first batches of a run more in page pinning than their classification */
+                size_t cap = (size_t)(tc_per_read.load() * (double)m) + 4096;
                 if (ND == 1) { R.tt = std::move(j->tt); R.tc = std::move(j->tc); }       /* the job's own (pinned, recycled) buffers */
                 for (;;) {
                     R.tt.resize_uninit(cap); R.tc.resize_uninit(cap);
                     mtb_status st = pack
-                        ? mtb_classify_batch_packed(engs[d]->ctx, engs[d]->index, &pd, j->r1.packed2.data() + 2 * slot_lo[d], j->r1.nmask.data() + slot_lo[d], j->r1.lens.data() + lo,
+                        ? mtb_classify_batch_packed(cx, engs[d]->index, &pd, j->r1.packed2.data() + 2 * slot_lo[d], j->r1.nmask.data() + slot_lo[d], j->r1.lens.data() + lo,
                                                     paired ? j->r2.packed2.data() + 2 * slot2_lo[d] : nullptr, paired ? j->r2.nmask.data() + slot2_lo[d] : nullptr,
                                                     paired ? j->r2.lens.data() + lo : nullptr, m, j->res.data() + lo, R.tt.data(), R.tc.data(), cap, &R.ntc)
-                        : mtb_classify_batch(engs[d]->ctx, engs[d]->index, &pd, j->r1.bases.data() + b0, R.offs.data(),
+                        : mtb_classify_batch(cx, engs[d]->index, &pd, j->r1.bases.data() + b0, R.offs.data(),
                                              paired ? j->r2.bases.data() + c0 : nullptr, paired ? R.offs2.data() : nullptr, m,
                                              j->res.data() + lo, R.tt.data(), R.tc.data(), cap, &R.ntc);
-                    if (st == MTB_ERR_CAPACITY && R.ntc > cap) { cap = R.ntc; continue; }
+                    if (st == MTB_ERR_CAPACITY && R.ntc > cap) { cap = R.ntc + R.ntc / 8; continue; }
                     if (st != MTB_OK) R.err = mtb_last_error();
-                    else { mtb_batch_stats bs; if (mtb_last_batch_stats(engs[d]->ctx, &bs) == MTB_OK) R.dev_ms = bs.ms_total; }
+                    else { mtb_batch_stats bs; if (mtb_last_batch_stats(cx, &bs) == MTB_OK) R.dev_ms = bs.ms_total; }
+                    if (st == MTB_OK && m) { const double need = 1.5 * (double)R.ntc / (double)m; double cur = tc_per_read.load(); while (need > cur && !tc_per_read.compare_exchange_weak(cur, need)) {} }
                     break;
                 }
             };
+            std::string err;
             if (partitioned) {
                 /* every engine owns a value range: its share of the reads is extracted there, the sorted metamers travel to the range
                  * owners and the matches back (peer copies inside the library), rows come back in input order */
@@ -471,34 +487,67 @@ int main(int argc, char **argv) {
                     break;
                 }
                 if (R.err.empty()) { j->tt = std::move(R.tt); j->tc = std::move(R.tc); }
-                for (size_t d = 1; d < ND; d++) rg[d].ntc = 0;
-                if (!R.err.empty()) gpu_err = R.err;
-                t_gpu += now() - t0;
-                if (gpu_err.empty()) scored.put(std::move(j));
-                continue;
-            }
-            if (ND == 1) run(0);
-            else { std::vector<std::thread> th; for (size_t d = 0; d < ND; d++) th.emplace_back(run, d); for (auto &x : th) x.join(); }
-            uint64_t tot_tc = 0;
-            for (size_t d = 0; d < ND; d++) { if (!rg[d].err.empty() && gpu_err.empty()) gpu_err = rg[d].err; tot_tc += rg[d].ntc; }
-            if (gpu_err.empty()) {
-                if (tot_tc >= (1ull << 32)) gpu_err = "taxcnt lists of one host batch exceed 2^32 entries; lower --max-reads";
-                else if (ND == 1) { j->tt = std::move(rg[0].tt); j->tc = std::move(rg[0].tc); }
-                else {
-                    j->tt.resize_uninit(tot_tc); j->tc.resize_uninit(tot_tc);
-                    uint64_t base = 0;
-                    for (size_t d = 0; d < ND; d++) {
-                        const size_t lo = n * d / ND, hi = n * (d + 1) / ND;
-                        if (rg[d].ntc) { memcpy(j->tt.data() + base, rg[d].tt.data(), rg[d].ntc * 4); memcpy(j->tc.data() + base, rg[d].tc.data(), rg[d].ntc * 4); }
-                        for (size_t i = lo; i < hi; i++) j->res[i].taxcnt_off += (uint32_t)base;
-                        base += rg[d].ntc;
+                err = R.err;
+            } else {
+                if (ND == 1) run(0);
+                else { std::vector<std::thread> th; for (size_t d = 0; d < ND; d++) th.emplace_back(run, d); for (auto &x : th) x.join(); }
+                uint64_t tot_tc = 0;
+                for (size_t d = 0; d < ND; d++) { if (!rg[d].err.empty() && err.empty()) err = rg[d].err; tot_tc += rg[d].ntc; }
+                if (err.empty()) {
+                    if (tot_tc >= (1ull << 32)) err = "taxcnt lists of one host batch exceed 2^32 entries; lower --max-reads";
+                    else if (ND == 1) { j->tt = std::move(rg[0].tt); j->tc = std::move(rg[0].tc); }
+                    else {
+                        j->tt.resize_uninit(tot_tc); j->tc.resize_uninit(tot_tc);
+                        uint64_t base = 0;
+                        for (size_t d = 0; d < ND; d++) {
+                            const size_t lo = n * d / ND, hi = n * (d + 1) / ND;
+                            if (rg[d].ntc) { memcpy(j->tt.data() + base, rg[d].tt.data(), rg[d].ntc * 4); memcpy(j->tc.data() + base, rg[d].tc.data(), rg[d].ntc * 4); }
+                            for (size_t i = lo; i < hi; i++) j->res[i].taxcnt_off += (uint32_t)base;
+                            base += rg[d].ntc;
+                        }
                     }
                 }
+                double mx = 0; for (size_t d = 0; d < ND; d++) mx = std::max(mx, rg[d].dev_ms);
+                w_dev[(size_t)w] += mx * 1e-3;
             }
-            t_gpu += now() - t0;
-            { double mx = 0; for (size_t d = 0; d < ND; d++) mx = std::max(mx, rg[d].dev_ms); t_dev += mx * 1e-3; }
-            if (gpu_err.empty()) scored.put(std::move(j));
+            w_busy[(size_t)w] += now() - t0;
+            if (!err.empty()) { std::lock_guard<std::mutex> l(gpu_err_mu); if (gpu_err.empty()) gpu_err = err; }
+        };
+        auto failed = [&] { std::lock_guard<std::mutex> l(gpu_err_mu); return !gpu_err.empty(); };
+        /* worker w takes batches w, w + W, ...; the collector hands them on in that order */
+        std::vector<std::unique_ptr<Channel<Job>>> win, wout;
+        for (int w = 0; w < W; w++) { win.emplace_back(new Channel<Job>(1)); wout.emplace_back(new Channel<Job>(1)); }
+        std::vector<std::thread> workers;
+        for (int w = 0; w < W; w++) workers.emplace_back([&, w] {
+            for (;;) {
+                std::unique_ptr<Job> j = win[(size_t)w]->get();
+                const bool last = j->last;
+                if (!last && !failed()) process(*j, w);
+                wout[(size_t)w]->put(std::move(j));
+                if (last) break;
+            }
+        });
+        std::thread collector([&] {
+            for (size_t k = 0;; k++) {
+                std::unique_ptr<Job> j = wout[k % (size_t)W]->get();
+                if (j->last) { scored.put(std::move(j)); break; }
+                if (failed()) idle.put(std::move(j));        /* after a failure nothing is written any more; the buffers keep the reader going until the input ends */
+                else scored.put(std::move(j));
+            }
+        });
+        const double t_stage0 = now();
+        for (size_t k = 0;; k++) {
+            std::unique_ptr<Job> j = parsed.get();
+            const bool last = j->last;
+            if (last) for (int w = 0; w < W; w++) if ((size_t)w != k % (size_t)W) { std::unique_ptr<Job> s2(new Job()); s2->last = true; win[(size_t)w]->put(std::move(s2)); }
+            win[k % (size_t)W]->put(std::move(j));
+            if (last) break;
         }
+        for (auto &t : workers) t.join();
+        collector.join();
+        const double t_stage = now() - t_stage0;
+        for (int w = 0; w < W; w++) { t_gpu = std::max(t_gpu, w_busy[(size_t)w]); t_dev += w_dev[(size_t)w]; }
+        for (int w = 1; w < W; w++) for (size_t d = 0; d < ND; d++) mtb_ctx_destroy(wctx[(size_t)w][d]);
         reader.join(); writer.join();
         fclose(out);
         for (int k = 0; k < 2; k++) { if (flt[k]) fclose(flt[k]); if (rmv[k]) fclose(rmv[k]); }
@@ -518,8 +567,8 @@ int main(int argc, char **argv) {
             write_krona(fp, ct, total);
             fclose(fp);
         }
-        fprintf(stderr, "mtb_classify: %lu reads in %.2f s on %zu GPU(s) (index open %.2f s; stage busy time: parse %.2f s, GPU incl. PCIe %.2f s (kernels %.2f s), format+write %.2f s (rows %.2f s, file %.2f s); %d host threads)\n",
-                total, now() - t_start, ND, t_open, t_parse, t_gpu, t_dev, t_write, t_fmt, t_app, threads);
+        fprintf(stderr, "mtb_classify: %lu reads in %.2f s on %zu GPU(s) (index open %.2f s; stage busy time: parse %.2f s, GPU incl. PCIe %.2f s busiest of %d worker(s) over %.2f s (device time of all batches %.2f s), format+write %.2f s (rows %.2f s, file %.2f s); %d host threads)\n",
+                total, now() - t_start, ND, t_open, t_parse, t_gpu, W, t_stage, t_dev, t_write, t_fmt, t_app, threads);
     } catch (const std::exception &e) {
         fprintf(stderr, "mtb_classify: %s\n", e.what());
         return 1;

@@ -1548,13 +1548,14 @@ static mtb_status score_fixed_slots(mtb_ctx *c, mtb_index *ix, const mtb_params 
 
 /* results of a batch to the host with the taxID:count lists packed on the device first: only what they hold crosses PCIe */
 static mtb_status download_packed(mtb_ctx *c, mtb_result *d_res, const int32_t *d_tt, const uint32_t *d_tc, uint64_t n_reads, mtb_result *results,
-                                  int32_t *taxcnt_tax, uint32_t *taxcnt_cnt, uint64_t *n_taxcnt) {
+                                  int32_t *taxcnt_tax, uint32_t *taxcnt_cnt, uint64_t *n_taxcnt, uint64_t host_cap = ~0ull) {
     uint32_t *d_n; uint64_t *d_off, *d_ws; int32_t *d_tt2; uint32_t *d_tc2;
     STCHK(ensure(c, "tcn", n_reads, &d_n)); STCHK(ensure(c, "tcnewoff", n_reads + 1, &d_off)); STCHK(ensure(c, "scanws", scan_ws_elems(n_reads + 1), &d_ws));
     hipLaunchKernelGGL(k_taxcnt_n, dim3((uint32_t)((n_reads + 255) / 256)), dim3(256), 0, c->stream, (const mtb_result *)d_res, n_reads, d_n);
     scan_launch<uint32_t, uint64_t, false>(c->stream, d_n, n_reads, true, d_off, d_ws);
     uint64_t total = 0;
     STCHK(d2h(c, &total, d_off + n_reads, 8));
+    if (total > host_cap) { *n_taxcnt = total; return fail(MTB_ERR_CAPACITY, "taxcnt arrays too small for the batch's taxID:count lists"); }
     STCHK(ensure(c, "tctax2", total, &d_tt2)); STCHK(ensure(c, "tccnt2", total, &d_tc2));
     hipLaunchKernelGGL(k_taxcnt_pack, dim3((uint32_t)((n_reads + 255) / 256)), dim3(256), 0, c->stream, d_res, n_reads, (const uint64_t *)d_off, d_tt, d_tc, d_tt2, d_tc2);
     HIPCHK(hipGetLastError());
@@ -1892,6 +1893,14 @@ mtb_status mtb_classify_batch_device(mtb_ctx *c, mtb_index *ix, const mtb_params
     return MTB_OK;
 }
 
+/* Device-side taxcnt slots of a batch: one per position bucket of every read (k_taxcnt_bound), sum floor((len + 3) / shift) + 2 <=
+ * (bases + 3 reads) / shift + 2 reads.  The host arrays of the single-stream calls only receive the packed lists (download_packed), so their
+ * capacity may be far smaller (2-3 entries per read is typical); MTB_ERR_CAPACITY reports what the lists need. */
+static uint64_t taxcnt_device_slots(const mtb_params *p, uint64_t n_reads, uint64_t n_bases) {
+    mtb_score_params sp; mtb_make_score_params(p, &sp);
+    return (n_bases + 3 * n_reads) / (uint64_t)std::max(1, sp.dna_shift) + 2 * n_reads + 64;
+}
+
 mtb_status mtb_classify_batch(mtb_ctx *c, mtb_index *ix, const mtb_params *p, const char *bases, const uint64_t *offs, const char *bases2,
                               const uint64_t *offs2, uint64_t n_reads, mtb_result *results, int32_t *taxcnt_tax, uint32_t *taxcnt_cnt,
                               uint64_t taxcnt_cap, uint64_t *n_taxcnt) {
@@ -1902,10 +1911,12 @@ mtb_status mtb_classify_batch(mtb_ctx *c, mtb_index *ix, const mtb_params *p, co
     char *d_b, *d_b2; uint64_t *d_o, *d_o2; uint64_t nb;
     STCHK(upload_reads(c, p, bases, offs, bases2, offs2, n_reads, &d_b, &d_o, &d_b2, &d_o2, &nb));
     mtb_result *d_res; int32_t *d_tt; uint32_t *d_tc;
-    STCHK(ensure(c, "results", n_reads, &d_res)); STCHK(ensure(c, "tctax", taxcnt_cap, &d_tt)); STCHK(ensure(c, "tccnt", taxcnt_cap, &d_tc));
-    mtb_status st = mtb_classify_batch_device(c, ix, p, d_b, d_o, d_b2, d_o2, n_reads, nb, d_res, d_tt, d_tc, taxcnt_cap, n_taxcnt);
+    /* one stream: the lists come back packed, the device arrays are sized here and taxcnt_cap only bounds what the host receives */
+    const uint64_t dcap = c->lanes.size() < 2 ? std::max<uint64_t>(taxcnt_cap, taxcnt_device_slots(p, n_reads, nb)) : taxcnt_cap;
+    STCHK(ensure(c, "results", n_reads, &d_res)); STCHK(ensure(c, "tctax", dcap, &d_tt)); STCHK(ensure(c, "tccnt", dcap, &d_tc));
+    mtb_status st = mtb_classify_batch_device(c, ix, p, d_b, d_o, d_b2, d_o2, n_reads, nb, d_res, d_tt, d_tc, dcap, n_taxcnt);
     if (st != MTB_OK) return st;
-    if (c->lanes.size() < 2 && *n_taxcnt) return download_packed(c, d_res, d_tt, d_tc, n_reads, results, taxcnt_tax, taxcnt_cnt, n_taxcnt);
+    if (c->lanes.size() < 2 && *n_taxcnt) return download_packed(c, d_res, d_tt, d_tc, n_reads, results, taxcnt_tax, taxcnt_cnt, n_taxcnt, taxcnt_cap);
     STCHK(d2h(c, results, d_res, n_reads * sizeof(mtb_result)));
     if (*n_taxcnt) { STCHK(d2h(c, taxcnt_tax, d_tt, *n_taxcnt * 4)); STCHK(d2h(c, taxcnt_cnt, d_tc, *n_taxcnt * 4)); }
     return MTB_OK;
@@ -1962,14 +1973,15 @@ mtb_status mtb_classify_batch_packed(mtb_ctx *c, mtb_index *ix, const mtb_params
         STCHK(upload_packed(c, "2", packed2_mate, nmask_mate, lens_mate, n_reads, &d_b2, &d_o2, &nb2));
     }
     mtb_result *d_res; int32_t *d_tt; uint32_t *d_tc;
-    STCHK(ensure(c, "results", n_reads, &d_res)); STCHK(ensure(c, "tctax", taxcnt_cap, &d_tt)); STCHK(ensure(c, "tccnt", taxcnt_cap, &d_tc));
+    const uint64_t dcap = c->lanes.size() < 2 ? std::max<uint64_t>(taxcnt_cap, taxcnt_device_slots(p, n_reads, nb + nb2)) : taxcnt_cap;     /* (as in mtb_classify_batch) */
+    STCHK(ensure(c, "results", n_reads, &d_res)); STCHK(ensure(c, "tctax", dcap, &d_tt)); STCHK(ensure(c, "tccnt", dcap, &d_tc));
     if (timing) HIPCHK(hipStreamSynchronize(c->stream));
     const double t1 = now();
-    mtb_status st = mtb_classify_batch_device(c, ix, p, d_b, d_o, d_b2, d_o2, n_reads, nb + nb2, d_res, d_tt, d_tc, taxcnt_cap, n_taxcnt);
+    mtb_status st = mtb_classify_batch_device(c, ix, p, d_b, d_o, d_b2, d_o2, n_reads, nb + nb2, d_res, d_tt, d_tc, dcap, n_taxcnt);
     if (st != MTB_OK) return st;
     const double t2 = now();
     if (c->lanes.size() < 2 && *n_taxcnt) {
-        st = download_packed(c, d_res, d_tt, d_tc, n_reads, results, taxcnt_tax, taxcnt_cnt, n_taxcnt);
+        st = download_packed(c, d_res, d_tt, d_tc, n_reads, results, taxcnt_tax, taxcnt_cnt, n_taxcnt, taxcnt_cap);
         if (timing) fprintf(stderr, "mtb_classify_batch_packed: %llu reads: upload + unpack %.1f ms, classify %.1f ms (device %.1f ms), pack + download %.1f ms\n",
                             (unsigned long long)n_reads, t1 - t0, t2 - t1, (double)c->stats.ms_total, now() - t2);
         return st;

@@ -1,5 +1,5 @@
 # end-to-end timing of the stand-alone driver (FASTQ on disk -> TSVs on disk) on a synthetic database written by
-# mtb_index_write; usage: python profiles/scripts/e2e_driver.py [n_reads] [n_filler] [threads] [max_reads per host batch, comma list]
+# mtb_index_write; usage: python profiles/scripts/e2e_driver.py [n_reads] [n_filler] [threads] [max_reads per host batch, comma list] [gpu workers, comma list]
 import os, sys, time, subprocess, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
@@ -8,6 +8,7 @@ N = int(float(sys.argv[1])) if len(sys.argv) > 1 else 2_000_000
 NF = int(float(sys.argv[2])) if len(sys.argv) > 2 else 200_000_000
 TH = sys.argv[3] if len(sys.argv) > 3 else "8"
 MR = (sys.argv[4] if len(sys.argv) > 4 else "2000000").split(",")
+GW = (sys.argv[5] if len(sys.argv) > 5 else "2").split(",")
 dev = torch.device("cuda", 0)
 ctx = M.Context(0)
 params = M.default_params(seq_mode=1, syncmer=1, smer_len=5)
@@ -35,10 +36,11 @@ del ix, dv, di, bases; ctx.close(); torch.cuda.empty_cache()
 out = os.path.join(work, "out"); os.makedirs(out)
 exe = os.path.join(os.path.dirname(M.LIB_PATH), "mtb_classify")
 for mr in MR:
+ for gw in GW:
   for rep in range(2):
     t0 = time.perf_counter()
-    subprocess.check_call([exe, "--seq-mode", "1", "--threads", TH, "--max-reads", mr, fq, db, out, "job"], stdout=subprocess.DEVNULL)
+    subprocess.check_call([exe, "--seq-mode", "1", "--threads", TH, "--max-reads", mr, "--gpu-workers", gw, fq, db, out, "job"], stdout=subprocess.DEVNULL)
     dt = time.perf_counter() - t0
-    print(f"max-reads {mr}, run {rep}: {N} reads ({os.path.getsize(fq) / 2**20:.0f} MiB FASTQ) end to end in {dt:.2f} s = {N / dt / 1e6:.2f} Mreads/s "
+    print(f"max-reads {mr}, gpu-workers {gw}, run {rep}: {N} reads ({os.path.getsize(fq) / 2**20:.0f} MiB FASTQ) end to end in {dt:.2f} s = {N / dt / 1e6:.2f} Mreads/s "
           f"(includes opening the index: decode {T} metamers, taxonomy), {TH} host threads", flush=True)
 print(open(os.path.join(out, "job_report.tsv")).read()[:400])

@@ -128,6 +128,25 @@ def test_fused_batch(ctx, toy):
     ix.close()
 
 
+def test_host_taxcnt_arrays_hold_the_packed_lists_only(ctx, toy):
+    """The host arrays of mtb_classify_batch receive the taxID:count lists packed: a capacity of exactly the lists' total is enough
+    (the device-side slots, one per position bucket of every read, are the library's), one entry less is MTB_ERR_CAPACITY reporting
+    the total, and nothing depends on which capacity was offered."""
+    p = _params(toy)
+    ix = ctx.open_index(toy.dbdir, p)
+    res, tt, tc = ctx.classify_batch(ix, p, toy.b1, toy.o1, toy.b2, toy.o2)
+    _check_results(toy, res, tt, tc)
+    total = int(res["n_taxcnt"].sum())
+    assert total > 0
+    res2, tt2, tc2 = ctx.classify_batch(ix, p, toy.b1, toy.o1, toy.b2, toy.o2, taxcnt_cap=total)
+    assert ctx.last_capacity_retries == 0
+    assert (res2 == res).all() and (tt2 == tt).all() and (tc2 == tc).all()
+    res3, tt3, tc3 = ctx.classify_batch(ix, p, toy.b1, toy.o1, toy.b2, toy.o2, taxcnt_cap=total - 1)
+    assert ctx.last_capacity_retries == 1                    # the second call was given the reported size = total
+    assert (res3 == res).all() and (tt3 == tt).all() and (tc3 == tc).all()
+    ix.close()
+
+
 def test_empty_and_ragged_inputs(ctx, orc):
     import metabuli_amd as M
     from helpers import default_params
