@@ -1870,6 +1870,10 @@ mtb_status mtb_classify_batch_device(mtb_ctx *c, mtb_index *ix, const mtb_params
     for (size_t i = 0; i < L; i++) {
         th.emplace_back([&, i]() {
             mtb_ctx *l = c->lanes[i];
+            /* experiment switch: lane i starts i * MTB_LANE_STAGGER_MS late, so that the lanes are in DIFFERENT stages at any moment
+             * (the join is bound by store transactions, the sort by HBM bandwidth, extraction and scoring by VALU issue) */
+            static const int stagger_ms = getenv("MTB_LANE_STAGGER_MS") ? atoi(getenv("MTB_LANE_STAGGER_MS")) : 0;
+            if (stagger_ms > 0 && i > 0) std::this_thread::sleep_for(std::chrono::milliseconds((long)stagger_ms * (long)i));
             for (size_t k = i; k < NC; k += L) {
                 uint64_t lo = n_reads * k / NC, hi = n_reads * (k + 1) / NC;
                 uint64_t n_tc = 0;
