@@ -74,13 +74,13 @@ __global__ __launch_bounds__(MTB_SO_NT) void k_seg_order(const mtb_slot16 *__res
     __shared__ uint16_t sp_dummy[MTB_SO_HASH];
     __shared__ uint32_t s_red[MTB_SO_NW];
     __shared__ unsigned long long s_r;
-    __shared__ uint32_t s_nsp, s_bad, s_total, s_live;
+    __shared__ uint32_t s_nsp, s_bad, s_total, s_live, s_nkept;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const uint64_t lt = lanemask_lt();
 
     for (;;) {
         __syncthreads();
-        if (tid == 0) { s_r = atomicAdd(work, 1ull); s_nsp = 0; s_bad = 0; s_total = 0; s_live = 0; }
+        if (tid == 0) { s_r = atomicAdd(work, 1ull); s_nsp = 0; s_bad = 0; s_total = 0; s_live = 0; s_nkept = 0; }
         __syncthreads();
         const uint64_t r = s_r;
         if (r >= n_reads) break;
@@ -106,7 +106,15 @@ __global__ __launch_bounds__(MTB_SO_NT) void k_seg_order(const mtb_slot16 *__res
             const uint32_t old = atomicOr(&b_once[w], bit);
             if (old & bit) atomicOr(&b_twice[w], bit);
         };
-        for (uint32_t i = q_lo + lane; i < q_hi; i += 64) { const mtb_slot16 x = seg[i]; if (mtb_lslot_live(x)) { mark(mtb_lslot_species(x)); my_live++; } }
+        /* (four 64-slot steps of the quarter per iteration, their loads in flight together: with 8 waves per CU a step per round trip
+         * was the kernel's time; the counting passes do not care about the order inside a quarter) */
+        for (uint32_t i0 = q_lo + lane; i0 < q_hi; i0 += 256) {
+            mtb_slot16 x[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { x[u].a = 0; x[u].b = 0; if (i0 + 64u * u < q_hi) x[u] = seg[i0 + 64u * u]; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) if (mtb_lslot_live(x[u])) { mark(mtb_lslot_species(x[u])); my_live++; }
+        }
         for (uint32_t i = tid; i < t; i += MTB_SO_NT) { const mtb_slot16 x = seg[d + i]; if (mtb_lslot_live(x)) { mark(mtb_lslot_species(x)); my_live++; } else s_bad = 1; }
         if (my_live) atomicAdd(&s_live, my_live);
         __syncthreads();
@@ -124,9 +132,13 @@ __global__ __launch_bounds__(MTB_SO_NT) void k_seg_order(const mtb_slot16 *__res
             return 0;
         };
         /* ---- pass 2: exact counts of those species, per wave quarter; the tail's sort keys ---- */
-        for (uint32_t i = q_lo + lane; i < q_hi; i += 64) {
-            const mtb_slot16 x = seg[i];
-            if (mtb_lslot_live(x)) { const int32_t spc = mtb_lslot_species(x); if (twice(spc)) atomicAdd(&h_cnt[wv >> 1][slot_of(spc)], (wv & 1u) ? 0x10000u : 1u); }
+        for (uint32_t i0 = q_lo + lane; i0 < q_hi; i0 += 256) {
+            mtb_slot16 x[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { x[u].a = 0; x[u].b = 0; if (i0 + 64u * u < q_hi) x[u] = seg[i0 + 64u * u]; }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (mtb_lslot_live(x[u])) { const int32_t spc = mtb_lslot_species(x[u]); if (twice(spc)) atomicAdd(&h_cnt[wv >> 1][slot_of(spc)], (wv & 1u) ? 0x10000u : 1u); }
         }
         for (uint32_t i = tid; i < t; i += MTB_SO_NT) {
             const mtb_slot16 x = seg[d + i];
@@ -153,13 +165,15 @@ __global__ __launch_bounds__(MTB_SO_NT) void k_seg_order(const mtb_slot16 *__res
             if (i == 0 || (uint32_t)(t_key[i - 1] >> 46) != h) h_tstart[h] = i;
         }
         /* ---- kept species ascending -> start of every species' region in the output ---- */
+        /* (only the kept species are sorted -- a few dozen for a typical read, not the table's 1024 slots: 15 - 21 network stages
+         * with a barrier each instead of 55) */
         for (uint32_t q = tid; q < MTB_SO_HASH; q += MTB_SO_NT) {
             const int32_t k = h_key[q];
-            sp_sort[q] = k < 0 ? ~0ull : (((uint64_t)(uint32_t)k << 16) | q);
-            sp_dummy[q] = 0;
+            if (k >= 0) { const uint32_t at = atomicAdd(&s_nkept, 1u); sp_sort[at] = ((uint64_t)(uint32_t)k << 16) | q; sp_dummy[at] = 0; }
         }
         __syncthreads();
-        so_bitonic(sp_sort, sp_dummy, MTB_SO_HASH, tid);
+        const uint32_t n_kept = s_nkept;
+        if (n_kept > 1) so_bitonic(sp_sort, sp_dummy, n_kept, tid);
         __syncthreads();
         {   /* exclusive prefix of the species totals in sorted order (four species per thread); the quarters' running positions
                replace their counts: S[h], S[h] + c0, S[h] + c0 + c1, ... */
@@ -168,7 +182,7 @@ __global__ __launch_bounds__(MTB_SO_NT) void k_seg_order(const mtb_slot16 *__res
             for (int u = 0; u < 4; u++) {
                 const uint32_t j = tid * 4 + u;
                 c[u] = 0; hs[u] = 0;
-                if (j < MTB_SO_HASH && sp_sort[j] != ~0ull) {
+                if (j < n_kept) {
                     hs[u] = (uint32_t)(sp_sort[j] & 0xFFFFu);
                     const uint32_t a = h_cnt[0][hs[u]], b = h_cnt[1][hs[u]];
                     c[u] = (a & 0xFFFFu) + (a >> 16) + (b & 0xFFFFu) + (b >> 16) + h_tcnt[hs[u]];
@@ -193,10 +207,13 @@ __global__ __launch_bounds__(MTB_SO_NT) void k_seg_order(const mtb_slot16 *__res
         }
         __syncthreads();
         /* ---- scatter pass: every wave its quarter, in order ---- */
+        mtb_slot16 x_next; x_next.a = 0; x_next.b = 0;
+        if (q_lo + lane < q_hi) x_next = seg[q_lo + lane];
         for (uint32_t c0 = q_lo; c0 < q_hi; c0 += 64) {
             const uint32_t i = c0 + lane;
-            mtb_slot16 x; x.a = 0; x.b = 0;
-            if (i < q_hi) x = seg[i];
+            const mtb_slot16 x = x_next;                        /* this step's slots were requested a step ago */
+            x_next.a = 0; x_next.b = 0;
+            if (i + 64 < q_hi) x_next = seg[i + 64];
             bool lv = i < q_hi && mtb_lslot_live(x);
             uint32_t h = 0;
             if (lv) {       /* kept = in the exact table and not marked (a species that never entered the table ends the probe at an empty slot) */

@@ -1,0 +1,8 @@
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r3s; O=gpurun_out/r3s
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "long or fused or score or large" > $O/pytest.log 2>&1; tail -3 $O/pytest.log
+timeout 600 python bench.py --cpu-reads 20000 --cpu-targets 16e6 --steps 2 --warmup 2 --seq-mode 3 --reads 200000 --read-len 10000 > $O/bench_long.json 2> $O/bench_long.log; grep "stage ms" $O/bench_long.log; grep "parity" $O/bench_long.log | cut -c1-200
+python - <<'PY'
+import json
+j=json.load(open("gpurun_out/r3s/bench_long.json")); k=j["kernel_ms"]
+print(round(j["ms_per_step"],1), {x:round(k[x]["ms"],2) for x in k if k[x]["ms"]>0}, (j.get("parity_full_index") or {}).get("mismatches"), (j.get("parity_sample") or {}).get("mismatches"))
+PY
