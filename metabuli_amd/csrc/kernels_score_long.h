@@ -42,6 +42,14 @@ struct mtb_lpath { int32_t start, end; float score; int32_t ham; uint32_t rehs; 
 static_assert(sizeof(mtb_lpath) == 32, "32-byte path records");
 static_assert(MTB_LONG_MAXP * sizeof(mtb_lpath) >= MTB_LONG_MAXBKT * 8, "the filter's buckets live in the (dead) path storage");
 
+/* profiling build only (make libmtb_xlprof.so X=-DMTB_LONG_PHASE_CYCLES): cycles of thread 0 per phase, summed over the workgroups;
+ * dev_score_long prints them.  0 setup, 1 block list, 2 walk, 3 rank, 4 species ranges, 5 combination, 6 decision, 7 filter, 8 taxCnt gather, 9 descent + output */
+#ifdef MTB_LONG_PHASE_CYCLES
+__device__ unsigned long long mtb_long_cycles[16];
+#define MTB_LP_MARK(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); lp_acc[k] += t_ - lp_t; lp_t = t_; } while (0)
+#else
+#define MTB_LP_MARK(k) do {} while (0)
+#endif
 __device__ __forceinline__ int32_t lrl_i(int32_t v, int32_t l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ float lrl_f(float v, int32_t l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 __device__ __forceinline__ void lwave_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
@@ -76,6 +84,9 @@ __global__ __launch_bounds__(MTB_LONG_NT) void k_score_long(const mtb_match *__r
     __shared__ mtb_result s_R;
     const int32_t tid = (int32_t)threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint64_t lt = lanemask_lt();
+#ifdef MTB_LONG_PHASE_CYCLES
+    unsigned long long lp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long lp_t = __builtin_readcyclecounter();
+#endif
 
     for (;;) {
         __syncthreads();
@@ -87,6 +98,7 @@ __global__ __launch_bounds__(MTB_LONG_NT) void k_score_long(const mtb_match *__r
         const uint64_t s0 = seg_start[it];
         const int32_t n = seg_cnt ? (int32_t)seg_cnt[it] : (int32_t)(seg_start[it + 1] - s0);      /* (ordered slot segments: the read's records fill the front of its slot range) */
         const mtb_match *m = matches + s0;
+        MTB_LP_MARK(9);
         const int32_t ql1 = qlen[r], ql2 = qlen2[r], read_len = ql1 + ql2;
         const int32_t nb = mtb_num_buckets(read_len, sp.dna_shift);
         const uint64_t off = tc_off[r], room = tc_off[r + 1] - off;
@@ -98,7 +110,10 @@ __global__ __launch_bounds__(MTB_LONG_NT) void k_score_long(const mtb_match *__r
         if (n < 2) { __syncthreads(); if (tid == 0) results[r] = s_R; continue; }          /* no block of two matches: no path, unclassified */
         if (nb > MTB_LONG_MAXBKT) { if (tid == 0) todo[r] = 1; continue; }
 
+        MTB_LP_MARK(0);
         /* ---- blocks: heads of the (species, frame) blocks that hold at least two matches, in order ---- */
+        /* (a wave reserves the places of its step's heads with one LDS atomic: the list's order does not matter -- a path's place in
+         * the emission order is its end match's index -- and the two workgroup barriers per step were an eighth of the kernel) */
         for (int32_t c0 = 0; c0 < n; c0 += MTB_LONG_NT) {
             const int32_t i = c0 + tid;
             bool cand = false;
@@ -110,20 +125,21 @@ __global__ __launch_bounds__(MTB_LONG_NT) void k_score_long(const mtb_match *__r
                 cand = head && k1 == k2;
             }
             const uint64_t cm = __ballot(cand);
-            if (lane == 0) s_red[wv] = (uint32_t)__popcll(cm);
-            __syncthreads();
-            uint32_t before = s_nblk, tot = 0;
-#pragma unroll
-            for (int k = 0; k < MTB_LONG_NW; k++) { const uint32_t c = s_red[k]; if (k < wv) before += c; tot += c; }
-            if (cand) { const uint32_t at = before + (uint32_t)__popcll(cm & lt); if (at < MTB_LONG_MAXBLK) s_blk[at] = (uint32_t)i; }
-            __syncthreads();
-            if (tid == 0) { s_nblk += tot; if (s_nblk > MTB_LONG_MAXBLK) s_fail = 1; }
+            if (cm) {
+                uint32_t at0 = 0;
+                if (lane == 0) at0 = atomicAdd(&s_nblk, (uint32_t)__popcll(cm));
+                at0 = (uint32_t)__shfl((int)at0, 0, 64);
+                if (cand) { const uint32_t at = at0 + (uint32_t)__popcll(cm & lt); if (at < MTB_LONG_MAXBLK) s_blk[at] = (uint32_t)i; }
+            }
         }
+        __syncthreads();
+        if (tid == 0 && s_nblk > MTB_LONG_MAXBLK) s_fail = 1;
         __syncthreads();
         const uint32_t nblk = s_nblk;
         if (s_fail) { if (tid == 0) todo[r] = 1; continue; }
         if (nblk == 0) { if (tid == 0) results[r] = s_R; continue; }
 
+        MTB_LP_MARK(1);
         /* ---- walk: one wave per block ---- */
         for (;;) {
             uint32_t b = 0;
@@ -266,6 +282,7 @@ __global__ __launch_bounds__(MTB_LONG_NT) void k_score_long(const mtb_match *__r
         const int32_t np = (int32_t)s_npath;
         if (np == 0) { if (tid == 0) results[r] = s_R; continue; }               /* no species produced a path: unclassified, score 0 (:372-375) */
 
+        MTB_LP_MARK(2);
         /* ---- combine: stable order by all-pairs rank ---- */
         for (int32_t e = tid; e < np; e += MTB_LONG_NT) {
             const mtb_lpath pe_ = s_path[e];
@@ -277,6 +294,7 @@ __global__ __launch_bounds__(MTB_LONG_NT) void k_score_long(const mtb_match *__r
             s_sidx[rank] = (uint16_t)e;
         }
         __syncthreads();
+        MTB_LP_MARK(3);
         /* species ranges of the sorted list */
         for (int32_t c0 = 0; c0 < np; c0 += MTB_LONG_NT) {
             const int32_t k = c0 + tid;
@@ -297,50 +315,72 @@ __global__ __launch_bounds__(MTB_LONG_NT) void k_score_long(const mtb_match *__r
         const int32_t nsp = (int32_t)s_nsp;
         if (tid == 0) s_splo[nsp] = (uint16_t)np;
         __syncthreads();
-        /* greedy combination, one wave per species */
+        MTB_LP_MARK(4);
+        /* greedy combination, one wave per species.  The accepted paths' (trimmed) ends live in registers, path q * 64 + a in lane a of
+         * register q (the first 256 of a species; further ones are tested out of LDS as before): a candidate is tested against 64
+         * accepted paths per ballot with no LDS gather in the loop -- this loop was a quarter of the kernel (one wave works, the read's
+         * true species holds nearly all paths). */
         for (int32_t j = wv; j < nsp; j += MTB_LONG_NW) {
             const int32_t lo = s_splo[j], hi = s_splo[j + 1];
             float score = 0.0f; int32_t na = 0;
+            int32_t a_st[4] = {0, 0, 0, 0}, a_en[4] = {0, 0, 0, 0};
             for (int32_t k = lo; k < hi; k++) {
                 const int32_t pi = s_sidx[k];
                 mtb_lpath p = s_path[pi];
                 const int32_t p0s = p.start, p0e = p.end;
                 bool drop = false;
-                for (int32_t a0 = 0; a0 < na && !drop; a0 += 64) {
-                    const int32_t a = a0 + lane;
-                    bool ov = false;
-                    if (a < na) { const mtb_lpath c = s_path[s_acc[lo + a]]; ov = !((p0e < c.start) || (c.end < p0s)); }
-                    uint64_t mask = __ballot(ov);                       /* against the untrimmed candidate: a superset (trimming only shrinks it) */
-                    while (mask && !drop) {
-                        const int32_t bq = a0 + (int32_t)__builtin_ctzll(mask); mask &= mask - 1;
-                        const mtb_lpath c = s_path[s_acc[lo + bq]];
-                        if (!((p.end < c.start) || (c.end < p.start))) {
-                            const int32_t ov2 = (p.end < c.end ? p.end : c.end) - (p.start > c.start ? p.start : c.start) + 1;
-                            if (ov2 == p.end - p.start + 1) { drop = true; break; }
-                            if (ov2 < 24) {
-                                if (p.start < c.start) {
-                                    p.end = c.start - 1;
-                                    const int32_t h = p.ham - mtb_part_ham(p.rehs >> 16, ov2 / 3, false); p.ham = h > 0 ? h : 0;
-                                    p.score = p.score - mtb_part_score(p.rehs >> 16, ov2 / 3, false) - (float)(ov2 % 3);
-                                } else {
-                                    p.start = c.end + 1;
-                                    const int32_t h = p.ham - mtb_part_ham(p.rehs & 0xFFFFu, ov2 / 3, true); p.ham = h > 0 ? h : 0;
-                                    p.score = p.score - mtb_part_score(p.rehs & 0xFFFFu, ov2 / 3, true) - (float)(ov2 % 3);
-                                }
-                            } else drop = true;
+                auto against = [&](int32_t cst, int32_t cen) {        /* the reference's loop body for one accepted path (combineMatchPaths :428-468, trimMatchPath :475-485) */
+                    if (!((p.end < cst) || (cen < p.start))) {
+                        const int32_t ov2 = (p.end < cen ? p.end : cen) - (p.start > cst ? p.start : cst) + 1;
+                        if (ov2 == p.end - p.start + 1) { drop = true; return; }
+                        if (ov2 < 24) {
+                            if (p.start < cst) {
+                                p.end = cst - 1;
+                                const int32_t h = p.ham - mtb_part_ham(p.rehs >> 16, ov2 / 3, false); p.ham = h > 0 ? h : 0;
+                                p.score = p.score - mtb_part_score(p.rehs >> 16, ov2 / 3, false) - (float)(ov2 % 3);
+                            } else {
+                                p.start = cen + 1;
+                                const int32_t h = p.ham - mtb_part_ham(p.rehs & 0xFFFFu, ov2 / 3, true); p.ham = h > 0 ? h : 0;
+                                p.score = p.score - mtb_part_score(p.rehs & 0xFFFFu, ov2 / 3, true) - (float)(ov2 % 3);
+                            }
+                        } else drop = true;
+                    }
+                };
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    if (q * 64 < na && !drop) {
+                        const int32_t a = q * 64 + lane;
+                        const bool ov = a < na && !((p0e < a_st[q]) || (a_en[q] < p0s));      /* against the untrimmed candidate: a superset (trimming only shrinks it) */
+                        uint64_t mask = __ballot(ov);
+                        while (mask && !drop) {
+                            const int32_t l = (int32_t)__builtin_ctzll(mask); mask &= mask - 1;
+                            against(lrl_i(a_st[q], l), lrl_i(a_en[q], l));
                         }
                     }
                 }
+                for (int32_t a0 = 256; a0 < na && !drop; a0 += 64) {
+                    const int32_t a = a0 + lane;
+                    bool ov = false;
+                    if (a < na) { const mtb_lpath c = s_path[s_acc[lo + a]]; ov = !((p0e < c.start) || (c.end < p0s)); }
+                    uint64_t mask = __ballot(ov);
+                    while (mask && !drop) {
+                        const int32_t bq = a0 + (int32_t)__builtin_ctzll(mask); mask &= mask - 1;
+                        const mtb_lpath c = s_path[s_acc[lo + bq]];
+                        against(c.start, c.end);
+                    }
+                }
                 if (!drop) {
-                    if (lane == 0) { s_path[pi] = p; s_acc[lo + na] = (uint16_t)pi; }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) if (q == (na >> 6) && lane == (na & 63)) { a_st[q] = p.start; a_en[q] = p.end; }
+                    if (na >= 256) { if (lane == 0) { s_path[pi] = p; s_acc[lo + na] = (uint16_t)pi; } lwave_fence(); }
                     na++; score += p.score;
-                    lwave_fence();
                 }
             }
             float sc = score / (float)read_len; sc = sc < 1.0f ? sc : 1.0f;
             if (lane == 0) s_spsc[j] = sc;
         }
         __syncthreads();
+        MTB_LP_MARK(5);
         /* ---- species decision (thread 0): getBestSpeciesMatches second half, chooseBestTaxon's early exits ---- */
         if (tid == 0) {
             mtb_result R = s_R;
@@ -375,14 +415,55 @@ __global__ __launch_bounds__(MTB_LONG_NT) void k_score_long(const mtb_match *__r
         __syncthreads();
         if (!s_go) { if (tid == 0) results[r] = s_R; continue; }
         const int32_t species = s_species;
+        MTB_LP_MARK(6);
         /* ---- redundancy filter over the best species' matches; buckets in the (dead) path storage ---- */
         uint32_t *hmin = (uint32_t *)s_path; int32_t *btax = (int32_t *)(hmin + MTB_LONG_MAXBKT);
         for (int32_t q = tid; q < nb; q += MTB_LONG_NT) { hmin[q] = 255u; btax[q] = -1; }
         __syncthreads();
-        for (int32_t i = tid; i < n; i += MTB_LONG_NT) if (m[i].species_id == species) mtb_ph_filter_min(m, i, sp.dna_shift, nb, hmin);
+        /* (both passes: the records of two steps requested together; the second pass was a quarter of the kernel because nearly every
+         * match paid an LCA walk of dependent global loads -- the matches of one species carry a handful of distinct taxa, so a thread
+         * keeps its last four (a, b) -> LCA answers in registers) */
+        for (int32_t c0 = 0; c0 < n; c0 += 2 * MTB_LONG_NT) {
+            const int32_t i0 = c0 + tid, i1 = i0 + MTB_LONG_NT;
+            int32_t s0_ = -1, s1_ = -1; uint32_t p0 = 0, p1 = 0, h0 = 0, h1 = 0;
+            if (i0 < n) { s0_ = m[i0].species_id; p0 = mtb_q_pos(m[i0].qinfo); h0 = m[i0].hamming; }
+            if (i1 < n) { s1_ = m[i1].species_id; p1 = mtb_q_pos(m[i1].qinfo); h1 = m[i1].hamming; }
+            if (i0 < n && s0_ == species) { const int32_t q = (int32_t)(p0 / (uint32_t)sp.dna_shift); if (q < nb) atomicMin(&hmin[q], h0); }
+            if (i1 < n && s1_ == species) { const int32_t q = (int32_t)(p1 / (uint32_t)sp.dna_shift); if (q < nb) atomicMin(&hmin[q], h1); }
+        }
         __syncthreads();
-        for (int32_t i = tid; i < n; i += MTB_LONG_NT) if (m[i].species_id == species) mtb_ph_filter_merge(m, i, sp.dna_shift, nb, hmin, btax, &tx);
+        {
+            int32_t ka[4] = {-1, -1, -1, -1}, kb[4] = {-1, -1, -1, -1}, kr[4] = {0, 0, 0, 0}; int kn = 0;
+            auto lca_memo = [&](int32_t a, int32_t b) -> int32_t {
+#pragma unroll
+                for (int u = 0; u < 4; u++) if (ka[u] == a && kb[u] == b) return kr[u];
+                const int32_t v = mtb_lca(&tx, a, b);
+#pragma unroll
+                for (int u = 0; u < 4; u++) if (u == kn) { ka[u] = a; kb[u] = b; kr[u] = v; }
+                kn = (kn + 1) & 3;
+                return v;
+            };
+            auto merge = [&](int32_t q, int32_t t) {            /* mtb_ph_filter_merge with the memo */
+                int32_t old = atomicCAS(&btax[q], -1, t);       /* first id of the bucket stays raw */
+                while (old != -1) {
+                    const int32_t merged = lca_memo(old, t);
+                    if (merged == old) break;
+                    const int32_t seen = atomicCAS(&btax[q], old, merged);
+                    if (seen == old) break;
+                    old = seen;
+                }
+            };
+            for (int32_t c0 = 0; c0 < n; c0 += 2 * MTB_LONG_NT) {
+                const int32_t i0 = c0 + tid, i1 = i0 + MTB_LONG_NT;
+                int32_t s0_ = -1, s1_ = -1, t0 = 0, t1 = 0; uint32_t p0 = 0, p1 = 0, h0 = 0, h1 = 0;
+                if (i0 < n) { s0_ = m[i0].species_id; p0 = mtb_q_pos(m[i0].qinfo); h0 = m[i0].hamming; t0 = m[i0].target_id; }
+                if (i1 < n) { s1_ = m[i1].species_id; p1 = mtb_q_pos(m[i1].qinfo); h1 = m[i1].hamming; t1 = m[i1].target_id; }
+                if (i0 < n && s0_ == species) { const int32_t q = (int32_t)(p0 / (uint32_t)sp.dna_shift); if (q < nb && h0 == hmin[q]) merge(q, t0); }
+                if (i1 < n && s1_ == species) { const int32_t q = (int32_t)(p1 / (uint32_t)sp.dna_shift); if (q < nb && h1 == hmin[q]) merge(q, t1); }
+            }
+        }
         __syncthreads();
+        MTB_LP_MARK(7);
         /* Query::taxCnt: distinct bucket taxa ascending with their bucket counts (std::map order) */
         int32_t ntc = 0, last = -1;
         while ((uint64_t)ntc < room) {
@@ -411,6 +492,7 @@ __global__ __launch_bounds__(MTB_LONG_NT) void k_score_long(const mtb_match *__r
             ntc++; last = mn;
         }
         __syncthreads();
+        MTB_LP_MARK(8);
         /* ---- sub-species descent ---- */
         int32_t slow = ntc > MTB_LR_MAXE ? 1 : 0;
         if (!slow && tid < ntc) {
@@ -433,6 +515,9 @@ __global__ __launch_bounds__(MTB_LONG_NT) void k_score_long(const mtb_match *__r
             results[r] = R;
         }
     }
+#ifdef MTB_LONG_PHASE_CYCLES
+    if (tid == 0) for (int k = 0; k < 10; k++) atomicAdd(&mtb_long_cycles[k], lp_acc[k]);
+#endif
 }
 
 #endif

@@ -869,7 +869,21 @@ static mtb_status dev_score_long(mtb_ctx *c, mtb_index *ix, const mtb_params *p,
     {   KTimer kt(c, MTB_K_SCORE_FAST);       /* booked with the register-resident scorer's id: the workgroup-per-read kernel of long reads */
         const uint32_t grid = (uint32_t)std::min<uint64_t>(d_list ? n_list : n_reads, 256ull * 3);
         hipLaunchKernelGGL(k_score_long, dim3(grid), dim3(MTB_LONG_NT), 0, c->stream, d_m, d_seg, n_reads, d_qlen, d_qlen2, tax_view(ix), sp, (const uint64_t *)d_tcoff,
-                           d_res, d_tc_tax, d_tc_cnt, tc_cap, tc_base, d_todo, d_work, d_segcnt, d_list, n_list); }
+                           d_res, d_tc_tax, d_tc_cnt, tc_cap, tc_base, d_todo, d_work, d_segcnt, d_list, n_list);
+#ifdef MTB_LONG_PHASE_CYCLES
+    {   /* profiling build: cycles of thread 0 per phase of k_score_long, summed over the workgroups (and reset) */
+        HIPCHK(hipStreamSynchronize(c->stream));
+        unsigned long long h[16], z[16] = {0};
+        HIPCHK(hipMemcpyFromSymbol(h, HIP_SYMBOL(mtb_long_cycles), sizeof(h)));
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(mtb_long_cycles), z, sizeof(z)));
+        static const char *nm[10] = {"setup", "block list", "walk", "rank", "species ranges", "combination", "decision", "filter", "taxCnt gather", "descent + output + next read"};
+        unsigned long long tot = 0; for (int k = 0; k < 10; k++) tot += h[k];
+        fprintf(stderr, "k_score_long phases (%llu reads):", (unsigned long long)(d_list ? n_list : n_reads));
+        for (int k = 0; k < 10; k++) fprintf(stderr, " %s %.1f %%;", nm[k], tot ? 100.0 * (double)h[k] / (double)tot : 0.0);
+        fprintf(stderr, "\n");
+    }
+#endif
+    }
     hipLaunchKernelGGL(k_count_flags, dim3(256), dim3(256), 0, c->stream, (const uint8_t *)d_todo, n_reads, (unsigned long long *)(c->d_scal + 6));
     HIPCHK(hipGetLastError());
     uint64_t n_left = 0;
