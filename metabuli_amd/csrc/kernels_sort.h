@@ -269,7 +269,21 @@ __global__ __launch_bounds__(THREADS) void k_radix_hist_seg(const uint16_t *__re
             }
             continue;
         }
-        for (uint32_t i = base + threadIdx.x; i < end; i += THREADS) { const uint32_t d = dig[i]; atomicAdd(&s_h[g][d < NB ? d : NB - 1], 1u); }
+        /* a bucket starts anywhere, so most tiles are not 16-byte aligned: aligned 16-byte chunks over [base, end) with the digits
+         * outside the tile masked (eight 2-byte loads per thread made this kernel 1.8 ms against the aligned kernel's 1.0; the side
+         * arrays end with slack, dev_sort) */
+        const uint32_t a0 = base & ~7u;
+        for (uint32_t ch = threadIdx.x; a0 + 8u * ch < end; ch += THREADS) {
+            const uint32_t first = a0 + 8u * ch;
+            const uint4 q = *(const uint4 *)(dig + first);
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t i0 = first + 2u * k, d0 = w[k] & 0xFFFFu, d1 = w[k] >> 16;
+                if (i0 >= base && i0 < end) atomicAdd(&s_h[g][d0 < NB ? d0 : NB - 1], 1u);
+                if (i0 + 1 >= base && i0 + 1 < end) atomicAdd(&s_h[g][d1 < NB ? d1 : NB - 1], 1u);
+            }
+        }
     }
     __syncthreads();
     const uint32_t last = tile0 + MTB_HIST_GROUP <= tiles ? tile0 + MTB_HIST_GROUP - 1 : tiles - 1;

@@ -443,7 +443,7 @@ static mtb_status dev_extract(mtb_ctx *c, const mtb_params *p, const char *d_bas
         for (int attempt = 0; attempt < 2; attempt++) {
             mtb_kmer *d_k; uint16_t *d_dig = nullptr;
             STCHK(ensure(c, "kmersA", cap, &d_k));
-            if (dig) { STCHK(ensure(c, "digA", cap, &d_dig)); *dig = d_dig; }
+            if (dig) { STCHK(ensure(c, "digA", cap + 8, &d_dig)); *dig = d_dig; }      /* (+8: the bucket-local histograms read whole 16-byte chunks) */
             HIPCHK(hipMemsetAsync(c->d_xscal, 0, 32, c->stream));
             { KTimer kt(c, MTB_K_EXTRACT_EMIT);
             hipLaunchKernelGGL((k_extract<2>), dim3(grid), dim3(64), 0, c->stream, a, c->d_tabs, d_counts, (const uint64_t *)nullptr,
@@ -509,7 +509,7 @@ static mtb_status dev_sort(mtb_ctx *c, mtb_kmer *d_a, uint64_t n, int first_bit,
         /* AA6 with a digit side array: every histogram reads 2-byte digits (the extractor wrote the first pass's, each
          * scatter writes the next pass's in output order) instead of the 16-byte records */
         uint16_t *dig_src = aa ? d_dig : nullptr, *dig_dst = nullptr;
-        if (dig_src) STCHK(ensure(c, "digB", n, &dig_dst));
+        if (dig_src) STCHK(ensure(c, "digB", n + 8, &dig_dst));
         /* the directory join (kernels_dir.h) looks every query up on its own: the sort only buys locality of the directory /
          * target accesses, so the fused path may stop after fewer letter pairs (aa_first_shift: 34 = six letters, 44 = four, 54 = two) */
         if (aa && dig_src && aa_first_shift == 34 && sort_msd_first()) {
