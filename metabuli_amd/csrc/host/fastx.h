@@ -11,8 +11,9 @@
  * fresh pages) and the workers are a persistent pool (round 2 spawned threads per 64 MB block and parsed into per-piece buffers
  * that were copied again: 10 M reads/s with 128 threads, slower than with 32).
  * Sources: plain files are mapped; BGZF (blocked gzip: bgzip, many sequencers' output) is inflated block-parallel -- every
- * block's compressed and uncompressed size is in its header / trailer; any other gzip stream is inflated serially by zlib
- * (~0.4 GB/s of text is the ceiling there: recompress with bgzip for more).
+ * block's compressed and uncompressed size is in its header / trailer; any other gzip stream is inflated serially by zlib on a
+ * background thread of its own, a few chunks ahead of the parser (~0.4 GB/s of text per file is the ceiling there -- the two files of
+ * a paired run inflate concurrently; recompress with bgzip for more).
  *
  * Formats: FASTQ with four lines per record (what sequencers and the reference's test data use; multi-line FASTQ is not
  * supported), FASTA with sequences over any number of lines.  Names end at the first blank, as kseq's do.  Lower-case bases and
@@ -201,6 +202,7 @@ public:
         }
     }
     ~FastxReader() {
+        if (zthread_.joinable()) { { std::lock_guard<std::mutex> l(zm_); zstop_ = true; } zcv_.notify_all(); zthread_.join(); }
         if (gz_) gzclose(gz_);
         if (map_) munmap((void *)map_, map_len_);
     }
@@ -296,17 +298,23 @@ private:
         /* drop what has been consumed, then append at least `more` bytes */
         if (spos_) { const size_t keep = sbuf_.size() - spos_; if (keep) memmove(sbuf_.data(), sbuf_.data() + spos_, keep); sbuf_.resize_uninit(keep); spos_ = 0; }
         if (kind_ == 'z') {
-            const size_t at = sbuf_.size();
-            const size_t add = std::max<size_t>(more, 16u << 20);
-            sbuf_.resize_uninit(at + add);
+            /* a plain gzip stream has one inflate thread at best (~0.4 GB/s of text); it runs in the BACKGROUND, a few chunks ahead, so
+             * that it overlaps the parsing of what it delivered -- and the mate file's stream, which has a thread of its own */
+            if (!zthread_.joinable()) zthread_ = std::thread([this] { inflate_loop(); });
             size_t got = 0;
-            while (got < add) {
-                const int r = gzread(gz_, sbuf_.data() + at + got, (unsigned)std::min<size_t>(add - got, 1u << 30));
-                if (r < 0) throw std::runtime_error("read error (corrupt gzip stream?)");
-                if (r == 0) { src_eof_ = true; break; }
-                got += (size_t)r;
+            const size_t goal = std::max<size_t>(more, ZCHUNK);
+            while (got < goal && !src_eof_) {
+                std::unique_ptr<ZChunk> ch;
+                {
+                    std::unique_lock<std::mutex> l(zm_);
+                    zcv_.wait(l, [&] { return !zq_.empty(); });
+                    ch = std::move(zq_.front()); zq_.erase(zq_.begin());
+                }
+                zcv_.notify_all();
+                if (!ch->err.empty()) throw std::runtime_error(ch->err);
+                if (ch->data.size()) { sbuf_.append(ch->data.data(), ch->data.data() + ch->data.size()); got += ch->data.size(); }
+                if (ch->eof) src_eof_ = true;
             }
-            sbuf_.resize_uninit(at + got);
             return;
         }
         /* BGZF: walk the block headers from the compressed position until `more` uncompressed bytes are covered, inflate the blocks
@@ -353,6 +361,37 @@ private:
         pool_->rethrow();
         pos_ = cp;
         if (pos_ >= map_len_) src_eof_ = true;
+    }
+
+    /* background inflater of a plain gzip stream: chunks of inflated text through a bounded queue */
+    struct ZChunk { PodVec<char> data; bool eof = false; std::string err; };
+    static constexpr size_t ZCHUNK = 16u << 20;
+    void inflate_loop() {
+        for (;;) {
+            std::unique_ptr<ZChunk> ch(new ZChunk());
+            ch->data.resize_uninit(ZCHUNK);
+            size_t got = 0;
+            while (got < ZCHUNK) {
+                const int r = gzread(gz_, ch->data.data() + got, (unsigned)(ZCHUNK - got));
+                if (r < 0) { ch->err = "read error (corrupt gzip stream?)"; break; }
+                if (r == 0) {
+                    int en = Z_OK; (void)gzerror(gz_, &en);
+                    if (en != Z_OK && en != Z_STREAM_END) ch->err = "truncated or corrupt gzip stream";      /* (zlib reports a premature end as Z_BUF_ERROR) */
+                    ch->eof = true; break;
+                }
+                got += (size_t)r;
+            }
+            ch->data.resize_uninit(got);
+            const bool last = ch->eof || !ch->err.empty();
+            {
+                std::unique_lock<std::mutex> l(zm_);
+                zcv_.wait(l, [&] { return zq_.size() < 4 || zstop_; });
+                if (zstop_) return;
+                zq_.push_back(std::move(ch));
+            }
+            zcv_.notify_all();
+            if (last) return;
+        }
     }
 
     /* ---- record geometry ---- */
@@ -470,6 +509,7 @@ private:
     char format_ = 0, kind_ = 'p';              /* p plain (mapped), b BGZF (mapped, inflated block-parallel), z other gzip (zlib stream) */
     const char *map_ = nullptr; size_t map_len_ = 0, pos_ = 0;
     gzFile gz_ = nullptr;
+    std::thread zthread_; std::mutex zm_; std::condition_variable zcv_; std::vector<std::unique_ptr<ZChunk>> zq_; bool zstop_ = false;
     PodVec<char> sbuf_; size_t spos_ = 0; bool src_eof_ = false;         /* inflated text of the stream sources */
     double avg_rec_ = 0.0;                       /* bytes of input per record, from the previous batch: sizes the next window */
     const PackTable *pack_ = nullptr;

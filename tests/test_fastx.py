@@ -105,3 +105,28 @@ def test_bgzf_is_inflated_block_parallel_and_two_bit_packing(dump, tmp_path):
     p.write_bytes(text.encode())
     assert _run(dump, str(p), 4, 3000, 100, "pack") == exp
     assert _run(dump, str(pz), 3, 2000, 77, "pack") == exp
+
+
+def test_plain_gzip_stream_longer_than_the_inflaters_queue(dump, tmp_path):
+    """A plain (non-BGZF) gzip file is inflated by a background thread 16 MB at a time through a bounded queue: 100 MB of FASTQ
+    (more than the queue holds, many refills) must parse exactly like the uncompressed file, and a reader that is destroyed with
+    the stream half read must shut its thread down (the truncated-file case ends with an error, not a hang)."""
+    import hashlib
+    rng = np.random.default_rng(5)
+    seq = "".join(rng.choice(list("ACGT"), size=150))
+    one = "".join(f"@read{i}\n{seq}\n+\n{'I' * 150}\n" for i in range(2000))
+    text = (one * 160).encode()                                  # ~100 MB, 320 000 records
+    p = tmp_path / "big.fq"; p.write_bytes(text)
+    pz = tmp_path / "big.fq.gz"
+    with gzip.open(pz, "wb", compresslevel=1) as f:
+        f.write(text)
+    def digest(path):
+        out = subprocess.run([dump, str(path), "4", str(64 << 20), "50000"], capture_output=True, check=True).stdout
+        return hashlib.sha1(out).hexdigest(), out.count(b"\n")
+    a, b = digest(p), digest(pz)
+    assert a == b and a[1] == 320000
+    # truncated stream: an error, not a hang
+    pt = tmp_path / "cut.fq.gz"
+    pt.write_bytes(pz.read_bytes()[: pz.stat().st_size // 2])
+    r = subprocess.run([dump, str(pt), "4", str(64 << 20), "50000"], capture_output=True, timeout=120)
+    assert r.returncode != 0 and b"error" in r.stderr
