@@ -303,6 +303,10 @@ private:
             if (!zthread_.joinable()) zthread_ = std::thread([this] { inflate_loop(); });
             size_t got = 0;
             const size_t goal = std::max<size_t>(more, ZCHUNK);
+            /* the thread may run a whole request ahead: while this file's batch is parsed (or the mate file's stream is waited for),
+             * the next batch's text is already being inflated */
+            { std::lock_guard<std::mutex> l(zm_); zcap_ = std::max(zcap_, goal / ZCHUNK + 2); }
+            zcv_.notify_all();
             while (got < goal && !src_eof_) {
                 std::unique_ptr<ZChunk> ch;
                 {
@@ -385,7 +389,7 @@ private:
             const bool last = ch->eof || !ch->err.empty();
             {
                 std::unique_lock<std::mutex> l(zm_);
-                zcv_.wait(l, [&] { return zq_.size() < 4 || zstop_; });
+                zcv_.wait(l, [&] { return zq_.size() < zcap_ || zstop_; });
                 if (zstop_) return;
                 zq_.push_back(std::move(ch));
             }
@@ -509,7 +513,7 @@ private:
     char format_ = 0, kind_ = 'p';              /* p plain (mapped), b BGZF (mapped, inflated block-parallel), z other gzip (zlib stream) */
     const char *map_ = nullptr; size_t map_len_ = 0, pos_ = 0;
     gzFile gz_ = nullptr;
-    std::thread zthread_; std::mutex zm_; std::condition_variable zcv_; std::vector<std::unique_ptr<ZChunk>> zq_; bool zstop_ = false;
+    std::thread zthread_; std::mutex zm_; std::condition_variable zcv_; std::vector<std::unique_ptr<ZChunk>> zq_; bool zstop_ = false; size_t zcap_ = 4;
     PodVec<char> sbuf_; size_t spos_ = 0; bool src_eof_ = false;         /* inflated text of the stream sources */
     double avg_rec_ = 0.0;                       /* bytes of input per record, from the previous batch: sizes the next window */
     const PackTable *pack_ = nullptr;
