@@ -256,6 +256,52 @@ class Context:
             _chk(st)
             return compact_taxcnt(res, tt, tc)
 
+    @staticmethod
+    def pack_reads(bases, offs):
+        """host-side 2-bit form of a read batch as mtb_classify_batch_packed takes it (what the C++ parser writes): per read
+        ceil(len / 8) groups of 8 bases -- 16 bits of codes (A 0, C 1, T 2, G 3 and their IUPAC classes, mtb_core.h; base j of a
+        group at bits 2j, little endian) + 8 bits that mark the bases outside those classes -> (packed2, nmask, lens)"""
+        cls = np.full(256, 255, np.uint8)
+        for c, letters in enumerate(("ARW", "CMS", "HTY", "BDGKU")):
+            for ch in letters:
+                cls[ord(ch)] = c; cls[ord(ch.lower())] = c
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offs = np.asarray(offs, dtype=np.uint64)
+        lens = (offs[1:] - offs[:-1]).astype(np.uint32)
+        groups = (lens.astype(np.int64) + 7) // 8
+        gstart = np.zeros(len(lens) + 1, np.int64); np.cumsum(groups, out=gstart[1:])
+        code = cls[bases]
+        # position of every base inside the padded (8 per group) layout
+        read_of = np.repeat(np.arange(len(lens)), lens.astype(np.int64))
+        k = np.arange(len(bases), dtype=np.int64) - offs[:-1].astype(np.int64)[read_of]
+        slot = gstart[:-1][read_of] * 8 + k
+        padded_code = np.zeros(int(gstart[-1]) * 8, np.uint16)
+        padded_bad = np.zeros(int(gstart[-1]) * 8, np.uint8)
+        padded_code[slot] = np.where(code < 4, code, 0)
+        padded_bad[slot] = code >= 4
+        sh2 = (2 * np.arange(8)).astype(np.uint16)
+        packed = (padded_code.reshape(-1, 8) << sh2).sum(axis=1).astype(np.uint16)
+        nmask = (padded_bad.reshape(-1, 8).astype(np.uint16) << np.arange(8).astype(np.uint16)).sum(axis=1).astype(np.uint8)
+        return packed.view(np.uint8).copy(), nmask, lens
+
+    def classify_batch_packed(self, index, params, bases, offs, bases2=None, offs2=None):
+        """mtb_classify_batch_packed on reads packed here (pack_reads); results as classify_batch"""
+        n = len(offs) - 1
+        p1 = self.pack_reads(bases, offs)
+        p2 = self.pack_reads(bases2, offs2) if bases2 is not None else (None, None, None)
+        res = np.zeros(n, result_dt)
+        cap = max(1024, 8 * n)
+        while True:
+            tt = np.zeros(cap, np.int32); tc = np.zeros(cap, np.uint32)
+            cnt = C.c_uint64()
+            st = self.L.mtb_classify_batch_packed(self.h, index.h, C.byref(params), _p(p1[0]), _p(p1[1]), _p(p1[2]), _p(p2[0]), _p(p2[1]), _p(p2[2]),
+                                                  C.c_uint64(n), _p(res), _p(tt), _p(tc), C.c_uint64(cap), C.byref(cnt))
+            if st == MTB_ERR_CAPACITY and cnt.value > cap:
+                cap = cnt.value
+                continue
+            _chk(st)
+            return compact_taxcnt(res, tt, tc)
+
     def classify_batch_device(self, index, params, d_bases, d_offs, d_bases2, d_offs2, n_reads, n_bases,
                               d_results, d_tc_tax, d_tc_cnt, tc_cap):
         cnt = C.c_uint64()

@@ -147,6 +147,25 @@ def test_host_taxcnt_arrays_hold_the_packed_lists_only(ctx, toy):
     ix.close()
 
 
+def test_two_bit_reads_give_the_results_of_the_text(ctx, toy):
+    """mtb_classify_batch_packed (2-bit codes + invalid mask, what the driver sends over PCIe) = mtb_classify_batch on the text, also
+    with invalid letters (N, '-', '*'), IUPAC classes, lower case and lengths that are not multiples of a group of eight"""
+    p = _params(toy)
+    ix = ctx.open_index(toy.dbdir, p)
+    rng = np.random.default_rng(11)
+    def spoil(b):
+        b = b.copy()
+        hit = rng.random(len(b)) < 0.01
+        b[hit] = rng.choice(np.frombuffer(b"NnRYKMSWBDHV-*acgt", np.uint8), size=int(hit.sum()))
+        return b
+    b1 = spoil(toy.b1); b2 = spoil(toy.b2) if toy.b2 is not None else None
+    want = ctx.classify_batch(ix, p, b1, toy.o1, b2, toy.o2)
+    got = ctx.classify_batch_packed(ix, p, b1, toy.o1, b2, toy.o2)
+    for a, b in zip(want, got):
+        assert (a == b).all()
+    ix.close()
+
+
 def test_empty_and_ragged_inputs(ctx, orc):
     import metabuli_amd as M
     from helpers import default_params
