@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <memory>
@@ -181,8 +182,33 @@ inline void fixed_codes(BlockCodes &bc) {
 /* output of a chunk: 16-bit symbols, < 256 = that byte, >= 256 = the byte at position (symbol - 256) of the 32 KB that precede the
  * chunk's output.  known_window: the chunk starts where the history is known (start of a member, or the resolved end of the
  * previous work): then `window` holds it and no marker is ever produced. */
+/* growable array of 16-bit symbols that is never value-initialised and keeps its storage when emptied (64 threads growing
+ * zero-filled vectors page by page were the inflater's time on the GPU box) */
+class SymBuf {
+public:
+    SymBuf() = default;
+    ~SymBuf() { free(p_); }
+    SymBuf(const SymBuf &) = delete; SymBuf &operator=(const SymBuf &) = delete;
+    SymBuf(SymBuf &&o) noexcept : p_(o.p_), n_(o.n_), cap_(o.cap_) { o.p_ = nullptr; o.n_ = o.cap_ = 0; }
+    SymBuf &operator=(SymBuf &&o) noexcept { if (this != &o) { free(p_); p_ = o.p_; n_ = o.n_; cap_ = o.cap_; o.p_ = nullptr; o.n_ = o.cap_ = 0; } return *this; }
+    size_t size() const { return n_; }
+    uint16_t *data() { return p_; } const uint16_t *data() const { return p_; }
+    uint16_t &operator[](size_t i) { return p_[i]; } const uint16_t &operator[](size_t i) const { return p_[i]; }
+    void resize(size_t n) {
+        if (n > cap_) {
+            const size_t c = std::max(n, cap_ + cap_ / 2);
+            uint16_t *q = (uint16_t *)realloc(p_, c * sizeof(uint16_t));
+            if (!q) throw std::bad_alloc();
+            p_ = q; cap_ = c;
+        }
+        n_ = n;
+    }
+    void drop_front(size_t k) { if (k >= n_) { n_ = 0; return; } memmove(p_, p_ + k, (n_ - k) * sizeof(uint16_t)); n_ -= k; }
+private:
+    uint16_t *p_ = nullptr; size_t n_ = 0, cap_ = 0;
+};
 struct Symbols {
-    std::vector<uint16_t> s;
+    SymBuf s;
     bool exact = false;                  /* no markers inside */
 };
 
@@ -198,7 +224,7 @@ inline bool inflate_blocks(BitReader &br, Symbols &out, uint32_t hist, bool text
     BlockCodes bc;
     const uint64_t end_bits = (uint64_t)br.n * 8;
     size_t pos = out.s.size();
-    auto room = [&](size_t need) { if (out.s.size() < pos + need) out.s.resize(std::max(out.s.size() * 3 / 2, pos + need + 65536)); };
+    auto room = [&](size_t need) { if (out.s.size() < pos + need) out.s.resize(pos + need + 65536); };      /* (SymBuf grows its storage geometrically) */
     auto fail = [&]() { out.s.resize(pos); return false; };
     auto done = [&]() { out.s.resize(pos); return true; };
     for (;;) {
@@ -317,12 +343,15 @@ private:
         std::string err;
         uint32_t next = 0;             /* index of the chunk whose start this one reached (n = none: ran to the end) */
         size_t out_off = 0;
+        void reset() { start = end = 0; sym.s.resize(0); sym.exact = false; ok = false; final_member_end = false; member_ends.clear(); err.clear(); next = 0; out_off = 0; }
     };
+    std::vector<Chunk> chunks_;
 
     /* block finder: first bit position >= from (and < to) where a non-final dynamic block with complete codes starts whose first
      * symbols are text */
     uint64_t find_start(uint64_t from, uint64_t to) const {
         pgz::BlockCodes bc;
+        pgz::Symbols s;
         for (uint64_t b = from; b < to; b++) {
             pgz::BitReader br(d_, n_, b);
             const uint64_t w = br.peek();
@@ -333,7 +362,8 @@ private:
             if (!pgz::read_dynamic_header(br, bc)) continue;
             /* trial: the block's first symbols */
             pgz::BitReader t(d_, n_, b);
-            pgz::Symbols s; bool fin = false;
+            bool fin = false;
+            s.s.resize(0);
             if (!pgz::inflate_blocks(t, s, pgz::WIN, true, 8192, [](uint64_t) { return true; }, &fin)) continue;
             if (s.s.size() < 64 || fin) continue;
             return b;
@@ -349,7 +379,10 @@ private:
         const size_t byte0 = (size_t)(bit_ >> 3);
         size_t nch = 1;
         while (nch < G + 1 && byte0 + nch * chunk_ + 64 < n_) nch++;
-        std::vector<Chunk> ch(nch);
+        std::vector<Chunk> &ch = chunks_;                  /* (kept between waves: their symbol buffers are grown once) */
+        if (ch.size() < nch) ch.resize(nch);
+        while (ch.size() > nch) ch.pop_back();
+        for (auto &c : ch) c.reset();
         ch[0].start = bit_;
         /* 1. starts of the chunks 1 .. nch-1 (the last one is only a stop mark for this wave) */
         run_(nch - 1, [&](size_t k) {
@@ -479,12 +512,12 @@ private:
                 if (!ds) { c.err = "garbage after a gzip member"; return; }
                 br.pos = (uint64_t)ds * 8;
                 /* a new member starts without history */
-                if (lead) { c.sym.s.erase(c.sym.s.begin(), c.sym.s.begin() + (long)lead); lead = 0; }
+                if (lead) { c.sym.s.drop_front(lead); lead = 0; }
                 member_start_fix(c, hist);
                 while (next < nch && (ch[next].start == 0 || ch[next].start < br.pos)) next++;
                 if (next < nch && ch[next].start == br.pos) { c.next = next; c.end = br.pos; break; }
             }
-            if (lead) c.sym.s.erase(c.sym.s.begin(), c.sym.s.begin() + (long)lead);
+            if (lead) c.sym.s.drop_front(lead);
             c.ok = true;
         } catch (const std::exception &e) { c.err = e.what(); }
     }
