@@ -12,7 +12,7 @@
  * that were copied again: 10 M reads/s with 128 threads, slower than with 32).
  * Sources: plain files are mapped; BGZF (blocked gzip: bgzip, many sequencers' output) is inflated block-parallel -- every
  * block's compressed and uncompressed size is in its header / trailer; an ordinary gzip file is inflated block-parallel too, from
- * guessed block starts with unknown windows (pgzip.h: 2.8 GB/s of text on 64 threads of the GPU box against 0.39 through one zlib
+ * guessed block starts with unknown windows (pgzip.h: 3.3 GB/s of text on 64 threads of the GPU box against 0.39 through one zlib
  * stream); files below 4 MB, or a reader with one thread, use a zlib stream on a background thread of its own.
  *
  * Formats: FASTQ with four lines per record (what sequencers and the reference's test data use; multi-line FASTQ is not

@@ -134,6 +134,11 @@ inline bool read_dynamic_header(BitReader &br, BlockCodes &bc) {
     uint8_t cl[19]; memset(cl, 0, sizeof(cl));
     if (br.eof(3 * hclen)) return false;
     for (uint32_t i = 0; i < hclen; i++) cl[order[i]] = (uint8_t)br.bits(3);
+    {   /* Kraft sum of the code-length code first: nearly every wrong candidate of the block finder ends here, before any table is built */
+        uint32_t kraft = 0;
+        for (int i = 0; i < 19; i++) if (cl[i]) kraft += 128u >> cl[i];
+        if (kraft != 128u) return false;
+    }
     Huff clh;
     if (clh.build(cl, 19) != 0) return false;                      /* zlib requires a complete code-length code */
     uint8_t lens[286 + 30];
@@ -246,6 +251,62 @@ inline bool inflate_blocks(BitReader &br, Symbols &out, uint32_t hist, bool text
         } else {
             if (btype == 1) fixed_codes(bc);
             else if (!read_dynamic_header(br, bc)) return fail();
+            /* fast loop: far from the end of the input and with room for a few hundred symbols, no per-symbol bounds checks; a short
+             * literal leaves enough valid bits in the loaded word for the symbol behind it (57 - 9 >= 48), so common text costs one
+             * load per two symbols.  Leaves to the careful loop below at the block's end, near the input's end, or in finder mode. */
+            if (!text_only && !max_symbols) {
+                const uint8_t *base = br.p;
+                const uint64_t safe_end = br.n > 32 ? (uint64_t)(br.n - 32) * 8 : 0;
+                uint64_t bp = br.pos;
+                bool more = true;
+                while (more && bp < safe_end) {
+                    room(8192);
+                    uint16_t *o = out.s.data();
+                    const size_t stop_at = out.s.size() - 600;
+                    while (pos < stop_at && bp < safe_end) {
+                        uint64_t w; memcpy(&w, base + (bp >> 3), 8); w >>= (bp & 7);
+                        uint32_t used;
+                        int sym = bc.lit.decode_word(w, &used);
+                        if (sym < 256) {
+                            if (sym < 0) { br.pos = bp; return fail(); }
+                            o[pos++] = (uint16_t)sym; bp += used;
+                            if (used > 9) continue;
+                            w >>= used;
+                            sym = bc.lit.decode_word(w, &used);
+                            if (sym < 256) { if (sym < 0) { br.pos = bp; return fail(); } o[pos++] = (uint16_t)sym; bp += used; continue; }
+                        }
+                        bp += used;
+                        if (sym == 256) { more = false; break; }
+                        if (sym > 285) { br.pos = bp; return fail(); }
+                        w >>= used;
+                        const uint32_t le = LEN_EXTRA[sym - 257];
+                        const uint32_t len = LEN_BASE[sym - 257] + (uint32_t)(w & ((1u << le) - 1u));
+                        w >>= le; bp += le;
+                        if (!bc.dist_usable) { br.pos = bp; return fail(); }
+                        const int ds = bc.dist.decode_word(w, &used);
+                        if (ds < 0 || ds > 29) { br.pos = bp; return fail(); }
+                        w >>= used;
+                        const uint32_t de = DIST_EXTRA[ds];
+                        const uint32_t dist = DIST_BASE[ds] + (uint32_t)(w & ((1u << de) - 1u));
+                        bp += used + de;
+                        if (dist > pos + hist) { br.pos = bp; return fail(); }
+                        if (dist <= pos) {
+                            const size_t from = pos - dist;
+                            if (dist >= len) memcpy(o + pos, o + from, 2u * len);
+                            else for (uint32_t i = 0; i < len; i++) o[pos + i] = o[from + i];
+                        } else {
+                            if (out.exact) { br.pos = bp; return fail(); }
+                            for (uint32_t i = 0; i < len; i++) {
+                                const int64_t src = (int64_t)pos + i - (int64_t)dist;
+                                o[pos + i] = src >= 0 ? o[src] : (uint16_t)(256 + (int64_t)WIN + src);
+                            }
+                        }
+                        pos += len;
+                    }
+                }
+                br.pos = bp;
+                if (!more) goto block_done;                          /* end-of-block symbol seen */
+            }
             for (;;) {
                 if (br.pos > end_bits) return fail();
                 room(260);
@@ -293,10 +354,35 @@ inline bool inflate_blocks(BitReader &br, Symbols &out, uint32_t hist, bool text
                 if (max_symbols && pos > max_symbols) return done();
             }
         }
+    block_done:
         if (br.pos > end_bits) return fail();
         if (bfinal) { *final_seen = true; return done(); }
         if (stop(br.pos)) return done();
     }
+}
+
+/* CRC-32 (the gzip polynomial, reflected 0xEDB88320) eight bytes per step with eight tables: zlib 1.2.11's crc32() ran at ~0.55 GB/s
+ * and was a third of a thread's time; same values (so crc32_combine joins the pieces).  Little-endian hosts. */
+struct Crc32Tables {
+    uint32_t t[8][256];
+    Crc32Tables() {
+        for (uint32_t i = 0; i < 256; i++) { uint32_t c = i; for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1; t[0][i] = c; }
+        for (uint32_t i = 0; i < 256; i++) for (int k = 1; k < 8; k++) t[k][i] = (t[k - 1][i] >> 8) ^ t[0][t[k - 1][i] & 0xFF];
+    }
+};
+inline uint32_t crc32_fast(const uint8_t *p, size_t n) {
+    static const Crc32Tables T;
+    uint32_t c = 0xFFFFFFFFu;
+    while (n && ((uintptr_t)p & 7)) { c = T.t[0][(c ^ *p++) & 0xFF] ^ (c >> 8); n--; }
+    while (n >= 8) {
+        uint64_t v; memcpy(&v, p, 8);
+        v ^= c;
+        c = T.t[7][v & 0xFF] ^ T.t[6][(v >> 8) & 0xFF] ^ T.t[5][(v >> 16) & 0xFF] ^ T.t[4][(v >> 24) & 0xFF] ^
+            T.t[3][(v >> 32) & 0xFF] ^ T.t[2][(v >> 40) & 0xFF] ^ T.t[1][(v >> 48) & 0xFF] ^ T.t[0][v >> 56];
+        p += 8; n -= 8;
+    }
+    while (n--) c = T.t[0][(c ^ *p++) & 0xFF] ^ (c >> 8);
+    return c ^ 0xFFFFFFFFu;
 }
 
 /* gzip member header at byte offset `at` (RFC 1952); returns the offset of the deflate data, 0 if there is no valid header */
@@ -439,18 +525,34 @@ private:
             char *o = dst + c.out_off;
             const size_t m = c.sym.s.size();
             const uint16_t *s = c.sym.s.data();
-            if (c.sym.exact) for (size_t j = 0; j < m; j++) o[j] = (char)s[j];
-            else {
-                if (w.size() != pgz::WIN) {
-                    for (size_t j = 0; j < m; j++) { if (s[j] >= 256) throw std::runtime_error("gzip: reference before the start of the stream"); o[j] = (char)s[j]; }
-                } else for (size_t j = 0; j < m; j++) o[j] = s[j] < 256 ? (char)s[j] : (char)w[s[j] - 256];
+            {   /* eight symbols at a time where none of them is a marker (markers thin out quickly behind a chunk's first 32 KB) */
+                const bool have_w = w.size() == pgz::WIN;
+                size_t j = 0;
+                for (; j + 8 <= m; j += 8) {
+                    uint64_t a, b; memcpy(&a, s + j, 8); memcpy(&b, s + j + 4, 8);
+                    if (((a | b) & 0xFF00FF00FF00FF00ull) == 0) {
+                        const uint64_t lo = (a & 0xFF) | ((a >> 8) & 0xFF00) | ((a >> 16) & 0xFF0000) | ((a >> 24) & 0xFF000000ull);
+                        const uint64_t hi = (b & 0xFF) | ((b >> 8) & 0xFF00) | ((b >> 16) & 0xFF0000) | ((b >> 24) & 0xFF000000ull);
+                        const uint64_t v = lo | (hi << 32);
+                        memcpy(o + j, &v, 8);
+                    } else {
+                        for (size_t k = j; k < j + 8; k++) {
+                            if (s[k] < 256) o[k] = (char)s[k];
+                            else { if (!have_w) throw std::runtime_error("gzip: reference before the start of the stream"); o[k] = (char)w[s[k] - 256]; }
+                        }
+                    }
+                }
+                for (; j < m; j++) {
+                    if (s[j] < 256) o[j] = (char)s[j];
+                    else { if (!have_w) throw std::runtime_error("gzip: reference before the start of the stream"); o[j] = (char)w[s[j] - 256]; }
+                }
             }
             size_t from = 0;
             for (auto &me : c.member_ends) {
-                pieces[i].push_back(Piece{(uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef *)o + from, (uInt)(me.first - from)), me.first - from});
+                pieces[i].push_back(Piece{pgz::crc32_fast((const uint8_t *)o + from, me.first - from), me.first - from});
                 from = me.first;
             }
-            pieces[i].push_back(Piece{(uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef *)o + from, (uInt)(m - from)), m - from});
+            pieces[i].push_back(Piece{pgz::crc32_fast((const uint8_t *)o + from, m - from), m - from});
         });
         /* 6. member checks (CRC-32 and ISIZE of RFC 1952) in file order */
         for (size_t i = 0; i < chain.size(); i++) {
