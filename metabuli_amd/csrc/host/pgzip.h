@@ -416,7 +416,7 @@ public:
     /* appends at least `want` bytes of inflated text to `out` (fewer only at the end of the file) */
     template <class Vec> void produce(Vec &out, size_t want) {
         size_t made = 0;
-        while (made < want && !done_) made += wave(out);
+        while (made < want && !done_) made += wave(out, want - made);
     }
 
 private:
@@ -458,9 +458,11 @@ private:
     }
 
     /* one wave: up to 2 x threads chunks from the current position; returns the bytes appended */
-    template <class Vec> size_t wave(Vec &out) {
+    template <class Vec> size_t wave(Vec &out, size_t want) {
         const uint64_t total_bits = (uint64_t)n_ * 8;
-        const size_t G = (size_t)threads_ * 2;
+        /* two chunks per thread, but no more than the request is likely to need (text inflates ~3 - 4 x): the symbols of a wave take
+         * four bytes of memory per byte of compressed input and two per byte of text */
+        const size_t G = std::max<size_t>(2, std::min<size_t>((size_t)threads_ * 2, want / (3 * chunk_) + 2));
         /* chunk k >= 1 starts searching at byte (cur_byte + k * chunk_); chunk 0 starts exactly at bit_ */
         const size_t byte0 = (size_t)(bit_ >> 3);
         size_t nch = 1;
