@@ -50,3 +50,11 @@ def test_reference_flags_without_a_meaning_here_are_accepted(exe, tmp_path):
     assert "unknown flag" not in err and "usage:" not in err
     assert err.count("accepted for compatibility") == 9         # everything above except --mask 0 (silently fine) and --threads / --seq-mode
     assert "mtb_classify:" in err.splitlines()[-1]              # the actual failure comes last and names the program
+
+
+def test_own_flags_are_parsed(exe, tmp_path):
+    """--max-reads / --pack-reads / --gpu-workers / --devices / --partitioned are the driver's own flags: they must get through the
+    parser (the run then fails at the database, not at the command line)"""
+    rc, err = _run(exe, "--max-reads", "100000", "--pack-reads", "0", "--gpu-workers", "2", "--devices", "0", "--partitioned", "0", "--lineage", "1",
+                   "--seq-mode", "1", "r.fq", str(tmp_path / "nodb"), str(tmp_path), "job")
+    assert rc == 1 and "unknown flag" not in err and "usage:" not in err and "missing value" not in err
