@@ -13,3 +13,13 @@ def test_float_and_integer_formatting_equal_printf(tmp_path):
     out = subprocess.check_output([exe, "61"], text=True)
     assert out.startswith("OK "), out
     assert int(out.split()[1]) > 5_000_000
+
+
+def test_batched_path_combination_equals_the_serial_loop(tmp_path):
+    """tests/emu/combine_batched_check.cpp: the greedy combination of a species' paths evaluated 64 (and 7) candidates at a time =
+    the reference's one-at-a-time loop (accepted paths, trims, score bits) on random path sets -- the wave-parallel form the long-read
+    scorer's combination phase is to take next"""
+    exe = str(tmp_path / "combine_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "emu", "combine_batched_check.cpp")])
+    out = subprocess.check_output([exe, "5000"], text=True)
+    assert out.startswith("OK "), out
