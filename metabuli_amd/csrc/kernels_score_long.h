@@ -316,20 +316,23 @@ __global__ __launch_bounds__(MTB_LONG_NT) void k_score_long(const mtb_match *__r
         if (tid == 0) s_splo[nsp] = (uint16_t)np;
         __syncthreads();
         MTB_LP_MARK(4);
-        /* greedy combination, one wave per species.  The accepted paths' (trimmed) ends live in registers, path q * 64 + a in lane a of
-         * register q (the first 256 of a species; further ones are tested out of LDS as before): a candidate is tested against 64
-         * accepted paths per ballot with no LDS gather in the loop -- this loop was a quarter of the kernel (one wave works, the read's
-         * true species holds nearly all paths). */
+        /* greedy combination, one wave per species, 64 candidate paths per step (a lane each).  Every lane runs its candidate against the
+         * paths accepted BEFORE the batch, in order (their trimmed ends are broadcast: the first 256 live in registers, path q * 64 + a in
+         * lane a of register q; further ones in LDS); then the first surviving lane is accepted -- nothing accepted later can precede it
+         * -- and the lanes behind it run against that path, and so on.  A candidate meets exactly the accepted paths it meets in the
+         * reference's one-at-a-time loop (combineMatchPaths :428-468, trimMatchPath :475-485), in the same order, and the scores are
+         * added in acceptance order: same bits (checked on the host, tests/emu/combine_batched_check.cpp).  The serial form was a
+         * quarter of the kernel: one wave tested one candidate per step while the read's true species holds nearly all paths. */
         for (int32_t j = wv; j < nsp; j += MTB_LONG_NW) {
             const int32_t lo = s_splo[j], hi = s_splo[j + 1];
             float score = 0.0f; int32_t na = 0;
             int32_t a_st[4] = {0, 0, 0, 0}, a_en[4] = {0, 0, 0, 0};
-            for (int32_t k = lo; k < hi; k++) {
-                const int32_t pi = s_sidx[k];
+            for (int32_t k0 = lo; k0 < hi; k0 += 64) {
+                const int32_t nbt = hi - k0 < 64 ? hi - k0 : 64;
+                const int32_t pi = lane < nbt ? (int32_t)s_sidx[k0 + lane] : 0;
                 mtb_lpath p = s_path[pi];
-                const int32_t p0s = p.start, p0e = p.end;
-                bool drop = false;
-                auto against = [&](int32_t cst, int32_t cen) {        /* the reference's loop body for one accepted path (combineMatchPaths :428-468, trimMatchPath :475-485) */
+                bool drop = lane >= nbt, taken = false;
+                auto against = [&](int32_t cst, int32_t cen) {        /* the reference's loop body for one accepted path */
                     if (!((p.end < cst) || (cen < p.start))) {
                         const int32_t ov2 = (p.end < cen ? p.end : cen) - (p.start > cst ? p.start : cst) + 1;
                         if (ov2 == p.end - p.start + 1) { drop = true; return; }
@@ -346,34 +349,36 @@ __global__ __launch_bounds__(MTB_LONG_NT) void k_score_long(const mtb_match *__r
                         } else drop = true;
                     }
                 };
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    if (q * 64 < na && !drop) {
-                        const int32_t a = q * 64 + lane;
-                        const bool ov = a < na && !((p0e < a_st[q]) || (a_en[q] < p0s));      /* against the untrimmed candidate: a superset (trimming only shrinks it) */
-                        uint64_t mask = __ballot(ov);
-                        while (mask && !drop) {
-                            const int32_t l = (int32_t)__builtin_ctzll(mask); mask &= mask - 1;
-                            against(lrl_i(a_st[q], l), lrl_i(a_en[q], l));
-                        }
-                    }
+                /* the paths accepted before this batch */
+                const int32_t na0 = na;
+                for (int32_t a = 0; a < na0; a++) {
+                    int32_t cst, cen;
+                    if (a < 256) {
+                        const int32_t q = a >> 6, l = a & 63;
+                        const int32_t vs = q == 0 ? a_st[0] : q == 1 ? a_st[1] : q == 2 ? a_st[2] : a_st[3];
+                        const int32_t ve = q == 0 ? a_en[0] : q == 1 ? a_en[1] : q == 2 ? a_en[2] : a_en[3];
+                        cst = lrl_i(vs, l); cen = lrl_i(ve, l);
+                    } else { const mtb_lpath c = s_path[s_acc[lo + a]]; cst = c.start; cen = c.end; }
+                    if (!__any(!drop)) break;
+                    if (!drop) against(cst, cen);
                 }
-                for (int32_t a0 = 256; a0 < na && !drop; a0 += 64) {
-                    const int32_t a = a0 + lane;
-                    bool ov = false;
-                    if (a < na) { const mtb_lpath c = s_path[s_acc[lo + a]]; ov = !((p0e < c.start) || (c.end < p0s)); }
-                    uint64_t mask = __ballot(ov);
-                    while (mask && !drop) {
-                        const int32_t bq = a0 + (int32_t)__builtin_ctzll(mask); mask &= mask - 1;
-                        const mtb_lpath c = s_path[s_acc[lo + bq]];
-                        against(c.start, c.end);
-                    }
-                }
-                if (!drop) {
+                /* the batch's survivors, in order */
+                for (;;) {
+                    const uint64_t sm = __ballot(!drop && !taken);
+                    if (!sm) break;
+                    const int32_t f = (int32_t)__builtin_ctzll(sm);
+                    const int32_t fst = lrl_i(p.start, f), fen = lrl_i(p.end, f);
+                    const float fsc = lrl_f(p.score, f);
+                    if (na < 256) {
 #pragma unroll
-                    for (int q = 0; q < 4; q++) if (q == (na >> 6) && lane == (na & 63)) { a_st[q] = p.start; a_en[q] = p.end; }
-                    if (na >= 256) { if (lane == 0) { s_path[pi] = p; s_acc[lo + na] = (uint16_t)pi; } lwave_fence(); }
-                    na++; score += p.score;
+                        for (int q = 0; q < 4; q++) if (q == (na >> 6) && lane == (na & 63)) { a_st[q] = fst; a_en[q] = fen; }
+                    } else {
+                        if (lane == f) { s_path[pi] = p; s_acc[lo + na] = (uint16_t)pi; }
+                        lwave_fence();
+                    }
+                    na++; score += fsc;
+                    if (lane == f) taken = true;
+                    if (lane > f && !drop) against(fst, fen);
                 }
             }
             float sc = score / (float)read_len; sc = sc < 1.0f ? sc : 1.0f;
