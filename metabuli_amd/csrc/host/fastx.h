@@ -176,10 +176,19 @@ public:
         : window_(window_bytes < 16 ? 16 : window_bytes) {
         if (pool) pool_ = pool; else { own_pool_.reset(new WorkerPool(threads)); pool_ = own_pool_.get(); }
         threads_ = pool ? pool->size() : (threads < 1 ? 1 : threads);
+        struct stat sb;
+        if (stat(path.c_str(), &sb) != 0) throw std::runtime_error("cannot open " + path);
+        if (!S_ISREG(sb.st_mode)) {
+            /* a pipe (process substitution, /dev/stdin): nothing to map or to look ahead in, and it can be opened only once -- zlib's
+             * stream reader takes gzip and plain text alike (as the reference's KSeqWrapper over gzread does) */
+            gz_ = gzopen(path.c_str(), "rb");
+            if (!gz_) throw std::runtime_error("cannot open " + path);
+            gzbuffer(gz_, 1u << 20);
+            kind_ = 'z';
+            return;
+        }
         int fd = open(path.c_str(), O_RDONLY);
         if (fd < 0) throw std::runtime_error("cannot open " + path);
-        struct stat sb;
-        if (fstat(fd, &sb) != 0) { close(fd); throw std::runtime_error("cannot stat " + path); }
         unsigned char magic[18]; memset(magic, 0, sizeof(magic));
         const ssize_t got = pread(fd, magic, sizeof(magic), 0);
         const bool gz = got >= 2 && magic[0] == 0x1f && magic[1] == 0x8b;

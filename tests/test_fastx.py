@@ -130,3 +130,22 @@ def test_plain_gzip_stream_longer_than_the_inflaters_queue(dump, tmp_path):
     pt.write_bytes(pz.read_bytes()[: pz.stat().st_size // 2])
     r = subprocess.run([dump, str(pt), "4", str(64 << 20), "50000"], capture_output=True, timeout=120)
     assert r.returncode != 0 and b"error" in r.stderr
+
+
+def test_reads_from_a_pipe(dump, tmp_path):
+    """a FIFO (process substitution) cannot be mapped or looked ahead in: it goes through the zlib stream reader, plain or gzip"""
+    rng = np.random.default_rng(3)
+    recs, text = _records(rng, 500, True)
+    for payload in (text.encode(), gzip.compress(text.encode())):
+        fifo = tmp_path / "in.fifo"
+        if fifo.exists():
+            fifo.unlink()
+        os.mkfifo(fifo)
+        import threading
+        def feed():
+            with open(fifo, "wb") as f:
+                f.write(payload)
+        t = threading.Thread(target=feed); t.start()
+        got = _run(dump, str(fifo), 4, 1 << 20, 100)
+        t.join()
+        assert got == recs
