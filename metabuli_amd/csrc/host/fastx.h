@@ -465,6 +465,11 @@ private:
             const char *q_end = plus_end < e ? line_end(plus_end + 1, e) : e;
             if (partial && q_end >= e) return nullptr;
             const char *se = s_end; if (se > s && se[-1] == '\r') se--;
+            /* four-line records only (what sequencers write); anything else -- wrapped sequence lines, a missing '+' line, a quality
+             * string of another length -- is refused, not guessed at */
+            const char *qs = plus_end < e ? plus_end + 1 : e, *qe = q_end; if (qe > qs && qe[-1] == '\r') qe--;
+            if (*p != '@' || s_end + 1 >= e || s_end[1] != '+' || (size_t)(qe - qs) != (size_t)(se - s))
+                throw std::runtime_error("malformed FASTQ record (four-line records are expected): " + std::string(p, (size_t)std::min<ptrdiff_t>(h_end - p, 60)));
             on_name(name, (size_t)(ne - name));
             on_seq(s, (size_t)(se - s));
             return q_end < e ? q_end + 1 : e;

@@ -149,3 +149,17 @@ def test_reads_from_a_pipe(dump, tmp_path):
         got = _run(dump, str(fifo), 4, 1 << 20, 100)
         t.join()
         assert got == recs
+
+
+def test_malformed_fastq_is_refused(dump, tmp_path):
+    """wrapped sequence lines, a missing '+' line or a quality string of another length: an error that names the record, not a guess"""
+    good = "@r1\nACGTACGT\n+\nIIIIIIII\n@r2\nACGT\n+\nIIII\n"
+    for bad in ("@r1\nACGT\nACGT\n+\nIIII\nIIII\n",            # wrapped
+                "@r1\nACGTACGT\nIIIIIIII\n@r2\nACGT\n+\nIIII\n",  # no '+' line
+                "@r1\nACGTACGT\n+\nIII\n@r2\nACGT\n+\nIIII\n"):   # quality too short
+        p = tmp_path / "bad.fq"
+        p.write_text(bad)
+        r = subprocess.run([dump, str(p), "2", "1000", "10"], capture_output=True)
+        assert r.returncode != 0 and b"malformed FASTQ" in r.stderr, (bad, r.stderr)
+    p = tmp_path / "good.fq"; p.write_text(good)
+    assert _run(dump, str(p), 2, 1000, 10) == [("r1", "ACGTACGT"), ("r2", "ACGT")]
