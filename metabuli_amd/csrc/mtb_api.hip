@@ -2221,6 +2221,17 @@ mtb_status mtb_classify_batch_partitioned(mtb_ctx **ctxs, mtb_index **parts, uin
         mtb_match *d_matches = nullptr;                   /* as an owner */
         std::vector<mtb_result> res; std::vector<int32_t> tt; std::vector<uint32_t> tc; uint64_t ntc = 0;
     };
+    /* direct device-to-device copies over xGMI where the devices can reach each other (without peer access hipMemcpyPeerAsync stages
+     * through host memory); enabling it twice is reported as an error that means "already on" */
+    for (uint32_t i = 0; i < n; i++) for (uint32_t j = 0; j < n; j++) {
+        if (!ctxs[i] || !ctxs[j] || ctxs[i]->device == ctxs[j]->device) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, ctxs[i]->device, ctxs[j]->device) != hipSuccess) { (void)hipGetLastError(); continue; }
+        if (!can) continue;
+        if (hipSetDevice(ctxs[i]->device) != hipSuccess) { (void)hipGetLastError(); continue; }
+        const hipError_t e = hipDeviceEnablePeerAccess(ctxs[j]->device, 0);
+        if (e != hipSuccess) (void)hipGetLastError();
+    }
     std::vector<Rank> R(n);
     for (uint32_t k = 0; k < n; k++) { R[k].lo = n_reads * k / n; R[k].hi = n_reads * (k + 1) / n; R[k].counts.assign(n, 0); R[k].starts.assign(n, 0); R[k].m_count.assign(n, 0); R[k].m_start.assign(n, 0); }
     std::string err;
