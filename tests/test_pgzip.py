@@ -98,3 +98,27 @@ def test_reader_takes_big_gzip_files_through_the_parallel_inflater(tools, tmp_pa
     assert want[1] == 60000
     assert digest(gz) == want
     assert digest(gz, env=dict(os.environ, MTB_NO_PGZIP="1")) == want
+
+
+def test_other_compressor_strategies_and_binary_data(tools, tmp_path, text):
+    """fixed-Huffman-only, Huffman-only and run-length streams, binary data (nothing passes the finder's text test: one thread inflates it
+    all), and a text that only starts after megabytes of binary"""
+    import zlib
+    chk = tools[0]
+    rng = np.random.default_rng(2)
+    binary = rng.integers(0, 256, size=3_000_000, dtype=np.uint8).tobytes()
+    cases = []
+    for strategy in (zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FILTERED):
+        co = zlib.compressobj(6, zlib.DEFLATED, 31, 8, strategy)
+        cases.append((text[:2_500_000], co.compress(text[:2_500_000]) + co.flush()))
+    cases.append((binary, gzip.compress(binary, 6)))
+    mixed = binary + text[:3_000_000]
+    cases.append((mixed, gzip.compress(mixed, 6)))
+    low = b"".join(bytes([65 + (i * 7) % 4]) * (1 + i % 300) for i in range(20000))          # long runs: matches at distance 1, overlapping copies
+    cases.append((low, gzip.compress(low, 9)))
+    for k, (plain, comp) in enumerate(cases):
+        assert gzip.decompress(comp) == plain
+        p = tmp_path / f"c{k}.gz"; p.write_bytes(comp)
+        for threads, chunk in ((4, 65536), (2, 1 << 20)):
+            r = _inflate(chk, p, threads, chunk)
+            assert r.returncode == 0 and r.stdout == plain, (k, threads, chunk, r.stderr[:200])
