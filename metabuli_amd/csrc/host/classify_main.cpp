@@ -339,7 +339,7 @@ int main(int argc, char **argv) {
         const size_t ND = engs.size();
         const double t_open = now() - t_start;
         double t_parse = 0, t_gpu = 0, t_write = 0, t_dev = 0, t_fmt = 0, t_app = 0;  /* busy time of the three stages; device time inside the GPU stage */
-        FILE *out = fopen((prefix + "_classifications.tsv").c_str(), "w");
+        FILE *out = fopen((prefix + "_classifications.tsv").c_str(), "w+");      /* read + write: append_parts maps the file MAP_SHARED, which needs a readable descriptor */
         if (!out) throw std::runtime_error("cannot write " + prefix + "_classifications.tsv");
         FILE *flt[2] = {nullptr, nullptr}, *rmv[2] = {nullptr, nullptr};
         if (filter) {
@@ -391,6 +391,8 @@ int main(int argc, char **argv) {
                 const double t0 = now();
                 const size_t n = j->r1.size();
                 format_pool.run(NP, [&](size_t t) { format_reads(*j, n * t / NP, n * (t + 1) / NP, eng.index, lineage, parts[t], &piece_counts[t]); });
+                try { format_pool.rethrow(); } catch (const std::exception &e) { if (writer_err.empty()) writer_err = std::string("formatting failed: ") + e.what(); }
+                if (!writer_err.empty()) { idle.put(std::move(j)); continue; }      /* nothing is written after a failure; the buffers keep the pipeline draining */
                 const double t1 = now();
                 append_parts(out, parts, format_pool, writer_err);
                 t_fmt += t1 - t0; t_app += now() - t1;

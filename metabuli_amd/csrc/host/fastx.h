@@ -278,7 +278,7 @@ public:
             }
             /* places in the batch */
             std::vector<size_t> r0(used + 1), b0(used + 1), n0(used + 1), s0(used + 1);
-            r0[0] = out.size(); b0[0] = out.bases.size(); n0[0] = out.names.size(); s0[0] = out.slots;
+            r0[0] = out.size(); b0[0] = out.size() ? (size_t)out.offs[out.size()] : 0; n0[0] = out.names.size(); s0[0] = out.slots;      /* (the running base count, also when the text itself is not kept) */
             for (size_t k = 0; k < used; k++) { r0[k + 1] = r0[k] + pc[k].n_rec; b0[k + 1] = b0[k] + pc[k].n_bases; n0[k + 1] = n0[k] + pc[k].n_name; s0[k + 1] = s0[k] + pc[k].n_slots; }
             out.offs.resize_uninit(r0[used] + 1); out.name_offs.resize_uninit(r0[used] + 1);
             if (text_needed()) out.bases.resize_uninit(b0[used]);
@@ -355,7 +355,7 @@ private:
             if (h[0] != 0x1f || h[1] != 0x8b || !(h[3] & 4)) throw std::runtime_error("not a BGZF block where one is expected");
             const size_t xlen = h[10] | ((size_t)h[11] << 8);
             size_t bsize = 0;
-            for (size_t x = 12; x + 4 <= 12 + xlen && cp + x + 4 <= map_len_;) {            /* the 'BC' subfield: total block size - 1 */
+            for (size_t x = 12; x + 6 <= 12 + xlen && cp + x + 6 <= map_len_;) {            /* the 'BC' subfield: total block size - 1 */
                 const size_t slen = h[x + 2] | ((size_t)h[x + 3] << 8);
                 if (h[x] == 'B' && h[x + 1] == 'C' && slen == 2) { bsize = (h[x + 4] | ((size_t)h[x + 5] << 8)) + 1; break; }
                 x += 4 + slen;
@@ -363,6 +363,7 @@ private:
             if (bsize < 12 + xlen + 8 || cp + bsize > map_len_) throw std::runtime_error("corrupt BGZF block");
             const unsigned char *tail = h + bsize - 4;
             const size_t isize = tail[0] | ((size_t)tail[1] << 8) | ((size_t)tail[2] << 16) | ((size_t)tail[3] << 24);
+            if (isize > 65536) throw std::runtime_error("corrupt BGZF block (ISIZE beyond 64 KiB)");      /* the format's bound; the trailer is not trusted for the allocation */
             blks.push_back(Blk{cp + 12 + xlen, bsize - 12 - xlen - 8, up, isize});
             cp += bsize; up += isize;
         }
@@ -381,6 +382,9 @@ private:
                 zs.next_out = (Bytef *)(dst + b.upos); zs.avail_out = (uInt)b.ulen;
                 const int rc = inflate(&zs, Z_FINISH);
                 if (rc != Z_STREAM_END || zs.avail_out != 0) { inflateEnd(&zs); throw std::runtime_error("corrupt BGZF block (inflate)"); }
+                const unsigned char *tr = (const unsigned char *)map_ + b.cpos + b.clen;              /* CRC32 of the block's text, little endian, in front of ISIZE */
+                const uint32_t want = tr[0] | ((uint32_t)tr[1] << 8) | ((uint32_t)tr[2] << 16) | ((uint32_t)tr[3] << 24);
+                if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef *)(dst + b.upos), (uInt)b.ulen) != want) { inflateEnd(&zs); throw std::runtime_error("corrupt BGZF block (CRC mismatch)"); }
             }
             inflateEnd(&zs);
         });

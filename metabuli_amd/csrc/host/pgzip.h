@@ -613,7 +613,7 @@ private:
                 while (nh < n_ && d_[nh] == 0) nh++;                                                /* zero padding between / after members is tolerated (as gzip -d does) */
                 if (nh >= n_) { c.final_member_end = true; c.end = 0; c.next = (uint32_t)nch; break; }
                 const size_t ds = pgz::member_header(d_, n_, nh);
-                if (!ds) { c.err = "garbage after a gzip member"; return; }
+                if (!ds) { c.final_member_end = true; c.end = 0; c.next = (uint32_t)nch; break; }      /* non-gzip bytes behind a complete member end the input, as zlib's gzread (the small-file path and the reference's kseq reader) treats them */
                 br.pos = (uint64_t)ds * 8;
                 /* a new member starts without history */
                 if (lead) { c.sym.s.drop_front(lead); lead = 0; }

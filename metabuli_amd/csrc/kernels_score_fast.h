@@ -267,7 +267,7 @@ __global__ __launch_bounds__(64, K <= 3 ? 5 : 4) void k_score_fast(const mtb_slo
                             if (u == t) continue;
                             const FKey ku = s_key[s_tl[u]];
                             if (!same_run(ku, kt)) continue;
-                            n_tl_less += less(ku, kt) ? 1u : 0u; n_tl_before += u < t ? 1u : 0u;
+                            n_tl_less += (less(ku, kt) || (!less(kt, ku) && u < t)) ? 1u : 0u; n_tl_before += u < t ? 1u : 0u;      /* equal keys (one metamer value in several targets of a species): tail order breaks the tie, two records never share a place */
                         }
                         const int32_t run_start = ti - (int32_t)n_dir_run - (int32_t)n_tl_before;
 #pragma unroll

@@ -2132,7 +2132,12 @@ mtb_status mtb_part_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_kmers, uin
         sa.list = 1; sa.ovf = d_out; sa.ovf_cap = cap;
         return dev_join(c, ix, d_kmers, n, nullptr, 0, nullptr, count, &sa);
     }
-    return dev_join(c, ix, d_kmers, n, d_out, cap, nullptr, count);
+    /* no directory over this range (MTB_NO_DIR, no room, a letter >= 21, a tiny range): the bisection join.  The runs of a slot-mode
+     * batch are ordered on the leading amino-acid letters only (bits [34, 64) for kmer_format 2, mtb_part_extract), and k_join_bounds
+     * derives a tile's target window from its first and last query under exactly that assumption -- so the sender's granularity is
+     * passed on (the exact-order runs of the other modes are ordered on those bits too).  Records leave with pad = 0: the home rank
+     * places them through the tails / the overflow list, which is slower but exact. */
+    return dev_join(c, ix, d_kmers, n, d_out, cap, nullptr, count, nullptr, ix->params.kmer_format == 2 ? 34 : 32);
 }
 
 mtb_status mtb_part_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, mtb_match *d_matches, uint64_t n_matches, uint64_t n_reads,
