@@ -3,10 +3,19 @@
 the reads and the target index already resident in HBM.
 
 One "step" = one pass of the whole hot path (extract -> radix sort -> join
-against the resident index -> regroup/segment sort -> per-read scoring) over one
-batch of synthetic reads (BASELINE.json configs[1]: 10 M x 150 bp single-end
-vs a GTDB-scale synthetic index).  One process per GPU; reads are sharded, the
-index is replicated, there is no data-path collective (weak scaling).
+against the resident index -> per-read scoring) over one batch of synthetic
+reads (BASELINE.json configs[1]: 10 M x 150 bp single-end vs a GTDB-scale
+synthetic index).  One process per GPU; reads are sharded, the index is
+replicated, there is no data-path collective (weak scaling).
+
+The workload (round 4): reads drawn from 2400 genomes (0.6 x coverage -- not the
+62 x of 24 genomes, which is this engine's best case and is reported beside it as
+`best_case`), an index whose candidate runs are heavy-tailed (conserved segments
+shared by the genomes at Zipf-like prevalence, multiplied by further species:
+runs up to ~10^4 where the reads hit them; `run_lengths` in the line), and --
+after the timed region, outside it -- short legs of the other two single-GPU
+configurations (configs[3]'s per-GPU shape: read pairs; configs[2]: long reads)
+with parity samples of their own (`other_configs`).
 
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8 ...
@@ -25,21 +34,54 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PEAK_GBS = 8000.0        # HBM3E peak of one MI355X (MI355X_MICROARCH.md)
+
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+# --------------------------------------------------------------------------------------------------------------------
+# synthetic world
+# --------------------------------------------------------------------------------------------------------------------
 def build_world(seed, n_species, genome_len, n_filler_species):
     from metabuli_amd import synth
     return synth.make_world(seed=seed, n_genera=max(1, n_species // 4), species_per_genus=4, strains_per_species=1,
                             genome_len=genome_len, n_filler_species=n_filler_species)
 
 
-def build_world_fast(torch, dev, seed, n_species, genome_len, n_filler_species):
+# conserved segments: (prevalence = fraction of the genomes that carry a segment of the class, segments of the class).  With 2400 genomes
+# a segment of prevalence 0.55 gives candidate runs of ~1000 species for the amino-acid 8-mers of its coding frame (78 % of the copies
+# keep an 8-mer), prevalence 1 gives ~1900; about 1 % of a batch's query metamers meet such a run.
+CONSERVED_CLASSES = ((1.0, 10), (0.55, 150), (0.25, 20), (0.1, 20))
+_GENETIC_CODE_TCAG = "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG"      # standard code, codons in TCAG order
+
+
+def _codon_tables(torch, dev):
+    """codon index = 16 b0 + 4 b1 + b2 with bases in A C G T order (0..3).  -> (syn [64, 6] synonymous codons of every sense codon,
+    n_syn [64], sense [61] the sense codons)"""
+    tcag = "TCAG"
+    aa_of = [None] * 64
+    for i, aa in enumerate(_GENETIC_CODE_TCAG):
+        b = (tcag[i // 16], tcag[(i // 4) % 4], tcag[i % 4])
+        aa_of[16 * "ACGT".index(b[0]) + 4 * "ACGT".index(b[1]) + "ACGT".index(b[2])] = aa
+    syn = torch.zeros((64, 6), dtype=torch.int64, device=dev); n_syn = torch.ones(64, dtype=torch.int64, device=dev)
+    for c in range(64):
+        same = [d for d in range(64) if aa_of[d] == aa_of[c]] if aa_of[c] != "*" else [c]
+        n_syn[c] = len(same)
+        syn[c, : len(same)] = torch.tensor(same, device=dev)
+    sense = torch.tensor([c for c in range(64) if aa_of[c] != "*"], device=dev)
+    return syn, n_syn, sense
+
+
+def build_world_fast(torch, dev, seed, n_species, genome_len, n_filler_species, conserved=True, p_syn=0.7, p_nonsyn=0.03, seg_len=999):
     """Same shape as synth.make_world (root -> {Bacteria, Eukaryota} -> genus -> 4 species -> 1 strain, genus divergence 15 %,
-    strain divergence 1 %) for THOUSANDS of genomes: sequences are drawn and mutated on the device (Bernoulli substitutions) instead
-    of numpy's choice-without-replacement per genome.  Used for the genome-diversity runs (--species >= 200)."""
+    strain divergence 1 %) for THOUSANDS of genomes: sequences are drawn and mutated on the device (Bernoulli substitutions).
+    conserved: every genome additionally carries protein-coding segments of a common pool (CONSERVED_CLASSES: 333 codons each, present in
+    a class-dependent fraction of the genomes) at random places, every copy with 70 % of its codons redrawn among the synonymous ones
+    and 3 % replaced by another amino acid's -- core genes as real databases hold them: the amino-acid 8-mers of the coding frame are
+    shared by hundreds to thousands of species (candidate runs of that length in the index, where reads of ANY genome hit them) while
+    their DNA differs from species to species, so that a long run costs its scan, not thousands of matches."""
     from metabuli_amd import synth
     g = torch.Generator(device=dev); g.manual_seed(seed)
     tax = synth.Taxonomy()
@@ -52,6 +94,14 @@ def build_world_fast(torch, dev, seed, n_species, genome_len, n_filler_species):
         m = torch.rand(x.shape, generator=g, device=dev) < rate
         sub = (x + torch.randint(1, 4, x.shape, generator=g, device=dev, dtype=torch.uint8)) & 3       # a DIFFERENT base
         return torch.where(m, sub, x)
+    n_slots = genome_len // seg_len
+    n_seg = sum(n for _, n in CONSERVED_CLASSES)
+    n_cod = seg_len // 3
+    conserved = conserved and n_slots >= 3 * n_seg
+    if conserved:
+        syn, n_syn, sense = _codon_tables(torch, dev)
+        pool = sense[torch.randint(0, len(sense), (n_seg, n_cod), generator=g, device=dev)]           # codons of the pool's segments
+        prev = torch.tensor([f for f, n in CONSERVED_CLASSES for _ in range(n)], device=dev)
     genomes, species = [], []
     for gi in range(n_genera):
         dom = 3 if gi == n_genera - 1 else 2
@@ -64,17 +114,91 @@ def build_world_fast(torch, dev, seed, n_species, genome_len, n_filler_species):
             species.append(sid)
             tid = nxt; nxt += 1
             tax.add(tid, sid, "no rank", f"Genus{gi} species{sidx} strain0")
-            genomes.append((tid, acgt[mutate(mutate(anc, 0.15), 0.01).long()].cpu().numpy()))
+            seq = mutate(mutate(anc, 0.15), 0.01)
+            if conserved:
+                carried = torch.nonzero(torch.rand(n_seg, generator=g, device=dev) < prev).flatten()
+                if len(carried):
+                    cod = pool[carried]
+                    u = torch.rand(cod.shape, generator=g, device=dev)
+                    r = torch.randint(0, 1 << 30, cod.shape, generator=g, device=dev)
+                    cod = torch.where(u < p_syn, syn[cod, r % n_syn[cod]], cod)
+                    cod = torch.where((u >= p_syn) & (u < p_syn + p_nonsyn), sense[r % len(sense)], cod)
+                    nt = torch.stack(((cod >> 4) & 3, (cod >> 2) & 3, cod & 3), dim=2).reshape(len(carried), n_cod * 3).to(torch.uint8)
+                    slots = torch.randperm(n_slots, generator=g, device=dev)[: len(carried)]
+                    seq[: n_slots * seg_len].view(n_slots, seg_len)[slots, : n_cod * 3] = nt
+            genomes.append((tid, acgt[seq.long()].cpu().numpy()))
     lo = nxt
     for i in range(n_filler_species):
         tax.add(nxt, 2, "species", f"filler{i}"); nxt += 1
     return synth.World(tax, genomes, species, lo, nxt - 1)
 
 
-def extract_targets(ctx, M, world, params, torch=None, dev=None, genomes_per_call=48):
+def _mix64(torch, x):
+    """splitmix64 finaliser on int64 tensors (wrapping arithmetic)"""
+    x = (x ^ (x >> 30).bitwise_and(0x3FFFFFFFF)) * -4658895280553007687          # 0xBF58476D1CE4E5B9
+    x = (x ^ (x >> 27).bitwise_and(0x1FFFFFFFFF)) * -7723592293110705685         # 0x94D049BB133111EB
+    return x ^ (x >> 31).bitwise_and(0x1FFFFFFFF)
+
+
+# shared-run multiplier by a hash of the amino-acid part: most shared runs stay as the genomes give them, a few grow 2 - 8 x
+HOT_MULT = (0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 3, 7)
+
+
+def hot_run_extras(torch, dev, hv, tax_lo, tax_span, hot_min, seed):
+    """Further species for the candidate runs that the genomes already share: hv = the genome-derived target values of one sign half,
+    ascending.  A run (equal amino-acid part) of r >= hot_min entries gets m x r extra entries, m = HOT_MULT[hash of the amino-acid
+    part] (the longest runs of ~1900 genome-derived entries reach ~15 000): each extra is the DNA of one entry of its run with one to
+    three codons redrawn among the OTHER codons the index holds for that amino acid (the letter -> codon-id table is read off the
+    genome-derived entries themselves), filed under a species of the filler range.  Returns (values, taxids) ordered by (value, taxid)."""
+    aa = hv >> 24
+    uniq, counts = torch.unique_consecutive(aa, return_counts=True)
+    starts = torch.cumsum(counts, 0) - counts
+    mult = torch.tensor(HOT_MULT, device=dev)[(_mix64(torch, uniq + seed) >> 7) & 15]
+    hot = (counts >= hot_min) & (mult > 0)
+    if not bool(hot.any()):
+        return hv[:0], torch.empty(0, dtype=torch.int32, device=dev)
+    h_start, h_cnt, h_aa, mult = starts[hot], counts[hot], uniq[hot], mult[hot]
+    del uniq, counts, starts, aa, hot
+    # valid codon ids of every 5-bit amino-acid letter, from a sample of the entries (letter j of 8: bits 24 + 5 (7 - j), its codon id: bits 3 (7 - j))
+    smp = hv[:: max(1, len(hv) // 4_000_000)]
+    tbl = torch.zeros((32, 8), dtype=torch.bool, device=dev)
+    for j in range(8):
+        tbl[(smp >> (24 + 5 * (7 - j))) & 31, (smp >> (3 * (7 - j))) & 7] = True
+    n_cid = tbl.sum(1)
+    cid_list = torch.zeros((32, 8), dtype=torch.int64, device=dev); cid_pos = torch.zeros((32, 8), dtype=torch.int64, device=dev)
+    for L in range(32):
+        ids = torch.nonzero(tbl[L]).flatten()
+        cid_list[L, : len(ids)] = ids; cid_pos[L, ids] = torch.arange(len(ids), device=dev)
+    n_extra = h_cnt * mult
+    tot = int(n_extra.sum().item())
+    run = torch.repeat_interleave(torch.arange(len(h_cnt), device=dev), n_extra)
+    k = torch.arange(tot, device=dev) - (torch.cumsum(n_extra, 0) - n_extra)[run]
+    e_aa = h_aa[run]
+    h = _mix64(torch, e_aa * 1000003 + k + seed)
+    dna = hv[h_start[run] + ((h >> 3) & 0x7FFFFFFF) % h_cnt[run]] & 0xFFFFFF
+    n_mut = 1 + ((h >> 40) & 0xFFFF) % 3
+    for m in range(3):
+        hm = _mix64(torch, h + 77 * (m + 1))
+        sh = 3 * (7 - ((hm >> 9) & 7))                               # the codon that changes
+        L = (e_aa >> (5 * (7 - ((hm >> 9) & 7)))) & 31
+        cur = (dna >> sh) & 7
+        n = n_cid[L]
+        other = (cid_pos[L, cur] + 1 + ((hm >> 20) & 0xFFFF) % torch.clamp(n - 1, min=1)) % torch.clamp(n, min=1)
+        newc = torch.where(n > 1, cid_list[L, other], cur)
+        dna = torch.where(m < n_mut, (dna & ~(7 << sh)) | (newc << sh), dna)
+    ev = (e_aa << 24) | dna
+    et = (tax_lo + ((h >> 20) & 0x7FFFFFFF) % tax_span).to(torch.int32)
+    o = torch.sort(et, stable=True).indices
+    ev, et = ev[o], et[o]
+    o = torch.sort(ev, stable=True).indices
+    return ev[o], et[o]
+
+
+def extract_targets(ctx, M, world, params, torch=None, dev=None, genomes_per_call=48, hot_min=0, seed=0):
     """Six-frame (sync)metamers of every genome, on the GPU, via the public extraction entry point (long-read geometry,
     overlapping 20 kb pieces), a few dozen genomes per call; per-genome de-duplication and the final (value, taxid) order on the
-    device when torch is given (thousands of genomes), else numpy."""
+    device when torch is given (thousands of genomes), else numpy.  hot_min > 0 (device path): runs shared by at least that many
+    genome-derived entries are multiplied by further species (hot_run_extras).  Returns (values, taxids, n_extras)."""
     piece, ov = 20000, 32
     p = M.default_params(seq_mode=3, syncmer=params.syncmer, smer_len=params.smer_len)
     vals, tids = [], []
@@ -109,74 +233,46 @@ def extract_targets(ctx, M, world, params, torch=None, dev=None, genomes_per_cal
     if torch is not None:
         # unsigned 64-bit order = the non-negative int64 values ascending, then the negative ones ascending; the halves are
         # sorted separately (torch.sort and boolean masks take < 2^31 elements per call)
-        out_v, out_t = [], []
+        out_v, out_t, n_extras = [], [], 0
         for half in (0, 1):
             hv = torch.cat([x[half] for x in vals])
             ht = torch.cat([torch.full((len(x[half]),), tid, dtype=torch.int32, device=dev) for x, tid in zip(vals, tids)])
             if len(hv) >= 2**31:
                 raise SystemExit(f"{len(hv)} genome-derived metamers in one sign half: more than one torch.sort call takes")
             order = torch.sort(hv, stable=True).indices
-            out_v.append(hv[order].cpu().numpy().view(np.uint64)); out_t.append(ht[order].cpu().numpy())
-            del hv, ht, order
+            hv, ht = hv[order], ht[order]
+            del order
+            if hot_min > 0 and len(hv):
+                ev, et = hot_run_extras(torch, dev, hv, world.filler_tax_lo, world.filler_tax_hi - world.filler_tax_lo + 1, hot_min, seed)
+                if len(ev):
+                    if len(hv) + len(ev) >= 2**31:
+                        raise SystemExit("genome-derived metamers + shared-run extras of one sign half exceed one torch.sort call")
+                    n_extras += len(ev)
+                    # filler species ids lie above every strain id: behind the genome-derived entries of the same value, a stable sort by value keeps (value, taxid) order
+                    hv = torch.cat([hv, ev]); ht = torch.cat([ht, et])
+                    del ev, et
+                    order = torch.sort(hv, stable=True).indices
+                    hv, ht = hv[order], ht[order]
+                    del order
+            out_v.append(hv.cpu().numpy().view(np.uint64)); out_t.append(ht.cpu().numpy())
+            del hv, ht
         del vals
         torch.cuda.empty_cache()
-        return np.concatenate(out_v), np.concatenate(out_t)
+        return np.concatenate(out_v), np.concatenate(out_t), n_extras
     vals = np.concatenate(vals); tids = np.concatenate(tids)
     order = np.lexsort((tids, vals))
-    return vals[order], tids[order]
+    return vals[order], tids[order], 0
 
 
-def candidate_closure(torch, d_values, d_info, T, q_values):
-    """Every target of the flat device index whose amino-acid part equals that of a query metamer, plus the index's true last
-    entry -- computed with torch.searchsorted on the flat arrays, i.e. by nothing of the library under test.  Matches(q) depends on
-    no other target (C(q) = {t < T-1 : AA(t) = AA(q)}), so the oracle on this sub-database must give every read of
-    the sample the answer the GPU gives against the whole index.  Returns (values u64, taxids i32) as numpy arrays."""
-    dev = d_values.device
-    aa = np.unique(np.asarray(q_values, dtype=np.uint64) >> np.uint64(24))
-    v = d_values[:T]
-    # the array is sorted as UNSIGNED 64-bit; as int64 it is [non-negative ascending | negative ascending]: find the split by
-    # bisection on single elements and search each half with the queries of its sign
-    lo, hi = 0, T
-    while lo < hi:
-        mid = (lo + hi) // 2
-        if int(v[mid].item()) >= 0:
-            lo = mid + 1
-        else:
-            hi = mid
-    n_pos = lo
-    lo_key = (aa << np.uint64(24)).view(np.int64)
-    hi_key = (((aa + np.uint64(1)) << np.uint64(24)) - np.uint64(1)).view(np.int64)       # last value of the amino-acid part (no wrap at the top)
-    neg = lo_key < 0
-    starts = np.empty(len(aa), np.int64); ends = np.empty(len(aa), np.int64)
-    for sel, base, seg in ((~neg, 0, v[:n_pos]), (neg, n_pos, v[n_pos:])):
-        if not sel.any():
-            continue
-        a = torch.searchsorted(seg, torch.from_numpy(lo_key[sel]).to(dev), right=False) + base
-        b = torch.searchsorted(seg, torch.from_numpy(hi_key[sel]).to(dev), right=True) + base
-        starts[sel] = a.cpu().numpy(); ends[sel] = b.cpu().numpy()
-    cnt = ends - starts
-    keep = cnt > 0
-    starts, cnt = starts[keep], cnt[keep]
-    tot = int(cnt.sum())
-    first = np.zeros(len(cnt) + 1, np.int64); np.cumsum(cnt, out=first[1:])
-    idx = np.repeat(starts - first[:-1], cnt) + np.arange(tot, dtype=np.int64)
-    if tot == 0 or idx[-1] != T - 1:
-        idx = np.append(idx, T - 1)                      # the entry the `t < T-1` rule excludes must be the sub-database's last one too
-    di = torch.from_numpy(idx).to(dev)
-    cv = d_values[di].cpu().numpy().view(np.uint64); ct = d_info[di].cpu().numpy().view(np.int32) & np.int32(0x7FFFFFFF)
-    assert (cv[1:] >= cv[:-1]).all()
-    return cv, ct
-
-
-def gen_reads(torch, dev, world, n_reads, read_len, frac_random, err, seed, paired=False, frag_len=400):
+def gen_reads(torch, dev, genomes, n_reads, read_len, frac_random, err, seed, paired=False, frag_len=400):
     """Reads sampled from the genomes (both strands, substitutions) + random
     reads, generated on the device so that the inputs are HBM-resident.
     paired: fragments of frag_len bases, mate 1 = its first read_len bases, mate 2 = the first read_len bases of its
     reverse complement (BASELINE.json configs[3] shape); returns (bases1, offs, bases2)."""
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
-    G = torch.from_numpy(np.concatenate([x for _, x in world.genomes]).astype(np.uint8)).to(dev)
-    lens = torch.tensor([len(x) for _, x in world.genomes], device=dev, dtype=torch.int64)
+    G = torch.from_numpy(np.concatenate([x for _, x in genomes]).astype(np.uint8)).to(dev)
+    lens = torch.tensor([len(x) for _, x in genomes], device=dev, dtype=torch.int64)
     starts = torch.cumsum(lens, 0) - lens
     comp = torch.full((256,), ord("N"), dtype=torch.uint8, device=dev)
     for a, b in zip(b"ACGT", b"TGCA"):
@@ -186,7 +282,7 @@ def gen_reads(torch, dev, world, n_reads, read_len, frac_random, err, seed, pair
     out2 = torch.empty(n_reads * read_len, dtype=torch.uint8, device=dev) if paired else None
     span = frag_len if paired else read_len
     ar = torch.arange(span, device=dev, dtype=torch.int64)
-    chunk = 1_000_000
+    chunk = max(1, min(1_000_000, 200_000_000 // span))
     for c0 in range(0, n_reads, chunk):
         n = min(chunk, n_reads - c0)
         gi = torch.randint(0, len(lens), (n,), generator=g, device=dev)
@@ -207,6 +303,83 @@ def gen_reads(torch, dev, world, n_reads, read_len, frac_random, err, seed, pair
     if paired:
         return out, offs, out2
     return out, offs
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# parity: a sample of a batch against the oracle on a sub-database of the timed index
+# --------------------------------------------------------------------------------------------------------------------
+def _unsigned_split(d_values, T):
+    """the flat array is sorted as UNSIGNED 64-bit; as int64 it is [non-negative ascending | negative ascending]: the split"""
+    lo, hi = 0, T
+    while lo < hi:
+        mid = (lo + hi) // 2
+        if int(d_values[mid].item()) >= 0:
+            lo = mid + 1
+        else:
+            hi = mid
+    return lo
+
+
+def closure_positions(torch, d_values, T, q_values, stride=0):
+    """Positions (ascending, device tensor) of every target of the flat device index whose amino-acid part equals that of a query
+    metamer, plus the index's true last entry, plus -- stride > 0 -- every stride-th target: computed with torch.searchsorted on the
+    flat array, i.e. by nothing of the library under test.  Matches(q) depends on no other target (C(q) = {t < T-1 :
+    AA(t) = AA(q)}), so the oracle on any sub-database that holds these positions gives every read of the sample the answer the GPU
+    gives against the whole index."""
+    dev = d_values.device
+    aa = torch.unique(torch.from_numpy(np.ascontiguousarray(q_values).view(np.int64)).to(dev) >> 24)       # arithmetic shift: sign-extended, still one key per amino-acid part
+    v = d_values[:T]
+    n_pos = _unsigned_split(d_values, T)
+    lo_key = aa << 24
+    hi_key = lo_key | 0xFFFFFF
+    neg = lo_key < 0
+    pieces = []
+    for sel, base, seg in ((~neg, 0, v[:n_pos]), (neg, n_pos, v[n_pos:])):
+        if not bool(sel.any()) or len(seg) == 0:
+            continue
+        a = torch.searchsorted(seg, lo_key[sel], right=False)
+        b = torch.searchsorted(seg, hi_key[sel], right=True)
+        cnt = b - a
+        keep = cnt > 0
+        a, cnt = a[keep], cnt[keep]
+        tot = int(cnt.sum().item())
+        if tot:
+            first = torch.cumsum(cnt, 0) - cnt
+            pieces.append(torch.repeat_interleave(a - first, cnt) + torch.arange(tot, device=dev) + base)
+    pieces.append(torch.tensor([T - 1], device=dev))           # the entry the `t < T-1` rule excludes must be the sub-database's last one too
+    pos_c = torch.unique(torch.cat(pieces))
+    del pieces
+    if stride <= 0:
+        return pos_c
+    # union with the strided positions without sorting 10^9 numbers: both lists are ascending, so every element's place in the
+    # union is its own rank plus its rank in the other list
+    pos_c = pos_c[pos_c % stride != 0]
+    n_c, n_s = len(pos_c), (T + stride - 1) // stride
+    out = torch.empty(n_c + n_s, dtype=torch.int64, device=dev)
+    out[torch.arange(n_c, device=dev) + torch.div(pos_c, stride, rounding_mode="floor") + 1] = pos_c
+    for j0 in range(0, n_s, 1 << 27):
+        j = torch.arange(j0, min(n_s, j0 + (1 << 27)), device=dev)
+        out[j + torch.searchsorted(pos_c, j * stride)] = j * stride
+    return out
+
+
+def gather_subindex(d_values, d_info, pos):
+    cv = d_values[pos].cpu().numpy().view(np.uint64)
+    ct = (d_info[pos].cpu().numpy().view(np.int32) & np.int32(0x7FFFFFFF))
+    assert (cv[1:] >= cv[:-1]).all()
+    return cv, ct
+
+
+def sample_closure(ctx, torch, params, d_values, d_info, T, d_bases, d_bases2, read_len, n, stride=0):
+    """the candidate closure (+ optional strided sample) of the first n reads of a batch, taken from the flat arrays"""
+    sb = d_bases[: n * read_len].cpu().numpy()
+    so = np.arange(n + 1, dtype=np.uint64) * np.uint64(read_len)
+    sk, _, _ = ctx.extract(params, sb, so, d_bases2[: n * read_len].cpu().numpy() if d_bases2 is not None else None, so if d_bases2 is not None else None)
+    pos = closure_positions(torch, d_values, T, sk["value"], stride)
+    n_k = len(sk)
+    del sk
+    cv, ct = gather_subindex(d_values, d_info, pos)
+    return dict(values=cv, taxids=ct, n_reads=n, n_kmers=n_k, stride=stride)
 
 
 def compare_with_oracle(M, res, tt, tc, R):
@@ -234,124 +407,85 @@ def compare_with_oracle(M, res, tt, tc, R):
                 checked="classification, is_classified, score (fp32 bits), query lengths, taxID:match_count lists")
 
 
-def cpu_baseline_and_parity(ctx, M, torch, dev, world, real_v, real_t, params, taxdir, d_bases, d_bases2, read_len, n_sample, n_filler_small, seed,
-                            run_cpu=True):
-    """(a) cpu_baseline: the oracle (CPU restatement of the reference algorithm) on a bounded sample -- the first
-    n_sample reads of this rank against an index built by the same generator with fewer filler metamers -- on all host
-    cores and on one.  (b) parity_sample: the SAME reads against the SAME small index through the benchmarked entry
-    points (mtb_synth_index -> mtb_index_from_device -> mtb_classify_batch_device, device-resident inputs), compared
-    with the oracle's answer read by read.  Outside the timed region."""
+def gpu_sample(ctx, M, torch, dev, index, params, d_bases, d_bases2, read_len, n):
+    """the first n reads of a device-resident batch through the benchmarked entry point against `index`"""
+    paired = params.seq_mode == 2
+    offs = torch.arange(n + 1, device=dev, dtype=torch.int64) * read_len
+    s_res = torch.empty(n * 24, dtype=torch.uint8, device=dev)
+    s_cap = n * (20 + read_len // 9) * (2 if paired else 1) + 1024
+    s_tt = torch.empty(s_cap, dtype=torch.int32, device=dev); s_tc = torch.empty(s_cap, dtype=torch.int32, device=dev)
+    ntc = ctx.classify_batch_device(index, params, d_bases.data_ptr(), offs.data_ptr(), d_bases2.data_ptr() if paired else 0,
+                                    offs.data_ptr() if paired else 0, n, n * read_len * (2 if paired else 1),
+                                    s_res.data_ptr(), s_tt.data_ptr(), s_tc.data_ptr(), s_cap)
+    torch.cuda.synchronize()
+    res = np.frombuffer(s_res.cpu().numpy().tobytes(), dtype=M.result_dt)
+    return M.compact_taxcnt(res, s_tt[:ntc].cpu().numpy(), s_tc[:ntc].cpu().numpy().view(np.uint32)) + (int(ctx.last_stats().n_matches),)
+
+
+def oracle_parity(ctx, M, torch, dev, index, params, taxdir, d_bases, d_bases2, read_len, sub, T, time_cpu=False, label=""):
+    """(a) The oracle (CPU restatement of the reference algorithm, test infrastructure) on the sample's reads against the
+    sub-database `sub` of the timed index (sample_closure: the candidate closure of the sample, for the headline sample also every
+    stride-th target); (b) the SAME reads through the benchmarked entry point against THE TIMED INDEX ITSELF, compared read by read.
+    time_cpu: the oracle run is also the reported CPU baseline (all host cores, one core on a part of the sample, cold first run).
+    Outside the timed region."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import Oracle, default_params as odp
     orc = Oracle()
-    T = n_filler_small + len(real_v)
-    dv = torch.empty(T, dtype=torch.int64, device=dev); di = torch.empty(T, dtype=torch.int32, device=dev)
-    n = ctx.synth_index(seed, n_filler_small, world.filler_tax_lo, world.filler_tax_hi, real_v, real_t, dv.data_ptr(), di.data_ptr())
-    vals = dv[:n].cpu().numpy().view(np.uint64); tids = di[:n].cpu().numpy()
-    d = tempfile.mkdtemp(prefix="mtb_cpu_")
+    cv, ct, n = sub["values"], sub["taxids"], sub["n_reads"]
+    d = tempfile.mkdtemp(prefix="mtb_sub_")
     op = odp(seq_mode=params.seq_mode, syncmer=params.syncmer, smer_len=params.smer_len)
-    orc.write_db(d, vals, tids, op)
+    t0 = time.perf_counter()
+    orc.write_db(d, cv, ct, op)
+    t_write = time.perf_counter() - t0
     tax = orc.load_taxonomy(taxdir)
     db = orc.open_db(d, tax, op)
     paired = params.seq_mode == 2
-    bases = d_bases[: n_sample * read_len].cpu().numpy()
-    offs = (np.arange(n_sample + 1, dtype=np.uint64) * np.uint64(read_len))
-    bases2 = d_bases2[: n_sample * read_len].cpu().numpy() if paired else None
+    bases = d_bases[: n * read_len].cpu().numpy()
+    offs = np.arange(n + 1, dtype=np.uint64) * np.uint64(read_len)
+    bases2 = d_bases2[: n * read_len].cpu().numpy() if paired else None
     offs2 = offs if paired else None
     ncores = os.cpu_count() or 1
-    cold_s = None
-    if run_cpu and drop_page_cache():       # first run with the database files out of the page cache (they were just written)
-        tc0 = time.perf_counter()
-        orc.classify_batch(db, tax, op, bases, offs, bases2, offs2, threads=ncores)
-        cold_s = time.perf_counter() - tc0
-    nw = min(n_sample, 20000)      # untimed: creates the OpenMP thread pool
-    orc.classify_batch(db, tax, op, bases[: nw * read_len], offs[: nw + 1], bases2[: nw * read_len] if paired else None, offs[: nw + 1] if paired else None, threads=ncores)
+    cpu = None
+    if time_cpu:
+        cold_s = None
+        if drop_page_cache():       # first run with the database files out of the page cache (they were just written)
+            tc0 = time.perf_counter()
+            orc.classify_batch(db, tax, op, bases, offs, bases2, offs2, threads=ncores)
+            cold_s = time.perf_counter() - tc0
+        nw = min(n, 20000)          # untimed: creates the OpenMP thread pool
+        orc.classify_batch(db, tax, op, bases[: nw * read_len], offs[: nw + 1], bases2[: nw * read_len] if paired else None, offs[: nw + 1] if paired else None, threads=ncores)
     t0 = time.perf_counter()
     R = orc.classify_batch(db, tax, op, bases, offs, bases2, offs2, threads=ncores)
     dt = time.perf_counter() - t0
     stage_s = dict(orc.last_stage_s); oracle_counts = dict(orc.last_counts)
-    cpu = None
-    if run_cpu:
-        # the single-thread figure on a quarter of the sample (same code, threads=1)
-        n1 = max(1, min(n_sample // 4, 100000))
+    if time_cpu:
+        n1 = max(1, min(n // 8, 50000))          # the single-thread figure on a part of the sample (same code, threads=1)
         t1 = time.perf_counter()
         orc.classify_batch(db, tax, op, bases[: n1 * read_len], offs[: n1 + 1], bases2[: n1 * read_len] if paired else None, offs[: n1 + 1] if paired else None, threads=1)
         dt1 = time.perf_counter() - t1
         cls = int((R["results"]["is_classified"] != 0).sum())
-        cpu = dict(value=n_sample / dt / 1e6, unit="Mreads/s", cores=ncores, kind="port", cpu_model=cpu_model(),
+        fbytes = int(sum(os.path.getsize(os.path.join(d, f)) for f in ("diffIdx", "info")))
+        cpu = dict(value=n / dt / 1e6, unit="Mreads/s", cores=ncores, kind="port", cpu_model=cpu_model(),
                    single_thread_value=n1 / dt1 / 1e6, stage_seconds={k: round(v, 3) for k, v in stage_s.items()},
                    cold_cache_first_run_s=cold_s, cold_cache_note=("database files dropped from the page cache before the first run (includes creating the OpenMP pool)"
                                                                    if cold_s is not None else "could not drop the page cache: warm runs only"),
-                   numa=numa_layout(), index_targets=int(n), index_file_bytes=int(sum(os.path.getsize(os.path.join(d, f)) for f in ("diffIdx", "info"))),
-                   sample=f"{n_sample} x {'2 x ' if paired else ''}{read_len} bp reads vs {n} target metamers ({len(real_v)} genome-derived + {n_filler_small} filler; "
-                          f"{n * 12 / 2**20:.0f} MiB flat), oracle/liboracle.so with OpenMP on {ncores} threads, {dt:.1f} s "
-                          f"(1 thread on {n1} reads: {dt1:.1f} s), {cls} classified")
-    # ---- the same sample through the benchmarked GPU path ----
-    taxid_list = np.concatenate([np.unique(real_t), np.arange(world.filler_tax_lo, world.filler_tax_hi + 1, dtype=np.int32)])
-    small = ctx.index_from_device(dv.data_ptr(), di.data_ptr(), n, taxdir, taxid_list, params)
-    s_res = torch.empty(n_sample * 24, dtype=torch.uint8, device=dev)
-    s_cap = n_sample * (20 + read_len // 9) * (2 if paired else 1) + 1024
-    s_tt = torch.empty(s_cap, dtype=torch.int32, device=dev); s_tc = torch.empty(s_cap, dtype=torch.int32, device=dev)
-    s_offs = torch.arange(n_sample + 1, device=dev, dtype=torch.int64) * read_len
-    ntc = ctx.classify_batch_device(small, params, d_bases.data_ptr(), s_offs.data_ptr(), d_bases2.data_ptr() if paired else 0,
-                                    s_offs.data_ptr() if paired else 0, n_sample, n_sample * read_len * (2 if paired else 1),
-                                    s_res.data_ptr(), s_tt.data_ptr(), s_tc.data_ptr(), s_cap)
-    torch.cuda.synchronize()
-    res = np.frombuffer(s_res.cpu().numpy().tobytes(), dtype=M.result_dt)
-    g_res, g_tt, g_tc = M.compact_taxcnt(res, s_tt[:ntc].cpu().numpy(), s_tc[:ntc].cpu().numpy().view(np.uint32))
+                   numa=numa_layout(), index_targets=int(len(cv)), index_file_bytes=fbytes, timed_index_targets=int(T),
+                   sample=f"the first {n} x {'2 x ' if paired else ''}{read_len} bp reads of the timed batch vs a {len(cv)}-target sub-database of the timed index "
+                          f"(every {sub['stride']}th target + the candidate closure of the sample's {sub['n_kmers']} metamers: the answers equal those against "
+                          f"all {T} targets, which the reference would stream once per batch -- its match stage grows with the database, {stage_s.get('match', 0):.1f} s here); "
+                          f"oracle/liboracle.so with OpenMP on {ncores} threads, {dt:.1f} s (1 thread on {n1} reads: {dt1:.1f} s), {cls} classified")
+    g_res, g_tt, g_tc, g_matches = gpu_sample(ctx, M, torch, dev, index, params, d_bases, d_bases2, read_len, n)
     par = compare_with_oracle(M, g_res, g_tt, g_tc, R)
-    par["index"] = f"{n} target metamers via mtb_synth_index -> mtb_index_from_device; reads via mtb_classify_batch_device (device-resident)"
-    par["matches"] = int(ctx.last_stats().n_matches); par["oracle_matches"] = int(oracle_counts["matches"])
-    if par["matches"] != par["oracle_matches"]:
-        par["mismatches"] += 1
-    small.close()
-    del dv, di
-    return cpu, par
-
-
-def parity_full_index(ctx, M, torch, dev, index, params, taxdir, d_bases, d_bases2, read_len, n_s, closure, T):
-    """The first n_s reads of the timed batch through the benchmarked entry point against THE TIMED INDEX ITSELF (sealed, packed
-    words, depth-7 directory, > 2^32 targets), compared read by read with the oracle run on the candidate closure of those reads
-    (candidate_closure above, taken from the flat arrays before they were packed).  Outside the timed region."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from helpers import Oracle, default_params as odp
-    orc = Oracle()
-    cv, ct = closure
-    d = tempfile.mkdtemp(prefix="mtb_closure_")
-    op = odp(seq_mode=params.seq_mode, syncmer=params.syncmer, smer_len=params.smer_len)
-    orc.write_db(d, cv, ct, op)
-    tax = orc.load_taxonomy(taxdir)
-    db = orc.open_db(d, tax, op)
-    paired = params.seq_mode == 2
-    offs_all = d_bases_offsets(torch, dev, n_s, read_len)
-    bases = d_bases[: n_s * read_len].cpu().numpy()
-    offs = np.arange(n_s + 1, dtype=np.uint64) * np.uint64(read_len)
-    bases2 = d_bases2[: n_s * read_len].cpu().numpy() if paired else None
-    R = orc.classify_batch(db, tax, op, bases, offs, bases2, offs if paired else None, threads=os.cpu_count() or 1)
-    oracle_counts = dict(orc.last_counts)
-    s_res = torch.empty(n_s * 24, dtype=torch.uint8, device=dev)
-    s_cap = n_s * (20 + read_len // 9) * (2 if paired else 1) + 1024
-    s_tt = torch.empty(s_cap, dtype=torch.int32, device=dev); s_tc = torch.empty(s_cap, dtype=torch.int32, device=dev)
-    ntc = ctx.classify_batch_device(index, params, d_bases.data_ptr(), offs_all.data_ptr(), d_bases2.data_ptr() if paired else 0,
-                                    offs_all.data_ptr() if paired else 0, n_s, n_s * read_len * (2 if paired else 1),
-                                    s_res.data_ptr(), s_tt.data_ptr(), s_tc.data_ptr(), s_cap)
-    torch.cuda.synchronize()
-    res = np.frombuffer(s_res.cpu().numpy().tobytes(), dtype=M.result_dt)
-    g_res, g_tt, g_tc = M.compact_taxcnt(res, s_tt[:ntc].cpu().numpy(), s_tc[:ntc].cpu().numpy().view(np.uint32))
-    par = compare_with_oracle(M, g_res, g_tt, g_tc, R)
-    par["matches"] = int(ctx.last_stats().n_matches); par["oracle_matches"] = int(oracle_counts["matches"])
+    par["matches"] = g_matches; par["oracle_matches"] = int(oracle_counts["matches"])
     if par["matches"] != par["oracle_matches"]:
         par["mismatches"] += 1
     stt = index.state()
     par["index"] = (f"the timed index itself: {T} targets, directory depth {stt['dir_depth']}, {'packed 8-byte words' if stt['packed'] else 'flat {value, info}'}"
-                    f"{', sealed' if stt['sealed'] else ''}; oracle on the candidate closure of the sample's metamers ({len(cv)} targets incl. the index's last entry, "
-                    "gathered with torch.searchsorted from the flat arrays before packing)")
-    par["closure_targets"] = int(len(cv))
-    return par
-
-
-def d_bases_offsets(torch, dev, n, read_len):
-    return torch.arange(n + 1, device=dev, dtype=torch.int64) * read_len
+                    f"{', sealed' if stt['sealed'] else ''}; oracle on a sub-database of {len(cv)} targets (candidate closure of the sample's metamers"
+                    f"{', every %dth target' % sub['stride'] if sub['stride'] else ''} and the index's last entry, gathered with torch.searchsorted from the flat arrays before packing)")
+    par["sub_database_targets"] = int(len(cv)); par["oracle_seconds"] = round(dt, 2); par["db_write_seconds"] = round(t_write, 2)
+    log(f"[rank 0] parity {label}: {par['reads']} reads, {par['mismatches']} mismatches, {par['matches']} matches (oracle {par['oracle_matches']}), sub-database {len(cv)} targets, oracle {dt:.1f}s")
+    return cpu, par
 
 
 def numa_layout():
@@ -410,6 +544,116 @@ def finish(dist, line):
         print(line, flush=True)
 
 
+# --------------------------------------------------------------------------------------------------------------------
+# per-kernel roofline of one profiled step
+# --------------------------------------------------------------------------------------------------------------------
+def hist_summary(by_log2, weights=None):
+    """quantiles (upper edge of the log2 bin) of a run-length histogram"""
+    c = np.asarray(by_log2, dtype=np.float64)
+    tot = c.sum()
+    if tot == 0:
+        return dict(n=0)
+    cum = np.cumsum(c) / tot
+    q = {f"p{int(p * 100) if p < 0.995 else 99.9}": int(2 ** (int(np.searchsorted(cum, p)) + 1) - 1) for p in (0.5, 0.9, 0.99, 0.999)}
+    q["max_bin_upper"] = int(2 ** (int(np.flatnonzero(c)[-1]) + 1) - 1)
+    q["n"] = int(tot)
+    return q
+
+
+def pmc_traffic(key, workload_tuple, kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes of this very workload (profiles/pmc_traffic_<key>.json), or None"""
+    for name in (f"pmc_traffic_{key}.json", "pmc_traffic.json"):
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", name)))
+            wl = pj["workload"]
+            if (wl["reads"], wl["read_len"], wl["targets"], wl["seq_mode"]) == workload_tuple and wl.get("key", "default") == key and kernel in pj["kernels"]:
+                kk = pj["kernels"][kernel]
+                return (2.0 * kk.get("fetch_size_kb", 0.0) + kk.get("write_size_kb", 0.0)) * 1024.0, f"{pj['source']}: {pj['correction']}"
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, f"no PMC passes for this workload (profiles/pmc_traffic_{key}.json)"
+
+
+def profiled_step(ctx, M, index, params, step_fn, streams, key, workload_tuple):
+    """one extra, untimed, profiled step on ONE stream (kernels not overlapped, full-batch launches): HIP events on the library's
+    stream around every kernel launch -> per-kernel ms, the contract roofline of the dominant kernel (SURVEY 8(d) bytes), its
+    PMC traffic when the passes exist, and for the directory join the index-side working set (`footprint`) with
+    frac_design = (least_fetch_bytes + 16 B x matches) / launch time / peak: the bandwidth fraction against what THIS design has
+    to move at least."""
+    ctx.set_streams(1)
+    ctx.set_profiling(True)
+    step_fn()
+    ps = ctx.last_stats()
+    ctx.set_profiling(False)
+    ctx.set_streams(streams)
+    kern = {M.KERNEL_NAMES[i]: dict(ms=float(ps.ms_kernel[i]), launches=int(ps.n_launch[i])) for i in range(len(M.KERNEL_NAMES))}
+    footprint, runs = None, None
+    try:
+        fp = ctx.join_footprint(index)
+        least = fp.target_sectors * 64 + fp.dir_sectors * 64 + 16 * fp.n_queries
+        footprint = dict(query_metamers=int(fp.n_queries), distinct_buckets=int(fp.distinct_buckets), buckets=int(fp.n_buckets),
+                         directory_sectors_64B=int(fp.dir_sectors), target_sectors_64B=int(fp.target_sectors),
+                         target_sectors_total=int(fp.n_targets * 8 // 64), target_fraction_touched=fp.target_sectors * 64 / max(1, fp.n_targets * 8),
+                         least_fetch_bytes=int(least),
+                         note="distinct 64-byte sectors the batch's queries address (bucket spans of the target array, directory words) + 16 B per query: "
+                              "the least k_join_dir can fetch for this batch; 12 x T of the contract formula is a streaming-merge figure this kernel never pays")
+        rh = ctx.join_run_histogram(index)
+        runs = dict(queries_without_candidate=rh["no_candidate"], queries_by_log2_run_length=rh["queries_by_log2"][:16],
+                    candidates_scanned_by_log2_run_length=rh["candidates_by_log2"][:16], quantiles=hist_summary(rh["queries_by_log2"]),
+                    candidates_scanned=int(sum(rh["candidates_by_log2"])),
+                    note="length of the candidate run (targets sharing the query's amino-acid part) every query metamer of the step meets; bin b = lengths 2^b .. 2^(b+1)-1")
+    except M.MtbError as e:
+        log(f"no join footprint / run histogram: {e}")
+    Kq, Mm, N, L = ps.n_kmers, ps.n_matches, ps.n_reads, ps.n_bases
+    # algorithmic bytes of one whole step per kernel (SURVEY.md 8(d) per-stage split; DESIGN.md section 3);
+    # a step launches every kernel once per stream (and per radix pass): bytes per launch = total / launches
+    alg_step = {"extract_count": L, "extract_emit": L + 16 * Kq, "radix_hist": 16 * Kq, "radix_scatter": 32 * Kq,
+                "join": 16 * Kq + 24 * Mm, "regroup": 48 * Mm, "segsort": 48 * Mm, "score": 24 * Mm + 16 * N, "score_fast": 24 * Mm + 16 * N}
+    if params.kmer_format == 2 and kern["radix_hist"]["launches"]:
+        # the fused path's histograms read the 2-byte digit side arrays and write the 4-byte tile table, not the 16-byte records
+        alg_step["radix_hist"] = kern["radix_hist"]["launches"] * (2 * Kq + 4 * 512 * ((Kq + 4095) // 4096))
+    alg = {k: v / max(1, kern[k]["launches"]) for k, v in alg_step.items()}
+    if kern.get("score_fast", {}).get("launches") and params.seq_mode != 3:         # the two scoring kernels share the reads
+        gfrac = ps.n_generic_reads / max(1, N)
+        alg["score"] *= gfrac; alg["score_fast"] *= 1.0 - gfrac
+    alg["join"] += 12 * ps.n_targets          # the 12*T_span term is paid by every launch (one per HBM-budgeted sub-batch): each spans the whole index
+    dom = max((k for k in alg), key=lambda k: kern[k]["ms"])
+    avg_ms = kern[dom]["ms"] / max(1, kern[dom]["launches"])
+    achieved = alg[dom] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    traffic, traffic_note = pmc_traffic(key, workload_tuple, dom)
+    roofline_all = {k: dict(ms=round(kern[k]["ms"], 3), launches=kern[k]["launches"], algorithmic_gb_per_launch=round(alg[k] / 1e9, 3),
+                            achieved_gb_s=round(alg[k] / (kern[k]["ms"] / max(1, kern[k]["launches"]) * 1e-3) / 1e9, 1),
+                            frac=round(alg[k] / (kern[k]["ms"] / max(1, kern[k]["launches"]) * 1e-3) / 1e9 / PEAK_GBS, 4))
+                    for k in alg if kern[k]["ms"] > 0}
+    effective = (traffic / (avg_ms * 1e-3) / 1e9 / PEAK_GBS) if (traffic and avg_ms > 0) else None
+    frac_design = None
+    join_ms = kern["join"]["ms"] / max(1, kern["join"]["launches"])
+    if footprint is not None and join_ms > 0:
+        frac_design = (footprint["least_fetch_bytes"] + 16 * Mm) / (join_ms * 1e-3) / 1e9 / PEAK_GBS
+    roofline = dict(bound="hbm", kernel=dom, achieved=achieved, peak=PEAK_GBS, unit="GB/s", frac=achieved / PEAK_GBS, traffic=traffic, traffic_note=traffic_note,
+                    effective=effective,
+                    effective_note="traffic / avg_launch_ms / peak: the fraction of HBM bandwidth the kernel really moves (PMC bytes, not the contract's algorithmic bytes)",
+                    frac_design=frac_design,
+                    frac_design_note="join only: (distinct index sectors + directory sectors + 16 B per query + 16 B per match slot) / join launch time / peak -- the least this "
+                                     "design (directory lookup, scattered slot stores) can move; the kernel is bound by the NUMBER of scattered 16-byte store transactions, not by these bytes",
+                    avg_launch_ms=avg_ms, launches=kern[dom]["launches"], algorithmic_bytes_per_launch=alg[dom],
+                    footprint=footprint if dom == "join" else None,
+                    note="per-kernel durations from HIP events around every launch of one extra step; traffic = HBM bytes per launch from the PMC passes; "
+                         "`frac` follows SURVEY 8(d)'s formula (16 Kq + 12 T + 24 M for the join) and is NOT a bandwidth fraction for the directory join: see `effective`, `frac_design` and `footprint`")
+    return ps, kern, roofline, roofline_all, footprint, runs
+
+
+def timed_leg(torch, step_fn, warmup, steps):
+    for _ in range(warmup):
+        step_fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -418,27 +662,34 @@ def main():
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--targets", type=float, default=16e9,
-                    help="filler metamers in the synthetic index (per GPU, replicated); 16 G = SURVEY 8(d)'s GTDB-scale planning size, 192 GB flat")
-    ap.add_argument("--species", type=int, default=24,
-                    help="genomes the reads are drawn from (and whose metamers are in the index); >= 200 takes the device-side generator: "
-                         "the genome-diversity run is --species 2400 --fixed-total (0.6 x coverage instead of 62 x)")
-    ap.add_argument("--fixed-total", action="store_true", help="--targets is the TOTAL number of target metamers (filler = total - genome-derived)")
-    ap.add_argument("--full-parity-reads", type=int, default=32768, help="reads of the parity check against the timed index itself (0 = off)")
+                    help="TOTAL target metamers of the synthetic index (per GPU, replicated): genome-derived + shared-run extras + filler; "
+                         "16 G = SURVEY 8(d)'s GTDB-scale planning size, 192 GB flat")
+    ap.add_argument("--species", type=int, default=2400,
+                    help="genomes the reads are drawn from (and whose metamers are in the index); >= 200 takes the device-side generator "
+                         "(2400 x 1 Mbp: 0.6 x coverage by 10 M reads); 24 is the round-3 headline (62 x coverage: this design's best case)")
+    ap.add_argument("--fixed-total", action="store_true", help="(accepted for compatibility: --targets always is the total now)")
+    ap.add_argument("--no-conserved", action="store_true", help="device-side generator: no conserved segments, no shared-run extras (uniform candidate runs of 1-4 entries)")
+    ap.add_argument("--hot-min", type=int, default=8, help="genome-derived entries a candidate run must hold to be multiplied by further species")
+    ap.add_argument("--full-parity-reads", type=int, default=16384, help="reads of the parity samples of the other configurations' legs (pairs; long reads scaled by length)")
     ap.add_argument("--genome-len", type=int, default=1_000_000)
     ap.add_argument("--filler-species", type=int, default=130_000)
-    ap.add_argument("--cpu-reads", type=int, default=2_000_000, help="reads of the CPU-baseline / parity sample (the first reads of rank 0's batch)")
-    ap.add_argument("--cpu-targets", type=float, default=1e9,
-                    help="filler metamers of the CPU baseline's / parity sample's index (1 G: 9 GB of diffIdx + info on the host, the oracle streams it "
-                         "from every split checkpoint; the whole bench run then takes about two minutes, 16e6 brings it back to 35 s)")
+    ap.add_argument("--cpu-reads", type=int, default=1_000_000, help="reads of the CPU-baseline / parity sample (the first reads of rank 0's batch)")
+    ap.add_argument("--cpu-stride", type=int, default=16,
+                    help="the CPU baseline's database = every stride-th target of the timed index + the candidate closure of the sample (16: 1 G + closure of 16 G targets, "
+                         "~15 GB of diffIdx + info on the host; the oracle streams it from every split checkpoint)")
+    ap.add_argument("--cpu-targets", type=float, default=0, help="(ignored; the CPU baseline's database is a sub-database of the timed index, see --cpu-stride)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the timed CPU baseline (the parity sample still runs the oracle)")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle comparison of the benchmarked path (and the CPU baseline)")
+    ap.add_argument("--no-legs", action="store_true", help="skip the legs of the other configurations (best case, pairs, long reads)")
+    ap.add_argument("--leg-pairs", type=int, default=2_000_000, help="read pairs of the paired-end leg")
+    ap.add_argument("--leg-long", type=int, default=20_000, help="reads of the long-read leg (x --leg-long-len bp)")
+    ap.add_argument("--leg-long-len", type=int, default=10_000)
     ap.add_argument("--streams", type=int, default=1, help="HIP streams a batch is pipelined over inside the library")
     ap.add_argument("--seq-mode", type=int, default=1, choices=[1, 2, 3],
                     help="1 = short single-end (configs[1]); 2 = paired-end, --reads pairs of 2 x --read-len (configs[3] shape); 3 = long reads (configs[2])")
     ap.add_argument("--partitioned", action="store_true",
                     help="SURVEY 8(e) row 2: every rank owns one value range of the index; metamers and matches travel by all-to-all "
                          "(functional/perf check of that path; the default is the replicated index)")
-    ap.add_argument("--prealloc", action="store_true", help="experiment: grow the context's workspace on a tiny index BEFORE the big index is allocated")
     ap.add_argument("--no-seal", action="store_true", help="keep the flat {value, info} arrays next to the packed state (mtb_index_seal not called)")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--dist-backend", default="nccl", help="testing only: gloo lets several ranks share one GPU (RCCL refuses duplicate devices)")
@@ -470,32 +721,23 @@ def main():
     ctx.set_streams(args.streams)
     ctx.set_placement_probe(True)      # this process has allocated and freed > 200 GB through torch by now: see mtb_ctx_set_placement_probe (include/mtb.h)
     params = M.default_params(seq_mode=args.seq_mode, syncmer=1, smer_len=5)
+    single = rank == 0 and world_size == 1 and not args.partitioned
+    do_parity = single and not args.no_parity
+    do_legs = single and not args.no_legs and args.seq_mode == 1
 
     t_setup = time.perf_counter()
     big_world = args.species >= 200
-    world = build_world_fast(torch, dev, args.seed, args.species, args.genome_len, args.filler_species) if big_world else \
+    conserved = big_world and not args.no_conserved
+    world = build_world_fast(torch, dev, args.seed, args.species, args.genome_len, args.filler_species, conserved=conserved) if big_world else \
         build_world(args.seed, args.species, args.genome_len, args.filler_species)
     taxdir = tempfile.mkdtemp(prefix="mtb_tax_")
     world.tax.write(taxdir)
-    real_v, real_t = extract_targets(ctx, M, world, params, torch if big_world else None, dev)
-    n_filler = int(args.targets) - (len(real_v) if args.fixed_total else 0)
-    log(f"[rank {rank}] world: {len(world.genomes)} genomes x {args.genome_len} bp, {len(real_v)} genome-derived target metamers ({time.perf_counter()-t_setup:.1f}s)")
+    real_v, real_t, n_extras = extract_targets(ctx, M, world, params, torch if big_world else None, dev, hot_min=args.hot_min if conserved else 0, seed=args.seed)
+    n_filler = int(args.targets) - len(real_v)
+    if n_filler < 0:
+        raise SystemExit(f"--targets {int(args.targets)} is the TOTAL: the genomes alone give {len(real_v)} target metamers")
+    log(f"[rank {rank}] world: {len(world.genomes)} genomes x {args.genome_len} bp, {len(real_v) - n_extras} genome-derived target metamers + {n_extras} shared-run extras ({time.perf_counter()-t_setup:.1f}s)")
     T_cap = n_filler + len(real_v)
-    if args.prealloc:
-        nf0 = 1_000_000
-        v0 = torch.empty(nf0 + len(real_v), dtype=torch.int64, device=dev); i0 = torch.empty(nf0 + len(real_v), dtype=torch.int32, device=dev)
-        T0 = ctx.synth_index(args.seed, nf0, world.filler_tax_lo, world.filler_tax_hi, real_v, real_t, v0.data_ptr(), i0.data_ptr())
-        tl0 = np.concatenate([np.unique(real_t), np.arange(world.filler_tax_lo, world.filler_tax_hi + 1, dtype=np.int32)])
-        ix0 = ctx.index_from_device(v0.data_ptr(), i0.data_ptr(), T0, taxdir, tl0, params)
-        b0, o0 = gen_reads(torch, dev, world, args.reads, args.read_len, 0.10, 0.005, args.seed + 17 * (rank + 1))
-        r0 = torch.empty(args.reads * 24, dtype=torch.uint8, device=dev)
-        cap0 = args.reads * (20 + args.read_len // 9) + 1024
-        t0_ = torch.empty(cap0, dtype=torch.int32, device=dev); c0_ = torch.empty(cap0, dtype=torch.int32, device=dev)
-        for _ in range(2):
-            ctx.classify_batch_device(ix0, params, b0.data_ptr(), o0.data_ptr(), 0, 0, args.reads, args.reads * args.read_len, r0.data_ptr(), t0_.data_ptr(), c0_.data_ptr(), cap0)
-        torch.cuda.synchronize()
-        del ix0, v0, i0, b0, o0, r0, t0_, c0_
-        torch.cuda.empty_cache()
     free, total = torch.cuda.mem_get_info(dev)
     need = T_cap * 12 + args.reads * (args.read_len + 8)
     if need > free * 0.9:
@@ -504,23 +746,42 @@ def main():
     d_info = torch.empty(T_cap, dtype=torch.int32, device=dev)
     T = ctx.synth_index(args.seed, n_filler, world.filler_tax_lo, world.filler_tax_hi, real_v, real_t, d_values.data_ptr(), d_info.data_ptr())
     taxid_list = np.concatenate([np.unique(real_t), np.arange(world.filler_tax_lo, world.filler_tax_hi + 1, dtype=np.int32)])
+    n_real = len(real_v)
+    del real_v, real_t
     index = ctx.index_from_device(d_values.data_ptr(), d_info.data_ptr(), T, taxdir, taxid_list, params)
+    rseed = args.seed + 17 * (rank + 1)
     d_bases2 = None
     if args.seq_mode == 2:
-        d_bases, d_offs, d_bases2 = gen_reads(torch, dev, world, args.reads, args.read_len, 0.10, 0.005, args.seed + 17 * (rank + 1), paired=True)
+        d_bases, d_offs, d_bases2 = gen_reads(torch, dev, world.genomes, args.reads, args.read_len, 0.10, 0.005, rseed, paired=True)
     else:
-        d_bases, d_offs = gen_reads(torch, dev, world, args.reads, args.read_len, 0.10, 0.005, args.seed + 17 * (rank + 1))
-    # candidate closure of the parity sample, from the flat arrays and before anything packs them (parity_full_index below)
-    closure, n_full = None, 0
-    if rank == 0 and world_size == 1 and not args.no_parity and not args.partitioned and args.full_parity_reads > 0:
-        n_full = min(args.reads, args.full_parity_reads if args.seq_mode != 3 else max(1, args.full_parity_reads * 150 // args.read_len))
-        sb = d_bases[: n_full * args.read_len].cpu().numpy()
-        so = np.arange(n_full + 1, dtype=np.uint64) * np.uint64(args.read_len)
-        sk, _, _ = ctx.extract(params, sb, so, d_bases2[: n_full * args.read_len].cpu().numpy() if d_bases2 is not None else None, so if d_bases2 is not None else None)
+        d_bases, d_offs = gen_reads(torch, dev, world.genomes, args.reads, args.read_len, 0.10, 0.005, rseed)
+    # the other configurations' reads and every parity sample's sub-database: taken from the flat arrays, before anything packs them
+    legs = {}
+    if do_legs:
+        pb, po, pb2 = gen_reads(torch, dev, world.genomes, args.leg_pairs, args.read_len, 0.10, 0.005, rseed + 1, paired=True)
+        lb, lo_ = gen_reads(torch, dev, world.genomes, args.leg_long, args.leg_long_len, 0.10, 0.005, rseed + 2)
+        legs["paired"] = dict(seq_mode=2, n=args.leg_pairs, read_len=args.read_len, b=pb, o=po, b2=pb2)
+        legs["long"] = dict(seq_mode=3, n=args.leg_long, read_len=args.leg_long_len, b=lb, o=lo_, b2=None)
+        if big_world:
+            bb, bo = gen_reads(torch, dev, world.genomes[:24], args.reads, args.read_len, 0.10, 0.005, rseed + 3)
+            legs["best_case"] = dict(seq_mode=1, n=args.reads, read_len=args.read_len, b=bb, o=bo, b2=None)
+    sub_main, index_runs = None, None
+    if do_parity:
         t_c = time.perf_counter()
-        closure = candidate_closure(torch, d_values, d_info, T, sk["value"])
-        log(f"[rank 0] candidate closure of {n_full} reads ({len(sk)} metamers): {len(closure[0])} targets ({time.perf_counter()-t_c:.1f}s)")
-        del sk
+        n_s = min(args.reads, args.cpu_reads if args.seq_mode != 3 else max(1, args.cpu_reads * 150 // args.read_len))
+        sub_main = sample_closure(ctx, torch, params, d_values, d_info, T, d_bases, d_bases2, args.read_len, n_s, stride=0 if args.no_cpu else args.cpu_stride)
+        log(f"[rank 0] sub-database of the headline sample ({n_s} reads, {sub_main['n_kmers']} metamers): {len(sub_main['values'])} targets ({time.perf_counter()-t_c:.1f}s)")
+        for name, lg in legs.items():
+            if name == "best_case":
+                continue
+            n_l = min(lg["n"], max(1, args.full_parity_reads * 150 // lg["read_len"]) if lg["seq_mode"] == 3 else args.full_parity_reads)
+            lp = M.default_params(seq_mode=lg["seq_mode"], syncmer=1, smer_len=5)
+            lg["sub"] = sample_closure(ctx, torch, lp, d_values, d_info, T, lg["b"], lg["b2"], lg["read_len"], n_l)
+    if single:
+        rl, tl = index.run_histogram()
+        index_runs = dict(runs_by_log2_length=rl[:16], targets_by_log2_run_length=tl[:16], quantiles_over_targets=hist_summary(tl),
+                          quantiles_over_runs=hist_summary(rl), genome_derived=int(n_real - n_extras), shared_run_extras=int(n_extras), filler=int(n_filler),
+                          note="candidate runs (targets sharing one amino-acid part) of the whole timed index; bin b = lengths 2^b .. 2^(b+1)-1")
     sealed = False
     if not args.partitioned and not args.no_seal:
         # dedicate the index to the fused path: packed 8-byte target words under the amino-acid directory; the info array lent to
@@ -536,7 +797,7 @@ def main():
     tc_cap = args.reads * (20 + args.read_len // 9) * (2 if args.seq_mode == 2 else 1) + 1024
     d_tt = torch.empty(tc_cap, dtype=torch.int32, device=dev); d_tc = torch.empty(tc_cap, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
-    log(f"[rank {rank}] setup {time.perf_counter()-t_setup:.1f}s: T={T} ({len(real_v)} genome-derived), reads={args.reads}x{args.read_len}")
+    log(f"[rank {rank}] setup {time.perf_counter()-t_setup:.1f}s: T={T} ({n_real - n_extras} genome-derived, {n_extras} shared-run extras), reads={args.reads}x{args.read_len}")
 
     part = None
     if args.partitioned:
@@ -555,13 +816,16 @@ def main():
         log(f"[rank {rank}] partitioned: range {rank} holds {part.num_targets} of {T} targets")
         last = {}
 
+    def make_step(p, b, o, b2, n, n_bases):
+        return lambda: ctx.classify_batch_device(index, p, b.data_ptr(), o.data_ptr(), b2.data_ptr() if b2 is not None else 0, o.data_ptr() if b2 is not None else 0,
+                                                 n, n_bases, d_res.data_ptr(), d_tt.data_ptr(), d_tc.data_ptr(), tc_cap)
+    main_step = make_step(params, d_bases, d_offs, d_bases2, args.reads, n_bases_step)
+
     def step():
         if part is not None:
             last["res"] = parallel.classify_partitioned(stages, bounds, dist)
             return 0
-        return ctx.classify_batch_device(index, params, d_bases.data_ptr(), d_offs.data_ptr(),
-                                         d_bases2.data_ptr() if d_bases2 is not None else 0, d_offs.data_ptr() if d_bases2 is not None else 0,
-                                         args.reads, n_bases_step, d_res.data_ptr(), d_tt.data_ptr(), d_tc.data_ptr(), tc_cap)
+        return main_step()
 
     def barrier():
         torch.cuda.synchronize()
@@ -603,69 +867,9 @@ def main():
         finish(dist, line if rank == 0 else None)
         return
 
-    # one extra, untimed, profiled step on ONE stream (kernels not overlapped, full-batch launches):
-    # HIP events on the library's stream around every kernel launch
-    ctx.set_streams(1)
-    ctx.set_profiling(True)
-    step()
-    ps = ctx.last_stats()
-    ctx.set_profiling(False)
-    ctx.set_streams(args.streams)
-    kern = {M.KERNEL_NAMES[i]: dict(ms=float(ps.ms_kernel[i]), launches=int(ps.n_launch[i])) for i in range(len(M.KERNEL_NAMES))}
-    # index-side working set of that step's directory join (diagnostic kernel over the step's sorted metamers)
-    footprint = None
-    try:
-        fp = ctx.join_footprint(index)
-        least = fp.target_sectors * 64 + fp.dir_sectors * 64 + 16 * fp.n_queries
-        footprint = dict(query_metamers=int(fp.n_queries), distinct_buckets=int(fp.distinct_buckets), buckets=int(fp.n_buckets),
-                         directory_sectors_64B=int(fp.dir_sectors), target_sectors_64B=int(fp.target_sectors),
-                         target_sectors_total=int(fp.n_targets * 8 // 64), target_fraction_touched=fp.target_sectors * 64 / max(1, fp.n_targets * 8),
-                         least_fetch_bytes=int(least),
-                         note="distinct 64-byte sectors the batch's queries address (bucket spans of the target array, directory words) + 16 B per query: "
-                              "the least k_join_dir can fetch for this batch; 12 x T of the contract formula is a streaming-merge figure this kernel never pays")
-    except M.MtbError as e:
-        log(f"[rank {rank}] no join footprint: {e}")
-    Kq, Mm, N, L = ps.n_kmers, ps.n_matches, ps.n_reads, ps.n_bases
-    # algorithmic bytes of one whole step per kernel (SURVEY.md 8(d) per-stage split);
-    # a step launches every kernel once per stream (and per radix pass): bytes per launch = total / launches
-    alg_step = {"extract_count": L, "extract_emit": L + 16 * Kq, "radix_hist": 16 * Kq, "radix_scatter": 32 * Kq,
-                "join": 16 * Kq + 24 * Mm, "regroup": 48 * Mm, "score": 24 * Mm + 16 * N, "score_fast": 24 * Mm + 16 * N}
-    if params.kmer_format == 2 and kern["radix_hist"]["launches"]:
-        # the fused path's histograms read the 2-byte digit side arrays and write the 4-byte tile table, not the 16-byte records
-        alg_step["radix_hist"] = kern["radix_hist"]["launches"] * (2 * Kq + 4 * 512 * ((Kq + 4095) // 4096))
-    alg = {k: v / max(1, kern[k]["launches"]) for k, v in alg_step.items()}
-    if kern.get("score_fast", {}).get("launches"):         # the two scoring kernels share the reads
-        gfrac = ps.n_generic_reads / max(1, N)
-        alg["score"] *= gfrac; alg["score_fast"] *= 1.0 - gfrac
-    alg["join"] += 12 * ps.n_targets          # the 12*T_span term is paid by every launch (one per HBM-budgeted sub-batch): each spans the whole index
-    dom = max((k for k in alg), key=lambda k: kern[k]["ms"])
-    avg_ms = kern[dom]["ms"] / max(1, kern[dom]["launches"])
-    achieved = alg[dom] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 cannot run inside this process);
-    # only when they were taken on this very workload
-    traffic, traffic_note = None, "no PMC passes for this workload (profiles/pmc_traffic.json)"
-    try:
-        pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        wl = pj["workload"]
-        if (wl["reads"], wl["read_len"], wl["targets"], wl["seq_mode"]) == (args.reads, args.read_len, int(ps.n_targets), args.seq_mode) and dom in pj["kernels"]:
-            kk = pj["kernels"][dom]
-            traffic = (2.0 * kk.get("fetch_size_kb", 0.0) + kk.get("write_size_kb", 0.0)) * 1024.0
-            traffic_note = f"{pj['source']}: {pj['correction']}"
-    except (OSError, KeyError, ValueError):
-        pass
-    # every kernel of the step against the same peak (informational; `roofline` below is the dominant one)
-    roofline_all = {k: dict(ms=round(kern[k]["ms"], 3), launches=kern[k]["launches"], algorithmic_gb_per_launch=round(alg[k] / 1e9, 3),
-                            achieved_gb_s=round(alg[k] / (kern[k]["ms"] / max(1, kern[k]["launches"]) * 1e-3) / 1e9, 1),
-                            frac=round(alg[k] / (kern[k]["ms"] / max(1, kern[k]["launches"]) * 1e-3) / 1e9 / 8000.0, 4))
-                    for k in alg if kern[k]["ms"] > 0}
-    effective = (traffic / (avg_ms * 1e-3) / 1e9 / 8000.0) if (traffic and avg_ms > 0) else None
-    roofline = dict(bound="hbm", kernel=dom, achieved=achieved, peak=8000.0, unit="GB/s", frac=achieved / 8000.0, traffic=traffic, traffic_note=traffic_note,
-                    effective=effective,
-                    effective_note="traffic / avg_launch_ms / peak: the fraction of HBM bandwidth the kernel really moves (PMC bytes, not the contract's algorithmic bytes)",
-                    avg_launch_ms=avg_ms, launches=kern[dom]["launches"], algorithmic_bytes_per_launch=alg[dom],
-                    footprint=footprint if dom == "join" else None,
-                    note="per-kernel durations from HIP events around every launch of one extra step; traffic = HBM bytes per launch from the PMC passes; "
-                         "`frac` follows SURVEY 8(d)'s formula (16 Kq + 12 T + 24 M for the join) and is NOT a bandwidth fraction for the directory join: see `effective` and `footprint`")
+    wl_key = ("diversity" if big_world else "default") + ("" if args.seq_mode == 1 else f"_mode{args.seq_mode}")
+    ps, kern, roofline, roofline_all, footprint, query_runs = profiled_step(ctx, M, index, params, step, args.streams, wl_key,
+                                                                           (args.reads, args.read_len, int(T), args.seq_mode))
 
     # sanity of the timed output: fraction of reads classified
     res = np.frombuffer(d_res.cpu().numpy().tobytes(), dtype=M.result_dt)
@@ -675,40 +879,70 @@ def main():
     if frac_cls < 0.5:   # 90 % of the reads come from genomes that are in the index
         raise SystemExit(f"sanity check failed: only {frac_cls:.4f} of the reads were classified")
 
+    # ---- the other configurations, after and outside the timed region: short legs on the SAME sealed index ----
+    other = {}
+    for name, lg in legs.items():
+        lp = M.default_params(seq_mode=lg["seq_mode"], syncmer=1, smer_len=5)
+        nb = lg["n"] * lg["read_len"] * (2 if lg["seq_mode"] == 2 else 1)
+        lstep = make_step(lp, lg["b"], lg["o"], lg["b2"], lg["n"], nb)
+        ms = timed_leg(torch, lstep, 1, 3 if name != "long" else 2)
+        ls = ctx.last_stats()
+        lres = np.frombuffer(d_res[: lg["n"] * 24].cpu().numpy().tobytes(), dtype=M.result_dt)
+        entry = dict(workload=dict(best_case=f"{lg['n']/1e6:g}M x {lg['read_len']} bp single-end reads drawn from 24 of the {len(world.genomes)} genomes (62 x coverage: the round-3 headline's read set) vs the same index",
+                                   paired=f"{lg['n']/1e6:g}M x 2 x {lg['read_len']} bp read pairs (BASELINE.json configs[3], per-GPU shape) vs the same index",
+                                   long=f"{lg['n']/1e3:g}k x {lg['read_len']} bp long reads (BASELINE.json configs[2] shape) vs the same index")[name],
+                     seq_mode=lg["seq_mode"], reads=lg["n"], read_len=lg["read_len"], ms_per_step=ms,
+                     mreads_per_s=lg["n"] / ms / 1e3, gbp_per_s=nb / ms / 1e6, sub_batches=int(ctx.last_sub_batches),
+                     stage_ms=dict(extract=ls.ms_extract, sort=ls.ms_sort, join=ls.ms_join, order=ls.ms_regroup + ls.ms_segsort, score=ls.ms_score, total=ls.ms_total),
+                     query_metamers=int(ls.n_kmers), matches=int(ls.n_matches), classified_fraction=float((lres["is_classified"] != 0).mean()),
+                     reads_scored_by_generic_kernel=int(ls.n_generic_reads))
+        try:
+            lps, lkern, lroof, _, _, lruns = profiled_step(ctx, M, index, lp, lstep, args.streams, wl_key + "_" + name, (lg["n"], lg["read_len"], int(T), lg["seq_mode"]))
+            entry["kernel_ms"] = {k: v for k, v in lkern.items() if v["launches"]}
+            entry["roofline"] = {k: lroof[k] for k in ("kernel", "achieved", "frac", "traffic", "effective", "frac_design", "avg_launch_ms", "launches", "algorithmic_bytes_per_launch")}
+            if lruns is not None:
+                entry["query_run_length_quantiles"] = lruns["quantiles"]
+        except M.MtbError as e:
+            log(f"[rank 0] leg {name}: no profiled step: {e}")
+        if do_parity and "sub" in lg:
+            _, lpar = oracle_parity(ctx, M, torch, dev, index, lp, taxdir, lg["b"], lg["b2"], lg["read_len"], lg["sub"], T, label=name)
+            entry["parity"] = lpar; entry["mismatches"] = lpar["mismatches"]
+            if lpar["mismatches"]:
+                raise SystemExit(f"parity check of the {name} leg failed: {lpar}")
+        log(f"[rank 0] leg {name}: {ms:.1f} ms per step = {entry['mreads_per_s']:.2f} Mreads/s = {entry['gbp_per_s']:.2f} Gbp/s")
+        other[name] = entry
+    best_case = other.pop("best_case", None)
+
     cpu, parity = None, None
-    if rank == 0 and world_size == 1 and not args.no_parity and not big_world:       # (the small-index sample would need all 2.4 G genome-derived entries: the diversity run keeps the check against the timed index only)
-        cpu, parity = cpu_baseline_and_parity(ctx, M, torch, dev, world, real_v, real_t, params, taxdir, d_bases, d_bases2, args.read_len,
-                                              min(args.cpu_reads, args.reads), int(args.cpu_targets), args.seed, run_cpu=not args.no_cpu)
-        log(f"[rank 0] parity sample: {parity}")
+    if do_parity:
+        cpu, parity = oracle_parity(ctx, M, torch, dev, index, params, taxdir, d_bases, d_bases2, args.read_len, sub_main, T, time_cpu=not args.no_cpu, label="headline")
         if parity["mismatches"]:
-            raise SystemExit(f"parity check failed: {parity}")
-    parity_full = None
-    if closure is not None:
-        parity_full = parity_full_index(ctx, M, torch, dev, index, params, taxdir, d_bases, d_bases2, args.read_len, n_full, closure, T)
-        log(f"[rank 0] parity against the timed index: {parity_full}")
-        if parity_full["mismatches"]:
-            raise SystemExit(f"parity check against the timed index failed: {parity_full}")
+            raise SystemExit(f"parity check against the timed index failed: {parity}")
 
     if rank == 0:
         total_reads = args.reads * world_size * args.steps
         value = total_reads / dt / 1e6
+        cfg_name = {1: 'BASELINE.json configs[1]', 2: 'BASELINE.json configs[3] shape: paired-end, index replicated, reads sharded', 3: 'BASELINE.json configs[2] shape: long reads'}[args.seq_mode]
         out = dict(metric="Mreads/s classified (metabuli classify hot path, reads + index resident in HBM)",
                    value=value, unit="Mreads/s", n_gpus=world_size, steps=args.steps, warmup=args.warmup,
                    ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None,
                    dtype="u64", data="synthetic",
                    config=dict(workload=f"{args.reads/1e6:g}M x {'2 x ' if args.seq_mode == 2 else ''}{args.read_len} bp synthetic "
-                                        f"{ {1: 'single-end', 2: 'paired-end', 3: 'long'}[args.seq_mode] } reads per GPU vs synthetic "
-                                        f"GTDB-scale index of {T/1e9:.2f} G metamers ({T*12/2**30:.0f} GiB flat, replicated per GPU), "
-                                        f"syncmer s=5, kmer_format 2 ({ {1: 'BASELINE.json configs[1]', 2: 'BASELINE.json configs[3] shape: paired-end, index replicated, reads sharded', 3: 'BASELINE.json configs[2] shape: long reads'}[args.seq_mode] })",
+                                        f"{ {1: 'single-end', 2: 'paired-end', 3: 'long'}[args.seq_mode] } reads per GPU, drawn from {len(world.genomes)} genomes, vs synthetic "
+                                        f"GTDB-scale index of {T/1e9:.2f} G metamers ({T*12/2**30:.0f} GiB flat, replicated per GPU"
+                                        f"{', heavy-tailed candidate runs: conserved segments + shared-run extras' if conserved else ''}), syncmer s=5, kmer_format 2 ({cfg_name})",
                                reads_per_gpu=args.reads, read_len=args.read_len, targets=int(T), seq_mode=args.seq_mode,
                                gbp_per_s=value * args.read_len * (2 if args.seq_mode == 2 else 1) / 1e3, query_metamers=int(st.n_kmers), matches=int(st.n_matches),
                                classified_fraction=frac_cls, parallelism=f"reads sharded x{world_size}, index replicated", streams_per_gpu=args.streams,
                                sub_batches_per_step=sub_batches_timed, index_sealed=sealed,
-                               index_bytes=int(T * (8 if sealed else 12) + 4 * (21 ** index.state()["dir_depth"] + 1)), species=args.species, genome_len=args.genome_len, reads_scored_by_generic_kernel=int(ps.n_generic_reads), reads_on_ordinal_slots=int(ps.n_slot_reads)),
+                               index_bytes=int(T * (8 if sealed else 12) + 4 * (21 ** index.state()["dir_depth"] + 1)), species=args.species, genome_len=args.genome_len,
+                               conserved_segments=conserved, reads_scored_by_generic_kernel=int(ps.n_generic_reads), reads_on_ordinal_slots=int(ps.n_slot_reads)),
                    stage_ms=dict(extract=st.ms_extract, sort=st.ms_sort, join=st.ms_join, regroup=st.ms_regroup,
                                  segsort=st.ms_segsort, score=st.ms_score, total=st.ms_total),
-                   kernel_ms=kern, roofline=roofline, roofline_all=roofline_all, join_footprint=footprint, cpu_baseline=cpu, parity_sample=parity,
-                   parity_full_index=parity_full)
+                   kernel_ms=kern, roofline=roofline, roofline_all=roofline_all, join_footprint=footprint,
+                   run_lengths=dict(index=index_runs, queries=query_runs),
+                   best_case=best_case, other_configs=other,
+                   cpu_baseline=cpu, parity_sample=parity, parity_full_index=parity)
         finish(dist, json.dumps(out))
     else:
         finish(dist, None)

@@ -266,6 +266,16 @@ mtb_status mtb_last_batch_stats(mtb_ctx *, mtb_batch_stats *out);
 typedef struct { uint64_t n_queries, distinct_buckets, dir_sectors, target_sectors, n_buckets, n_targets; } mtb_join_footprint;
 mtb_status mtb_ctx_join_footprint(mtb_ctx *, mtb_index *, mtb_join_footprint *out);
 
+/* Diagnostics, outside any timed region: lengths of the candidate runs (targets sharing one amino-acid part: what a query's scan in
+ * KmerMatcher.cpp:363-416 walks).  hist64 receives 64 counters.
+ * mtb_index_run_histogram: over the whole index (it is brought to the flat state first): [b] = runs with floor(log2(length)) = b,
+ * [32 + b] = targets in them (b = 0..31).
+ * mtb_ctx_join_run_histogram: over the query metamers of the LAST mtb_classify_batch* call of the context (same conditions as
+ * mtb_ctx_join_footprint): [0] = queries without a candidate, [1 + b] = queries whose run has floor(log2(length)) = b (b = 0..31),
+ * [40 + b] = candidates those queries scan (b = 0..23, longer runs in the last bin).                                             */
+mtb_status mtb_index_run_histogram(mtb_index *, uint64_t *hist64);
+mtb_status mtb_ctx_join_run_histogram(mtb_ctx *, mtb_index *, uint64_t *hist64);
+
 /* Writes the resident index in the reference's on-disk format -- diffIdx
  * (IndexCreator::getDiffIdx, IndexCreator.cpp:874-892), info, split
  * (writeTargetFilesAndSplits, :817-872, `split_num` checkpoints; the reference

@@ -361,6 +361,13 @@ class Context:
         _chk(self.L.mtb_ctx_join_footprint(self.h, index.h, C.byref(f)))
         return f
 
+    def join_run_histogram(self, index):
+        """lengths of the candidate runs the last fused batch's queries met (mtb_ctx_join_run_histogram; diagnostic) ->
+        dict(no_candidate, queries_by_log2[32], candidates_by_log2[24])"""
+        h = np.zeros(64, np.uint64)
+        _chk(self.L.mtb_ctx_join_run_histogram(self.h, index.h, _p(h)))
+        return dict(no_candidate=int(h[0]), queries_by_log2=[int(x) for x in h[1:33]], candidates_by_log2=[int(x) for x in h[40:64]])
+
     def last_stats(self):
         s = BatchStats()
         _chk(self.L.mtb_last_batch_stats(self.h, C.byref(s)))
@@ -395,6 +402,13 @@ class Index:
         h = C.c_void_p()
         _chk(self.ctx.L.mtb_index_slice(self.h, C.c_uint64(int(lo_value)), C.c_uint64(int(hi_value)), C.c_int(1 if is_last else 0), C.byref(h)))
         return Index(self.ctx, h)
+
+    def run_histogram(self):
+        """candidate-run lengths over the whole index (mtb_index_run_histogram; brings the index to the flat state) ->
+        (runs_by_log2[32], targets_by_log2[32])"""
+        h = np.zeros(64, np.uint64)
+        _chk(self.ctx.L.mtb_index_run_histogram(self.h, _p(h)))
+        return [int(x) for x in h[:32]], [int(x) for x in h[32:]]
 
     def write(self, dbdir, split_num=4096):
         """the index in the reference's on-disk format (mtb_index_write); dbdir must exist"""

@@ -122,10 +122,26 @@ __global__ __launch_bounds__(256) void k_index_unpack(uint64_t *__restrict__ val
 #define MTB_JOIN_DIR_QPT 2
 #endif
 
+/* Candidate runs longer than this are scanned by the whole wave (64 lanes over consecutive 8-byte words, ballot-ranked emission) instead
+ * of by their query's lane alone.  Real databases have heavy-tailed runs -- an amino-acid 8-mer of a conserved protein is shared by
+ * 10^3 - 10^4 species -- and a lane that walks such a run twice on its own (minimum, then emission: the reference's
+ * loop, KmerMatcher.cpp:363-416) stalls the other 63 lanes of its wave for thousands of dependent loads. */
+#ifndef MTB_JOIN_COOP_MIN
+#define MTB_JOIN_COOP_MIN 32          /* default of JoinSegArgs::coop_min; MTB_JOIN_COOP_MIN=<n> in the environment of mtb_ctx_create overrides it (A/B runs) */
+#endif
+__device__ __forceinline__ uint64_t wave_bcast64(uint64_t v, int src) {
+    return ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 64) << 32) | (uint64_t)(uint32_t)__shfl((int)(uint32_t)v, src, 64);
+}
+__device__ __forceinline__ uint32_t wave_min_shfl_u32(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64); v = o < v ? o : v; }
+    return v;
+}
+
 /* MODE 0: slot segments of fixed stride (short reads); 1: per-read slot ranges (long reads); 2: dense list of Match records
  * (owner side of the range-partitioned index: the home rank of the read places them into ITS slot segments, k_slot_place) */
 template <bool PACKED, int MODE = 0>
-__global__ __launch_bounds__(256) void k_join_dir(const mtb_kmer *__restrict__ q, uint64_t n, mtb_index_view ix, uint64_t limit, mtb_dir_view dv,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && MODE == 0) ? 6 : 5))) void k_join_dir(const mtb_kmer *__restrict__ q, uint64_t n, mtb_index_view ix, uint64_t limit, mtb_dir_view dv,
                                                    const mtb_tables *__restrict__ tabs, JoinSegArgs sa, uint32_t *__restrict__ overflow) {
     constexpr int Q = MTB_JOIN_DIR_QPT;
     constexpr bool LONG = MODE == 1, LIST = MODE == 2;
@@ -210,6 +226,43 @@ __global__ __launch_bounds__(256) void k_join_dir(const mtb_kmer *__restrict__ q
             }
         }
     }
+    /* long candidate runs (see MTB_JOIN_COOP_MIN): a query whose bucket still holds more than the threshold behind its first candidate
+     * finds the END of its run by a second bisection; runs beyond the threshold are taken away from the lane (valid[u] = false) and
+     * scanned by the wave below. */
+    bool lng[Q];                                     /* (a long run's end replaces the bucket's end in e_hi[u]) */
+#pragma unroll
+    for (int u = 0; u < Q; u++) {
+        lng[u] = false;
+        if (valid[u] && e_hi[u] > lo[u] && e_hi[u] - lo[u] > (uint64_t)sa.coop_min) {
+            const uint64_t qk = qkey(k[u].value);
+            uint64_t a = lo[u], b = e_hi[u];
+            while (a < b) { const uint64_t mid = a + ((b - a) >> 1); if (tkey(ix.values[mid]) <= qk) a = mid + 1; else b = mid; }
+            if (a - lo[u] > (uint64_t)sa.coop_min) { lng[u] = true; e_hi[u] = a; valid[u] = false; }
+        }
+    }
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    /* ONE pass over a wave-scanned run [s, e), four 64-candidate steps in flight per iteration: the minimum hamming sum (-> the
+     * selection threshold) and, per lane, the candidates of its stripe with a sum <= 7 -- no other can be selected, the threshold
+     * being min(2 x minimum, 7) -- as (offset in the run << 4 | sum): the last four are kept (c0 = newest), n_c counts them all.
+     * Runs whose lanes all stay within four are emitted from these registers; the others are walked a second time. */
+    auto coop_scan = [&](const mtb_qrows &qr, uint64_t s, uint64_t e, uint32_t &c0, uint32_t &c1, uint32_t &c2, uint32_t &c3, uint32_t &n_c) -> uint32_t {
+        uint32_t mn = 255u; n_c = 0; c0 = 0; c1 = 0; c2 = 0; c3 = 0;
+        for (uint64_t t0 = s + lane; t0 < e; t0 += 256) {
+            uint64_t v[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = t0 + 64 * j < e ? ix.values[t0 + 64 * j] : 0ull;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (t0 + 64 * j < e) {
+                    const uint32_t h = mtb_ham_sum(&qr, (uint32_t)v[j] & 0xFFFFFFu);
+                    mn = h < mn ? h : mn;
+                    if (h <= 7u) { c3 = c2; c2 = c1; c1 = c0; c0 = ((uint32_t)(t0 + 64 * j - s) << 4) | h; n_c++; }
+                }
+            }
+        }
+        return mtb_ham_threshold(wave_min_shfl_u32(mn));
+    };
     if (LIST) {
         /* dense list (owner side of the partitioned index): count the selected candidates of the thread's queries, one workgroup
          * scan, ONE atomic per workgroup for the output range, then emit (a per-match atomic on the list's single counter cost
@@ -235,14 +288,73 @@ __global__ __launch_bounds__(256) void k_join_dir(const mtb_kmer *__restrict__ q
             for (uint64_t t = s0; t < e; t++) { const uint64_t v = t == s0 ? v0 : ix.values[t]; c += mtb_ham_sum(&qr, (uint32_t)v & 0xFFFFFFu) <= thr ? 1u : 0u; }
             rs[u] = s0; re[u] = e; thr_[u] = thr; cnt[u] = c; tot_c += c;
         }
+        /* wave-scanned runs: threshold and count now, emission behind the reservation */
+#pragma unroll
+        for (int u = 0; u < Q; u++) {
+            uint64_t todo = __ballot(lng[u]);
+            while (todo) {
+                const int src = __ffsll((unsigned long long)todo) - 1; todo &= todo - 1;
+                const uint64_t s0 = wave_bcast64(lo[u], src), e = wave_bcast64(e_hi[u], src);
+                mtb_qrows qr; mtb_prepare_query_rows(s_hr, wave_bcast64(k[u].value, src), &qr);
+                uint32_t c0, c1, c2, c3, n_c;
+                const uint32_t thr = coop_scan(qr, s0, e, c0, c1, c2, c3, n_c);
+                uint32_t c = 0;
+                if (!__any(n_c > 4u)) {
+                    const uint32_t mine = (n_c > 0 && (c0 & 15u) <= thr ? 1u : 0u) + (n_c > 1 && (c1 & 15u) <= thr ? 1u : 0u) +
+                                          (n_c > 2 && (c2 & 15u) <= thr ? 1u : 0u) + (n_c > 3 && (c3 & 15u) <= thr ? 1u : 0u);
+                    c = wave_inclusive_scan<uint32_t>(mine);
+                    c = (uint32_t)__shfl((int)c, 63, 64);
+                } else {
+                    for (uint64_t t0 = s0; t0 < e; t0 += 64) {
+                        const uint64_t t = t0 + lane;
+                        const bool sel = t < e && mtb_ham_sum(&qr, (uint32_t)ix.values[t] & 0xFFFFFFu) <= thr;
+                        c += (uint32_t)__popcll(__ballot(sel));
+                    }
+                }
+                if ((int)lane == src) { rs[u] = s0; re[u] = e; thr_[u] = thr; cnt[u] = c; tot_c += c; }
+            }
+        }
         uint32_t tot;
         const uint32_t off = block256_exclusive_scan<uint32_t>(tot_c, s_scan, &tot);
         if (threadIdx.x == 0) s_base = tot ? atomicAdd(sa.ovf_counter, (unsigned long long)tot) : 0ull;
         __syncthreads();
-        unsigned long long o = s_base + off;
+        unsigned long long o_of[Q];
+        { unsigned long long o_run = s_base + off;
+#pragma unroll
+          for (int u = 0; u < Q; u++) { o_of[u] = o_run; o_run += cnt[u]; } }
+#pragma unroll
+        for (int u = 0; u < Q; u++) {            /* wave-scanned runs: selected candidates in index order from the query's offset, ranks by ballot */
+            uint64_t todo = __ballot(lng[u] && cnt[u] != 0);
+            while (todo) {
+                const int src = __ffsll((unsigned long long)todo) - 1; todo &= todo - 1;
+                const uint64_t s0 = wave_bcast64(rs[u], src), e = wave_bcast64(re[u], src), qi = wave_bcast64(k[u].qinfo, src);
+                const uint32_t thr = (uint32_t)__shfl((int)thr_[u], src, 64);
+                unsigned long long ob = wave_bcast64(o_of[u], src);
+                mtb_qrows qr; mtb_prepare_query_rows(s_hr, wave_bcast64(k[u].value, src), &qr);
+                const bool rev = mtb_hammings_reversed(mtb_q_frame(qi), ix.kmer_format);
+                bool first = true;
+                for (uint64_t t0 = s0; t0 < e; t0 += 64) {
+                    const uint64_t t = t0 + lane;
+                    uint64_t v = 0; uint32_t td = 0, h = 255u;
+                    if (t < e) { v = ix.values[t]; td = (uint32_t)v & 0xFFFFFFu; h = mtb_ham_sum(&qr, td); }
+                    const bool sel = h <= thr;
+                    const uint64_t m = __ballot(sel);
+                    if (!m) continue;
+                    const uint32_t rk = (uint32_t)__popcll(m & lt_mask);
+                    if (sel && ob + rk < sa.ovf_cap) {
+                        const int32_t tid = (int32_t)((PACKED ? (uint32_t)(v >> MTB_PACK_LOW) : ix.info[t]) & ix.info_mask);
+                        mtb_match mm; mm.qinfo = qi; mm.target_id = tid; mm.species_id = (tid >= 0 && tid <= ix.max_taxid) ? ix.tax2species[tid] : 0;
+                        mm.dna = td; mm.right_end_hamming = mtb_hammings(&qr, td, rev); mm.hamming = (uint8_t)h; mm.pad = (first && rk == 0) ? 1 : 0;
+                        sa.ovf[ob + rk] = mm;
+                    }
+                    ob += (uint32_t)__popcll(m); first = false;
+                }
+            }
+        }
 #pragma unroll
         for (int u = 0; u < Q; u++) {
-            if (cnt[u] == 0) continue;
+            if (cnt[u] == 0 || lng[u]) continue;
+            unsigned long long o = o_of[u];
             mtb_qrows qr; mtb_prepare_query_rows(s_hr, k[u].value, &qr);
             const bool rev = mtb_hammings_reversed(mtb_q_frame(k[u].qinfo), ix.kmer_format);
             bool first = true;
@@ -263,6 +375,86 @@ __global__ __launch_bounds__(256) void k_join_dir(const mtb_kmer *__restrict__ q
         return;
     }
     const uint32_t tail_cap = sa.stride - sa.direct;
+    /* wave-scanned runs: one pass (minimum + the few candidates that can be selected, kept in registers), then emission -- the selected
+     * candidate with the lowest index takes the query's ordinal slot, the others the read's tail (ONE returning atomic per step for all
+     * of them), beyond that the overflow list: the contract of the per-lane loop below */
+#pragma unroll
+    for (int u = 0; u < Q; u++) {
+        uint64_t todo = __ballot(lng[u]);
+        while (todo) {
+            const int src = __ffsll((unsigned long long)todo) - 1; todo &= todo - 1;
+            const uint64_t s0 = wave_bcast64(lo[u], src), e = wave_bcast64(e_hi[u], src), qi_t = wave_bcast64(k[u].qinfo, src);
+            mtb_qrows qr; mtb_prepare_query_rows(s_hr, wave_bcast64(k[u].value, src), &qr);
+            uint32_t cb[4], n_c;
+            const uint32_t thr = coop_scan(qr, s0, e, cb[0], cb[1], cb[2], cb[3], n_c);
+            const uint32_t r = mtb_q_seq(qi_t) - 1, ord = mtb_q_pos(qi_t) >> 16;
+            const uint64_t qinfo = qi_t & ~0xFFFF0000ull;
+            const bool rev = mtb_hammings_reversed(mtb_q_frame(qinfo), ix.kmer_format);
+            uint32_t direct = sa.direct, tcap = tail_cap;
+            mtb_slot16 *seg;
+            if (LONG) { direct = sa.dcnt[r]; tcap = mtb_lslot_tail(direct, sa.tf); seg = sa.seg + sa.rb[r]; }
+            else seg = sa.seg + (uint64_t)r * sa.stride;
+            bool first = ord < direct;
+            /* one selected candidate -> its slot: `at` = place in the read's tail, or ~0u for the query's ordinal slot */
+            auto put = [&](uint64_t t, uint64_t v, uint32_t h, uint32_t at) {
+                const uint32_t td = (uint32_t)v & 0xFFFFFFu;
+                const int32_t tid = (int32_t)((PACKED ? (uint32_t)(v >> MTB_PACK_LOW) : ix.info[t]) & ix.info_mask);
+                const int32_t sp = (tid >= 0 && tid <= ix.max_taxid) ? ix.tax2species[tid] : 0;
+                const uint16_t reh = mtb_hammings(&qr, td, rev);
+                const mtb_slot16 sl = LONG ? mtb_lslot_pack(qinfo, tid, sp, td, reh, h) : mtb_slot_pack(qinfo, tid, sp, td, reh, h, sa.epoch);
+                if (at == ~0u) MTB_SLOT_STORE(sl, &seg[ord]);
+                else if (at < tcap) MTB_SLOT_STORE(sl, &seg[direct + at]);
+                else {
+                    const unsigned long long o = atomicAdd(sa.ovf_counter, 1ull);
+                    if (LONG) { }                      /* counted only: the caller retries the join with a larger tail */
+                    else if (o < sa.ovf_cap) {
+                        mtb_match mm; mm.qinfo = qinfo; mm.target_id = tid; mm.species_id = sp; mm.dna = td; mm.right_end_hamming = reh; mm.hamming = (uint8_t)h; mm.pad = 0;
+                        sa.ovf[o] = mm;
+                    } else *overflow = 1;
+                }
+            };
+            if (!__any(n_c > 4u)) {
+                /* from the registers: the lowest selected offset of the wave owns the ordinal slot */
+                uint32_t low = ~0u;
+#pragma unroll
+                for (int b = 0; b < 4; b++) if ((uint32_t)b < n_c && (cb[b] & 15u) <= thr) low = (cb[b] >> 4) < low ? (cb[b] >> 4) : low;
+                low = first ? wave_min_shfl_u32(low) : ~0u;
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const bool sel = (uint32_t)b < n_c && (cb[b] & 15u) <= thr;
+                    const uint32_t off = cb[b] >> 4;
+                    const bool own = sel && off == low;              /* (~0u never equals an offset: runs are shorter than 2^28) */
+                    const uint64_t m = __ballot(sel && !own);
+                    uint32_t at0 = 0;
+                    if (m) {
+                        const int leader = __ffsll((unsigned long long)m) - 1;
+                        if ((int)lane == leader) at0 = atomicAdd(&sa.cursor[r], (uint32_t)__popcll(m));
+                        at0 = (uint32_t)__shfl((int)at0, leader, 64);
+                    }
+                    if (sel) put(s0 + off, ix.values[s0 + off], cb[b] & 15u, own ? ~0u : at0 + (uint32_t)__popcll(m & lt_mask));
+                }
+                continue;
+            }
+            for (uint64_t t0 = s0; t0 < e; t0 += 64) {      /* a lane met more than four possible candidates: second walk, 64 per step */
+                const uint64_t t = t0 + lane;
+                uint64_t v = 0; uint32_t h = 255u;
+                if (t < e) { v = ix.values[t]; h = mtb_ham_sum(&qr, (uint32_t)v & 0xFFFFFFu); }
+                const bool sel = h <= thr;
+                const uint64_t m = __ballot(sel);
+                if (!m) continue;
+                const uint32_t rk = (uint32_t)__popcll(m & lt_mask), n_sel = (uint32_t)__popcll(m);
+                const uint32_t skip = first ? 1u : 0u, n_tail = n_sel - skip;
+                uint32_t at0 = 0;
+                if (n_tail) {
+                    const int leader = __ffsll((unsigned long long)m) - 1;
+                    if ((int)lane == leader) at0 = atomicAdd(&sa.cursor[r], n_tail);
+                    at0 = (uint32_t)__shfl((int)at0, leader, 64);
+                }
+                if (sel) put(t, v, h, (first && rk == 0) ? ~0u : at0 + rk - skip);
+                first = false;
+            }
+        }
+    }
 #pragma unroll
     for (int u = 0; u < Q; u++) {
         if (!valid[u]) continue;
@@ -337,6 +529,45 @@ __global__ __launch_bounds__(256) void k_join_footprint(const mtb_kmer *__restri
     uint64_t lo = dv.base[b >> 16] + dv.dir[b], hi = dv.base[(b + 1) >> 16] + dv.dir[b + 1];
     if (hi > T) hi = T;
     for (uint64_t sct = (lo * 8) >> 6; lo < hi && sct <= ((hi * 8 - 1) >> 6); sct++) atomicOr(&bm_tgtsec[sct >> 5], 1u << (sct & 31u));
+}
+/* ---- diagnostics (not on the timed path): candidate-run lengths ------------------------------------------------------------------
+ * k_index_run_hist: runs of equal amino-acid parts of a FLAT target array, counted at their first entry: hist[b] += 1 and
+ * hist[32 + b] += length for b = floor(log2(length)) -- the index-side run-length distribution (heavy-tailed in real
+ * databases).  k_join_run_hist: for every query of the last batch the length of the run it meets (what k_join_dir scans for it):
+ * hist[0] = queries without a candidate, hist[1 + b] = queries with floor(log2(length)) = b, hist[40 + b] = candidates they scan. */
+__global__ __launch_bounds__(256) void k_index_run_hist(const uint64_t *__restrict__ values, uint64_t T, unsigned long long *__restrict__ hist) {
+    const uint64_t AAM = ~0xFFFFFFull;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < T; i += (uint64_t)gridDim.x * 256) {
+        const uint64_t aa = values[i] & AAM;
+        if (i > 0 && (values[i - 1] & AAM) == aa) continue;
+        uint64_t e = i + 1;
+        while (e < T && (values[e] & AAM) == aa) e++;
+        const uint32_t b = 63u - (uint32_t)__clzll((unsigned long long)(e - i));
+        atomicAdd(&hist[b < 31u ? b : 31u], 1ull); atomicAdd(&hist[32 + (b < 31u ? b : 31u)], (unsigned long long)(e - i));
+    }
+}
+template <bool PACKED>
+__global__ __launch_bounds__(256) void k_join_run_hist(const mtb_kmer *__restrict__ q, uint64_t n, const uint64_t *__restrict__ values, uint64_t limit, mtb_dir_view dv,
+                                                        unsigned long long *__restrict__ hist) {
+    const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const mtb_kmer k = q[j];
+    if (mtb_q_seq(k.qinfo) == 0) return;
+    const uint64_t AAM = ~0xFFFFFFull;
+    auto tkey = [&](uint64_t w) -> uint64_t { return PACKED ? (w & 0x1F000000ull) : (w & AAM); };
+    const uint64_t qk = !PACKED ? (k.value & AAM) : (dv.kmer_format == 1 ? (((k.value >> 24) % 21ull) << 24) : (k.value & 0x1F000000ull));
+    const uint32_t b = mtb_dir_bucket(k.value, dv.L, dv.kmer_format);
+    uint64_t lo = 0, hi = 0;
+    if (b < dv.n_buckets) { lo = dv.base[b >> 16] + dv.dir[b]; hi = dv.base[(b + 1) >> 16] + dv.dir[b + 1]; if (hi > limit) hi = limit; if (lo > hi) lo = hi; }
+    uint64_t a = lo, z = hi;
+    while (a < z) { const uint64_t mid = a + ((z - a) >> 1); if (tkey(values[mid]) < qk) a = mid + 1; else z = mid; }
+    const uint64_t s = a;
+    z = hi;
+    while (a < z) { const uint64_t mid = a + ((z - a) >> 1); if (tkey(values[mid]) <= qk) a = mid + 1; else z = mid; }
+    const uint64_t len = a - s;
+    if (len == 0) { atomicAdd(&hist[0], 1ull); return; }
+    const uint32_t bin = 63u - (uint32_t)__clzll((unsigned long long)len);
+    atomicAdd(&hist[1 + (bin < 31u ? bin : 31u)], 1ull); atomicAdd(&hist[40 + (bin < 23u ? bin : 23u)], (unsigned long long)len);
 }
 __global__ __launch_bounds__(256) void k_popcount_words(const uint32_t *__restrict__ w, uint64_t n_words, unsigned long long *__restrict__ out) {
     unsigned long long acc = 0;

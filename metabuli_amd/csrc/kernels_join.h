@@ -72,6 +72,7 @@ struct JoinSegArgs {
      * + mtb_lslot_tail(dcnt[r], tf) tail slots; matches beyond the tail are only counted (the caller retries with a larger tail) */
     const uint64_t *rb; const uint32_t *dcnt; uint32_t tf;
     uint32_t list;      /* k_join_dir<.., 2>: matches go to the dense list ovf[0 .. ovf_cap) (owner side of the partitioned index) */
+    uint32_t coop_min;  /* k_join_dir: candidate runs longer than this are scanned by the whole wave (kernels_dir.h) */
 };
 
 #ifdef MTB_SCORE_PHASE_CYCLES

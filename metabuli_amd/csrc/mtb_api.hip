@@ -106,6 +106,7 @@ struct mtb_ctx {
     bool fast_used = false;          /* the last dev_score call launched k_score_fast (its slow-list count sits in d_scal[6]) */
     bool no_lslot = false;           /* classify_one is redoing a long-read range on the exact-segment path */
     const mtb_kmer *last_sorted = nullptr; uint64_t last_sorted_n = 0;       /* the last fused slot-path batch's sorted metamers (mtb_ctx_join_footprint) */
+    uint32_t join_coop_min = MTB_JOIN_COOP_MIN;      /* k_join_dir: runs longer than this are scanned by the whole wave; MTB_JOIN_COOP_MIN in the environment at mtb_ctx_create */
 };
 /* buffers that carry a call's inputs / outputs (host-buffer entry points) are not workspace */
 static bool is_io_buf(const std::string &n) { return n == "bases" || n == "offs" || n == "bases2" || n == "offs2" || n == "results" || n == "tctax" || n == "tccnt" || n.compare(0, 2, "pk") == 0; }
@@ -330,6 +331,7 @@ mtb_status mtb_ctx_create(int device, void *stream, mtb_ctx **out) {
     c->d_xscal = c->d_scal + 8;
     for (int i = 0; i < 8; i++) HIPCHK(hipEventCreate(&c->ev[i]));
     memset(&c->stats, 0, sizeof(c->stats));
+    if (const char *e = getenv("MTB_JOIN_COOP_MIN")) c->join_coop_min = (uint32_t)std::max(1, atoi(e));
     *out = c;
     return MTB_OK;
 }
@@ -374,7 +376,7 @@ mtb_status mtb_ctx_set_streams(mtb_ctx *c, int n) {
     while ((int)c->lanes.size() > (n == 1 ? 0 : n)) { mtb_ctx_destroy(c->lanes.back()); c->lanes.pop_back(); }
     while (n > 1 && (int)c->lanes.size() < n) {
         mtb_ctx *l = new mtb_ctx();
-        l->device = c->device; l->is_lane = true; l->d_tabs = c->d_tabs; l->h_tabs = c->h_tabs; l->profiling = c->profiling; l->placement_probe = c->placement_probe;
+        l->device = c->device; l->is_lane = true; l->d_tabs = c->d_tabs; l->h_tabs = c->h_tabs; l->profiling = c->profiling; l->placement_probe = c->placement_probe; l->join_coop_min = c->join_coop_min;
         HIPCHK(hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking));
         HIPCHK(hipMalloc((void **)&l->d_scal, 16 * sizeof(uint64_t)));
         l->d_xscal = l->d_scal + 8;
@@ -655,7 +657,7 @@ static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint6
     if (seg && ix->d_dir) {
         STCHK(use.acquire(ix, true));
         KTimer kt(c, MTB_K_JOIN);
-        JoinSegArgs sa = *seg; sa.ovf_counter = (unsigned long long *)c->d_scal;
+        JoinSegArgs sa = *seg; sa.ovf_counter = (unsigned long long *)c->d_scal; sa.coop_min = c->join_coop_min;
         const uint32_t g2 = (uint32_t)((n + 256 * MTB_JOIN_DIR_QPT - 1) / (256 * MTB_JOIN_DIR_QPT));
         if (sa.list) {      /* owner side of the partitioned index: a dense list of Match records */
             if (state_owner(ix)->packed) hipLaunchKernelGGL((k_join_dir<true, 2>), dim3(g2), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1));
@@ -2406,6 +2408,52 @@ mtb_status mtb_ctx_join_footprint(mtb_ctx *c, mtb_index *ix, mtb_join_footprint 
     if (e != hipSuccess) st = fail(MTB_ERR_DEVICE, std::string("join footprint: ") + hipGetErrorString(e));
     (void)hipFree(bm); (void)hipFree(d_cnt);
     out->n_queries = h[0]; out->distinct_buckets = h[1]; out->dir_sectors = h[2]; out->target_sectors = h[3]; out->n_buckets = nb; out->n_targets = T;
+    return st;
+}
+
+mtb_status mtb_index_run_histogram(mtb_index *ix, uint64_t *hist64) {
+    if (!ix || !hist64) return fail(MTB_ERR_ARG, "NULL argument");
+    memset(hist64, 0, 64 * sizeof(uint64_t));
+    if (ix->T == 0) return MTB_OK;
+    mtb_ctx *c = ix->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    STCHK(ensure_flat(ix));
+    unsigned long long *d_h = nullptr;
+    if (hipMalloc((void **)&d_h, 64 * 8) != hipSuccess) { (void)hipGetLastError(); return fail(MTB_ERR_OOM, "no HBM for the histogram"); }
+    hipError_t e = hipMemsetAsync(d_h, 0, 64 * 8, c->stream);
+    if (e == hipSuccess) { hipLaunchKernelGGL(k_index_run_hist, dim3((uint32_t)std::min<uint64_t>((ix->T + 255) / 256, 1u << 20)), dim3(256), 0, c->stream, (const uint64_t *)ix->d_values, ix->T, d_h); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(hist64, d_h, 64 * 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_h);
+    if (e != hipSuccess) return fail(MTB_ERR_DEVICE, std::string("run histogram: ") + hipGetErrorString(e));
+    return MTB_OK;
+}
+
+mtb_status mtb_ctx_join_run_histogram(mtb_ctx *c, mtb_index *ix, uint64_t *hist64) {
+    if (!c || !ix || !hist64) return fail(MTB_ERR_ARG, "NULL argument");
+    memset(hist64, 0, 64 * sizeof(uint64_t));
+    if (!c->last_sorted || !ix->d_dir || c->last_sub_batches != 1) return fail(MTB_ERR_UNSUPPORTED, "no directory join of a single sub-batch to look at");
+    HIPCHK(hipSetDevice(c->device));
+    unsigned long long *d_h = nullptr;
+    if (hipMalloc((void **)&d_h, 64 * 8) != hipSuccess) { (void)hipGetLastError(); return fail(MTB_ERR_OOM, "no HBM for the histogram"); }
+    mtb_status st = MTB_OK;
+    {
+        IndexUse use;                                       /* the array keeps the state it is in while the kernel reads it */
+        mtb_index *own = state_owner(ix);
+        st = use.acquire(ix, own->packed);
+        const uint64_t limit = ix->T ? ix->T - (ix->match_last ? 0 : 1) : 0;
+        hipError_t e = st == MTB_OK ? hipMemsetAsync(d_h, 0, 64 * 8, c->stream) : hipSuccess;
+        if (st == MTB_OK && e == hipSuccess && c->last_sorted_n) {
+            const dim3 g((uint32_t)((c->last_sorted_n + 255) / 256));
+            if (own->packed) hipLaunchKernelGGL((k_join_run_hist<true>), g, dim3(256), 0, c->stream, c->last_sorted, c->last_sorted_n, (const uint64_t *)ix->d_values, limit, dir_view(ix), d_h);
+            else hipLaunchKernelGGL((k_join_run_hist<false>), g, dim3(256), 0, c->stream, c->last_sorted, c->last_sorted_n, (const uint64_t *)ix->d_values, limit, dir_view(ix), d_h);
+            e = hipGetLastError();
+        }
+        if (st == MTB_OK && e == hipSuccess) e = hipMemcpyAsync(hist64, d_h, 64 * 8, hipMemcpyDeviceToHost, c->stream);
+        if (st == MTB_OK && e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (st == MTB_OK && e != hipSuccess) st = fail(MTB_ERR_DEVICE, std::string("join run histogram: ") + hipGetErrorString(e));
+    }
+    (void)hipFree(d_h);
     return st;
 }
 

@@ -557,8 +557,21 @@ int orc_write_db(const char *dir, const uint64_t *values, const int32_t *taxids,
     f = fopen((d + "/split").c_str(), "wb"); if (!f) return 1;
     fwrite(splits.data(), sizeof(Split), splits.size(), f); fclose(f);
     // taxID_list: distinct taxids, one per line
-    std::vector<int32_t> u(taxids, taxids + n);
-    std::sort(u.begin(), u.end()); u.erase(std::unique(u.begin(), u.end()), u.end());
+    // (distinct ids through a byte map when they are small non-negative numbers -- sorting a copy of 10^9 entries took longer than
+    //  everything else of this function; the sorted distinct list is the same)
+    std::vector<int32_t> u;
+    {
+        int32_t mn = 0, mx = 0;
+        for (size_t j = 0; j < n; j++) { mn = std::min(mn, taxids[j]); mx = std::max(mx, taxids[j]); }
+        if (mn >= 0 && mx < (1 << 28)) {
+            std::vector<uint8_t> seen((size_t)mx + 1, 0);
+            for (size_t j = 0; j < n; j++) seen[(size_t)taxids[j]] = 1;
+            for (size_t t = 0; t < seen.size(); t++) if (seen[t]) u.push_back((int32_t)t);
+        } else {
+            u.assign(taxids, taxids + n);
+            std::sort(u.begin(), u.end()); u.erase(std::unique(u.begin(), u.end()), u.end());
+        }
+    }
     f = fopen((d + "/taxID_list").c_str(), "w"); if (!f) return 1;
     for (int32_t t : u) fprintf(f, "%d\n", t);
     fclose(f);

@@ -87,6 +87,52 @@ class Toy:
         self.ref = orc.classify(self.db, self.tax, self.p, self.b1, self.o1, self.b2, self.o2)
 
 
+class HotToy:
+    """A toy database with LONG candidate runs: every fourth metamer of the first genome is also filed under `n_hot` further species of
+    its genus, each with the amino-acid part kept and 0-3 codon ids of the DNA part redrawn -- a conserved protein shared by many
+    species (runs of 10^3-10^4 candidates in real databases).  A query of that genome then meets a run of > n_hot
+    candidates with a spread of hamming sums: the join's wave-cooperative scan (kernels_dir.h, MTB_JOIN_COOP_MIN) instead of its
+    per-lane loop."""
+
+    def __init__(self, orc, tmpdir, seq_mode=1, n_reads=150, length=150, n_hot=70, seed=77, err=0.01, lognormal=False):
+        from helpers import build_toy_db, default_params
+        from metabuli_amd import synth
+        paired = seq_mode == 2
+        self.p = default_params(seq_mode=seq_mode, syncmer=1)
+        w = synth.make_world(seed=seed, n_genera=2, species_per_genus=2, strains_per_species=1, genome_len=20000, with_euk=False)
+        rng = np.random.default_rng(seed)
+        nxt = max(w.tax.parent) + 1
+        g0 = w.genomes[0][1]
+        k, _, _ = orc.extract_batch(default_params(seq_mode=3, syncmer=1), g0, np.array([0, len(g0)], np.uint64))
+        v0 = np.unique(k["value"])[::4]
+        ev, et = [], []
+        for i in range(n_hot):
+            w.tax.add(nxt, 4, "species", f"hot{i}")
+            dna = v0 & np.uint64(0xFFFFFF)
+            for _ in range(3):                         # up to three codon ids redrawn (none for a third of the entries)
+                pos = rng.integers(0, 8, size=len(v0)).astype(np.uint64) * np.uint64(3)
+                newc = rng.integers(0, 8, size=len(v0)).astype(np.uint64)
+                hit = rng.random(len(v0)) < 0.45
+                dna = np.where(hit, (dna & ~(np.uint64(7) << pos)) | (newc << pos), dna)
+            ev.append((v0 & ~np.uint64(0xFFFFFF)) | dna); et.append(np.full(len(v0), nxt, np.int32))
+            nxt += 1
+        self.world = w
+        self.dbdir = str(tmpdir); os.makedirs(self.dbdir, exist_ok=True)
+        self.values, self.taxids = build_toy_db(orc, w, self.p, self.dbdir, extra=(np.concatenate(ev), np.concatenate(et)))
+        aa = self.values >> np.uint64(24)
+        self.max_run = int(np.diff(np.flatnonzero(np.concatenate([[True], aa[1:] != aa[:-1], [True]]))).max())
+        self.tax = orc.load_taxonomy(os.path.join(self.dbdir, "taxonomy"))
+        self.db = orc.open_db(self.dbdir, self.tax, self.p)
+        out = synth.sample_reads(np.random.default_rng(seed + 1), w, n_reads, length=length, err=err, frac_random=0.1, paired=paired, lognormal=lognormal)
+        if paired:
+            self.b1, self.o1, self.b2, self.o2, self.truth = out
+        else:
+            self.b1, self.o1, self.truth = out
+            self.b2 = self.o2 = None
+        self.n_reads = n_reads
+        self.ref = orc.classify(self.db, self.tax, self.p, self.b1, self.o1, self.b2, self.o2)
+
+
 TOY_MODES = {
     "sync_se": dict(syncmer=1, paired=False, seed=1),
     "dense_se": dict(syncmer=0, paired=False, seed=2),

@@ -107,6 +107,26 @@ def test_bgzf_is_inflated_block_parallel_and_two_bit_packing(dump, tmp_path):
     assert _run(dump, str(pz), 3, 2000, 77, "pack") == exp
 
 
+def test_damaged_bgzf_blocks_are_errors(dump, tmp_path):
+    """block CRC32 is checked, ISIZE beyond the format's 64 KiB is refused, a truncated 'BC' subfield is not read past the mapping"""
+    rng = np.random.default_rng(5)
+    recs, text = _records(rng, 400, True)
+    good = bytearray(_bgzf(text.encode()))
+    # flip one bit of the first block's CRC32 (8 bytes before the end of the block; BSIZE at offset 16)
+    bsize = (good[16] | (good[17] << 8)) + 1
+    bad = bytearray(good); bad[bsize - 8] ^= 1
+    p = tmp_path / "crc.fq.gz"; p.write_bytes(bad)
+    r = subprocess.run([dump, str(p), "4", "3000", "128"], capture_output=True)
+    assert r.returncode != 0 and b"CRC" in r.stderr
+    bad = bytearray(good); bad[bsize - 2] = 0x7F                  # ISIZE claims gigabytes
+    p.write_bytes(bad)
+    r = subprocess.run([dump, str(p), "4", "3000", "128"], capture_output=True)
+    assert r.returncode != 0 and b"BGZF" in r.stderr
+    p.write_bytes(good[:17])                                     # the mapping ends inside the BC subfield
+    r = subprocess.run([dump, str(p), "4", "3000", "128"], capture_output=True)
+    assert r.returncode != 0
+
+
 def test_plain_gzip_stream_longer_than_the_inflaters_queue(dump, tmp_path):
     """A plain (non-BGZF) gzip file is inflated by a background thread 16 MB at a time through a bounded queue: 100 MB of FASTQ
     (more than the queue holds, many refills) must parse exactly like the uncompressed file, and a reader that is destroyed with

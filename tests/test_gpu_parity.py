@@ -593,6 +593,43 @@ def test_many_matches_per_query_take_the_large_segment_path(ctx, orc, tmp_path):
     ix.close()
 
 
+@pytest.mark.parametrize("seq_mode", [1, 2, 3])
+@pytest.mark.parametrize("depth7", [False, True])
+def test_long_candidate_runs_are_scanned_by_the_wave(orc, tmp_path, seq_mode, depth7, monkeypatch):
+    """runs of > 70 candidates per query (a conserved amino-acid 8-mer filed under 70 species, DNA parts varied): k_join_dir hands
+    them to the whole wave (second bisection for the run's end, 64 candidates per step, ballot-ranked emission) -- short reads into
+    fixed slot segments, pairs, long reads into slot ranges; on the flat array and on packed words under a depth-7 directory.  The
+    per-read answers and the match totals are the oracle's."""
+    import metabuli_amd as M
+    from conftest import HotToy
+    t = HotToy(orc, tmp_path / "db", seq_mode=seq_mode, n_reads=12 if seq_mode == 3 else 150, length=4000 if seq_mode == 3 else 150,
+               lognormal=seq_mode == 3, err=0.03 if seq_mode == 3 else 0.01)
+    assert t.max_run > 64
+    if depth7:
+        monkeypatch.setenv("MTB_DIR_DEPTH", "7")
+    c = M.Context(0)
+    p = M.default_params(seq_mode=seq_mode, syncmer=1)
+    ix = c.open_index(t.dbdir, p)
+    monkeypatch.delenv("MTB_DIR_DEPTH", raising=False)
+    assert ix.state()["dir_depth"] == (7 if depth7 else ix.state()["dir_depth"]) and ix.state()["dir_depth"] > 0
+    res, tt, tc = c.classify_batch(ix, p, t.b1, t.o1, t.b2, t.o2)
+    assert ix.state()["packed"] == depth7
+    ro = t.ref["results"]
+    amb = ro["flag"] != 0
+    assert ((res["classification"] == ro["classification"]) | amb).all()
+    assert ((res["score"].view(np.uint32) == ro["score"].view(np.uint32)) | amb).all()
+    assert ((res["n_taxcnt"] == ro["n_taxcnt"]) | amb).all()
+    if not amb.any():
+        assert (tt == t.ref["tc_tax"]).all() and (tc == t.ref["tc_cnt"]).all()
+    if seq_mode != 3:                      # (the long-read slot path drops matches that are alone in their species before it counts)
+        assert c.last_stats().n_matches == len(t.ref["matches"])
+    assert (res["is_classified"] != 0).sum() >= (6 if seq_mode == 3 else 60)
+    # the stage join (k_join: LDS window) on the same database gives the same match list as the oracle: the two joins agree through it
+    m = c.sort_matches(c.match(ix, t.ref["kmers"]), t.n_reads)
+    assert (m == t.ref["matches"]).all()
+    ix.close(); c.close()
+
+
 @pytest.mark.parametrize("name", ["toy_sync_se", "toy_dense_pe", "toy_oldfmt_pe", "toy_sync_long"])
 def test_golden_vectors_through_the_c_abi(ctx, orc, tmp_path, name):
     """the committed golden vectors (tests/golden/*.npz: inputs, database arrays and the oracle's outputs at the time
@@ -694,15 +731,17 @@ def test_redundancy_bit_of_legacy_databases(ctx, orc, tmp_path):
 def test_bench_path_matches_the_oracle(tmp_path):
     """bench.py's own configuration in small: synthetic filler index (mtb_synth_index), borrowed device arrays
     (mtb_index_from_device), device-resident reads (mtb_classify_batch_device) -- the entry points the headline number is
-    measured on -- compared with the oracle read by read inside bench.py (`parity_sample`).  A filler-dominated index
-    is a different join / scorer regime from the toy genomes: amino-acid runs full of foreign candidates."""
+    measured on -- compared with the oracle read by read inside bench.py (`parity_sample`: the sample against the timed index itself,
+    the oracle on a sub-database that holds the sample's candidate closure).  A filler-dominated index is a different join /
+    scorer regime from the toy genomes: amino-acid runs full of foreign candidates."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for mode in (1, 2):
-        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--reads", "20000", "--targets", "1.5e6",
-                              "--cpu-reads", "20000", "--cpu-targets", "1.5e6", "--species", "8", "--genome-len", "150000", "--filler-species", "3000",
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--reads", "20000", "--targets", "3e6",
+                              "--cpu-reads", "20000", "--cpu-stride", "4", "--species", "8", "--genome-len", "150000", "--filler-species", "3000",
+                              "--leg-pairs", "3000", "--leg-long", "40", "--leg-long-len", "3000", "--full-parity-reads", "3000",
                               "--seq-mode", str(mode)], capture_output=True, text=True, timeout=900)
         assert out.returncode == 0, out.stderr[-2000:]
         line = json.loads(out.stdout.strip().split("\n")[-1])
@@ -710,6 +749,33 @@ def test_bench_path_matches_the_oracle(tmp_path):
         assert ps["reads"] == 20000 and ps["mismatches"] == 0 and ps["classified"] > 10000, ps
         assert ps["matches"] == ps["oracle_matches"] > 0
         assert line["cpu_baseline"]["cores"] >= 1 and line["cpu_baseline"]["kind"] == "port"
+        assert line["roofline"]["frac"] > 0 and line["run_lengths"]["index"]["runs_by_log2_length"][0] > 0
+        if mode == 1:                        # the legs of the other configurations ride on the single-end run
+            oc = line["other_configs"]
+            assert oc["paired"]["mismatches"] == 0 and oc["long"]["mismatches"] == 0
+            assert oc["paired"]["parity"]["reads"] == 3000 and oc["long"]["parity"]["matches"] == oc["long"]["parity"]["oracle_matches"] > 0
+
+
+def test_bench_heavy_tailed_workload_in_small(tmp_path):
+    """the device-side world generator (conserved protein-coding segments shared at class-dependent prevalence) + shared-run extras:
+    200 genomes give candidate runs of > 100 species where the reads hit them; the wave-cooperative scan of k_join_dir answers them
+    as the oracle does (headline sample, pairs, long reads), and the best-case leg runs"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--reads", "100000", "--targets", "2.5e8",
+                          "--cpu-reads", "30000", "--cpu-stride", "8", "--species", "200", "--genome-len", "600000", "--filler-species", "5000",
+                          "--leg-pairs", "20000", "--leg-long", "100", "--leg-long-len", "5000", "--full-parity-reads", "4000", "--no-cpu"],
+                         capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().split("\n")[-1])
+    assert line["parity_sample"]["mismatches"] == 0 and line["parity_sample"]["reads"] == 30000
+    assert line["other_configs"]["paired"]["mismatches"] == 0 and line["other_configs"]["long"]["mismatches"] == 0
+    assert line["best_case"]["ms_per_step"] > 0
+    rl = line["run_lengths"]
+    assert rl["index"]["shared_run_extras"] > 0 and rl["index"]["quantiles_over_targets"]["max_bin_upper"] >= 127
+    assert rl["queries"]["quantiles"]["max_bin_upper"] >= 127            # queries meet runs of > 64 candidates: the wave-scanned path ran
 
 
 def test_format1_database_without_kmer_format_line(ctx, orc, tmp_path):

@@ -148,7 +148,12 @@ def _gpu_worker(rank, world, port, dbdir, npz, out, seq_mode):
     dev = torch.device("cuda:0")
     st = parallel.GpuStages(ctx, ix, p, dev)
     st.overlapping = not os.environ.get("MTB_TEST_PART_LEGACY")
-    st.set_reads(torch.from_numpy(b.copy()).to(dev), torch.from_numpy(o.astype(np.int64)).to(dev), hi - lo)
+    if seq_mode == 2:
+        b2, o2, _, _ = parallel.shard_reads(g["bases2"], g["offs2"], rank, world)
+        st.set_reads(torch.from_numpy(b.copy()).to(dev), torch.from_numpy(o.astype(np.int64)).to(dev), hi - lo,
+                     torch.from_numpy(b2.copy()).to(dev), torch.from_numpy(o2.astype(np.int64)).to(dev))
+    else:
+        st.set_reads(torch.from_numpy(b.copy()).to(dev), torch.from_numpy(o.astype(np.int64)).to(dev), hi - lo)
     res, tt, tc = parallel.classify_partitioned(st, bounds, dist)
     slot_reads = int(ctx.last_stats().n_slot_reads) if st.overlapping else -1
     gathered = [None] * world
@@ -178,6 +183,50 @@ def test_gpu_partitioned_two_processes(orc, tmp_path, world, legacy, monkeypatch
     if legacy:
         monkeypatch.setenv("MTB_TEST_PART_LEGACY", "1")
     mp.spawn(_gpu_worker, args=(world, 30700 + os.getpid() % 500, t.dbdir, npz, out, 1), nprocs=world, join=True)
+    _check(out, t.ref)
+    assert int(np.load(out)["T"]) == len(t.values) and bool(np.load(out)["slot_ok"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seq_mode", [2, 3])
+def test_gpu_partitioned_pairs_and_long_reads(orc, tmp_path, seq_mode):
+    """the partitioned batch against the oracle for read pairs (slot path: mate offsets in the ordinal-tagged positions) and for long
+    reads (exact-order runs, regroup + segment sort at home)"""
+    from conftest import Toy
+    if seq_mode == 2:
+        t = Toy(orc, tmp_path / "db", syncmer=1, paired=True, seed=25, n_reads=200)
+    else:
+        t = Toy(orc, tmp_path / "db", syncmer=1, paired=False, seed=26, n_reads=16, length=3000, seq_mode=3, err=0.05, lognormal=True)
+    npz = str(tmp_path / "in.npz"); out = str(tmp_path / "out.npz")
+    if seq_mode == 2:
+        np.savez(npz, bases=t.b1, offs=t.o1, bases2=t.b2, offs2=t.o2)
+    else:
+        np.savez(npz, bases=t.b1, offs=t.o1)
+    mp.spawn(_gpu_worker, args=(2, 30900 + os.getpid() % 500, t.dbdir, npz, out, seq_mode), nprocs=2, join=True)
+    r = np.load(out); ro = t.ref["results"]; amb = ro["flag"] != 0
+    assert ((r["cls"] == ro["classification"]) | amb).all()
+    assert ((r["score"].view(np.uint32) == ro["score"].view(np.uint32)) | amb).all()
+    if not amb.any():
+        assert (r["tt"] == t.ref["tc_tax"]).all() and (r["tc"] == t.ref["tc_cnt"]).all()
+    assert int(r["T"]) == len(t.values)
+    if seq_mode == 2:
+        assert bool(r["slot_ok"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("no_dir", [False, True])
+def test_gpu_partitioned_long_runs_and_the_bisection_fallback(orc, tmp_path, no_dir, monkeypatch):
+    """(a) candidate runs of > 70 entries on the owner side: k_join_dir's dense-list mode scans them with the whole wave (count before
+    the workgroup's reservation, ballot-ranked emission behind it); (b) ADVICE r3: an owner without a directory (MTB_NO_DIR) falls back
+    to the bisection join, whose tile windows must follow the SENDER's sort granularity (slot-mode runs are ordered on bits [34, 64)
+    only) -- no match may be lost, and the records (pad = 0) still reach the home rank's slots through the tails"""
+    from conftest import HotToy
+    t = HotToy(orc, tmp_path / "db", seq_mode=1, n_reads=200)
+    npz = str(tmp_path / "in.npz"); out = str(tmp_path / "out.npz")
+    np.savez(npz, bases=t.b1, offs=t.o1)
+    if no_dir:
+        monkeypatch.setenv("MTB_NO_DIR", "1")
+    mp.spawn(_gpu_worker, args=(2, 31100 + os.getpid() % 500, t.dbdir, npz, out, 1), nprocs=2, join=True)
     _check(out, t.ref)
     assert int(np.load(out)["T"]) == len(t.values) and bool(np.load(out)["slot_ok"])
 

@@ -122,3 +122,14 @@ def test_other_compressor_strategies_and_binary_data(tools, tmp_path, text):
         for threads, chunk in ((4, 65536), (2, 1 << 20)):
             r = _inflate(chk, p, threads, chunk)
             assert r.returncode == 0 and r.stdout == plain, (k, threads, chunk, r.stderr[:200])
+
+
+def test_bytes_behind_a_complete_member_end_the_input_like_zlib(tools, tmp_path, text):
+    """non-gzip bytes after a valid member: zlib's gzread (the small-file path, the reference's kseq reader) stops there; the
+    block-parallel inflater must accept the same file, whatever its size and thread count"""
+    chk = tools[0]
+    p = tmp_path / "trail.gz"
+    p.write_bytes(gzip.compress(text, 6) + b"this is not a gzip header, just bytes somebody appended\n" * 10)
+    for threads, chunk in ((1, 1 << 20), (4, 65536), (8, 150000)):
+        r = _inflate(chk, p, threads, chunk)
+        assert r.returncode == 0 and r.stdout == text, (threads, chunk, r.stderr[:200])
