@@ -202,6 +202,8 @@ def extract_targets(ctx, M, world, params, torch=None, dev=None, genomes_per_cal
     piece, ov = 20000, 32
     p = M.default_params(seq_mode=3, syncmer=params.syncmer, smer_len=params.smer_len)
     vals, tids = [], []
+    if torch is not None:
+        qcuts = torch.tensor([-2**62, 0, 2**62], dtype=torch.int64, device=dev)
     for g0 in range(0, len(world.genomes), genomes_per_call):
         chunk = world.genomes[g0:g0 + genomes_per_call]
         seqs, owner = [], []
@@ -222,23 +224,26 @@ def extract_targets(ctx, M, world, params, torch=None, dev=None, genomes_per_cal
             kv = torch.from_numpy(np.ascontiguousarray(k["value"]).view(np.int64)).to(dev)
         for gi, (tid, g) in enumerate(chunk):
             if torch is not None:
-                v = torch.unique(kv[first[gi]:first[gi + 1]])                                   # signed ascending: [negative values | non-negative values]
-                n_neg = int((v < 0).sum().item())
-                vals.append((v[n_neg:], v[:n_neg])); tids.append(tid)
+                v = torch.unique(kv[first[gi]:first[gi + 1]])                                   # signed ascending = unsigned quarters [2, 3, 0, 1] of the value range
+                c = torch.searchsorted(v, qcuts).tolist()
+                vals.append((v[c[1]:c[2]], v[c[2]:], v[:c[0]], v[c[0]:c[1]])); tids.append(tid)
             else:
                 v = np.unique(k["value"][first[gi]:first[gi + 1]])
                 vals.append(v); tids.append(np.full(len(v), tid, np.int32))
     # one strain per species here, so (value, species) pairs are already unique; strain ids rise with the genome order,
     # so a STABLE sort by value of the genome-major concatenation is (value, taxid) order
     if torch is not None:
-        # unsigned 64-bit order = the non-negative int64 values ascending, then the negative ones ascending; the halves are
-        # sorted separately (torch.sort and boolean masks take < 2^31 elements per call)
+        # unsigned 64-bit order = the four quarters of the value range one after another, each ascending as int64 (all of one sign);
+        # the quarters are sorted separately (torch.sort and boolean masks take < 2^31 elements per call; with 2400 genomes the
+        # non-negative values alone are ~2 G)
         out_v, out_t, n_extras = [], [], 0
-        for half in (0, 1):
+        for half in (0, 1, 2, 3):
             hv = torch.cat([x[half] for x in vals])
             ht = torch.cat([torch.full((len(x[half]),), tid, dtype=torch.int32, device=dev) for x, tid in zip(vals, tids)])
             if len(hv) >= 2**31:
-                raise SystemExit(f"{len(hv)} genome-derived metamers in one sign half: more than one torch.sort call takes")
+                raise SystemExit(f"{len(hv)} genome-derived metamers in one quarter of the value range: more than one torch.sort call takes")
+            if len(hv) == 0:
+                continue
             order = torch.sort(hv, stable=True).indices
             hv, ht = hv[order], ht[order]
             del order
@@ -246,7 +251,7 @@ def extract_targets(ctx, M, world, params, torch=None, dev=None, genomes_per_cal
                 ev, et = hot_run_extras(torch, dev, hv, world.filler_tax_lo, world.filler_tax_hi - world.filler_tax_lo + 1, hot_min, seed)
                 if len(ev):
                     if len(hv) + len(ev) >= 2**31:
-                        raise SystemExit("genome-derived metamers + shared-run extras of one sign half exceed one torch.sort call")
+                        raise SystemExit(f"genome-derived metamers ({len(hv)}) + shared-run extras ({len(ev)}) of one quarter of the value range exceed one torch.sort call")
                     n_extras += len(ev)
                     # filler species ids lie above every strain id: behind the genome-derived entries of the same value, a stable sort by value keeps (value, taxid) order
                     hv = torch.cat([hv, ev]); ht = torch.cat([ht, et])

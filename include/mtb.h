@@ -148,6 +148,14 @@ uint32_t   mtb_ctx_last_sub_batches(const mtb_ctx *);
  * `params` is in/out: db.parameters overrides are written back.             */
 mtb_status mtb_index_open(mtb_ctx *, const char *dbdir, const char *taxonomy_dir,
                           mtb_params *params, mtb_index **out);
+/* How the files came in.  The target list is decoded in CHUNKS of the diffIdx stream (the reference streams the files as well,
+ * KmerMatcher.cpp:212-217, 256-271): peak HBM during the open = what the index keeps + one chunk, whatever the database size; a
+ * workspace limit on the context (mtb_ctx_set_workspace_limit) bounds the chunk.  Databases of >= 2^28 targets whose directory has
+ * depth 7 open SEALED (packed 8-byte words, info[] folded in chunk by chunk and never resident: mtb_index_seal's state, 8.4 bytes per
+ * target -- 16 G targets fit one 288 GB GPU); smaller ones open flat.
+ * out4: [0] chunks decoded, [1] 16-bit words per chunk, [2] peak device bytes in use during the open beyond what was in use before
+ * it (values + info + directory + chunk buffers), [3] 1 if the index was packed on load.                                          */
+mtb_status mtb_index_open_stats(const mtb_index *, uint64_t *out4);
 /* Same, from an already flat index resident on the device (synthetic-index
  * benchmark path).  The arrays are borrowed, not copied: they must outlive
  * the index -- and they are NOT read-only: while the index lives the fused

@@ -383,6 +383,12 @@ class Index:
     def num_targets(self):
         return self.ctx.L.mtb_index_num_targets(self.h)
 
+    def open_stats(self):
+        """mtb_index_open_stats: how the database files came in (chunked decode)"""
+        o = np.zeros(4, np.uint64)
+        _chk(self.ctx.L.mtb_index_open_stats(self.h, _p(o)))
+        return dict(chunks=int(o[0]), chunk_words=int(o[1]), peak_bytes=int(o[2]), packed_on_load=bool(o[3]))
+
     def seal(self):
         """mtb_index_seal: packed state + info[] released (the lender of a borrowed info array may free it afterwards)"""
         _chk(self.ctx.L.mtb_index_seal(self.h))

@@ -83,6 +83,60 @@ __global__ __launch_bounds__(256) void k_dir_tail(const uint64_t *__restrict__ v
     }
 }
 
+/* The same directory built while the target array arrives in chunks (mtb_index_open: the flat values of chunk [g0, g0 + m) are complete,
+ * everything before may already be packed): *prev = the flat value of entry g0 - 1.  First the group bases that start inside the chunk,
+ * then the bucket starts (they need the bases); k_dir_finish closes the table behind the last target. */
+__device__ __forceinline__ bool mtb_dir_letters_ok(uint64_t v, int fmt) {
+    if (fmt == 1) return true;
+    bool bad = false;
+    for (int j = 0; j < 8; j++) bad |= ((v >> (59 - 5 * j)) & 31u) > 20u;
+    return !bad;
+}
+__global__ __launch_bounds__(256) void k_dir_chunk_base(const uint64_t *__restrict__ values, uint64_t g0, uint64_t m, const uint64_t *__restrict__ prev, int L, int fmt,
+                                                         uint32_t n_buckets, uint64_t *__restrict__ base, uint32_t *__restrict__ flags) {
+    for (uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x; j < m; j += (uint64_t)gridDim.x * 256) {
+        const uint64_t i = g0 + j, v = values[i];
+        if (!mtb_dir_letters_ok(v, fmt)) { flags[0] = 1; continue; }
+        const uint32_t b = mtb_dir_bucket(v, L, fmt);
+        if (b >= n_buckets) { flags[0] = 1; continue; }
+        int64_t pb = -1;
+        if (i > 0) { pb = (int64_t)mtb_dir_bucket(j ? values[i - 1] : *prev, L, fmt); if (pb > (int64_t)b) { flags[0] = 1; continue; } }
+        for (int64_t g = pb < 0 ? 0 : (pb >> 16) + 1; g <= (int64_t)(b >> 16); g++) base[g] = i;       /* groups whose first bucket lies in (pb, b] */
+    }
+}
+__global__ __launch_bounds__(256) void k_dir_chunk_fill(const uint64_t *__restrict__ values, uint64_t g0, uint64_t m, const uint64_t *__restrict__ prev, int L, int fmt,
+                                                         uint32_t n_buckets, const uint64_t *__restrict__ base, uint32_t *__restrict__ dir, uint32_t *__restrict__ flags) {
+    for (uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x; j < m; j += (uint64_t)gridDim.x * 256) {
+        const uint64_t i = g0 + j, v = values[i];
+        if (!mtb_dir_letters_ok(v, fmt)) continue;
+        const uint32_t b = mtb_dir_bucket(v, L, fmt);
+        if (b >= n_buckets) continue;
+        int64_t pb = -1;
+        if (i > 0) { pb = (int64_t)mtb_dir_bucket(j ? values[i - 1] : *prev, L, fmt); if (pb >= (int64_t)b) continue; }
+        for (int64_t x = pb + 1; x <= (int64_t)b; x++) {
+            const uint64_t rel = i - base[(uint64_t)x >> 16];
+            if (rel >> 32) flags[1] = 1;
+            dir[x] = (uint32_t)rel;
+        }
+    }
+}
+/* behind the last target (*last = its flat value): the bases of the groups that never started, the empty buckets, the end sentinel */
+__global__ __launch_bounds__(256) void k_dir_finish(const uint64_t *__restrict__ last, uint64_t T, int L, int fmt, uint32_t n_buckets, uint32_t n_groups,
+                                                     uint64_t *__restrict__ base, uint32_t *__restrict__ dir, uint32_t *__restrict__ flags, int phase) {
+    const uint64_t first = T ? (uint64_t)mtb_dir_bucket(*last, L, fmt) + 1 : 0;
+    if (phase == 0) {
+        for (uint64_t g = (T ? ((first - 1) >> 16) + 1 : 0) + (uint64_t)blockIdx.x * 256 + threadIdx.x; g <= n_groups; g += (uint64_t)gridDim.x * 256) base[g] = T;
+        return;
+    }
+    for (uint64_t x = first + (uint64_t)blockIdx.x * 256 + threadIdx.x; x <= n_buckets; x += (uint64_t)gridDim.x * 256) {
+        const uint64_t rel = T - base[x >> 16];
+        if (rel >> 32) flags[1] = 1;
+        dir[x] = (uint32_t)rel;
+    }
+}
+/* pack entries [g0, g0 + m) with the info entries of that chunk (pack on load: the whole info[] never exists on the device) */
+__global__ __launch_bounds__(256) void k_index_pack_chunk(uint64_t *__restrict__ values, const uint32_t *__restrict__ info_chunk, uint64_t g0, uint64_t m, int fmt);
+
 /* ---- packed state of the target array (directory depth 7 only) ------------------------------------------------------------
  * Inside a bucket of the depth-7 directory all targets share their first seven amino-acid letters, so a target is told apart by
  * 29 bits: its eighth letter (5 bits; format 1: the last base-21 digit) and its 24 DNA bits.  The other 35 bits of the 64-bit
@@ -104,6 +158,9 @@ MTB_HD uint64_t mtb_unpack_value(uint64_t w, uint32_t bucket, int fmt) {
 }
 __global__ __launch_bounds__(256) void k_index_pack(uint64_t *__restrict__ values, const uint32_t *__restrict__ info, uint64_t T, int fmt) {
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < T; i += (uint64_t)gridDim.x * 256) values[i] = mtb_pack_word(values[i], info[i], fmt);
+}
+__global__ __launch_bounds__(256) void k_index_pack_chunk(uint64_t *__restrict__ values, const uint32_t *__restrict__ info_chunk, uint64_t g0, uint64_t m, int fmt) {
+    for (uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x; j < m; j += (uint64_t)gridDim.x * 256) values[g0 + j] = mtb_pack_word(values[g0 + j], info_chunk[j], fmt);
 }
 /* one thread per bucket: its targets get their prefix back, info[] (if given) is rewritten from the upper bits */
 __global__ __launch_bounds__(256) void k_index_unpack(uint64_t *__restrict__ values, uint32_t *__restrict__ info, mtb_dir_view dv) {

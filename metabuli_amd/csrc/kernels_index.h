@@ -55,6 +55,67 @@ __global__ __launch_bounds__(256) void k_diff_assemble(const uint16_t *__restric
     }
 }
 
+/* first delta of a chunk += the last value of the previous chunk (chunked decode: the 64-bit prefix sum then runs per chunk);
+ * k_save_last keeps the chunk's last FLAT value for the next chunk (the array may be packed in place right afterwards) */
+__global__ void k_diff_add_carry(uint64_t *__restrict__ first_delta, const uint64_t *__restrict__ carry) { *first_delta += *carry; }
+__global__ void k_save_last(const uint64_t *__restrict__ last, uint64_t *__restrict__ carry) { *carry = *last; }
+
+/* ---------------- diffIdx encode (mtb_index_write): IndexCreator::getDiffIdx (IndexCreator.cpp:874-892) on the device ----------------
+ * words of entry i = 15-bit groups of (value[i] - value[i-1]), most significant first, the last one flagged 0x8000 */
+__device__ __forceinline__ uint32_t mtb_diff_words(uint64_t dlt) {
+    const uint32_t bits = dlt ? 64u - (uint32_t)__clzll((unsigned long long)dlt) : 1u;
+    return (bits + 14u) / 15u;
+}
+__global__ __launch_bounds__(256) void k_diff_nwords(const uint64_t *__restrict__ values, uint64_t i0, uint64_t m, uint32_t *__restrict__ nw) {
+    const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    const uint64_t i = i0 + j;
+    nw[j] = mtb_diff_words(values[i] - (i ? values[i - 1] : 0ull));
+}
+__global__ __launch_bounds__(256) void k_diff_encode(const uint64_t *__restrict__ values, uint64_t i0, uint64_t m, const uint64_t *__restrict__ off, uint16_t *__restrict__ enc) {
+    const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    const uint64_t i = i0 + j;
+    const uint64_t dlt = values[i] - (i ? values[i - 1] : 0ull);
+    const uint32_t n = mtb_diff_words(dlt);
+    uint16_t *o = enc + off[j];
+    for (uint32_t q = 0; q < n; q++) {
+        const uint32_t g = n - 1 - q;
+        o[q] = (uint16_t)(((dlt >> (15 * g)) & 0x7FFFull) | (g == 0 ? 0x8000u : 0u));
+    }
+}
+/* taxID_list (IndexCreator.cpp:329-333): ids that occur, as a byte map; ids outside [0, max_id] are appended to a short list */
+__global__ __launch_bounds__(256) void k_mark_taxids(const uint32_t *__restrict__ info, uint64_t i0, uint64_t m, uint8_t *__restrict__ seen, int32_t max_id,
+                                                      int32_t *__restrict__ extra, uint32_t extra_cap, uint32_t *__restrict__ n_extra) {
+    const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    const int32_t t = (int32_t)(info[i0 + j] & 0x7FFFFFFFu);
+    if (t >= 0 && t <= max_id + 1) { if (!seen[t]) seen[t] = 1; }
+    else { const uint32_t at = atomicAdd(n_extra, 1u); if (at < extra_cap) extra[at] = t; }
+}
+/* split checkpoints (IndexCreator.cpp:848-857): checkpoint k is armed at entry k * size_of_split - 1 with that entry's amino-acid part and
+ * recorded at the first later entry of another amino-acid part: j[k] = its index (n if there is none) */
+__global__ __launch_bounds__(256) void k_split_find(const uint64_t *__restrict__ values, uint64_t n, uint64_t size_of_split, uint32_t n_k, uint64_t *__restrict__ j_out) {
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x + 1;
+    if (k > n_k) return;
+    const uint64_t i0 = (uint64_t)k * size_of_split - 1;
+    uint64_t j = n;
+    if (i0 < n) {
+        const uint64_t aa = values[i0] & ~0xFFFFFFull;
+        j = i0 + 1;
+        while (j < n && (values[j] & ~0xFFFFFFull) == aa) j++;
+    }
+    j_out[k - 1] = j;
+}
+/* value[j] and the word offset BEHIND entry j (inside the current slice [i0, i0 + m)) for a short list of entries */
+__global__ void k_split_gather(const uint64_t *__restrict__ values, const uint64_t *__restrict__ off, uint64_t i0, const uint64_t *__restrict__ js, uint32_t n,
+                               uint64_t *__restrict__ out_value, uint64_t *__restrict__ out_off) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const uint64_t j = js[t];
+    out_value[t] = values[j]; out_off[t] = off[j - i0 + 1];
+}
+
 /* ---------------- synthetic filler index ---------------- */
 #define MTB_AA_SPACE 37822859361ull   /* 21^8 */
 

@@ -3,6 +3,9 @@
  * launches kernels on the context's stream and reports HIP errors.           */
 #include <hip/hip_runtime.h>
 
+#include <fcntl.h>
+#include <unistd.h>
+
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
@@ -169,6 +172,7 @@ struct mtb_index {
     std::mutex state_mu; std::condition_variable state_cv; int users = 0;
     int views = 0;                   /* live mtb_index_slice views: they read the parent's flat arrays, so the parent stays flat */
     mtb_index *parent = nullptr;     /* of a view */
+    uint64_t open_chunks = 0, open_chunk_words = 0, open_peak_bytes = 0, open_free0 = 0;      /* mtb_index_open_stats */
 };
 
 template <typename T>
@@ -1022,14 +1026,33 @@ static mtb_status plan_parts(const std::string &d, uint32_t n_parts, PartPlan *p
     return MTB_OK;
 }
 
+/* bytes [off, off + len) of a file into a (pinned) host buffer, with a few threads: one pread stream tops out near 3 GB/s from the page
+ * cache, the files of a GTDB-scale database are ~150 GB */
+static bool pread_parallel(int fd, void *dst, uint64_t off, size_t len, int n_threads) {
+    if (len == 0) return true;
+    const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, len >> 22));
+    std::vector<char> ok((size_t)nt, 1);
+    auto part = [&](int t) {
+        size_t lo = len * (size_t)t / (size_t)nt, hi = len * ((size_t)t + 1) / (size_t)nt;
+        while (lo < hi) {
+            const ssize_t r = pread(fd, (char *)dst + lo, hi - lo, (off_t)(off + lo));
+            if (r <= 0) { ok[(size_t)t] = 0; return; }
+            lo += (size_t)r;
+        }
+    };
+    if (nt == 1) part(0);
+    else { std::vector<std::thread> th; for (int t = 0; t < nt; t++) th.emplace_back(part, t); for (auto &x : th) x.join(); }
+    for (char k : ok) if (!k) return false;
+    return true;
+}
+
 /* bytes [off, off + len) of a file -> device memory, double-buffered through pinned host memory */
 static mtb_status stream_file_to_device(mtb_ctx *c, const std::string &path, uint64_t off, uint64_t len, void *d_dst) {
     if (len == 0) return MTB_OK;
-    FILE *f = fopen(path.c_str(), "rb");
-    if (!f) return fail(MTB_ERR_IO, "cannot open " + path);
-    if (fseeko(f, (off_t)off, SEEK_SET) != 0) { fclose(f); return fail(MTB_ERR_IO, "cannot seek in " + path); }
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) return fail(MTB_ERR_IO, "cannot open " + path);
     const size_t CH = 64u << 20;
-    void *buf[2] = {nullptr, nullptr}; hipEvent_t ev[2]; bool used[2] = {false, false};
+    void *buf[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr}; bool used[2] = {false, false};
     mtb_status st = MTB_OK;
     if (hipHostMalloc(&buf[0], CH, hipHostMallocDefault) != hipSuccess || hipHostMalloc(&buf[1], CH, hipHostMallocDefault) != hipSuccess ||
         hipEventCreate(&ev[0]) != hipSuccess || hipEventCreate(&ev[1]) != hipSuccess) { (void)hipGetLastError(); st = fail(MTB_ERR_OOM, "no pinned host memory for the index upload"); }
@@ -1037,16 +1060,155 @@ static mtb_status stream_file_to_device(mtb_ctx *c, const std::string &path, uin
     while (st == MTB_OK && done < len) {
         const size_t n = (size_t)std::min<uint64_t>(CH, len - done);
         if (used[k] && hipEventSynchronize(ev[k]) != hipSuccess) { st = fail(MTB_ERR_DEVICE, "hipEventSynchronize failed during the index upload"); break; }
-        if (fread(buf[k], 1, n, f) != n) { st = fail(MTB_ERR_IO, "short read from " + path); break; }
+        if (!pread_parallel(fd, buf[k], off + done, n, 8)) { st = fail(MTB_ERR_IO, "short read from " + path); break; }
         if (hipMemcpyAsync((char *)d_dst + done, buf[k], n, hipMemcpyHostToDevice, c->stream) != hipSuccess || hipEventRecord(ev[k], c->stream) != hipSuccess) {
             st = fail(MTB_ERR_DEVICE, "H2D copy failed during the index upload"); break; }
         used[k] = true; done += n; k ^= 1;
     }
     hipError_t e = hipStreamSynchronize(c->stream); (void)e;
-    fclose(f);
-    for (int i = 0; i < 2; i++) { if (buf[i]) e = hipHostFree(buf[i]); }
-    e = hipEventDestroy(ev[0]); e = hipEventDestroy(ev[1]); (void)e;
+    close(fd);
+    for (int i = 0; i < 2; i++) { if (buf[i]) e = hipHostFree(buf[i]); if (ev[i]) e = hipEventDestroy(ev[i]); }
+    (void)e;
     return st;
+}
+
+/* The target list of a database (or of one value range of it) into HBM, decoded in CHUNKS of the diffIdx stream (the reference streams
+ * the files too: KmerMatcher.cpp:212-217, 256-271, getNextTargetKmer KmerMatcher.h:282-297):
+ *   chunk of 16-bit words (+ the words of a metamer cut by the previous chunk's end) -> terminators per tile -> offsets -> deltas
+ *   written to their final places in value[] -> first delta += the previous chunk's last value -> 64-bit inclusive scan of the chunk
+ *   -> the amino-acid directory rows of the chunk (k_dir_chunk_*) -> with `pack`, the chunk's info entries (streamed into a chunk
+ *   buffer) are folded into packed 8-byte words at once (kernels_dir.h) and info[] is never resident.
+ * Peak HBM: 8 bytes per target (+ 4 for info[] without `pack`) + the directory + one chunk (2 B per word, 4 B per metamer of it):
+ * a 16 G-target database opens on one 288 GB GPU; the whole-file decode of round 3 held ~18 bytes per target at once.
+ * On return *dir_ok says whether the directory is usable (else it has been freed); with `pack` a false *dir_ok is an error to the
+ * caller (the array is partly packed): it opens again without. */
+struct OpenPlan { uint64_t n16 = 0, T = 0, expect = 0, lead = 0, diff_off = 0, info_off = 0, first_value = 0; };
+static mtb_status decode_chunked(mtb_ctx *c, mtb_index *ix, const std::string &d, const OpenPlan &P, bool want_dir, int L, bool pack, bool *dir_ok) {
+    *dir_ok = false;
+    hipStream_t st = c->stream;
+    /* 16-bit words per chunk: 128 M (256 MB), less when the context's workspace limit asks for it (a chunk costs ~16 bytes per word:
+     * the words twice, tile tables, the info entries of its metamers, scan workspace); MTB_OPEN_CHUNK: tests (a few dozen words) */
+    uint64_t CH = 128ull << 20;
+    if (c->ws_limit) CH = std::max<uint64_t>(1u << 16, std::min<uint64_t>(CH, c->ws_limit / 16));
+    if (getenv("MTB_OPEN_CHUNK")) CH = std::max<uint64_t>(16, strtoull(getenv("MTB_OPEN_CHUNK"), nullptr, 10));
+    const int fmt = ix->params.kmer_format;
+    const uint32_t nbk = want_dir ? mtb_pow21(L) : 0, n_groups = want_dir ? (nbk >> 16) + 1 : 0;
+    uint32_t *d_flags = (uint32_t *)(c->d_scal + 6);
+    uint64_t *d_carry = c->d_scal + 5;                      /* last flat value of the previous chunk */
+    if (want_dir) {
+        HIPCHK(hipMalloc((void **)&ix->d_dir, ((size_t)nbk + 1) * 4));
+        HIPCHK(hipMalloc((void **)&ix->d_dirbase, ((size_t)n_groups + 2) * 8));
+        HIPCHK(hipMemsetAsync(d_flags, 0, 8, st));
+    }
+    const int fd_d = open((d + "/diffIdx").c_str(), O_RDONLY), fd_i = open((d + "/info").c_str(), O_RDONLY);
+    struct Files { int a, b; ~Files() { if (a >= 0) close(a); if (b >= 0) close(b); } } files{fd_d, fd_i};
+    if (fd_d < 0 || fd_i < 0) return fail(MTB_ERR_IO, "cannot open diffIdx / info in " + d);
+    const uint64_t chunk_words = std::min<uint64_t>(CH, std::max<uint64_t>(P.n16, 1));
+    const uint64_t info_cap = std::min<uint64_t>(chunk_words + 8, P.T + 1);      /* metamers of a chunk <= its words */
+    struct Pinned { void *p[3] = {nullptr, nullptr, nullptr}; ~Pinned() { for (void *q : p) if (q) { hipError_t e = hipHostFree(q); (void)e; } } } pin;
+    if (hipHostMalloc(&pin.p[0], (chunk_words + 8) * 2, hipHostMallocDefault) != hipSuccess || hipHostMalloc(&pin.p[1], (chunk_words + 8) * 2, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc(&pin.p[2], info_cap * 4, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return fail(MTB_ERR_OOM, "no pinned host memory for the index upload"); }
+    uint16_t *d_chunk; uint32_t *d_tc; uint64_t *d_toff, *d_ws; uint32_t *d_ichunk = nullptr;
+    const uint64_t max_tiles = (chunk_words + 8 + 2047) / 2048 + 1;
+    STCHK(ensure(c, "diffraw", chunk_words + 8, &d_chunk)); STCHK(ensure(c, "difftc", max_tiles, &d_tc)); STCHK(ensure(c, "difftoff", max_tiles + 1, &d_toff));
+    STCHK(ensure(c, "scanws", scan_ws_elems(std::max<uint64_t>(max_tiles + 1, info_cap + 1)), &d_ws));
+    if (pack) STCHK(ensure(c, "infochunk", info_cap, &d_ichunk));
+    { const uint64_t c0 = P.lead ? P.first_value : 0; STCHK(h2d(c, d_carry, &c0, 8)); }
+    if (P.lead) {
+        /* a range that starts at a split checkpoint: its first metamer is given by the checkpoint, not coded in the byte range -- a chunk
+         * of one entry (value, info entry, directory rows, packing) */
+        STCHK(h2d(c, ix->d_values, &P.first_value, 8));
+        if (!pread_parallel(fd_i, pin.p[2], P.info_off * 4, 4, 1)) return fail(MTB_ERR_IO, "short read from " + d + "/info");
+        STCHK(h2d(c, pack ? d_ichunk : ix->d_info, pin.p[2], 4));
+        if (want_dir) {
+            hipLaunchKernelGGL(k_dir_chunk_base, dim3(1), dim3(256), 0, st, (const uint64_t *)ix->d_values, (uint64_t)0, (uint64_t)1, (const uint64_t *)d_carry, L, fmt, nbk, ix->d_dirbase, d_flags);
+            hipLaunchKernelGGL(k_dir_chunk_fill, dim3(1), dim3(256), 0, st, (const uint64_t *)ix->d_values, (uint64_t)0, (uint64_t)1, (const uint64_t *)d_carry, L, fmt, nbk,
+                               (const uint64_t *)ix->d_dirbase, ix->d_dir, d_flags);
+        }
+        if (pack) hipLaunchKernelGGL(k_index_pack_chunk, dim3(1), dim3(256), 0, st, ix->d_values, (const uint32_t *)d_ichunk, (uint64_t)0, (uint64_t)1, fmt);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    ix->open_chunk_words = chunk_words;
+    uint64_t done_words = 0, g = P.lead, found = 0;       /* g: next free place in value[] */
+    uint16_t carry_w[8]; uint32_t n_carry = 0;
+    /* the first chunk is read here, every further one by a helper thread while the device works on its predecessor */
+    uint64_t cur_new = std::min<uint64_t>(chunk_words, P.n16);
+    if (cur_new && !pread_parallel(fd_d, pin.p[0], (P.diff_off + done_words) * 2, cur_new * 2, 16)) return fail(MTB_ERR_IO, "short read from " + d + "/diffIdx");
+    int cur = 0;
+    while (done_words < P.n16) {
+        const uint64_t next_off = done_words + cur_new, next_new = std::min<uint64_t>(chunk_words, P.n16 - next_off);
+        bool next_ok = true;
+        std::thread reader;
+        if (next_new) reader = std::thread([&, next_off, next_new] { next_ok = pread_parallel(fd_d, pin.p[cur ^ 1], (P.diff_off + next_off) * 2, next_new * 2, 16); });
+        struct Join { std::thread &t; ~Join() { if (t.joinable()) t.join(); } } join_reader{reader};
+        const uint16_t *hw = (const uint16_t *)pin.p[cur];
+        /* words of a metamer cut by this chunk's end stay for the next one */
+        uint32_t tail = 0;
+        while (tail < 5 && tail < cur_new && !(hw[cur_new - 1 - tail] & 0x8000u)) tail++;
+        if (tail == cur_new && cur_new < 5) { /* (a chunk of fewer than five words without a terminator: all of it is carried) */ }
+        if (tail >= 5 || (next_new == 0 && tail != 0)) return fail(MTB_ERR_IO, "diffIdx is corrupt: a metamer without its terminator word");
+        const uint64_t use_new = cur_new - tail, n_use = n_carry + use_new;
+        if (n_carry) HIPCHK(hipMemcpyAsync(d_chunk, carry_w, n_carry * 2, hipMemcpyHostToDevice, st));
+        if (use_new) HIPCHK(hipMemcpyAsync(d_chunk + n_carry, hw, use_new * 2, hipMemcpyHostToDevice, st));
+        uint64_t n_k = 0;
+        if (n_use) {
+            const uint64_t tiles = (n_use + 2047) / 2048;
+            hipLaunchKernelGGL(k_diff_tile_count, dim3((uint32_t)tiles), dim3(256), 0, st, (const uint16_t *)d_chunk, n_use, d_tc);
+            scan_launch<uint32_t, uint64_t, false>(st, d_tc, tiles, true, d_toff, d_ws);
+            STCHK(d2h(c, &n_k, d_toff + tiles, 8));
+            if (found + n_k > P.expect) return fail(MTB_ERR_IO, "diffIdx holds more metamers than info and split announce (" + std::to_string(P.expect) + ")");
+            if (n_k) {
+                const uint64_t m = std::min<uint64_t>(g + n_k, P.T) - std::min<uint64_t>(g, P.T);       /* entries of the chunk that belong to the index (a dropped last one does not) */
+                /* info entries of the chunk: into the chunk buffer (pack) or straight to their places */
+                if (m) {
+                    if (!pread_parallel(fd_i, pin.p[2], (P.info_off + g) * 4, m * 4, 16)) return fail(MTB_ERR_IO, "short read from " + d + "/info");
+                    HIPCHK(hipMemcpyAsync(pack ? d_ichunk : ix->d_info + g, pin.p[2], m * 4, hipMemcpyHostToDevice, st));
+                }
+                hipLaunchKernelGGL(k_diff_assemble, dim3((uint32_t)tiles), dim3(256), 0, st, (const uint16_t *)d_chunk, n_use, (const uint64_t *)d_toff, ix->d_values + g);
+                hipLaunchKernelGGL(k_diff_add_carry, dim3(1), dim3(1), 0, st, ix->d_values + g, (const uint64_t *)d_carry);
+                scan_launch<uint64_t, uint64_t, true>(st, ix->d_values + g, n_k, false, ix->d_values + g, d_ws);
+                if (want_dir && m) {
+                    const dim3 grid((uint32_t)std::min<uint64_t>((m + 255) / 256, 1u << 16));
+                    hipLaunchKernelGGL(k_dir_chunk_base, grid, dim3(256), 0, st, (const uint64_t *)ix->d_values, g, m, (const uint64_t *)d_carry, L, fmt, nbk, ix->d_dirbase, d_flags);
+                    hipLaunchKernelGGL(k_dir_chunk_fill, grid, dim3(256), 0, st, (const uint64_t *)ix->d_values, g, m, (const uint64_t *)d_carry, L, fmt, nbk,
+                                       (const uint64_t *)ix->d_dirbase, ix->d_dir, d_flags);
+                }
+                hipLaunchKernelGGL(k_save_last, dim3(1), dim3(1), 0, st, (const uint64_t *)(ix->d_values + g + n_k - 1), d_carry);
+                if (pack && m) hipLaunchKernelGGL(k_index_pack_chunk, dim3((uint32_t)std::min<uint64_t>((m + 255) / 256, 1u << 16)), dim3(256), 0, st, ix->d_values, (const uint32_t *)d_ichunk, g, m, fmt);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipStreamSynchronize(st));          /* the pinned buffers are refilled next */
+                g += n_k; found += n_k;
+                { size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) == hipSuccess && ix->open_free0 > fr) ix->open_peak_bytes = std::max<uint64_t>(ix->open_peak_bytes, ix->open_free0 - fr); }
+                ix->open_chunks++;
+            }
+        }
+        for (uint32_t k = 0; k < tail; k++) carry_w[k] = hw[cur_new - tail + k];
+        if (n_use == 0 && n_carry) { /* nothing decodable yet: keep the old carry in front (cannot happen: a carry is < 5 words and a metamer ends within 5) */
+            return fail(MTB_ERR_IO, "diffIdx is corrupt: a metamer of more than five words"); }
+        n_carry = tail;
+        if (reader.joinable()) reader.join();
+        if (!next_ok) return fail(MTB_ERR_IO, "short read from " + d + "/diffIdx");
+        done_words = next_off; cur_new = next_new; cur ^= 1;
+    }
+    if (found != P.expect)    /* validateDatabase.cpp:17-142: #terminators must equal #info entries */
+        return fail(MTB_ERR_IO, "diffIdx holds " + std::to_string(found) + " metamers where info and split announce " + std::to_string(P.expect));
+    if (want_dir) {
+        /* (*d_carry = the last decoded value; with a dropped last entry the index's own last flat value is one before it: re-read it) */
+        if (P.T && g > P.T) {
+            if (pack) return fail(MTB_ERR_UNSUPPORTED, "pack on load of a range whose last coded metamer is dropped");       /* (never chosen: see open_impl) */
+            hipLaunchKernelGGL(k_save_last, dim3(1), dim3(1), 0, st, (const uint64_t *)(ix->d_values + P.T - 1), d_carry);
+        }
+        hipLaunchKernelGGL(k_dir_finish, dim3(64), dim3(256), 0, st, (const uint64_t *)d_carry, P.T, L, fmt, nbk, n_groups, ix->d_dirbase, ix->d_dir, d_flags, 0);
+        hipLaunchKernelGGL(k_dir_finish, dim3(4096), dim3(256), 0, st, (const uint64_t *)d_carry, P.T, L, fmt, nbk, n_groups, ix->d_dirbase, ix->d_dir, d_flags, 1);
+        HIPCHK(hipGetLastError());
+        uint32_t fl[2] = {0, 0};
+        STCHK(d2h(c, fl, d_flags, 8));
+        if (fl[0] || fl[1]) { hipError_t e = hipFree(ix->d_dir); e = hipFree(ix->d_dirbase); (void)e; ix->d_dir = nullptr; ix->d_dirbase = nullptr; }
+        else { ix->dir_L = L; ix->dir_buckets = nbk; *dir_ok = true; }
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    return MTB_OK;
 }
 
 static mtb_status open_impl(mtb_ctx *c, const char *dbdir, const char *taxonomy_dir, mtb_params *params, uint32_t part, uint32_t n_parts, mtb_index **out) {
@@ -1068,6 +1230,8 @@ static mtb_status open_impl(mtb_ctx *c, const char *dbdir, const char *taxonomy_
     STCHK(plan_parts(d, n_parts, &plan));
     const PartPlan::P &P = plan.parts[part];
     mtb_index *ix = new mtb_index();
+    /* every early return below hands the index (and what it holds on the device) back */
+    struct Guard { mtb_index *ix; ~Guard() { if (ix) mtb_index_close(ix); } } guard{ix};
     ix->ctx = c; ix->params = *params; ix->own = true;
     for (uint32_t q = part + 1; q < n_parts; q++) if (!plan.parts[q].empty) ix->match_last = true;
     std::string err;
@@ -1076,48 +1240,58 @@ static mtb_status open_impl(mtb_ctx *c, const char *dbdir, const char *taxonomy_
         tax_ok = mtbhost::load_taxonomy_db(d + "/taxonomyDB", &ix->tax, &err);
         if (!tax_ok) {
             const std::string fb = d + "/taxonomy";
-            if (!mtbhost::file_exists(fb + "/nodes.dmp")) { delete ix; return fail(MTB_ERR_IO, err); }
+            if (!mtbhost::file_exists(fb + "/nodes.dmp")) return fail(MTB_ERR_IO, err);
             taxdir = fb; err.clear();
         }
     }
-    if (!tax_ok && !mtbhost::load_taxonomy(taxdir, &ix->tax, &err)) { delete ix; return fail(MTB_ERR_IO, err); }
+    if (!tax_ok && !mtbhost::load_taxonomy(taxdir, &ix->tax, &err)) return fail(MTB_ERR_IO, err);
     std::vector<int32_t> ids;
-    if (!mtbhost::read_taxid_list(d + "/taxID_list", &ids)) { delete ix; return fail(MTB_ERR_IO, "cannot open " + d + "/taxID_list"); }
+    if (!mtbhost::read_taxid_list(d + "/taxID_list", &ids)) return fail(MTB_ERR_IO, "cannot open " + d + "/taxID_list");
     mtbhost::build_tax2species(&ix->tax, ids.data(), ids.size());
     ix->info_mask = ~((uint32_t)(params->skip_redundancy == 0) << 31);   /* KmerMatcher.cpp:204-205 */
-    mtb_status st = upload_taxonomy(ix);
-    if (st != MTB_OK) { mtb_index_close(ix); return st; }
-    if (P.empty) { ix->T = 0; *out = ix; return MTB_OK; }
-    /* only this partition's byte ranges are read from the files, streamed through two pinned 64 MiB buffers straight into HBM
-     * (fread of chunk k+1 overlaps the H2D copy of chunk k): no whole-file copy in host memory, whatever the database size */
-    const uint64_t n16 = P.diff_hi - P.diff_lo, T = P.info_hi - P.info_lo;
-    const uint64_t expect = T - (P.explicit_first ? 1 : 0) + (P.drop_last ? 1 : 0);     /* metamers coded in the byte range */
-    /* decode on the GPU: terminators per tile -> offsets -> deltas -> inclusive scan */
-    uint16_t *d_diff; uint32_t *d_tc; uint64_t *d_toff; uint64_t *d_ws;
-    uint64_t tiles = std::max<uint64_t>((n16 + 2047) / 2048, 1);
-    if ((st = ensure(c, "diffraw", n16 + 1, &d_diff)) != MTB_OK || (st = ensure(c, "difftc", tiles, &d_tc)) != MTB_OK ||
-        (st = ensure(c, "difftoff", tiles + 1, &d_toff)) != MTB_OK ||
-        (st = ensure(c, "scanws", scan_ws_elems(std::max<uint64_t>(tiles + 1, T + 1)), &d_ws)) != MTB_OK) { mtb_index_close(ix); return st; }
-    HIPCHK(hipMalloc((void **)&ix->d_values, (T + 1) * 8)); HIPCHK(hipMalloc((void **)&ix->d_info, T * 4));
-    if ((st = stream_file_to_device(c, d + "/diffIdx", P.diff_lo * 2, n16 * 2, d_diff)) != MTB_OK ||
-        (st = stream_file_to_device(c, d + "/info", P.info_lo * 4, T * 4, ix->d_info)) != MTB_OK) { mtb_index_close(ix); return st; }
-    hipLaunchKernelGGL(k_diff_tile_count, dim3((uint32_t)tiles), dim3(256), 0, c->stream, (const uint16_t *)d_diff, n16, d_tc);
-    scan_launch<uint32_t, uint64_t, false>(c->stream, d_tc, tiles, true, d_toff, d_ws);
-    uint64_t found = 0;
-    if ((st = d2h(c, &found, d_toff + tiles, 8)) != MTB_OK) { mtb_index_close(ix); return st; }
-    if (found != expect) {   /* validateDatabase.cpp:17-142: #terminators must equal #info entries */
-        mtb_index_close(ix);
-        return fail(MTB_ERR_IO, "diffIdx holds " + std::to_string(found) + " metamers where info and split announce " + std::to_string(expect));
+    STCHK(upload_taxonomy(ix));
+    if (P.empty) { ix->T = 0; guard.ix = nullptr; *out = ix; return MTB_OK; }
+    /* only this partition's byte ranges are read from the files, chunk by chunk through pinned buffers straight into HBM (the next
+     * chunk is read while the device decodes the current one): no whole-file copy in host OR device memory, whatever the database size */
+    OpenPlan O;
+    O.n16 = P.diff_hi - P.diff_lo; O.T = P.info_hi - P.info_lo; O.lead = P.explicit_first ? 1 : 0;
+    O.expect = O.T - O.lead + (P.drop_last ? 1 : 0);     /* metamers coded in the byte range */
+    O.diff_off = P.diff_lo; O.info_off = P.info_lo; O.first_value = P.ad;
+    const uint64_t T = O.T;
+    /* the directory this index will have (build_directory's rule), decided before the load so that it is built chunk by chunk */
+    int L = 1;
+    while (L < 7 && (uint64_t)mtb_pow21(L) < T / 8) L++;
+    if (getenv("MTB_DIR_DEPTH")) L = std::max(1, std::min(7, atoi(getenv("MTB_DIR_DEPTH"))));
+    bool want_dir = T >= 2 && !getenv("MTB_NO_DIR");
+    if (want_dir) {
+        size_t fr = 0, tot = 0;
+        HIPCHK(hipMemGetInfo(&fr, &tot));
+        const uint32_t nbk = mtb_pow21(L);
+        if (((size_t)nbk + 1) * 4 + ((size_t)(nbk >> 16) + 3) * 8 + (T + 1) * 8 + (64u << 20) > fr) want_dir = false;        /* no room next to the values: the bisection join still works */
     }
-    const uint64_t lead = P.explicit_first ? 1 : 0;
-    if (lead && (st = h2d(c, ix->d_values, &P.ad, 8)) != MTB_OK) { mtb_index_close(ix); return st; }
-    hipLaunchKernelGGL(k_diff_assemble, dim3((uint32_t)tiles), dim3(256), 0, c->stream, (const uint16_t *)d_diff, n16, (const uint64_t *)d_toff, ix->d_values + lead);
-    scan_launch<uint64_t, uint64_t, true>(c->stream, ix->d_values, found + lead, false, ix->d_values, d_ws);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(c->stream));
-    release(c, "diffraw"); release(c, "difftc"); release(c, "difftoff");
+    /* pack on load: big databases (>= 2^28 targets; MTB_OPEN_PACKED=1 / 0 forces it on toy databases / off) whose directory has depth 7
+     * open in the SEALED state -- packed 8-byte words, info[] never resident (mtb_index_seal's state; everything that needs the flat
+     * arrays unpacks on demand as for any sealed index) */
+    const char *env_pack = getenv("MTB_OPEN_PACKED");
+    bool pack = want_dir && L == 7 && !P.drop_last && !getenv("MTB_NO_PACK") && (env_pack ? atoi(env_pack) != 0 : T >= (1ull << 28));
+    { size_t fr = 0, tot = 0; HIPCHK(hipMemGetInfo(&fr, &tot)); ix->open_free0 = fr; }
+    for (int attempt = 0; attempt < 2; attempt++) {
+        ix->open_chunks = 0; ix->open_peak_bytes = 0;
+        HIPCHK(hipMalloc((void **)&ix->d_values, (T + 1) * 8));
+        if (!pack) HIPCHK(hipMalloc((void **)&ix->d_info, std::max<uint64_t>(T, 1) * 4));
+        bool dir_ok = false;
+        STCHK(decode_chunked(c, ix, d, O, want_dir, L, pack, &dir_ok));
+        release(c, "diffraw"); release(c, "difftc"); release(c, "difftoff"); release(c, "infochunk");
+        if (pack && !dir_ok) {      /* a letter >= 21 or a bucket group of 2^32 targets: no directory, hence no packed state -- once more, flat */
+            hipError_t e = hipFree(ix->d_values); (void)e; ix->d_values = nullptr;
+            pack = false;
+            continue;
+        }
+        if (pack) ix->packed = true;
+        break;
+    }
     ix->T = T;
-    if ((st = build_directory(c, ix)) != MTB_OK) { mtb_index_close(ix); return st; }
+    guard.ix = nullptr;
     *out = ix;
     return MTB_OK;
 }
@@ -1195,6 +1369,11 @@ void mtb_index_close(mtb_index *ix) {
     delete ix;
 }
 uint64_t mtb_index_num_targets(const mtb_index *ix) { return ix ? ix->T : 0; }
+mtb_status mtb_index_open_stats(const mtb_index *ix, uint64_t *out4) {
+    if (!ix || !out4) return fail(MTB_ERR_ARG, "NULL argument");
+    out4[0] = ix->open_chunks; out4[1] = ix->open_chunk_words; out4[2] = ix->open_peak_bytes; out4[3] = (ix->packed && !ix->d_info) ? 1 : 0;
+    return MTB_OK;
+}
 mtb_status mtb_index_state(const mtb_index *ix, int32_t *dir_depth, int32_t *packed, int32_t *sealed) {
     if (!ix) return fail(MTB_ERR_ARG, "NULL index");
     const mtb_index *o = ix->parent ? ix->parent : ix;
@@ -1229,55 +1408,101 @@ mtb_status mtb_index_download(mtb_index *ix, uint64_t *values, uint32_t *info, u
     return MTB_OK;
 }
 /* IndexCreator::writeTargetFilesAndSplits + writeDbParameters (IndexCreator.cpp:817-892, 1251-1272) and the
- * taxID_list dump (:329-333) for an index that is resident on the device -- e.g. a synthetic one.  The metamers are
- * streamed to the host in slices; the delta coder and the split rule are sequential by nature. */
-mtb_status mtb_index_write(const mtb_index *ix, const char *dbdir, int split_num) {
-    if (!ix || !dbdir || split_num < 2) return fail(MTB_ERR_ARG, "NULL argument / split_num < 2");
+ * taxID_list dump (:329-333) for an index that is resident on the device -- e.g. a synthetic one.  The delta coder runs on the
+ * device, a slice of targets at a time (words per entry -> exclusive scan -> every entry writes its 15-bit groups at its offset), the
+ * coded slice and its info entries cross PCIe into pinned buffers and a writer thread appends them to the files while the next slice
+ * is coded; the split checkpoints -- armed at every size_of_split-th entry, recorded at the first later entry of another amino-acid
+ * part -- are located by one small kernel up front and get their word offsets from the slice that holds them. */
+mtb_status mtb_index_write(const mtb_index *cix, const char *dbdir, int split_num) {
+    if (!cix || !dbdir || split_num < 2) return fail(MTB_ERR_ARG, "NULL argument / split_num < 2");
+    mtb_index *ix = const_cast<mtb_index *>(cix);
     mtb_ctx *c = ix->ctx;
     HIPCHK(hipSetDevice(c->device));
-    STCHK(ensure_flat(const_cast<mtb_index *>(ix)));
+    STCHK(ensure_flat(ix));
+    hipStream_t st = c->stream;
     const std::string d(dbdir);
     FILE *fd = fopen((d + "/diffIdx").c_str(), "wb"), *fi = fopen((d + "/info").c_str(), "wb");
-    if (!fd || !fi) { if (fd) fclose(fd); if (fi) fclose(fi); return fail(MTB_ERR_IO, "cannot create diffIdx/info in " + d); }
+    struct Files { FILE *a, *b; ~Files() { if (a) fclose(a); if (b) fclose(b); } } files{fd, fi};
+    if (!fd || !fi) return fail(MTB_ERR_IO, "cannot create diffIdx/info in " + d);
     struct Split { uint64_t ad, diff_off, info_off; };
     std::vector<Split> splits((size_t)split_num, Split{0, 0, 0});
-    const uint64_t n = ix->T, AAMASK = ~0xFFFFFFull;
+    const uint64_t n = ix->T;
     const uint64_t size_of_split = n / (uint64_t)(split_num - 1);
-    uint64_t next_off = size_of_split;                 /* offsetList[1], [2], ... = k * sizeOfSplit */
-    int split_idx = 1; bool armed = false; uint64_t aa_of_temp = UINT64_MAX;
-    std::vector<uint8_t> seen((size_t)ix->tax.max_id + 2, 0);
-    std::vector<int32_t> extra_ids;                    /* ids outside the taxonomy's range (kept for taxID_list) */
-    const uint64_t SLICE = 1ull << 24;
-    std::vector<uint64_t> hv(std::min<uint64_t>(SLICE, std::max<uint64_t>(n, 1))); std::vector<uint32_t> hi(hv.size());
-    std::vector<uint16_t> enc; enc.reserve(hv.size() * 3);
-    uint64_t last = 0, diff_count = 0;
-    bool ok = true;
-    for (uint64_t s0 = 0; s0 < n && ok; s0 += SLICE) {
-        const uint64_t m = std::min<uint64_t>(SLICE, n - s0);
-        if (hipMemcpy(hv.data(), ix->d_values + s0, m * 8, hipMemcpyDeviceToHost) != hipSuccess ||
-            hipMemcpy(hi.data(), ix->d_info + s0, m * 4, hipMemcpyDeviceToHost) != hipSuccess) { ok = false; break; }
-        enc.clear();
-        for (uint64_t j = 0; j < m; j++) {
-            const uint64_t v = hv[j];
-            uint64_t dlt = v - last; uint16_t buf[5]; int idx = 3;      /* getDiffIdx: big-endian 15-bit groups, last one flagged */
-            buf[4] = (uint16_t)(0x8000u | (dlt & 0x7FFFu)); dlt >>= 15;
-            while (dlt) { buf[idx--] = (uint16_t)(dlt & 0x7FFFu); dlt >>= 15; }
-            for (int q = idx + 1; q <= 4; q++) enc.push_back(buf[q]);
-            last = v;
-            const uint64_t info_cnt = s0 + j + 1;
-            if ((last & AAMASK) != aa_of_temp && armed) {
-                if (split_idx < split_num) splits[(size_t)split_idx++] = Split{last, diff_count + enc.size(), info_cnt};
-                armed = false;
-            }
-            if (size_of_split && info_cnt == next_off) { aa_of_temp = last & AAMASK; armed = true; next_off += size_of_split; }
-            const int32_t t = (int32_t)(hi[j] & 0x7FFFFFFFu);
-            if (t >= 0 && (size_t)t < seen.size()) seen[(size_t)t] = 1; else extra_ids.push_back(t);
-        }
-        ok = fwrite(enc.data(), 2, enc.size(), fd) == enc.size() && fwrite(hi.data(), 4, m, fi) == m;
-        diff_count += enc.size();
+    /* where the checkpoints fall: j[k] for every arming position k * size_of_split; equal neighbours are one checkpoint (an arming
+     * inside a run that is still armed changes nothing); at most split_num - 1 are kept */
+    std::vector<uint64_t> cps;
+    if (size_of_split && n) {
+        const uint64_t n_k64 = n / size_of_split;
+        const uint32_t n_k = (uint32_t)std::min<uint64_t>(n_k64, 1u << 24);
+        uint64_t *d_j;
+        STCHK(ensure(c, "wsplitj", n_k, &d_j));
+        hipLaunchKernelGGL(k_split_find, dim3((n_k + 255) / 256), dim3(256), 0, st, (const uint64_t *)ix->d_values, n, size_of_split, n_k, d_j);
+        HIPCHK(hipGetLastError());
+        std::vector<uint64_t> hj(n_k);
+        STCHK(d2h(c, hj.data(), d_j, (size_t)n_k * 8));
+        for (uint32_t k = 0; k < n_k && cps.size() + 1 < (size_t)split_num; k++) if (hj[k] < n && (cps.empty() || cps.back() != hj[k])) cps.push_back(hj[k]);
+        release(c, "wsplitj");
     }
-    fclose(fd); fclose(fi);
-    if (!ok) return fail(MTB_ERR_IO, "short write / device copy failed while writing " + d);
+    const uint64_t SLICE = std::min<uint64_t>(1ull << 25, std::max<uint64_t>(n, 1));
+    uint32_t *d_nw; uint64_t *d_off, *d_ws; uint16_t *d_enc; uint8_t *d_seen; int32_t *d_extra; uint32_t *d_nextra; uint64_t *d_cpj, *d_cpv, *d_cpo;
+    const uint32_t EXTRA_CAP = 1u << 20;
+    STCHK(ensure(c, "wnw", SLICE, &d_nw)); STCHK(ensure(c, "woff", SLICE + 1, &d_off)); STCHK(ensure(c, "scanws", scan_ws_elems(SLICE + 1), &d_ws));
+    STCHK(ensure(c, "wenc", SLICE * 5, &d_enc)); STCHK(ensure(c, "wseen", (size_t)ix->tax.max_id + 2, &d_seen));
+    STCHK(ensure(c, "wextra", EXTRA_CAP + 1, &d_extra)); d_nextra = (uint32_t *)(d_extra + EXTRA_CAP);
+    STCHK(ensure(c, "wcp", 3 * (cps.size() + 1), &d_cpj)); d_cpv = d_cpj + cps.size() + 1; d_cpo = d_cpv + cps.size() + 1;
+    HIPCHK(hipMemsetAsync(d_seen, 0, (size_t)ix->tax.max_id + 2, st)); HIPCHK(hipMemsetAsync(d_nextra, 0, 4, st));
+    if (!cps.empty()) STCHK(h2d(c, d_cpj, cps.data(), cps.size() * 8));
+    struct Pinned { void *e[2] = {nullptr, nullptr}, *i[2] = {nullptr, nullptr}; ~Pinned() { for (int k = 0; k < 2; k++) { if (e[k]) { hipError_t x = hipHostFree(e[k]); (void)x; } if (i[k]) { hipError_t x = hipHostFree(i[k]); (void)x; } } } } pin;
+    for (int k = 0; k < 2; k++)
+        if (hipHostMalloc(&pin.e[k], SLICE * 10, hipHostMallocDefault) != hipSuccess || hipHostMalloc(&pin.i[k], SLICE * 4, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError(); return fail(MTB_ERR_OOM, "no pinned host memory for the index download"); }
+    std::thread writers[2]; bool write_ok = true;         /* writers[k]: appends the slice that sits in buffer pair k; one at a time, in slice order */
+    struct Join { std::thread *t; ~Join() { for (int k = 0; k < 2; k++) if (t[k].joinable()) t[k].join(); } } join_writers{writers};
+    uint64_t diff_count = 0; size_t cp_at = 0; int cur = 0;
+    std::vector<uint64_t> cpv, cpo;
+    for (uint64_t s0 = 0; s0 < n; s0 += SLICE, cur ^= 1) {
+        const uint64_t m = std::min<uint64_t>(SLICE, n - s0);
+        const dim3 grid((uint32_t)((m + 255) / 256));
+        hipLaunchKernelGGL(k_diff_nwords, grid, dim3(256), 0, st, (const uint64_t *)ix->d_values, s0, m, d_nw);
+        scan_launch<uint32_t, uint64_t, false>(st, d_nw, m, true, d_off, d_ws);
+        hipLaunchKernelGGL(k_diff_encode, grid, dim3(256), 0, st, (const uint64_t *)ix->d_values, s0, m, (const uint64_t *)d_off, d_enc);
+        hipLaunchKernelGGL(k_mark_taxids, grid, dim3(256), 0, st, (const uint32_t *)ix->d_info, s0, m, d_seen, ix->tax.max_id, d_extra, EXTRA_CAP, d_nextra);
+        HIPCHK(hipGetLastError());
+        uint64_t words = 0;
+        STCHK(d2h(c, &words, d_off + m, 8));
+        /* checkpoints inside this slice: value and word offset behind the entry */
+        size_t cp_hi = cp_at;
+        while (cp_hi < cps.size() && cps[cp_hi] < s0 + m) cp_hi++;
+        if (cp_hi > cp_at) {
+            const uint32_t q = (uint32_t)(cp_hi - cp_at);
+            hipLaunchKernelGGL(k_split_gather, dim3((q + 63) / 64), dim3(64), 0, st, (const uint64_t *)ix->d_values, (const uint64_t *)d_off, s0, (const uint64_t *)(d_cpj + cp_at), q, d_cpv, d_cpo);
+            HIPCHK(hipGetLastError());
+            cpv.resize(q); cpo.resize(q);
+            STCHK(d2h(c, cpv.data(), d_cpv, (size_t)q * 8)); STCHK(d2h(c, cpo.data(), d_cpo, (size_t)q * 8));
+            for (uint32_t t = 0; t < q; t++) splits[cp_at + t + 1] = Split{cpv[t], diff_count + cpo[t], cps[cp_at + t] + 1};
+            cp_at = cp_hi;
+        }
+        if (writers[cur].joinable()) writers[cur].join();  /* (two slices back: its buffers are `cur`'s) */
+        if (!write_ok) return fail(MTB_ERR_IO, "short write while writing " + d);
+        HIPCHK(hipMemcpyAsync(pin.e[cur], d_enc, words * 2, hipMemcpyDeviceToHost, st));          /* while the previous slice is being written from the other pair */
+        HIPCHK(hipMemcpyAsync(pin.i[cur], ix->d_info + s0, m * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (writers[cur ^ 1].joinable()) writers[cur ^ 1].join();          /* file order */
+        if (!write_ok) return fail(MTB_ERR_IO, "short write while writing " + d);
+        const void *pe = pin.e[cur], *pi = pin.i[cur];
+        writers[cur] = std::thread([&write_ok, fd, fi, pe, pi, words, m] { if (!(fwrite(pe, 2, words, fd) == words && fwrite(pi, 4, m, fi) == m)) write_ok = false; });
+        diff_count += words;
+    }
+    for (int k = 0; k < 2; k++) if (writers[k].joinable()) writers[k].join();
+    if (!write_ok) return fail(MTB_ERR_IO, "short write while writing " + d);
+    std::vector<uint8_t> seen((size_t)ix->tax.max_id + 2, 0);
+    STCHK(d2h(c, seen.data(), d_seen, seen.size()));
+    uint32_t n_extra = 0;
+    STCHK(d2h(c, &n_extra, d_nextra, 4));
+    if (n_extra > EXTRA_CAP) return fail(MTB_ERR_UNSUPPORTED, "more than 2^20 info entries outside the taxonomy's id range");
+    std::vector<int32_t> extra_ids(n_extra);           /* ids outside the taxonomy's range (kept for taxID_list) */
+    if (n_extra) STCHK(d2h(c, extra_ids.data(), d_extra, (size_t)n_extra * 4));
+    release(c, "wnw"); release(c, "woff"); release(c, "wenc"); release(c, "wseen"); release(c, "wextra"); release(c, "wcp");
     FILE *f = fopen((d + "/split").c_str(), "wb"); if (!f) return fail(MTB_ERR_IO, "cannot create " + d + "/split");
     fwrite(splits.data(), sizeof(Split), splits.size(), f); fclose(f);
     std::sort(extra_ids.begin(), extra_ids.end()); extra_ids.erase(std::unique(extra_ids.begin(), extra_ids.end()), extra_ids.end());

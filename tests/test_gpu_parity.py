@@ -522,6 +522,79 @@ def test_index_write_reproduces_the_database_files(ctx, toy, tmp_path):
     ix2.close()
 
 
+@pytest.mark.parametrize("chunk", [16, 37, 4096])
+@pytest.mark.parametrize("packed", [False, True])
+def test_database_opens_chunk_by_chunk(orc, tmp_path, monkeypatch, chunk, packed):
+    """mtb_index_open decodes the diffIdx stream in chunks (here: 16 / 37 / 4096 sixteen-bit words, so that metamers of 1-5 words
+    are cut by chunk ends in every way): carried words, the running value, the directory rows built per chunk, and -- packed --
+    the info entries folded into packed words chunk by chunk (the index opens sealed).  The arrays download as the database's, the
+    batch classifies as the oracle says; the same for value ranges opened through the split checkpoints."""
+    import metabuli_amd as M
+    from conftest import Toy
+    toy = Toy(orc, tmp_path / "db", syncmer=1, paired=False, seed=31, n_reads=120, genome_len=4000)       # ~40 k targets: thousands of tiny chunks
+    monkeypatch.setenv("MTB_OPEN_CHUNK", str(chunk))
+    if packed:
+        monkeypatch.setenv("MTB_DIR_DEPTH", "7"); monkeypatch.setenv("MTB_OPEN_PACKED", "1")
+    c = M.Context(0)
+    p = _params(toy)
+    ix = c.open_index(toy.dbdir, p)
+    st = ix.open_stats()
+    assert st["chunk_words"] == chunk and st["chunks"] >= len(toy.values) * 1 // chunk and st["packed_on_load"] == packed
+    if packed:
+        assert ix.state() == dict(dir_depth=7, packed=True, sealed=True)
+    res, tt, tc = c.classify_batch(ix, p, toy.b1, toy.o1, toy.b2, toy.o2)
+    _check_results(toy, res, tt, tc)
+    v, info = ix.download()
+    assert (v == toy.values).all() and (info.astype(np.int32) == toy.taxids).all()
+    ix.close()
+    for world in (3,):
+        vs, infos = [], []
+        for r in range(world):
+            pp = _params(toy)
+            part = c.open_index_part(toy.dbdir, pp, r, world)
+            a, b = part.download(); vs.append(a); infos.append(b); part.close()
+        assert (np.concatenate(vs) == toy.values).all() and (np.concatenate(infos).astype(np.int32) == toy.taxids).all()
+    c.close()
+
+
+def test_open_under_a_workspace_limit_smaller_than_the_raw_diffidx(tmp_path):
+    """a 40 M-target synthetic database written by the device-side coder (mtb_index_write), opened with a workspace limit of 1/16
+    of its diffIdx file: the chunked decode keeps the peak at what the index itself holds plus one small chunk (the whole-file
+    decode of round 3 held the raw file, the values, the info entries and scan workspace at once), and the arrays come back equal"""
+    import torch
+    import metabuli_amd as M
+    from metabuli_amd import synth
+    dev = torch.device("cuda:0")
+    c = M.Context(0)
+    w = synth.make_world(seed=3, n_genera=1, species_per_genus=2, strains_per_species=1, genome_len=2000, n_filler_species=500)
+    taxdir = str(tmp_path / "tax"); w.tax.write(taxdir)
+    p = M.default_params(seq_mode=1, syncmer=1)
+    T = 40_000_000
+    dv = torch.empty(T, dtype=torch.int64, device=dev); di = torch.empty(T, dtype=torch.int32, device=dev)
+    n = c.synth_index(7, T, w.filler_tax_lo, w.filler_tax_hi, np.zeros(0, np.uint64), np.zeros(0, np.int32), dv.data_ptr(), di.data_ptr())
+    src = c.index_from_device(dv.data_ptr(), di.data_ptr(), n, taxdir, np.arange(w.filler_tax_lo, w.filler_tax_hi + 1, dtype=np.int32), p)
+    d = tmp_path / "db"; d.mkdir()
+    import shutil
+    shutil.copytree(taxdir, d / "taxonomy")
+    src.write(str(d))
+    raw = os.path.getsize(d / "diffIdx")
+    assert os.path.getsize(d / "info") == 4 * n and raw > 2 * n
+    want_v = dv[:n].cpu().numpy().view(np.uint64); want_i = di[:n].cpu().numpy()
+    src.close(); del dv, di
+    torch.cuda.empty_cache()
+    c2 = M.Context(0)
+    c2.set_workspace_limit(raw // 16)
+    p2 = M.default_params(seq_mode=1, syncmer=1)
+    ix = c2.open_index(str(d), p2)
+    st = ix.open_stats()
+    assert st["chunks"] >= 12 and st["chunk_words"] * 2 <= raw // 16
+    resident = n * 12 + 4 * (21 ** ix.state()["dir_depth"] + 1)
+    assert st["peak_bytes"] < resident + raw // 4, (st, resident, raw)          # far below resident + raw file
+    v, info = ix.download()
+    assert (v == want_v).all() and (info.view(np.int32) == want_i).all()
+    ix.close(); c2.close(); c.close()
+
+
 def test_slot_epoch_wraps_without_stale_matches(toy, orc):
     """the slot segments of the fused path are never cleared between batches: live slots carry a 5-bit epoch tag that
     wraps every 31 batches.  40 batches on one context, alternating two different read sets, must keep giving the
@@ -613,7 +686,8 @@ def test_long_candidate_runs_are_scanned_by_the_wave(orc, tmp_path, seq_mode, de
     monkeypatch.delenv("MTB_DIR_DEPTH", raising=False)
     assert ix.state()["dir_depth"] == (7 if depth7 else ix.state()["dir_depth"]) and ix.state()["dir_depth"] > 0
     res, tt, tc = c.classify_batch(ix, p, t.b1, t.o1, t.b2, t.o2)
-    assert ix.state()["packed"] == depth7
+    if seq_mode != 3:                      # (long reads whose tails overflow twice are redone on exact segments: the flat-state k_join)
+        assert ix.state()["packed"] == depth7
     ro = t.ref["results"]
     amb = ro["flag"] != 0
     assert ((res["classification"] == ro["classification"]) | amb).all()
