@@ -604,8 +604,9 @@ def profiled_step(ctx, M, index, params, step_fn, streams, key, workload_tuple):
                               "the least k_join_dir can fetch for this batch; 12 x T of the contract formula is a streaming-merge figure this kernel never pays")
         rh = ctx.join_run_histogram(index)
         runs = dict(queries_without_candidate=rh["no_candidate"], queries_by_log2_run_length=rh["queries_by_log2"][:16],
-                    candidates_scanned_by_log2_run_length=rh["candidates_by_log2"][:16], quantiles=hist_summary(rh["queries_by_log2"]),
-                    candidates_scanned=int(sum(rh["candidates_by_log2"])),
+                    run_targets_by_log2_run_length=rh["candidates_by_log2"][:16], quantiles=hist_summary(rh["queries_by_log2"]),
+                    run_targets_met=int(sum(rh["candidates_by_log2"])),
+                    queries_with_own_dna_in_a_long_run=rh["exact_queries"], run_targets_not_scanned_for_them=rh["exact_run_targets"],
                     note="length of the candidate run (targets sharing the query's amino-acid part) every query metamer of the step meets; bin b = lengths 2^b .. 2^(b+1)-1")
     except M.MtbError as e:
         log(f"no join footprint / run histogram: {e}")

@@ -168,6 +168,11 @@ mtb_status mtb_index_from_device(mtb_ctx *, uint64_t *d_values, uint32_t *d_info
                                  uint64_t n_targets, const char *taxonomy_dir,
                                  const int32_t *taxid_list, size_t n_taxids,
                                  const mtb_params *params, mtb_index **out);
+/* SURVEY.md 8(e) row 1 ("load once, broadcast over xGMI"): a copy of a resident index on another context's GPU, made with
+ * device-to-device peer copies -- target words in the state they are in (packed / flat), info[] if resident, the directory -- plus
+ * the taxonomy tables; the database files are read and decoded once per node, not once per GPU.  The copy is independent of its
+ * source (own memory, own state).  `src` must not be a view.                                                          */
+mtb_status mtb_index_clone(mtb_index *src, mtb_ctx *dst_ctx, mtb_index **out);
 /* Dedicate an index to the fused path (mtb_classify_batch*): its target array goes to the packed state -- one 8-byte word per
  * target carrying the eighth amino-acid letter, the DNA bits and the info entry under the depth-7 amino-acid directory,
  * kernels_dir.h -- and info[] is let go of: freed if the library owns it, else the caller may free the array it lent
@@ -265,6 +270,13 @@ mtb_status mtb_classify_batch_packed(mtb_ctx *, mtb_index *, const mtb_params *,
                                      const uint32_t *lens, const uint8_t *packed2_mate, const uint8_t *nmask_mate,
                                      const uint32_t *lens_mate, uint64_t n_reads, mtb_result *results, int32_t *taxcnt_tax,
                                      uint32_t *taxcnt_cnt, uint64_t taxcnt_cap, uint64_t *n_taxcnt);
+/* Upload of the NEXT batch while the current one computes: starts the H2D copies of the arrays a following
+ * mtb_classify_batch_packed call will be given (same pointers, same n_reads) on a copy stream of the context, into the second of two
+ * input buffer sets, and returns at once.  Call order per context thread: prefetch(k+1), classify(k), prefetch(k+2), classify(k+1) ...
+ * The arrays must be pinned (mtb_host_alloc) and stay untouched until their classify call returns.  (The reference's producer fills a
+ * batch, then the batch is processed: KmerExtractor.cpp:117-173.)                                                                    */
+mtb_status mtb_prefetch_batch_packed(mtb_ctx *, const mtb_params *, const uint8_t *packed2, const uint8_t *nmask, const uint32_t *lens,
+                                     const uint8_t *packed2_mate, const uint8_t *nmask_mate, const uint32_t *lens_mate, uint64_t n_reads);
 mtb_status mtb_last_batch_stats(mtb_ctx *, mtb_batch_stats *out);
 /* Diagnostic, outside any timed region: the index-side working set of the LAST mtb_classify_batch* call of this context
  * when it took the directory join (short reads, index with a directory): distinct directory buckets its query metamers fall
@@ -280,7 +292,8 @@ mtb_status mtb_ctx_join_footprint(mtb_ctx *, mtb_index *, mtb_join_footprint *ou
  * [32 + b] = targets in them (b = 0..31).
  * mtb_ctx_join_run_histogram: over the query metamers of the LAST mtb_classify_batch* call of the context (same conditions as
  * mtb_ctx_join_footprint): [0] = queries without a candidate, [1 + b] = queries whose run has floor(log2(length)) = b (b = 0..31),
- * [40 + b] = candidates those queries scan (b = 0..23, longer runs in the last bin).                                             */
+ * [40 + b] = targets in those runs (b = 0..23, longer runs in the last bin); [33] / [34] = queries, and the targets of their runs,
+ * that find their own DNA part in a run of more than 8 targets -- the join selects that block by bisection without scanning the run. */
 mtb_status mtb_index_run_histogram(mtb_index *, uint64_t *hist64);
 mtb_status mtb_ctx_join_run_histogram(mtb_ctx *, mtb_index *, uint64_t *hist64);
 

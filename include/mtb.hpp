@@ -74,6 +74,11 @@ public:
         check(mtb_ctx_create(device, nullptr, &ctx));
         check(mtb_index_open_part(ctx, dbDir.c_str(), taxonomyDir.empty() ? nullptr : taxonomyDir.c_str(), &par, part, n_parts, &index));
     }
+    /* a further GPU of the node: the index is copied from an engine that already holds it (peer copies, mtb_index_clone) */
+    Engine(int device, Engine &loaded) {
+        check(mtb_ctx_create(device, nullptr, &ctx));
+        check(mtb_index_clone(loaded.index, ctx, &index));
+    }
     ~Engine() { mtb_index_close(index); mtb_ctx_destroy(ctx); }
     mtb_ctx *ctx = nullptr;
     mtb_index *index = nullptr;

@@ -177,6 +177,12 @@ class Context:
                                    C.byref(params), C.byref(h)))
         return Index(self, h)
 
+    def clone_index(self, src):
+        """a copy of a resident index (of any context) on this context's GPU: peer copies, no file access (mtb_index_clone)"""
+        h = C.c_void_p()
+        _chk(self.L.mtb_index_clone(src.h, self.h, C.byref(h)))
+        return Index(self, h)
+
     def index_from_device(self, d_values, d_info, n_targets, taxonomy_dir, taxid_list, params):
         h = C.c_void_p()
         tl = np.ascontiguousarray(taxid_list, dtype=np.int32)
@@ -366,7 +372,8 @@ class Context:
         dict(no_candidate, queries_by_log2[32], candidates_by_log2[24])"""
         h = np.zeros(64, np.uint64)
         _chk(self.L.mtb_ctx_join_run_histogram(self.h, index.h, _p(h)))
-        return dict(no_candidate=int(h[0]), queries_by_log2=[int(x) for x in h[1:33]], candidates_by_log2=[int(x) for x in h[40:64]])
+        return dict(no_candidate=int(h[0]), queries_by_log2=[int(x) for x in h[1:33]], candidates_by_log2=[int(x) for x in h[40:64]],
+                    exact_queries=int(h[33]), exact_run_targets=int(h[34]))
 
     def last_stats(self):
         s = BatchStats()

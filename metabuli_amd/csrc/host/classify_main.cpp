@@ -77,6 +77,7 @@ public:
     explicit Channel(size_t cap) : cap_(cap) {}
     void put(std::unique_ptr<T> v) { std::unique_lock<std::mutex> l(m_); cv_.wait(l, [&] { return q_.size() < cap_; }); q_.push_back(std::move(v)); cv_.notify_all(); }
     std::unique_ptr<T> get() { std::unique_lock<std::mutex> l(m_); cv_.wait(l, [&] { return !q_.empty(); }); auto v = std::move(q_.front()); q_.erase(q_.begin()); cv_.notify_all(); return v; }
+    std::unique_ptr<T> try_get() { std::unique_lock<std::mutex> l(m_); if (q_.empty()) return nullptr; auto v = std::move(q_.front()); q_.erase(q_.begin()); cv_.notify_all(); return v; }
 private:
     std::mutex m_; std::condition_variable cv_; std::vector<std::unique_ptr<T>> q_; size_t cap_;
 };
@@ -325,30 +326,9 @@ int main(int argc, char **argv) {
         auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         const double t_start = now();
         if (devices.empty()) throw std::runtime_error("--devices: empty list");
-        /* one engine (context + resident copy of the index) per GPU; db.parameters overrides the flags (common.cpp:88-133) */
-        std::vector<std::unique_ptr<mtb::Engine>> engs;
-        std::vector<uint64_t> bounds(devices.size(), 0);
-        if (partitioned) mtb::check(mtb_index_part_bounds(dbdir.c_str(), (uint32_t)devices.size(), bounds.data()));
-        for (size_t d = 0; d < devices.size(); d++) {
-            mtb_params pd = par;
-            /* --partitioned 1: engine d holds range d of the database (SURVEY 8(e) row 2: databases larger than one HBM) */
-            if (partitioned) engs.emplace_back(new mtb::Engine(devices[d], dbdir, taxdir, d == 0 ? par : pd, (uint32_t)d, (uint32_t)devices.size()));
-            else engs.emplace_back(new mtb::Engine(devices[d], dbdir, taxdir, d == 0 ? par : pd));
-        }
-        mtb::Engine &eng = *engs[0];                          /* taxonomy services for formatting */
-        const size_t ND = engs.size();
-        const double t_open = now() - t_start;
+        /* the parser starts before the database is opened: the first batches are parsed (and their pinned buffers allocated) while the
+         * index streams into HBM, so the GPU stage finds work waiting when the open returns */
         double t_parse = 0, t_gpu = 0, t_write = 0, t_dev = 0, t_fmt = 0, t_app = 0;  /* busy time of the three stages; device time inside the GPU stage */
-        FILE *out = fopen((prefix + "_classifications.tsv").c_str(), "w+");      /* read + write: append_parts maps the file MAP_SHARED, which needs a readable descriptor */
-        if (!out) throw std::runtime_error("cannot write " + prefix + "_classifications.tsv");
-        FILE *flt[2] = {nullptr, nullptr}, *rmv[2] = {nullptr, nullptr};
-        if (filter) {
-            auto open_w = [](const std::string &p) { FILE *f = fopen(p.c_str(), "w"); if (!f) throw std::runtime_error("cannot write " + p); return f; };
-            flt[0] = open_w(base1 + "_filtered.fna"); if (paired) flt[1] = open_w(base2 + "_filtered.fna");
-            if (print_mode == 2) { rmv[0] = open_w(base1 + "_removed.fna"); if (paired) rmv[1] = open_w(base2 + "_removed.fna"); }
-        }
-        fputs(lineage ? "#is_classified\tname\ttaxID\tquery_length\tscore\trank\tlineage\ttaxID:match_count\n"
-                      : "#is_classified\tname\ttaxID\tquery_length\tscore\trank\ttaxID:match_count\n", out);
         Channel<Job> parsed(2), scored(2), idle((size_t)gpu_workers + 4);
         /* a few batches are in flight (parse / GPU workers / format); their buffers are recycled, so that after the first round no stage
          * touches fresh pages, and what crosses PCIe sits in pinned memory */
@@ -378,6 +358,41 @@ int main(int argc, char **argv) {
                 }
             } catch (const std::exception &e) { reader_err = e.what(); std::unique_ptr<Job> j(new Job()); j->last = true; parsed.put(std::move(j)); }
         });
+        /* one engine (context + resident copy of the index) per GPU; db.parameters overrides the flags (common.cpp:88-133) */
+        std::vector<std::unique_ptr<mtb::Engine>> engs;
+        std::vector<uint64_t> bounds(devices.size(), 0);
+        try {
+        if (partitioned) mtb::check(mtb_index_part_bounds(dbdir.c_str(), (uint32_t)devices.size(), bounds.data()));
+        for (size_t d = 0; d < devices.size(); d++) {
+            mtb_params pd = par;
+            /* --partitioned 1: engine d holds range d of the database (SURVEY 8(e) row 2: databases larger than one HBM) */
+            if (partitioned) engs.emplace_back(new mtb::Engine(devices[d], dbdir, taxdir, d == 0 ? par : pd, (uint32_t)d, (uint32_t)devices.size()));
+            else if (d == 0) engs.emplace_back(new mtb::Engine(devices[d], dbdir, taxdir, par));
+            else engs.emplace_back(new mtb::Engine(devices[d], *engs[0]));           /* the files are read and decoded once: the other GPUs get peer copies */
+        }
+        } catch (const std::exception &e) {                   /* (the parser thread is running: leave at once) */
+            fprintf(stderr, "mtb_classify: %s\n", e.what()); fflush(stderr); _exit(1);
+        }
+        mtb::Engine &eng = *engs[0];                          /* taxonomy services for formatting */
+        const size_t ND = engs.size();
+        const double t_open = now() - t_start;
+        {   uint64_t os4[4] = {0, 0, 0, 0}; int32_t depth = 0, pk = 0, sealed = 0;
+            if (mtb_index_open_stats(eng.index, os4) == MTB_OK && mtb_index_state(eng.index, &depth, &pk, &sealed) == MTB_OK)
+                fprintf(stderr, "mtb_classify: database of %llu targets open in %.2f s: %llu chunks of %llu 16-bit words, peak device memory during the open %.2f GiB, directory depth %d%s\n",
+                        (unsigned long long)mtb_index_num_targets(eng.index), t_open, (unsigned long long)os4[0], (unsigned long long)os4[1], (double)os4[2] / 1073741824.0, depth,
+                        os4[3] ? ", packed on load (8-byte words, info folded in)" : "");
+        }
+
+        FILE *out = fopen((prefix + "_classifications.tsv").c_str(), "w+");      /* read + write: append_parts maps the file MAP_SHARED, which needs a readable descriptor */
+        if (!out) throw std::runtime_error("cannot write " + prefix + "_classifications.tsv");
+        FILE *flt[2] = {nullptr, nullptr}, *rmv[2] = {nullptr, nullptr};
+        if (filter) {
+            auto open_w = [](const std::string &p) { FILE *f = fopen(p.c_str(), "w"); if (!f) throw std::runtime_error("cannot write " + p); return f; };
+            flt[0] = open_w(base1 + "_filtered.fna"); if (paired) flt[1] = open_w(base2 + "_filtered.fna");
+            if (print_mode == 2) { rmv[0] = open_w(base1 + "_removed.fna"); if (paired) rmv[1] = open_w(base2 + "_removed.fna"); }
+        }
+        fputs(lineage ? "#is_classified\tname\ttaxID\tquery_length\tscore\trank\tlineage\ttaxID:match_count\n"
+                      : "#is_classified\tname\ttaxID\tquery_length\tscore\trank\ttaxID:match_count\n", out);
         /* stage 3: format + append, per-taxon read counts (Classifier.cpp:201-203) */
         std::vector<uint64_t> tax_counts((size_t)mtb_tax_max_id(eng.index) + 2, 0);
         unsigned long total = 0;
@@ -520,13 +535,28 @@ int main(int argc, char **argv) {
         std::vector<std::unique_ptr<Channel<Job>>> win, wout;
         for (int w = 0; w < W; w++) { win.emplace_back(new Channel<Job>(1)); wout.emplace_back(new Channel<Job>(1)); }
         std::vector<std::thread> workers;
+        /* the batch behind the one in work starts crossing PCIe before that one's kernels are launched (mtb_prefetch_batch_packed: copy
+         * stream + second input buffer set inside the context), so its upload is hidden behind them */
+        const bool can_prefetch = pack && !partitioned && ND == 1;
         for (int w = 0; w < W; w++) workers.emplace_back([&, w] {
+            std::unique_ptr<Job> j = win[(size_t)w]->get();
             for (;;) {
-                std::unique_ptr<Job> j = win[(size_t)w]->get();
                 const bool last = j->last;
-                if (!last && !failed()) process(*j, w);
+                std::unique_ptr<Job> nxt;
+                if (!last) {
+                    nxt = win[(size_t)w]->try_get();
+                    if (nxt && !nxt->last && can_prefetch && nxt->r1.size() && !failed()) {
+                        mtb_params pd = par;
+                        const mtb_status ps = mtb_prefetch_batch_packed(wctx[(size_t)w][0], &pd, nxt->r1.packed2.data(), nxt->r1.nmask.data(), nxt->r1.lens.data(),
+                                                                        paired ? nxt->r2.packed2.data() : nullptr, paired ? nxt->r2.nmask.data() : nullptr,
+                                                                        paired ? nxt->r2.lens.data() : nullptr, nxt->r1.size());
+                        (void)ps;               /* a failed prefetch only means that the batch is uploaded by its own call */
+                    }
+                    if (!failed()) process(*j, w);
+                }
                 wout[(size_t)w]->put(std::move(j));
                 if (last) break;
+                j = nxt ? std::move(nxt) : win[(size_t)w]->get();
             }
         });
         std::thread collector([&] {

@@ -183,6 +183,9 @@ __global__ __launch_bounds__(256) void k_index_unpack(uint64_t *__restrict__ val
  * of by their query's lane alone.  Real databases have heavy-tailed runs -- an amino-acid 8-mer of a conserved protein is shared by
  * 10^3 - 10^4 species -- and a lane that walks such a run twice on its own (minimum, then emission: the reference's
  * loop, KmerMatcher.cpp:363-416) stalls the other 63 lanes of its wave for thousands of dependent loads. */
+#ifndef MTB_JOIN_EXACT_MIN
+#define MTB_JOIN_EXACT_MIN 8          /* runs beyond this length are first searched for the query's own DNA part (see k_join_dir) */
+#endif
 #ifndef MTB_JOIN_COOP_MIN
 #define MTB_JOIN_COOP_MIN 32          /* default of JoinSegArgs::coop_min; MTB_JOIN_COOP_MIN=<n> in the environment of mtb_ctx_create overrides it (A/B runs) */
 #endif
@@ -283,18 +286,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
             }
         }
     }
-    /* long candidate runs (see MTB_JOIN_COOP_MIN): a query whose bucket still holds more than the threshold behind its first candidate
-     * finds the END of its run by a second bisection; runs beyond the threshold are taken away from the lane (valid[u] = false) and
-     * scanned by the wave below. */
+    /* Longer candidate runs.  A query whose bucket still holds more than MTB_JOIN_EXACT_MIN entries behind its first candidate finds the
+     * END of its run by a second bisection, and in a run beyond that length it looks its own DNA part up by a third one: inside a run
+     * the targets are ordered by their DNA part, and the hamming sum of two DNA parts is 0 exactly when they are equal (every
+     * off-diagonal entry of the lookup is >= 1, KmerMatcher.h:66-70).  If the query's DNA is there, the minimum over the run is 0, the
+     * threshold min(2 x 0, 7) = 0 (KmerMatcher.cpp:1136) and the selection is exactly the block of equal DNA parts: the run shrinks to
+     * that block, nothing is scanned -- a read of a conserved gene meets its own species' entry among thousands of others.  Runs that
+     * stay longer than sa.coop_min are taken away from the lane (valid[u] = false) and scanned by the wave below. */
     bool lng[Q];                                     /* (a long run's end replaces the bucket's end in e_hi[u]) */
 #pragma unroll
     for (int u = 0; u < Q; u++) {
         lng[u] = false;
-        if (valid[u] && e_hi[u] > lo[u] && e_hi[u] - lo[u] > (uint64_t)sa.coop_min) {
+        if (valid[u] && e_hi[u] > lo[u] && e_hi[u] - lo[u] > (uint64_t)MTB_JOIN_EXACT_MIN) {
             const uint64_t qk = qkey(k[u].value);
             uint64_t a = lo[u], b = e_hi[u];
             while (a < b) { const uint64_t mid = a + ((b - a) >> 1); if (tkey(ix.values[mid]) <= qk) a = mid + 1; else b = mid; }
-            if (a - lo[u] > (uint64_t)sa.coop_min) { lng[u] = true; e_hi[u] = a; valid[u] = false; }
+            if (a - lo[u] > (uint64_t)MTB_JOIN_EXACT_MIN) {
+                const uint32_t qd = (uint32_t)k[u].value & 0xFFFFFFu;
+                uint64_t x = lo[u], y = a;
+                while (x < y) { const uint64_t mid = x + ((y - x) >> 1); if (((uint32_t)ix.values[mid] & 0xFFFFFFu) < qd) x = mid + 1; else y = mid; }
+                if (x < a && ((uint32_t)ix.values[x] & 0xFFFFFFu) == qd) {
+                    uint64_t x2 = x + 1; y = a;
+                    while (x2 < y) { const uint64_t mid = x2 + ((y - x2) >> 1); if (((uint32_t)ix.values[mid] & 0xFFFFFFu) <= qd) x2 = mid + 1; else y = mid; }
+                    lo[u] = x; a = x2;                      /* the block of equal DNA parts: an ordinary run of hamming-0 candidates from here on */
+                }
+                e_hi[u] = a;
+                if (a - lo[u] > (uint64_t)sa.coop_min) { lng[u] = true; valid[u] = false; }
+            }
         }
     }
     const uint32_t lane = threadIdx.x & 63u;
@@ -591,40 +609,63 @@ __global__ __launch_bounds__(256) void k_join_footprint(const mtb_kmer *__restri
  * k_index_run_hist: runs of equal amino-acid parts of a FLAT target array, counted at their first entry: hist[b] += 1 and
  * hist[32 + b] += length for b = floor(log2(length)) -- the index-side run-length distribution (heavy-tailed in real
  * databases).  k_join_run_hist: for every query of the last batch the length of the run it meets (what k_join_dir scans for it):
- * hist[0] = queries without a candidate, hist[1 + b] = queries with floor(log2(length)) = b, hist[40 + b] = candidates they scan. */
+ * hist[0] = queries without a candidate, hist[1 + b] = queries with floor(log2(length)) = b, hist[40 + b] = targets in those runs,
+ * hist[33] / hist[34] = queries (and the targets of their runs) that find their own DNA part in a run beyond MTB_JOIN_EXACT_MIN: the join
+ * selects that block by bisection instead of scanning the run. */
 __global__ __launch_bounds__(256) void k_index_run_hist(const uint64_t *__restrict__ values, uint64_t T, unsigned long long *__restrict__ hist) {
     const uint64_t AAM = ~0xFFFFFFull;
+    __shared__ unsigned long long s_h[64];           /* per workgroup: 13 G runs on two global counters would serialise on them */
+    if (threadIdx.x < 64) s_h[threadIdx.x] = 0;
+    __syncthreads();
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < T; i += (uint64_t)gridDim.x * 256) {
         const uint64_t aa = values[i] & AAM;
         if (i > 0 && (values[i - 1] & AAM) == aa) continue;
         uint64_t e = i + 1;
         while (e < T && (values[e] & AAM) == aa) e++;
         const uint32_t b = 63u - (uint32_t)__clzll((unsigned long long)(e - i));
-        atomicAdd(&hist[b < 31u ? b : 31u], 1ull); atomicAdd(&hist[32 + (b < 31u ? b : 31u)], (unsigned long long)(e - i));
+        atomicAdd(&s_h[b < 31u ? b : 31u], 1ull); atomicAdd(&s_h[32 + (b < 31u ? b : 31u)], (unsigned long long)(e - i));
     }
+    __syncthreads();
+    if (threadIdx.x < 64 && s_h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_h[threadIdx.x]);
 }
 template <bool PACKED>
 __global__ __launch_bounds__(256) void k_join_run_hist(const mtb_kmer *__restrict__ q, uint64_t n, const uint64_t *__restrict__ values, uint64_t limit, mtb_dir_view dv,
                                                         unsigned long long *__restrict__ hist) {
+    __shared__ unsigned long long s_h[64];
+    if (threadIdx.x < 64) s_h[threadIdx.x] = 0;
+    __syncthreads();
     const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (j >= n) return;
-    const mtb_kmer k = q[j];
-    if (mtb_q_seq(k.qinfo) == 0) return;
+    mtb_kmer k; k.value = 0; k.qinfo = 0;
+    if (j < n) k = q[j];
+    const bool live = j < n && mtb_q_seq(k.qinfo) != 0;
     const uint64_t AAM = ~0xFFFFFFull;
     auto tkey = [&](uint64_t w) -> uint64_t { return PACKED ? (w & 0x1F000000ull) : (w & AAM); };
     const uint64_t qk = !PACKED ? (k.value & AAM) : (dv.kmer_format == 1 ? (((k.value >> 24) % 21ull) << 24) : (k.value & 0x1F000000ull));
     const uint32_t b = mtb_dir_bucket(k.value, dv.L, dv.kmer_format);
     uint64_t lo = 0, hi = 0;
-    if (b < dv.n_buckets) { lo = dv.base[b >> 16] + dv.dir[b]; hi = dv.base[(b + 1) >> 16] + dv.dir[b + 1]; if (hi > limit) hi = limit; if (lo > hi) lo = hi; }
+    if (live && b < dv.n_buckets) { lo = dv.base[b >> 16] + dv.dir[b]; hi = dv.base[(b + 1) >> 16] + dv.dir[b + 1]; if (hi > limit) hi = limit; if (lo > hi) lo = hi; }
     uint64_t a = lo, z = hi;
     while (a < z) { const uint64_t mid = a + ((z - a) >> 1); if (tkey(values[mid]) < qk) a = mid + 1; else z = mid; }
     const uint64_t s = a;
     z = hi;
     while (a < z) { const uint64_t mid = a + ((z - a) >> 1); if (tkey(values[mid]) <= qk) a = mid + 1; else z = mid; }
     const uint64_t len = a - s;
-    if (len == 0) { atomicAdd(&hist[0], 1ull); return; }
-    const uint32_t bin = 63u - (uint32_t)__clzll((unsigned long long)len);
-    atomicAdd(&hist[1 + (bin < 31u ? bin : 31u)], 1ull); atomicAdd(&hist[40 + (bin < 23u ? bin : 23u)], (unsigned long long)len);
+    if (live) {
+        if (len == 0) atomicAdd(&s_h[0], 1ull);
+        else {
+            const uint32_t bin = 63u - (uint32_t)__clzll((unsigned long long)len);
+            atomicAdd(&s_h[1 + (bin < 31u ? bin : 31u)], 1ull); atomicAdd(&s_h[40 + (bin < 23u ? bin : 23u)], (unsigned long long)len);
+            /* does the run hold the query's own DNA part?  (then the join selects that block without a scan) */
+            if (len > (uint64_t)MTB_JOIN_EXACT_MIN) {
+                const uint32_t qd = (uint32_t)k.value & 0xFFFFFFu;
+                uint64_t x = s, y = a;
+                while (x < y) { const uint64_t mid = x + ((y - x) >> 1); if (((uint32_t)values[mid] & 0xFFFFFFu) < qd) x = mid + 1; else y = mid; }
+                if (x < a && ((uint32_t)values[x] & 0xFFFFFFu) == qd) { atomicAdd(&s_h[33], 1ull); atomicAdd(&s_h[34], (unsigned long long)len); }
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64 && s_h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_h[threadIdx.x]);
 }
 __global__ __launch_bounds__(256) void k_popcount_words(const uint32_t *__restrict__ w, uint64_t n_words, unsigned long long *__restrict__ out) {
     unsigned long long acc = 0;

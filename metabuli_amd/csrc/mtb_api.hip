@@ -109,6 +109,11 @@ struct mtb_ctx {
     bool fast_used = false;          /* the last dev_score call launched k_score_fast (its slow-list count sits in d_scal[6]) */
     bool no_lslot = false;           /* classify_one is redoing a long-read range on the exact-segment path */
     const mtb_kmer *last_sorted = nullptr; uint64_t last_sorted_n = 0;       /* the last fused slot-path batch's sorted metamers (mtb_ctx_join_footprint) */
+    /* upload of the NEXT batch's packed reads while the current batch computes (mtb_prefetch_batch_packed): a copy stream, two sets of
+     * input buffers, and what the set that is being filled holds */
+    hipStream_t copy_stream = nullptr; hipEvent_t copy_done = nullptr;
+    int pk_set = 0;                                  /* the set the last classify call read */
+    struct Prefetched { const void *key = nullptr, *key2 = nullptr; uint64_t n_reads = 0, slots = 0, slots2 = 0; bool valid = false; } pre;
     uint32_t join_coop_min = MTB_JOIN_COOP_MIN;      /* k_join_dir: runs longer than this are scanned by the whole wave; MTB_JOIN_COOP_MIN in the environment at mtb_ctx_create */
 };
 /* buffers that carry a call's inputs / outputs (host-buffer entry points) are not workspace */
@@ -349,6 +354,8 @@ void mtb_ctx_destroy(mtb_ctx *c) {
     if (c->d_tabs && !c->is_lane) e = hipFree(c->d_tabs);
     if (c->d_scal) e = hipFree(c->d_scal);
     if (c->is_lane && c->stream) e = hipStreamDestroy(c->stream);
+    if (c->copy_stream) { e = hipStreamSynchronize(c->copy_stream); e = hipStreamDestroy(c->copy_stream); }
+    if (c->copy_done) e = hipEventDestroy(c->copy_done);
     for (int i = 0; i < 8; i++) e = hipEventDestroy(c->ev[i]);
     for (auto &k : c->kev) { e = hipEventDestroy(k.a); e = hipEventDestroy(k.b); }
     for (auto &x : c->ev_pool) e = hipEventDestroy(x);
@@ -1046,6 +1053,24 @@ static bool pread_parallel(int fd, void *dst, uint64_t off, size_t len, int n_th
     return true;
 }
 
+static bool pwrite_parallel(int fd, const void *src, uint64_t off, size_t len, int n_threads) {
+    if (len == 0) return true;
+    const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, len >> 22));
+    std::vector<char> ok((size_t)nt, 1);
+    auto part = [&](int t) {
+        size_t lo = len * (size_t)t / (size_t)nt, hi = len * ((size_t)t + 1) / (size_t)nt;
+        while (lo < hi) {
+            const ssize_t r = pwrite(fd, (const char *)src + lo, hi - lo, (off_t)(off + lo));
+            if (r <= 0) { ok[(size_t)t] = 0; return; }
+            lo += (size_t)r;
+        }
+    };
+    if (nt == 1) part(0);
+    else { std::vector<std::thread> th; for (int t = 0; t < nt; t++) th.emplace_back(part, t); for (auto &x : th) x.join(); }
+    for (char k : ok) if (!k) return false;
+    return true;
+}
+
 /* bytes [off, off + len) of a file -> device memory, double-buffered through pinned host memory */
 static mtb_status stream_file_to_device(mtb_ctx *c, const std::string &path, uint64_t off, uint64_t len, void *d_dst) {
     if (len == 0) return MTB_OK;
@@ -1331,6 +1356,60 @@ mtb_status mtb_index_from_device(mtb_ctx *c, uint64_t *d_values, uint32_t *d_inf
     return MTB_OK;
 }
 
+/* "load once, broadcast over xGMI".  The resident index of one GPU copied to another context's GPU with peer
+ * copies (hipMemcpyPeerAsync: device to device over xGMI where the devices can reach each other; same-device contexts get a
+ * device-to-device copy) -- the target words in the state they are in (packed / flat), info[] if it is resident, the directory --
+ * and the taxonomy tables uploaded from the host copy.  A node that classifies on 8 GPUs reads and decodes the database files once
+ * instead of 8 times.  The reference has one address space and no analogue (KmerMatcher.cpp:212-217 opens the files per thread). */
+mtb_status mtb_index_clone(mtb_index *src, mtb_ctx *dst, mtb_index **out) {
+    if (!src || !dst || !out) return fail(MTB_ERR_ARG, "NULL argument");
+    if (src->parent) return fail(MTB_ERR_ARG, "a view cannot be cloned: clone its parent");
+    mtb_ctx *sc = src->ctx;
+    if (sc->device != dst->device) {
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, dst->device, sc->device) == hipSuccess && can) {
+            if (hipSetDevice(dst->device) == hipSuccess) { const hipError_t e = hipDeviceEnablePeerAccess(sc->device, 0); if (e != hipSuccess) (void)hipGetLastError(); }      /* (twice = "already on") */
+        } else (void)hipGetLastError();
+    }
+    HIPCHK(hipSetDevice(dst->device));
+    mtb_index *ix = new mtb_index();
+    struct Guard { mtb_index *ix; ~Guard() { if (ix) mtb_index_close(ix); } } guard{ix};
+    ix->ctx = dst; ix->params = src->params; ix->own = true; ix->tax = src->tax; ix->info_mask = src->info_mask; ix->match_last = src->match_last; ix->T = src->T;
+    STCHK(upload_taxonomy(ix));
+    IndexUse use;                                   /* the source keeps its state (and is not converted) while it is read */
+    {
+        std::unique_lock<std::mutex> lk(src->state_mu);
+        src->users++; use.o = src;
+    }
+    const bool packed = src->packed;
+    auto peer = [&](void *d, const void *s_, size_t bytes) -> mtb_status {
+        const size_t CH = 1ull << 30;               /* 1 GiB pieces: progress is visible to the stream, a failure is local */
+        for (size_t o = 0; o < bytes; o += CH) {
+            const size_t nb = std::min(CH, bytes - o);
+            if (sc->device == dst->device) HIPCHK(hipMemcpyAsync((char *)d + o, (const char *)s_ + o, nb, hipMemcpyDeviceToDevice, dst->stream));
+            else HIPCHK(hipMemcpyPeerAsync((char *)d + o, dst->device, (const char *)s_ + o, sc->device, nb, dst->stream));
+        }
+        return MTB_OK;
+    };
+    HIPCHK(hipStreamSynchronize(sc->stream));       /* whatever the source context still had in flight on the arrays */
+    HIPCHK(hipMalloc((void **)&ix->d_values, (src->T + 1) * 8));
+    STCHK(peer(ix->d_values, src->d_values, src->T * 8));
+    if (src->d_info) { HIPCHK(hipMalloc((void **)&ix->d_info, std::max<uint64_t>(src->T, 1) * 4)); STCHK(peer(ix->d_info, src->d_info, src->T * 4)); }
+    if (src->d_dir) {
+        const uint32_t n_groups = (src->dir_buckets >> 16) + 1;
+        HIPCHK(hipMalloc((void **)&ix->d_dir, ((size_t)src->dir_buckets + 1) * 4));
+        HIPCHK(hipMalloc((void **)&ix->d_dirbase, ((size_t)n_groups + 2) * 8));
+        STCHK(peer(ix->d_dir, src->d_dir, ((size_t)src->dir_buckets + 1) * 4));
+        STCHK(peer(ix->d_dirbase, src->d_dirbase, ((size_t)n_groups + 2) * 8));
+        ix->dir_L = src->dir_L; ix->dir_buckets = src->dir_buckets;
+    }
+    HIPCHK(hipStreamSynchronize(dst->stream));
+    ix->packed = packed;
+    guard.ix = nullptr;
+    *out = ix;
+    return MTB_OK;
+}
+
 void mtb_index_close(mtb_index *ix) {
     if (!ix) return;
     hipError_t e = hipSuccess;
@@ -1421,9 +1500,9 @@ mtb_status mtb_index_write(const mtb_index *cix, const char *dbdir, int split_nu
     STCHK(ensure_flat(ix));
     hipStream_t st = c->stream;
     const std::string d(dbdir);
-    FILE *fd = fopen((d + "/diffIdx").c_str(), "wb"), *fi = fopen((d + "/info").c_str(), "wb");
-    struct Files { FILE *a, *b; ~Files() { if (a) fclose(a); if (b) fclose(b); } } files{fd, fi};
-    if (!fd || !fi) return fail(MTB_ERR_IO, "cannot create diffIdx/info in " + d);
+    const int fd = open((d + "/diffIdx").c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644), fi = open((d + "/info").c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    struct Files { int a, b; ~Files() { if (a >= 0) close(a); if (b >= 0) close(b); } } files{fd, fi};
+    if (fd < 0 || fi < 0) return fail(MTB_ERR_IO, "cannot create diffIdx/info in " + d);
     struct Split { uint64_t ad, diff_off, info_off; };
     std::vector<Split> splits((size_t)split_num, Split{0, 0, 0});
     const uint64_t n = ix->T;
@@ -1490,7 +1569,15 @@ mtb_status mtb_index_write(const mtb_index *cix, const char *dbdir, int split_nu
         if (writers[cur ^ 1].joinable()) writers[cur ^ 1].join();          /* file order */
         if (!write_ok) return fail(MTB_ERR_IO, "short write while writing " + d);
         const void *pe = pin.e[cur], *pi = pin.i[cur];
-        writers[cur] = std::thread([&write_ok, fd, fi, pe, pi, words, m] { if (!(fwrite(pe, 2, words, fd) == words && fwrite(pi, 4, m, fi) == m)) write_ok = false; });
+        const uint64_t at_d = diff_count * 2, at_i = s0 * 4;
+        /* several pwrite streams per file: one stream into the page cache tops out near 2-3 GB/s, a 16 G-target database is 150 GB */
+        writers[cur] = std::thread([&write_ok, fd, fi, pe, pi, words, m, at_d, at_i] {
+            bool ok_i = true;
+            std::thread ti([&] { ok_i = pwrite_parallel(fi, pi, at_i, m * 4, 6); });
+            const bool ok_d = pwrite_parallel(fd, pe, at_d, words * 2, 10);
+            ti.join();
+            if (!ok_d || !ok_i) write_ok = false;
+        });
         diff_count += words;
     }
     for (int k = 0; k < 2; k++) if (writers[k].joinable()) writers[k].join();
@@ -1771,11 +1858,21 @@ static mtb_status score_fixed_slots(mtb_ctx *c, mtb_index *ix, const mtb_params 
                            (const uint32_t *)d_rc, (const uint32_t *)d_biglist, (const uint64_t *)d_bigstart, n_big, d_bigcur, d_big);
         if (n_ovf) hipLaunchKernelGGL(k_big_ovf, dim3((uint32_t)((n_ovf + 255) / 256)), dim3(256), 0, st, (const mtb_match *)d_ovf, n_ovf,
                                       (const uint32_t *)d_bigidx, (const uint64_t *)d_bigstart, d_bigcur, d_big);
+        /* segments of up to 512 matches (nearly all: a read of a conserved gene brings a few hundred) are sorted in LDS by one wave
+         * each; only the ones beyond go through the HBM-resident bitonic network (36 global-memory stages for 256 records: it cost
+         * ~70 us per segment, and 7 % of the reads of a realistic batch come here) */
+        uint32_t *d_lg;
+        STCHK(ensure(c, "large", n_big, &d_lg));
+        HIPCHK(hipMemsetAsync(c->d_xscal + 2, 0, 8, st));
+        hipLaunchKernelGGL(k_segsort_small, dim3(std::min<uint32_t>(n_big, 256u * 40u)), dim3(64), 0, st, d_big, (const uint64_t *)d_bigstart, (uint64_t)n_big, d_lg,
+                           (uint32_t *)(c->d_xscal + 2), (uint32_t *)nullptr);
         hipLaunchKernelGGL((k_segsort_large<mtb_match>), dim3(std::min<uint32_t>(n_big, 1024)), dim3(256), 0, st, d_big, (const uint64_t *)d_bigstart,
-                           (const uint32_t *)nullptr, (const uint32_t *)(c->d_scal + 5));
+                           (const uint32_t *)d_lg, (const uint32_t *)(c->d_xscal + 2));
         HIPCHK(hipGetLastError());
         b->m = d_big; b->seg = d_bigstart; b->list = d_biglist; b->n_list = (const uint32_t *)(c->d_scal + 5); b->seg_by_list = 1;
-        b->sort = false; b->max_seg = (uint32_t)mx; b->grid = std::min<uint32_t>(n_big, 1024);
+        /* one wave per workgroup, 14 of them resident per CU: a thousand workgroups left three quarters of the chip idle when hundreds of
+         * thousands of reads come here (reads of conserved genes: hundreds of matches each); the slab pool stays bounded by dev_score */
+        b->sort = false; b->max_seg = (uint32_t)mx; b->grid = std::min<uint32_t>(n_big, 256u * 14u);
         return MTB_OK;
     };
     STCHK(dev_score(c, ix, p, n_reads, d_ql, d_ql2, max_len, d_results, d_taxcnt_tax, d_taxcnt_cnt, taxcnt_cap, n_taxcnt, tc_base, a, &second));
@@ -2175,18 +2272,32 @@ void *mtb_host_alloc(size_t bytes) {
 }
 void mtb_host_free(void *p) { if (p) { hipError_t e = hipHostFree(p); (void)e; } }
 
-static mtb_status upload_packed(mtb_ctx *c, const char *tag, const uint8_t *packed2, const uint8_t *nmask, const uint32_t *lens, uint64_t n_reads,
-                                char **d_bases, uint64_t **d_offs, uint64_t *n_bases) {
-    const std::string t(tag);
+static uint64_t packed_slots(const uint32_t *lens, uint64_t n_reads) {
     uint64_t slots = 0;
     for (uint64_t i = 0; i < n_reads; i++) slots += (lens[i] + 7u) >> 3;
+    return slots;
+}
+/* the three packed arrays of one mate into input buffer set `set`, on stream `on` */
+static mtb_status copy_packed(mtb_ctx *c, const char *tag, int set, hipStream_t on, const uint8_t *packed2, const uint8_t *nmask, const uint32_t *lens,
+                              uint64_t n_reads, uint64_t slots, uint8_t **d_p2, uint8_t **d_nm, uint32_t **d_len) {
+    const std::string t = std::string(tag) + (set ? "#1" : "#0");
+    STCHK(ensure(c, ("pk2" + t).c_str(), slots * 2 + 8, d_p2)); STCHK(ensure(c, ("pkm" + t).c_str(), slots + 8, d_nm)); STCHK(ensure(c, ("pklen" + t).c_str(), n_reads, d_len));
+    HIPCHK(hipMemcpyAsync(*d_p2, packed2, slots * 2, hipMemcpyHostToDevice, on));
+    HIPCHK(hipMemcpyAsync(*d_nm, nmask, slots, hipMemcpyHostToDevice, on));
+    HIPCHK(hipMemcpyAsync(*d_len, lens, n_reads * 4, hipMemcpyHostToDevice, on));
+    return MTB_OK;
+}
+/* `prefetched`: the arrays already sit (or are arriving: the compute stream waits for the copy event) in set `set` */
+static mtb_status upload_packed(mtb_ctx *c, const char *tag, int set, bool prefetched, const uint8_t *packed2, const uint8_t *nmask, const uint32_t *lens, uint64_t n_reads,
+                                char **d_bases, uint64_t **d_offs, uint64_t *n_bases) {
+    const std::string t(tag);
     uint8_t *d_p2, *d_nm; uint32_t *d_len, *d_sl; uint64_t *d_so, *d_ws;
-    STCHK(ensure(c, ("pk2" + t).c_str(), slots * 2 + 8, &d_p2)); STCHK(ensure(c, ("pkm" + t).c_str(), slots + 8, &d_nm));
-    STCHK(ensure(c, ("pklen" + t).c_str(), n_reads, &d_len)); STCHK(ensure(c, ("pksl" + t).c_str(), n_reads, &d_sl)); STCHK(ensure(c, ("pkso" + t).c_str(), n_reads + 1, &d_so));
+    if (prefetched) {
+        const std::string ts = t + (set ? "#1" : "#0");
+        d_p2 = (uint8_t *)c->bufs["pk2" + ts].p; d_nm = (uint8_t *)c->bufs["pkm" + ts].p; d_len = (uint32_t *)c->bufs["pklen" + ts].p;
+    } else STCHK(copy_packed(c, tag, set, c->stream, packed2, nmask, lens, n_reads, packed_slots(lens, n_reads), &d_p2, &d_nm, &d_len));
+    STCHK(ensure(c, ("pksl" + t).c_str(), n_reads, &d_sl)); STCHK(ensure(c, ("pkso" + t).c_str(), n_reads + 1, &d_so));
     STCHK(ensure(c, ("offs" + t).c_str(), n_reads + 1, d_offs)); STCHK(ensure(c, "scanws", scan_ws_elems(n_reads + 1), &d_ws));
-    HIPCHK(hipMemcpyAsync(d_p2, packed2, slots * 2, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(d_nm, nmask, slots, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(d_len, lens, n_reads * 4, hipMemcpyHostToDevice, c->stream));
     scan_launch<uint32_t, uint64_t, false>(c->stream, d_len, n_reads, true, *d_offs, d_ws);
     hipLaunchKernelGGL(k_pack_slots, dim3((uint32_t)((n_reads + 255) / 256)), dim3(256), 0, c->stream, (const uint32_t *)d_len, n_reads, d_sl);
     scan_launch<uint32_t, uint64_t, false>(c->stream, d_sl, n_reads, true, d_so, d_ws);
@@ -2212,11 +2323,16 @@ mtb_status mtb_classify_batch_packed(mtb_ctx *c, mtb_index *ix, const mtb_params
     static const bool timing = getenv("MTB_HOST_TIMING") != nullptr;      /* wall time of the call's three parts on stderr (the uploads are synchronised for it) */
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
-    STCHK(upload_packed(c, "", packed2, nmask, lens, n_reads, &d_b, &d_o, &nb));
-    if (p->seq_mode == 2) {
-        if (!packed2_mate || !nmask_mate || !lens_mate) return fail(MTB_ERR_ARG, "seq_mode 2 needs the mates");
-        STCHK(upload_packed(c, "2", packed2_mate, nmask_mate, lens_mate, n_reads, &d_b2, &d_o2, &nb2));
-    }
+    if (p->seq_mode == 2 && (!packed2_mate || !nmask_mate || !lens_mate)) return fail(MTB_ERR_ARG, "seq_mode 2 needs the mates");
+    /* this batch may already be on its way (mtb_prefetch_batch_packed): then the compute stream only waits for the copy */
+    const bool pre = c->pre.valid && c->pre.key == (const void *)packed2 && c->pre.n_reads == n_reads && (p->seq_mode != 2 || c->pre.key2 == (const void *)packed2_mate);
+    const int set = pre ? (c->pk_set ^ 1) : c->pk_set;
+    if (c->pre.valid && !pre) HIPCHK(hipStreamSynchronize(c->copy_stream));       /* a prefetch nobody came for: let it finish before its buffers are reused */
+    c->pre.valid = false;
+    if (pre) HIPCHK(hipStreamWaitEvent(c->stream, c->copy_done, 0));
+    c->pk_set = set;
+    STCHK(upload_packed(c, "", set, pre, packed2, nmask, lens, n_reads, &d_b, &d_o, &nb));
+    if (p->seq_mode == 2) STCHK(upload_packed(c, "2", set, pre, packed2_mate, nmask_mate, lens_mate, n_reads, &d_b2, &d_o2, &nb2));
     mtb_result *d_res; int32_t *d_tt; uint32_t *d_tc;
     const uint64_t dcap = c->lanes.size() < 2 ? std::max<uint64_t>(taxcnt_cap, taxcnt_device_slots(p, n_reads, nb + nb2)) : taxcnt_cap;     /* (as in mtb_classify_batch) */
     STCHK(ensure(c, "results", n_reads, &d_res)); STCHK(ensure(c, "tctax", dcap, &d_tt)); STCHK(ensure(c, "tccnt", dcap, &d_tc));
@@ -2233,6 +2349,30 @@ mtb_status mtb_classify_batch_packed(mtb_ctx *c, mtb_index *ix, const mtb_params
     }
     STCHK(d2h(c, results, d_res, n_reads * sizeof(mtb_result)));
     if (*n_taxcnt) { STCHK(d2h(c, taxcnt_tax, d_tt, *n_taxcnt * 4)); STCHK(d2h(c, taxcnt_cnt, d_tc, *n_taxcnt * 4)); }
+    return MTB_OK;
+}
+
+/* Starts the upload of the NEXT batch (the arrays mtb_classify_batch_packed will be called with) on the context's copy stream, into
+ * the input buffer set the running batch does not use, and returns at once: the PCIe transfer of batch k+1 overlaps the kernels of
+ * batch k (the serial producer this replaces: KmerExtractor.cpp:117-173 fills a batch, then the batch is processed).  Call it from the
+ * context's thread right before the mtb_classify_batch_packed of batch k; the arrays must stay valid (pinned: mtb_host_alloc) until
+ * the classify call for batch k+1 returns.  A prefetch that is not followed by its classify call is discarded. */
+mtb_status mtb_prefetch_batch_packed(mtb_ctx *c, const mtb_params *p, const uint8_t *packed2, const uint8_t *nmask, const uint32_t *lens,
+                                     const uint8_t *packed2_mate, const uint8_t *nmask_mate, const uint32_t *lens_mate, uint64_t n_reads) {
+    if (!c || !p || !packed2 || !nmask || !lens) return fail(MTB_ERR_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(c->device));
+    if (n_reads == 0 || c->lanes.size() > 1) return MTB_OK;
+    if (p->seq_mode == 2 && (!packed2_mate || !nmask_mate || !lens_mate)) return fail(MTB_ERR_ARG, "seq_mode 2 needs the mates");
+    if (!c->copy_stream) { HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming)); }
+    if (c->pre.valid) HIPCHK(hipStreamSynchronize(c->copy_stream));
+    c->pre.valid = false;
+    const int set = c->pk_set ^ 1;
+    uint8_t *a, *b; uint32_t *l;
+    const uint64_t s1 = packed_slots(lens, n_reads);
+    STCHK(copy_packed(c, "", set, c->copy_stream, packed2, nmask, lens, n_reads, s1, &a, &b, &l));
+    if (p->seq_mode == 2) STCHK(copy_packed(c, "2", set, c->copy_stream, packed2_mate, nmask_mate, lens_mate, n_reads, packed_slots(lens_mate, n_reads), &a, &b, &l));
+    HIPCHK(hipEventRecord(c->copy_done, c->copy_stream));
+    c->pre.key = packed2; c->pre.key2 = packed2_mate; c->pre.n_reads = n_reads; c->pre.valid = true;
     return MTB_OK;
 }
 

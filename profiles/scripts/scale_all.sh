@@ -13,12 +13,12 @@ for N in 1 2 4 8; do
   [ $N -gt $MAXG ] && break
   if [ $N -eq 1 ]; then
     timeout 600 python bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu > $O/replicated_$N.json 2> $O/replicated_$N.log
-    MTB_PART_TIMING=1 timeout 600 python bench.py --partitioned --reads 2000000 --targets 2e9 --steps 5 --warmup 2 --no-parity > $O/partitioned_$N.json 2> $O/partitioned_$N.log
+    MTB_PART_TIMING=1 timeout 600 python bench.py --partitioned --species 24 --reads 2000000 --targets 2e9 --steps 5 --warmup 2 --no-parity > $O/partitioned_$N.json 2> $O/partitioned_$N.log
   else
     timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $PORT bench.py --gpus $N --steps 5 --warmup 2 --no-cpu > $O/replicated_$N.json 2> $O/replicated_$N.log
     PORT=$((PORT+1))
     # every rank brings 2 M reads (weak on the reads); the 2 G-target index is cut into N value ranges, one per rank
-    MTB_PART_TIMING=1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $PORT bench.py --gpus $N --partitioned --reads 2000000 --targets 2e9 --steps 5 --warmup 2 --no-parity > $O/partitioned_$N.json 2> $O/partitioned_$N.log
+    MTB_PART_TIMING=1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $PORT bench.py --gpus $N --partitioned --species 24 --reads 2000000 --targets 2e9 --steps 5 --warmup 2 --no-parity > $O/partitioned_$N.json 2> $O/partitioned_$N.log
     PORT=$((PORT+1))
   fi
   tail -1 $O/replicated_$N.json | cut -c1-300; tail -1 $O/partitioned_$N.json | cut -c1-300

@@ -595,6 +595,37 @@ def test_open_under_a_workspace_limit_smaller_than_the_raw_diffidx(tmp_path):
     ix.close(); c2.close(); c.close()
 
 
+@pytest.mark.parametrize("state", ["flat", "packed", "sealed"])
+def test_index_clone_is_an_independent_equal_copy(toy, monkeypatch, state):
+    """mtb_index_clone (load once, copy to the other GPUs): a second context -- here on the same device -- gets the
+    resident index by device copies in whatever state it is in; the source is closed, and the copy still downloads as the database's
+    arrays and classifies as the oracle says"""
+    import metabuli_amd as M
+    if state != "flat":
+        monkeypatch.setenv("MTB_DIR_DEPTH", "7")
+    a, b = M.Context(0), M.Context(0)
+    p = _params(toy)
+    src = a.open_index(toy.dbdir, p)
+    monkeypatch.delenv("MTB_DIR_DEPTH", raising=False)
+    if state != "flat":
+        if toy.p.seq_mode == 3:
+            src.close(); a.close(); b.close(); pytest.skip("long toy reads may leave the index flat")
+        a.classify_batch(src, p, toy.b1, toy.o1, toy.b2, toy.o2)          # the fused join packs a depth-7 index
+        if not src.state()["packed"]:
+            src.close(); a.close(); b.close(); pytest.skip("this mode's reads stay on the flat-state path")
+    if state == "sealed":
+        src.seal()
+    st = src.state()
+    cp = b.clone_index(src)
+    assert cp.state() == st and cp.num_targets == len(toy.values)
+    src.close(); a.close()
+    res, tt, tc = b.classify_batch(cp, p, toy.b1, toy.o1, toy.b2, toy.o2)
+    _check_results(toy, res, tt, tc)
+    v, info = cp.download()
+    assert (v == toy.values).all() and (info.astype(np.int32) == toy.taxids).all()
+    cp.close(); b.close()
+
+
 def test_slot_epoch_wraps_without_stale_matches(toy, orc):
     """the slot segments of the fused path are never cleared between batches: live slots carry a 5-bit epoch tag that
     wraps every 31 batches.  40 batches on one context, alternating two different read sets, must keep giving the
