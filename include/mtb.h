@@ -277,6 +277,13 @@ mtb_status mtb_classify_batch_packed(mtb_ctx *, mtb_index *, const mtb_params *,
  * batch, then the batch is processed: KmerExtractor.cpp:117-173.)                                                                    */
 mtb_status mtb_prefetch_batch_packed(mtb_ctx *, const mtb_params *, const uint8_t *packed2, const uint8_t *nmask, const uint32_t *lens,
                                      const uint8_t *packed2_mate, const uint8_t *nmask_mate, const uint32_t *lens_mate, uint64_t n_reads);
+/* Host-side helpers of a driver that overlaps its start-up: mtb_db_parameters applies DBDIR/db.parameters to *p (what mtb_index_open
+ * does first: common.cpp:88-133) without opening anything; mtb_ctx_reserve grows the context's big workspace buffers (metamer buffers,
+ * digit arrays, slot segments) for short-read batches of n_reads reads / n_bases bases ahead of time -- it may run on ANOTHER thread while
+ * the context's thread is inside mtb_index_open, so that tens of GB of hipMalloc hide behind the database load instead of delaying the
+ * first batch.  Purely an optimisation: a batch that needs more grows its buffers as always.                                          */
+mtb_status mtb_db_parameters(const char *dbdir, mtb_params *p);
+mtb_status mtb_ctx_reserve(mtb_ctx *, const mtb_params *, uint64_t n_reads, uint64_t n_bases);
 mtb_status mtb_last_batch_stats(mtb_ctx *, mtb_batch_stats *out);
 /* Diagnostic, outside any timed region: the index-side working set of the LAST mtb_classify_batch* call of this context
  * when it took the directory join (short reads, index with a directory): distinct directory buckets its query metamers fall

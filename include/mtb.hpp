@@ -67,6 +67,11 @@ class Engine {      /* one GPU: context + resident index (replaces the per-call 
 public:
     Engine(int device, const std::string &dbDir, const std::string &taxonomyDir, LocalParameters &par) {
         check(mtb_ctx_create(device, nullptr, &ctx));
+        open(dbDir, taxonomyDir, par);
+    }
+    /* two steps, for a host that does something with the context (mtb_ctx_reserve on a helper thread) while the database loads */
+    explicit Engine(int device) { check(mtb_ctx_create(device, nullptr, &ctx)); }
+    void open(const std::string &dbDir, const std::string &taxonomyDir, LocalParameters &par) {
         check(mtb_index_open(ctx, dbDir.c_str(), taxonomyDir.empty() ? nullptr : taxonomyDir.c_str(), &par, &index));
     }
     /* range `part` of `n_parts` of a database larger than one HBM (mtb_index_open_part) */

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void k_index_unpack(uint64_t *__restrict__ val
  * 10^3 - 10^4 species -- and a lane that walks such a run twice on its own (minimum, then emission: the reference's
  * loop, KmerMatcher.cpp:363-416) stalls the other 63 lanes of its wave for thousands of dependent loads. */
 #ifndef MTB_JOIN_EXACT_MIN
-#define MTB_JOIN_EXACT_MIN 8          /* runs beyond this length are first searched for the query's own DNA part (see k_join_dir) */
+#define MTB_JOIN_EXACT_MIN 8          /* diagnostics (k_join_run_hist): runs beyond this length count as long when a query finds its own DNA part in them */
 #endif
 #ifndef MTB_JOIN_COOP_MIN
 #define MTB_JOIN_COOP_MIN 32          /* default of JoinSegArgs::coop_min; MTB_JOIN_COOP_MIN=<n> in the environment of mtb_ctx_create overrides it (A/B runs) */
@@ -237,83 +237,81 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
         if (!PACKED) return v & AAM;
         return dv.kmer_format == 1 ? (((v >> 24) % 21ull) << 24) : (v & 0x1F000000ull);
     };
-    /* first target of the bucket with the query's amino-acid part.  The first eight words of the bucket (one or two 64-byte
-     * sectors; most buckets hold fewer) are fetched with four independent 16-byte loads and counted in registers: one memory
-     * round trip instead of a 3-4 step bisection chain; larger buckets finish by bisection behind the window. */
     uint64_t e_hi[Q];
 #pragma unroll
     for (int u = 0; u < Q; u++) e_hi[u] = hi[u];
-#ifdef MTB_JOIN_DIR_WINDOW       /* measured: no gain over the plain bisection (44-54 ms either way; the kernel is bound by its scattered slot stores) */
+    /* ONE bisection per query, on the whole value: inside a bucket the targets are ordered by (amino-acid part, DNA part), so the lower
+     * bound of the query's own (amino-acid part, DNA part) -- the flat value, or the low 29 bits of a packed word -- lands either ON the
+     * block of targets equal to the query or inside / next to the run of its amino-acid part.
+     *   equal block found: the hamming sum of two DNA parts is 0 exactly when they are equal (every off-diagonal entry of the lookup is
+     *     >= 1, KmerMatcher.h:66-70), so the minimum over the run is 0, the threshold min(2 x 0, 7) = 0 (KmerMatcher.cpp:1136) and the
+     *     selection IS that block: the rest of the run -- thousands of other species for a conserved protein -- is never read;
+     *   no equal target: the run's ends are found by stepping from the landing place (runs are 1-4 entries as a rule; beyond eight steps
+     *     a bisection takes over), then minimum and selection as the reference's loop does them (KmerMatcher.cpp:363-416).
+     * Afterwards [lo[u], e_hi[u]) is exactly the query's candidate set to evaluate (empty: valid[u] = false). */
+    auto tcomp = [&](uint64_t w) -> uint64_t { return PACKED ? (w & 0x1FFFFFFFull) : w; };
+    uint64_t blo[Q];
+#pragma unroll
+    for (int u = 0; u < Q; u++) blo[u] = lo[u];
     {
-        ulonglong2 w[Q][4];
+        uint64_t qc[Q];
 #pragma unroll
-        for (int u = 0; u < Q; u++) {
-            const uint64_t a0 = lo[u] & ~1ull;
+        for (int u = 0; u < Q; u++) qc[u] = PACKED ? (qkey(k[u].value) | (k[u].value & 0xFFFFFFull)) : k[u].value;
+        bool more = false;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                w[u][j] = make_ulonglong2(~0ull, ~0ull);
-                if (lo[u] < hi[u] && a0 + 2 * j < hi[u]) w[u][j] = *(const ulonglong2 *)(ix.values + a0 + 2 * j);
+        for (int u = 0; u < Q; u++) more |= lo[u] < hi[u];
+        while (more) {
+            more = false;
+#pragma unroll
+            for (int u = 0; u < Q; u++) {
+                if (lo[u] < hi[u]) {
+                    const uint64_t mid = lo[u] + ((hi[u] - lo[u]) >> 1);
+                    if (tcomp(ix.values[mid]) < qc[u]) lo[u] = mid + 1; else hi[u] = mid;
+                    more |= lo[u] < hi[u];
+                }
             }
         }
 #pragma unroll
         for (int u = 0; u < Q; u++) {
-            if (lo[u] >= hi[u]) continue;
-            const uint64_t a0 = lo[u] & ~1ull, qk = qkey(k[u].value);
-            uint32_t less = 0, seen = 0;
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const uint64_t idx = a0 + j, word = (j & 1) ? w[u][j >> 1].y : w[u][j >> 1].x;
-                const bool in = idx >= lo[u] && idx < hi[u];
-                seen += in ? 1u : 0u;
-                less += (in && tkey(word) < qk) ? 1u : 0u;
+            if (!valid[u]) continue;
+            const uint64_t p = lo[u], end = e_hi[u], qk = qkey(k[u].value);
+            uint64_t s0 = p, e0 = p;
+            if (p < end && tcomp(ix.values[p]) == qc[u]) {
+                /* the block of targets equal to the query (several species may file the same metamer) */
+                e0 = p + 1;
+                uint32_t n = 0;
+                while (e0 < end && n < 8u && tcomp(ix.values[e0]) == qc[u]) { e0++; n++; }
+                if (n == 8u && e0 < end && tcomp(ix.values[e0]) == qc[u]) {
+                    uint64_t y = end;
+                    while (e0 < y) { const uint64_t mid = e0 + ((y - e0) >> 1); if (tcomp(ix.values[mid]) <= qc[u]) e0 = mid + 1; else y = mid; }
+                }
+            } else {
+                /* the run of the query's amino-acid part around the landing place */
+                uint32_t n = 0;
+                while (s0 > blo[u] && n < 8u && tkey(ix.values[s0 - 1]) == qk) { s0--; n++; }
+                if (n == 8u && s0 > blo[u] && tkey(ix.values[s0 - 1]) == qk) {
+                    uint64_t x = blo[u], y = s0;
+                    while (x < y) { const uint64_t mid = x + ((y - x) >> 1); if (tkey(ix.values[mid]) < qk) x = mid + 1; else y = mid; }
+                    s0 = x;
+                }
+                n = 0;
+                while (e0 < end && n < 8u && tkey(ix.values[e0]) == qk) { e0++; n++; }
+                if (n == 8u && e0 < end && tkey(ix.values[e0]) == qk) {
+                    uint64_t y = end;
+                    while (e0 < y) { const uint64_t mid = e0 + ((y - e0) >> 1); if (tkey(ix.values[mid]) <= qk) e0 = mid + 1; else y = mid; }
+                }
             }
-            if (less < seen || lo[u] + seen >= hi[u]) { lo[u] += less; hi[u] = lo[u]; }        /* answer inside the window (or the bucket ends in it) */
-            else lo[u] += seen;                                                                   /* everything seen is smaller: continue behind the window */
+            lo[u] = s0; e_hi[u] = e0;
+            if (s0 >= e0) valid[u] = false;
         }
     }
-#endif
-    bool more = false;
-#pragma unroll
-    for (int u = 0; u < Q; u++) more |= lo[u] < hi[u];
-    while (more) {
-        more = false;
-#pragma unroll
-        for (int u = 0; u < Q; u++) {
-            if (lo[u] < hi[u]) {
-                const uint64_t mid = lo[u] + ((hi[u] - lo[u]) >> 1);
-                if (tkey(ix.values[mid]) < qkey(k[u].value)) lo[u] = mid + 1; else hi[u] = mid;
-                more |= lo[u] < hi[u];
-            }
-        }
-    }
-    /* Longer candidate runs.  A query whose bucket still holds more than MTB_JOIN_EXACT_MIN entries behind its first candidate finds the
-     * END of its run by a second bisection, and in a run beyond that length it looks its own DNA part up by a third one: inside a run
-     * the targets are ordered by their DNA part, and the hamming sum of two DNA parts is 0 exactly when they are equal (every
-     * off-diagonal entry of the lookup is >= 1, KmerMatcher.h:66-70).  If the query's DNA is there, the minimum over the run is 0, the
-     * threshold min(2 x 0, 7) = 0 (KmerMatcher.cpp:1136) and the selection is exactly the block of equal DNA parts: the run shrinks to
-     * that block, nothing is scanned -- a read of a conserved gene meets its own species' entry among thousands of others.  Runs that
-     * stay longer than sa.coop_min are taken away from the lane (valid[u] = false) and scanned by the wave below. */
-    bool lng[Q];                                     /* (a long run's end replaces the bucket's end in e_hi[u]) */
+    /* runs that are still longer than sa.coop_min (no equal target in a long run: a sequencing error, a variant the index does not hold)
+     * are taken away from the lane and scanned by the wave below */
+    bool lng[Q];
 #pragma unroll
     for (int u = 0; u < Q; u++) {
-        lng[u] = false;
-        if (valid[u] && e_hi[u] > lo[u] && e_hi[u] - lo[u] > (uint64_t)MTB_JOIN_EXACT_MIN) {
-            const uint64_t qk = qkey(k[u].value);
-            uint64_t a = lo[u], b = e_hi[u];
-            while (a < b) { const uint64_t mid = a + ((b - a) >> 1); if (tkey(ix.values[mid]) <= qk) a = mid + 1; else b = mid; }
-            if (a - lo[u] > (uint64_t)MTB_JOIN_EXACT_MIN) {
-                const uint32_t qd = (uint32_t)k[u].value & 0xFFFFFFu;
-                uint64_t x = lo[u], y = a;
-                while (x < y) { const uint64_t mid = x + ((y - x) >> 1); if (((uint32_t)ix.values[mid] & 0xFFFFFFu) < qd) x = mid + 1; else y = mid; }
-                if (x < a && ((uint32_t)ix.values[x] & 0xFFFFFFu) == qd) {
-                    uint64_t x2 = x + 1; y = a;
-                    while (x2 < y) { const uint64_t mid = x2 + ((y - x2) >> 1); if (((uint32_t)ix.values[mid] & 0xFFFFFFu) <= qd) x2 = mid + 1; else y = mid; }
-                    lo[u] = x; a = x2;                      /* the block of equal DNA parts: an ordinary run of hamming-0 candidates from here on */
-                }
-                e_hi[u] = a;
-                if (a - lo[u] > (uint64_t)sa.coop_min) { lng[u] = true; valid[u] = false; }
-            }
-        }
+        lng[u] = valid[u] && e_hi[u] - lo[u] > (uint64_t)sa.coop_min;
+        if (lng[u]) valid[u] = false;
     }
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
@@ -349,15 +347,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
         for (int u = 0; u < Q; u++) {
             rs[u] = 0; re[u] = 0; thr_[u] = 0; cnt[u] = 0;
             if (!valid[u]) continue;
-            const uint64_t s0 = lo[u], end = e_hi[u];
-            const uint64_t aa = qkey(k[u].value);
-            if (s0 >= end) continue;
+            const uint64_t s0 = lo[u], e = e_hi[u];
             const uint64_t v0 = ix.values[s0];
-            if (tkey(v0) != aa) continue;
             mtb_qrows qr; mtb_prepare_query_rows(s_hr, k[u].value, &qr);
             uint32_t mn = mtb_ham_sum(&qr, (uint32_t)v0 & 0xFFFFFFu);
-            uint64_t e = s0 + 1;
-            while (e < end) { const uint64_t v = ix.values[e]; if (tkey(v) != aa) break; const uint32_t h = mtb_ham_sum(&qr, (uint32_t)v & 0xFFFFFFu); mn = h < mn ? h : mn; e++; }
+            for (uint64_t t = s0 + 1; t < e; t++) { const uint32_t h = mtb_ham_sum(&qr, (uint32_t)ix.values[t] & 0xFFFFFFu); mn = h < mn ? h : mn; }
             const uint32_t thr = mtb_ham_threshold(mn);
             uint32_t c = 0;
             for (uint64_t t = s0; t < e; t++) { const uint64_t v = t == s0 ? v0 : ix.values[t]; c += mtb_ham_sum(&qr, (uint32_t)v & 0xFFFFFFu) <= thr ? 1u : 0u; }
@@ -469,7 +463,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
             mtb_slot16 *seg;
             if (LONG) { direct = sa.dcnt[r]; tcap = mtb_lslot_tail(direct, sa.tf); seg = sa.seg + sa.rb[r]; }
             else seg = sa.seg + (uint64_t)r * sa.stride;
-            bool first = ord < direct;
+            const bool offr = !LONG && sa.off && sa.off[r];            /* a read the slot records cannot hold (positions / metamer count) */
+            const uint32_t inc = offr ? tcap + 1u : 1u;
+            bool first = ord < direct && !offr;
             /* one selected candidate -> its slot: `at` = place in the read's tail, or ~0u for the query's ordinal slot */
             auto put = [&](uint64_t t, uint64_t v, uint32_t h, uint32_t at) {
                 const uint32_t td = (uint32_t)v & 0xFFFFFFu;
@@ -503,10 +499,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
                     uint32_t at0 = 0;
                     if (m) {
                         const int leader = __ffsll((unsigned long long)m) - 1;
-                        if ((int)lane == leader) at0 = atomicAdd(&sa.cursor[r], (uint32_t)__popcll(m));
+                        if ((int)lane == leader) at0 = atomicAdd(&sa.cursor[r], (uint32_t)__popcll(m) * inc);
                         at0 = (uint32_t)__shfl((int)at0, leader, 64);
                     }
-                    if (sel) put(s0 + off, ix.values[s0 + off], cb[b] & 15u, own ? ~0u : at0 + (uint32_t)__popcll(m & lt_mask));
+                    if (sel) put(s0 + off, ix.values[s0 + off], cb[b] & 15u, own ? ~0u : (offr ? tcap : at0 + (uint32_t)__popcll(m & lt_mask)));
                 }
                 continue;
             }
@@ -522,10 +518,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
                 uint32_t at0 = 0;
                 if (n_tail) {
                     const int leader = __ffsll((unsigned long long)m) - 1;
-                    if ((int)lane == leader) at0 = atomicAdd(&sa.cursor[r], n_tail);
+                    if ((int)lane == leader) at0 = atomicAdd(&sa.cursor[r], n_tail * inc);
                     at0 = (uint32_t)__shfl((int)at0, leader, 64);
                 }
-                if (sel) put(t, v, h, (first && rk == 0) ? ~0u : at0 + rk - skip);
+                if (sel) put(t, v, h, (first && rk == 0) ? ~0u : (offr ? tcap : at0 + rk - skip));
                 first = false;
             }
         }
@@ -533,16 +529,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
 #pragma unroll
     for (int u = 0; u < Q; u++) {
         if (!valid[u]) continue;
-        const uint64_t s = lo[u], end = e_hi[u];
-        const uint64_t aa = qkey(k[u].value);
-        if (s >= end) continue;
+        const uint64_t s = lo[u], e = e_hi[u];
         uint64_t v0 = ix.values[s];
-        if (tkey(v0) != aa) continue;
         const uint32_t info0 = PACKED ? (uint32_t)(v0 >> MTB_PACK_LOW) : ix.info[s];      /* flat state: issued now, the first candidate is selected more often than not */
         mtb_qrows qr; mtb_prepare_query_rows(s_hr, k[u].value, &qr);
         uint32_t mn = mtb_ham_sum(&qr, (uint32_t)v0 & 0xFFFFFFu);
-        uint64_t e = s + 1;
-        while (e < end) { const uint64_t v = ix.values[e]; if (tkey(v) != aa) break; const uint32_t h = mtb_ham_sum(&qr, (uint32_t)v & 0xFFFFFFu); mn = h < mn ? h : mn; e++; }
+        for (uint64_t t = s + 1; t < e; t++) { const uint32_t h = mtb_ham_sum(&qr, (uint32_t)ix.values[t] & 0xFFFFFFu); mn = h < mn ? h : mn; }
         const uint32_t thr = mtb_ham_threshold(mn);
         const uint32_t r = mtb_q_seq(k[u].qinfo) - 1;
         const uint32_t ord = mtb_q_pos(k[u].qinfo) >> 16;
@@ -552,7 +544,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
         mtb_slot16 *seg;
         if (LONG) { direct = sa.dcnt[r]; tcap = mtb_lslot_tail(direct, sa.tf); seg = sa.seg + sa.rb[r]; }
         else seg = sa.seg + (uint64_t)r * sa.stride;
-        bool first = ord < direct;
+        const bool offr = !LONG && sa.off && sa.off[r];
+        bool first = ord < direct && !offr;
         for (uint64_t t = s; t < e; t++) {
             const uint64_t v = t == s ? v0 : ix.values[t];
             const uint32_t td = (uint32_t)v & 0xFFFFFFu;
@@ -566,7 +559,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
              * these 1.1 G scattered 16-byte stores: 20.5 ms without them, 29 ms with dense stores (profiles/r02_notes.md) */
             if (first) { const mtb_slot16 sl = LONG ? mtb_lslot_pack(qinfo, tid, sp, td, reh, h) : mtb_slot_pack(qinfo, tid, sp, td, reh, h, sa.epoch);
                          MTB_SLOT_STORE(sl, &seg[ord]); first = false; continue; }
-            const uint32_t at = atomicAdd(&sa.cursor[r], 1u);
+            const uint32_t at = offr ? (atomicAdd(&sa.cursor[r], tcap + 1u), tcap) : atomicAdd(&sa.cursor[r], 1u);
             if (at < tcap) { const mtb_slot16 sl = LONG ? mtb_lslot_pack(qinfo, tid, sp, td, reh, h) : mtb_slot_pack(qinfo, tid, sp, td, reh, h, sa.epoch);
                              MTB_SLOT_STORE(sl, &seg[direct + at]); }
             else {

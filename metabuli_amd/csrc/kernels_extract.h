@@ -45,7 +45,7 @@ __global__ __launch_bounds__(64) void k_extract(ExtractArgs a, const mtb_tables 
                                                 mtb_kmer *__restrict__ out, int32_t *__restrict__ qlen,
                                                 int32_t *__restrict__ qlen2, uint32_t *__restrict__ max_len,
                                                 unsigned long long *__restrict__ counter, uint64_t out_cap,
-                                                uint16_t *__restrict__ dig_out = nullptr) {
+                                                uint16_t *__restrict__ dig_out = nullptr, uint8_t *__restrict__ off_flags = nullptr) {
     constexpr bool EMIT = MODE != 0;
     constexpr bool STATS = MODE != 1;             /* qlen / max_len are produced by the count pass or the single pass */
     __shared__ mtb_kmer s_out[MODE == 2 ? MTB_EXTRACT_BUF : 1];
@@ -94,6 +94,7 @@ __global__ __launch_bounds__(64) void k_extract(ExtractArgs a, const mtb_tables 
     for (uint32_t i = lane; i < sizeof(mtb_tables) / 4; i += 64) ((uint32_t *)&s_tab)[i] = ((const uint32_t *)tabs)[i];
     __syncthreads();
     uint32_t my_max = 0, my_maxq = 0;
+    uint32_t el_max = 0, el_maxq = 0, n_off = 0;       /* single pass with off_flags: maxima over the reads the slot segments can hold, and the others counted */
     const bool paired = a.seq_mode == 2;
     for (uint64_t r = blockIdx.x; r < a.n_reads; r += gridDim.x) {
         cur_read = r; reads_done++;
@@ -227,12 +228,20 @@ __global__ __launch_bounds__(64) void k_extract(ExtractArgs a, const mtb_tables 
         }
         if ((MODE == 0 || (MODE == 2 && counts)) && lane == 0) counts[r] = total;      /* single pass: only the long-read slot path asks for them */
         my_maxq = total > my_maxq ? total : my_maxq;
+        if (MODE == 2 && off_flags) {
+            /* a read whose positions do not fit the 12-bit field of a slot record, or with more metamers than a slot segment has direct
+             * slots for, is marked: the join files its matches in the overflow list, it is scored from an exact segment (mtb_api.hip) */
+            const uint32_t tl = (uint32_t)(ql1 + ql2);
+            if (tl + 3u >= MTB_SLOT_MAX_POS || total > MTB_SLOT_MAX_Q) { if (lane == 0) off_flags[r] = 1; n_off++; }
+            else { el_max = tl > el_max ? tl : el_max; el_maxq = total > el_maxq ? total : el_maxq; }
+        }
     }
     flush();
     if (MODE == 2) {
         mtb_kmer blank; blank.value = 0; blank.qinfo = 0;
         if (!overflow) for (uint64_t i = chunk_pos + threadIdx.x; i < chunk_end; i += 64) { out[i] = blank; if (dig_out) dig_out[i] = 0; }
-        if (threadIdx.x == 0) { if (overflow) counter[1] = 1ull; else atomicAdd(counter + 2, (unsigned long long)produced); atomicMax(counter + 3, (unsigned long long)my_maxq); }
+        if (threadIdx.x == 0) { if (overflow) counter[1] = 1ull; else atomicAdd(counter + 2, (unsigned long long)produced); atomicMax(counter + 3, (unsigned long long)my_maxq);
+                                if (off_flags) { atomicMax(counter + 4, (unsigned long long)el_maxq); if (n_off) atomicAdd(counter + 5, (unsigned long long)n_off); atomicMax(counter + 6, (unsigned long long)el_max); } }
     }
     if (STATS && max_len) {
         for (int d = 32; d > 0; d >>= 1) { uint32_t o = __shfl_down(my_max, d, 64); my_max = o > my_max ? o : my_max; }

@@ -73,6 +73,8 @@ struct JoinSegArgs {
     const uint64_t *rb; const uint32_t *dcnt; uint32_t tf;
     uint32_t list;      /* k_join_dir<.., 2>: matches go to the dense list ovf[0 .. ovf_cap) (owner side of the partitioned index) */
     uint32_t coop_min;  /* k_join_dir: candidate runs longer than this are scanned by the whole wave (kernels_dir.h) */
+    const uint8_t *off; /* k_join_dir, fixed segments: reads marked here never use their slots -- every match goes to the overflow list and the read's
+                         * tail cursor is pushed beyond the tail's capacity, so that the scorers hand the read to the exact-segment path */
 };
 
 #ifdef MTB_SCORE_PHASE_CYCLES

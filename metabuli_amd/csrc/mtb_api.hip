@@ -86,6 +86,7 @@ struct mtb_ctx {
     mtb_tables *d_tabs = nullptr;
     mtb_tables h_tabs;
     std::map<std::string, DevBuf> bufs;
+    std::mutex bufs_mu;              /* the buffer table may be grown from a helper thread (mtb_ctx_reserve) while the context's thread opens an index */
     uint64_t *d_scal = nullptr;      /* [0] match counter, [1] overflow, [2] n_large, [3] max_seg, [4] max_len, [5] n_big */
     uint64_t *d_xscal = nullptr;     /* = d_scal + 8: single-pass extraction counters */
     hipEvent_t ev[8];
@@ -118,10 +119,11 @@ struct mtb_ctx {
 };
 /* buffers that carry a call's inputs / outputs (host-buffer entry points) are not workspace */
 static bool is_io_buf(const std::string &n) { return n == "bases" || n == "offs" || n == "bases2" || n == "offs2" || n == "results" || n == "tctax" || n == "tccnt" || n.compare(0, 2, "pk") == 0; }
-static size_t held_bytes(const mtb_ctx *c) { size_t b = 0; for (auto &kv : c->bufs) if (!is_io_buf(kv.first)) b += kv.second.cap; return b; }
+static size_t held_bytes(mtb_ctx *c) { std::lock_guard<std::mutex> lk(c->bufs_mu); size_t b = 0; for (auto &kv : c->bufs) if (!is_io_buf(kv.first)) b += kv.second.cap; return b; }
 /* the part of it that grows with the sub-batch (the slab pool of the large-segment scorer is bounded on its own) */
-static size_t scaling_bytes(const mtb_ctx *c) { size_t b = 0; for (auto &kv : c->bufs) if (!is_io_buf(kv.first) && kv.first != "slabs") b += kv.second.cap; return b; }
+static size_t scaling_bytes(mtb_ctx *c) { std::lock_guard<std::mutex> lk(c->bufs_mu); size_t b = 0; for (auto &kv : c->bufs) if (!is_io_buf(kv.first) && kv.first != "slabs") b += kv.second.cap; return b; }
 static void release_workspace(mtb_ctx *c) {
+    std::lock_guard<std::mutex> lk(c->bufs_mu);
     for (auto &kv : c->bufs) if (kv.second.p && !is_io_buf(kv.first)) { hipError_t e = hipFree(kv.second.p); (void)e; kv.second.p = nullptr; kv.second.cap = 0; }
     c->ws_per_base = 0.0; c->ws_max_sub_bases = 0;
 }
@@ -182,6 +184,7 @@ struct mtb_index {
 
 template <typename T>
 static mtb_status ensure(mtb_ctx *c, const char *name, size_t elems, T **out) {
+    std::lock_guard<std::mutex> lk(c->bufs_mu);
     DevBuf &b = c->bufs[name];
     size_t bytes = elems * sizeof(T);
     if (bytes == 0) bytes = 64;
@@ -310,6 +313,7 @@ static mtb_status ensure_placed(mtb_ctx *c, const char *name, size_t elems, mtb_
     return MTB_OK;
 }
 static void release(mtb_ctx *c, const char *name) {
+    std::lock_guard<std::mutex> lk(c->bufs_mu);
     auto it = c->bufs.find(name);
     if (it != c->bufs.end()) { if (it->second.p) { hipError_t e = hipFree(it->second.p); (void)e; } c->bufs.erase(it); }
 }
@@ -418,6 +422,15 @@ static mtb_status h2d(mtb_ctx *c, void *dst, const void *src, size_t bytes) {
 /* fused-path sort: first pass on the top letter pair, the two lower pairs bucket-local (kernels_sort.h); MTB_SORT_LSD=1: the three LSD passes of round 2 (A/B) */
 static bool sort_msd_first() { static const bool lsd = getenv("MTB_SORT_LSD") != nullptr; return !lsd; }
 
+/* records the single-pass extractor's output buffer is sized for: six frames x L/3 windows bound the output by 2 metamers per base;
+ * syncmer selection keeps about half of them, so the buffer follows the previous batch's yield (first batch of a context: < 1 metamer
+ * per base with s = 5 -- 0.86 measured --, 2 in dense mode) and the extractor reports an overflow if that was too optimistic */
+static uint64_t extract_bound(uint64_t n_bases, uint32_t grid) { return 2 * n_bases + (uint64_t)grid * MTB_EXTRACT_CHUNK; }      /* + at most one partly used chunk per wave */
+static uint64_t extract_cap_guess(const mtb_ctx *c, const mtb_params *p, uint64_t n_bases, uint32_t grid) {
+    const double guess = c->extract_yield > 0.0 ? c->extract_yield : (p->syncmer ? 1.0 : 2.0);
+    return std::min<uint64_t>(extract_bound(n_bases, grid), (uint64_t)((double)n_bases * guess * 1.15) + 4096 + (uint64_t)grid * 64);
+}
+
 /* extract.  Result in buffer "kmersA".  Two passes (counts -> offsets -> emit) give the reference's emission order
  * (stage API); `single_pass` (fused path, n_bases = bases of the batch) runs the arithmetic once and lets every
  * wave reserve its output with an atomic: run order arbitrary, which the radix sort does not mind. */
@@ -426,7 +439,9 @@ static mtb_status dev_extract(mtb_ctx *c, const mtb_params *p, const char *d_bas
                               int32_t *d_qlen2, uint32_t *max_len, bool single_pass = false, uint64_t n_bases = 0,
                               uint64_t *real_count = nullptr, bool tag_ord = false, uint32_t *max_q = nullptr, uint16_t **dig = nullptr,
                               uint32_t *d_counts = nullptr /* single pass: metamers per read (long-read slot path) */,
-                              uint64_t *n_bases_exact = nullptr /* single pass: bases of the read range, from its offsets */) {
+                              uint64_t *n_bases_exact = nullptr /* single pass: bases of the read range, from its offsets */,
+                              uint8_t *d_off = nullptr /* tagged single pass: reads the slot records cannot hold are marked here ... */,
+                              uint64_t *off_stats = nullptr /* ... [0] most metamers of an unmarked read, [1] marked reads, [2] longest unmarked read */) {
     if (n_reads >= (1ull << 29)) return fail(MTB_ERR_ARG, "more than 2^29-1 reads per batch (sequenceID is 29 bits, Kmer.h:13)");
     if (p->kmer_format != 1 && p->kmer_format != 2) return fail(MTB_ERR_UNSUPPORTED, "only kmer_format 1 and 2 are implemented");
     if (p->syncmer && (p->smer_len < 1 || p->smer_len > 8)) return fail(MTB_ERR_ARG, "smer_len out of range");
@@ -448,22 +463,22 @@ static mtb_status dev_extract(mtb_ctx *c, const mtb_params *p, const char *d_bas
     if (single_pass && n_bases) {
         /* six frames x L/3 windows bound the output by 2 metamers per base; syncmer selection keeps about half of them:
          * size the buffer from the previous batch's yield and fall back to the bound if that was too optimistic */
-        const uint64_t bound = 2 * n_bases + (uint64_t)grid * MTB_EXTRACT_CHUNK;      /* + at most one partly used chunk per wave */
-        /* first batch of a context: syncmer selection keeps < 1 metamer per base (0.86 measured with s = 5), dense mode 2 */
-        const double guess = c->extract_yield > 0.0 ? c->extract_yield : (p->syncmer ? 1.0 : 2.0);
-        uint64_t cap = std::min<uint64_t>(bound, (uint64_t)((double)n_bases * guess * 1.15) + 4096 + (uint64_t)grid * 64);
+        const uint64_t bound = extract_bound(n_bases, grid);
+        uint64_t cap = extract_cap_guess(c, p, n_bases, grid);
         cap = std::max<uint64_t>(cap, std::min<uint64_t>(bound, c->bufs["kmersA"].cap / sizeof(mtb_kmer)));
         for (int attempt = 0; attempt < 2; attempt++) {
             mtb_kmer *d_k; uint16_t *d_dig = nullptr;
             STCHK(ensure(c, "kmersA", cap, &d_k));
             if (dig) { STCHK(ensure(c, "digA", cap + 8, &d_dig)); *dig = d_dig; }      /* (+8: the bucket-local histograms read whole 16-byte chunks) */
-            HIPCHK(hipMemsetAsync(c->d_xscal, 0, 32, c->stream));
+            HIPCHK(hipMemsetAsync(c->d_xscal, 0, 64, c->stream));
+            if (d_off) HIPCHK(hipMemsetAsync(d_off, 0, n_reads, c->stream));
             { KTimer kt(c, MTB_K_EXTRACT_EMIT);
             hipLaunchKernelGGL((k_extract<2>), dim3(grid), dim3(64), 0, c->stream, a, c->d_tabs, d_counts, (const uint64_t *)nullptr,
-                               d_k, d_qlen, d_qlen2, (uint32_t *)(c->d_scal + 4), (unsigned long long *)c->d_xscal, cap, d_dig); }
+                               d_k, d_qlen, d_qlen2, (uint32_t *)(c->d_scal + 4), (unsigned long long *)c->d_xscal, cap, d_dig, d_off); }
             HIPCHK(hipGetLastError());
-            uint64_t sc[4];
-            STCHK(d2h(c, sc, c->d_xscal, 32));             /* records allocated (incl. blank tails), overflow, real metamers */
+            uint64_t sc[8];
+            STCHK(d2h(c, sc, c->d_xscal, 64));             /* records allocated (incl. blank tails), overflow, real metamers, most metamers of a read; marked-read statistics */
+            if (off_stats) { off_stats[0] = sc[4]; off_stats[1] = sc[5]; off_stats[2] = sc[6]; }
             if (max_len) { uint64_t ml = 0; STCHK(d2h(c, &ml, c->d_scal + 4, 8)); *max_len = (uint32_t)ml; }
             if (sc[1] == 0) {
                 if (sc[0] >= (1ull << 32)) return fail(MTB_ERR_ARG, "more than 2^32-1 query metamers in one batch; split the batch");
@@ -760,7 +775,8 @@ struct ScoreSrc {
 typedef std::function<mtb_status(ScoreSrc *, bool *)> ScoreSecond;
 static mtb_status dev_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, uint64_t n_reads, const int32_t *d_qlen, const int32_t *d_qlen2,
                             uint32_t max_len, mtb_result *d_res, int32_t *d_tc_tax, uint32_t *d_tc_cnt, uint64_t tc_cap, uint64_t *n_tc,
-                            uint64_t tc_base, const ScoreSrc &first, const ScoreSecond *second) {
+                            uint64_t tc_base, const ScoreSrc &first, const ScoreSecond *second,
+                            uint32_t max_len_second = 0 /* the deferred reads' launch may meet longer reads than the first one (reads routed around the slot segments) */) {
     mtb_score_params sp; mtb_make_score_params(p, &sp);
     uint32_t *d_bound; uint64_t *d_tcoff; uint64_t *d_ws;
     STCHK(ensure(c, "bound", n_reads, &d_bound));
@@ -776,10 +792,12 @@ static mtb_status dev_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, uint
     if (tc_base + tot >= (1ull << 32)) return fail(MTB_ERR_ARG, "more than 2^32-1 taxcnt slots in one batch (mtb_result.taxcnt_off is 32 bits); split the batch");
     /* single-word sort key when taxids < 2^22 and positions < 2^11 (hamming of a match is <= 7) */
     const bool key64 = ix->tax.max_id < (1 << 22) && max_len + 3 < (1u << 11);
-    const uint32_t max_nb = (uint32_t)mtb_num_buckets((int32_t)max_len, sp.dna_shift);
-    if (max_nb > 65535u) return fail(MTB_ERR_ARG, "read too long for mtb_result.n_taxcnt (16 bits): more than 65535 position buckets");
+    const uint32_t max_nb_first = (uint32_t)mtb_num_buckets((int32_t)max_len, sp.dna_shift);
+    const uint32_t max_nb_second = (uint32_t)mtb_num_buckets((int32_t)std::max(max_len, max_len_second), sp.dna_shift);
+    if (max_nb_second > 65535u) return fail(MTB_ERR_ARG, "read too long for mtb_result.n_taxcnt (16 bits): more than 65535 position buckets");
     ScoreSrc second_src;
     for (int pass = 0; pass < 2; pass++) {
+        const uint32_t max_nb = pass ? max_nb_second : max_nb_first;
         const ScoreSrc *S = &first;
         if (pass == 1) {
             if (!second) break;
@@ -1819,7 +1837,8 @@ static void slot_geometry(uint32_t max_q, uint32_t *direct, uint32_t *stride) {
  * d_rc = per-read tail cursors, d_ovf / n_ovf = the overflow list.  *nm = matches seen (statistics). */
 static mtb_status score_fixed_slots(mtb_ctx *c, mtb_index *ix, const mtb_params *p, uint64_t n_reads, const int32_t *d_ql, const int32_t *d_ql2, uint32_t max_len,
                                     uint64_t nk_real, mtb_slot16 *d_segm, uint32_t *d_rc, uint32_t stride, uint32_t direct, uint32_t epoch, mtb_match *d_ovf, uint64_t n_ovf,
-                                    mtb_result *d_results, int32_t *d_taxcnt_tax, uint32_t *d_taxcnt_cnt, uint64_t taxcnt_cap, uint64_t *n_taxcnt, uint64_t tc_base, uint64_t *nm_out) {
+                                    mtb_result *d_results, int32_t *d_taxcnt_tax, uint32_t *d_taxcnt_cnt, uint64_t taxcnt_cap, uint64_t *n_taxcnt, uint64_t tc_base, uint64_t *nm_out,
+                                    uint32_t max_len_deferred = 0) {
     hipStream_t st = c->stream;
     uint64_t nm = 0;
     uint32_t *d_biglist, *d_bigcnt, *d_bigidx, *d_bigcur, *d_cnt; uint64_t *d_bigstart = nullptr, *d_ws2, *d_tot; mtb_match *d_big = nullptr;
@@ -1875,7 +1894,7 @@ static mtb_status score_fixed_slots(mtb_ctx *c, mtb_index *ix, const mtb_params 
         b->sort = false; b->max_seg = (uint32_t)mx; b->grid = std::min<uint32_t>(n_big, 256u * 14u);
         return MTB_OK;
     };
-    STCHK(dev_score(c, ix, p, n_reads, d_ql, d_ql2, max_len, d_results, d_taxcnt_tax, d_taxcnt_cnt, taxcnt_cap, n_taxcnt, tc_base, a, &second));
+    STCHK(dev_score(c, ix, p, n_reads, d_ql, d_ql2, max_len, d_results, d_taxcnt_tax, d_taxcnt_cnt, taxcnt_cap, n_taxcnt, tc_base, a, &second, max_len_deferred));
     /* number of matches (statistics): live records seen by the first launch + the deferred reads' segments */
     { KTimer kt(c, MTB_K_SCAN); scan_launch<uint32_t, uint64_t, false>(st, d_cnt, n_reads, true, d_tot, d_ws2); }
     STCHK(d2h(c, &nm, d_tot + n_reads, 8));
@@ -1932,8 +1951,20 @@ static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, c
     uint16_t *d_dig = nullptr;               /* first radix pass's digits, written by the single-pass extractor */
     const bool aa6 = p->kmer_format == 2;           /* 5-bit amino-acid letters: three base-21 pair passes order bits [34,64) */
     uint64_t n_bases_exact = n_bases_total;      /* the caller's figure is an estimate for a sub-batch of variable-length reads: the budget is kept on the exact one */
-    STCHK(dev_extract(c, p, d_bases, d_offs, d_bases2, d_offs2, n_reads, &d_k, &nk, d_ql, d_ql2, &max_len, true, n_bases_total, &nk_real, fixed || lslot, &max_q, aa6 ? &d_dig : nullptr, d_dcnt, &n_bases_exact));
-    if ((fixed && (max_len + 3 >= MTB_SLOT_MAX_POS || max_q > 384)) || (lslot && (max_len + 3 >= 65536u || max_q >= 65535u))) {
+    /* short-read batches: reads whose positions do not fit a slot record (>= 4093 used bases) or that carry more metamers than a segment
+     * has direct slots for are marked by the extractor and routed AROUND the slot segments one by one (join: overflow list; scoring:
+     * exact segments) -- a handful of long reads in an Illumina batch no longer send the whole batch down the exact-segment path */
+    uint8_t *d_off = nullptr; uint64_t off_stats[3] = {0, 0, 0};
+    if (fixed && ix->d_dir) STCHK(ensure(c, "offreads", n_reads, &d_off));
+    STCHK(dev_extract(c, p, d_bases, d_offs, d_bases2, d_offs2, n_reads, &d_k, &nk, d_ql, d_ql2, &max_len, true, n_bases_total, &nk_real, fixed || lslot, &max_q, aa6 ? &d_dig : nullptr, d_dcnt, &n_bases_exact,
+                      d_off, off_stats));
+    uint32_t max_len_all = max_len;
+    bool route_off = false;
+    if (fixed && d_off && off_stats[1] > 0 && off_stats[1] * 4 <= n_reads && max_len + 3 < 65536u && max_q < 65535u && off_stats[1] < n_reads) {
+        route_off = true;
+        max_q = (uint32_t)off_stats[0]; max_len = (uint32_t)off_stats[2];       /* the slot geometry and the first scoring launch follow the reads that use the slots */
+    }
+    if ((fixed && !route_off && (max_len + 3 >= MTB_SLOT_MAX_POS || max_q > MTB_SLOT_MAX_Q)) || (lslot && (max_len + 3 >= 65536u || max_q >= 65535u))) {
         fixed = false; lslot = false;      /* tags would collide with positions / segments would be huge: extract again untagged */
         STCHK(dev_extract(c, p, d_bases, d_offs, d_bases2, d_offs2, n_reads, &d_k, &nk, d_ql, d_ql2, &max_len, true, n_bases_total, &nk_real, false, &max_q, aa6 ? &d_dig : nullptr));
     }
@@ -1965,7 +1996,7 @@ static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, c
             STCHK(ensure(c, "ovf", ovf_cap, &d_ovf));
             JoinSegArgs sa; memset(&sa, 0, sizeof(sa));
             sa.seg = d_segm; sa.stride = stride; sa.direct = direct; sa.cursor = d_rc; sa.ovf = d_ovf; sa.ovf_cap = ovf_cap;
-            sa.ovf_counter = nullptr; sa.epoch = epoch;
+            sa.ovf_counter = nullptr; sa.epoch = epoch; sa.off = route_off ? d_off : nullptr;
             mtb_status s2 = dev_join(c, ix, d_s, nk, nullptr, 0, nullptr, &n_ovf, &sa, low_bits);
             if (s2 == MTB_OK) break;
             if (s2 != MTB_ERR_CAPACITY || attempt == 2) return s2;
@@ -1976,7 +2007,7 @@ static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, c
         HIPCHK(hipEventRecord(c->ev[4], st));
         HIPCHK(hipEventRecord(c->ev[5], st));
         STCHK(score_fixed_slots(c, ix, p, n_reads, d_ql, d_ql2, max_len, nk_real, d_segm, d_rc, stride, direct, epoch, d_ovf, n_ovf,
-                                d_results, d_taxcnt_tax, d_taxcnt_cnt, taxcnt_cap, n_taxcnt, tc_base, &nm));
+                                d_results, d_taxcnt_tax, d_taxcnt_cnt, taxcnt_cap, n_taxcnt, tc_base, &nm, route_off ? max_len_all : 0));
     } else if (lslot) {
         /* ---- long reads on ordinal slots: join into per-read slot ranges, order every range by a stable species partition, score ---- */
         uint32_t *d_sizes; uint64_t *d_rb, *d_ws2; uint32_t *d_live;
@@ -2820,6 +2851,39 @@ mtb_status mtb_ctx_join_run_histogram(mtb_ctx *c, mtb_index *ix, uint64_t *hist6
     }
     (void)hipFree(d_h);
     return st;
+}
+
+/* db.parameters of a database directory applied to *p (what mtb_index_open does first), without opening anything */
+mtb_status mtb_db_parameters(const char *dbdir, mtb_params *p) {
+    if (!dbdir || !p) return fail(MTB_ERR_ARG, "NULL argument");
+    int reduced = 0;
+    mtbhost::load_db_parameters(dbdir, p, &reduced);
+    return MTB_OK;
+}
+
+/* Grows the big workspace buffers of a short-read batch of that size ahead of time: the metamer buffers of the extractor and the sort,
+ * their digit arrays, the slot segments (hipMalloc of ~35 GB for 4 M reads costs several hundred milliseconds -- the first batch of a
+ * run used to pay them).  The sizes are those the first batch will ask for if its reads look like the estimate; a batch that needs
+ * more simply grows a buffer as before.  MAY BE CALLED FROM ANOTHER THREAD while the context's thread is inside mtb_index_open (the
+ * buffer table is locked per access): a driver hides the allocations behind the database load. */
+mtb_status mtb_ctx_reserve(mtb_ctx *c, const mtb_params *p, uint64_t n_reads, uint64_t n_bases) {
+    if (!c || !p) return fail(MTB_ERR_ARG, "NULL argument");
+    if (n_reads == 0 || n_bases == 0 || p->seq_mode == 3) return MTB_OK;
+    HIPCHK(hipSetDevice(c->device));
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(n_reads, 256ull * 256);
+    const uint64_t cap = extract_cap_guess(c, p, n_bases, grid);
+    mtb_kmer *k; uint16_t *dg; mtb_slot16 *sg;
+    STCHK(ensure(c, "kmersA", cap, &k)); STCHK(ensure(c, "kmersB", cap, &k));
+    if (p->kmer_format == 2) { STCHK(ensure(c, "digA", cap + 8, &dg)); STCHK(ensure(c, "digB", cap + 8, &dg)); }
+    /* slot segments: metamers of the longest read guessed from the mean length (six frames of L/3 - 7 windows per mate; syncmer
+     * selection keeps a little over half), one direct slot each + the tail */
+    const int mates = p->seq_mode == 2 ? 2 : 1;
+    const double L = (double)n_bases / (double)n_reads / mates;
+    const double per_read = std::max(0.0, L / 3.0 - 7.0) * 6.0 * mates * (p->syncmer ? 0.56 : 1.0) * 1.10;
+    uint32_t direct, stride;
+    slot_geometry((uint32_t)std::min<double>(per_read, (double)MTB_SLOT_MAX_Q), &direct, &stride);
+    STCHK(ensure(c, "segm", n_reads * (uint64_t)stride, &sg));
+    return MTB_OK;
 }
 
 mtb_status mtb_last_batch_stats(mtb_ctx *c, mtb_batch_stats *out) {

@@ -306,6 +306,7 @@ MTB_HD void mtb_join_find(const uint64_t *v, uint64_t n, uint64_t qvalue, uint64
  *   b = epoch[59..63] ham[55..58] frame[52..54] pos[40..51] right_end_hamming[24..39] dna[0..23]                  */
 typedef struct { uint64_t a, b; } mtb_slot16;
 #define MTB_SLOT_MAX_POS 4096u
+#define MTB_SLOT_MAX_Q 384u         /* metamers of a read that its slot segment has direct slots for (the register-resident scorer's widest instantiation) */
 #define MTB_SLOT_EPOCHS 31u
 MTB_HD mtb_slot16 mtb_slot_pack(uint64_t qinfo, int32_t target_id, int32_t species_id, uint32_t dna, uint32_t reh, uint32_t ham, uint32_t epoch) {
     mtb_slot16 s;

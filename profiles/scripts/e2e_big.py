@@ -13,7 +13,11 @@ MR = (sys.argv[4] if len(sys.argv) > 4 else "2000000,4000000").split(",")
 dev = torch.device("cuda", 0)
 ctx = M.Context(0)
 params = M.default_params(seq_mode=1, syncmer=1, smer_len=5)
-work = "/dev/shm/mtb_e2e_big"
+# the box's local disk if it has room for the database + the reads + the output (its page cache then holds them: 3 TB of RAM), else /dev/shm
+need = T_WANT * 9.6 + N * 330 + N * 70
+base = "/tmp" if shutil.disk_usage("/tmp").free > 1.3 * need else "/dev/shm"
+work = os.path.join(base, "mtb_e2e_big")
+print(f"working directory {work} ({shutil.disk_usage(base).free / 2**30:.0f} GiB free; {need / 2**30:.0f} GiB needed)", flush=True)
 shutil.rmtree(work, ignore_errors=True)
 db = os.path.join(work, "db"); os.makedirs(os.path.join(db, "taxonomy"))
 world = bench.build_world(1234, 8, 500000, 5000)

@@ -626,6 +626,53 @@ def test_index_clone_is_an_independent_equal_copy(toy, monkeypatch, state):
     cp.close(); b.close()
 
 
+@pytest.mark.parametrize("paired", [False, True])
+def test_a_few_long_reads_do_not_send_the_batch_down_the_exact_path(orc, tmp_path, paired):
+    """one read of >= 4093 used bases (positions beyond a slot record's 12 bits) or with more than 384 metamers used
+    to send the WHOLE short-read batch through a second extraction and the exact-segment path.  Now the extractor marks such reads,
+    the join files their matches in the overflow list and only they are scored from exact segments: the batch stays on the slot
+    path and every read -- 150 bp, 600 bp, 5 kb, 9 kb -- gets the oracle's answer."""
+    import metabuli_amd as M
+    from conftest import Toy
+    from metabuli_amd import synth
+    t = Toy(orc, tmp_path / "db", syncmer=1, paired=paired, seed=41, n_reads=300)
+    rng = np.random.default_rng(9)
+    # splice longer reads (both mates long for pairs) into the batch at scattered places
+    extra_at = {5: 5000, 77: 600, 150: 9000, 151: 700, 299: 4200}
+    def rebuild(b, o):
+        seqs = [b[int(o[i]):int(o[i + 1])] for i in range(len(o) - 1)]
+        for at, L in extra_at.items():
+            tid, g = t.world.genomes[at % len(t.world.genomes)]
+            st = int(rng.integers(0, len(g) - L))
+            seqs[at] = synth.mutate(rng, g[st:st + L], 0.01)
+        oo = np.zeros(len(seqs) + 1, np.uint64); oo[1:] = np.cumsum([len(x) for x in seqs])
+        return np.concatenate(seqs), oo
+    b1, o1 = rebuild(t.b1, t.o1)
+    b2, o2 = rebuild(t.b2, t.o2) if paired else (None, None)
+    ref = orc.classify(t.db, t.tax, t.p, b1, o1, b2, o2)
+    c = M.Context(0)
+    p = _params(t)
+    ix = c.open_index(t.dbdir, p)
+    res, tt, tc = c.classify_batch(ix, p, b1, o1, b2, o2)
+    st = c.last_stats()
+    assert st.n_slot_reads == 300                                  # the batch kept its slot segments
+    ro = ref["results"]; amb = ro["flag"] != 0
+    assert ((res["classification"] == ro["classification"]) | amb).all()
+    assert ((res["score"].view(np.uint32) == ro["score"].view(np.uint32)) | amb).all()
+    assert (res["qlen"] == ro["qlen"]).all() and (res["qlen2"] == ro["qlen2"]).all()
+    assert ((res["n_taxcnt"] == ro["n_taxcnt"]) | amb).all()
+    assert st.n_matches == len(ref["matches"])
+    for at in extra_at:
+        assert res["is_classified"][at] == ro["is_classified"][at] == 1
+    # a batch made of long reads only still takes the whole-batch route (nothing to keep the slots for)
+    sel = sorted(extra_at)
+    bl = np.concatenate([b1[int(o1[i]):int(o1[i + 1])] for i in sel]); ol = np.zeros(len(sel) + 1, np.uint64); ol[1:] = np.cumsum([int(o1[i + 1] - o1[i]) for i in sel])
+    if not paired:
+        r2, _, _ = c.classify_batch(ix, p, bl, ol)
+        assert (r2["classification"] == ro["classification"][sel]).all() and c.last_stats().n_slot_reads == 0
+    ix.close(); c.close()
+
+
 def test_slot_epoch_wraps_without_stale_matches(toy, orc):
     """the slot segments of the fused path are never cleared between batches: live slots carry a 5-bit epoch tag that
     wraps every 31 batches.  40 batches on one context, alternating two different read sets, must keep giving the
