@@ -873,6 +873,13 @@ def main():
         finish(dist, line if rank == 0 else None)
         return
 
+    if hasattr(M.lib(), "mtb_debug_phase_cycles"):        # profiling build (MTB_LIB=.../libmtb_prof.so): where the join's cycles go
+        import ctypes
+        pc = (ctypes.c_ulonglong * 24)()
+        M.lib().mtb_debug_phase_cycles(ctx.h, pc)
+        jt = max(1, sum(pc[16:21]))
+        log("[rank 0] k_join_dir phase cycles (thread 0 of every workgroup): " + ", ".join(
+            f"{n} {100.0 * pc[16 + i] / jt:.1f} %" for i, n in enumerate(("queries + directory", "bisection", "run ends", "wave-scanned runs", "per-lane evaluation + emission"))))
     wl_key = ("diversity" if big_world else "default") + ("" if args.seq_mode == 1 else f"_mode{args.seq_mode}")
     ps, kern, roofline, roofline_all, footprint, query_runs = profiled_step(ctx, M, index, params, step, args.streams, wl_key,
                                                                            (args.reads, args.read_len, int(T), args.seq_mode))

@@ -309,10 +309,10 @@ int main(int argc, char **argv) {
         /* the parser starts before the database is opened: the first batches are parsed (and their pinned buffers allocated) while the
          * index streams into HBM, so the GPU stage finds work waiting when the open returns */
         double t_parse = 0, t_gpu = 0, t_write = 0, t_dev = 0, t_fmt = 0, t_app = 0;  /* busy time of the three stages; device time inside the GPU stage */
-        Channel<Job> parsed(2), scored(2), idle((size_t)gpu_workers + 4);
+        Channel<Job> parsed(2), scored(2), idle((size_t)gpu_workers + 6);
         /* a few batches are in flight (parse / GPU workers / format); their buffers are recycled, so that after the first round no stage
          * touches fresh pages, and what crosses PCIe sits in pinned memory */
-        for (int k = 0; k < gpu_workers + 3; k++) { std::unique_ptr<Job> j(new Job()); if (pack) j->pin(); idle.put(std::move(j)); }
+        for (int k = 0; k < gpu_workers + 5; k++) { std::unique_ptr<Job> j(new Job()); if (pack) j->pin(); idle.put(std::move(j)); }
         mtbhost::WorkerPool parse_pool(threads), format_pool(threads);
         mtbhost::PackTable pack_table;
         { static mtb_tables tabs; mtb_build_tables(&tabs); for (int c = 0; c < 256; c++) pack_table.code[c] = tabs.base[c] < 4 ? tabs.base[c] : 0xFF; }
@@ -522,7 +522,7 @@ int main(int argc, char **argv) {
         auto failed = [&] { std::lock_guard<std::mutex> l(gpu_err_mu); return !gpu_err.empty(); };
         /* worker w takes batches w, w + W, ...; the collector hands them on in that order */
         std::vector<std::unique_ptr<Channel<Job>>> win, wout;
-        for (int w = 0; w < W; w++) { win.emplace_back(new Channel<Job>(1)); wout.emplace_back(new Channel<Job>(1)); }
+        for (int w = 0; w < W; w++) { win.emplace_back(new Channel<Job>(2)); wout.emplace_back(new Channel<Job>(1)); }      /* (two in: the batch behind the one in work must already be there for its prefetch) */
         std::vector<std::thread> workers;
         /* the batch behind the one in work starts crossing PCIe before that one's kernels are launched (mtb_prefetch_batch_packed: copy
          * stream + second input buffer set inside the context), so its upload is hidden behind them */

@@ -209,6 +209,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
     __shared__ uint32_t s_hr[8];                    /* hammingLookup rows as nibble words: the only table the join arithmetic reads */
     if (threadIdx.x < 8) s_hr[threadIdx.x] = tabs->hamrow[threadIdx.x];
     const uint64_t base_q = (uint64_t)blockIdx.x * (256 * Q);
+    MTB_JP_BEGIN();                                  /* profiling build only: cycles of thread 0 per phase (mtb_join_cycles: 0 queries + directory, 1 bisection, 2 run ends, 3 wave-scanned runs, 4 per-lane evaluation + emission) */
     mtb_kmer k[Q]; bool valid[Q]; uint64_t lo[Q], hi[Q];
 #pragma unroll
     for (int u = 0; u < Q; u++) {
@@ -250,6 +251,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
      *     a bisection takes over), then minimum and selection as the reference's loop does them (KmerMatcher.cpp:363-416).
      * Afterwards [lo[u], e_hi[u]) is exactly the query's candidate set to evaluate (empty: valid[u] = false). */
     auto tcomp = [&](uint64_t w) -> uint64_t { return PACKED ? (w & 0x1FFFFFFFull) : w; };
+    MTB_JP_MARK(0);
     uint64_t blo[Q];
 #pragma unroll
     for (int u = 0; u < Q; u++) blo[u] = lo[u];
@@ -271,6 +273,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
                 }
             }
         }
+        MTB_JP_MARK(1);
 #pragma unroll
         for (int u = 0; u < Q; u++) {
             if (!valid[u]) continue;
@@ -313,6 +316,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
         lng[u] = valid[u] && e_hi[u] - lo[u] > (uint64_t)sa.coop_min;
         if (lng[u]) valid[u] = false;
     }
+    MTB_JP_MARK(2);
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     /* ONE pass over a wave-scanned run [s, e), four 64-candidate steps in flight per iteration: the minimum hamming sum (-> the
@@ -526,6 +530,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
             }
         }
     }
+    MTB_JP_MARK(3);
 #pragma unroll
     for (int u = 0; u < Q; u++) {
         if (!valid[u]) continue;
@@ -572,6 +577,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
             }
         }
     }
+    MTB_JP_MARK(4);
     MTB_END_RELEASE();
 }
 

@@ -216,7 +216,8 @@ __device__ __forceinline__ bool seg_slot_live(const mtb_slot16 &s, uint32_t i, u
 }
 __global__ __launch_bounds__(64) void k_big_count(const mtb_slot16 *__restrict__ seg, uint32_t stride, uint32_t direct, uint32_t epoch,
                                                    const uint32_t *__restrict__ cursor, const uint32_t *__restrict__ big_list, uint32_t n_big,
-                                                   uint32_t *__restrict__ big_cnt, uint32_t *__restrict__ bigidx, uint32_t *__restrict__ max_seg) {
+                                                   uint32_t *__restrict__ big_cnt, uint32_t *__restrict__ bigidx, uint32_t *__restrict__ max_seg,
+                                                   const uint8_t *__restrict__ off = nullptr /* reads routed around their slots: the join pushed their cursor by tail_cap + 1 per match */) {
     uint32_t mx = 0;
     for (uint32_t b = blockIdx.x; b < n_big; b += gridDim.x) {
         const uint32_t r = big_list[b];
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(64) void k_big_count(const mtb_slot16 *__restrict__
             if (i < stride) { mtb_slot16 x = s[i]; live = seg_slot_live(x, i, direct, tail_n, epoch); }
             n += (uint32_t)__popcll(__ballot(live));
         }
-        n += cur - tail_n;                                  /* overflow entries */
+        n += (off && off[r]) ? cur / (tail_cap + 1u) : cur - tail_n;       /* overflow entries */
         if (threadIdx.x == 0) { big_cnt[b] = n; bigidx[r] = b; }
         mx = n > mx ? n : mx;
     }

@@ -861,6 +861,7 @@ static mtb_status dev_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, uint
             else if (key64) MTB_LAUNCH_SCORE(true, true, MTB_SCORE_LDS, true, false); else MTB_LAUNCH_SCORE(true, false, MTB_SCORE_LDS, true, false);
         }
         else if (S->sort) { if (key64) MTB_LAUNCH_SCORE(true, true, MTB_SCORE_LDS, false, false); else MTB_LAUNCH_SCORE(true, false, MTB_SCORE_LDS, false, false); }
+        else if (S->cap >= 320) MTB_LAUNCH_SCORE(false, false, 320, false, false);      /* the deferred reads of a slot batch: a few hundred matches each stay in LDS, only the rest works out of slabs */
         else MTB_LAUNCH_SCORE(false, false, MTB_SCORE_LDS, false, false);
 #undef MTB_LAUNCH_SCORE
     }
@@ -1838,7 +1839,7 @@ static void slot_geometry(uint32_t max_q, uint32_t *direct, uint32_t *stride) {
 static mtb_status score_fixed_slots(mtb_ctx *c, mtb_index *ix, const mtb_params *p, uint64_t n_reads, const int32_t *d_ql, const int32_t *d_ql2, uint32_t max_len,
                                     uint64_t nk_real, mtb_slot16 *d_segm, uint32_t *d_rc, uint32_t stride, uint32_t direct, uint32_t epoch, mtb_match *d_ovf, uint64_t n_ovf,
                                     mtb_result *d_results, int32_t *d_taxcnt_tax, uint32_t *d_taxcnt_cnt, uint64_t taxcnt_cap, uint64_t *n_taxcnt, uint64_t tc_base, uint64_t *nm_out,
-                                    uint32_t max_len_deferred = 0) {
+                                    uint32_t max_len_deferred = 0, const uint8_t *d_off_reads = nullptr) {
     hipStream_t st = c->stream;
     uint64_t nm = 0;
     uint32_t *d_biglist, *d_bigcnt, *d_bigidx, *d_bigcur, *d_cnt; uint64_t *d_bigstart = nullptr, *d_ws2, *d_tot; mtb_match *d_big = nullptr;
@@ -1867,7 +1868,7 @@ static mtb_status score_fixed_slots(mtb_ctx *c, mtb_index *ix, const mtb_params 
         KTimer kt(c, MTB_K_SEGSORT);
         STCHK(ensure(c, "bigcnt", n_big, &d_bigcnt)); STCHK(ensure(c, "bigstart", (uint64_t)n_big + 1, &d_bigstart)); STCHK(ensure(c, "bigcur", n_big, &d_bigcur));
         hipLaunchKernelGGL(k_big_count, dim3(std::min<uint32_t>(n_big, 4096)), dim3(64), 0, st, (const mtb_slot16 *)d_segm, stride, direct, epoch,
-                           (const uint32_t *)d_rc, (const uint32_t *)d_biglist, n_big, d_bigcnt, d_bigidx, (uint32_t *)(c->d_scal + 3));
+                           (const uint32_t *)d_rc, (const uint32_t *)d_biglist, n_big, d_bigcnt, d_bigidx, (uint32_t *)(c->d_scal + 3), d_off_reads);
         scan_launch<uint32_t, uint64_t, false>(st, d_bigcnt, n_big, true, d_bigstart, d_ws2);
         uint64_t mx = 0;
         STCHK(d2h(c, &big_total, d_bigstart + n_big, 8));
@@ -1891,7 +1892,7 @@ static mtb_status score_fixed_slots(mtb_ctx *c, mtb_index *ix, const mtb_params 
         b->m = d_big; b->seg = d_bigstart; b->list = d_biglist; b->n_list = (const uint32_t *)(c->d_scal + 5); b->seg_by_list = 1;
         /* one wave per workgroup, 14 of them resident per CU: a thousand workgroups left three quarters of the chip idle when hundreds of
          * thousands of reads come here (reads of conserved genes: hundreds of matches each); the slab pool stays bounded by dev_score */
-        b->sort = false; b->max_seg = (uint32_t)mx; b->grid = std::min<uint32_t>(n_big, 256u * 14u);
+        b->sort = false; b->max_seg = (uint32_t)mx; b->grid = std::min<uint32_t>(n_big, 256u * 14u); b->cap = 320;
         return MTB_OK;
     };
     STCHK(dev_score(c, ix, p, n_reads, d_ql, d_ql2, max_len, d_results, d_taxcnt_tax, d_taxcnt_cnt, taxcnt_cap, n_taxcnt, tc_base, a, &second, max_len_deferred));
@@ -2007,7 +2008,7 @@ static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, c
         HIPCHK(hipEventRecord(c->ev[4], st));
         HIPCHK(hipEventRecord(c->ev[5], st));
         STCHK(score_fixed_slots(c, ix, p, n_reads, d_ql, d_ql2, max_len, nk_real, d_segm, d_rc, stride, direct, epoch, d_ovf, n_ovf,
-                                d_results, d_taxcnt_tax, d_taxcnt_cnt, taxcnt_cap, n_taxcnt, tc_base, &nm, route_off ? max_len_all : 0));
+                                d_results, d_taxcnt_tax, d_taxcnt_cnt, taxcnt_cap, n_taxcnt, tc_base, &nm, route_off ? max_len_all : 0, route_off ? d_off : nullptr));
     } else if (lslot) {
         /* ---- long reads on ordinal slots: join into per-read slot ranges, order every range by a stable species partition, score ---- */
         uint32_t *d_sizes; uint64_t *d_rb, *d_ws2; uint32_t *d_live;

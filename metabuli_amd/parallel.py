@@ -126,6 +126,10 @@ def _exchange(torch, dist, send, send_counts, width, xdev, send_starts=None):
     (batch_isend_irecv = one ncclGroup per round on RCCL): nothing is concatenated or copied back, the own share is a
     device-to-device copy, and a peer's share is cut into rounds of at most _XCHG_BYTES."""
     world, me = dist.get_world_size(), dist.get_rank()
+    if world == 1:
+        # one rank owns everything: its share is already where it has to be -- a view, no collective, no copy
+        n0 = int(send_counts[0]); o0 = int(send_starts[0]) if send_starts is not None else 0
+        return send[o0:o0 + n0], [n0]
     sc = torch.tensor([int(x) for x in send_counts], dtype=torch.int64, device=xdev)
     allc = torch.empty(world * world, dtype=torch.int64, device=xdev)
     dist.all_gather_into_tensor(allc, sc)
@@ -187,7 +191,7 @@ def classify_partitioned(stages, bounds, dist):
     for n in recv_counts:                                                         # runs arrive sorted: one join per source, no merge
         runs.append(stages.join(recv[o:o + n])); o += n
     m_counts = [int(r.shape[0]) for r in runs]
-    m_send = torch.cat(runs) if runs else torch.empty((0, 3), dtype=torch.int64, device=home)
+    m_send = runs[0] if len(runs) == 1 else (torch.cat(runs) if runs else torch.empty((0, 3), dtype=torch.int64, device=home))
     mark()
     m_recv, _ = _exchange(torch, dist, m_send, m_counts, 3, xdev)                 # all-to-all #2: matches back to the read's home
     m_recv = m_recv.to(home)
