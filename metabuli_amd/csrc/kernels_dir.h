@@ -183,6 +183,9 @@ __global__ __launch_bounds__(256) void k_index_unpack(uint64_t *__restrict__ val
  * of by their query's lane alone.  Real databases have heavy-tailed runs -- an amino-acid 8-mer of a conserved protein is shared by
  * 10^3 - 10^4 species -- and a lane that walks such a run twice on its own (minimum, then emission: the reference's
  * loop, KmerMatcher.cpp:363-416) stalls the other 63 lanes of its wave for thousands of dependent loads. */
+#ifndef MTB_JOIN_WAVES
+#define MTB_JOIN_WAVES 6              /* waves per SIMD the short-read instantiation on packed words is compiled for (80 registers) */
+#endif
 #ifndef MTB_JOIN_EXACT_MIN
 #define MTB_JOIN_EXACT_MIN 8          /* diagnostics (k_join_run_hist): runs beyond this length count as long when a query finds its own DNA part in them */
 #endif
@@ -201,7 +204,7 @@ __device__ __forceinline__ uint32_t wave_min_shfl_u32(uint32_t v) {
 /* MODE 0: slot segments of fixed stride (short reads); 1: per-read slot ranges (long reads); 2: dense list of Match records
  * (owner side of the range-partitioned index: the home rank of the read places them into ITS slot segments, k_slot_place) */
 template <bool PACKED, int MODE = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && MODE == 0) ? 6 : 5))) void k_join_dir(const mtb_kmer *__restrict__ q, uint64_t n, mtb_index_view ix, uint64_t limit, mtb_dir_view dv,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && MODE == 0) ? MTB_JOIN_WAVES : 5))) void k_join_dir(const mtb_kmer *__restrict__ q, uint64_t n, mtb_index_view ix, uint64_t limit, mtb_dir_view dv,
                                                    const mtb_tables *__restrict__ tabs, JoinSegArgs sa, uint32_t *__restrict__ overflow) {
     constexpr int Q = MTB_JOIN_DIR_QPT;
     constexpr bool LONG = MODE == 1, LIST = MODE == 2;
@@ -252,9 +255,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
      * Afterwards [lo[u], e_hi[u]) is exactly the query's candidate set to evaluate (empty: valid[u] = false). */
     auto tcomp = [&](uint64_t w) -> uint64_t { return PACKED ? (w & 0x1FFFFFFFull) : w; };
     MTB_JP_MARK(0);
-    uint64_t blo[Q];
-#pragma unroll
-    for (int u = 0; u < Q; u++) blo[u] = lo[u];
     {
         uint64_t qc[Q];
 #pragma unroll
@@ -289,11 +289,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
                     while (e0 < y) { const uint64_t mid = e0 + ((y - e0) >> 1); if (tcomp(ix.values[mid]) <= qc[u]) e0 = mid + 1; else y = mid; }
                 }
             } else {
-                /* the run of the query's amino-acid part around the landing place */
+                /* the run of the query's amino-acid part around the landing place (the bucket's start is read again from the directory:
+                 * keeping it in registers across the bisection cost the kernel a wave of occupancy) */
+                const uint32_t bk = mtb_dir_bucket(k[u].value, dv.L, dv.kmer_format);
+                const uint64_t blo = dv.base[bk >> 16] + dv.dir[bk];
                 uint32_t n = 0;
-                while (s0 > blo[u] && n < 8u && tkey(ix.values[s0 - 1]) == qk) { s0--; n++; }
-                if (n == 8u && s0 > blo[u] && tkey(ix.values[s0 - 1]) == qk) {
-                    uint64_t x = blo[u], y = s0;
+                while (s0 > blo && n < 8u && tkey(ix.values[s0 - 1]) == qk) { s0--; n++; }
+                if (n == 8u && s0 > blo && tkey(ix.values[s0 - 1]) == qk) {
+                    uint64_t x = blo, y = s0;
                     while (x < y) { const uint64_t mid = x + ((y - x) >> 1); if (tkey(ix.values[mid]) < qk) x = mid + 1; else y = mid; }
                     s0 = x;
                 }
@@ -448,6 +451,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
         return;
     }
     const uint32_t tail_cap = sa.stride - sa.direct;
+    /* a place in the overflow list: the workgroup's stripe (its own counter and region), or the single dense list */
+    const uint32_t stripe = sa.ovf_stripes ? blockIdx.x & (sa.ovf_stripes - 1u) : 0u;
+    auto ovf_put = [&](const mtb_match &mm) {
+        const unsigned long long o = atomicAdd(sa.ovf_counter + 8u * stripe, 1ull);
+        if (LONG) return;                          /* counted only: the caller retries the join with a larger tail */
+        const unsigned long long room = sa.ovf_stripes ? sa.ovf_region : sa.ovf_cap;
+        if (o < room) sa.ovf[(uint64_t)stripe * sa.ovf_region + o] = mm; else *overflow = 1;
+    };
     /* wave-scanned runs: one pass (minimum + the few candidates that can be selected, kept in registers), then emission -- the selected
      * candidate with the lowest index takes the query's ordinal slot, the others the read's tail (ONE returning atomic per step for all
      * of them), beyond that the overflow list: the contract of the per-lane loop below */
@@ -480,12 +491,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
                 if (at == ~0u) MTB_SLOT_STORE(sl, &seg[ord]);
                 else if (at < tcap) MTB_SLOT_STORE(sl, &seg[direct + at]);
                 else {
-                    const unsigned long long o = atomicAdd(sa.ovf_counter, 1ull);
-                    if (LONG) { }                      /* counted only: the caller retries the join with a larger tail */
-                    else if (o < sa.ovf_cap) {
-                        mtb_match mm; mm.qinfo = qinfo; mm.target_id = tid; mm.species_id = sp; mm.dna = td; mm.right_end_hamming = reh; mm.hamming = (uint8_t)h; mm.pad = 0;
-                        sa.ovf[o] = mm;
-                    } else *overflow = 1;
+                    mtb_match mm; mm.qinfo = qinfo; mm.target_id = tid; mm.species_id = sp; mm.dna = td; mm.right_end_hamming = reh; mm.hamming = (uint8_t)h; mm.pad = 0;
+                    ovf_put(mm);
                 }
             };
             if (!__any(n_c > 4u)) {
@@ -568,12 +575,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
             if (at < tcap) { const mtb_slot16 sl = LONG ? mtb_lslot_pack(qinfo, tid, sp, td, reh, h) : mtb_slot_pack(qinfo, tid, sp, td, reh, h, sa.epoch);
                              MTB_SLOT_STORE(sl, &seg[direct + at]); }
             else {
-                const unsigned long long o = atomicAdd(sa.ovf_counter, 1ull);
-                if (LONG) { }                      /* counted only: the caller retries the join with a larger tail */
-                else if (o < sa.ovf_cap) {
-                    mtb_match m; m.qinfo = qinfo; m.target_id = tid; m.species_id = sp; m.dna = td; m.right_end_hamming = reh; m.hamming = (uint8_t)h; m.pad = 0;
-                    sa.ovf[o] = m;
-                } else *overflow = 1;
+                mtb_match m; m.qinfo = qinfo; m.target_id = tid; m.species_id = sp; m.dna = td; m.right_end_hamming = reh; m.hamming = (uint8_t)h; m.pad = 0;
+                ovf_put(m);
             }
         }
     }

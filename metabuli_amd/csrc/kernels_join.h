@@ -73,6 +73,11 @@ struct JoinSegArgs {
     const uint64_t *rb; const uint32_t *dcnt; uint32_t tf;
     uint32_t list;      /* k_join_dir<.., 2>: matches go to the dense list ovf[0 .. ovf_cap) (owner side of the partitioned index) */
     uint32_t coop_min;  /* k_join_dir: candidate runs longer than this are scanned by the whole wave (kernels_dir.h) */
+    /* The overflow list of k_join_dir's slot modes is cut into ovf_stripes regions of ovf_region entries, each with a counter of its own
+     * (64 bytes apart, ovf_counter[8 * stripe]; a workgroup uses stripe blockIdx.x mod ovf_stripes): ONE counter for the whole list made
+     * every overflowing match a returning atomic on one address -- ~19 ns each once they no longer coalesce inside a wave, +100 ms per
+     * 10 M reads of a sample in which the reads of conserved genes overflow their tails (profiles/r04_notes.md).  0: one dense list. */
+    uint32_t ovf_stripes; uint64_t ovf_region;
     const uint8_t *off; /* k_join_dir, fixed segments: reads marked here never use their slots -- every match goes to the overflow list and the read's
                          * tail cursor is pushed beyond the tail's capacity, so that the scorers hand the read to the exact-segment path */
 };
@@ -262,10 +267,16 @@ __global__ __launch_bounds__(64) void k_big_copy(const mtb_slot16 *__restrict__ 
         if (threadIdx.x == 0) bigcur[b] = n;
     }
 }
+/* region_cap != 0: the list is striped (JoinSegArgs::ovf_stripes): blockIdx.y = stripe, its entries [0, counters[8 * stripe]) */
 __global__ __launch_bounds__(256) void k_big_ovf(const mtb_match *__restrict__ ovf, uint64_t n_ovf, const uint32_t *__restrict__ bigidx,
-                                                  const uint64_t *__restrict__ big_start, uint32_t *__restrict__ bigcur, mtb_match *__restrict__ big) {
+                                                  const uint64_t *__restrict__ big_start, uint32_t *__restrict__ bigcur, mtb_match *__restrict__ big,
+                                                  uint64_t region_cap = 0, const unsigned long long *__restrict__ counters = nullptr) {
     uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_ovf) return;
+    if (region_cap) {
+        const unsigned long long cnt = counters[8 * blockIdx.y];
+        if (i >= cnt || i >= region_cap) return;
+        i += (uint64_t)blockIdx.y * region_cap;
+    } else if (i >= n_ovf) return;
     mtb_match m = ovf[i];
     uint32_t b = bigidx[mtb_q_seq(m.qinfo) - 1];
     uint32_t slot = atomicAdd(&bigcur[b], 1u);

@@ -79,6 +79,7 @@ __global__ __launch_bounds__(64) void k_unpack_reads(const uint8_t *__restrict__
 }
 
 struct DevBuf { void *p = nullptr; size_t cap = 0; };
+#define MTB_OVF_STRIPES 256u
 
 struct mtb_ctx {
     int device = 0;
@@ -89,6 +90,8 @@ struct mtb_ctx {
     std::mutex bufs_mu;              /* the buffer table may be grown from a helper thread (mtb_ctx_reserve) while the context's thread opens an index */
     uint64_t *d_scal = nullptr;      /* [0] match counter, [1] overflow, [2] n_large, [3] max_seg, [4] max_len, [5] n_big */
     uint64_t *d_xscal = nullptr;     /* = d_scal + 8: single-pass extraction counters */
+    unsigned long long *d_ovfctr = nullptr;      /* MTB_OVF_STRIPES counters of the striped overflow list, 64 bytes apart (JoinSegArgs::ovf_stripes) */
+    uint64_t ovf_region = 0, ovf_max_region = 0; /* entries per region in the last slot-mode join; fullest region */
     hipEvent_t ev[8];
     mtb_batch_stats stats;
     int profiling = 0;
@@ -342,6 +345,7 @@ mtb_status mtb_ctx_create(int device, void *stream, mtb_ctx **out) {
     HIPCHK(hipMemcpy(c->d_tabs, &c->h_tabs, sizeof(mtb_tables), hipMemcpyHostToDevice));
     HIPCHK(hipMalloc((void **)&c->d_scal, 16 * sizeof(uint64_t)));
     c->d_xscal = c->d_scal + 8;
+    HIPCHK(hipMalloc((void **)&c->d_ovfctr, MTB_OVF_STRIPES * 64));
     for (int i = 0; i < 8; i++) HIPCHK(hipEventCreate(&c->ev[i]));
     memset(&c->stats, 0, sizeof(c->stats));
     if (const char *e = getenv("MTB_JOIN_COOP_MIN")) c->join_coop_min = (uint32_t)std::max(1, atoi(e));
@@ -357,6 +361,7 @@ void mtb_ctx_destroy(mtb_ctx *c) {
     for (auto &kv : c->bufs) if (kv.second.p) e = hipFree(kv.second.p);
     if (c->d_tabs && !c->is_lane) e = hipFree(c->d_tabs);
     if (c->d_scal) e = hipFree(c->d_scal);
+    if (c->d_ovfctr) e = hipFree(c->d_ovfctr);
     if (c->is_lane && c->stream) e = hipStreamDestroy(c->stream);
     if (c->copy_stream) { e = hipStreamSynchronize(c->copy_stream); e = hipStreamDestroy(c->copy_stream); }
     if (c->copy_done) e = hipEventDestroy(c->copy_done);
@@ -395,6 +400,7 @@ mtb_status mtb_ctx_set_streams(mtb_ctx *c, int n) {
         HIPCHK(hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking));
         HIPCHK(hipMalloc((void **)&l->d_scal, 16 * sizeof(uint64_t)));
         l->d_xscal = l->d_scal + 8;
+        HIPCHK(hipMalloc((void **)&l->d_ovfctr, MTB_OVF_STRIPES * 64));
         for (int i = 0; i < 8; i++) HIPCHK(hipEventCreate(&l->ev[i]));
         memset(&l->stats, 0, sizeof(l->stats));
         c->lanes.push_back(l);
@@ -680,10 +686,16 @@ static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint6
     STCHK(ensure(c, "jbounds", 2ull * grid, &d_bounds));
     uint64_t limit = ix->T ? ix->T - (ix->match_last ? 0 : 1) : 0;          /* the last entry of the (whole) index is never a candidate */
     IndexUse use;                     /* released after the stream sync below (the d2h of the counters) */
+    const bool striped = seg && ix->d_dir && !seg->list;       /* the slot modes of the directory join: striped overflow list */
     if (seg && ix->d_dir) {
         STCHK(use.acquire(ix, true));
         KTimer kt(c, MTB_K_JOIN);
         JoinSegArgs sa = *seg; sa.ovf_counter = (unsigned long long *)c->d_scal; sa.coop_min = c->join_coop_min;
+        if (striped) {
+            HIPCHK(hipMemsetAsync(c->d_ovfctr, 0, MTB_OVF_STRIPES * 64, c->stream));
+            sa.ovf_counter = c->d_ovfctr; sa.ovf_stripes = MTB_OVF_STRIPES; sa.ovf_region = sa.ovf_cap / MTB_OVF_STRIPES;
+            c->ovf_region = sa.ovf_region;
+        }
         const uint32_t g2 = (uint32_t)((n + 256 * MTB_JOIN_DIR_QPT - 1) / (256 * MTB_JOIN_DIR_QPT));
         if (sa.list) {      /* owner side of the partitioned index: a dense list of Match records */
             if (state_owner(ix)->packed) hipLaunchKernelGGL((k_join_dir<true, 2>), dim3(g2), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1));
@@ -713,6 +725,24 @@ static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint6
     HIPCHK(hipGetLastError());
     uint64_t sc[2];
     STCHK(d2h(c, sc, c->d_scal, 16));
+    if (striped) {
+        /* entries per stripe: the list fits when the fullest region does; else the caller comes again with room for 256 x that */
+        unsigned long long h[MTB_OVF_STRIPES * 8];
+        STCHK(d2h(c, h, c->d_ovfctr, sizeof(h)));
+        uint64_t tot = 0, mx = 0;
+        for (uint32_t k = 0; k < MTB_OVF_STRIPES; k++) { tot += h[8 * k]; mx = std::max<uint64_t>(mx, h[8 * k]); }
+        c->ovf_max_region = mx;
+        if (seg->rb) {                                 /* long reads: counted only */
+            *count = tot;
+            if (tot > seg->ovf_cap) return fail(MTB_ERR_CAPACITY, "match buffer too small");
+            return MTB_OK;
+        }
+        *count = mx > c->ovf_region ? (mx + mx / 8 + 64) * MTB_OVF_STRIPES : tot;
+        if (tot >= (1ull << 32)) return fail(MTB_ERR_ARG, "more than 2^32-1 matches in one batch; split the batch");
+        if (mx > c->ovf_region) return fail(MTB_ERR_CAPACITY, "match buffer too small");
+        return MTB_OK;
+    }
+    c->ovf_region = 0;
     *count = sc[0];
     if (sc[0] >= (1ull << 32)) return fail(MTB_ERR_ARG, "more than 2^32-1 matches in one batch; split the batch");
     if (sc[0] > (seg ? seg->ovf_cap : cap)) return fail(MTB_ERR_CAPACITY, "match buffer too small");
@@ -1829,8 +1859,9 @@ static mtb_status prepare_slots(mtb_ctx *c, uint64_t n_reads, uint32_t stride, m
     return MTB_OK;
 }
 static void slot_geometry(uint32_t max_q, uint32_t *direct, uint32_t *stride) {
+    static const uint32_t tail_min = getenv("MTB_TAIL_MIN") ? (uint32_t)std::max(8, atoi(getenv("MTB_TAIL_MIN"))) & ~7u : 16u;      /* experiment switch: longer tails */
     *direct = std::max<uint32_t>(8, (max_q + 7) & ~7u);
-    *stride = *direct + std::max<uint32_t>(16, (*direct / 8 + 7) & ~7u);
+    *stride = *direct + std::max<uint32_t>(tail_min, (*direct / 8 + 7) & ~7u);
 }
 
 /* Scoring out of filled slot segments (fused path after the join; partitioned path after the matches came home): the
@@ -1839,7 +1870,7 @@ static void slot_geometry(uint32_t max_q, uint32_t *direct, uint32_t *stride) {
 static mtb_status score_fixed_slots(mtb_ctx *c, mtb_index *ix, const mtb_params *p, uint64_t n_reads, const int32_t *d_ql, const int32_t *d_ql2, uint32_t max_len,
                                     uint64_t nk_real, mtb_slot16 *d_segm, uint32_t *d_rc, uint32_t stride, uint32_t direct, uint32_t epoch, mtb_match *d_ovf, uint64_t n_ovf,
                                     mtb_result *d_results, int32_t *d_taxcnt_tax, uint32_t *d_taxcnt_cnt, uint64_t taxcnt_cap, uint64_t *n_taxcnt, uint64_t tc_base, uint64_t *nm_out,
-                                    uint32_t max_len_deferred = 0, const uint8_t *d_off_reads = nullptr) {
+                                    uint32_t max_len_deferred = 0, const uint8_t *d_off_reads = nullptr, uint64_t ovf_region = 0 /* != 0: the overflow list is striped (dev_join) */) {
     hipStream_t st = c->stream;
     uint64_t nm = 0;
     uint32_t *d_biglist, *d_bigcnt, *d_bigidx, *d_bigcur, *d_cnt; uint64_t *d_bigstart = nullptr, *d_ws2, *d_tot; mtb_match *d_big = nullptr;
@@ -1876,6 +1907,10 @@ static mtb_status score_fixed_slots(mtb_ctx *c, mtb_index *ix, const mtb_params 
         STCHK(ensure(c, "bigm", big_total, &d_big));
         hipLaunchKernelGGL(k_big_copy, dim3(std::min<uint32_t>(n_big, 4096)), dim3(64), 0, st, (const mtb_slot16 *)d_segm, stride, direct, epoch,
                            (const uint32_t *)d_rc, (const uint32_t *)d_biglist, (const uint64_t *)d_bigstart, n_big, d_bigcur, d_big);
+        if (ovf_region) {            /* striped list (the directory join's): every stripe's entries */
+            if (c->ovf_max_region) hipLaunchKernelGGL(k_big_ovf, dim3((uint32_t)((c->ovf_max_region + 255) / 256), MTB_OVF_STRIPES), dim3(256), 0, st, (const mtb_match *)d_ovf, n_ovf,
+                                                      (const uint32_t *)d_bigidx, (const uint64_t *)d_bigstart, d_bigcur, d_big, ovf_region, (const unsigned long long *)c->d_ovfctr);
+        } else
         if (n_ovf) hipLaunchKernelGGL(k_big_ovf, dim3((uint32_t)((n_ovf + 255) / 256)), dim3(256), 0, st, (const mtb_match *)d_ovf, n_ovf,
                                       (const uint32_t *)d_bigidx, (const uint64_t *)d_bigstart, d_bigcur, d_big);
         /* segments of up to 512 matches (nearly all: a read of a conserved gene brings a few hundred) are sorted in LDS by one wave
@@ -2008,7 +2043,7 @@ static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, c
         HIPCHK(hipEventRecord(c->ev[4], st));
         HIPCHK(hipEventRecord(c->ev[5], st));
         STCHK(score_fixed_slots(c, ix, p, n_reads, d_ql, d_ql2, max_len, nk_real, d_segm, d_rc, stride, direct, epoch, d_ovf, n_ovf,
-                                d_results, d_taxcnt_tax, d_taxcnt_cnt, taxcnt_cap, n_taxcnt, tc_base, &nm, route_off ? max_len_all : 0, route_off ? d_off : nullptr));
+                                d_results, d_taxcnt_tax, d_taxcnt_cnt, taxcnt_cap, n_taxcnt, tc_base, &nm, route_off ? max_len_all : 0, route_off ? d_off : nullptr, c->ovf_region));
     } else if (lslot) {
         /* ---- long reads on ordinal slots: join into per-read slot ranges, order every range by a stable species partition, score ---- */
         uint32_t *d_sizes; uint64_t *d_rb, *d_ws2; uint32_t *d_live;
