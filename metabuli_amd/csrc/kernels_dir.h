@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void k_index_unpack(uint64_t *__restrict__ val
  * 10^3 - 10^4 species -- and a lane that walks such a run twice on its own (minimum, then emission: the reference's
  * loop, KmerMatcher.cpp:363-416) stalls the other 63 lanes of its wave for thousands of dependent loads. */
 #ifndef MTB_JOIN_WAVES
-#define MTB_JOIN_WAVES 6              /* waves per SIMD the short-read instantiation on packed words is compiled for (80 registers) */
+#define MTB_JOIN_WAVES 5              /* waves per SIMD the short-read instantiation on packed words is compiled for: 6 (80 registers) spills 16 of them since the search and overflow rework and measured 91.8 ms against 87.6 (profiles/r04_notes.md) */
 #endif
 #ifndef MTB_JOIN_EXACT_MIN
 #define MTB_JOIN_EXACT_MIN 8          /* diagnostics (k_join_run_hist): runs beyond this length count as long when a query finds its own DNA part in them */

@@ -118,6 +118,7 @@ struct mtb_ctx {
     hipStream_t copy_stream = nullptr; hipEvent_t copy_done = nullptr;
     int pk_set = 0;                                  /* the set the last classify call read */
     struct Prefetched { const void *key = nullptr, *key2 = nullptr; uint64_t n_reads = 0, slots = 0, slots2 = 0; bool valid = false; } pre;
+    uint32_t lslot_tf_start = 1;                     /* long-read slot ranges: tail factor the next batch starts with (1 = a quarter of the metamers, 4 = all) */
     uint32_t join_coop_min = MTB_JOIN_COOP_MIN;      /* k_join_dir: runs longer than this are scanned by the whole wave; MTB_JOIN_COOP_MIN in the environment at mtb_ctx_create */
 };
 /* buffers that carry a call's inputs / outputs (host-buffer entry points) are not workspace */
@@ -2052,7 +2053,9 @@ static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, c
         uint32_t *d_fail;
         STCHK(ensure(c, "lfail", n_reads, &d_fail));
         bool done = false;
-        for (uint32_t tf = 1; tf <= 4 && !done; tf *= 4) {            /* tail = a quarter of the read's metamers, then all of them */
+        /* tail = a quarter of the read's metamers, then all of them; a context whose last batch needed the long tails starts with them
+         * (a database with long candidate runs overflows the short ones batch after batch: the join ran twice every time) */
+        for (uint32_t tf = c->lslot_tf_start; tf <= 4 && !done; tf *= 4) {
             hipLaunchKernelGGL(k_lslot_sizes, dim3((uint32_t)((n_reads + 255) / 256)), dim3(256), 0, st, (const uint32_t *)d_dcnt, n_reads, tf, d_sizes);
             { KTimer kt(c, MTB_K_SCAN); scan_launch<uint32_t, uint64_t, false>(st, d_sizes, n_reads, true, d_rb, d_ws2); }
             uint64_t n_slots = 0;
@@ -2067,6 +2070,7 @@ static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, c
             uint64_t n_ovf = 0;
             mtb_status s2 = dev_join(c, ix, d_s, nk, nullptr, 0, nullptr, &n_ovf, &sa, low_bits);
             if (s2 == MTB_ERR_CAPACITY) {                              /* some read's tail overran: larger tails */
+                c->lslot_tf_start = 4;
                 if (getenv("MTB_LSLOT_VERBOSE")) fprintf(stderr, "mtb: long-read slot path: %llu matches beyond the tails at tail factor %u/4\n", (unsigned long long)n_ovf, tf);
                 continue;
             }
