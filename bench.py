@@ -479,6 +479,29 @@ def oracle_parity(ctx, M, torch, dev, index, params, taxdir, d_bases, d_bases2, 
                           f"(every {sub['stride']}th target + the candidate closure of the sample's {sub['n_kmers']} metamers: the answers equal those against "
                           f"all {T} targets, which the reference would stream once per batch -- its match stage grows with the database, {stage_s.get('match', 0):.1f} s here); "
                           f"oracle/liboracle.so with OpenMP on {ncores} threads, {dt:.1f} s (1 thread on {n1} reads: {dt1:.1f} s), {cls} classified")
+    dead = None
+    if time_cpu:
+        # VERDICT r3 item 6(i), the measurement: how many matches can never score?  A match takes part in a path only inside a
+        # (species, frame) group of >= 2 matches (Taxonomer.cpp:342); a species none of whose groups in the read has two matches gets no
+        # path, hence no score, hence is never the read's species: all its matches in that read are dead weight for the join's stores.
+        n2 = min(n, 50000)
+        S = orc.classify(db, tax, op, bases[: n2 * read_len], offs[: n2 + 1], bases2[: n2 * read_len] if paired else None, offs[: n2 + 1] if paired else None, threads=ncores)
+        mm = S["matches"]
+        if len(mm):
+            seq = ((mm["qinfo"] >> np.uint64(32)) & np.uint64(0x1FFFFFFF)).astype(np.int64)
+            frame = (mm["qinfo"] >> np.uint64(61)).astype(np.int64)
+            g_key = (seq * (1 << 32) + mm["species_id"].astype(np.int64)) * 8 + frame
+            _, g_inv, g_cnt = np.unique(g_key, return_inverse=True, return_counts=True)
+            s_key = seq * (1 << 32) + mm["species_id"].astype(np.int64)
+            _, s_inv = np.unique(s_key, return_inverse=True)
+            best = np.zeros(s_inv.max() + 1, np.int64)
+            np.maximum.at(best, s_inv, g_cnt[g_inv])
+            dead = dict(sample_reads=int(n2), matches=int(len(mm)), in_groups_of_one=int((g_cnt[g_inv] == 1).sum()),
+                        of_species_without_any_pair=int((best[s_inv] == 1).sum()),
+                        note="matches of a (read, species) none of whose (species, frame) groups holds two matches can never score (Taxonomer.cpp:342): "
+                             "the share of the join's slot stores a per-read sketch could skip")
+            dead["dead_fraction"] = dead["of_species_without_any_pair"] / max(1, dead["matches"])
+        del S, mm
     g_res, g_tt, g_tc, g_matches = gpu_sample(ctx, M, torch, dev, index, params, d_bases, d_bases2, read_len, n)
     par = compare_with_oracle(M, g_res, g_tt, g_tc, R)
     par["matches"] = g_matches; par["oracle_matches"] = int(oracle_counts["matches"])
@@ -489,6 +512,8 @@ def oracle_parity(ctx, M, torch, dev, index, params, taxdir, d_bases, d_bases2, 
                     f"{', sealed' if stt['sealed'] else ''}; oracle on a sub-database of {len(cv)} targets (candidate closure of the sample's metamers"
                     f"{', every %dth target' % sub['stride'] if sub['stride'] else ''} and the index's last entry, gathered with torch.searchsorted from the flat arrays before packing)")
     par["sub_database_targets"] = int(len(cv)); par["oracle_seconds"] = round(dt, 2); par["db_write_seconds"] = round(t_write, 2)
+    if dead is not None:
+        par["dead_matches"] = dead
     log(f"[rank 0] parity {label}: {par['reads']} reads, {par['mismatches']} mismatches, {par['matches']} matches (oracle {par['oracle_matches']}), sub-database {len(cv)} targets, oracle {dt:.1f}s")
     return cpu, par
 

@@ -1254,7 +1254,8 @@ static mtb_status decode_chunked(mtb_ctx *c, mtb_index *ix, const std::string &d
                 HIPCHK(hipGetLastError());
                 HIPCHK(hipStreamSynchronize(st));          /* the pinned buffers are refilled next */
                 g += n_k; found += n_k;
-                { size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) == hipSuccess && ix->open_free0 > fr) ix->open_peak_bytes = std::max<uint64_t>(ix->open_peak_bytes, ix->open_free0 - fr); }
+                if (ix->open_chunks < 4 || (ix->open_chunks & 63u) == 0) {        /* (a driver query: not for every one of thousands of tiny test chunks) */
+                    size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) == hipSuccess && ix->open_free0 > fr) ix->open_peak_bytes = std::max<uint64_t>(ix->open_peak_bytes, ix->open_free0 - fr); }
                 ix->open_chunks++;
             }
         }
