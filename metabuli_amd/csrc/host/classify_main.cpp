@@ -69,6 +69,16 @@ struct Job {
         res.set_allocator(mtb_host_alloc, mtb_host_free); tt.set_allocator(mtb_host_alloc, mtb_host_free); tc.set_allocator(mtb_host_alloc, mtb_host_free);
     }
     void reset() { r1.clear(); r2.clear(); res.clear(); tt.clear(); tc.clear(); last = false; }
+    /* the pinned buffers at the size a batch of max_reads reads of ~est_len bases will need, allocated up front (while the database
+     * loads): pinning half a GB costs 0.1 - 0.3 s, and a buffer that grows on its first use does that inside the parse or the GPU stage */
+    void prealloc(size_t max_reads, bool paired, size_t est_len) {
+        const size_t groups = max_reads * ((est_len + 7) / 8 + 1);
+        for (mtbhost::FlatBatch *b : {&r1, &r2}) {
+            if (b == &r2 && !paired) continue;
+            b->packed2.reserve(groups * 2); b->nmask.reserve(groups); b->lens.reserve(max_reads + 16);
+        }
+        res.reserve(max_reads + max_reads / 8 + 16); tt.reserve(7 * max_reads + 4096); tc.reserve(7 * max_reads + 4096);
+    }
 };
 
 /* bounded single-producer / single-consumer hand-over */
@@ -312,7 +322,14 @@ int main(int argc, char **argv) {
         Channel<Job> parsed(2), scored(2), idle((size_t)gpu_workers + 6);
         /* a few batches are in flight (parse / GPU workers / format); their buffers are recycled, so that after the first round no stage
          * touches fresh pages, and what crosses PCIe sits in pinned memory */
-        for (int k = 0; k < gpu_workers + 5; k++) { std::unique_ptr<Job> j(new Job()); if (pack) j->pin(); idle.put(std::move(j)); }
+        const int n_jobs = gpu_workers + 5;
+        std::thread job_maker([&, n_jobs] {      /* (the first batch can be parsed as soon as the first job's buffers are pinned; the rest follow while the database loads) */
+            for (int k = 0; k < n_jobs; k++) {
+                std::unique_ptr<Job> j(new Job());
+                if (pack) { j->pin(); try { j->prealloc(max_reads, paired, 152); } catch (const std::exception &) { /* the buffers then grow on first use */ } }
+                idle.put(std::move(j));
+            }
+        });
         mtbhost::WorkerPool parse_pool(threads), format_pool(threads);
         mtbhost::PackTable pack_table;
         { static mtb_tables tabs; mtb_build_tables(&tabs); for (int c = 0; c < 256; c++) pack_table.code[c] = tabs.base[c] < 4 ? tabs.base[c] : 0xFF; }
@@ -569,7 +586,7 @@ int main(int argc, char **argv) {
         const double t_stage = now() - t_stage0;
         for (int w = 0; w < W; w++) { t_gpu = std::max(t_gpu, w_busy[(size_t)w]); t_dev += w_dev[(size_t)w]; }
         for (int w = 1; w < W; w++) for (size_t d = 0; d < ND; d++) mtb_ctx_destroy(wctx[(size_t)w][d]);
-        reader.join(); writer.join();
+        job_maker.join(); reader.join(); writer.join();
         fclose(out);
         for (int k = 0; k < 2; k++) { if (flt[k]) fclose(flt[k]); if (rmv[k]) fclose(rmv[k]); }
         if (!reader_err.empty()) throw std::runtime_error(reader_err);
