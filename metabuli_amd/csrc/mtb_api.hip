@@ -207,6 +207,7 @@ static mtb_status ensure(mtb_ctx *c, const char *name, size_t elems, T **out) {
         b.cap = want;
 #ifdef MTB_POISON_ALLOC     /* robustness build (make libmtb_xpoison.so X=-DMTB_POISON_ALLOC): no kernel may rely on fresh device memory being zero */
         HIPCHK(hipMemsetAsync(b.p, 0xA5, want, c->stream));         /* on the library's stream: it must not overtake or trail the kernels that use the buffer */
+        HIPCHK(hipStreamSynchronize(c->stream));                    /* ... nor a copy that another stream (mtb_prefetch_batch_packed) is about to make into it */
 #endif
     }
     *out = (T *)b.p;
@@ -1356,8 +1357,10 @@ static mtb_status open_impl(mtb_ctx *c, const char *dbdir, const char *taxonomy_
         HIPCHK(hipMalloc((void **)&ix->d_values, (T + 1) * 8));
         if (!pack) HIPCHK(hipMalloc((void **)&ix->d_info, std::max<uint64_t>(T, 1) * 4));
         bool dir_ok = false;
-        STCHK(decode_chunked(c, ix, d, O, want_dir, L, pack, &dir_ok));
-        release(c, "diffraw"); release(c, "difftc"); release(c, "difftoff"); release(c, "infochunk");
+        {   /* the chunk buffers go back whatever way the decode ends */
+            struct Scratch { mtb_ctx *c; ~Scratch() { release(c, "diffraw"); release(c, "difftc"); release(c, "difftoff"); release(c, "infochunk"); } } scratch{c};
+            STCHK(decode_chunked(c, ix, d, O, want_dir, L, pack, &dir_ok));
+        }
         if (pack && !dir_ok) {      /* a letter >= 21 or a bucket group of 2^32 targets: no directory, hence no packed state -- once more, flat */
             hipError_t e = hipFree(ix->d_values); (void)e; ix->d_values = nullptr;
             pack = false;

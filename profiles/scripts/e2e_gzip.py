@@ -16,7 +16,7 @@ work = tempfile.mkdtemp(prefix="mtb_e2egz_")
 db = os.path.join(work, "db"); os.makedirs(os.path.join(db, "taxonomy"))
 world = bench.build_world(1234, 8, 500000, 5000)
 world.tax.write(os.path.join(db, "taxonomy"))
-rv, rt = bench.extract_targets(ctx, M, world, params)
+rv, rt, _ = bench.extract_targets(ctx, M, world, params)
 Tc = NF + len(rv)
 dv = torch.empty(Tc, dtype=torch.int64, device=dev); di = torch.empty(Tc, dtype=torch.int32, device=dev)
 T = ctx.synth_index(1234, NF, world.filler_tax_lo, world.filler_tax_hi, rv, rt, dv.data_ptr(), di.data_ptr())
@@ -24,7 +24,7 @@ tl = np.concatenate([np.unique(rt), np.arange(world.filler_tax_lo, world.filler_
 ix = ctx.index_from_device(dv.data_ptr(), di.data_ptr(), T, os.path.join(db, "taxonomy"), tl, params)
 ix.write(db)
 L = 150
-bases, _ = bench.gen_reads(torch, dev, world, N, L, 0.10, 0.005, 99)
+bases, _ = bench.gen_reads(torch, dev, world.genomes, N, L, 0.10, 0.005, 99)
 b = bases.cpu().numpy().reshape(N, L)
 name = np.char.zfill(np.arange(N).astype("U8"), 8).astype("S8").view(np.uint8).reshape(N, 8)
 rec = np.empty((N, 1 + 8 + 1 + L + 3 + L + 1), np.uint8)

@@ -15,7 +15,7 @@ ctx = M.Context(0)
 params = M.default_params(seq_mode=mode, syncmer=1, smer_len=5)
 world = bench.build_world(1234, 24, 1_000_000, 130_000)
 taxdir = tempfile.mkdtemp(); world.tax.write(taxdir)
-rv, rt = bench.extract_targets(ctx, M, world, params)
+rv, rt, _ = bench.extract_targets(ctx, M, world, params)
 T_cap = targets + len(rv)
 dv = torch.empty(T_cap, dtype=torch.int64, device=dev); di = torch.empty(T_cap, dtype=torch.int32, device=dev)
 T = ctx.synth_index(1234, targets, world.filler_tax_lo, world.filler_tax_hi, rv, rt, dv.data_ptr(), di.data_ptr())
@@ -23,9 +23,9 @@ tl = np.concatenate([np.unique(rt), np.arange(world.filler_tax_lo, world.filler_
 ix = ctx.index_from_device(dv.data_ptr(), di.data_ptr(), T, taxdir, tl, params)
 b2 = None
 if mode == 2:
-    b, o, b2 = bench.gen_reads(torch, dev, world, reads, 150, 0.10, 0.005, 1234 + 17, paired=True)
+    b, o, b2 = bench.gen_reads(torch, dev, world.genomes, reads, 150, 0.10, 0.005, 1234 + 17, paired=True)
 else:
-    b, o = bench.gen_reads(torch, dev, world, reads, 150, 0.10, 0.005, 1234 + 17)
+    b, o = bench.gen_reads(torch, dev, world.genomes, reads, 150, 0.10, 0.005, 1234 + 17)
 res = torch.empty(reads * 24, dtype=torch.uint8, device=dev)
 cap = reads * 40 * mode + 1024
 tt = torch.empty(cap, dtype=torch.int32, device=dev); tc = torch.empty(cap, dtype=torch.int32, device=dev)

@@ -10,14 +10,14 @@ params = M.default_params(seq_mode=SEQ_MODE, syncmer=1, smer_len=5)
 import tempfile
 world = bench.build_world(1234, 8, 500000, 5000)
 taxdir = tempfile.mkdtemp(); world.tax.write(taxdir)
-rv, rt = bench.extract_targets(ctx, M, world, params)
+rv, rt, _ = bench.extract_targets(ctx, M, world, params)
 nf = int(2e8); Tc = nf + len(rv)
 dv = torch.empty(Tc, dtype=torch.int64, device=dev); di = torch.empty(Tc, dtype=torch.int32, device=dev)
 T = ctx.synth_index(1234, nf, world.filler_tax_lo, world.filler_tax_hi, rv, rt, dv.data_ptr(), di.data_ptr())
 tl = np.concatenate([np.unique(rt), np.arange(world.filler_tax_lo, world.filler_tax_hi + 1, dtype=np.int32)])
 ix = ctx.index_from_device(dv.data_ptr(), di.data_ptr(), T, taxdir, tl, params)
 N = NREADS
-db, do = bench.gen_reads(torch, dev, world, N, RLEN, 0.10, 0.005, 99)
+db, do = bench.gen_reads(torch, dev, world.genomes, N, RLEN, 0.10, 0.005, 99)
 dres = torch.empty(N * 24, dtype=torch.uint8, device=dev); cap = N * (20 + RLEN // 9) + 1024
 dtt = torch.empty(cap, dtype=torch.int32, device=dev); dtc = torch.empty(cap, dtype=torch.int32, device=dev)
 out = (C.c_ulonglong * 24)()

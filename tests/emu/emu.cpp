@@ -74,6 +74,30 @@ size_t emu_join(const uint64_t *values, const uint32_t *info, uint64_t T, const 
     return m;
 }
 
+/* The search of k_join_dir (kernels_dir.h) restated sequentially, without the directory (the whole index is one bucket): ONE lower bound on
+ * the query's whole value; a target equal to the query ends the search -- the selection is the block of equal targets (hamming 0 <=> equal
+ * DNA parts, threshold min(2 x 0, 7) = 0) --, otherwise the run of the amino-acid part is found by stepping from the landing place and
+ * evaluated as the reference does.  Must give emu_join's (= the reference loop's) matches, in the same order. */
+size_t emu_join_one_bisection(const uint64_t *values, const uint32_t *info, uint64_t T, const int32_t *tax2species, int32_t max_taxid,
+                              uint32_t info_mask, int kmer_format, const mtb_kmer *q, size_t n, mtb_match *out, size_t cap, uint64_t *n_exact) {
+    mtb_tables t; mtb_build_tables(&t);
+    const uint64_t AAM = ~0xFFFFFFull, limit = T ? T - 1 : 0;
+    size_t m = 0; uint64_t exact = 0;
+    for (size_t j = 0; j < n; j++) {
+        const uint64_t qv = q[j].value, aa = qv & AAM;
+        const uint64_t p = mtb_lower_bound(values, limit, qv);
+        uint64_t s = p, e = p;
+        if (p < limit && values[p] == qv) { e = p + 1; while (e < limit && values[e] == qv) e++; exact++; }
+        else { while (s > 0 && (values[s - 1] & AAM) == aa) s--; while (e < limit && (values[e] & AAM) == aa) e++; }
+        if (s >= e) continue;
+        const uint32_t c = mtb_join_select(&t, values, s, (uint32_t)(e - s), qv, q[j].qinfo, info, 0, tax2species, max_taxid, info_mask, kmer_format, (mtb_match *)nullptr, 0);
+        if (m + c <= cap) mtb_join_select(&t, values, s, (uint32_t)(e - s), qv, q[j].qinfo, info, 0, tax2species, max_taxid, info_mask, kmer_format, out + m, c);
+        m += c;
+    }
+    if (n_exact) *n_exact = exact;
+    return m;
+}
+
 void emu_sort_matches(mtb_match *m, size_t n) { std::sort(m, m + n, [](const mtb_match &a, const mtb_match &b) { return mtb_match_less(a, b); }); }
 
 // mirrors kernels_score.hip score_read(): sequential over the sf blocks / species blocks

@@ -251,6 +251,20 @@ class Emu:
                 return out[:n].copy()
             cap = n
 
+    def join_one_bisection(self, values, info, tax2species, info_mask, kmer_format, q):
+        """k_join_dir's search restated sequentially (emu_join_one_bisection) -> (matches, queries that found a target equal to themselves)"""
+        self.lib.emu_join_one_bisection.restype = C.c_size_t
+        cap = max(1024, 8 * len(q))
+        ne = C.c_uint64()
+        while True:
+            out = np.zeros(cap, match_dt)
+            n = self.lib.emu_join_one_bisection(_ptr(values), _ptr(info), C.c_uint64(len(values)), _ptr(tax2species),
+                                                C.c_int32(len(tax2species) - 1), C.c_uint32(info_mask), C.c_int(kmer_format),
+                                                _ptr(q), C.c_size_t(len(q)), _ptr(out), C.c_size_t(cap), C.byref(ne))
+            if n <= cap:
+                return out[:n].copy(), int(ne.value)
+            cap = n
+
     def sort_matches(self, m):
         m = m.copy()
         self.lib.emu_sort_matches(_ptr(m), C.c_size_t(len(m)))

@@ -60,6 +60,50 @@ def test_join_equals_oracle(toy, orc, emu):
     assert len(ms) == len(toy.ref["matches"]) and (ms == toy.ref["matches"]).all()
 
 
+def test_join_one_bisection_search_equals_reference_loop(toy, orc, emu):
+    """The search k_join_dir runs -- one bisection on the whole value; a target equal to the query ends it with the block of equal
+    targets as the selection; otherwise the run is found by stepping from the landing place -- selects what the reference's loop over the
+    run of the amino-acid part selects (KmerMatcher.cpp:1117-1146: the minimum is 0, the threshold min(2 x 0, 7) = 0, and only equal DNA
+    parts have hamming sum 0)."""
+    t2s, _ = _tables(toy, orc)
+    q = np.sort(toy.ref["kmers"], order=["value"], kind="stable")
+    info = toy.taxids.astype(np.uint32)
+    m, n_exact = emu.join_one_bisection(toy.values, info, t2s, 0xFFFFFFFF, toy.p.kmer_format, q)
+    ref = emu.join(toy.values, info, t2s, 0xFFFFFFFF, toy.p.kmer_format, q)
+    assert len(m) == len(ref) and (m == ref).all()            # same matches in the same (query, index) order
+    ms = emu.sort_matches(m)
+    assert len(ms) == len(toy.ref["matches"]) and (ms == toy.ref["matches"]).all()
+    assert n_exact > 0                                        # reads sampled from the genomes: both branches are taken
+    assert n_exact < len(q)
+
+
+def test_join_one_bisection_search_on_long_runs(orc, emu, tmp_path):
+    """The same on a database with runs of > 70 candidates and a spread of hamming sums, including runs where several species hold
+    the query's own value (a block of equal targets inside a long run) and queries that land past the end of their run."""
+    from conftest import HotToy
+    t = HotToy(orc, tmp_path / "db", seq_mode=1, n_reads=200)
+    assert t.max_run > 64
+    mx = orc.lib.orc_tax_max_id(t.tax)
+    t2s = tax2species_table(orc, t.tax, t.taxids, mx)
+    info = t.taxids.astype(np.uint32)
+    q = np.sort(t.ref["kmers"], order=["value"], kind="stable")
+    # edge queries: DNA part all-ones / all-zeros of existing amino-acid parts (land at the end / the start of the run), and absent parts
+    from helpers import kmer_dt
+    extra = np.zeros(6, kmer_dt)
+    v = t.values[len(t.values) // 2]
+    aam = ~np.uint64(0xFFFFFF)
+    extra["value"] = [v | np.uint64(0xFFFFFF), v & aam, t.values[0] & aam, t.values[-2] | np.uint64(0xFFFFFF), np.uint64(0), (v & aam) + np.uint64(1 << 24)]
+    extra["qinfo"] = np.uint64(1) << np.uint64(32)
+    q = np.sort(np.concatenate([q, extra]), order=["value"], kind="stable")
+    m, n_exact = emu.join_one_bisection(t.values, info, t2s, 0xFFFFFFFF, t.p.kmer_format, q)
+    ref = emu.join(t.values, info, t2s, 0xFFFFFFFF, t.p.kmer_format, q)
+    assert len(m) == len(ref) and (m == ref).all()
+    mo = orc.sort_matches(orc.match(t.db, q))
+    ms = emu.sort_matches(m)
+    assert len(ms) == len(mo) and (ms == mo).all()
+    assert n_exact > 0
+
+
 def test_join_last_index_entry_is_never_a_candidate(toy, orc, emu):
     from helpers import kmer_dt
     t2s, _ = _tables(toy, orc)
