@@ -330,6 +330,18 @@ int main(int argc, char **argv) {
                 idle.put(std::move(j));
             }
         });
+        /* the output files are opened while the database loads: a job that is run again truncates GBs of rows of its previous run, which
+         * took several tenths of a second between the open and the first batch */
+        FILE *out = nullptr, *flt[2] = {nullptr, nullptr}, *rmv[2] = {nullptr, nullptr};
+        std::string out_err;
+        std::thread out_opener([&] {
+            auto open_w = [&](const std::string &p) { FILE *f = fopen(p.c_str(), "w"); if (!f && out_err.empty()) out_err = "cannot write " + p; return f; };
+            out = open_w(prefix + "_classifications.tsv");
+            if (filter) {
+                flt[0] = open_w(base1 + "_filtered.fna"); if (paired) flt[1] = open_w(base2 + "_filtered.fna");
+                if (print_mode == 2) { rmv[0] = open_w(base1 + "_removed.fna"); if (paired) rmv[1] = open_w(base2 + "_removed.fna"); }
+            }
+        });
         mtbhost::WorkerPool parse_pool(threads), format_pool(threads);
         mtbhost::PackTable pack_table;
         { static mtb_tables tabs; mtb_build_tables(&tabs); for (int c = 0; c < 256; c++) pack_table.code[c] = tabs.base[c] < 4 ? tabs.base[c] : 0xFF; }
@@ -389,14 +401,8 @@ int main(int argc, char **argv) {
                         os4[3] ? ", packed on load (8-byte words, info folded in)" : "");
         }
 
-        FILE *out = fopen((prefix + "_classifications.tsv").c_str(), "w");
-        if (!out) throw std::runtime_error("cannot write " + prefix + "_classifications.tsv");
-        FILE *flt[2] = {nullptr, nullptr}, *rmv[2] = {nullptr, nullptr};
-        if (filter) {
-            auto open_w = [](const std::string &p) { FILE *f = fopen(p.c_str(), "w"); if (!f) throw std::runtime_error("cannot write " + p); return f; };
-            flt[0] = open_w(base1 + "_filtered.fna"); if (paired) flt[1] = open_w(base2 + "_filtered.fna");
-            if (print_mode == 2) { rmv[0] = open_w(base1 + "_removed.fna"); if (paired) rmv[1] = open_w(base2 + "_removed.fna"); }
-        }
+        out_opener.join();
+        if (!out_err.empty()) { fprintf(stderr, "mtb_classify: %s\n", out_err.c_str()); fflush(stderr); _exit(1); }      /* (the parser thread is running: leave at once) */
         fputs(lineage ? "#is_classified\tname\ttaxID\tquery_length\tscore\trank\tlineage\ttaxID:match_count\n"
                       : "#is_classified\tname\ttaxID\tquery_length\tscore\trank\ttaxID:match_count\n", out);
         /* stage 3: format + append, per-taxon read counts (Classifier.cpp:201-203) */
@@ -440,7 +446,7 @@ int main(int argc, char **argv) {
         const int W = gpu_workers;
         std::atomic<double> tc_per_read{6.0};
         std::vector<std::vector<mtb_ctx *>> wctx((size_t)W, std::vector<mtb_ctx *>(ND, nullptr));
-        for (int w = 0; w < W; w++) for (size_t d = 0; d < ND; d++) { if (w == 0) wctx[0][d] = engs[d]->ctx; else mtb::check(mtb_ctx_create(devices[d], nullptr, &wctx[(size_t)w][d])); }
+        for (int w = 0; w < W; w++) for (size_t d = 0; d < ND; d++) { if (w == 0) wctx[0][d] = engs[d]->ctx; else if (mtb_ctx_create(devices[d], nullptr, &wctx[(size_t)w][d]) != MTB_OK) { fprintf(stderr, "mtb_classify: mtb: %s\n", mtb_last_error()); fflush(stderr); _exit(1); } }
         std::vector<double> w_busy((size_t)W, 0.0), w_dev((size_t)W, 0.0);
         auto process = [&](Job &job, int w) {
             Job *j = &job;
