@@ -128,6 +128,8 @@ inline bool finalize_taxonomy(Taxonomy *t, const std::vector<RawNode> &nodes, co
     int32_t mx = std::max<int32_t>(max_id, 1);
     for (auto &n : nodes) mx = std::max(mx, std::max(n.id, n.parent));
     for (auto &m : aliases) mx = std::max(mx, std::max(m.first, m.second));
+    /* the tables are dense in the taxon id (NCBI ids are below 2^22 today): a damaged file must not ask for tens of GB of them */
+    if (mx > (1 << 28)) { *err = "taxonomy: implausible taxon id " + std::to_string(mx); return false; }
     t->max_id = mx;
     size_t sz = (size_t)mx + 1;
     t->canon.assign(sz, -1); t->parent.assign(sz, -1); t->depth.assign(sz, 0); t->rank_idx.assign(sz, -1);
@@ -143,10 +145,16 @@ inline bool finalize_taxonomy(Taxonomy *t, const std::vector<RawNode> &nodes, co
         t->acc_leaf[(size_t)n.id] = (n.rank.empty() || n.rank == "accession") ? 1 : 0;
     }
     for (auto &n : nodes) if (t->canon[(size_t)n.parent] < 0) { *err = "taxonomy: missing parent taxon"; return false; }
+    {   /* one tree: the walks of two taxa towards each other (lca, here and on the device) end at a common root */
+        int32_t root = -1;
+        for (auto &n : nodes) if (n.parent == n.id) { if (root >= 0 && root != n.id) { *err = "taxonomy: more than one root (" + std::to_string(root) + ", " + std::to_string(n.id) + ")"; return false; } root = n.id; }
+    }
     for (auto &m : aliases) if (m.first >= 0 && m.second >= 0 && t->canon[(size_t)m.first] < 0 && t->canon[(size_t)m.second] >= 0) t->canon[(size_t)m.first] = t->canon[(size_t)m.second];
     for (auto &n : nodes) {
         int32_t d = 0, c = n.id;
         while (t->parent[(size_t)c] != c && d < 100000) { c = t->parent[(size_t)c]; d++; }
+        /* every walk towards the root below (and on the device) relies on reaching a node that is its own parent */
+        if (d >= 100000) { *err = "taxonomy: the parent links of taxon " + std::to_string(n.id) + " do not lead to a root (cycle)"; return false; }
         t->depth[(size_t)n.id] = d;
     }
     const int SPECIES = find_rank_index("species");

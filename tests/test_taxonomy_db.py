@@ -135,3 +135,43 @@ def test_two_independent_writers_read_alike(emu, tmp_path, use_internal):
         assert (a[key] == b[key]).all() and (a[key] == c[key]).all(), key
     assert a["euk"] == b["euk"] == c["euk"] != 0
     assert open(p1, "rb").read() != open(p2, "rb").read()          # (different bytes: string block and tour tables)
+
+
+@pytest.fixture(scope="module")
+def taxonomy_check(tmp_path_factory):
+    import subprocess
+    exe = str(tmp_path_factory.mktemp("taxchk") / "taxonomy_check")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-o", exe, os.path.join(root, "tests", "emu", "taxonomy_check.cpp")])
+    return exe
+
+
+def test_damaged_taxonomies_are_refused(taxonomy_check, tmp_path):
+    """What mtb_index_open's host side does with taxonomy files that do not describe one tree: an error, not a walk that never ends
+    (the LCA walks here and on the device rely on a single root that is its own parent) and not tables sized by a garbage id.
+    Found by mutating valid files under AddressSanitizer (byte flips, truncation, zeroed ranges, extreme integers: no crash)."""
+    import subprocess
+
+    def check(lines, merged=b""):
+        d = tmp_path / f"t{check.n}"; check.n += 1
+        os.makedirs(d)
+        (d / "nodes.dmp").write_bytes(b"".join(b"%d\t|\t%d\t|\t%s\t|\t\t|\n" % (a, b, r) for a, b, r in lines))
+        (d / "names.dmp").write_bytes(b"".join(b"%d\t|\tn%d\t|\t\t|\tscientific name\t|\n" % (a, a) for a, _, _ in lines) + b"3\t|\tEukaryota\t|\t\t|\tscientific name\t|\n")
+        (d / "merged.dmp").write_bytes(merged)
+        return subprocess.run([taxonomy_check, "dmp", str(d)], capture_output=True, timeout=60)
+    check.n = 0
+    good = [(1, 1, b"no rank"), (2, 1, b"superkingdom"), (3, 1, b"superkingdom"), (4, 2, b"genus"), (5, 4, b"species"), (6, 3, b"species")]
+    r = check(good)
+    assert r.returncode == 0 and b"ok max_id 6, 6 nodes, eukaryota 3" in r.stdout
+    r = check(good[:4] + [(5, 6, b"species"), (6, 5, b"genus")])                      # two nodes that are each other's parent
+    assert r.returncode == 1 and b"cycle" in r.stderr
+    r = check(good + [(7, 7, b"no rank"), (8, 7, b"species")])                        # a second tree
+    assert r.returncode == 1 and b"more than one root" in r.stderr
+    r = check(good + [(9, 10, b"species")])
+    assert r.returncode == 1 and b"missing parent" in r.stderr
+    r = check(good + [(2000000000, 1, b"species")])
+    assert r.returncode == 1 and b"implausible taxon id" in r.stderr
+    r = check(good + [(-7, 1, b"species")])
+    assert r.returncode == 1 and b"negative" in r.stderr
+    r = check(good, merged=b"77\t|\t5\t|\n-3\t|\t5\t|\n5\t|\t-3\t|\n")               # aliases: a usable one and two with negative ids (ignored)
+    assert r.returncode == 0 and b"ok max_id 77" in r.stdout
