@@ -277,6 +277,18 @@ mtb_status mtb_classify_batch_packed(mtb_ctx *, mtb_index *, const mtb_params *,
  * batch, then the batch is processed: KmerExtractor.cpp:117-173.)                                                                    */
 mtb_status mtb_prefetch_batch_packed(mtb_ctx *, const mtb_params *, const uint8_t *packed2, const uint8_t *nmask, const uint32_t *lens,
                                      const uint8_t *packed2_mate, const uint8_t *nmask_mate, const uint32_t *lens_mate, uint64_t n_reads);
+/* Results on their way back while the NEXT batch computes: mtb_classify_batch_packed_async is mtb_classify_batch_packed, except that it
+ * returns once the copies of the rows and of the packed taxID:count lists into the caller's arrays (pinned: mtb_host_alloc) are QUEUED on a
+ * download stream of the context.  *n_taxcnt is final on return; MTB_ERR_CAPACITY as before (nothing queued: call again with larger arrays).
+ * The arrays of call k belong to the library until call k + 1 of the same context returns -- whatever its status -- or until
+ * mtb_ctx_wait_results().  Call order per context thread: prefetch(k+1), async(k), [hand on batch k-1], prefetch(k+2), async(k+1), ...,
+ * mtb_ctx_wait_results(), [hand on the last batch].  (The reference hands a batch on when it is through, Classifier.cpp:81-125; here the
+ * hand-over happens one batch later and the device does not wait for PCIe between batches.) */
+mtb_status mtb_classify_batch_packed_async(mtb_ctx *, mtb_index *, const mtb_params *, const uint8_t *packed2, const uint8_t *nmask,
+                                           const uint32_t *lens, const uint8_t *packed2_mate, const uint8_t *nmask_mate,
+                                           const uint32_t *lens_mate, uint64_t n_reads, mtb_result *results, int32_t *taxcnt_tax,
+                                           uint32_t *taxcnt_cnt, uint64_t taxcnt_cap, uint64_t *n_taxcnt);
+mtb_status mtb_ctx_wait_results(mtb_ctx *);
 /* Host-side helpers of a driver that overlaps its start-up: mtb_db_parameters applies DBDIR/db.parameters to *p (what mtb_index_open
  * does first: common.cpp:88-133) without opening anything; mtb_ctx_reserve grows the context's big workspace buffers (metamer buffers,
  * digit arrays, slot segments) for short-read batches of n_reads reads / n_bases bases ahead of time -- it may run on ANOTHER thread while

@@ -308,6 +308,34 @@ class Context:
             _chk(st)
             return compact_taxcnt(res, tt, tc)
 
+    def classify_batches_packed_async(self, index, params, batches):
+        """mtb_classify_batch_packed_async over a list of (bases, offs, bases2, offs2) batches the way a driver uses it: batch k's results are
+        taken after the call for batch k + 1 has returned (the last one's after mtb_ctx_wait_results) -> list of (results, taxcnt_tax, taxcnt_cnt)"""
+        out, held = [], None
+        for (bases, offs, bases2, offs2) in batches:
+            n = len(offs) - 1
+            p1 = self.pack_reads(bases, offs)
+            p2 = self.pack_reads(bases2, offs2) if bases2 is not None else (None, None, None)
+            res = np.frombuffer(bytearray(b"\xEE" * (n * result_dt.itemsize)), dtype=result_dt)
+            cap = max(1024, 3 * n)
+            while True:
+                tt = np.full(cap, -286331154, np.int32); tc = np.full(cap, 0xEEEEEEEE, np.uint32)
+                cnt = C.c_uint64()
+                st = self.L.mtb_classify_batch_packed_async(self.h, index.h, C.byref(params), _p(p1[0]), _p(p1[1]), _p(p1[2]), _p(p2[0]), _p(p2[1]), _p(p2[2]),
+                                                            C.c_uint64(n), _p(res), _p(tt), _p(tc), C.c_uint64(cap), C.byref(cnt))
+                if st == MTB_ERR_CAPACITY and cnt.value > cap:
+                    cap = cnt.value
+                    continue
+                _chk(st)
+                break
+            if held is not None:                       # the previous batch's arrays are complete now
+                out.append(compact_taxcnt(*held))
+            held = (res, tt, tc, p1, p2)[:3]
+        _chk(self.L.mtb_ctx_wait_results(self.h))
+        if held is not None:
+            out.append(compact_taxcnt(*held))
+        return out
+
     def classify_batch_device(self, index, params, d_bases, d_offs, d_bases2, d_offs2, n_reads, n_bases,
                               d_results, d_tc_tax, d_tc_cnt, tc_cap):
         cnt = C.c_uint64()

@@ -27,7 +27,8 @@
  *   own flags: --max-reads N (host batch)  --gpu-workers W (default 1; W batches inside the GPU stage at once, each on contexts of its own, so that
  *          one batch's PCIe transfers overlap another's kernels -- measured on one MI355X: no gain, the kernels of two batches slow each other
  *          by what the overlap wins, profiles/r03_notes.md)  --pack-reads 0|1 (default 1: the reads cross PCIe as 2-bit codes + invalid mask out of
- *          pinned buffers, mtb_classify_batch_packed; 0: as text)  --partitioned 1 (with --devices: engine d holds value range d of the database -- for
+ *          pinned buffers, mtb_classify_batch_packed; 0: as text)  --async-results 1 (default 0; one device, packed reads: a batch's results are copied out
+ *          while the next batch computes -- mtb_classify_batch_packed_async -- and reach the formatter one batch later)  --partitioned 1 (with --devices: engine d holds value range d of the database -- for
  *          databases larger than one GPU's HBM; metamers and matches are exchanged between the GPUs)
  *          --device N | --devices 0,1,... (one engine per GPU: every host batch is cut into
  *          contiguous read ranges, one per device, classified concurrently, results concatenated in input order and
@@ -263,7 +264,7 @@ int main(int argc, char **argv) {
     mtb_params par; mtb_default_params(&par);
     std::string taxdir; std::vector<int> devices(1, 0); size_t max_reads = 2000000;
     int threads = (int)std::max(1u, std::min(128u, std::thread::hardware_concurrency()));
-    bool lineage = false, filter = false, min_score_given = false, partitioned = false, pack = true; int print_mode = 1, gpu_workers = 1;
+    bool lineage = false, filter = false, min_score_given = false, partitioned = false, pack = true, async_results = false; int print_mode = 1, gpu_workers = 1;
     std::vector<std::string> pos;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -285,6 +286,7 @@ int main(int argc, char **argv) {
         else if (a == "--device") { devices.assign(1, atoi(val().c_str())); }
         else if (a == "--partitioned") partitioned = atoi(val().c_str()) != 0;
         else if (a == "--pack-reads") pack = atoi(val().c_str()) != 0;
+        else if (a == "--async-results") async_results = atoi(val().c_str()) != 0;
         else if (a == "--gpu-workers") gpu_workers = std::max(1, std::min(4, atoi(val().c_str())));
         else if (a == "--devices") { devices.clear(); std::stringstream ss(val()); std::string tok; while (std::getline(ss, tok, ',')) if (!tok.empty()) devices.push_back(atoi(tok.c_str())); }
         else if (a == "--reduced-aa") { if (atoi(val().c_str()) != 0) { fprintf(stderr, "mtb_classify: --reduced-aa 1 is not implemented\n"); return 1; } }
@@ -308,6 +310,7 @@ int main(int argc, char **argv) {
     }
     if (filter && !min_score_given) par.min_score = 0.5f;     /* setFilterDefaults, filter.cpp:8 */
     if (partitioned) { pack = false; gpu_workers = 1; }        /* (the partitioned batch takes the text; its engines work on one batch together) */
+    if (!pack || partitioned || devices.size() != 1) async_results = false;      /* (one engine per worker, packed reads: mtb_classify_batch_packed_async) */
     const std::string dbdir = pos[paired ? 2 : 1];
     /* classify: <OUTDIR>/<JobID>_*; filter: <base of the first input>_* (QueryFilter.cpp:75-93) */
     const std::string base1 = filter ? query_base_name(pos[0]) : std::string(), base2 = filter && paired ? query_base_name(pos[1]) : std::string();
@@ -484,7 +487,7 @@ int main(int argc, char **argv) {
                 for (;;) {
                     R.tt.resize_uninit(cap); R.tc.resize_uninit(cap);
                     mtb_status st = pack
-                        ? mtb_classify_batch_packed(cx, engs[d]->index, &pd, j->r1.packed2.data() + 2 * slot_lo[d], j->r1.nmask.data() + slot_lo[d], j->r1.lens.data() + lo,
+                        ? (async_results ? mtb_classify_batch_packed_async : mtb_classify_batch_packed)(cx, engs[d]->index, &pd, j->r1.packed2.data() + 2 * slot_lo[d], j->r1.nmask.data() + slot_lo[d], j->r1.lens.data() + lo,
                                                     paired ? j->r2.packed2.data() + 2 * slot2_lo[d] : nullptr, paired ? j->r2.nmask.data() + slot2_lo[d] : nullptr,
                                                     paired ? j->r2.lens.data() + lo : nullptr, m, j->res.data() + lo, R.tt.data(), R.tc.data(), cap, &R.ntc)
                         : mtb_classify_batch(cx, engs[d]->index, &pd, j->r1.bases.data() + b0, R.offs.data(),
@@ -552,9 +555,28 @@ int main(int argc, char **argv) {
         const bool can_prefetch = pack && !partitioned && ND == 1;
         for (int w = 0; w < W; w++) workers.emplace_back([&, w] {
             std::unique_ptr<Job> j = win[(size_t)w]->get();
+            std::unique_ptr<Job> held;           /* --async-results 1: the batch whose results are still being copied out */
             for (;;) {
                 const bool last = j->last;
                 std::unique_ptr<Job> nxt;
+                if (async_results) {
+                    const bool run_it = !last && !failed();
+                    if (run_it) {
+                        nxt = win[(size_t)w]->try_get();
+                        if (nxt && !nxt->last && can_prefetch && nxt->r1.size()) {
+                            mtb_params pd = par;
+                            (void)mtb_prefetch_batch_packed(wctx[(size_t)w][0], &pd, nxt->r1.packed2.data(), nxt->r1.nmask.data(), nxt->r1.lens.data(), paired ? nxt->r2.packed2.data() : nullptr,
+                                                            paired ? nxt->r2.nmask.data() : nullptr, paired ? nxt->r2.lens.data() : nullptr, nxt->r1.size());
+                        }
+                        process(*j, w);          /* returns with this batch's copies queued; the previous batch's are complete (whatever the status) */
+                    } else if (mtb_ctx_wait_results(wctx[(size_t)w][0]) != MTB_OK) { std::lock_guard<std::mutex> l(gpu_err_mu); if (gpu_err.empty()) gpu_err = mtb_last_error(); }
+                    if (held) wout[(size_t)w]->put(std::move(held));
+                    if (last) { wout[(size_t)w]->put(std::move(j)); break; }
+                    if (run_it && !failed()) held = std::move(j);
+                    else wout[(size_t)w]->put(std::move(j));       /* nothing is in flight for this batch (the collector recycles it after a failure) */
+                    j = nxt ? std::move(nxt) : win[(size_t)w]->get();
+                    continue;
+                }
                 if (!last) {
                     nxt = win[(size_t)w]->try_get();
                     if (nxt && !nxt->last && can_prefetch && nxt->r1.size() && !failed()) {

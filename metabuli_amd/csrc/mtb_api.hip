@@ -116,6 +116,9 @@ struct mtb_ctx {
     /* upload of the NEXT batch's packed reads while the current batch computes (mtb_prefetch_batch_packed): a copy stream, two sets of
      * input buffers, and what the set that is being filled holds */
     hipStream_t copy_stream = nullptr; hipEvent_t copy_done = nullptr;
+    /* results on their way back while the next batch computes (mtb_classify_batch_packed_async): a download stream, the event that closes the
+     * queued copies, and which of the two device-side result buffer sets the next call writes */
+    hipStream_t down_stream = nullptr; hipEvent_t down_ready = nullptr, down_done = nullptr; bool down_pending = false; int res_set = 0;
     int pk_set = 0;                                  /* the set the last classify call read */
     struct Prefetched { const void *key = nullptr, *key2 = nullptr; uint64_t n_reads = 0, slots = 0, slots2 = 0; bool valid = false; } pre;
     uint32_t lslot_tf_start = 1;                     /* long-read slot ranges: tail factor the next batch starts with (1 = a quarter of the metamers, 4 = all) */
@@ -365,6 +368,9 @@ void mtb_ctx_destroy(mtb_ctx *c) {
     if (c->d_scal) e = hipFree(c->d_scal);
     if (c->d_ovfctr) e = hipFree(c->d_ovfctr);
     if (c->is_lane && c->stream) e = hipStreamDestroy(c->stream);
+    if (c->down_stream) { e = hipStreamSynchronize(c->down_stream); e = hipStreamDestroy(c->down_stream); }
+    if (c->down_ready) e = hipEventDestroy(c->down_ready);
+    if (c->down_done) e = hipEventDestroy(c->down_done);
     if (c->copy_stream) { e = hipStreamSynchronize(c->copy_stream); e = hipStreamDestroy(c->copy_stream); }
     if (c->copy_done) e = hipEventDestroy(c->copy_done);
     for (int i = 0; i < 8; i++) e = hipEventDestroy(c->ev[i]);
@@ -1946,7 +1952,7 @@ static mtb_status score_fixed_slots(mtb_ctx *c, mtb_index *ix, const mtb_params 
 
 /* results of a batch to the host with the taxID:count lists packed on the device first: only what they hold crosses PCIe */
 static mtb_status download_packed(mtb_ctx *c, mtb_result *d_res, const int32_t *d_tt, const uint32_t *d_tc, uint64_t n_reads, mtb_result *results,
-                                  int32_t *taxcnt_tax, uint32_t *taxcnt_cnt, uint64_t *n_taxcnt, uint64_t host_cap = ~0ull) {
+                                  int32_t *taxcnt_tax, uint32_t *taxcnt_cnt, uint64_t *n_taxcnt, uint64_t host_cap = ~0ull, int async_set = -1 /* >= 0: queue the copies on the download stream, packed lists in buffer set async_set */) {
     uint32_t *d_n; uint64_t *d_off, *d_ws; int32_t *d_tt2; uint32_t *d_tc2;
     STCHK(ensure(c, "tcn", n_reads, &d_n)); STCHK(ensure(c, "tcnewoff", n_reads + 1, &d_off)); STCHK(ensure(c, "scanws", scan_ws_elems(n_reads + 1), &d_ws));
     hipLaunchKernelGGL(k_taxcnt_n, dim3((uint32_t)((n_reads + 255) / 256)), dim3(256), 0, c->stream, (const mtb_result *)d_res, n_reads, d_n);
@@ -1954,9 +1960,20 @@ static mtb_status download_packed(mtb_ctx *c, mtb_result *d_res, const int32_t *
     uint64_t total = 0;
     STCHK(d2h(c, &total, d_off + n_reads, 8));
     if (total > host_cap) { *n_taxcnt = total; return fail(MTB_ERR_CAPACITY, "taxcnt arrays too small for the batch's taxID:count lists"); }
-    STCHK(ensure(c, "tctax2", total, &d_tt2)); STCHK(ensure(c, "tccnt2", total, &d_tc2));
+    STCHK(ensure(c, async_set == 1 ? "tctax2b" : "tctax2", total, &d_tt2)); STCHK(ensure(c, async_set == 1 ? "tccnt2b" : "tccnt2", total, &d_tc2));
     hipLaunchKernelGGL(k_taxcnt_pack, dim3((uint32_t)((n_reads + 255) / 256)), dim3(256), 0, c->stream, d_res, n_reads, (const uint64_t *)d_off, d_tt, d_tc, d_tt2, d_tc2);
     HIPCHK(hipGetLastError());
+    if (async_set >= 0) {
+        /* the rows and the packed lists leave on the download stream once the pack kernel is through; the compute stream is free for the next batch */
+        HIPCHK(hipEventRecord(c->down_ready, c->stream));
+        HIPCHK(hipStreamWaitEvent(c->down_stream, c->down_ready, 0));
+        HIPCHK(hipMemcpyAsync(results, d_res, n_reads * sizeof(mtb_result), hipMemcpyDeviceToHost, c->down_stream));
+        if (total) { HIPCHK(hipMemcpyAsync(taxcnt_tax, d_tt2, total * 4, hipMemcpyDeviceToHost, c->down_stream)); HIPCHK(hipMemcpyAsync(taxcnt_cnt, d_tc2, total * 4, hipMemcpyDeviceToHost, c->down_stream)); }
+        HIPCHK(hipEventRecord(c->down_done, c->down_stream));
+        c->down_pending = true;
+        *n_taxcnt = total;
+        return MTB_OK;
+    }
     STCHK(d2h(c, results, d_res, n_reads * sizeof(mtb_result)));
     if (total) { STCHK(d2h(c, taxcnt_tax, d_tt2, total * 4)); STCHK(d2h(c, taxcnt_cnt, d_tc2, total * 4)); }
     *n_taxcnt = total;
@@ -2386,13 +2403,27 @@ static mtb_status upload_packed(mtb_ctx *c, const char *tag, int set, bool prefe
     return MTB_OK;
 }
 
-mtb_status mtb_classify_batch_packed(mtb_ctx *c, mtb_index *ix, const mtb_params *p, const uint8_t *packed2, const uint8_t *nmask, const uint32_t *lens,
-                                     const uint8_t *packed2_mate, const uint8_t *nmask_mate, const uint32_t *lens_mate, uint64_t n_reads,
-                                     mtb_result *results, int32_t *taxcnt_tax, uint32_t *taxcnt_cnt, uint64_t taxcnt_cap, uint64_t *n_taxcnt) {
+} // extern "C"
+
+static mtb_status wait_results(mtb_ctx *c) {
+    if (c->down_pending) { HIPCHK(hipEventSynchronize(c->down_done)); c->down_pending = false; }
+    return MTB_OK;
+}
+
+static mtb_status classify_packed_impl(mtb_ctx *c, mtb_index *ix, const mtb_params *p, const uint8_t *packed2, const uint8_t *nmask, const uint32_t *lens,
+                                       const uint8_t *packed2_mate, const uint8_t *nmask_mate, const uint32_t *lens_mate, uint64_t n_reads,
+                                       mtb_result *results, int32_t *taxcnt_tax, uint32_t *taxcnt_cnt, uint64_t taxcnt_cap, uint64_t *n_taxcnt, bool async) {
     if (!c || !ix || !p || !n_taxcnt) return fail(MTB_ERR_ARG, "NULL argument");
     HIPCHK(hipSetDevice(c->device));
     *n_taxcnt = 0;
-    if (n_reads == 0) return MTB_OK;
+    if (!async) STCHK(wait_results(c));          /* (a synchronous call after asynchronous ones: nothing stays in flight behind it) */
+    if (n_reads == 0) return async ? wait_results(c) : MTB_OK;
+    if (async && !c->down_stream) {
+        HIPCHK(hipStreamCreateWithFlags(&c->down_stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&c->down_ready, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->down_done, hipEventDisableTiming));
+    }
+    /* asynchronous results: this call's rows and lists are built in the device buffer set the copies still in flight do not read */
+    const int rset = async ? c->res_set : 0;
     if (!packed2 || !nmask || !lens) return fail(MTB_ERR_ARG, "packed2/nmask/lens NULL");
     char *d_b = nullptr, *d_b2 = nullptr; uint64_t *d_o = nullptr, *d_o2 = nullptr; uint64_t nb = 0, nb2 = 0;
     static const bool timing = getenv("MTB_HOST_TIMING") != nullptr;      /* wall time of the call's three parts on stderr (the uploads are synchronised for it) */
@@ -2410,21 +2441,59 @@ mtb_status mtb_classify_batch_packed(mtb_ctx *c, mtb_index *ix, const mtb_params
     if (p->seq_mode == 2) STCHK(upload_packed(c, "2", set, pre, packed2_mate, nmask_mate, lens_mate, n_reads, &d_b2, &d_o2, &nb2));
     mtb_result *d_res; int32_t *d_tt; uint32_t *d_tc;
     const uint64_t dcap = c->lanes.size() < 2 ? std::max<uint64_t>(taxcnt_cap, taxcnt_device_slots(p, n_reads, nb + nb2)) : taxcnt_cap;     /* (as in mtb_classify_batch) */
-    STCHK(ensure(c, "results", n_reads, &d_res)); STCHK(ensure(c, "tctax", dcap, &d_tt)); STCHK(ensure(c, "tccnt", dcap, &d_tc));
+    STCHK(ensure(c, rset == 1 ? "resultsb" : "results", n_reads, &d_res)); STCHK(ensure(c, "tctax", dcap, &d_tt)); STCHK(ensure(c, "tccnt", dcap, &d_tc));
     if (timing) HIPCHK(hipStreamSynchronize(c->stream));
     const double t1 = now();
     mtb_status st = mtb_classify_batch_device(c, ix, p, d_b, d_o, d_b2, d_o2, n_reads, nb + nb2, d_res, d_tt, d_tc, dcap, n_taxcnt);
     if (st != MTB_OK) return st;
     const double t2 = now();
     if (c->lanes.size() < 2 && *n_taxcnt) {
+        if (async) {
+            /* the previous call's copies have had this whole batch to finish: its results are the caller's from here on (mtb.h) */
+            STCHK(wait_results(c));
+            st = download_packed(c, d_res, d_tt, d_tc, n_reads, results, taxcnt_tax, taxcnt_cnt, n_taxcnt, taxcnt_cap, rset);
+            if (st == MTB_OK) c->res_set ^= 1;
+            return st;
+        }
         st = download_packed(c, d_res, d_tt, d_tc, n_reads, results, taxcnt_tax, taxcnt_cnt, n_taxcnt, taxcnt_cap);
         if (timing) fprintf(stderr, "mtb_classify_batch_packed: %llu reads: upload + unpack %.1f ms, classify %.1f ms (device %.1f ms), pack + download %.1f ms\n",
                             (unsigned long long)n_reads, t1 - t0, t2 - t1, (double)c->stats.ms_total, now() - t2);
         return st;
     }
+    /* (several streams, or a batch without a single taxID:count entry: plain copies) */
+    if (async) STCHK(wait_results(c));
     STCHK(d2h(c, results, d_res, n_reads * sizeof(mtb_result)));
     if (*n_taxcnt) { STCHK(d2h(c, taxcnt_tax, d_tt, *n_taxcnt * 4)); STCHK(d2h(c, taxcnt_cnt, d_tc, *n_taxcnt * 4)); }
     return MTB_OK;
+}
+
+extern "C" {
+
+mtb_status mtb_classify_batch_packed(mtb_ctx *c, mtb_index *ix, const mtb_params *p, const uint8_t *packed2, const uint8_t *nmask, const uint32_t *lens,
+                                     const uint8_t *packed2_mate, const uint8_t *nmask_mate, const uint32_t *lens_mate, uint64_t n_reads,
+                                     mtb_result *results, int32_t *taxcnt_tax, uint32_t *taxcnt_cnt, uint64_t taxcnt_cap, uint64_t *n_taxcnt) {
+    return classify_packed_impl(c, ix, p, packed2, nmask, lens, packed2_mate, nmask_mate, lens_mate, n_reads, results, taxcnt_tax, taxcnt_cnt, taxcnt_cap, n_taxcnt, false);
+}
+
+/* The same with the results on their way back while the next batch computes: returns once the copies of the rows and of the packed
+ * taxID:count lists into the caller's (pinned) arrays are QUEUED on a download stream of the context; *n_taxcnt is final on return
+ * (MTB_ERR_CAPACITY as before, nothing queued).  The arrays of call k belong to the library until call k + 1 of this context returns --
+ * whatever its status -- or until mtb_ctx_wait_results().  Two device-side result buffer sets alternate, so the batch in work never writes
+ * what the copies in flight read.  (Classifier.cpp:81-125 hands a batch's results on when the batch is through; here the hand-over of
+ * batch k happens one batch later and costs the device nothing.) */
+mtb_status mtb_classify_batch_packed_async(mtb_ctx *c, mtb_index *ix, const mtb_params *p, const uint8_t *packed2, const uint8_t *nmask, const uint32_t *lens,
+                                           const uint8_t *packed2_mate, const uint8_t *nmask_mate, const uint32_t *lens_mate, uint64_t n_reads,
+                                           mtb_result *results, int32_t *taxcnt_tax, uint32_t *taxcnt_cnt, uint64_t taxcnt_cap, uint64_t *n_taxcnt) {
+    mtb_status st = classify_packed_impl(c, ix, p, packed2, nmask, lens, packed2_mate, nmask_mate, lens_mate, n_reads, results, taxcnt_tax, taxcnt_cnt, taxcnt_cap, n_taxcnt, true);
+    if (st != MTB_OK && c && c->down_pending) {     /* the contract holds on every path: the previous call's copies are complete when this one returns */
+        hipError_t e = hipEventSynchronize(c->down_done); (void)e; c->down_pending = false;
+    }
+    return st;
+}
+mtb_status mtb_ctx_wait_results(mtb_ctx *c) {
+    if (!c) return fail(MTB_ERR_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(c->device));
+    return wait_results(c);
 }
 
 /* Starts the upload of the NEXT batch (the arrays mtb_classify_batch_packed will be called with) on the context's copy stream, into

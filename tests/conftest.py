@@ -43,6 +43,8 @@ def pytest_collection_modifyitems(config, items):
         return
     if os.path.exists("/dev/kfd") or _hip_device_count() > 0:       # /dev/kfd: the ROCm compute device node
         return
+    if os.environ.get("MTB_HIPEMU") and os.environ.get("MTB_LIB"):   # the library's sources built against tests/hipemu (tests/test_hipemu.py sets this up)
+        return
     skip = pytest.mark.skip(reason="no HIP device on this machine (libmtb has no CPU path)")
     for it in items:
         if "gpu" in it.keywords:

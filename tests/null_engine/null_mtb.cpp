@@ -51,6 +51,16 @@ struct mtb_ctx {
     /* the prefetch protocol of mtb.h: prefetch(k+1), classify(k), prefetch(k+2), classify(k+1) ... with the same pointers */
     const void *pf_p2 = nullptr, *pf_nm = nullptr, *pf_len = nullptr; uint64_t pf_n = 0; bool pf_pending = false, pf_ready = false;
     const void *rd_p2 = nullptr, *rd_nm = nullptr, *rd_len = nullptr; uint64_t rd_n = 0;
+    /* mtb_classify_batch_packed_async: the results of a call reach the caller's arrays when the NEXT call returns or at mtb_ctx_wait_results;
+     * until then the arrays are filled with 0xEE, so that a driver that hands a batch on too early writes garbage rows */
+    std::vector<mtb_result> as_res; std::vector<int32_t> as_tt; std::vector<uint32_t> as_tc;
+    mtb_result *as_dst = nullptr; int32_t *as_dtt = nullptr; uint32_t *as_dtc = nullptr; bool as_pending = false;
+    void deliver() {
+        if (!as_pending) return;
+        if (!as_res.empty()) memcpy(as_dst, as_res.data(), as_res.size() * sizeof(mtb_result));
+        if (!as_tt.empty()) { memcpy(as_dtt, as_tt.data(), as_tt.size() * 4); memcpy(as_dtc, as_tc.data(), as_tc.size() * 4); }
+        as_pending = false;
+    }
 };
 struct mtb_index {
     mtbhost::Taxonomy tax;
@@ -273,6 +283,22 @@ mtb_status mtb_classify_batch_packed(mtb_ctx *c, mtb_index *ix, const mtb_params
     c->pf_ready = c->pf_pending; c->rd_p2 = c->pf_p2; c->rd_nm = c->pf_nm; c->rd_len = c->pf_len; c->rd_n = c->pf_n; c->pf_pending = false;
     return st;
 }
+
+mtb_status mtb_classify_batch_packed_async(mtb_ctx *c, mtb_index *ix, const mtb_params *p, const uint8_t *packed2, const uint8_t *nmask, const uint32_t *lens,
+                                           const uint8_t *packed2_mate, const uint8_t *nmask_mate, const uint32_t *lens_mate, uint64_t n,
+                                           mtb_result *results, int32_t *tt, uint32_t *tc, uint64_t cap, uint64_t *ntc) {
+    if (!c || !results || !ntc) return fail(MTB_ERR_ARG, "NULL argument");
+    std::vector<mtb_result> r(n); std::vector<int32_t> a(cap); std::vector<uint32_t> b(cap);
+    mtb_status st = mtb_classify_batch_packed(c, ix, p, packed2, nmask, lens, packed2_mate, nmask_mate, lens_mate, n, r.data(), a.data(), b.data(), cap, ntc);
+    if (st == MTB_ERR_CAPACITY) return st;      /* nothing queued, nothing delivered: the same batch comes again */
+    c->deliver();                               /* the previous call's results are the caller's now, whatever this call's status */
+    if (st != MTB_OK) return st;
+    a.resize(*ntc); b.resize(*ntc);
+    c->as_res.swap(r); c->as_tt.swap(a); c->as_tc.swap(b); c->as_dst = results; c->as_dtt = tt; c->as_dtc = tc; c->as_pending = true;
+    memset(results, 0xEE, n * sizeof(mtb_result)); if (cap) { memset(tt, 0xEE, cap * 4); memset(tc, 0xEE, cap * 4); }
+    return MTB_OK;
+}
+mtb_status mtb_ctx_wait_results(mtb_ctx *c) { if (!c) return fail(MTB_ERR_ARG, "NULL argument"); c->deliver(); return MTB_OK; }
 
 /* one process, several engines, every engine owning a value range: here simply the text entry point on the first engine */
 mtb_status mtb_classify_batch_partitioned(mtb_ctx **ctxs, mtb_index **parts, uint32_t n, const uint64_t *bounds, const mtb_params *p, const char *bases,

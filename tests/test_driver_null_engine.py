@@ -140,7 +140,8 @@ def same_report(got, want):
 
 
 @pytest.mark.parametrize("pack", [1, 0])
-@pytest.mark.parametrize("extra", [[], ["--devices", "0,1,2"], ["--gpu-workers", "3"], ["--threads", "1"], ["--devices", "1,3", "--gpu-workers", "2"]])
+@pytest.mark.parametrize("extra", [[], ["--devices", "0,1,2"], ["--gpu-workers", "3"], ["--threads", "1"], ["--devices", "1,3", "--gpu-workers", "2"],
+                                   ["--async-results", "1"], ["--async-results", "1", "--gpu-workers", "2"]])
 def test_single_end_rows_in_input_order(null_driver, null_db, tmp_path, pack, extra):
     d, tax, ids = null_db
     n = 1000
@@ -178,6 +179,21 @@ def test_paired_end_and_input_formats(null_driver, null_db, tmp_path, pack, kind
     assert same_report(open(tmp_path / "job_report.tsv").read(), want_r)
 
 
+def test_paired_end_with_results_in_flight(null_driver, null_db, tmp_path):
+    """--async-results 1 (mtb_classify_batch_packed_async): a batch reaches the formatter after the NEXT call has returned -- the null engine keeps
+    the caller's arrays filled with 0xEE until then --, the last one after mtb_ctx_wait_results; one batch only, and no batch at all"""
+    d, tax, ids = null_db
+    for n, mr in ((700, 64), (50, 1000), (0, 10)):
+        names = [f"pair{i}" for i in range(n)]
+        r1, r2 = make_reads(n, 20 + n, odd=n > 100), make_reads(n, 21 + n, odd=n > 100)
+        f1, f2 = str(tmp_path / "a.fq"), str(tmp_path / "b.fq")
+        write_fastq(f1, names, r1); write_fastq(f2, names, r2)
+        want_c, want_r, _, _, _ = expected_files(str(tmp_path), tax, ids, names, r1, r2)
+        run(null_driver, ["--seq-mode", "2", "--max-reads", str(mr), "--async-results", "1", f1, f2, d, str(tmp_path), "job"])
+        assert open(tmp_path / "job_classifications.tsv").read() == want_c
+        assert same_report(open(tmp_path / "job_report.tsv").read(), want_r)
+
+
 def test_taxid_count_lists_longer_than_the_first_guess(null_driver, null_db, tmp_path):
     """the pinned taxID:count arrays start at 6 entries per read; a batch that needs more is redone with the exact size"""
     d, tax, ids = null_db
@@ -187,10 +203,10 @@ def test_taxid_count_lists_longer_than_the_first_guess(null_driver, null_db, tmp
     fq = str(tmp_path / "r.fq"); write_fastq(fq, names, r1)
     want_c, want_r, res, _, _ = expected_files(str(tmp_path), tax, ids, names, r1, None, tc_max=16)
     assert res["n_taxcnt"].sum() > 6 * n + 4096
-    for extra in ([], ["--devices", "0,1,2"]):
+    for extra in ([], ["--devices", "0,1,2"], ["--async-results", "1"]):
         p = run(null_driver, ["--seq-mode", "1", "--max-reads", "10000"] + extra + [fq, d, str(tmp_path), "job"], env={"MTB_NULL_TC_MAX": "16", "MTB_NULL_VERBOSE": "1"})
         assert open(tmp_path / "job_classifications.tsv").read() == want_c
-        if not extra:
+        if extra != ["--devices", "0,1,2"]:
             assert " 1 capacity retries" in p.stderr.decode()
 
 
@@ -203,11 +219,12 @@ def test_next_batch_is_prefetched(null_driver, null_db, tmp_path):
     r1 = make_reads(n, 5)
     fq = str(tmp_path / "r.fq"); write_fastq(fq, names, r1)
     want_c, _, _, _, _ = expected_files(str(tmp_path), tax, ids, names, r1, None)
-    p = run(null_driver, ["--seq-mode", "1", "--max-reads", "100", fq, d, str(tmp_path), "job"], env={"MTB_NULL_DELAY_MS": "30", "MTB_NULL_VERBOSE": "1"})
-    assert open(tmp_path / "job_classifications.tsv").read() == want_c
-    msg = p.stderr.decode().split("null engine: ")[1]
-    n_pref = int(msg.split(" prefetch calls, ")[1].split(" batches found prefetched")[0])
-    assert n_pref >= 6, msg                 # 12 batches of 30 ms each: the parser is far ahead after the first ones
+    for extra in ([], ["--async-results", "1"]):
+        p = run(null_driver, ["--seq-mode", "1", "--max-reads", "100"] + extra + [fq, d, str(tmp_path), "job"], env={"MTB_NULL_DELAY_MS": "30", "MTB_NULL_VERBOSE": "1"})
+        assert open(tmp_path / "job_classifications.tsv").read() == want_c
+        msg = p.stderr.decode().split("null engine: ")[1]
+        n_pref = int(msg.split(" prefetch calls, ")[1].split(" batches found prefetched")[0])
+        assert n_pref >= 6, msg                 # 12 batches of 30 ms each: the parser is far ahead after the first ones
 
 
 def test_engine_failure_ends_the_run(null_driver, null_db, tmp_path):
@@ -217,7 +234,7 @@ def test_engine_failure_ends_the_run(null_driver, null_db, tmp_path):
     r1 = make_reads(n, 6)
     fq = str(tmp_path / "r.fq"); write_fastq(fq, names, r1)
     want_c, _, _, _, _ = expected_files(str(tmp_path), tax, ids, names, r1, None)
-    for extra in ([], ["--gpu-workers", "2"], ["--devices", "0,1"]):
+    for extra in ([], ["--gpu-workers", "2"], ["--devices", "0,1"], ["--async-results", "1"], ["--async-results", "1", "--gpu-workers", "2"]):
         p = run(null_driver, ["--seq-mode", "1", "--max-reads", "100"] + extra + [fq, d, str(tmp_path), "job"], env={"MTB_NULL_FAIL_CALL": "4"}, check=False)
         assert p.returncode == 1 and "injected failure" in p.stderr.decode()
         got = open(tmp_path / "job_classifications.tsv").read()

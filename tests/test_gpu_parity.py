@@ -166,6 +166,39 @@ def test_two_bit_reads_give_the_results_of_the_text(ctx, toy):
     ix.close()
 
 
+def test_results_on_their_way_back_while_the_next_batch_runs(ctx, toy):
+    """mtb_classify_batch_packed_async: a batch's rows and taxID:count lists are copied out on a download stream while the next batch computes
+    (two device-side result buffer sets alternate) and belong to the caller once the NEXT call has returned or after mtb_ctx_wait_results.
+    Five ragged batches through the pipeline = the same batches through the synchronous call, one by one; a synchronous call afterwards
+    still works; an empty batch in the middle flushes."""
+    p = _params(toy)
+    ix = ctx.open_index(toy.dbdir, p)
+    n = toy.n_reads
+    cuts = [0, n // 7, n // 7 + 1, n // 2, n - 3, n]
+    o1 = toy.o1.astype(np.int64); o2 = toy.o2.astype(np.int64) if toy.o2 is not None else None
+
+    def part(a, b):
+        b1 = toy.b1[o1[a]:o1[b]]; q1 = (o1[a:b + 1] - o1[a]).astype(np.uint64)
+        if o2 is None:
+            return (b1, q1, None, None)
+        return (b1, q1, toy.b2[o2[a]:o2[b]], (o2[a:b + 1] - o2[a]).astype(np.uint64))
+    batches = [part(a, b) for a, b in zip(cuts[:-1], cuts[1:])]
+    want = [ctx.classify_batch_packed(ix, p, *bt) for bt in batches]
+    got = ctx.classify_batches_packed_async(ix, p, batches)
+    assert len(got) == len(want)
+    for w, g in zip(want, got):
+        for a, b in zip(w, g):
+            assert len(a) == len(b) and (a == b).all()
+    again = ctx.classify_batch_packed(ix, p, *batches[3])
+    for a, b in zip(want[3], again):
+        assert (a == b).all()
+    got2 = ctx.classify_batches_packed_async(ix, p, batches[::-1])
+    for w, g in zip(want[::-1], got2):
+        for a, b in zip(w, g):
+            assert len(a) == len(b) and (a == b).all()
+    ix.close()
+
+
 def test_empty_and_ragged_inputs(ctx, orc):
     import metabuli_amd as M
     from helpers import default_params
@@ -266,6 +299,11 @@ def test_classify_driver_tsv_outputs(toy, orc, tmp_path):
         body = krona[krona.index('<node name="all">'):-len("</krona></div></body></html>")]
         assert sorted(body.split("<node ")) == sorted(nodes.split("<node "))                 # same nodes; sibling order among ties free
         assert body.count("</node>") == nodes.count("</node>")
+    # --async-results 1: every batch's results copied out while the next one computes; the same files
+    args_a = args[:1] + ["--async-results", "1"] + args[1:-1] + ["joba"]
+    subprocess.check_call(args_a, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    assert open(str(tmp_path / "joba_classifications.tsv")).read() == open(str(tmp_path / "job_classifications.tsv")).read()
+    assert open(str(tmp_path / "joba_report.tsv")).read() == open(str(tmp_path / "job_report.tsv")).read()
     # --lineage 1 adds the lineage column (Reporter.cpp:38-40, 57-59, 74-76)
     args_l = args[:1] + ["--lineage", "1"] + args[1:-1] + ["jobl"]
     subprocess.check_call(args_l, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
@@ -422,6 +460,13 @@ class _Hip:
     def __init__(self):
         import ctypes as C
         self.C = C
+        if os.environ.get("MTB_HIPEMU"):        # the emulated build (tests/hipemu): "device" memory is host memory, the calls are exported under other names
+            class _Names:
+                pass
+            e = C.CDLL(os.environ["MTB_LIB"])
+            self.lib = _Names()
+            self.lib.hipMalloc, self.lib.hipMemcpy, self.lib.hipFree, self.lib.hipDeviceSynchronize = e.hipemu_c_malloc, e.hipemu_c_memcpy, e.hipemu_c_free, e.hipemu_c_device_synchronize
+            return
         self.lib = C.CDLL("libamdhip64.so.7")
 
     def to_device(self, a):
@@ -556,6 +601,10 @@ def test_database_opens_chunk_by_chunk(orc, tmp_path, monkeypatch, chunk, packed
     c.close()
 
 
+_needs_device = pytest.mark.skipif(bool(os.environ.get("MTB_HIPEMU")), reason="needs a HIP device of its own (torch device tensors / a hipcc build); not part of the emulated run (tests/hipemu)")
+
+
+@_needs_device
 def test_open_under_a_workspace_limit_smaller_than_the_raw_diffidx(tmp_path):
     """a 40 M-target synthetic database written by the device-side coder (mtb_index_write), opened with a workspace limit of 1/16
     of its diffIdx file: the chunked decode keeps the peak at what the index itself holds plus one small chunk (the whole-file
@@ -879,6 +928,7 @@ def test_redundancy_bit_of_legacy_databases(ctx, orc, tmp_path):
     ix.close()
 
 
+@_needs_device
 def test_bench_path_matches_the_oracle(tmp_path):
     """bench.py's own configuration in small: synthetic filler index (mtb_synth_index), borrowed device arrays
     (mtb_index_from_device), device-resident reads (mtb_classify_batch_device) -- the entry points the headline number is
@@ -907,6 +957,7 @@ def test_bench_path_matches_the_oracle(tmp_path):
             assert oc["paired"]["parity"]["reads"] == 3000 and oc["long"]["parity"]["matches"] == oc["long"]["parity"]["oracle_matches"] > 0
 
 
+@_needs_device
 def test_bench_heavy_tailed_workload_in_small(tmp_path):
     """the device-side world generator (conserved protein-coding segments shared at class-dependent prevalence) + shared-run extras:
     200 genomes give candidate runs of > 100 species where the reads hit them; the wave-cooperative scan of k_join_dir answers them
@@ -1057,6 +1108,7 @@ def test_register_resident_scorer_variants(ctx, orc, tmp_path, paired, length):
     ix.close()
 
 
+@_needs_device
 def test_no_kernel_relies_on_zeroed_device_memory(orc, tmp_path):
     """hipMalloc happens to hand out cleared VRAM; nothing may depend on it.  libmtb_xpoison.so (-DMTB_POISON_ALLOC) fills every new
     workspace buffer with 0xA5 on the library's stream before its first use; a single-end and a paired toy batch through the fused

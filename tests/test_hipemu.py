@@ -1,0 +1,105 @@
+"""The kernels' LOGIC on a machine without a GPU: the library's sources (metabuli_amd/csrc/mtb_api.hip and its kernel headers, unchanged) are
+compiled with g++ against tests/hipemu/hip/hip_runtime.h -- a stand-in for the HIP runtime that runs every workgroup as a set of cooperative
+fibers, with wave64 ballots / shuffles / DPP / readlane, LDS, barriers and atomics modelled -- and a subset of the GPU parity tests
+(tests/test_gpu_parity.py, `-m gpu`) is run against that build in a subprocess (MTB_HIPEMU=1, MTB_LIB=<the emulated build>).
+
+TEST INFRASTRUCTURE ONLY.  It is not a product path (nothing under metabuli_amd/ knows about it; libmtb.so has no CPU path), not a
+performance model and not a memory-model checker; the parity claims rest on the `-m gpu` run on an MI355X.  What it buys: kernel logic is
+checked against the oracle before GPU minutes are spent, fresh "device" memory is poisoned, and the same build under AddressSanitizer finds
+out-of-bounds accesses that a GPU hides (python tests/hipemu/build_emulated.py DIR asan).
+
+The whole `-m gpu` suite through the emulator (about 45 minutes on 8 cores):
+    python tests/hipemu/build_emulated.py /tmp/mtb_hipemu
+    MTB_HIPEMU=1 MTB_LIB=/tmp/mtb_hipemu/libmtb_hipemu.so python -m pytest tests -m gpu -q
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def emulated_lib(tmp_path_factory):
+    sys.path.insert(0, os.path.join(ROOT, "tests", "hipemu"))
+    import build_emulated
+    d = os.environ.get("MTB_HIPEMU_DIR") or str(tmp_path_factory.mktemp("hipemu"))       # MTB_HIPEMU_DIR: reuse a build between runs
+    return build_emulated.build(d)
+
+
+def _run(lib, select, timeout=1500):
+    env = dict(os.environ, MTB_HIPEMU="1", MTB_LIB=lib)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "-k", select],
+                       env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout)
+    tail = r.stdout[-3000:]
+    assert r.returncode == 0, tail
+    assert " passed" in tail and " failed" not in tail, tail
+    return tail
+
+
+def test_emulator_primitives(tmp_path):
+    """the wave64 operations of the stand-in runtime against their definitions, on a kernel of its own"""
+    src = tmp_path / "prim.cpp"
+    src.write_text(r'''
+#include <hip/hip_runtime.h>
+__global__ void k(uint64_t *out) {
+    const uint32_t t = threadIdx.x, lane = t & 63u;
+    __shared__ uint32_t s[256];
+    s[t] = t * 3u;
+    __syncthreads();
+    uint64_t acc = s[(t + 1) % blockDim.x];
+    acc += __popcll(__ballot(lane % 3 == 0));                                  /* 22 lanes */
+    acc += (uint64_t)__shfl((int)lane, 5) + (uint64_t)__shfl_xor((int)lane, 1) + (uint64_t)__shfl_up((int)lane, 2) + (uint64_t)__shfl_down((int)lane, 3);
+    acc += (uint64_t)__shfl((int)lane, 3, 16);                                  /* lane 3 of the lane's group of 16 */
+    acc += __any(lane == 63) ? 1000 : 0;
+    acc += __all(lane < 64) ? 10000 : 0;
+    acc += (uint32_t)__builtin_amdgcn_readlane((int)(lane * 7), 9);
+    int v = (int)lane;                                                          /* inclusive scan with DPP row shifts / broadcasts (dev_util.h's sequence) */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true); v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true); v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false); v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);
+    acc += (uint64_t)v << 20;
+    if (t >= 200) return;                                                        /* ended lanes leave the later operations' active sets */
+    acc += (uint64_t)__popcll(__ballot(1)) << 40;
+    const int any_or = __syncthreads_or(t == 7);
+    out[(uint64_t)blockIdx.x * 256 + t] = acc + ((uint64_t)any_or << 50);
+    atomicAdd(&out[65536], (uint64_t)1);
+}
+int main() {
+    uint64_t *d; hipMalloc(&d, 65537 * 8); hipMemset(d, 0, 65537 * 8);
+    hipLaunchKernelGGL(k, dim3(256), dim3(256), 0, 0, d);
+    unsigned long long bad = 0;
+    for (uint32_t b = 0; b < 256; b++) for (uint32_t t = 0; t < 200; t++) {
+        const uint32_t lane = t & 63u, w = t >> 6;
+        uint64_t e = ((t + 1) % 256) * 3u + 22;
+        e += 5 + (lane ^ 1) + (lane >= 2 ? lane - 2 : lane) + (lane + 3 <= 63 ? lane + 3 : lane);
+        e += (lane & ~15u) | 3u;
+        e += 1000 + 10000 + 9 * 7;
+        e += (uint64_t)(lane * (lane + 1) / 2) << 20;
+        e += (uint64_t)(w < 3 ? 64 : 8) << 40;                                  /* wavefront 3 keeps lanes 192..199 */
+        e += (uint64_t)1 << 50;
+        if (d[(uint64_t)b * 256 + t] != e) bad++;
+    }
+    printf("bad %llu count %llu\n", bad, (unsigned long long)d[65536]);
+    return bad != 0 || d[65536] != 256 * 200;
+}
+''')
+    exe = tmp_path / "prim"
+    here = os.path.join(ROOT, "tests", "hipemu")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", "-fno-extern-tls-init", "-I", here, "-include", os.path.join(here, "hipemu_dyn_shared.h"), "-Wno-attributes", "-o", str(exe), str(src)])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_stages_and_fused_batch_on_the_emulator(emulated_lib):
+    """every stage entry point and the fused batch (directory join, slot scorers, deferred reads) against the oracle: single-end syncmer toy,
+    dense paired-end toy (the large-segment sort with dynamic LDS), legacy format"""
+    _run(emulated_lib, "(test_extract_matches_oracle or test_sort_kmers or test_index_decode or test_match_and_sort_matches or test_score or test_fused_batch "
+                       "or test_two_bit_reads_give_the_results_of_the_text) and (sync_se or dense_pe or old_format_pe) and not sync_se_acc2")
+
+
+def test_long_reads_and_long_runs_on_the_emulator(emulated_lib):
+    """long reads on ordinal slots (k_join_dir<.., LONG>, k_seg_order, k_score_long) and the wave-cooperative scan of long candidate runs"""
+    _run(emulated_lib, "(test_fused_batch and sync_long) or (test_long_candidate_runs_are_scanned_by_the_wave and True-1) or test_empty_and_ragged_inputs")
