@@ -728,6 +728,12 @@ def main():
     args = ap.parse_args()
 
     import torch  # before libmtb: both must share one HIP runtime (libamdhip64.so.7)
+    emulated = bool(os.environ.get("MTB_HIPEMU") and os.environ.get("MTB_LIB"))
+    if emulated:
+        # tests only (tests/hipemu): the library's sources built against the CPU stand-in of the HIP runtime -- "device" memory is host memory, so
+        # torch CPU tensors play the device tensors' part.  Small sizes, no timing claims: this checks bench.py's own logic without a GPU.
+        torch.cuda.synchronize = lambda *a, **k: None; torch.cuda.set_device = lambda *a, **k: None; torch.cuda.empty_cache = lambda: None
+        torch.cuda.mem_get_info = lambda *a, **k: (64 << 30, 64 << 30)
     rank = int(os.environ.get("RANK", "0")); world_size = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     silence_other_ranks(rank)
@@ -736,7 +742,7 @@ def main():
     if args.shared_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank) if not emulated else torch.device("cpu")
     dist = None
     if world_size > 1:
         import torch.distributed as dist

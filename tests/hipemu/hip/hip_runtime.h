@@ -149,13 +149,36 @@ inline thread_local Lane *t_lane = nullptr;
 inline std::atomic<unsigned long> g_divergent{0};
 constexpr size_t STACK = 192 << 10;
 
+#if defined(__SANITIZE_ADDRESS__)
+extern "C" void __sanitizer_start_switch_fiber(void **fake_stack_save, const void *bottom, size_t size);
+extern "C" void __sanitizer_finish_switch_fiber(void *fake_stack_save, const void **bottom_old, size_t *size_old);
+inline thread_local const void *t_sched_bottom = nullptr; inline thread_local size_t t_sched_size = 0;
+#define HIPEMU_ASAN_ENTER_FIBER(fake, lane) __sanitizer_start_switch_fiber(&(fake), (lane).stack, hipemu::STACK)
+#define HIPEMU_ASAN_BACK_IN_SCHEDULER(fake) __sanitizer_finish_switch_fiber((fake), nullptr, nullptr)
+#define HIPEMU_ASAN_FIBER_STARTED() __sanitizer_finish_switch_fiber(nullptr, &hipemu::t_sched_bottom, &hipemu::t_sched_size)
+#define HIPEMU_ASAN_LEAVE_FIBER(fake_ptr) __sanitizer_start_switch_fiber((fake_ptr), hipemu::t_sched_bottom, hipemu::t_sched_size)
+#define HIPEMU_ASAN_BACK_IN_FIBER(fake) __sanitizer_finish_switch_fiber((fake), &hipemu::t_sched_bottom, &hipemu::t_sched_size)
+#else
+#define HIPEMU_ASAN_ENTER_FIBER(fake, lane) ((void)(fake))
+#define HIPEMU_ASAN_BACK_IN_SCHEDULER(fake) ((void)0)
+#define HIPEMU_ASAN_FIBER_STARTED() ((void)0)
+#define HIPEMU_ASAN_LEAVE_FIBER(fake_ptr) ((void)0)
+#define HIPEMU_ASAN_BACK_IN_FIBER(fake) ((void)(fake))
+#endif
 inline void fiber_main() {
+    HIPEMU_ASAN_FIBER_STARTED();
     (*t_blk->body)();
     t_lane->state = DONE;
+    HIPEMU_ASAN_LEAVE_FIBER(nullptr);          /* (no fake stack to keep: this fiber is over) */
     hipemu_switch(&t_lane->sp, t_blk->sched_sp);
     abort();            /* a finished fiber is never resumed */
 }
-inline void yield_to_scheduler() { Lane *me = t_lane; hipemu_switch(&me->sp, t_blk->sched_sp); }
+inline void yield_to_scheduler() {
+    Lane *me = t_lane; void *fake = nullptr;
+    HIPEMU_ASAN_LEAVE_FIBER(&fake);
+    hipemu_switch(&me->sp, t_blk->sched_sp);
+    HIPEMU_ASAN_BACK_IN_FIBER(fake);
+}
 
 inline uint64_t wave_op(Op op, uint32_t site, uint64_t a, int32_t b = 0, int32_t c = 0, uint32_t d = 0) {
     Lane *me = t_lane;
@@ -233,7 +256,7 @@ inline void run_block(Block &B) {
         x.sp = sp;
     }
     const uint32_t nw = (n + 63) / 64;
-    auto run_lane = [&](Lane &x) { t_lane = &x; hipemu_switch(&B.sched_sp, x.sp); t_lane = nullptr; };
+    auto run_lane = [&](Lane &x) { void *fake = nullptr; t_lane = &x; HIPEMU_ASAN_ENTER_FIBER(fake, x); hipemu_switch(&B.sched_sp, x.sp); HIPEMU_ASAN_BACK_IN_SCHEDULER(fake); t_lane = nullptr; };
     for (;;) {
         bool any_live = false;
         for (uint32_t w = 0; w < nw; w++) {

@@ -928,7 +928,6 @@ def test_redundancy_bit_of_legacy_databases(ctx, orc, tmp_path):
     ix.close()
 
 
-@_needs_device
 def test_bench_path_matches_the_oracle(tmp_path):
     """bench.py's own configuration in small: synthetic filler index (mtb_synth_index), borrowed device arrays
     (mtb_index_from_device), device-resident reads (mtb_classify_batch_device) -- the entry points the headline number is
