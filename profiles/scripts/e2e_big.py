@@ -10,6 +10,7 @@ T_WANT = int(float(sys.argv[1])) if len(sys.argv) > 1 else 8_000_000_000
 N = int(float(sys.argv[2])) if len(sys.argv) > 2 else 60_000_000
 TH = sys.argv[3] if len(sys.argv) > 3 else "64"
 MR = (sys.argv[4] if len(sys.argv) > 4 else "2000000,4000000").split(",")
+EXTRA = [x.split() for x in os.environ.get("E2E_VARIANTS", "|--async-results 1").split("|")]      # driver flag sets to compare, '|'-separated ("" = defaults)
 dev = torch.device("cuda", 0)
 ctx = M.Context(0)
 params = M.default_params(seq_mode=1, syncmer=1, smer_len=5)
@@ -49,15 +50,26 @@ with open(fq, "wb") as f:
 ix.close(); del ix, dv, di; ctx.close(); torch.cuda.empty_cache()
 out = os.path.join(work, "out"); os.makedirs(out)
 exe = os.path.join(os.path.dirname(M.LIB_PATH), "mtb_classify")
+ref_sum = None
 for mr in MR:
+  for extra in EXTRA:
     for rep in range(2):
+        for fn in os.listdir(out):              # every run writes into an empty directory (truncating the previous run's GBs of rows costs tenths of a second)
+            os.remove(os.path.join(out, fn))
         t0 = time.perf_counter()
-        r = subprocess.run([exe, "--seq-mode", "1", "--threads", TH, "--max-reads", mr, fq, db, out, "job"], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+        r = subprocess.run([exe, "--seq-mode", "1", "--threads", TH, "--max-reads", mr] + extra + [fq, db, out, "job"], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
         dt = time.perf_counter() - t0
         print(r.stderr.strip(), flush=True)
         if r.returncode:
             raise SystemExit(f"mtb_classify failed ({r.returncode})")
-        print(f"max-reads {mr}, run {rep}: {N} reads ({os.path.getsize(fq) / 2**20:.0f} MiB FASTQ) end to end in {dt:.2f} s = {N / dt / 1e6:.2f} Mreads/s "
-              f"(includes opening the database of {T} targets from {(sz['diffIdx'] + sz['info']) / 2**30:.1f} GiB of files), {TH} host threads", flush=True)
+        import hashlib
+        h = hashlib.md5()
+        with open(os.path.join(out, "job_classifications.tsv"), "rb") as f:
+            for blk in iter(lambda: f.read(1 << 24), b""):
+                h.update(blk)
+        ref_sum = ref_sum or h.hexdigest()
+        print(f"max-reads {mr} {' '.join(extra) or '(defaults)'}, run {rep}: {N} reads ({os.path.getsize(fq) / 2**20:.0f} MiB FASTQ) end to end in {dt:.2f} s = {N / dt / 1e6:.2f} Mreads/s "
+              f"(includes opening the database of {T} targets from {(sz['diffIdx'] + sz['info']) / 2**30:.1f} GiB of files), {TH} host threads; rows md5 {h.hexdigest()[:12]}"
+              f"{'' if h.hexdigest() == ref_sum else ' DIFFERS FROM THE FIRST RUN'}", flush=True)
 print(open(os.path.join(out, "job_report.tsv")).read()[:400])
 shutil.rmtree(work, ignore_errors=True)
