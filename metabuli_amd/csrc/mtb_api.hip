@@ -125,7 +125,7 @@ struct mtb_ctx {
     uint32_t join_coop_min = MTB_JOIN_COOP_MIN;      /* k_join_dir: runs longer than this are scanned by the whole wave; MTB_JOIN_COOP_MIN in the environment at mtb_ctx_create */
 };
 /* buffers that carry a call's inputs / outputs (host-buffer entry points) are not workspace */
-static bool is_io_buf(const std::string &n) { return n == "bases" || n == "offs" || n == "bases2" || n == "offs2" || n == "results" || n == "tctax" || n == "tccnt" || n.compare(0, 2, "pk") == 0; }
+static bool is_io_buf(const std::string &n) { return n == "bases" || n == "offs" || n == "bases2" || n == "offs2" || n == "results" || n == "resultsb" || n == "tctax" || n == "tccnt" || n.compare(0, 2, "pk") == 0; }
 static size_t held_bytes(mtb_ctx *c) { std::lock_guard<std::mutex> lk(c->bufs_mu); size_t b = 0; for (auto &kv : c->bufs) if (!is_io_buf(kv.first)) b += kv.second.cap; return b; }
 /* the part of it that grows with the sub-batch (the slab pool of the large-segment scorer is bounded on its own) */
 static size_t scaling_bytes(mtb_ctx *c) { std::lock_guard<std::mutex> lk(c->bufs_mu); size_t b = 0; for (auto &kv : c->bufs) if (!is_io_buf(kv.first) && kv.first != "slabs") b += kv.second.cap; return b; }
@@ -191,6 +191,13 @@ struct mtb_index {
 
 template <typename T>
 static mtb_status ensure(mtb_ctx *c, const char *name, size_t elems, T **out) {
+    if (c->down_pending) {
+        /* asynchronous results (mtb_classify_batch_packed_async): whoever asks for a buffer that queued copies still read waits for them first
+         * (the asynchronous path itself asks for the other set) */
+        static const char *const sets[2][3] = {{"results", "tctax2", "tccnt2"}, {"resultsb", "tctax2b", "tccnt2b"}};
+        const int fl = c->res_set ^ 1;
+        if (!strcmp(name, sets[fl][0]) || !strcmp(name, sets[fl][1]) || !strcmp(name, sets[fl][2])) { HIPCHK(hipEventSynchronize(c->down_done)); c->down_pending = false; }
+    }
     std::lock_guard<std::mutex> lk(c->bufs_mu);
     DevBuf &b = c->bufs[name];
     size_t bytes = elems * sizeof(T);

@@ -146,7 +146,11 @@ struct Block {
 };
 inline thread_local Block *t_blk = nullptr;
 inline thread_local Lane *t_lane = nullptr;
-inline std::atomic<unsigned long> g_divergent{0};
+inline const char *g_kernel = "";
+inline std::atomic<unsigned long> g_divergent{0}, g_inactive_reads{0};
+struct ExitReport { ~ExitReport() { if (env_int("HIPEMU_VERBOSE", 0)) fprintf(stderr, "hipemu: %lu wavefront operations fired with several call sites waiting, %lu shuffle / readlane / DPP reads of a lane outside the active set (0 returned)\n",
+                                                                              g_divergent.load(), g_inactive_reads.load()); } };
+inline ExitReport g_exit_report;
 constexpr size_t STACK = 192 << 10;
 
 #if defined(__SANITIZE_ADDRESS__)
@@ -188,6 +192,9 @@ inline uint64_t wave_op(Op op, uint32_t site, uint64_t a, int32_t b = 0, int32_t
 }
 inline void block_barrier(int pred = 0) { t_lane->a = pred ? 1 : 0; t_lane->state = WAIT_BLOCK; yield_to_scheduler(); }
 
+inline void report_inactive(uint32_t site, int lane, int src) {
+    if (env_int("HIPEMU_VERBOSE", 0) >= 3) fprintf(stderr, "hipemu: call site %u in %s: lane %d reads lane %d, which is not in the active set\n", site, g_kernel, lane, src);
+}
 /* the operation of one active set: `idx` = lanes of the wavefront (0..63) that take part, L = their Lane records by lane number */
 inline void exec_wave_op(Lane **L, const int *idx, int n) {
     bool in[64] = {false};
@@ -202,11 +209,11 @@ inline void exec_wave_op(Lane **L, const int *idx, int n) {
         switch (op) {
         case OP_BALLOT: r = ballot; break;
         case OP_WAVE_BARRIER: break;
-        case OP_SHFL: { const int w = x->c, s = (l & ~(w - 1)) | (x->b & (w - 1)); r = in[s] ? L[s]->a : 0; break; }
+        case OP_SHFL: { const int w = x->c, s = (l & ~(w - 1)) | (x->b & (w - 1)); r = in[s] ? L[s]->a : (++g_inactive_reads, report_inactive(x->site, l, s), 0); break; }
         case OP_SHFL_UP: { const int w = x->c, s = l - x->b; r = (s < (l & ~(w - 1))) ? x->a : (in[s] ? L[s]->a : 0); break; }
         case OP_SHFL_DOWN: { const int w = x->c, s = l + x->b; r = (s > ((l & ~(w - 1)) | (w - 1))) ? x->a : (in[s] ? L[s]->a : 0); break; }
         case OP_SHFL_XOR: { const int w = x->c, s = l ^ x->b; r = (s > ((l & ~(w - 1)) | (w - 1)) || s < 0 || s > 63) ? x->a : (in[s] ? L[s]->a : 0); break; }
-        case OP_READLANE: { const int s = x->b & 63; r = in[s] ? L[s]->a : 0; break; }
+        case OP_READLANE: { const int s = x->b & 63; r = in[s] ? L[s]->a : (++g_inactive_reads, report_inactive(x->site, l, s), 0); break; }
         case OP_DPP: {
             /* a = src (low 32) | old (high 32); b = dpp_ctrl; c = row_mask | bank_mask << 4; d = bound_ctrl */
             const uint32_t src = (uint32_t)x->a, old = (uint32_t)(x->a >> 32);
@@ -289,7 +296,6 @@ inline void run_block(Block &B) {
 }
 
 inline thread_local const char *t_kernel = "";
-inline const char *g_kernel = "";
 inline void segv_report(int sig, siginfo_t *si, void *) {
     char buf[512];
     const Block *b = t_blk; const Lane *l = t_lane;
