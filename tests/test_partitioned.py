@@ -146,7 +146,25 @@ def _gpu_worker(rank, world, port, dbdir, npz, out, seq_mode):
     ix = ctx.open_index_part(dbdir, p, rank, world)
     b, o, lo, hi = parallel.shard_reads(g["bases"], g["offs"], rank, world)
     dev = torch.device("cuda:0")
-    st = parallel.GpuStages(ctx, ix, p, dev)
+    Stages = parallel.GpuStages
+    if os.environ.get("MTB_HIPEMU"):
+        # the emulated build (tests/hipemu): "device" memory is host memory -- CPU tensors, nothing to fence, the context-owned buffer seen through numpy
+        dev = torch.device("cpu")
+
+        class Stages(parallel.GpuStages):
+            def _fence(self):
+                pass
+
+            def extract_sorted(self, bounds):
+                import ctypes as C
+                b, o, b2, o2 = self.reads
+                ptr, nk, counts, starts = self.ctx.part_extract(self.params, b.data_ptr(), o.data_ptr(), b2.data_ptr() if b2 is not None else 0,
+                                                                o2.data_ptr() if o2 is not None else 0, self.n_reads, bounds, overlapping=self.overlapping)
+                if nk == 0:
+                    return torch.empty((0, 2), dtype=torch.int64), [0] * len(counts), [0] * len(counts)
+                view = np.ctypeslib.as_array((C.c_int64 * (2 * int(nk))).from_address(int(ptr))).reshape(int(nk), 2)
+                return torch.from_numpy(view), [int(c) for c in counts], [int(x) for x in starts]
+    st = Stages(ctx, ix, p, dev)
     st.overlapping = not os.environ.get("MTB_TEST_PART_LEGACY")
     if seq_mode == 2:
         b2, o2, _, _ = parallel.shard_reads(g["bases2"], g["offs2"], rank, world)
