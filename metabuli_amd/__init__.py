@@ -16,7 +16,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.environ.get("MTB_LIB") or os.path.join(_CSRC, "libmtb.so")   # MTB_LIB: profiling builds only
+LIB_PATH = os.environ.get("MTB_LIB") or os.path.join(_CSRC, "libmtb.so")   # MTB_LIB: profiling / tuning builds (and, in tests only, the emulated build of tests/hipemu)
 
 kmer_dt = np.dtype([("value", "<u8"), ("qinfo", "<u8")])
 match_dt = np.dtype([("qinfo", "<u8"), ("target_id", "<i4"), ("species_id", "<i4"), ("dna", "<u4"),
