@@ -25,6 +25,7 @@ def build(out_dir, asan=False, opt="-O1"):
                "-Wno-unknown-pragmas", "-Wno-attributes", "-o", lib, src]
         if asan:
             cmd[5:5] = ["-fsanitize=address", "-fno-omit-frame-pointer"]
+        cmd[5:5] = os.environ.get("HIPEMU_CXXFLAGS", "").split()          # tuning variants (-DMTB_JOIN_DIR_QPT=1 ...) get their logic checked here first
         subprocess.check_call(cmd)
     exe = os.path.join(out_dir, "mtb_classify")
     drv = os.path.join(ROOT, "metabuli_amd", "csrc", "host", "classify_main.cpp")
