@@ -27,6 +27,9 @@ def build(out_dir, asan=False, opt="-O1"):
             cmd[5:5] = ["-fsanitize=address", "-fno-omit-frame-pointer"]
         cmd[5:5] = os.environ.get("HIPEMU_CXXFLAGS", "").split()          # tuning variants (-DMTB_JOIN_DIR_QPT=1 ...) get their logic checked here first
         subprocess.check_call(cmd)
+    link = os.path.join(out_dir, "libmtb.so")            # tests that compile a program of their own against the library link with -lmtb
+    if not os.path.exists(link):
+        os.symlink("libmtb_hipemu.so", link)
     exe = os.path.join(out_dir, "mtb_classify")
     drv = os.path.join(ROOT, "metabuli_amd", "csrc", "host", "classify_main.cpp")
     if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(lib), os.path.getmtime(drv)):

@@ -65,7 +65,8 @@ enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 
 namespace hipemu {
 inline std::atomic<long long> g_allocated{0};
-inline long long mem_total() { const char *v = getenv("HIPEMU_MEM_MB"); return (v && *v ? atoll(v) : 16384ll) << 20; }
+/* the "device" reports 64 GB by default: the library sizes some pools by what is free, and buffers nobody touches cost no host memory */
+inline long long mem_total() { const char *v = getenv("HIPEMU_MEM_MB"); return (v && *v ? atoll(v) : 65536ll) << 20; }
 inline int env_int(const char *k, int d) { const char *v = getenv(k); return v && *v ? atoi(v) : d; }
 struct AllocHdr { size_t bytes; size_t pad; };
 inline void *dev_alloc(size_t bytes) {
@@ -75,7 +76,7 @@ inline void *dev_alloc(size_t bytes) {
     /* header in the first 256 bytes: the user pointer stays 256-byte aligned like hipMalloc's */
     ((AllocHdr *)p)->bytes = bytes;
     g_allocated += (long long)bytes;
-    if (env_int("HIPEMU_POISON", 1)) memset((char *)p + 256, 0xA5, bytes);      /* fresh device memory is not zero */
+    if (env_int("HIPEMU_POISON", 1) && bytes <= (256u << 20)) memset((char *)p + 256, 0xA5, bytes);      /* fresh device memory is not zero (buffers beyond 256 MB stay untouched: lazily mapped zero pages) */
     return (char *)p + 256;
 }
 inline void dev_free(void *u) { if (!u) return; char *p = (char *)u - 256; g_allocated -= (long long)((AllocHdr *)p)->bytes; free(p); }

@@ -103,3 +103,23 @@ def test_stages_and_fused_batch_on_the_emulator(emulated_lib):
 def test_long_reads_and_long_runs_on_the_emulator(emulated_lib):
     """long reads on ordinal slots (k_join_dir<.., LONG>, k_seg_order, k_score_long) and the wave-cooperative scan of long candidate runs"""
     _run(emulated_lib, "(test_fused_batch and sync_long) or (test_long_candidate_runs_are_scanned_by_the_wave and True-1) or test_empty_and_ragged_inputs")
+
+
+def test_bench_line_of_two_ranks_on_the_emulator(emulated_lib, tmp_path):
+    """bench.py launched the way the driver launches it for N = 2 (torch.distributed.run, one rank per GPU; here gloo and the emulated
+    build): every rank classifies its own reads against its own replica, the time is the maximum over the ranks, rank 0 prints ONE
+    JSON line for the whole job"""
+    import json
+    env = dict(os.environ, MTB_HIPEMU="1", MTB_LIB=emulated_lib, HIPEMU_THREADS="2")
+    port = 29600 + os.getpid() % 300
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--reads", "3000", "--targets", "1.5e6", "--species", "8",
+                        "--genome-len", "80000", "--filler-species", "2000", "--dist-backend", "gloo", "--shared-gpu"],
+                       env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().split("\n") if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak" and line["unit"] == "Mreads/s"
+    assert abs(line["value"] - 2 * 3000 * 2 / (line["ms_per_step"] * 2 / 1e3) / 1e6) < 1e-6 * max(1.0, line["value"])      # whole-job reads / max-over-ranks time
+    assert line["config"]["classified_fraction"] > 0.5 and {"bound", "achieved", "peak", "frac", "traffic"} <= set(line["roofline"])      # (which kernel dominates is the executor's business)
