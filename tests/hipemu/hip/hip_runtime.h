@@ -31,6 +31,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <condition_variable>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -320,6 +321,35 @@ inline void trace_launch(const char *name, dim3 grid, dim3 block, size_t shmem) 
     if (shmem > (160u << 10)) { fprintf(stderr, "hipemu: %s asks for %zu bytes of dynamic LDS (160 KB per workgroup)\n", name, shmem); abort(); }
     if (env_int("HIPEMU_VERBOSE", 0) >= 2) fprintf(stderr, "hipemu: launch %s grid (%u, %u, %u) x %u threads, %zu bytes of dynamic LDS\n", name, grid.x, grid.y, grid.z, block.x, shmem);
 }
+/* OS threads that take workgroups: created once and kept (their fiber stacks with them); a launch that finds the pool busy -- launches from
+ * several host threads at once -- runs its workgroups on the launching thread alone */
+struct Pool {
+    std::mutex use, m; std::condition_variable cv, cv_done;
+    const std::function<void()> *job = nullptr; uint64_t gen = 0; int want = 0, running = 0, n_threads = 0;
+    void grow(int n) {
+        while (n_threads < n) {
+            const int idx = n_threads++;
+            std::thread([this, idx] {
+                uint64_t seen = 0;
+                for (;;) {
+                    const std::function<void()> *f = nullptr;
+                    { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return gen != seen; }); seen = gen; if (idx < want) f = job; }
+                    if (!f) continue;
+                    (*f)();
+                    { std::lock_guard<std::mutex> l(m); if (--running == 0) cv_done.notify_all(); }
+                }
+            }).detach();                 /* (they wait for work until the process ends) */
+        }
+    }
+    void run(const std::function<void()> &f, int helpers) {
+        grow(helpers);
+        { std::lock_guard<std::mutex> l(m); job = &f; want = helpers; running = helpers; gen++; }
+        cv.notify_all();
+        f();
+        { std::unique_lock<std::mutex> l(m); cv_done.wait(l, [&] { return running == 0; }); job = nullptr; want = 0; }
+    }
+};
+inline Pool &pool() { static Pool *p = new Pool(); return *p; }      /* never destroyed: its threads wait on it until the process ends */
 template <class F> inline void launch(dim3 grid, dim3 block, F &&body_fn) {
     if (block.y != 1 || block.z != 1) { fprintf(stderr, "hipemu: only one-dimensional workgroups are modelled\n"); abort(); }
     const uint64_t total = (uint64_t)grid.x * grid.y * grid.z;
@@ -337,11 +367,10 @@ template <class F> inline void launch(dim3 grid, dim3 block, F &&body_fn) {
     };
     const int hw = std::max(1, std::min<int>(env_int("HIPEMU_THREADS", (int)std::thread::hardware_concurrency()), 64));
     const int nt = (int)std::min<uint64_t>((uint64_t)hw, total);
-    if (nt <= 1 || total * block.x < 4096) { worker(); return; }
-    std::vector<std::thread> th;
-    for (int k = 1; k < nt; k++) th.emplace_back(worker);
-    worker();
-    for (auto &t : th) t.join();
+    if (nt <= 1 || total * block.x < 4096 || !pool().use.try_lock()) { worker(); return; }
+    const std::function<void()> w(worker);
+    pool().run(w, nt - 1);
+    pool().use.unlock();
 }
 }  // namespace hipemu
 
