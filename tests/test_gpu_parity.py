@@ -830,6 +830,33 @@ def test_long_candidate_runs_are_scanned_by_the_wave(orc, tmp_path, seq_mode, de
     ix.close(); c.close()
 
 
+@pytest.mark.parametrize("depth7", [False, True])
+def test_runs_beyond_256_candidates_take_the_second_walk(orc, tmp_path, depth7, monkeypatch):
+    """runs of > 330 candidates, all within a few codon changes of the query: every lane of the wave meets more than the four possible
+    candidates the one-pass scan keeps in registers, so the run is walked a second time for the emission (k_join_dir: the
+    `__any(n_c > 4)` branch) -- found untested by a line-coverage run of the emulated build (profiles/r04_emulated_run_summary.md)."""
+    import metabuli_amd as M
+    from conftest import HotToy
+    t = HotToy(orc, tmp_path / "db", seq_mode=1, n_reads=120, n_hot=330)
+    assert t.max_run > 320
+    if depth7:
+        monkeypatch.setenv("MTB_DIR_DEPTH", "7")
+    c = M.Context(0)
+    p = M.default_params(seq_mode=1, syncmer=1)
+    ix = c.open_index(t.dbdir, p)
+    monkeypatch.delenv("MTB_DIR_DEPTH", raising=False)
+    res, tt, tc = c.classify_batch(ix, p, t.b1, t.o1)
+    ro = t.ref["results"]
+    amb = ro["flag"] != 0
+    assert ((res["classification"] == ro["classification"]) | amb).all()
+    assert ((res["score"].view(np.uint32) == ro["score"].view(np.uint32)) | amb).all()
+    assert ((res["n_taxcnt"] == ro["n_taxcnt"]) | amb).all()
+    if not amb.any():
+        assert (tt == t.ref["tc_tax"]).all() and (tc == t.ref["tc_cnt"]).all()
+    assert c.last_stats().n_matches == len(t.ref["matches"])
+    ix.close(); c.close()
+
+
 @pytest.mark.parametrize("name", ["toy_sync_se", "toy_dense_pe", "toy_oldfmt_pe", "toy_sync_long"])
 def test_golden_vectors_through_the_c_abi(ctx, orc, tmp_path, name):
     """the committed golden vectors (tests/golden/*.npz: inputs, database arrays and the oracle's outputs at the time
