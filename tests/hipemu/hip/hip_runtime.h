@@ -66,21 +66,31 @@ enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 
 namespace hipemu {
 inline std::atomic<long long> g_allocated{0};
-/* the "device" reports 64 GB by default: the library sizes some pools by what is free, and buffers nobody touches cost no host memory */
-inline long long mem_total() { const char *v = getenv("HIPEMU_MEM_MB"); return (v && *v ? atoll(v) : 65536ll) << 20; }
+/* the "device" reports the real one's 288 GB by default: the library sizes some pools by what is free (two streams of very long reads ask
+ * for two 48 GB slab pools), and pages nobody touches cost no host memory -- buffers of 256 MB and more are mapped MAP_NORESERVE */
+inline long long mem_total() { const char *v = getenv("HIPEMU_MEM_MB"); return (v && *v ? atoll(v) : 294912ll) << 20; }
 inline int env_int(const char *k, int d) { const char *v = getenv(k); return v && *v ? atoi(v) : d; }
-struct AllocHdr { size_t bytes; size_t pad; };
+struct AllocHdr { size_t bytes; size_t mapped; };
 inline void *dev_alloc(size_t bytes) {
     if ((long long)bytes + g_allocated.load() > mem_total()) return nullptr;
-    void *p = nullptr;
-    if (posix_memalign(&p, 256, bytes + sizeof(AllocHdr) + 256) != 0) return nullptr;
+    void *p = nullptr; size_t mapped = 0;
+    if (bytes >= (256u << 20)) {
+        mapped = (bytes + 256 + 4095) & ~(size_t)4095;
+        p = mmap(nullptr, mapped, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (p == MAP_FAILED) return nullptr;
+    } else if (posix_memalign(&p, 256, bytes + 256) != 0) return nullptr;
     /* header in the first 256 bytes: the user pointer stays 256-byte aligned like hipMalloc's */
-    ((AllocHdr *)p)->bytes = bytes;
+    ((AllocHdr *)p)->bytes = bytes; ((AllocHdr *)p)->mapped = mapped;
     g_allocated += (long long)bytes;
-    if (env_int("HIPEMU_POISON", 1) && bytes <= (256u << 20)) memset((char *)p + 256, 0xA5, bytes);      /* fresh device memory is not zero (buffers beyond 256 MB stay untouched: lazily mapped zero pages) */
+    if (env_int("HIPEMU_POISON", 1) && !mapped) memset((char *)p + 256, 0xA5, bytes);      /* fresh device memory is not zero (the big mapped buffers stay untouched zero pages) */
     return (char *)p + 256;
 }
-inline void dev_free(void *u) { if (!u) return; char *p = (char *)u - 256; g_allocated -= (long long)((AllocHdr *)p)->bytes; free(p); }
+inline void dev_free(void *u) {
+    if (!u) return;
+    char *p = (char *)u - 256; const AllocHdr h = *(AllocHdr *)p;
+    g_allocated -= (long long)h.bytes;
+    if (h.mapped) munmap(p, h.mapped); else free(p);
+}
 }  // namespace hipemu
 
 static inline hipError_t hipGetLastError() { return hipSuccess; }
