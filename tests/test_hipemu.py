@@ -8,7 +8,7 @@ performance model and not a memory-model checker; the parity claims rest on the 
 checked against the oracle before GPU minutes are spent, fresh "device" memory is poisoned, and the same build under AddressSanitizer finds
 out-of-bounds accesses that a GPU hides (python tests/hipemu/build_emulated.py DIR asan).
 
-The whole `-m gpu` suite through the emulator (about 45 minutes on 8 cores):
+The whole `-m gpu` suite through the emulator (about 30 minutes on 8 cores; 221 passed, 0 failed at the end of round 4):
     python tests/hipemu/build_emulated.py /tmp/mtb_hipemu
     MTB_HIPEMU=1 MTB_LIB=/tmp/mtb_hipemu/libmtb_hipemu.so python -m pytest tests -m gpu -q
 """
