@@ -74,16 +74,23 @@ def _codon_tables(torch, dev):
     return syn, n_syn, sense
 
 
-def build_world_fast(torch, dev, seed, n_species, genome_len, n_filler_species, conserved=True, p_syn=0.7, p_nonsyn=0.03, seg_len=999):
+def build_world_fast(torch, dev, seed, n_species, genome_len, n_filler_species, conserved=True, p_syn=0.7, p_nonsyn=0.03, seg_len=999, n_heldout=0, heldout_div=0.075):
     """Same shape as synth.make_world (root -> {Bacteria, Eukaryota} -> genus -> 4 species -> 1 strain, genus divergence 15 %,
     strain divergence 1 %) for THOUSANDS of genomes: sequences are drawn and mutated on the device (Bernoulli substitutions).
     conserved: every genome additionally carries protein-coding segments of a common pool (CONSERVED_CLASSES: 333 codons each, present in
     a class-dependent fraction of the genomes) at random places, every copy with 70 % of its codons redrawn among the synonymous ones
     and 3 % replaced by another amino acid's -- core genes as real databases hold them: the amino-acid 8-mers of the coding frame are
     shared by hundreds to thousands of species (candidate runs of that length in the index, where reads of ANY genome hit them) while
-    their DNA differs from species to species, so that a long run costs its scan, not thousands of matches."""
+    their DNA differs from species to species, so that a long run costs its scan, not thousands of matches.
+    n_heldout: the first species of the first n_heldout genera also gets a HELD-OUT sibling (world.heldout: (parent strain id, sequence)):
+    a new species of an indexed genus that is NOT in the index -- the parent's genome with heldout_div substitutions, and every conserved
+    segment the parent carries drawn again from the pool with its own synonymous redraws.  Reads of such an organism meet the long
+    candidate runs WITHOUT an equal target in them (the ordinary metagenomic case: the exact-match shortcut of the join does not apply).
+    The held-out genomes come from a generator of their own, so the indexed world is the same with and without them."""
     from metabuli_amd import synth
     g = torch.Generator(device=dev); g.manual_seed(seed)
+    g2 = torch.Generator(device=dev); g2.manual_seed(seed + 991)
+    heldout = []
     tax = synth.Taxonomy()
     tax.add(1, 1, "no rank", "root"); tax.add(2, 1, "superkingdom", "Bacteria"); tax.add(3, 1, "superkingdom", "Eukaryota")
     nxt = 4
@@ -127,10 +134,24 @@ def build_world_fast(torch, dev, seed, n_species, genome_len, n_filler_species, 
                     slots = torch.randperm(n_slots, generator=g, device=dev)[: len(carried)]
                     seq[: n_slots * seg_len].view(n_slots, seg_len)[slots, : n_cod * 3] = nt
             genomes.append((tid, acgt[seq.long()].cpu().numpy()))
+            if sidx == 0 and len(heldout) < n_heldout:
+                hm = torch.rand(seq.shape, generator=g2, device=dev) < heldout_div
+                hs = torch.where(hm, (seq + torch.randint(1, 4, seq.shape, generator=g2, device=dev, dtype=torch.uint8)) & 3, seq)
+                if conserved and len(carried):
+                    cod = pool[carried]
+                    u = torch.rand(cod.shape, generator=g2, device=dev)
+                    r = torch.randint(0, 1 << 30, cod.shape, generator=g2, device=dev)
+                    cod = torch.where(u < p_syn, syn[cod, r % n_syn[cod]], cod)
+                    cod = torch.where((u >= p_syn) & (u < p_syn + p_nonsyn), sense[r % len(sense)], cod)
+                    nt = torch.stack(((cod >> 4) & 3, (cod >> 2) & 3, cod & 3), dim=2).reshape(len(carried), n_cod * 3).to(torch.uint8)
+                    hs[: n_slots * seg_len].view(n_slots, seg_len)[slots, : n_cod * 3] = nt
+                heldout.append((tid, acgt[hs.long()].cpu().numpy()))
     lo = nxt
     for i in range(n_filler_species):
         tax.add(nxt, 2, "species", f"filler{i}"); nxt += 1
-    return synth.World(tax, genomes, species, lo, nxt - 1)
+    w = synth.World(tax, genomes, species, lo, nxt - 1)
+    w.heldout = heldout
+    return w
 
 
 def _mix64(torch, x):
@@ -657,12 +678,20 @@ def profiled_step(ctx, M, index, params, step_fn, streams, key, workload_tuple):
                             frac=round(alg[k] / (kern[k]["ms"] / max(1, kern[k]["launches"]) * 1e-3) / 1e9 / PEAK_GBS, 4))
                     for k in alg if kern[k]["ms"] > 0}
     effective = (traffic / (avg_ms * 1e-3) / 1e9 / PEAK_GBS) if (traffic and avg_ms > 0) else None
+    write_amp = None
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", f"pmc_traffic_{key}.json")))
+        if dom == "join" and "join" in pj["kernels"] and Mm:
+            write_amp = pj["kernels"]["join"]["write_size_kb"] * 1024.0 / (16.0 * Mm / max(1, kern["join"]["launches"]))
+    except (OSError, KeyError, ValueError):
+        pass
     frac_design = None
     join_ms = kern["join"]["ms"] / max(1, kern["join"]["launches"])
     if footprint is not None and join_ms > 0:
         frac_design = (footprint["least_fetch_bytes"] + 16 * Mm) / (join_ms * 1e-3) / 1e9 / PEAK_GBS
     roofline = dict(bound="hbm", kernel=dom, achieved=achieved, peak=PEAK_GBS, unit="GB/s", frac=achieved / PEAK_GBS, traffic=traffic, traffic_note=traffic_note,
-                    effective=effective,
+                    effective=effective, write_amplification=write_amp,
+                    write_amplification_note="join only: PMC WRITE_SIZE per launch / (16 B x matches per launch): every scattered 16-byte slot store is a 32-byte transaction",
                     effective_note="traffic / avg_launch_ms / peak: the fraction of HBM bandwidth the kernel really moves (PMC bytes, not the contract's algorithmic bytes)",
                     frac_design=frac_design,
                     frac_design_note="join only: (distinct index sectors + directory sectors + 16 B per query + 16 B per match slot) / join launch time / peak -- the least this "
@@ -685,7 +714,31 @@ def timed_leg(torch, step_fn, warmup, steps):
     return (time.perf_counter() - t0) / steps * 1e3
 
 
-def main():
+def copy_peak_gbs(torch, dev, nbytes=4 << 30, reps=5):
+    """what a plain device-to-device copy reaches on this GPU right now (read + write bytes / time): the practical ceiling next to the
+    8 TB/s data-sheet figure"""
+    try:
+        n = nbytes // 8
+        a = torch.empty(n, dtype=torch.int64, device=dev); b = torch.empty(n, dtype=torch.int64, device=dev)
+        a.fill_(1); b.copy_(a)
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            b.copy_(a)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        del a, b
+        torch.cuda.empty_cache()
+        return 2.0 * n * 8 / (ms * 1e-3) / 1e9
+    except Exception as e:       # (no timing events on the emulated build)
+        log(f"copy peak not measured: {e}")
+        return None
+
+
+def main(device=None):
+    """device: tests only (tests/hipemu/bench_emulated.py hands in torch.device("cpu") for the library build that runs on the CPU stand-in
+    of the HIP runtime); the product run takes cuda:LOCAL_RANK."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -715,6 +768,9 @@ def main():
     ap.add_argument("--leg-pairs", type=int, default=2_000_000, help="read pairs of the paired-end leg")
     ap.add_argument("--leg-long", type=int, default=20_000, help="reads of the long-read leg (x --leg-long-len bp)")
     ap.add_argument("--leg-long-len", type=int, default=10_000)
+    ap.add_argument("--leg-novel", type=int, default=2_000_000, help="reads of the held-out-organism leg (species of indexed genera that are NOT in the index)")
+    ap.add_argument("--heldout", type=int, default=200, help="held-out genomes the novel leg's reads are drawn from")
+    ap.add_argument("--long-parity-reads", type=int, default=5000, help="long reads of the long leg's parity sample")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams a batch is pipelined over inside the library")
     ap.add_argument("--seq-mode", type=int, default=1, choices=[1, 2, 3],
                     help="1 = short single-end (configs[1]); 2 = paired-end, --reads pairs of 2 x --read-len (configs[3] shape); 3 = long reads (configs[2])")
@@ -722,18 +778,15 @@ def main():
                     help="SURVEY 8(e) row 2: every rank owns one value range of the index; metamers and matches travel by all-to-all "
                          "(functional/perf check of that path; the default is the replicated index)")
     ap.add_argument("--no-seal", action="store_true", help="keep the flat {value, info} arrays next to the packed state (mtb_index_seal not called)")
+    ap.add_argument("--ab", default="", help="A/B legs after the timed region: ';'-separated NAME=VALUE settings of the library's per-batch experiment switches "
+                                             "(MTB_NO_SCORE_MANY=1, MTB_JOIN_VARIANT=q1w6 ...); each is timed on the headline batch (and the best-case batch) in this very process, "
+                                             "on this very index and allocation")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--dist-backend", default="nccl", help="testing only: gloo lets several ranks share one GPU (RCCL refuses duplicate devices)")
     ap.add_argument("--shared-gpu", action="store_true", help="testing only: every rank uses cuda:0")
     args = ap.parse_args()
 
     import torch  # before libmtb: both must share one HIP runtime (libamdhip64.so.7)
-    emulated = bool(os.environ.get("MTB_HIPEMU") and os.environ.get("MTB_LIB"))
-    if emulated:
-        # tests only (tests/hipemu): the library's sources built against the CPU stand-in of the HIP runtime -- "device" memory is host memory, so
-        # torch CPU tensors play the device tensors' part.  Small sizes, no timing claims: this checks bench.py's own logic without a GPU.
-        torch.cuda.synchronize = lambda *a, **k: None; torch.cuda.set_device = lambda *a, **k: None; torch.cuda.empty_cache = lambda: None
-        torch.cuda.mem_get_info = lambda *a, **k: (64 << 30, 64 << 30)
     rank = int(os.environ.get("RANK", "0")); world_size = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     silence_other_ranks(rank)
@@ -742,7 +795,7 @@ def main():
     if args.shared_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank) if not emulated else torch.device("cpu")
+    dev = device if device is not None else torch.device("cuda", local_rank)
     dist = None
     if world_size > 1:
         import torch.distributed as dist
@@ -765,7 +818,8 @@ def main():
     t_setup = time.perf_counter()
     big_world = args.species >= 200
     conserved = big_world and not args.no_conserved
-    world = build_world_fast(torch, dev, args.seed, args.species, args.genome_len, args.filler_species, conserved=conserved) if big_world else \
+    world = build_world_fast(torch, dev, args.seed, args.species, args.genome_len, args.filler_species, conserved=conserved,
+                             n_heldout=args.heldout if (single and not args.no_legs and args.seq_mode == 1) else 0) if big_world else \
         build_world(args.seed, args.species, args.genome_len, args.filler_species)
     taxdir = tempfile.mkdtemp(prefix="mtb_tax_")
     world.tax.write(taxdir)
@@ -802,6 +856,9 @@ def main():
         if big_world:
             bb, bo = gen_reads(torch, dev, world.genomes[:24], args.reads, args.read_len, 0.10, 0.005, rseed + 3)
             legs["best_case"] = dict(seq_mode=1, n=args.reads, read_len=args.read_len, b=bb, o=bo, b2=None)
+            if getattr(world, "heldout", None) and args.leg_novel > 0:
+                nb_, no_ = gen_reads(torch, dev, world.heldout, args.leg_novel, args.read_len, 0.10, 0.005, rseed + 4)
+                legs["novel"] = dict(seq_mode=1, n=args.leg_novel, read_len=args.read_len, b=nb_, o=no_, b2=None)
     sub_main, index_runs = None, None
     if do_parity:
         t_c = time.perf_counter()
@@ -811,7 +868,7 @@ def main():
         for name, lg in legs.items():
             if name == "best_case":
                 continue
-            n_l = min(lg["n"], max(1, args.full_parity_reads * 150 // lg["read_len"]) if lg["seq_mode"] == 3 else args.full_parity_reads)
+            n_l = min(lg["n"], args.long_parity_reads if lg["seq_mode"] == 3 else args.full_parity_reads)
             lp = M.default_params(seq_mode=lg["seq_mode"], syncmer=1, smer_len=5)
             lg["sub"] = sample_closure(ctx, torch, lp, d_values, d_info, T, lg["b"], lg["b2"], lg["read_len"], n_l)
     if single:
@@ -923,6 +980,34 @@ def main():
     if frac_cls < 0.5:   # 90 % of the reads come from genomes that are in the index
         raise SystemExit(f"sanity check failed: only {frac_cls:.4f} of the reads were classified")
 
+    # ---- A/B legs of the library's experiment switches (same process, same index, same buffers) ----
+    ab = {}
+
+    def ab_legs(tag, fn, n_reads_leg):
+        for setting in [x for x in args.ab.split(";") if "=" in x]:
+            k, v = setting.split("=", 1)
+            old = os.environ.get(k)
+            os.environ[k] = v
+            try:
+                ms = timed_leg(torch, fn, 1, 3)
+                s2 = ctx.last_stats()
+                ab.setdefault(tag, {})[setting] = dict(ms_per_step=ms, mreads_per_s=n_reads_leg / ms / 1e3,
+                                                       stage_ms=dict(extract=s2.ms_extract, sort=s2.ms_sort, join=s2.ms_join, score=s2.ms_score, total=s2.ms_total))
+                log(f"[rank 0] A/B {tag} {setting}: {ms:.1f} ms per step (join {s2.ms_join:.1f}, score {s2.ms_score:.1f})")
+            finally:
+                if old is None:
+                    del os.environ[k]
+                else:
+                    os.environ[k] = old
+        if args.ab:
+            ms = timed_leg(torch, fn, 1, 3)
+            s2 = ctx.last_stats()
+            ab.setdefault(tag, {})["default"] = dict(ms_per_step=ms, mreads_per_s=n_reads_leg / ms / 1e3,
+                                                     stage_ms=dict(extract=s2.ms_extract, sort=s2.ms_sort, join=s2.ms_join, score=s2.ms_score, total=s2.ms_total))
+            log(f"[rank 0] A/B {tag} default: {ms:.1f} ms per step (join {s2.ms_join:.1f}, score {s2.ms_score:.1f})")
+    if single and args.ab:
+        ab_legs("headline", main_step, args.reads)
+
     # ---- the other configurations, after and outside the timed region: short legs on the SAME sealed index ----
     other = {}
     for name, lg in legs.items():
@@ -934,18 +1019,26 @@ def main():
         lres = np.frombuffer(d_res[: lg["n"] * 24].cpu().numpy().tobytes(), dtype=M.result_dt)
         entry = dict(workload=dict(best_case=f"{lg['n']/1e6:g}M x {lg['read_len']} bp single-end reads drawn from 24 of the {len(world.genomes)} genomes (62 x coverage: the round-3 headline's read set) vs the same index",
                                    paired=f"{lg['n']/1e6:g}M x 2 x {lg['read_len']} bp read pairs (BASELINE.json configs[3], per-GPU shape) vs the same index",
-                                   long=f"{lg['n']/1e3:g}k x {lg['read_len']} bp long reads (BASELINE.json configs[2] shape) vs the same index")[name],
+                                   long=f"{lg['n']/1e3:g}k x {lg['read_len']} bp long reads (BASELINE.json configs[2] shape) vs the same index",
+                                   novel=f"{lg['n']/1e6:g}M x {lg['read_len']} bp single-end reads of {len(getattr(world, 'heldout', []))} HELD-OUT genomes (new species of indexed genera, not in the index: "
+                                         f"7.5 % substitutions against the indexed sibling, every conserved segment with its own synonymous redraws) vs the same index -- "
+                                         f"no query of a conserved gene finds a target equal to itself, so the join's exact-match shortcut does not apply")[name],
                      seq_mode=lg["seq_mode"], reads=lg["n"], read_len=lg["read_len"], ms_per_step=ms,
                      mreads_per_s=lg["n"] / ms / 1e3, gbp_per_s=nb / ms / 1e6, sub_batches=int(ctx.last_sub_batches),
                      stage_ms=dict(extract=ls.ms_extract, sort=ls.ms_sort, join=ls.ms_join, order=ls.ms_regroup + ls.ms_segsort, score=ls.ms_score, total=ls.ms_total),
                      query_metamers=int(ls.n_kmers), matches=int(ls.n_matches), classified_fraction=float((lres["is_classified"] != 0).mean()),
-                     reads_scored_by_generic_kernel=int(ls.n_generic_reads))
+                     reads_scored_by_generic_kernel=int(ls.n_generic_reads),
+                     reads_deferred=int(ls.n_deferred_reads), reads_scored_by_k_score_many=int(ls.n_many_reads),
+                     join_ms_per_G_query_metamers=ls.ms_join / max(1, ls.n_kmers) * 1e9,
+                     headline_join_ms_per_G_query_metamers=st.ms_join / max(1, st.n_kmers) * 1e9)
         try:
             lps, lkern, lroof, _, _, lruns = profiled_step(ctx, M, index, lp, lstep, args.streams, wl_key + "_" + name, (lg["n"], lg["read_len"], int(T), lg["seq_mode"]))
             entry["kernel_ms"] = {k: v for k, v in lkern.items() if v["launches"]}
             entry["roofline"] = {k: lroof[k] for k in ("kernel", "achieved", "frac", "traffic", "effective", "frac_design", "avg_launch_ms", "launches", "algorithmic_bytes_per_launch")}
             if lruns is not None:
                 entry["query_run_length_quantiles"] = lruns["quantiles"]
+                if name == "novel":
+                    entry["query_runs"] = lruns
         except M.MtbError as e:
             log(f"[rank 0] leg {name}: no profiled step: {e}")
         if do_parity and "sub" in lg:
@@ -955,6 +1048,8 @@ def main():
                 raise SystemExit(f"parity check of the {name} leg failed: {lpar}")
         log(f"[rank 0] leg {name}: {ms:.1f} ms per step = {entry['mreads_per_s']:.2f} Mreads/s = {entry['gbp_per_s']:.2f} Gbp/s")
         other[name] = entry
+        if args.ab and name in ("best_case", "novel", "paired"):
+            ab_legs(name, lstep, lg["n"])
     best_case = other.pop("best_case", None)
 
     cpu, parity = None, None
@@ -963,7 +1058,22 @@ def main():
         if parity["mismatches"]:
             raise SystemExit(f"parity check against the timed index failed: {parity}")
 
+    # which library was timed, on which device, per rank (SCALE runs are audited with this)
+    ident = dict(rank=rank, device=f"cuda:{local_rank}" if device is None else str(dev), library=os.path.realpath(M.LIB_PATH), version=M.lib().mtb_version().decode(),
+                 device_name=(torch.cuda.get_device_name(local_rank) if device is None else "emulated"))
+    log(f"[rank {rank}] library {ident['library']} ({ident['version']}) on {ident['device']} ({ident['device_name']})")
+    ranks = [ident]
+    if dist is not None:
+        ranks = [None] * world_size
+        dist.all_gather_object(ranks, ident)
+    peak_measured = copy_peak_gbs(torch, dev) if (rank == 0 and device is None) else None
     if rank == 0:
+        roofline["peak_measured"] = peak_measured
+        roofline["peak_measured_note"] = "device-to-device copy of 4 GiB measured in this run (read + write bytes / time): the practical HBM ceiling next to the data-sheet `peak`"
+        if peak_measured:
+            roofline["frac_of_measured_peak"] = roofline["achieved"] / peak_measured
+            if roofline.get("effective") is not None:
+                roofline["effective_of_measured_peak"] = roofline["effective"] * PEAK_GBS / peak_measured
         total_reads = args.reads * world_size * args.steps
         value = total_reads / dt / 1e6
         cfg_name = {1: 'BASELINE.json configs[1]', 2: 'BASELINE.json configs[3] shape: paired-end, index replicated, reads sharded', 3: 'BASELINE.json configs[2] shape: long reads'}[args.seq_mode]
@@ -986,7 +1096,12 @@ def main():
                    kernel_ms=kern, roofline=roofline, roofline_all=roofline_all, join_footprint=footprint,
                    run_lengths=dict(index=index_runs, queries=query_runs),
                    best_case=best_case, other_configs=other,
-                   cpu_baseline=cpu, parity_sample=parity, parity_full_index=parity)
+                   cpu_baseline=cpu, parity_sample=parity, parity_full_index=parity,
+                   library=dict(path=ident["library"], version=ident["version"]), ranks=ranks, ab=ab or None,
+                   deferred_reads=dict(deferred_by_the_slot_scorers=int(ps.n_deferred_reads), scored_by_k_score_many=int(ps.n_many_reads),
+                                       their_matches=int(ps.n_many_matches), survivors_of_the_dead_species_drop=int(ps.n_many_kept),
+                                       note="reads whose tails overflow (conserved genes: hundreds of matches over hundreds of species): k_score_many takes them from "
+                                            "slots + overflow entries and drops the species without a (species, frame) group of two before anything is ordered"))
         finish(dist, json.dumps(out))
     else:
         finish(dist, None)

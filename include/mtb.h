@@ -88,7 +88,8 @@ typedef struct mtb_index mtb_index;
 enum {
     MTB_K_EXTRACT_COUNT = 0, MTB_K_EXTRACT_EMIT = 1, MTB_K_RADIX_HIST = 2, MTB_K_RADIX_SCATTER = 3,
     MTB_K_JOIN = 4, MTB_K_REGROUP = 5, MTB_K_SEGSORT = 6, MTB_K_SCORE = 7, MTB_K_SCAN = 8, MTB_K_SCORE_FAST = 9,
-    MTB_NUM_KERNELS = 10
+    MTB_K_SCORE_MANY = 10,     /* the reads of conserved genes: overflow grouping + k_score_many (kernels_score_many.h) */
+    MTB_NUM_KERNELS = 11
 };
 
 /* Per-stage device time of the last mtb_classify_batch* call (HIP events on
@@ -104,6 +105,10 @@ typedef struct {
     uint64_t n_generic_reads;   /* reads the register-resident scorer (k_score_fast) / the workgroup-per-read scorer of long reads (k_score_long) handed to the generic k_score */
     uint64_t n_slot_reads;      /* reads whose matches went through per-read ordinal slots (short reads: fixed segments; long reads: per-read
                                  * ranges ordered by k_seg_order) instead of regroup + segment sort */
+    /* short reads on slot segments: reads the first scoring launches deferred (tail overflow, more live records than the staging); of
+     * those, the reads k_score_many scored straight from slots + overflow entries; the matches of these reads; and how many of them
+     * survived the dead-species drop (Taxonomer.cpp:342: a species without a (species, frame) group of two never scores) */
+    uint64_t n_deferred_reads, n_many_reads, n_many_matches, n_many_kept;
 } mtb_batch_stats;
 
 const char *mtb_version(void);
@@ -277,6 +282,10 @@ mtb_status mtb_classify_batch_packed(mtb_ctx *, mtb_index *, const mtb_params *,
  * batch, then the batch is processed: KmerExtractor.cpp:117-173.)                                                                    */
 mtb_status mtb_prefetch_batch_packed(mtb_ctx *, const mtb_params *, const uint8_t *packed2, const uint8_t *nmask, const uint32_t *lens,
                                      const uint8_t *packed2_mate, const uint8_t *nmask_mate, const uint32_t *lens_mate, uint64_t n_reads);
+/* Prefetches issued on this context / prefetches whose classify call found the batch on the device (or arriving) and did not upload
+ * it again.  In protocol order the two are equal; a driver that sees `used` fall behind is calling out of order.  Two prefetches may be
+ * outstanding at a time (batch k waiting for its classify call while batch k+1 is issued); a third is ignored (MTB_OK, not counted). */
+mtb_status mtb_ctx_prefetch_stats(mtb_ctx *, uint64_t *issued, uint64_t *used);
 /* Results on their way back while the NEXT batch computes: mtb_classify_batch_packed_async is mtb_classify_batch_packed, except that it
  * returns once the copies of the rows and of the packed taxID:count lists into the caller's arrays (pinned: mtb_host_alloc) are QUEUED on a
  * download stream of the context.  *n_taxcnt is final on return; MTB_ERR_CAPACITY as before (nothing queued: call again with larger arrays).

@@ -39,7 +39,8 @@ class BatchStats(C.Structure):
                 ("ms_segsort", C.c_float), ("ms_score", C.c_float), ("ms_total", C.c_float),
                 ("n_reads", C.c_uint64), ("n_bases", C.c_uint64), ("n_kmers", C.c_uint64),
                 ("n_matches", C.c_uint64), ("n_targets", C.c_uint64),
-                ("ms_kernel", C.c_float * 10), ("n_launch", C.c_uint32 * 10), ("n_generic_reads", C.c_uint64), ("n_slot_reads", C.c_uint64)]
+                ("ms_kernel", C.c_float * 11), ("n_launch", C.c_uint32 * 11), ("n_generic_reads", C.c_uint64), ("n_slot_reads", C.c_uint64),
+                ("n_deferred_reads", C.c_uint64), ("n_many_reads", C.c_uint64), ("n_many_matches", C.c_uint64), ("n_many_kept", C.c_uint64)]
 
 
 class JoinFootprint(C.Structure):
@@ -47,7 +48,7 @@ class JoinFootprint(C.Structure):
                 ("target_sectors", C.c_uint64), ("n_buckets", C.c_uint64), ("n_targets", C.c_uint64)]
 
 
-KERNEL_NAMES = ["extract_count", "extract_emit", "radix_hist", "radix_scatter", "join", "regroup", "segsort", "score", "scan", "score_fast"]
+KERNEL_NAMES = ["extract_count", "extract_emit", "radix_hist", "radix_scatter", "join", "regroup", "segsort", "score", "scan", "score_fast", "score_many"]
 
 
 class MtbError(RuntimeError):
@@ -334,6 +335,38 @@ class Context:
         _chk(self.L.mtb_ctx_wait_results(self.h))
         if held is not None:
             out.append(compact_taxcnt(*held))
+        return out
+
+    def prefetch_stats(self):
+        """(prefetches issued, prefetches a classify call used instead of uploading its batch again) -- mtb_ctx_prefetch_stats"""
+        a, b = C.c_uint64(), C.c_uint64()
+        _chk(self.L.mtb_ctx_prefetch_stats(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def classify_batches_packed_prefetched(self, index, params, batches):
+        """The driver's protocol (mtb.h): prefetch(k+1), classify(k), prefetch(k+2), classify(k+1) ... over a list of
+        (bases, offs, bases2, offs2) batches -> list of (results, taxcnt_tax, taxcnt_cnt).  The packed arrays stay alive until the end."""
+        packed = []
+        for (bases, offs, bases2, offs2) in batches:
+            packed.append((len(offs) - 1, self.pack_reads(bases, offs), self.pack_reads(bases2, offs2) if bases2 is not None else (None, None, None)))
+        out = []
+        for k, (n, p1, p2) in enumerate(packed):
+            if k + 1 < len(packed):
+                n2, q1, q2 = packed[k + 1]
+                _chk(self.L.mtb_prefetch_batch_packed(self.h, C.byref(params), _p(q1[0]), _p(q1[1]), _p(q1[2]), _p(q2[0]), _p(q2[1]), _p(q2[2]), C.c_uint64(n2)))
+            res = np.zeros(n, result_dt)
+            cap = max(1024, 8 * n)
+            while True:
+                tt = np.zeros(cap, np.int32); tc = np.zeros(cap, np.uint32)
+                cnt = C.c_uint64()
+                st = self.L.mtb_classify_batch_packed(self.h, index.h, C.byref(params), _p(p1[0]), _p(p1[1]), _p(p1[2]), _p(p2[0]), _p(p2[1]), _p(p2[2]),
+                                                      C.c_uint64(n), _p(res), _p(tt), _p(tc), C.c_uint64(cap), C.byref(cnt))
+                if st == MTB_ERR_CAPACITY and cnt.value > cap:
+                    cap = cnt.value
+                    continue
+                _chk(st)
+                break
+            out.append(compact_taxcnt(res, tt, tc))
         return out
 
     def classify_batch_device(self, index, params, d_bases, d_offs, d_bases2, d_offs2, n_reads, n_bases,

@@ -38,6 +38,7 @@
 #include <sys/mman.h>
 #include <unistd.h>
 #include <cstring>
+#include <cmath>
 #include <fstream>
 #include <algorithm>
 #include <functional>
@@ -389,7 +390,25 @@ int main(int argc, char **argv) {
                 try { engs[0]->open(dbdir, taxdir, par); } catch (...) { reserve.join(); throw; }
                 reserve.join();
             }
-            else engs.emplace_back(new mtb::Engine(devices[d], *engs[0]));           /* the files are read and decoded once: the other GPUs get peer copies */
+            else engs.emplace_back(nullptr);                                         /* cloned below, all destinations at once */
+        }
+        if (!partitioned && devices.size() > 1) {
+            /* the files are read and decoded once: the other GPUs get peer copies (mtb_index_clone) -- ALL AT ONCE, one host thread per
+             * destination: every destination pulls over its own xGMI link to GPU 0 (the fabric is point-to-point: seven copies issued one
+             * after another took seven times one copy where they can share the source's seven links), into its own HBM */
+            const double tc0 = now();
+            std::vector<std::string> cerr_(devices.size());
+            std::vector<std::thread> cl;
+            for (size_t d = 1; d < devices.size(); d++)
+                cl.emplace_back([&, d] { try { engs[d].reset(new mtb::Engine(devices[d], *engs[0])); } catch (const std::exception &e) { cerr_[d] = e.what(); if (cerr_[d].empty()) cerr_[d] = "clone failed"; } });
+            for (auto &t : cl) t.join();
+            for (size_t d = 1; d < devices.size(); d++) if (!cerr_[d].empty()) throw std::runtime_error("engine " + std::to_string(d) + ": " + cerr_[d]);
+            const double tc = now() - tc0;
+            int32_t depth = 0, pk = 0, sealed = 0;
+            (void)mtb_index_state(engs[0]->index, &depth, &pk, &sealed);
+            const double gb = ((double)mtb_index_num_targets(engs[0]->index) * (sealed ? 8.0 : 12.0) + (depth ? 4.0 * pow(21.0, depth) : 0.0)) / 1e9;
+            fprintf(stderr, "mtb_classify: resident index cloned to %zu more device(s) concurrently in %.2f s (%.1f GB each, %.1f GB/s aggregate)\n",
+                    devices.size() - 1, tc, gb, gb * (double)(devices.size() - 1) / std::max(tc, 1e-9));
         }
         } catch (const std::exception &e) {                   /* (the parser thread is running: leave at once) */
             fprintf(stderr, "mtb_classify: %s\n", e.what()); fflush(stderr); _exit(1);

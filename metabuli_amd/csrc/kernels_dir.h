@@ -203,10 +203,13 @@ __device__ __forceinline__ uint32_t wave_min_shfl_u32(uint32_t v) {
 
 /* MODE 0: slot segments of fixed stride (short reads); 1: per-read slot ranges (long reads); 2: dense list of Match records
  * (owner side of the range-partitioned index: the home rank of the read places them into ITS slot segments, k_slot_place) */
-template <bool PACKED, int MODE = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && MODE == 0) ? MTB_JOIN_WAVES : 5))) void k_join_dir(const mtb_kmer *__restrict__ q, uint64_t n, mtb_index_view ix, uint64_t limit, mtb_dir_view dv,
+/* QPT = queries per thread, WAVES = waves per SIMD the register allocation aims at: template parameters so that the A/B variants of the
+ * short-read instantiation live in ONE library and are compared inside one process, on one index, one allocation (MTB_JOIN_VARIANT=q<Q>w<W>
+ * in the environment, read per batch; between processes the placement of a 27 GB slot buffer alone moved the join by 10 %) */
+template <bool PACKED, int MODE = 0, int QPT = MTB_JOIN_DIR_QPT, int WAVES = MTB_JOIN_WAVES>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && MODE == 0) ? WAVES : 5))) void k_join_dir(const mtb_kmer *__restrict__ q, uint64_t n, mtb_index_view ix, uint64_t limit, mtb_dir_view dv,
                                                    const mtb_tables *__restrict__ tabs, JoinSegArgs sa, uint32_t *__restrict__ overflow) {
-    constexpr int Q = MTB_JOIN_DIR_QPT;
+    constexpr int Q = QPT;
     constexpr bool LONG = MODE == 1, LIST = MODE == 2;
     const uint64_t AAM = ~0xFFFFFFull;
     __shared__ uint32_t s_hr[8];                    /* hammingLookup rows as nibble words: the only table the join arithmetic reads */
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
                 hi[u] = dv.base[(b + 1) >> 16] + dv.dir[b + 1];
                 if (hi[u] > limit) hi[u] = limit;           /* the last entry of the (whole) index is never a candidate */
                 if (lo[u] > hi[u]) lo[u] = hi[u];
-            }
+            } else valid[u] = false;                        /* a metamer outside the directory's alphabet (stage API: any 64-bit value may arrive) has no candidate -- and no bucket row to read again below */
         }
     }
     __syncthreads();                                 /* s_hr; the query and directory loads above are in flight meanwhile */

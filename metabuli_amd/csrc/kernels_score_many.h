@@ -1,0 +1,195 @@
+/* kernels_score_many.h -- the short reads that meet MANY species: reads of conserved genes, whose query metamers land in candidate
+ * runs of 10^3 - 10^4 species and bring a few hundred matches each, most of them of species that appear once or twice.
+ * Their tails overflow, so neither k_score_fast nor the slot mode of k_score can take them from their slots; until round 4 they were
+ * copied to exact segments, sorted by a generic key sort and scored by the generic kernel out of HBM slabs (k_big_* -> k_segsort_* ->
+ * k_score<.., DYN>): a fifth of the step for a twelfth of the reads.
+ *
+ * What the reference does with such a read (Taxonomer::getBestSpeciesMatches, src/commons/Taxonomer.cpp:316-408): the sorted match list
+ * is cut into species, a species into (species, frame) groups, and ONLY groups of two or more matches reach getMatchPaths (:342,
+ * `if (i - start > 1)`).  A species none of whose groups holds two matches gets no path, hence no entry in sp2score, hence can be
+ * neither the best species nor part of a tie -- and the later steps (redundancy filter, taxCnt, lower-rank descent: :130-260) read
+ * the matches of the best species' range only.  So the matches of such species are DEAD: dropping them before anything is ordered
+ * changes no output of the read.  In a read of a conserved gene that is most of the matches.
+ *
+ * k_score_many, one wavefront per listed read (the reads k_score<SLOT> deferred), straight from where the join left the matches --
+ * the read's slot segment (direct + tail slots) and its entries of the overflow list, grouped by read by k_ovf_group:
+ *   pass 1  every live record enters its species into an open-addressing table in LDS (atomicCAS on the key) and marks its frame:
+ *           bit f = "a match in frame f", bit 8 + f = "a second match in frame f" (two atomicOr);
+ *   pass 2  the records are read again (L2 hits), those of species with any "second match" bit are staged in LDS in encounter order;
+ *   then    the generic per-read phases (score_read_par, kernels_score.h: rank sort on the 64-bit compareMatches key, paths,
+ *           combination, decision, filter, taxCnt, descent) run on the survivors -- a list of the size of an ordinary read.
+ * Reads it cannot take (survivors beyond the staging, species table full, reads routed around their slots, too many position buckets)
+ * are listed for the exact-segment path, which stays as the catch-all.
+ * The table lives in the part of the scoring workspace that pass 2 does not write (everything behind the match records).
+ * Algorithmic HBM bytes: 16 per slot + 24 per overflow entry, read twice (the second time from L2), + 24 per read result.      */
+#ifndef MTB_KERNELS_SCORE_MANY_H
+#define MTB_KERNELS_SCORE_MANY_H
+#include "dev_util.h"
+#include "mtb_core.h"
+#include "kernels_join.h"
+#include "kernels_score.h"
+
+#define MTB_MANY_HASH 1024u              /* species table entries (8 bytes each); a read with more than 3/4 of that many species is handed on */
+
+/* overflow entries per read: what the join pushed beyond the read's tail (cursor counts every match after the query's first one).
+ * Reads routed around their slots (off[]: cursor pushed by tail_cap + 1 per match) are not grouped: they go to the exact-segment path. */
+__global__ __launch_bounds__(256) void k_ovf_count(const uint32_t *__restrict__ cursor, const uint8_t *__restrict__ off, uint64_t n_reads, uint32_t tail_cap,
+                                                    uint32_t *__restrict__ novf) {
+    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_reads) return;
+    const uint32_t cur = cursor[r];
+    novf[r] = (cur > tail_cap && !(off && off[r])) ? cur - tail_cap : 0u;
+}
+/* every entry of the overflow list -> its read's group (place by a returning atomic on the read's counter; the order inside a group is
+ * irrelevant: the scorer sorts).  region_cap != 0: striped list (JoinSegArgs::ovf_stripes), blockIdx.y = stripe. */
+__global__ __launch_bounds__(256) void k_ovf_group(const mtb_match *__restrict__ ovf, uint64_t n_ovf, const uint64_t *__restrict__ start, const uint32_t *__restrict__ novf,
+                                                    uint32_t *__restrict__ ocur, mtb_match *__restrict__ out, uint64_t region_cap, const unsigned long long *__restrict__ counters) {
+    uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (region_cap) {
+        const unsigned long long cnt = counters[8 * blockIdx.y];
+        if (i >= cnt || i >= region_cap) return;
+        i += (uint64_t)blockIdx.y * region_cap;
+    } else if (i >= n_ovf) return;
+    const mtb_match m = ovf[i];
+    const uint32_t r = mtb_q_seq(m.qinfo) - 1;
+    const uint32_t cap = novf[r];
+    if (!cap) return;                                     /* a read routed around its slots */
+    const uint32_t at = atomicAdd(&ocur[r], 1u);
+    if (at < cap) out[start[r] + at] = m;
+}
+
+template <bool KEY64, int CAP>
+__global__ __launch_bounds__(64, (CAP > 192 ? 2 : 3)) void k_score_many(const mtb_slot16 *__restrict__ slots_all, uint32_t stride, uint32_t direct, uint32_t epoch,
+                                                       const uint32_t *__restrict__ cursor, const uint8_t *__restrict__ off_reads,
+                                                       const mtb_match *__restrict__ ovfg, const uint64_t *__restrict__ ovf_start,
+                                                       const uint32_t *__restrict__ list, const uint32_t *__restrict__ n_list,
+                                                       const int32_t *__restrict__ qlen, const int32_t *__restrict__ qlen2, mtb_tax_view tx, mtb_score_params sp,
+                                                       const uint64_t *__restrict__ tc_off, mtb_result *__restrict__ results, int32_t *__restrict__ tc_tax,
+                                                       uint32_t *__restrict__ tc_cnt, uint64_t tc_cap, uint64_t tc_base,
+                                                       uint32_t *__restrict__ rest_list, uint32_t *__restrict__ n_rest, uint32_t *__restrict__ cnt_out,
+                                                       unsigned long long *__restrict__ work, unsigned long long *__restrict__ stats /* [0] matches seen, [1] survivors (diagnostics) */) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_ws[MTB_SCORE_WS_BYTES_(CAP)];
+    static_assert(MTB_SCORE_WS_BYTES_(CAP) - CAP * sizeof(mtb_match) >= MTB_MANY_HASH * 8, "the species table fits behind the match records");
+    static_assert(CAP * sizeof(mtb_path) >= MTB_SCORE_BKT * 13 + (MTB_LR_MAXE + MTB_LR_MAXE * MTB_LR_K) * 4, "decide arrays must fit the path area");
+    uint32_t *const h_key = (uint32_t *)(s_ws + CAP * sizeof(mtb_match));
+    uint32_t *const h_val = h_key + MTB_MANY_HASH;
+    const uint32_t lane = threadIdx.x;
+    const uint64_t lt = lanemask_lt();
+    const uint32_t tail_cap = stride - direct;
+    MTB_BEGIN_ACQUIRE();
+    const uint64_t n_iter = (uint64_t)*n_list;
+    unsigned long long seen = 0, kept = 0;
+    /* reads differ a lot (a few dozen to a thousand records): claimed one by one */
+    for (uint64_t it = (uint64_t)__shfl(lane == 0 ? atomicAdd(work, 1ull) : 0ull, 0, 64); it < n_iter;
+         it = (uint64_t)__shfl(lane == 0 ? atomicAdd(work, 1ull) : 0ull, 0, 64)) {
+        const uint64_t r = (uint64_t)list[it];
+        const int32_t ql1 = qlen[r], ql2 = qlen2[r];
+        const int32_t read_len = ql1 + ql2;
+        const int32_t nb = mtb_num_buckets(read_len, sp.dna_shift);
+        const uint32_t cur = cursor[r];
+        const uint32_t tail_n = cur < tail_cap ? cur : tail_cap;
+        uint64_t o0 = 0; uint32_t n_ov = 0;
+        if (ovf_start) { o0 = ovf_start[r]; n_ov = (uint32_t)(ovf_start[r + 1] - o0); }
+        bool hand_on = (off_reads && off_reads[r]) || nb > MTB_SCORE_BKT || cur - tail_n != n_ov;
+        const mtb_slot16 *slots = slots_all + r * (uint64_t)stride;
+        mtb_sws<uint16_t> w;
+        mtb_sws_carve<uint16_t>(&w, s_ws, CAP);
+        uint32_t n = 0, n_all = 0;
+        if (!hand_on) {
+            score_sync<uint16_t>();                      /* the previous read is through with the workspace */
+            for (uint32_t q = lane; q < MTB_MANY_HASH; q += 64) { h_key[q] = 0xFFFFFFFFu; h_val[q] = 0u; }
+            score_sync<uint16_t>();
+            bool full = false;
+            /* species `s` (never 0xFFFFFFFF: ids are < 2^31), frame f: find or claim the entry, mark the frame */
+            auto enter = [&](uint32_t s, uint32_t f) {
+                uint32_t h = (s * 0x9E3779B1u) >> 22;
+                for (uint32_t p = 0; p < MTB_MANY_HASH; p++) {
+                    const uint32_t old = atomicCAS(&h_key[h], 0xFFFFFFFFu, s);
+                    if (old == 0xFFFFFFFFu || old == s) {
+                        const uint32_t bit = 1u << f;
+                        if (atomicOr(&h_val[h], bit) & bit) atomicOr(&h_val[h], bit << 8);
+                        return;
+                    }
+                    h = (h + 1u) & (MTB_MANY_HASH - 1u);
+                }
+                full = true;
+            };
+            for (uint32_t c0 = 0; c0 < stride; c0 += 64) {
+                const uint32_t i = c0 + lane;
+                mtb_slot16 x; x.a = 0; x.b = 0;
+                if (i < stride) x = slots[i];
+                const bool live = i < stride && seg_slot_live(x, i, direct, tail_n, epoch);
+                if (live) enter((uint32_t)(x.a >> 32), (uint32_t)(x.b >> 52) & 7u);
+                n_all += (uint32_t)__popcll(__ballot(live));
+            }
+            for (uint32_t c0 = 0; c0 < n_ov; c0 += 64) {
+                const uint32_t i = c0 + lane;
+                if (i < n_ov) { const mtb_match m = ovfg[o0 + i]; enter((uint32_t)m.species_id, mtb_q_frame(m.qinfo)); }
+            }
+            n_all += n_ov;
+            score_sync<uint16_t>();
+            /* occupancy: a table beyond 3/4 is handed on (probe chains; and `full` must never have been hit) */
+            uint32_t used = 0;
+            for (uint32_t q = lane; q < MTB_MANY_HASH; q += 64) used += h_key[q] != 0xFFFFFFFFu ? 1u : 0u;
+            for (int d = 32; d > 0; d >>= 1) used += (uint32_t)__shfl_xor((int)used, d, 64);
+            hand_on = __any(full) || used > MTB_MANY_HASH / 4u * 3u;
+            if (!hand_on) {
+                auto alive = [&](uint32_t s) -> bool {
+                    uint32_t h = (s * 0x9E3779B1u) >> 22;
+                    for (uint32_t p = 0; p < MTB_MANY_HASH; p++) {
+                        const uint32_t k = h_key[h];
+                        if (k == s) return (h_val[h] >> 8) != 0u;
+                        if (k == 0xFFFFFFFFu) return false;          /* (cannot happen: every record was entered) */
+                        h = (h + 1u) & (MTB_MANY_HASH - 1u);
+                    }
+                    return false;
+                };
+                uint64_t *dst64 = (uint64_t *)w.m;
+                auto put = [&](uint32_t pos, const mtb_match &m) {
+                    const uint64_t *q = (const uint64_t *)&m;
+                    dst64[3 * pos] = q[0]; dst64[3 * pos + 1] = q[1]; dst64[3 * pos + 2] = q[2];
+                };
+                for (uint32_t c0 = 0; c0 < stride; c0 += 64) {
+                    const uint32_t i = c0 + lane;
+                    mtb_slot16 x; x.a = 0; x.b = 0;
+                    if (i < stride) x = slots[i];
+                    const bool keep = i < stride && seg_slot_live(x, i, direct, tail_n, epoch) && alive((uint32_t)(x.a >> 32));
+                    const uint64_t mask = __ballot(keep);
+                    const uint32_t pos = n + (uint32_t)__popcll(mask & lt);
+                    if (keep && pos < (uint32_t)CAP) put(pos, mtb_slot_unpack(x, (uint32_t)r + 1));
+                    n += (uint32_t)__popcll(mask);
+                }
+                for (uint32_t c0 = 0; c0 < n_ov; c0 += 64) {
+                    const uint32_t i = c0 + lane;
+                    mtb_match m; m.qinfo = 0; m.target_id = 0; m.species_id = 0; m.dna = 0; m.right_end_hamming = 0; m.hamming = 0; m.pad = 0;
+                    bool keep = false;
+                    if (i < n_ov) { m = ovfg[o0 + i]; keep = alive((uint32_t)m.species_id); }
+                    const uint64_t mask = __ballot(keep);
+                    const uint32_t pos = n + (uint32_t)__popcll(mask & lt);
+                    if (keep && pos < (uint32_t)CAP) { m.pad = 0; put(pos, m); }
+                    n += (uint32_t)__popcll(mask);
+                }
+                hand_on = n > (uint32_t)CAP;
+                score_sync<uint16_t>();                  /* the table is dead from here on: the workspace behind the records is the scorer's */
+            }
+        }
+        if (hand_on) { if (lane == 0) rest_list[atomicAdd(n_rest, 1u)] = (uint32_t)r; continue; }
+        seen += n_all; kept += n;
+        mtb_result R;
+        R.classification = 0; R.score = 0.0f; R.query_length = ql1; R.query_length2 = ql2;
+        R.is_classified = 0; R.reserved = 0; R.n_taxcnt = 0; R.taxcnt_off = 0;
+        if (lane == 0) cnt_out[r] = n_all;
+        if (n == 0) { if (lane == 0) results[r] = R; continue; }
+        const uint64_t off = tc_off[r], room = tc_off[r + 1] - off;
+        int32_t *s_btax = (int32_t *)w.path, *s_otax = s_btax + MTB_SCORE_BKT;
+        uint32_t *s_ocnt = (uint32_t *)(s_otax + MTB_SCORE_BKT);
+        int32_t *s_lev = (int32_t *)(s_ocnt + MTB_SCORE_BKT), *s_anc = s_lev + MTB_LR_MAXE;
+        uint8_t *s_bham = (uint8_t *)(s_anc + MTB_LR_MAXE * MTB_LR_K);
+        score_read_par<uint16_t, true, KEY64, mtb_match, true, CAP>(w.m, (int32_t)n, w, s_btax, s_bham, s_otax, s_ocnt, s_lev, s_anc, nb, read_len, tx, sp, off, room,
+                                                                   tc_tax, tc_cnt, tc_cap, (mtb_match *)nullptr, R);
+        if (lane == 0) { R.query_length = ql1; R.query_length2 = ql2; R.reserved = 0; R.taxcnt_off += (uint32_t)tc_base; results[r] = R; }
+    }
+    if (stats && lane == 0 && seen) { atomicAdd(&stats[0], seen); atomicAdd(&stats[1], kept); }
+}
+
+#endif

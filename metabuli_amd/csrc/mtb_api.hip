@@ -6,6 +6,7 @@
 #include <fcntl.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
@@ -25,6 +26,7 @@
 #include "kernels_score.h"
 #include "kernels_score_fast.h"
 #include "kernels_score_long.h"
+#include "kernels_score_many.h"
 #include "kernels_seg_order.h"
 #include "kernels_sort.h"
 #include "mtb_core.h"
@@ -88,6 +90,8 @@ struct mtb_ctx {
     mtb_tables h_tabs;
     std::map<std::string, DevBuf> bufs;
     std::mutex bufs_mu;              /* the buffer table may be grown from a helper thread (mtb_ctx_reserve) while the context's thread opens an index */
+    std::mutex reserve_mu;           /* held by mtb_ctx_reserve for its whole run */
+    std::atomic<bool> reserve_cancel{false};     /* an index open on this context found device memory short: a running reservation stops after its current buffer, a new one does nothing, and what was reserved is handed back (open_make_room) */
     uint64_t *d_scal = nullptr;      /* [0] match counter, [1] overflow, [2] n_large, [3] max_seg, [4] max_len, [5] n_big */
     uint64_t *d_xscal = nullptr;     /* = d_scal + 8: single-pass extraction counters */
     unsigned long long *d_ovfctr = nullptr;      /* MTB_OVF_STRIPES counters of the striped overflow list, 64 bytes apart (JoinSegArgs::ovf_stripes) */
@@ -101,6 +105,7 @@ struct mtb_ctx {
     std::vector<mtb_ctx *> lanes;    /* extra stream contexts (mtb_ctx_set_streams) */
     bool is_lane = false;            /* lanes share the parent's tables  */
     uint32_t seg_epoch = 0;          /* tag of the live slots in the "segm" buffer (1..MTB_SLOT_EPOCHS) */
+    const void *seg_clean_p = nullptr; size_t seg_clean_cap = 0;     /* the allocation the epoch count belongs to: the one prepare_slots last cleared (another pointer or size, e.g. after mtb_ctx_reserve grew or created "segm", holds stale bytes) */
     double extract_yield = 0.0;      /* metamers per base of the previous batch (single-pass extraction buffer sizing) */
     uint64_t part_n_reads = 0; uint32_t part_max_len = 0;   /* batch state between mtb_part_extract and mtb_part_score */
     int part_mode = 0; uint32_t part_max_q = 0; uint64_t part_nk_real = 0;      /* part_mode 1: the batch's metamers carry ordinals, the matches come home into slot segments */
@@ -115,12 +120,19 @@ struct mtb_ctx {
     const mtb_kmer *last_sorted = nullptr; uint64_t last_sorted_n = 0;       /* the last fused slot-path batch's sorted metamers (mtb_ctx_join_footprint) */
     /* upload of the NEXT batch's packed reads while the current batch computes (mtb_prefetch_batch_packed): a copy stream, two sets of
      * input buffers, and what the set that is being filled holds */
-    hipStream_t copy_stream = nullptr; hipEvent_t copy_done = nullptr;
+    hipStream_t copy_stream = nullptr; hipEvent_t copy_done[2] = {nullptr, nullptr};       /* per input buffer set: the prefetch into it is complete */
+    hipEvent_t unpacked[2] = {nullptr, nullptr};     /* per set: the last classify call that read it has unpacked it (recorded on the compute stream; a prefetch into the set waits for it) */
+    bool unpacked_rec[2] = {false, false};
+    uint64_t prefetch_issued = 0, prefetch_used = 0; /* mtb_ctx_prefetch_stats */
     /* results on their way back while the next batch computes (mtb_classify_batch_packed_async): a download stream, the event that closes the
      * queued copies, and which of the two device-side result buffer sets the next call writes */
     hipStream_t down_stream = nullptr; hipEvent_t down_ready = nullptr, down_done = nullptr; bool down_pending = false; int res_set = 0;
     int pk_set = 0;                                  /* the set the last classify call read */
-    struct Prefetched { const void *key = nullptr, *key2 = nullptr; uint64_t n_reads = 0, slots = 0, slots2 = 0; bool valid = false; } pre;
+    /* one record per set.  The protocol of mtb.h is prefetch(k+1), classify(k): when batch k+1 is prefetched, batch k (prefetched one call
+     * earlier) is still waiting for its classify call, so TWO prefetches are outstanding for a moment -- with a single record classify(k)
+     * found batch k+1's key, discarded it and uploaded k again */
+    struct Prefetched { const void *key = nullptr, *key2 = nullptr; uint64_t n_reads = 0; bool valid = false; } pre[2];
+    uint64_t many_stats[4] = {0, 0, 0, 0};           /* last slot-path batch: reads deferred by the first scoring launches, of those scored by k_score_many, their matches, the survivors of the dead-species drop */
     uint32_t lslot_tf_start = 1;                     /* long-read slot ranges: tail factor the next batch starts with (1 = a quarter of the metamers, 4 = all) */
     uint32_t join_coop_min = MTB_JOIN_COOP_MIN;      /* k_join_dir: runs longer than this are scanned by the whole wave; MTB_JOIN_COOP_MIN in the environment at mtb_ctx_create */
 };
@@ -133,6 +145,7 @@ static void release_workspace(mtb_ctx *c) {
     std::lock_guard<std::mutex> lk(c->bufs_mu);
     for (auto &kv : c->bufs) if (kv.second.p && !is_io_buf(kv.first)) { hipError_t e = hipFree(kv.second.p); (void)e; kv.second.p = nullptr; kv.second.cap = 0; }
     c->ws_per_base = 0.0; c->ws_max_sub_bases = 0;
+    c->seg_clean_p = nullptr; c->seg_clean_cap = 0;       /* a later "segm" at the same address is not the buffer that was cleared */
 }
 
 /* RAII bracket around one kernel launch (only when profiling is on) */
@@ -379,7 +392,7 @@ void mtb_ctx_destroy(mtb_ctx *c) {
     if (c->down_ready) e = hipEventDestroy(c->down_ready);
     if (c->down_done) e = hipEventDestroy(c->down_done);
     if (c->copy_stream) { e = hipStreamSynchronize(c->copy_stream); e = hipStreamDestroy(c->copy_stream); }
-    if (c->copy_done) e = hipEventDestroy(c->copy_done);
+    for (int k = 0; k < 2; k++) { if (c->copy_done[k]) e = hipEventDestroy(c->copy_done[k]); if (c->unpacked[k]) e = hipEventDestroy(c->unpacked[k]); }
     for (int i = 0; i < 8; i++) e = hipEventDestroy(c->ev[i]);
     for (auto &k : c->kev) { e = hipEventDestroy(k.a); e = hipEventDestroy(k.b); }
     for (auto &x : c->ev_pool) e = hipEventDestroy(x);
@@ -701,7 +714,7 @@ static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint6
     STCHK(ensure(c, "jbounds", 2ull * grid, &d_bounds));
     uint64_t limit = ix->T ? ix->T - (ix->match_last ? 0 : 1) : 0;          /* the last entry of the (whole) index is never a candidate */
     IndexUse use;                     /* released after the stream sync below (the d2h of the counters) */
-    const bool striped = seg && ix->d_dir && !seg->list;       /* the slot modes of the directory join: striped overflow list */
+    const bool striped = seg && ix->d_dir && !seg->list && !seg->dense_ovf;       /* the slot modes of the directory join: striped overflow list */
     if (seg && ix->d_dir) {
         STCHK(use.acquire(ix, true));
         KTimer kt(c, MTB_K_JOIN);
@@ -720,7 +733,20 @@ static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint6
             if (state_owner(ix)->packed) hipLaunchKernelGGL((k_join_dir<true, 1>), dim3(g2), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1));
             else hipLaunchKernelGGL((k_join_dir<false, 1>), dim3(g2), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1));
         } else
-        if (state_owner(ix)->packed) hipLaunchKernelGGL((k_join_dir<true>), dim3(g2), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1));
+        if (state_owner(ix)->packed) {
+            /* the product instantiation, or one of its A/B variants (queries per thread x waves per SIMD) */
+#define MTB_LAUNCH_JV(QV, WV) hipLaunchKernelGGL((k_join_dir<true, 0, QV, WV>), dim3((uint32_t)((n + 256 * QV - 1) / (256 * QV))), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1))
+            int join_variant = 0;                     /* MTB_JOIN_VARIANT=q<Q>w<W>, read per batch: bench.py compares the variants inside one process */
+            if (const char *e = getenv("MTB_JOIN_VARIANT")) { if (e[0] == 'q' && e[1] >= '1' && e[1] <= '2' && e[2] == 'w' && e[3] >= '5' && e[3] <= '6') join_variant = ((e[1] - '0') << 4) | (e[3] - '0'); }
+            switch (join_variant) {
+            case 0x15: MTB_LAUNCH_JV(1, 5); break;
+            case 0x16: MTB_LAUNCH_JV(1, 6); break;
+            case 0x26: MTB_LAUNCH_JV(2, 6); break;
+            case 0x25: MTB_LAUNCH_JV(2, 5); break;
+            default: MTB_LAUNCH_JV(MTB_JOIN_DIR_QPT, MTB_JOIN_WAVES); break;
+            }
+#undef MTB_LAUNCH_JV
+        }
         else hipLaunchKernelGGL((k_join_dir<false>), dim3(g2), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1));
     } else
     { STCHK(use.acquire(ix, false));
@@ -752,7 +778,7 @@ static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint6
             if (tot > seg->ovf_cap) return fail(MTB_ERR_CAPACITY, "match buffer too small");
             return MTB_OK;
         }
-        *count = mx > c->ovf_region ? (mx + mx / 8 + 64) * MTB_OVF_STRIPES : tot;
+        *count = mx > c->ovf_region ? (mx + mx / 8 + 64) * MTB_OVF_STRIPES : tot;          /* (>= tot: also enough for a dense list) */
         if (tot >= (1ull << 32)) return fail(MTB_ERR_ARG, "more than 2^32-1 matches in one batch; split the batch");
         if (mx > c->ovf_region) return fail(MTB_ERR_CAPACITY, "match buffer too small");
         return MTB_OK;
@@ -817,7 +843,11 @@ struct ScoreSrc {
 /* d_results/d_tc_* are device outputs; *n_tc = sum of per-read bounds.  `second` (optional) runs after the launch
  * over `first`, may build a source for the reads that launch deferred (large-segment path) and returns true to
  * have it launched with the same per-read taxcnt slots. */
-typedef std::function<mtb_status(ScoreSrc *, bool *)> ScoreSecond;
+struct ScoreLaunch {                      /* what dev_score has set up by the time `second` runs: enough to launch a scorer of its own */
+    const uint64_t *d_tcoff; bool key64; mtb_score_params sp;
+    const int32_t *d_qlen, *d_qlen2; mtb_result *d_res; int32_t *d_tc_tax; uint32_t *d_tc_cnt; uint64_t tc_cap, tc_base;
+};
+typedef std::function<mtb_status(ScoreSrc *, bool *, const ScoreLaunch &)> ScoreSecond;
 static mtb_status dev_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, uint64_t n_reads, const int32_t *d_qlen, const int32_t *d_qlen2,
                             uint32_t max_len, mtb_result *d_res, int32_t *d_tc_tax, uint32_t *d_tc_cnt, uint64_t tc_cap, uint64_t *n_tc,
                             uint64_t tc_base, const ScoreSrc &first, const ScoreSecond *second,
@@ -847,7 +877,9 @@ static mtb_status dev_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, uint
         if (pass == 1) {
             if (!second) break;
             bool go = false;
-            STCHK((*second)(&second_src, &go));
+            ScoreLaunch SL; SL.d_tcoff = d_tcoff; SL.key64 = key64; SL.sp = sp; SL.d_qlen = d_qlen; SL.d_qlen2 = d_qlen2; SL.d_res = d_res;
+            SL.d_tc_tax = d_tc_tax; SL.d_tc_cnt = d_tc_cnt; SL.tc_cap = tc_cap; SL.tc_base = tc_base;
+            STCHK((*second)(&second_src, &go, SL));
             if (!go) break;
             S = &second_src;
         }
@@ -1301,6 +1333,17 @@ static mtb_status decode_chunked(mtb_ctx *c, mtb_index *ix, const std::string &d
     return MTB_OK;
 }
 
+/* An open that finds device memory short of what the index needs: the workspace a concurrent (or earlier) mtb_ctx_reserve took is worth
+ * less than the directory or the database itself -- stop the reservation, give the workspace back (batches grow it again as they did
+ * before there was a reservation).  Returns the free bytes afterwards. */
+static size_t open_make_room(mtb_ctx *c) {
+    c->reserve_cancel = true;
+    { std::lock_guard<std::mutex> lk(c->reserve_mu); release_workspace(c); }
+    size_t fr = 0, tot = 0;
+    hipError_t e = hipMemGetInfo(&fr, &tot); (void)e;
+    return fr;
+}
+
 static mtb_status open_impl(mtb_ctx *c, const char *dbdir, const char *taxonomy_dir, mtb_params *params, uint32_t part, uint32_t n_parts, mtb_index **out) {
     if (!c || !dbdir || !params || !out) return fail(MTB_ERR_ARG, "NULL argument");
     if (n_parts == 0 || part >= n_parts) return fail(MTB_ERR_ARG, "partition index out of range");
@@ -1353,11 +1396,17 @@ static mtb_status open_impl(mtb_ctx *c, const char *dbdir, const char *taxonomy_
     while (L < 7 && (uint64_t)mtb_pow21(L) < T / 8) L++;
     if (getenv("MTB_DIR_DEPTH")) L = std::max(1, std::min(7, atoi(getenv("MTB_DIR_DEPTH"))));
     bool want_dir = T >= 2 && !getenv("MTB_NO_DIR");
+    struct CancelReset { mtb_ctx *c; ~CancelReset() { c->reserve_cancel = false; } } cancel_reset{c};
     if (want_dir) {
         size_t fr = 0, tot = 0;
         HIPCHK(hipMemGetInfo(&fr, &tot));
         const uint32_t nbk = mtb_pow21(L);
-        if (((size_t)nbk + 1) * 4 + ((size_t)(nbk >> 16) + 3) * 8 + (T + 1) * 8 + (64u << 20) > fr) want_dir = false;        /* no room next to the values: the bisection join still works */
+        /* directory + target words + (flat state) info[] + the chunk buffers of the decode */
+        const bool pack_guess = L == 7 && !P.drop_last && !getenv("MTB_NO_PACK") && (getenv("MTB_OPEN_PACKED") ? atoi(getenv("MTB_OPEN_PACKED")) != 0 : T >= (1ull << 28));
+        const size_t need_dir = ((size_t)nbk + 1) * 4 + ((size_t)(nbk >> 16) + 3) * 8 + (T + 1) * 8 + (64u << 20);
+        const size_t need_all = need_dir + (pack_guess ? 0 : (size_t)T * 4) + (std::min<uint64_t>(O.n16, 1ull << 27) * 12 + (64u << 20));
+        if (need_all > fr && held_bytes(c) > 0) fr = open_make_room(c);      /* a reservation made for the first batches must not cost the index its directory */
+        if (need_dir > fr) want_dir = false;        /* no room next to the values: the bisection join still works */
     }
     /* pack on load: big databases (>= 2^28 targets; MTB_OPEN_PACKED=1 / 0 forces it on toy databases / off) whose directory has depth 7
      * open in the SEALED state -- packed 8-byte words, info[] never resident (mtb_index_seal's state; everything that needs the flat
@@ -1367,8 +1416,16 @@ static mtb_status open_impl(mtb_ctx *c, const char *dbdir, const char *taxonomy_
     { size_t fr = 0, tot = 0; HIPCHK(hipMemGetInfo(&fr, &tot)); ix->open_free0 = fr; }
     for (int attempt = 0; attempt < 2; attempt++) {
         ix->open_chunks = 0; ix->open_peak_bytes = 0;
-        HIPCHK(hipMalloc((void **)&ix->d_values, (T + 1) * 8));
-        if (!pack) HIPCHK(hipMalloc((void **)&ix->d_info, std::max<uint64_t>(T, 1) * 4));
+        {   /* short of memory with a workspace reservation in the way: hand the reservation back and try once more */
+            hipError_t e = hipMalloc((void **)&ix->d_values, (T + 1) * 8);
+            if (e == hipErrorOutOfMemory && held_bytes(c) > 0) { (void)hipGetLastError(); open_make_room(c); e = hipMalloc((void **)&ix->d_values, (T + 1) * 8); }
+            HIPCHK(e);
+            if (!pack) {
+                e = hipMalloc((void **)&ix->d_info, std::max<uint64_t>(T, 1) * 4);
+                if (e == hipErrorOutOfMemory && held_bytes(c) > 0) { (void)hipGetLastError(); open_make_room(c); e = hipMalloc((void **)&ix->d_info, std::max<uint64_t>(T, 1) * 4); }
+                HIPCHK(e);
+            }
+        }
         bool dir_ok = false;
         {   /* the chunk buffers go back whatever way the decode ends */
             struct Scratch { mtb_ctx *c; ~Scratch() { release(c, "diffraw"); release(c, "difftc"); release(c, "difftoff"); release(c, "infochunk"); } } scratch{c};
@@ -1862,15 +1919,16 @@ static mtb_status prepare_slots(mtb_ctx *c, uint64_t n_reads, uint32_t stride, m
     hipStream_t st = c->stream;
     mtb_slot16 *d_segm;
     DevBuf &sb = c->bufs["segm"];
-    void *before = sb.p; size_t cap_before = sb.cap;
     STCHK(ensure_placed(c, "segm", n_reads * (uint64_t)stride, &d_segm));
     static const char *clear_mode = getenv("MTB_SEGM_CLEAR");      /* experiment switch: kernel | sync | always (default: hipMemsetAsync when new / on epoch wrap) */
     const bool always = clear_mode && !strcmp(clear_mode, "always");
-    if (sb.p != before || sb.cap != cap_before || c->seg_epoch >= MTB_SLOT_EPOCHS || always) {
+    /* cleared when the allocation is not the one this function cleared last (new, grown, or created by mtb_ctx_reserve: never
+     * written by a clear), or when the tag wraps */
+    if (sb.p != c->seg_clean_p || sb.cap != c->seg_clean_cap || c->seg_epoch == 0 || c->seg_epoch >= MTB_SLOT_EPOCHS || always) {
         if (clear_mode && !strcmp(clear_mode, "kernel")) hipLaunchKernelGGL(k_clear_words, dim3(2048), dim3(256), 0, st, (uint64_t *)sb.p, (uint64_t)(sb.cap / 8));
         else HIPCHK(hipMemsetAsync(sb.p, 0, sb.cap, st));
         if (clear_mode && !strcmp(clear_mode, "sync")) HIPCHK(hipDeviceSynchronize());
-        c->seg_epoch = 0;
+        c->seg_epoch = 0; c->seg_clean_p = sb.p; c->seg_clean_cap = sb.cap;
     }
     c->seg_epoch++;
     *out = d_segm; *epoch_out = c->seg_epoch;
@@ -1891,6 +1949,7 @@ static mtb_status score_fixed_slots(mtb_ctx *c, mtb_index *ix, const mtb_params 
                                     uint32_t max_len_deferred = 0, const uint8_t *d_off_reads = nullptr, uint64_t ovf_region = 0 /* != 0: the overflow list is striped (dev_join) */) {
     hipStream_t st = c->stream;
     uint64_t nm = 0;
+    memset(c->many_stats, 0, sizeof(c->many_stats));
     uint32_t *d_biglist, *d_bigcnt, *d_bigidx, *d_bigcur, *d_cnt; uint64_t *d_bigstart = nullptr, *d_ws2, *d_tot; mtb_match *d_big = nullptr;
     STCHK(ensure(c, "biglist", n_reads, &d_biglist)); STCHK(ensure(c, "bigidx", n_reads, &d_bigidx)); STCHK(ensure(c, "livecnt", n_reads, &d_cnt));
     STCHK(ensure(c, "segstart", n_reads + 1, &d_tot)); STCHK(ensure(c, "scanws", scan_ws_elems(n_reads + 1), &d_ws2));
@@ -1908,12 +1967,52 @@ static mtb_status score_fixed_slots(mtb_ctx *c, mtb_index *ix, const mtb_params 
     a.max_seg = a.cap;
     a.big_list = d_biglist; a.n_big = (uint32_t *)(c->d_scal + 5); a.cnt_out = d_cnt;
     /* reads the first launch could not take from their slots: exact segments (live slots + overflow list), sorted in HBM */
-    ScoreSecond second = [&](ScoreSrc *b, bool *go) -> mtb_status {
+    ScoreSecond second = [&](ScoreSrc *b, bool *go, const ScoreLaunch &SL) -> mtb_status {
         uint64_t sc = 0;
         STCHK(d2h(c, &sc, c->d_scal + 5, 8));
-        const uint32_t n_big = (uint32_t)sc;
+        uint32_t n_big = (uint32_t)sc;
         *go = n_big != 0;
         if (!n_big) return MTB_OK;
+        c->many_stats[0] = n_big; c->many_stats[1] = 0;
+        const bool no_many = getenv("MTB_NO_SCORE_MANY") != nullptr;        /* A/B switch, read per batch: every deferred read through exact segments (round 4's path) */
+        if (!no_many && stride <= 384u) {
+            /* ---- the reads of conserved genes (kernels_score_many.h): scored straight from their slots + their overflow entries, dead
+             * species dropped before anything is ordered.  The overflow list is grouped by read first (counts from the tail cursors). ---- */
+            KTimer ktm(c, MTB_K_SCORE_MANY);
+            uint32_t *d_novf = nullptr, *d_ocur = nullptr, *d_rest; uint64_t *d_ostart = nullptr; mtb_match *d_ovfg = nullptr;
+            STCHK(ensure(c, "restlist", n_reads, &d_rest));
+            const bool have_ovf = ovf_region ? c->ovf_max_region != 0 : n_ovf != 0;
+            if (have_ovf) {
+                STCHK(ensure(c, "novf", n_reads, &d_novf)); STCHK(ensure(c, "ocur", n_reads, &d_ocur)); STCHK(ensure(c, "ovfstart", n_reads + 1, &d_ostart));
+                STCHK(ensure(c, "ovfg", n_ovf + 1, &d_ovfg));
+                HIPCHK(hipMemsetAsync(d_ocur, 0, n_reads * 4, st));
+                hipLaunchKernelGGL(k_ovf_count, dim3((uint32_t)((n_reads + 255) / 256)), dim3(256), 0, st, (const uint32_t *)d_rc, d_off_reads, n_reads, stride - direct, d_novf);
+                scan_launch<uint32_t, uint64_t, false>(st, d_novf, n_reads, true, d_ostart, d_ws2);
+                if (ovf_region) hipLaunchKernelGGL(k_ovf_group, dim3((uint32_t)((c->ovf_max_region + 255) / 256), MTB_OVF_STRIPES), dim3(256), 0, st, (const mtb_match *)d_ovf, n_ovf,
+                                                   (const uint64_t *)d_ostart, (const uint32_t *)d_novf, d_ocur, d_ovfg, ovf_region, (const unsigned long long *)c->d_ovfctr);
+                else hipLaunchKernelGGL(k_ovf_group, dim3((uint32_t)((n_ovf + 255) / 256)), dim3(256), 0, st, (const mtb_match *)d_ovf, n_ovf,
+                                        (const uint64_t *)d_ostart, (const uint32_t *)d_novf, d_ocur, d_ovfg, (uint64_t)0, (const unsigned long long *)nullptr);
+            }
+            HIPCHK(hipMemsetAsync(c->d_xscal + 2, 0, 8 * 4, st));       /* [2] reads handed on, [3] work counter, [4] matches seen, [5] survivors */
+            const uint32_t gridm = std::min<uint32_t>(n_big, 256u * (stride <= 192u ? 12u : 7u));
+#define MTB_LAUNCH_MANY(K64, CAPV) hipLaunchKernelGGL((k_score_many<K64, CAPV>), dim3(gridm), dim3(64), 0, st, (const mtb_slot16 *)d_segm, stride, direct, epoch, (const uint32_t *)d_rc, d_off_reads, \
+            (const mtb_match *)d_ovfg, (const uint64_t *)d_ostart, (const uint32_t *)d_biglist, (const uint32_t *)(c->d_scal + 5), SL.d_qlen, SL.d_qlen2, tax_view(ix), SL.sp, SL.d_tcoff, SL.d_res, \
+            SL.d_tc_tax, SL.d_tc_cnt, SL.tc_cap, SL.tc_base, d_rest, (uint32_t *)(c->d_xscal + 2), d_cnt, (unsigned long long *)(c->d_xscal + 3), (unsigned long long *)(c->d_xscal + 4))
+            if (stride <= 192u) { if (SL.key64) MTB_LAUNCH_MANY(true, 192); else MTB_LAUNCH_MANY(false, 192); }
+            else { if (SL.key64) MTB_LAUNCH_MANY(true, 320); else MTB_LAUNCH_MANY(false, 320); }
+#undef MTB_LAUNCH_MANY
+            HIPCHK(hipGetLastError());
+            uint64_t ms4[4] = {0, 0, 0, 0};
+            STCHK(d2h(c, ms4, c->d_xscal + 2, 32));
+            const uint32_t n_rest = (uint32_t)(ms4[0] & 0xFFFFFFFFull);
+            c->many_stats[1] = n_big - n_rest; c->many_stats[2] = ms4[2]; c->many_stats[3] = ms4[3];
+            n_big = n_rest;
+            *go = n_big != 0;
+            if (!n_big) return MTB_OK;
+            /* what is left goes the old way: the list of those reads, its length where the launches below read it */
+            d_biglist = d_rest;
+            HIPCHK(hipMemcpyAsync(c->d_scal + 5, c->d_xscal + 2, 8, hipMemcpyDeviceToDevice, st));
+        }
         KTimer kt(c, MTB_K_SEGSORT);
         STCHK(ensure(c, "bigcnt", n_big, &d_bigcnt)); STCHK(ensure(c, "bigstart", (uint64_t)n_big + 1, &d_bigstart)); STCHK(ensure(c, "bigcur", n_big, &d_bigcur));
         hipLaunchKernelGGL(k_big_count, dim3(std::min<uint32_t>(n_big, 4096)), dim3(64), 0, st, (const mtb_slot16 *)d_segm, stride, direct, epoch,
@@ -2062,11 +2161,12 @@ static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, c
             JoinSegArgs sa; memset(&sa, 0, sizeof(sa));
             sa.seg = d_segm; sa.stride = stride; sa.direct = direct; sa.cursor = d_rc; sa.ovf = d_ovf; sa.ovf_cap = ovf_cap;
             sa.ovf_counter = nullptr; sa.epoch = epoch; sa.off = route_off ? d_off : nullptr;
+            sa.dense_ovf = attempt == 2 ? 1u : 0u;            /* last attempt: one list that holds the total, whatever the stripes' fill */
             mtb_status s2 = dev_join(c, ix, d_s, nk, nullptr, 0, nullptr, &n_ovf, &sa, low_bits);
             if (s2 == MTB_OK) break;
             if (s2 != MTB_ERR_CAPACITY || attempt == 2) return s2;
             ovf_cap = n_ovf + n_ovf / 16 + 1024;
-            HIPCHK(hipMemsetAsync(d_rc, 0, n_reads * 4, st));     /* slots written by the failed attempt are rewritten identically */
+            HIPCHK(hipMemsetAsync(d_rc, 0, n_reads * 4, st));     /* ordinal slots are rewritten identically; tail slots and the overflow list are filled anew (their order follows the atomics) */
         }
         HIPCHK(hipEventRecord(c->ev[3], st));
         HIPCHK(hipEventRecord(c->ev[4], st));
@@ -2194,6 +2294,7 @@ static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, c
     if (c->fast_used) { uint64_t ns = 0; STCHK(d2h(c, &ns, c->d_scal + 6, 8)); S.n_generic_reads = ns & 0xFFFFFFFFull; c->fast_used = false; }
     else S.n_generic_reads = n_reads;
     S.n_slot_reads = (fixed || lslot) ? n_reads : 0;
+    if (fixed) { S.n_deferred_reads = c->many_stats[0]; S.n_many_reads = c->many_stats[1]; S.n_many_matches = c->many_stats[2]; S.n_many_kept = c->many_stats[3]; }
     return MTB_OK;
 }
 
@@ -2202,6 +2303,7 @@ static void merge_stats(mtb_batch_stats &S, const mtb_batch_stats &L) {
     S.ms_segsort += L.ms_segsort; S.ms_score += L.ms_score;
     S.n_reads += L.n_reads; S.n_bases += L.n_bases; S.n_kmers += L.n_kmers; S.n_matches += L.n_matches; S.n_targets = L.n_targets;
     S.n_generic_reads += L.n_generic_reads; S.n_slot_reads += L.n_slot_reads;
+    S.n_deferred_reads += L.n_deferred_reads; S.n_many_reads += L.n_many_reads; S.n_many_matches += L.n_many_matches; S.n_many_kept += L.n_many_kept;
     for (int i = 0; i < MTB_NUM_KERNELS; i++) { S.ms_kernel[i] += L.ms_kernel[i]; S.n_launch[i] += L.n_launch[i]; }
 }
 
@@ -2438,14 +2540,26 @@ static mtb_status classify_packed_impl(mtb_ctx *c, mtb_index *ix, const mtb_para
     const double t0 = now();
     if (p->seq_mode == 2 && (!packed2_mate || !nmask_mate || !lens_mate)) return fail(MTB_ERR_ARG, "seq_mode 2 needs the mates");
     /* this batch may already be on its way (mtb_prefetch_batch_packed): then the compute stream only waits for the copy */
-    const bool pre = c->pre.valid && c->pre.key == (const void *)packed2 && c->pre.n_reads == n_reads && (p->seq_mode != 2 || c->pre.key2 == (const void *)packed2_mate);
-    const int set = pre ? (c->pk_set ^ 1) : c->pk_set;
-    if (c->pre.valid && !pre) HIPCHK(hipStreamSynchronize(c->copy_stream));       /* a prefetch nobody came for: let it finish before its buffers are reused */
-    c->pre.valid = false;
-    if (pre) HIPCHK(hipStreamWaitEvent(c->stream, c->copy_done, 0));
+    int set = -1;
+    for (int k = 0; k < 2; k++)
+        if (c->pre[k].valid && c->pre[k].key == (const void *)packed2 && c->pre[k].n_reads == n_reads && (p->seq_mode != 2 || c->pre[k].key2 == (const void *)packed2_mate)) set = k;
+    const bool pre = set >= 0;
+    if (!pre) {
+        /* not prefetched: upload on the compute stream into a set no outstanding prefetch (of a LATER batch) is filling */
+        if (!c->pre[c->pk_set].valid) set = c->pk_set;
+        else if (!c->pre[c->pk_set ^ 1].valid) set = c->pk_set ^ 1;
+        else {      /* both sets hold prefetches nobody came for: let them finish, drop them */
+            HIPCHK(hipStreamSynchronize(c->copy_stream));
+            c->pre[0].valid = c->pre[1].valid = false; set = c->pk_set;
+        }
+    } else {
+        c->pre[set].valid = false; c->prefetch_used++;
+        HIPCHK(hipStreamWaitEvent(c->stream, c->copy_done[set], 0));
+    }
     c->pk_set = set;
     STCHK(upload_packed(c, "", set, pre, packed2, nmask, lens, n_reads, &d_b, &d_o, &nb));
     if (p->seq_mode == 2) STCHK(upload_packed(c, "2", set, pre, packed2_mate, nmask_mate, lens_mate, n_reads, &d_b2, &d_o2, &nb2));
+    if (c->unpacked[set]) { HIPCHK(hipEventRecord(c->unpacked[set], c->stream)); c->unpacked_rec[set] = true; }      /* the set may be overwritten by a prefetch from here on (stream order) */
     mtb_result *d_res; int32_t *d_tt; uint32_t *d_tc;
     const uint64_t dcap = c->lanes.size() < 2 ? std::max<uint64_t>(taxcnt_cap, taxcnt_device_slots(p, n_reads, nb + nb2)) : taxcnt_cap;     /* (as in mtb_classify_batch) */
     STCHK(ensure(c, rset == 1 ? "resultsb" : "results", n_reads, &d_res)); STCHK(ensure(c, "tctax", dcap, &d_tt)); STCHK(ensure(c, "tccnt", dcap, &d_tc));
@@ -2514,16 +2628,32 @@ mtb_status mtb_prefetch_batch_packed(mtb_ctx *c, const mtb_params *p, const uint
     HIPCHK(hipSetDevice(c->device));
     if (n_reads == 0 || c->lanes.size() > 1) return MTB_OK;
     if (p->seq_mode == 2 && (!packed2_mate || !nmask_mate || !lens_mate)) return fail(MTB_ERR_ARG, "seq_mode 2 needs the mates");
-    if (!c->copy_stream) { HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming)); }
-    if (c->pre.valid) HIPCHK(hipStreamSynchronize(c->copy_stream));
-    c->pre.valid = false;
-    const int set = c->pk_set ^ 1;
+    if (!c->copy_stream) {
+        HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        for (int k = 0; k < 2; k++) { HIPCHK(hipEventCreateWithFlags(&c->copy_done[k], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->unpacked[k], hipEventDisableTiming)); }
+    }
+    /* the set that holds no outstanding prefetch: in protocol order (prefetch(k+1) right before classify(k)) batch k waits in one set and
+     * the other was read by classify(k-1).  Both taken = the caller ran ahead of the protocol: nothing is prefetched, the batch is uploaded
+     * by its own classify call. */
+    int set = c->pk_set ^ 1;
+    if (c->pre[set].valid) set ^= 1;
+    if (c->pre[set].valid) return MTB_OK;
+    if (c->unpacked_rec[set]) HIPCHK(hipStreamWaitEvent(c->copy_stream, c->unpacked[set], 0));     /* the call that last read the set has turned it into text */
     uint8_t *a, *b; uint32_t *l;
     const uint64_t s1 = packed_slots(lens, n_reads);
     STCHK(copy_packed(c, "", set, c->copy_stream, packed2, nmask, lens, n_reads, s1, &a, &b, &l));
     if (p->seq_mode == 2) STCHK(copy_packed(c, "2", set, c->copy_stream, packed2_mate, nmask_mate, lens_mate, n_reads, packed_slots(lens_mate, n_reads), &a, &b, &l));
-    HIPCHK(hipEventRecord(c->copy_done, c->copy_stream));
-    c->pre.key = packed2; c->pre.key2 = packed2_mate; c->pre.n_reads = n_reads; c->pre.valid = true;
+    HIPCHK(hipEventRecord(c->copy_done[set], c->copy_stream));
+    c->pre[set].key = packed2; c->pre[set].key2 = packed2_mate; c->pre[set].n_reads = n_reads; c->pre[set].valid = true;
+    c->prefetch_issued++;
+    return MTB_OK;
+}
+
+/* prefetches issued / prefetches a classify call found and used instead of uploading the batch itself (in protocol order: all of them) */
+mtb_status mtb_ctx_prefetch_stats(mtb_ctx *c, uint64_t *issued, uint64_t *used) {
+    if (!c) return fail(MTB_ERR_ARG, "NULL argument");
+    if (issued) *issued = c->prefetch_issued;
+    if (used) *used = c->prefetch_used;
     return MTB_OK;
 }
 
@@ -2990,11 +3120,14 @@ mtb_status mtb_ctx_reserve(mtb_ctx *c, const mtb_params *p, uint64_t n_reads, ui
     if (!c || !p) return fail(MTB_ERR_ARG, "NULL argument");
     if (n_reads == 0 || n_bases == 0 || p->seq_mode == 3) return MTB_OK;
     HIPCHK(hipSetDevice(c->device));
+    std::lock_guard<std::mutex> rlk(c->reserve_mu);
+    /* an index open on this context that runs short of device memory cancels the reservation (open_make_room): checked between buffers */
+#define MTB_RESERVE_STEP(call) do { if (c->reserve_cancel) return MTB_OK; STCHK(call); } while (0)
     const uint32_t grid = (uint32_t)std::min<uint64_t>(n_reads, 256ull * 256);
     const uint64_t cap = extract_cap_guess(c, p, n_bases, grid);
     mtb_kmer *k; uint16_t *dg; mtb_slot16 *sg;
-    STCHK(ensure(c, "kmersA", cap, &k)); STCHK(ensure(c, "kmersB", cap, &k));
-    if (p->kmer_format == 2) { STCHK(ensure(c, "digA", cap + 8, &dg)); STCHK(ensure(c, "digB", cap + 8, &dg)); }
+    MTB_RESERVE_STEP(ensure(c, "kmersA", cap, &k)); MTB_RESERVE_STEP(ensure(c, "kmersB", cap, &k));
+    if (p->kmer_format == 2) { MTB_RESERVE_STEP(ensure(c, "digA", cap + 8, &dg)); MTB_RESERVE_STEP(ensure(c, "digB", cap + 8, &dg)); }
     /* slot segments: metamers of the longest read guessed from the mean length (six frames of L/3 - 7 windows per mate; syncmer
      * selection keeps a little over half), one direct slot each + the tail */
     const int mates = p->seq_mode == 2 ? 2 : 1;
@@ -3002,7 +3135,8 @@ mtb_status mtb_ctx_reserve(mtb_ctx *c, const mtb_params *p, uint64_t n_reads, ui
     const double per_read = std::max(0.0, L / 3.0 - 7.0) * 6.0 * mates * (p->syncmer ? 0.56 : 1.0) * 1.10;
     uint32_t direct, stride;
     slot_geometry((uint32_t)std::min<double>(per_read, (double)MTB_SLOT_MAX_Q), &direct, &stride);
-    STCHK(ensure(c, "segm", n_reads * (uint64_t)stride, &sg));
+    MTB_RESERVE_STEP(ensure(c, "segm", n_reads * (uint64_t)stride, &sg));
+#undef MTB_RESERVE_STEP
     return MTB_OK;
 }
 

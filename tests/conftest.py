@@ -96,7 +96,7 @@ class HotToy:
     candidates with a spread of hamming sums: the join's wave-cooperative scan (kernels_dir.h, MTB_JOIN_COOP_MIN) instead of its
     per-lane loop."""
 
-    def __init__(self, orc, tmpdir, seq_mode=1, n_reads=150, length=150, n_hot=70, seed=77, err=0.01, lognormal=False):
+    def __init__(self, orc, tmpdir, seq_mode=1, n_reads=150, length=150, n_hot=70, seed=77, err=0.01, lognormal=False, keep=1.0):
         from helpers import build_toy_db, default_params
         from metabuli_amd import synth
         paired = seq_mode == 2
@@ -116,7 +116,8 @@ class HotToy:
                 newc = rng.integers(0, 8, size=len(v0)).astype(np.uint64)
                 hit = rng.random(len(v0)) < 0.45
                 dna = np.where(hit, (dna & ~(np.uint64(7) << pos)) | (newc << pos), dna)
-            ev.append((v0 & ~np.uint64(0xFFFFFF)) | dna); et.append(np.full(len(v0), nxt, np.int32))
+            sel = rng.random(len(v0)) < keep if keep < 1.0 else np.ones(len(v0), bool)     # keep < 1: a hot species files only a sparse subset (most of its matches in a read are alone in their species)
+            ev.append(((v0 & ~np.uint64(0xFFFFFF)) | dna)[sel]); et.append(np.full(int(sel.sum()), nxt, np.int32))
             nxt += 1
         self.world = w
         self.dbdir = str(tmpdir); os.makedirs(self.dbdir, exist_ok=True)

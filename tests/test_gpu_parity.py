@@ -166,6 +166,41 @@ def test_two_bit_reads_give_the_results_of_the_text(ctx, toy):
     ix.close()
 
 
+def test_a_prefetched_batch_is_used_by_its_classify_call(ctx, toy):
+    """the protocol of mtb.h is prefetch(k+1), classify(k) -- two prefetches are outstanding when classify(k) runs (batch
+    k, issued one call earlier, and batch k+1).  With ONE record the library found batch k+1's key in classify(k), threw the prefetch away and
+    uploaded every batch a second time.  Here: five ragged batches in protocol order = the same batches one by one, and every prefetch issued
+    was consumed by its classify call (mtb_ctx_prefetch_stats)."""
+    p = _params(toy)
+    ix = ctx.open_index(toy.dbdir, p)
+    n = toy.n_reads
+    cuts = [0, n // 7, n // 7 + 1, n // 2, n - 3, n]
+    o1 = toy.o1.astype(np.int64); o2 = toy.o2.astype(np.int64) if toy.o2 is not None else None
+
+    def part(a, b):
+        b1 = toy.b1[o1[a]:o1[b]]; q1 = (o1[a:b + 1] - o1[a]).astype(np.uint64)
+        if o2 is None:
+            return (b1, q1, None, None)
+        return (b1, q1, toy.b2[o2[a]:o2[b]], (o2[a:b + 1] - o2[a]).astype(np.uint64))
+    batches = [part(a, b) for a, b in zip(cuts[:-1], cuts[1:])]
+    want = [ctx.classify_batch_packed(ix, p, *bt) for bt in batches]
+    i0, u0 = ctx.prefetch_stats()
+    got = ctx.classify_batches_packed_prefetched(ix, p, batches)
+    i1, u1 = ctx.prefetch_stats()
+    assert i1 - i0 == len(batches) - 1 and u1 - u0 == len(batches) - 1, (i0, u0, i1, u1)
+    for w, g in zip(want, got):
+        for a, b in zip(w, g):
+            assert len(a) == len(b) and (a == b).all()
+    # a prefetch nobody comes for does not disturb the calls after it
+    got2 = ctx.classify_batches_packed_prefetched(ix, p, batches[:2])
+    _ = ctx.classify_batch_packed(ix, p, *batches[4])
+    got3 = ctx.classify_batches_packed_prefetched(ix, p, batches[::-1])
+    for w, g in zip(want[::-1], got3):
+        for a, b in zip(w, g):
+            assert len(a) == len(b) and (a == b).all()
+    ix.close()
+
+
 def test_results_on_their_way_back_while_the_next_batch_runs(ctx, toy):
     """mtb_classify_batch_packed_async: a batch's rows and taxID:count lists are copied out on a download stream while the next batch computes
     (two device-side result buffer sets alternate) and belong to the caller once the NEXT call has returned or after mtb_ctx_wait_results.
@@ -827,6 +862,43 @@ def test_long_candidate_runs_are_scanned_by_the_wave(orc, tmp_path, seq_mode, de
     # the stage join (k_join: LDS window) on the same database gives the same match list as the oracle: the two joins agree through it
     m = c.sort_matches(c.match(ix, t.ref["kmers"]), t.n_reads)
     assert (m == t.ref["matches"]).all()
+    ix.close(); c.close()
+
+
+@pytest.mark.parametrize("seq_mode", [1, 2])
+def test_reads_that_meet_many_species_are_scored_from_their_slots(orc, tmp_path, seq_mode, monkeypatch):
+    """A conserved protein filed under 160 species, each of which holds only a sparse subset of its metamers: a read of that gene brings a
+    few hundred matches, most of them alone in their species.  Its tail overflows, so the slot scorers defer it; k_score_many
+    (kernels_score_many.h) takes it straight from its slots + its entries of the overflow list, drops the species that have no (species,
+    frame) group of two matches (Taxonomer.cpp:342: they can never score) and scores the rest in LDS.  Results = the oracle's; the
+    statistics say that the kernel ran and that it dropped matches; the exact-segment path of round 4 (MTB_NO_SCORE_MANY) gives the
+    same answers."""
+    import metabuli_amd as M
+    from conftest import HotToy
+    t = HotToy(orc, tmp_path / "db", seq_mode=seq_mode, n_reads=200, n_hot=160, keep=0.06)
+    c = M.Context(0)
+    p = M.default_params(seq_mode=seq_mode, syncmer=1)
+    ix = c.open_index(t.dbdir, p)
+    ro = t.ref["results"]
+    amb = ro["flag"] != 0
+
+    def check(res, tt, tc):
+        assert ((res["classification"] == ro["classification"]) | amb).all()
+        assert ((res["score"].view(np.uint32) == ro["score"].view(np.uint32)) | amb).all()
+        assert ((res["n_taxcnt"] == ro["n_taxcnt"]) | amb).all()
+        if not amb.any():
+            assert (tt == t.ref["tc_tax"]).all() and (tc == t.ref["tc_cnt"]).all()
+        assert c.last_stats().n_matches == len(t.ref["matches"])
+    check(*c.classify_batch(ix, p, t.b1, t.o1, t.b2, t.o2))
+    st = c.last_stats()
+    assert st.n_deferred_reads > 20 and st.n_many_reads > 20, (st.n_deferred_reads, st.n_many_reads)
+    assert 0 < st.n_many_kept < st.n_many_matches, (st.n_many_kept, st.n_many_matches)
+    monkeypatch.setenv("MTB_NO_SCORE_MANY", "1")
+    check(*c.classify_batch(ix, p, t.b1, t.o1, t.b2, t.o2))
+    st2 = c.last_stats()
+    assert st2.n_many_reads == 0 and st2.n_deferred_reads == st.n_deferred_reads
+    monkeypatch.delenv("MTB_NO_SCORE_MANY")
+    check(*c.classify_batch(ix, p, t.b1, t.o1, t.b2, t.o2))
     ix.close(); c.close()
 
 

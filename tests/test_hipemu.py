@@ -106,14 +106,14 @@ def test_long_reads_and_long_runs_on_the_emulator(emulated_lib):
 
 
 def test_bench_line_of_two_ranks_on_the_emulator(emulated_lib, tmp_path):
-    """bench.py launched the way the driver launches it for N = 2 (torch.distributed.run, one rank per GPU; here gloo and the emulated
-    build): every rank classifies its own reads against its own replica, the time is the maximum over the ranks, rank 0 prints ONE
+    """bench.py's main() launched the way the driver launches bench.py for N = 2 (torch.distributed.run, one rank per GPU; here gloo and the
+    emulated build, through tests/hipemu/bench_emulated.py, which hands main() a CPU device): every rank classifies its own reads against its own replica, the time is the maximum over the ranks, rank 0 prints ONE
     JSON line for the whole job"""
     import json
     env = dict(os.environ, MTB_HIPEMU="1", MTB_LIB=emulated_lib, HIPEMU_THREADS="2")
     port = 29600 + os.getpid() % 300
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--reads", "3000", "--targets", "1.5e6", "--species", "8",
+                        os.path.join(ROOT, "tests", "hipemu", "bench_emulated.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--reads", "3000", "--targets", "1.5e6", "--species", "8",
                         "--genome-len", "80000", "--filler-species", "2000", "--dist-backend", "gloo", "--shared-gpu"],
                        env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
