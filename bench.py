@@ -781,6 +781,9 @@ def main(device=None):
     ap.add_argument("--ab", default="", help="A/B legs after the timed region: ';'-separated NAME=VALUE settings of the library's per-batch experiment switches "
                                              "(MTB_NO_SCORE_MANY=1, MTB_JOIN_VARIANT=q1w6 ...); each is timed on the headline batch (and the best-case batch) in this very process, "
                                              "on this very index and allocation")
+    ap.add_argument("--reads-from", default="index", choices=["index", "heldout"],
+                    help="heldout: the timed batch's reads come from the held-out genomes (species of indexed genera that are NOT in the index) -- the novel leg's workload as the "
+                         "main one, for profiler runs")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--dist-backend", default="nccl", help="testing only: gloo lets several ranks share one GPU (RCCL refuses duplicate devices)")
     ap.add_argument("--shared-gpu", action="store_true", help="testing only: every rank uses cuda:0")
@@ -819,7 +822,7 @@ def main(device=None):
     big_world = args.species >= 200
     conserved = big_world and not args.no_conserved
     world = build_world_fast(torch, dev, args.seed, args.species, args.genome_len, args.filler_species, conserved=conserved,
-                             n_heldout=args.heldout if (single and not args.no_legs and args.seq_mode == 1) else 0) if big_world else \
+                             n_heldout=args.heldout if ((single and not args.no_legs and args.seq_mode == 1) or args.reads_from == "heldout") else 0) if big_world else \
         build_world(args.seed, args.species, args.genome_len, args.filler_species)
     taxdir = tempfile.mkdtemp(prefix="mtb_tax_")
     world.tax.write(taxdir)
@@ -845,7 +848,7 @@ def main(device=None):
     if args.seq_mode == 2:
         d_bases, d_offs, d_bases2 = gen_reads(torch, dev, world.genomes, args.reads, args.read_len, 0.10, 0.005, rseed, paired=True)
     else:
-        d_bases, d_offs = gen_reads(torch, dev, world.genomes, args.reads, args.read_len, 0.10, 0.005, rseed)
+        d_bases, d_offs = gen_reads(torch, dev, world.heldout if args.reads_from == "heldout" else world.genomes, args.reads, args.read_len, 0.10, 0.005, rseed)
     # the other configurations' reads and every parity sample's sub-database: taken from the flat arrays, before anything packs them
     legs = {}
     if do_legs:
@@ -1045,6 +1048,10 @@ def main(device=None):
             _, lpar = oracle_parity(ctx, M, torch, dev, index, lp, taxdir, lg["b"], lg["b2"], lg["read_len"], lg["sub"], T, label=name)
             entry["parity"] = lpar; entry["mismatches"] = lpar["mismatches"]
             if lpar["mismatches"]:
+                if "MTB_NO_SCORE_MANY" not in os.environ:        # diagnosis before giving up: the same sample with the deferred reads on round 4's exact-segment path
+                    os.environ["MTB_NO_SCORE_MANY"] = "1"
+                    _, lpar2 = oracle_parity(ctx, M, torch, dev, index, lp, taxdir, lg["b"], lg["b2"], lg["read_len"], lg["sub"], T, label=name + " (MTB_NO_SCORE_MANY=1)")
+                    log(f"[rank 0] the same sample without k_score_many: {lpar2['mismatches']} mismatches")
                 raise SystemExit(f"parity check of the {name} leg failed: {lpar}")
         log(f"[rank 0] leg {name}: {ms:.1f} ms per step = {entry['mreads_per_s']:.2f} Mreads/s = {entry['gbp_per_s']:.2f} Gbp/s")
         other[name] = entry

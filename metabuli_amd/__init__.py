@@ -337,6 +337,10 @@ class Context:
             out.append(compact_taxcnt(*held))
         return out
 
+    def reserve(self, params, n_reads, n_bases):
+        """mtb_ctx_reserve: grow the workspace of a short-read batch of that size ahead of time"""
+        _chk(self.L.mtb_ctx_reserve(self.h, C.byref(params), C.c_uint64(n_reads), C.c_uint64(n_bases)))
+
     def prefetch_stats(self):
         """(prefetches issued, prefetches a classify call used instead of uploading its batch again) -- mtb_ctx_prefetch_stats"""
         a, b = C.c_uint64(), C.c_uint64()

@@ -632,6 +632,8 @@ int main(int argc, char **argv) {
         collector.join();
         const double t_stage = now() - t_stage0;
         for (int w = 0; w < W; w++) { t_gpu = std::max(t_gpu, w_busy[(size_t)w]); t_dev += w_dev[(size_t)w]; }
+        uint64_t pf_issued = 0, pf_used = 0;           /* uploads that crossed PCIe behind the previous batch's kernels (mtb_prefetch_batch_packed) */
+        for (int w = 0; w < W; w++) { uint64_t a_ = 0, b_ = 0; if (mtb_ctx_prefetch_stats(wctx[(size_t)w][0], &a_, &b_) == MTB_OK) { pf_issued += a_; pf_used += b_; } }
         for (int w = 1; w < W; w++) for (size_t d = 0; d < ND; d++) mtb_ctx_destroy(wctx[(size_t)w][d]);
         job_maker.join(); reader.join(); writer.join();
         fclose(out);
@@ -652,8 +654,9 @@ int main(int argc, char **argv) {
             write_krona(fp, ct, total);
             fclose(fp);
         }
-        fprintf(stderr, "mtb_classify: %lu reads in %.2f s on %zu GPU(s) (index open %.2f s; stage busy time: parse %.2f s, GPU incl. PCIe %.2f s busiest of %d worker(s) over %.2f s (device time of all batches %.2f s), format+write %.2f s (rows %.2f s, file %.2f s); %d host threads)\n",
-                total, now() - t_start, ND, t_open, t_parse, t_gpu, W, t_stage, t_dev, t_write, t_fmt, t_app, threads);
+        fprintf(stderr, "mtb_classify: %lu reads in %.2f s on %zu GPU(s) (index open %.2f s; stage busy time: parse %.2f s, GPU incl. PCIe %.2f s busiest of %d worker(s) over %.2f s (device time of all batches %.2f s), format+write %.2f s (rows %.2f s, file %.2f s); %d host threads; %llu of %llu prefetched uploads used%s)\n",
+                total, now() - t_start, ND, t_open, t_parse, t_gpu, W, t_stage, t_dev, t_write, t_fmt, t_app, threads, (unsigned long long)pf_used, (unsigned long long)pf_issued,
+                async_results ? "; results copied out while the next batch runs" : "");
     } catch (const std::exception &e) {
         fprintf(stderr, "mtb_classify: %s\n", e.what());
         return 1;

@@ -184,7 +184,12 @@ __global__ __launch_bounds__(256) void k_index_unpack(uint64_t *__restrict__ val
  * 10^3 - 10^4 species -- and a lane that walks such a run twice on its own (minimum, then emission: the reference's
  * loop, KmerMatcher.cpp:363-416) stalls the other 63 lanes of its wave for thousands of dependent loads. */
 #ifndef MTB_JOIN_WAVES
-#define MTB_JOIN_WAVES 5              /* waves per SIMD the short-read instantiation on packed words is compiled for: 6 (80 registers) spills 16 of them since the search and overflow rework and measured 91.8 ms against 87.6 (profiles/r04_notes.md) */
+#define MTB_JOIN_WAVES 6              /* waves per SIMD the short-read instantiation on packed words is compiled for.  Round 5, in-process A/B on the heavy-tailed workload
+                                       * (profiles/r05_notes.md): two queries per thread at 5 waves 86.3 ms, at 6 waves (80 registers: 16 spilled) 91.7, ONE query per thread
+                                       * at 6 waves (no spill) 80.6, at 5 waves 88.7 -- occupancy beats the second query's instruction-level parallelism */
+#endif
+#ifndef MTB_JOIN_DIR_QPT0
+#define MTB_JOIN_DIR_QPT0 1           /* queries per thread of the short-read instantiation on packed words (the other modes keep MTB_JOIN_DIR_QPT) */
 #endif
 #ifndef MTB_JOIN_EXACT_MIN
 #define MTB_JOIN_EXACT_MIN 8          /* diagnostics (k_join_run_hist): runs beyond this length count as long when a query finds its own DNA part in them */
@@ -206,7 +211,7 @@ __device__ __forceinline__ uint32_t wave_min_shfl_u32(uint32_t v) {
 /* QPT = queries per thread, WAVES = waves per SIMD the register allocation aims at: template parameters so that the A/B variants of the
  * short-read instantiation live in ONE library and are compared inside one process, on one index, one allocation (MTB_JOIN_VARIANT=q<Q>w<W>
  * in the environment, read per batch; between processes the placement of a 27 GB slot buffer alone moved the join by 10 %) */
-template <bool PACKED, int MODE = 0, int QPT = MTB_JOIN_DIR_QPT, int WAVES = MTB_JOIN_WAVES>
+template <bool PACKED, int MODE = 0, int QPT = ((PACKED && MODE == 0) ? MTB_JOIN_DIR_QPT0 : MTB_JOIN_DIR_QPT), int WAVES = MTB_JOIN_WAVES>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && MODE == 0) ? WAVES : 5))) void k_join_dir(const mtb_kmer *__restrict__ q, uint64_t n, mtb_index_view ix, uint64_t limit, mtb_dir_view dv,
                                                    const mtb_tables *__restrict__ tabs, JoinSegArgs sa, uint32_t *__restrict__ overflow) {
     constexpr int Q = QPT;

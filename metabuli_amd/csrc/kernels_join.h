@@ -282,6 +282,7 @@ __global__ __launch_bounds__(256) void k_big_ovf(const mtb_match *__restrict__ o
     } else if (i >= n_ovf) return;
     mtb_match m = ovf[i];
     uint32_t b = bigidx[mtb_q_seq(m.qinfo) - 1];
+    if (b == 0xFFFFFFFFu) return;         /* a read that is not on the list (scored by k_score_many from the grouped overflow entries): bigidx[] is set to ~0 before k_big_count */
     uint32_t slot = atomicAdd(&bigcur[b], 1u);
     big[big_start[b] + slot] = m;
 }

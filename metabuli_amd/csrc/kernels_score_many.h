@@ -29,6 +29,7 @@
 #include "kernels_join.h"
 #include "kernels_score.h"
 
+#define MTB_MANY_CLAIM 16u               /* listed reads a wave claims per atomic on the work counter */
 #define MTB_MANY_HASH 1024u              /* species table entries (8 bytes each); a read with more than 3/4 of that many species is handed on */
 
 /* overflow entries per read: what the join pushed beyond the read's tail (cursor counts every match after the query's first one).
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(64, (CAP > 192 ? 2 : 3)) void k_score_many(const mt
                                                        const uint64_t *__restrict__ tc_off, mtb_result *__restrict__ results, int32_t *__restrict__ tc_tax,
                                                        uint32_t *__restrict__ tc_cnt, uint64_t tc_cap, uint64_t tc_base,
                                                        uint32_t *__restrict__ rest_list, uint32_t *__restrict__ n_rest, uint32_t *__restrict__ cnt_out,
-                                                       unsigned long long *__restrict__ work, unsigned long long *__restrict__ stats /* [0] matches seen, [1] survivors (diagnostics) */) {
+                                                       unsigned long long *__restrict__ work, unsigned long long *__restrict__ stats /* [0] matches seen, [1] survivors; reads handed on: [2] routed off / too many buckets / inconsistent counts, [3] species table full, [4] survivors beyond the staging */) {
     __shared__ __attribute__((aligned(16))) uint8_t s_ws[MTB_SCORE_WS_BYTES_(CAP)];
     static_assert(MTB_SCORE_WS_BYTES_(CAP) - CAP * sizeof(mtb_match) >= MTB_MANY_HASH * 8, "the species table fits behind the match records");
     static_assert(CAP * sizeof(mtb_path) >= MTB_SCORE_BKT * 13 + (MTB_LR_MAXE + MTB_LR_MAXE * MTB_LR_K) * 4, "decide arrays must fit the path area");
@@ -79,9 +80,11 @@ __global__ __launch_bounds__(64, (CAP > 192 ? 2 : 3)) void k_score_many(const mt
     MTB_BEGIN_ACQUIRE();
     const uint64_t n_iter = (uint64_t)*n_list;
     unsigned long long seen = 0, kept = 0;
-    /* reads differ a lot (a few dozen to a thousand records): claimed one by one */
-    for (uint64_t it = (uint64_t)__shfl(lane == 0 ? atomicAdd(work, 1ull) : 0ull, 0, 64); it < n_iter;
-         it = (uint64_t)__shfl(lane == 0 ? atomicAdd(work, 1ull) : 0ull, 0, 64)) {
+    /* reads differ a lot (a few dozen to a thousand records): claimed from a counter, MTB_MANY_CLAIM list entries per atomic -- one
+     * returning atomic per read on ONE address was ~19 ns each once 3000 waves hammer it: 15 of the kernel's 30 ms for 0.8 M reads */
+    for (uint64_t c0 = (uint64_t)__shfl(lane == 0 ? atomicAdd(work, (unsigned long long)MTB_MANY_CLAIM) : 0ull, 0, 64); c0 < n_iter;
+         c0 = (uint64_t)__shfl(lane == 0 ? atomicAdd(work, (unsigned long long)MTB_MANY_CLAIM) : 0ull, 0, 64))
+    for (uint64_t it = c0; it < c0 + MTB_MANY_CLAIM && it < n_iter; it++) {
         const uint64_t r = (uint64_t)list[it];
         const int32_t ql1 = qlen[r], ql2 = qlen2[r];
         const int32_t read_len = ql1 + ql2;
@@ -91,6 +94,7 @@ __global__ __launch_bounds__(64, (CAP > 192 ? 2 : 3)) void k_score_many(const mt
         uint64_t o0 = 0; uint32_t n_ov = 0;
         if (ovf_start) { o0 = ovf_start[r]; n_ov = (uint32_t)(ovf_start[r + 1] - o0); }
         bool hand_on = (off_reads && off_reads[r]) || nb > MTB_SCORE_BKT || cur - tail_n != n_ov;
+        uint32_t why = 2;
         const mtb_slot16 *slots = slots_all + r * (uint64_t)stride;
         mtb_sws<uint16_t> w;
         mtb_sws_carve<uint16_t>(&w, s_ws, CAP);
@@ -133,6 +137,7 @@ __global__ __launch_bounds__(64, (CAP > 192 ? 2 : 3)) void k_score_many(const mt
             for (uint32_t q = lane; q < MTB_MANY_HASH; q += 64) used += h_key[q] != 0xFFFFFFFFu ? 1u : 0u;
             for (int d = 32; d > 0; d >>= 1) used += (uint32_t)__shfl_xor((int)used, d, 64);
             hand_on = __any(full) || used > MTB_MANY_HASH / 4u * 3u;
+            why = 3;
             if (!hand_on) {
                 auto alive = [&](uint32_t s) -> bool {
                     uint32_t h = (s * 0x9E3779B1u) >> 22;
@@ -170,10 +175,11 @@ __global__ __launch_bounds__(64, (CAP > 192 ? 2 : 3)) void k_score_many(const mt
                     n += (uint32_t)__popcll(mask);
                 }
                 hand_on = n > (uint32_t)CAP;
+                why = 4;
                 score_sync<uint16_t>();                  /* the table is dead from here on: the workspace behind the records is the scorer's */
             }
         }
-        if (hand_on) { if (lane == 0) rest_list[atomicAdd(n_rest, 1u)] = (uint32_t)r; continue; }
+        if (hand_on) { if (lane == 0) { rest_list[atomicAdd(n_rest, 1u)] = (uint32_t)r; if (stats) atomicAdd(&stats[why], 1ull); } continue; }
         seen += n_all; kept += n;
         mtb_result R;
         R.classification = 0; R.score = 0.0f; R.query_length = ql1; R.query_length2 = ql2;

@@ -743,7 +743,7 @@ static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint6
             case 0x16: MTB_LAUNCH_JV(1, 6); break;
             case 0x26: MTB_LAUNCH_JV(2, 6); break;
             case 0x25: MTB_LAUNCH_JV(2, 5); break;
-            default: MTB_LAUNCH_JV(MTB_JOIN_DIR_QPT, MTB_JOIN_WAVES); break;
+            default: MTB_LAUNCH_JV(MTB_JOIN_DIR_QPT0, MTB_JOIN_WAVES); break;
             }
 #undef MTB_LAUNCH_JV
         }
@@ -1993,27 +1993,32 @@ static mtb_status score_fixed_slots(mtb_ctx *c, mtb_index *ix, const mtb_params 
                 else hipLaunchKernelGGL(k_ovf_group, dim3((uint32_t)((n_ovf + 255) / 256)), dim3(256), 0, st, (const mtb_match *)d_ovf, n_ovf,
                                         (const uint64_t *)d_ostart, (const uint32_t *)d_novf, d_ocur, d_ovfg, (uint64_t)0, (const unsigned long long *)nullptr);
             }
-            HIPCHK(hipMemsetAsync(c->d_xscal + 2, 0, 8 * 4, st));       /* [2] reads handed on, [3] work counter, [4] matches seen, [5] survivors */
+            unsigned long long *d_ms;                                  /* [0] reads handed on, [1] work counter, [2] matches seen, [3] survivors, [4..6] hand-over reasons */
+            STCHK(ensure(c, "manystat", 16, &d_ms));
+            HIPCHK(hipMemsetAsync(d_ms, 0, 16 * 8, st));
             const uint32_t gridm = std::min<uint32_t>(n_big, 256u * (stride <= 192u ? 12u : 7u));
 #define MTB_LAUNCH_MANY(K64, CAPV) hipLaunchKernelGGL((k_score_many<K64, CAPV>), dim3(gridm), dim3(64), 0, st, (const mtb_slot16 *)d_segm, stride, direct, epoch, (const uint32_t *)d_rc, d_off_reads, \
             (const mtb_match *)d_ovfg, (const uint64_t *)d_ostart, (const uint32_t *)d_biglist, (const uint32_t *)(c->d_scal + 5), SL.d_qlen, SL.d_qlen2, tax_view(ix), SL.sp, SL.d_tcoff, SL.d_res, \
-            SL.d_tc_tax, SL.d_tc_cnt, SL.tc_cap, SL.tc_base, d_rest, (uint32_t *)(c->d_xscal + 2), d_cnt, (unsigned long long *)(c->d_xscal + 3), (unsigned long long *)(c->d_xscal + 4))
+            SL.d_tc_tax, SL.d_tc_cnt, SL.tc_cap, SL.tc_base, d_rest, (uint32_t *)d_ms, d_cnt, d_ms + 1, d_ms + 2)
             if (stride <= 192u) { if (SL.key64) MTB_LAUNCH_MANY(true, 192); else MTB_LAUNCH_MANY(false, 192); }
             else { if (SL.key64) MTB_LAUNCH_MANY(true, 320); else MTB_LAUNCH_MANY(false, 320); }
 #undef MTB_LAUNCH_MANY
             HIPCHK(hipGetLastError());
-            uint64_t ms4[4] = {0, 0, 0, 0};
-            STCHK(d2h(c, ms4, c->d_xscal + 2, 32));
+            uint64_t ms4[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            STCHK(d2h(c, ms4, d_ms, 64));
             const uint32_t n_rest = (uint32_t)(ms4[0] & 0xFFFFFFFFull);
             c->many_stats[1] = n_big - n_rest; c->many_stats[2] = ms4[2]; c->many_stats[3] = ms4[3];
+            if (getenv("MTB_MANY_VERBOSE")) fprintf(stderr, "mtb: k_score_many: %u reads listed, %u handed on (routed off / buckets / counts %llu, species table full %llu, survivors beyond the staging %llu); %llu matches, %llu survive the dead-species drop\n",
+                                                    n_big, n_rest, (unsigned long long)ms4[4], (unsigned long long)ms4[5], (unsigned long long)ms4[6], (unsigned long long)ms4[2], (unsigned long long)ms4[3]);
             n_big = n_rest;
             *go = n_big != 0;
             if (!n_big) return MTB_OK;
             /* what is left goes the old way: the list of those reads, its length where the launches below read it */
             d_biglist = d_rest;
-            HIPCHK(hipMemcpyAsync(c->d_scal + 5, c->d_xscal + 2, 8, hipMemcpyDeviceToDevice, st));
+            HIPCHK(hipMemcpyAsync(c->d_scal + 5, d_ms, 8, hipMemcpyDeviceToDevice, st));
         }
         KTimer kt(c, MTB_K_SEGSORT);
+        HIPCHK(hipMemsetAsync(d_bigidx, 0xFF, n_reads * 4, st));        /* reads that are not listed (k_score_many took them) own entries of the overflow list too: k_big_ovf skips them */
         STCHK(ensure(c, "bigcnt", n_big, &d_bigcnt)); STCHK(ensure(c, "bigstart", (uint64_t)n_big + 1, &d_bigstart)); STCHK(ensure(c, "bigcur", n_big, &d_bigcur));
         hipLaunchKernelGGL(k_big_count, dim3(std::min<uint32_t>(n_big, 4096)), dim3(64), 0, st, (const mtb_slot16 *)d_segm, stride, direct, epoch,
                            (const uint32_t *)d_rc, (const uint32_t *)d_biglist, n_big, d_bigcnt, d_bigidx, (uint32_t *)(c->d_scal + 3), d_off_reads);

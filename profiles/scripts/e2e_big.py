@@ -2,6 +2,8 @@
 # on-disk format with the device-side coder (mtb_index_write) to /dev/shm (the page cache of the box: local disk would be the same bytes
 # through the same cache), then run the stand-alone driver (open = chunked decode + pack on load, then classify N reads from a FASTQ file).
 # usage: python profiles/scripts/e2e_big.py [targets] [n_reads] [threads] [max_reads per host batch, comma list]
+# environment: E2E_WORLD=heavy (2400 genomes, conserved segments, shared-run extras: the bench's heavy-tailed index), E2E_VARIANTS="|--async-results 1" (driver flag sets),
+#              E2E_REPS (runs per setting, default 2)
 import os, shutil, subprocess, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
@@ -21,9 +23,16 @@ work = os.path.join(base, "mtb_e2e_big")
 print(f"working directory {work} ({shutil.disk_usage(base).free / 2**30:.0f} GiB free; {need / 2**30:.0f} GiB needed)", flush=True)
 shutil.rmtree(work, ignore_errors=True)
 db = os.path.join(work, "db"); os.makedirs(os.path.join(db, "taxonomy"))
-world = bench.build_world(1234, 8, 500000, 5000)
-world.tax.write(os.path.join(db, "taxonomy"))
-rv, rt, _ = bench.extract_targets(ctx, M, world, params)
+HEAVY = os.environ.get("E2E_WORLD", "") == "heavy"      # the bench's default world: 2400 genomes with conserved segments + shared-run extras (heavy-tailed candidate runs)
+if HEAVY:
+    world = bench.build_world_fast(torch, dev, 1234, 2400, 1_000_000, 130_000, conserved=True)
+    world.tax.write(os.path.join(db, "taxonomy"))
+    rv, rt, n_extras = bench.extract_targets(ctx, M, world, params, torch, dev, hot_min=8, seed=1234)
+    print(f"heavy-tailed world: {len(world.genomes)} genomes, {len(rv) - n_extras} genome-derived targets + {n_extras} shared-run extras", flush=True)
+else:
+    world = bench.build_world(1234, 8, 500000, 5000)
+    world.tax.write(os.path.join(db, "taxonomy"))
+    rv, rt, _ = bench.extract_targets(ctx, M, world, params)
 NF = T_WANT - len(rv)
 dv = torch.empty(T_WANT, dtype=torch.int64, device=dev); di = torch.empty(T_WANT, dtype=torch.int32, device=dev)
 t0 = time.perf_counter()
@@ -53,7 +62,7 @@ exe = os.path.join(os.path.dirname(M.LIB_PATH), "mtb_classify")
 ref_sum = None
 for mr in MR:
   for extra in EXTRA:
-    for rep in range(2):
+    for rep in range(int(os.environ.get("E2E_REPS", "2"))):
         for fn in os.listdir(out):              # every run writes into an empty directory (truncating the previous run's GBs of rows costs tenths of a second)
             os.remove(os.path.join(out, fn))
         t0 = time.perf_counter()

@@ -298,6 +298,12 @@ mtb_status mtb_classify_batch_packed_async(mtb_ctx *c, mtb_index *ix, const mtb_
     memset(results, 0xEE, n * sizeof(mtb_result)); if (cap) { memset(tt, 0xEE, cap * 4); memset(tc, 0xEE, cap * 4); }
     return MTB_OK;
 }
+mtb_status mtb_ctx_prefetch_stats(mtb_ctx *c, uint64_t *issued, uint64_t *used) {
+    if (!c) return fail(MTB_ERR_ARG, "NULL argument");
+    if (issued) *issued = g_prefetch_calls.load();
+    if (used) *used = g_prefetched.load();
+    return MTB_OK;
+}
 mtb_status mtb_ctx_wait_results(mtb_ctx *c) { if (!c) return fail(MTB_ERR_ARG, "NULL argument"); c->deliver(); return MTB_OK; }
 
 /* one process, several engines, every engine owning a value range: here simply the text entry point on the first engine */

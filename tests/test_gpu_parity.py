@@ -1210,7 +1210,8 @@ def test_register_resident_scorer_variants(ctx, orc, tmp_path, paired, length):
 def test_no_kernel_relies_on_zeroed_device_memory(orc, tmp_path):
     """hipMalloc happens to hand out cleared VRAM; nothing may depend on it.  libmtb_xpoison.so (-DMTB_POISON_ALLOC) fills every new
     workspace buffer with 0xA5 on the library's stream before its first use; a single-end and a paired toy batch through the fused
-    path (slot segments, register-resident and generic scorer, taxID:count lists) must still equal the oracle."""
+    path (slot segments, register-resident and generic scorer, taxID:count lists) must still equal the oracle -- 34 times in a row after
+    an mtb_ctx_reserve that created the slot buffer (the epoch tags of stale slots: see the comment in the child's code)."""
     import subprocess
     import sys
     import metabuli_amd as M
@@ -1233,7 +1234,12 @@ r = np.load({inp!r}); e = np.load({exp!r})
 c = M.Context(0)
 p = M.default_params(seq_mode={int(t.p.seq_mode)}, syncmer=1)
 ix = c.open_index({t.dbdir!r}, p)
-for _ in range(2):
+# ADVICE r4 (high): a slot buffer created by mtb_ctx_reserve was never cleared -- the first batch found "its" pointer and size, skipped the
+# memset and ran epoch 1 on whatever the allocation held; with 0xA5 in every byte the stale slots' epoch field reads 20, so batch 20 saw
+# every unwritten slot alive.  Reserve first, then more than 20 batches (the tag wraps at 31: 34 batches cross that too).
+n_reads = len(r["o1"]) - 1
+c.reserve(p, n_reads, int(r["o1"][-1]) * (2 if "b2" in r else 1))
+for _ in range(34):
     res, tt, tc = c.classify_batch(ix, p, r["b1"], r["o1"], r["b2"] if "b2" in r else None, r["o2"] if "o2" in r else None)
     amb = e["flag"] != 0
     assert ((res["classification"] == e["cls"]) | amb).all()
