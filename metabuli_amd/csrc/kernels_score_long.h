@@ -36,6 +36,7 @@
 #define MTB_LONG_MAXP 1024          /* emitted paths of a read                        */
 #define MTB_LONG_MAXBLK 1024        /* (species, frame) blocks with >= 2 matches       */
 #define MTB_LONG_MAXSP 256          /* species with paths                             */
+#define MTB_LONG_TINY 8             /* blocks of up to this many matches (single-match position groups) are walked by one lane each */
 #define MTB_LONG_MAXBKT 4096        /* position buckets of the redundancy filter (reads up to ~36 kb with syncmers) */
 
 struct mtb_lpath { int32_t start, end; float score; int32_t ham; uint32_t rehs; /* start reh | end reh << 16 */ int32_t species; uint32_t eidx; uint32_t spare; };
@@ -62,6 +63,10 @@ __device__ __forceinline__ bool lpath_before(const mtb_lpath &a, const mtb_lpath
     return a.eidx < b.eidx;
 }
 
+/* MAXBLK / MAXSP: LDS budgets for the (species, frame) blocks of two or more matches and for the species with paths.  Long reads run the
+ * defaults; the short reads of conserved genes whose organism is NOT in the index (thousands of matches over a thousand species, a few
+ * of them with paths: kernels_score_many.h, k_many_sort) run <4096, 1024>. */
+template <int MAXBLK = MTB_LONG_MAXBLK, int MAXSP = MTB_LONG_MAXSP>
 __global__ __launch_bounds__(MTB_LONG_NT) void k_score_long(const mtb_match *__restrict__ matches, const uint64_t *__restrict__ seg_start, uint64_t n_reads,
                                                              const int32_t *__restrict__ qlen, const int32_t *__restrict__ qlen2, mtb_tax_view tx, mtb_score_params sp,
                                                              const uint64_t *__restrict__ tc_off, mtb_result *__restrict__ results, int32_t *__restrict__ tc_tax,
@@ -70,16 +75,16 @@ __global__ __launch_bounds__(MTB_LONG_NT) void k_score_long(const mtb_match *__r
                                                              const uint32_t *__restrict__ list = nullptr, uint32_t n_list = 0) {
     __shared__ __attribute__((aligned(16))) mtb_lpath s_path[MTB_LONG_MAXP];
     __shared__ uint16_t s_sidx[MTB_LONG_MAXP], s_acc[MTB_LONG_MAXP];
-    __shared__ uint32_t s_blk[MTB_LONG_MAXBLK];
+    __shared__ uint32_t s_blk[MAXBLK];
     __shared__ int32_t s_carry[MTB_LONG_NW][64][5];
-    __shared__ uint16_t s_splo[MTB_LONG_MAXSP + 1];
-    __shared__ int32_t s_spid[MTB_LONG_MAXSP];
-    __shared__ float s_spsc[MTB_LONG_MAXSP];
+    __shared__ uint16_t s_splo[MAXSP + 1];
+    __shared__ int32_t s_spid[MAXSP];
+    __shared__ float s_spsc[MAXSP];
     __shared__ int32_t s_otax[MTB_LR_MAXE]; __shared__ uint32_t s_ocnt[MTB_LR_MAXE];
     __shared__ int32_t s_lev[MTB_LR_MAXE], s_anc[MTB_LR_MAXE * MTB_LR_K];
     __shared__ uint32_t s_red[MTB_LONG_NW];
     __shared__ unsigned long long s_r;
-    __shared__ uint32_t s_nblk, s_next, s_npath, s_fail, s_nsp;
+    __shared__ uint32_t s_nblk, s_next, s_npath, s_fail, s_nsp, s_nbig;
     __shared__ int32_t s_go, s_species;
     __shared__ mtb_result s_R;
     const int32_t tid = (int32_t)threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -90,7 +95,7 @@ __global__ __launch_bounds__(MTB_LONG_NT) void k_score_long(const mtb_match *__r
 
     for (;;) {
         __syncthreads();
-        if (tid == 0) { s_r = atomicAdd(work, 1ull); s_nblk = 0; s_next = 0; s_npath = 0; s_fail = 0; s_nsp = 0; s_go = 0; }
+        if (tid == 0) { s_r = atomicAdd(work, 1ull); s_nblk = 0; s_next = 0; s_npath = 0; s_fail = 0; s_nsp = 0; s_go = 0; s_nbig = 0; }
         __syncthreads();
         const uint64_t it = s_r;
         if (it >= (list ? (uint64_t)n_list : n_reads)) break;
@@ -129,23 +134,82 @@ __global__ __launch_bounds__(MTB_LONG_NT) void k_score_long(const mtb_match *__r
                 uint32_t at0 = 0;
                 if (lane == 0) at0 = atomicAdd(&s_nblk, (uint32_t)__popcll(cm));
                 at0 = (uint32_t)__shfl((int)at0, 0, 64);
-                if (cand) { const uint32_t at = at0 + (uint32_t)__popcll(cm & lt); if (at < MTB_LONG_MAXBLK) s_blk[at] = (uint32_t)i; }
+                if (cand) { const uint32_t at = at0 + (uint32_t)__popcll(cm & lt); if (at < (uint32_t)MAXBLK) s_blk[at] = (uint32_t)i; }
             }
         }
         __syncthreads();
-        if (tid == 0 && s_nblk > MTB_LONG_MAXBLK) s_fail = 1;
+        if (tid == 0 && s_nblk > (uint32_t)MAXBLK) s_fail = 1;
         __syncthreads();
         const uint32_t nblk = s_nblk;
         if (s_fail) { if (tid == 0) todo[r] = 1; continue; }
         if (nblk == 0) { if (tid == 0) results[r] = s_R; continue; }
 
         MTB_LP_MARK(1);
+        /* ---- walk, tiny blocks first: ONE LANE per block of at most MTB_LONG_TINY matches whose position groups are single matches.  A
+         * short read of a conserved gene of an organism that is not in the index brings a thousand blocks of two or three matches (one
+         * per species and frame); a wave step per block -- one dependent HBM round trip each -- was the kernel's time on such reads
+         * (32 ms per 163 k of them).  The recurrence is the window's (a match links to the one before it or opens a chain; the block's
+         * matches are walked in order, so the sums are the same sums).  Blocks that are longer or hold a wider group are compacted to
+         * the front of the list for the wave walk below. ---- */
+        for (uint32_t b0 = 0; b0 < nblk; b0 += MTB_LONG_NT) {
+            const uint32_t b = b0 + (uint32_t)tid;
+            uint32_t bstart = 0;
+            if (b < nblk) bstart = s_blk[b];
+            __syncthreads();                                 /* every entry of this step is read: the compaction may overwrite them */
+            if (b < nblk) {
+                const mtb_match x0 = m[bstart];
+                const int32_t species = x0.species_id;
+                const uint32_t frame = mtb_q_frame(x0.qinfo);
+                uint32_t len = 1, ppos = mtb_q_pos(x0.qinfo);
+                bool tiny = true;
+                for (;;) {
+                    const uint32_t idx = bstart + len;
+                    if (idx >= (uint32_t)n) break;
+                    const int32_t xs = m[idx].species_id; const uint64_t xq = m[idx].qinfo;
+                    if (xs != species || mtb_q_frame(xq) != frame) break;
+                    const uint32_t xp = mtb_q_pos(xq);
+                    if (xp == ppos || len == MTB_LONG_TINY) { tiny = false; break; }
+                    ppos = xp; len++;
+                }
+                if (!tiny) s_blk[atomicAdd(&s_nbig, 1u)] = bstart;
+                else {
+                    const bool fwd = frame < 3u;
+                    const int32_t md = (species >= 0 && species <= tx.max_taxid && tx.under_euk[species]) ? sp.min_cons_cnt_euk : sp.min_cons_cnt;
+                    int32_t p_start = 0, p_ham = 0, p_depth = 0; float p_score = 0.0f; uint32_t p_sreh = 0;
+                    uint32_t q_pos = 0, q_dna = 0, q_reh = 0;
+                    auto out_path = [&](uint32_t idx, uint32_t pos, uint32_t reh) {
+                        const uint32_t at = atomicAdd(&s_npath, 1u);
+                        if (at < MTB_LONG_MAXP) {
+                            mtb_lpath P; P.start = p_start; P.end = (int32_t)pos + 23; P.score = p_score; P.ham = p_ham; P.rehs = (p_sreh & 0xFFFFu) | (reh << 16);
+                            P.species = species; P.eidx = idx; P.spare = 0;
+                            s_path[at] = P;
+                        } else s_fail = 1;
+                    };
+                    for (uint32_t j = 0; j < len; j++) {
+                        const mtb_match x = m[bstart + j];
+                        const uint32_t pos = mtb_q_pos(x.qinfo), dna = x.dna, reh = x.right_end_hamming;
+                        bool linked = false; int32_t sh = 0;
+                        if (j) {
+                            const int32_t s_ = (int32_t)(pos - q_pos) / 3;
+                            if (s_ > 0 && s_ <= sp.max_codon_shift && mtb_consecutive(q_dna, dna, s_, fwd, sp.kmer_format)) { linked = true; sh = s_; }
+                            if (!linked && p_depth >= md) out_path(bstart + j - 1, q_pos, q_reh);        /* the previous match is not connected to this one: its path ends */
+                        }
+                        if (linked) { p_score += mtb_part_score(reh, sh, false); p_ham += mtb_part_ham(reh, sh, false); p_depth += sh; }
+                        else { p_start = (int32_t)pos; p_score = mtb_part_score(reh, 8, false); p_ham = (int32_t)x.hamming; p_depth = 1; p_sreh = reh; }
+                        q_pos = pos; q_dna = dna; q_reh = reh;
+                    }
+                    if (p_depth >= md) out_path(bstart + len - 1, q_pos, q_reh);                        /* the block's last match: nothing follows it */
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t nbig = s_nbig;
         /* ---- walk: one wave per block ---- */
         for (;;) {
             uint32_t b = 0;
             if (lane == 0) b = atomicAdd(&s_next, 1u);
             b = (uint32_t)__shfl((int)b, 0, 64);
-            if (b >= nblk || s_fail) break;
+            if (b >= nbig || s_fail) break;
             const uint32_t bstart = s_blk[b];
             const int32_t species = m[bstart].species_id;
             const uint32_t frame = mtb_q_frame(m[bstart].qinfo);
@@ -306,9 +370,9 @@ __global__ __launch_bounds__(MTB_LONG_NT) void k_score_long(const mtb_match *__r
             uint32_t before = s_nsp, tot = 0;
 #pragma unroll
             for (int q = 0; q < MTB_LONG_NW; q++) { const uint32_t c = s_red[q]; if (q < wv) before += c; tot += c; }
-            if (head) { const uint32_t at = before + (uint32_t)__popcll(hm & lt); if (at < MTB_LONG_MAXSP) { s_splo[at] = (uint16_t)k; s_spid[at] = spc; } }
+            if (head) { const uint32_t at = before + (uint32_t)__popcll(hm & lt); if (at < (uint32_t)MAXSP) { s_splo[at] = (uint16_t)k; s_spid[at] = spc; } }
             __syncthreads();
-            if (tid == 0) { s_nsp += tot; if (s_nsp > MTB_LONG_MAXSP) s_fail = 1; }
+            if (tid == 0) { s_nsp += tot; if (s_nsp > (uint32_t)MAXSP) s_fail = 1; }
         }
         __syncthreads();
         if (s_fail) { if (tid == 0) todo[r] = 1; continue; }

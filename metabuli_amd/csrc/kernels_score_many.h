@@ -28,6 +28,8 @@
 #include "mtb_core.h"
 #include "kernels_join.h"
 #include "kernels_score.h"
+#include "kernels_score_long.h"
+#include "kernels_seg_order.h"
 
 #define MTB_MANY_CLAIM 16u               /* listed reads a wave claims per atomic on the work counter */
 #define MTB_MANY_HASH 1024u              /* species table entries (8 bytes each); a read with more than 3/4 of that many species is handed on */
@@ -57,6 +59,131 @@ __global__ __launch_bounds__(256) void k_ovf_group(const mtb_match *__restrict__
     if (!cap) return;                                     /* a read routed around its slots */
     const uint32_t at = atomicAdd(&ocur[r], 1u);
     if (at < cap) out[start[r] + at] = m;
+}
+
+/* ---- the reads beyond k_score_many's staging: a read of a conserved gene whose organism is NOT in the index has no equal target in its
+ * candidate runs, every query of it selects by hamming distance, and the read brings THOUSANDS of matches over a thousand species, most of
+ * them with two matches in some frame (the dead-species drop barely helps).  Until round 5 such reads were copied to exact segments and
+ * sorted by an HBM-resident bitonic network, then scored out of HBM slabs: 72 + 41 ms per 2 M reads of held-out organisms (163 k such
+ * reads).  k_many_sort, one workgroup per listed read, from the same two sources as k_score_many (slots + grouped overflow entries):
+ *   pass 1   species table in LDS (4096 entries), frame bits as above;
+ *   pass 2   the survivors' source indices -> a list (one LDS atomic per wave step);
+ *   pass 3   their 64-bit compareMatches keys (species, frame, position, hamming, dna: host-checked to fit) into the table's storage,
+ *            bitonic sort of (key, source index) in LDS;
+ *   pass 4   the records in order -> the read's exact segment in HBM (24-byte Match records), seg_cnt = survivors.
+ * k_score_long<4096, 1024> (kernels_score_long.h: a workgroup per read streaming its sorted segment) scores them.  Reads beyond the
+ * budgets here or there are flagged in `todo` and take the exact-segment path. */
+#define MTB_MSORT_NT 256
+#define MTB_MSORT_HASH 4096u
+#define MTB_MSORT_MAX 4096u              /* survivors sorted in LDS */
+__global__ __launch_bounds__(MTB_MSORT_NT) void k_many_sort(const mtb_slot16 *__restrict__ slots_all, uint32_t stride, uint32_t direct, uint32_t epoch,
+                                                             const uint32_t *__restrict__ cursor, const uint8_t *__restrict__ off_reads,
+                                                             const mtb_match *__restrict__ ovfg, const uint64_t *__restrict__ ovf_start,
+                                                             const uint32_t *__restrict__ list, uint32_t n_list, const int32_t *__restrict__ qlen, const int32_t *__restrict__ qlen2,
+                                                             int32_t dna_shift, const uint64_t *__restrict__ big_start, mtb_match *__restrict__ big, uint32_t *__restrict__ seg_cnt,
+                                                             uint8_t *__restrict__ todo) {
+    __shared__ __attribute__((aligned(16))) uint64_t s_u[MTB_MSORT_HASH];          /* the species table (keys | values), then the sort keys */
+    __shared__ uint16_t s_idx[MTB_MSORT_MAX];
+    __shared__ uint32_t s_n, s_full;
+    static_assert(MTB_MSORT_MAX * 8 <= MTB_MSORT_HASH * 8, "the sort keys live in the table's storage");
+    uint32_t *const h_key = (uint32_t *)s_u, *const h_val = h_key + MTB_MSORT_HASH;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint64_t lt = lanemask_lt();
+    const uint32_t tail_cap = stride - direct;
+    for (uint32_t b = blockIdx.x; b < n_list; b += gridDim.x) {
+        const uint64_t r = (uint64_t)list[b];
+        const uint32_t cur = cursor[r], tail_n = cur < tail_cap ? cur : tail_cap;
+        uint64_t o0 = 0; uint32_t n_ov = 0;
+        if (ovf_start) { o0 = ovf_start[r]; n_ov = (uint32_t)(ovf_start[r + 1] - o0); }
+        const int32_t nb = mtb_num_buckets(qlen[r] + qlen2[r], dna_shift);
+        const bool skip = (off_reads && off_reads[r]) || cur - tail_n != n_ov || stride + n_ov > 65535u || nb > MTB_LONG_MAXBKT;
+        __syncthreads();                                  /* the previous read is through with the LDS arrays */
+        if (skip) { if (tid == 0) { seg_cnt[b] = 0; todo[r] = 1; } continue; }
+        for (uint32_t q = tid; q < MTB_MSORT_HASH; q += MTB_MSORT_NT) { h_key[q] = 0xFFFFFFFFu; h_val[q] = 0u; }
+        if (tid == 0) { s_n = 0; s_full = 0; }
+        __syncthreads();
+        const mtb_slot16 *slots = slots_all + r * (uint64_t)stride;
+        const uint32_t n_src = stride + n_ov;
+        /* record `i` of the read's sources: slot i, or overflow entry i - stride.  -> (live, species, frame) */
+        auto probe = [&](uint32_t i, uint32_t *sp_, uint32_t *fr_) -> bool {
+            if (i < stride) { const mtb_slot16 x = slots[i]; *sp_ = (uint32_t)(x.a >> 32); *fr_ = (uint32_t)(x.b >> 52) & 7u; return seg_slot_live(x, i, direct, tail_n, epoch); }
+            const mtb_match m = ovfg[o0 + (i - stride)]; *sp_ = (uint32_t)m.species_id; *fr_ = mtb_q_frame(m.qinfo); return true;
+        };
+        for (uint32_t i = tid; i < n_src; i += MTB_MSORT_NT) {
+            uint32_t s_, f_;
+            if (!probe(i, &s_, &f_)) continue;
+            uint32_t h = (s_ * 0x9E3779B1u) >> 20; bool done = false;
+            for (uint32_t p = 0; p < MTB_MSORT_HASH && !done; p++) {
+                const uint32_t old = atomicCAS(&h_key[h], 0xFFFFFFFFu, s_);
+                if (old == 0xFFFFFFFFu || old == s_) { const uint32_t bit = 1u << f_; if (atomicOr(&h_val[h], bit) & bit) atomicOr(&h_val[h], bit << 8); done = true; }
+                h = (h + 1u) & (MTB_MSORT_HASH - 1u);
+            }
+            if (!done) s_full = 1;
+        }
+        __syncthreads();
+        uint32_t used = 0;
+        for (uint32_t q = tid; q < MTB_MSORT_HASH; q += MTB_MSORT_NT) used += h_key[q] != 0xFFFFFFFFu ? 1u : 0u;
+        if (used) atomicAdd(&s_n, used);
+        __syncthreads();
+        const bool over = s_full || s_n > MTB_MSORT_HASH / 4u * 3u;
+        __syncthreads();
+        if (over) { if (tid == 0) { seg_cnt[b] = 0; todo[r] = 1; } continue; }
+        if (tid == 0) s_n = 0;
+        __syncthreads();
+        /* pass 2: survivors' source indices (whole wave steps: one LDS atomic per step) */
+        for (uint32_t i0 = 0; i0 < n_src; i0 += MTB_MSORT_NT) {
+            const uint32_t i = i0 + tid;
+            bool keep = false;
+            if (i < n_src) {
+                uint32_t s_, f_;
+                if (probe(i, &s_, &f_)) {
+                    uint32_t h = (s_ * 0x9E3779B1u) >> 20;
+                    for (uint32_t p = 0; p < MTB_MSORT_HASH; p++) { const uint32_t k = h_key[h]; if (k == s_) { keep = (h_val[h] >> 8) != 0u; break; } if (k == 0xFFFFFFFFu) break; h = (h + 1u) & (MTB_MSORT_HASH - 1u); }
+                }
+            }
+            const uint64_t km = __ballot(keep);
+            if (km) {
+                uint32_t at0 = 0;
+                if (lane == 0) at0 = atomicAdd(&s_n, (uint32_t)__popcll(km));
+                at0 = (uint32_t)__shfl((int)at0, 0, 64);
+                if (keep) { const uint32_t at = at0 + (uint32_t)__popcll(km & lt); if (at < MTB_MSORT_MAX) s_idx[at] = (uint16_t)i; }
+            }
+        }
+        __syncthreads();
+        const uint32_t n = s_n;
+        __syncthreads();
+        if (n > MTB_MSORT_MAX) { if (tid == 0) { seg_cnt[b] = 0; todo[r] = 1; } continue; }
+        /* pass 3: keys (the table is dead) */
+        auto fetch = [&](uint32_t i) -> mtb_match {
+            if (i < stride) return mtb_slot_unpack(slots[i], (uint32_t)r + 1);
+            mtb_match m = ovfg[o0 + (i - stride)]; m.pad = 0; return m;
+        };
+        for (uint32_t j = tid; j < n; j += MTB_MSORT_NT) {
+            const mtb_match m = fetch(s_idx[j]);
+            s_u[j] = ((uint64_t)(uint32_t)m.species_id << 41) | ((uint64_t)mtb_q_frame(m.qinfo) << 38) | ((uint64_t)(mtb_q_pos(m.qinfo) & 0x7FFu) << 27) |
+                     ((uint64_t)(m.hamming & 7u) << 24) | (m.dna & 0xFFFFFFu);
+        }
+        __syncthreads();
+        so_bitonic(s_u, s_idx, n, tid);
+        /* pass 4: the records in order */
+        mtb_match *dst = big + big_start[b];
+        for (uint32_t j = tid; j < n; j += MTB_MSORT_NT) {
+            const mtb_match m = fetch(s_idx[j]);
+            uint64_t *d = (uint64_t *)(dst + j); const uint64_t *q = (const uint64_t *)&m;
+            d[0] = q[0]; d[1] = q[1]; d[2] = q[2];
+        }
+        if (tid == 0) seg_cnt[b] = n;
+    }
+}
+/* after k_score_long over the listed reads: the flagged ones (budgets exceeded in k_many_sort or k_score_long) -> the list of the
+ * exact-segment path; the others' match counts (all records, dropped ones included) -> cnt_out (statistics) */
+__global__ __launch_bounds__(256) void k_list_flagged(const uint32_t *__restrict__ list, uint32_t n_list, const uint8_t *__restrict__ todo, const uint32_t *__restrict__ big_cnt,
+                                                       uint32_t *__restrict__ rest, uint32_t *__restrict__ n_rest, uint32_t *__restrict__ cnt_out) {
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= n_list) return;
+    const uint32_t r = list[b];
+    if (todo[r]) rest[atomicAdd(n_rest, 1u)] = r;
+    else cnt_out[r] = big_cnt[b];
 }
 
 template <bool KEY64, int CAP>

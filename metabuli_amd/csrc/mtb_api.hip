@@ -977,7 +977,7 @@ static mtb_status dev_score_long(mtb_ctx *c, mtb_index *ix, const mtb_params *p,
     HIPCHK(hipMemsetAsync(c->d_scal + 6, 0, 8, c->stream));
     {   KTimer kt(c, MTB_K_SCORE_FAST);       /* booked with the register-resident scorer's id: the workgroup-per-read kernel of long reads */
         const uint32_t grid = (uint32_t)std::min<uint64_t>(d_list ? n_list : n_reads, 256ull * 3);
-        hipLaunchKernelGGL(k_score_long, dim3(grid), dim3(MTB_LONG_NT), 0, c->stream, d_m, d_seg, n_reads, d_qlen, d_qlen2, tax_view(ix), sp, (const uint64_t *)d_tcoff,
+        hipLaunchKernelGGL((k_score_long<MTB_LONG_MAXBLK, MTB_LONG_MAXSP>), dim3(grid), dim3(MTB_LONG_NT), 0, c->stream, d_m, d_seg, n_reads, d_qlen, d_qlen2, tax_view(ix), sp, (const uint64_t *)d_tcoff,
                            d_res, d_tc_tax, d_tc_cnt, tc_cap, tc_base, d_todo, d_work, d_segcnt, d_list, n_list);
 #ifdef MTB_LONG_PHASE_CYCLES
     {   /* profiling build: cycles of thread 0 per phase of k_score_long, summed over the workgroups (and reset) */
@@ -2011,11 +2011,38 @@ static mtb_status score_fixed_slots(mtb_ctx *c, mtb_index *ix, const mtb_params 
             if (getenv("MTB_MANY_VERBOSE")) fprintf(stderr, "mtb: k_score_many: %u reads listed, %u handed on (routed off / buckets / counts %llu, species table full %llu, survivors beyond the staging %llu); %llu matches, %llu survive the dead-species drop\n",
                                                     n_big, n_rest, (unsigned long long)ms4[4], (unsigned long long)ms4[5], (unsigned long long)ms4[6], (unsigned long long)ms4[2], (unsigned long long)ms4[3]);
             n_big = n_rest;
+            const unsigned long long *d_nleft = d_ms;                   /* where the number of reads still unscored sits on the device */
+            if (n_big && SL.key64 && !getenv("MTB_NO_MANY_SORT")) {
+                /* ---- reads beyond the staging (thousands of matches: conserved genes of organisms that are not in the index): a workgroup per
+                 * read gathers, drops dead species, sorts in LDS and writes the read's exact segment; k_score_long streams it ---- */
+                uint32_t *d_bc3, *d_segcnt, *d_rest2; uint64_t *d_bs3; uint8_t *d_todo; mtb_match *d_big3;
+                STCHK(ensure(c, "bigcnt", n_big, &d_bc3)); STCHK(ensure(c, "bigstart", (uint64_t)n_big + 1, &d_bs3)); STCHK(ensure(c, "bigseg", n_big, &d_segcnt));
+                STCHK(ensure(c, "restlist2", n_reads, &d_rest2)); STCHK(ensure(c, "todoflag", n_reads, &d_todo));
+                hipLaunchKernelGGL(k_big_count, dim3(std::min<uint32_t>(n_big, 4096)), dim3(64), 0, st, (const mtb_slot16 *)d_segm, stride, direct, epoch,
+                                   (const uint32_t *)d_rc, (const uint32_t *)d_rest, n_big, d_bc3, d_bigidx, (uint32_t *)(c->d_scal + 3), d_off_reads);
+                scan_launch<uint32_t, uint64_t, false>(st, d_bc3, n_big, true, d_bs3, d_ws2);
+                uint64_t total3 = 0;
+                STCHK(d2h(c, &total3, d_bs3 + n_big, 8));
+                STCHK(ensure(c, "bigm", total3 + 1, &d_big3));
+                HIPCHK(hipMemsetAsync(d_todo, 0, n_reads, st));
+                hipLaunchKernelGGL(k_many_sort, dim3(std::min<uint32_t>(n_big, 256u * 4u)), dim3(MTB_MSORT_NT), 0, st, (const mtb_slot16 *)d_segm, stride, direct, epoch, (const uint32_t *)d_rc, d_off_reads,
+                                   (const mtb_match *)d_ovfg, (const uint64_t *)d_ostart, (const uint32_t *)d_rest, n_big, SL.d_qlen, SL.d_qlen2, SL.sp.dna_shift, (const uint64_t *)d_bs3, d_big3, d_segcnt, d_todo);
+                hipLaunchKernelGGL((k_score_long<4096, 1024>), dim3(std::min<uint32_t>(n_big, 256u * 2u)), dim3(MTB_LONG_NT), 0, st, (const mtb_match *)d_big3, (const uint64_t *)d_bs3, n_reads, SL.d_qlen, SL.d_qlen2,
+                                   tax_view(ix), SL.sp, SL.d_tcoff, SL.d_res, SL.d_tc_tax, SL.d_tc_cnt, SL.tc_cap, SL.tc_base, d_todo, d_ms + 8, (const uint32_t *)d_segcnt, (const uint32_t *)d_rest, n_big);
+                hipLaunchKernelGGL(k_list_flagged, dim3((n_big + 255) / 256), dim3(256), 0, st, (const uint32_t *)d_rest, n_big, (const uint8_t *)d_todo, (const uint32_t *)d_bc3, d_rest2, (uint32_t *)(d_ms + 9), d_cnt);
+                HIPCHK(hipGetLastError());
+                uint64_t left = 0;
+                STCHK(d2h(c, &left, d_ms + 9, 8));
+                if (getenv("MTB_MANY_VERBOSE")) fprintf(stderr, "mtb: k_many_sort + k_score_long: %u reads (%llu records), %llu left for the exact-segment path\n", n_big, (unsigned long long)total3, (unsigned long long)(left & 0xFFFFFFFFull));
+                n_big = (uint32_t)(left & 0xFFFFFFFFull);
+                d_rest = d_rest2; d_nleft = d_ms + 9;
+            }
+            c->many_stats[1] = c->many_stats[0] - n_big;
             *go = n_big != 0;
             if (!n_big) return MTB_OK;
             /* what is left goes the old way: the list of those reads, its length where the launches below read it */
             d_biglist = d_rest;
-            HIPCHK(hipMemcpyAsync(c->d_scal + 5, d_ms, 8, hipMemcpyDeviceToDevice, st));
+            HIPCHK(hipMemcpyAsync(c->d_scal + 5, d_nleft, 8, hipMemcpyDeviceToDevice, st));
         }
         KTimer kt(c, MTB_K_SEGSORT);
         HIPCHK(hipMemsetAsync(d_bigidx, 0xFF, n_reads * 4, st));        /* reads that are not listed (k_score_many took them) own entries of the overflow list too: k_big_ovf skips them */

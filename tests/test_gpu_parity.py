@@ -824,6 +824,11 @@ def test_many_matches_per_query_take_the_large_segment_path(ctx, orc, tmp_path):
     if not amb.any():
         assert (tt == ref["tc_tax"]).all() and (tc == ref["tc_cnt"]).all()
     assert (res["is_classified"] != 0).sum() > 60
+    # round 5: such reads (a thousand matches, all of species with pairs of matches) are gathered, sorted in LDS by a workgroup each and
+    # scored by the streaming kernel (k_many_sort + k_score_long<4096, 1024>), not by the HBM-resident sort any more
+    st = ctx.last_stats()
+    assert st.n_deferred_reads > 30 and st.n_many_reads > 30, (st.n_deferred_reads, st.n_many_reads)
+    assert st.n_matches == len(ref["matches"])
     ix.close()
 
 
