@@ -200,6 +200,9 @@ __global__ __launch_bounds__(256) void k_index_unpack(uint64_t *__restrict__ val
 __device__ __forceinline__ uint64_t wave_bcast64(uint64_t v, int src) {
     return ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 64) << 32) | (uint64_t)(uint32_t)__shfl((int)(uint32_t)v, src, 64);
 }
+__device__ __forceinline__ uint64_t wave_bcast_xor64(uint64_t v, int d) {
+    return ((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), d, 64) << 32) | (uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)v, d, 64);
+}
 __device__ __forceinline__ uint32_t wave_min_shfl_u32(uint32_t v) {
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64); v = o < v ? o : v; }
@@ -211,21 +214,40 @@ __device__ __forceinline__ uint32_t wave_min_shfl_u32(uint32_t v) {
 /* QPT = queries per thread, WAVES = waves per SIMD the register allocation aims at: template parameters so that the A/B variants of the
  * short-read instantiation live in ONE library and are compared inside one process, on one index, one allocation (MTB_JOIN_VARIANT=q<Q>w<W>
  * in the environment, read per batch; between processes the placement of a 27 GB slot buffer alone moved the join by 10 %) */
-template <bool PACKED, int MODE = 0, int QPT = ((PACKED && MODE == 0) ? MTB_JOIN_DIR_QPT0 : MTB_JOIN_DIR_QPT), int WAVES = MTB_JOIN_WAVES>
+/* WIN (short reads on packed words, one query per thread): the tile's TARGET WINDOW is staged in LDS.  The workgroup's `qt` sorted queries
+ * (qt <= 256, chosen by the host from the batch's density) address buckets that lie next to each other: the span from the first query's
+ * bucket to the last one's is read ONCE with coalesced 8-byte loads (all 256 threads), and every later access of the search and the
+ * evaluation -- bisection steps, run ends, candidates, the wave scan of a long run -- is an LDS read.  With 10 M reads against 16 G targets
+ * a query owns 12.5 targets of the array on average: the windows of a batch ARE the array, streamed once (128 GB at copy speed) instead of
+ * ~8 dependent sector-random round trips per query (the kernel's time was latency x occupancy).  A tile whose window exceeds the LDS
+ * capacity (sparse tiles, buckets of long candidate runs) keeps reading global memory: same code, rdv() picks the source per tile. */
+#ifndef MTB_WIN_AUX
+#define MTB_WIN_AUX 0                 /* cache policy bits of the window's direct-to-LDS loads (2 = nt: streamed once; A/B build switch) */
+#endif
+#define MTB_JOIN_WINCAP 3968          /* 8-byte words = 31 pieces of 1 KiB (one wave-wide 16-byte direct-to-LDS load each): 31 KB -> five workgroups (20 waves) per CU.
+                                       * (A window per WAVE -- 64 queries, 896 words, no workgroup barrier -- measured 81.8 ms against 73.6 for the workgroup's window
+                                       * and 80.9 for the sector-random join: a sixth of the waves fell back, profiles/r05_notes.md) */
+template <bool PACKED, int MODE = 0, int QPT = ((PACKED && MODE == 0) ? MTB_JOIN_DIR_QPT0 : MTB_JOIN_DIR_QPT), int WAVES = MTB_JOIN_WAVES, bool WIN = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && MODE == 0) ? WAVES : 5))) void k_join_dir(const mtb_kmer *__restrict__ q, uint64_t n, mtb_index_view ix, uint64_t limit, mtb_dir_view dv,
-                                                   const mtb_tables *__restrict__ tabs, JoinSegArgs sa, uint32_t *__restrict__ overflow) {
+                                                   const mtb_tables *__restrict__ tabs, JoinSegArgs sa, uint32_t *__restrict__ overflow, uint32_t qt = 256) {
     constexpr int Q = QPT;
+    static_assert(!WIN || (QPT == 1 && PACKED && MODE == 0), "the window variant: short reads, packed words, one query per thread");
+    __shared__ __attribute__((aligned(16))) uint64_t s_win[WIN ? MTB_JOIN_WINCAP : 2];
+    __shared__ unsigned long long s_w0, s_w1;
+    uint64_t w0 = 0; bool use_win = false;
+    auto rdv = [&](uint64_t t) -> uint64_t { return (WIN && use_win) ? s_win[t - w0] : ix.values[t]; };
     constexpr bool LONG = MODE == 1, LIST = MODE == 2;
     const uint64_t AAM = ~0xFFFFFFull;
     __shared__ uint32_t s_hr[8];                    /* hammingLookup rows as nibble words: the only table the join arithmetic reads */
     if (threadIdx.x < 8) s_hr[threadIdx.x] = tabs->hamrow[threadIdx.x];
-    const uint64_t base_q = (uint64_t)blockIdx.x * (256 * Q);
+    const uint64_t base_q = WIN ? (uint64_t)blockIdx.x * qt : (uint64_t)blockIdx.x * (256 * Q);
+    if (WIN && threadIdx.x == 0) { s_w0 = ~0ull; s_w1 = 0ull; }
     MTB_JP_BEGIN();                                  /* profiling build only: cycles of thread 0 per phase (mtb_join_cycles: 0 queries + directory, 1 bisection, 2 run ends, 3 wave-scanned runs, 4 per-lane evaluation + emission) */
     mtb_kmer k[Q]; bool valid[Q]; uint64_t lo[Q], hi[Q];
 #pragma unroll
     for (int u = 0; u < Q; u++) {
         const uint64_t j = base_q + (uint64_t)u * 256 + threadIdx.x;
-        valid[u] = j < n;
+        valid[u] = j < n && (!WIN || threadIdx.x < qt);
         k[u].value = 0; k[u].qinfo = 0;
         if (valid[u]) { k[u] = q[j]; valid[u] = mtb_q_seq(k[u].qinfo) != 0; }        /* blank slots carry sequenceID 0 */
     }
@@ -243,6 +265,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
         }
     }
     __syncthreads();                                 /* s_hr; the query and directory loads above are in flight meanwhile */
+    if (WIN) {
+        /* the tile's window: from the lowest bucket start to the highest bucket end of its queries */
+        uint64_t mn = valid[0] && lo[0] < hi[0] ? lo[0] : ~0ull, mx = valid[0] && lo[0] < hi[0] ? hi[0] : 0ull;
+        for (int d = 32; d > 0; d >>= 1) {
+            const uint64_t on = wave_bcast_xor64(mn, d), ox = wave_bcast_xor64(mx, d);
+            mn = on < mn ? on : mn; mx = ox > mx ? ox : mx;
+        }
+        if ((threadIdx.x & 63u) == 0) { if (mn != ~0ull) atomicMin(&s_w0, (unsigned long long)mn); if (mx) atomicMax(&s_w1, (unsigned long long)mx); }
+        __syncthreads();
+        const uint64_t a0 = s_w0, a1 = s_w1;
+        if (a1 > a0 && a1 - a0 <= (uint64_t)MTB_JOIN_WINCAP) {
+            /* 1 KiB pieces, a wave each, straight into LDS (global_load_lds_dwordx4: no staging registers, no wait between the pieces -- a loop
+             * of load / ds_write pairs waited for every load: a dozen dependent round trips per tile, measured 96 ms against 80 for the random
+             * join).  The last piece may reach beyond the window (never read) -- but not beyond the array. */
+            const uint32_t n_piece = (uint32_t)((a1 - a0 + 127) >> 7), wv_ = threadIdx.x >> 6, ln_ = threadIdx.x & 63u;
+            for (uint32_t pc = wv_; pc < n_piece; pc += 4) {
+                const uint64_t src = a0 + ((uint64_t)pc << 7) + 2u * ln_;
+                if (a0 + ((uint64_t)pc << 7) + 128 > ix.n_targets) {           /* the piece that holds the array's end (one per index): plain guarded loads */
+                    if (src < ix.n_targets) s_win[((uint64_t)pc << 7) + 2u * ln_] = ix.values[src];
+                    if (src + 1 < ix.n_targets) s_win[((uint64_t)pc << 7) + 2u * ln_ + 1] = ix.values[src + 1];
+                    continue;
+                }
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ix.values + src),
+                                                 (__attribute__((address_space(3))) void *)(s_win + ((uint64_t)pc << 7)), 16, 0, MTB_WIN_AUX);
+            }
+            use_win = true; w0 = a0;
+        }
+        __syncthreads();
+    }
     /* what tells targets of one bucket apart: the whole amino-acid part (flat state) or the packed word's eighth letter */
     auto tkey = [&](uint64_t w) -> uint64_t { return PACKED ? (w & 0x1F000000ull) : (w & AAM); };
     auto qkey = [&](uint64_t v) -> uint64_t {
@@ -276,7 +327,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
             for (int u = 0; u < Q; u++) {
                 if (lo[u] < hi[u]) {
                     const uint64_t mid = lo[u] + ((hi[u] - lo[u]) >> 1);
-                    if (tcomp(ix.values[mid]) < qc[u]) lo[u] = mid + 1; else hi[u] = mid;
+                    if (tcomp(rdv(mid)) < qc[u]) lo[u] = mid + 1; else hi[u] = mid;
                     more |= lo[u] < hi[u];
                 }
             }
@@ -287,14 +338,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
             if (!valid[u]) continue;
             const uint64_t p = lo[u], end = e_hi[u], qk = qkey(k[u].value);
             uint64_t s0 = p, e0 = p;
-            if (p < end && tcomp(ix.values[p]) == qc[u]) {
+            if (p < end && tcomp(rdv(p)) == qc[u]) {
                 /* the block of targets equal to the query (several species may file the same metamer) */
                 e0 = p + 1;
                 uint32_t n = 0;
-                while (e0 < end && n < 8u && tcomp(ix.values[e0]) == qc[u]) { e0++; n++; }
-                if (n == 8u && e0 < end && tcomp(ix.values[e0]) == qc[u]) {
+                while (e0 < end && n < 8u && tcomp(rdv(e0)) == qc[u]) { e0++; n++; }
+                if (n == 8u && e0 < end && tcomp(rdv(e0)) == qc[u]) {
                     uint64_t y = end;
-                    while (e0 < y) { const uint64_t mid = e0 + ((y - e0) >> 1); if (tcomp(ix.values[mid]) <= qc[u]) e0 = mid + 1; else y = mid; }
+                    while (e0 < y) { const uint64_t mid = e0 + ((y - e0) >> 1); if (tcomp(rdv(mid)) <= qc[u]) e0 = mid + 1; else y = mid; }
                 }
             } else {
                 /* the run of the query's amino-acid part around the landing place (the bucket's start is read again from the directory:
@@ -302,17 +353,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
                 const uint32_t bk = mtb_dir_bucket(k[u].value, dv.L, dv.kmer_format);
                 const uint64_t blo = dv.base[bk >> 16] + dv.dir[bk];
                 uint32_t n = 0;
-                while (s0 > blo && n < 8u && tkey(ix.values[s0 - 1]) == qk) { s0--; n++; }
-                if (n == 8u && s0 > blo && tkey(ix.values[s0 - 1]) == qk) {
+                while (s0 > blo && n < 8u && tkey(rdv(s0 - 1)) == qk) { s0--; n++; }
+                if (n == 8u && s0 > blo && tkey(rdv(s0 - 1)) == qk) {
                     uint64_t x = blo, y = s0;
-                    while (x < y) { const uint64_t mid = x + ((y - x) >> 1); if (tkey(ix.values[mid]) < qk) x = mid + 1; else y = mid; }
+                    while (x < y) { const uint64_t mid = x + ((y - x) >> 1); if (tkey(rdv(mid)) < qk) x = mid + 1; else y = mid; }
                     s0 = x;
                 }
                 n = 0;
-                while (e0 < end && n < 8u && tkey(ix.values[e0]) == qk) { e0++; n++; }
-                if (n == 8u && e0 < end && tkey(ix.values[e0]) == qk) {
+                while (e0 < end && n < 8u && tkey(rdv(e0)) == qk) { e0++; n++; }
+                if (n == 8u && e0 < end && tkey(rdv(e0)) == qk) {
                     uint64_t y = end;
-                    while (e0 < y) { const uint64_t mid = e0 + ((y - e0) >> 1); if (tkey(ix.values[mid]) <= qk) e0 = mid + 1; else y = mid; }
+                    while (e0 < y) { const uint64_t mid = e0 + ((y - e0) >> 1); if (tkey(rdv(mid)) <= qk) e0 = mid + 1; else y = mid; }
                 }
             }
             lo[u] = s0; e_hi[u] = e0;
@@ -339,7 +390,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
         for (uint64_t t0 = s + lane; t0 < e; t0 += 256) {
             uint64_t v[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) v[j] = t0 + 64 * j < e ? ix.values[t0 + 64 * j] : 0ull;
+            for (int j = 0; j < 4; j++) v[j] = t0 + 64 * j < e ? rdv(t0 + 64 * j) : 0ull;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 if (t0 + 64 * j < e) {
@@ -363,13 +414,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
             rs[u] = 0; re[u] = 0; thr_[u] = 0; cnt[u] = 0;
             if (!valid[u]) continue;
             const uint64_t s0 = lo[u], e = e_hi[u];
-            const uint64_t v0 = ix.values[s0];
+            const uint64_t v0 = rdv(s0);
             mtb_qrows qr; mtb_prepare_query_rows(s_hr, k[u].value, &qr);
             uint32_t mn = mtb_ham_sum(&qr, (uint32_t)v0 & 0xFFFFFFu);
-            for (uint64_t t = s0 + 1; t < e; t++) { const uint32_t h = mtb_ham_sum(&qr, (uint32_t)ix.values[t] & 0xFFFFFFu); mn = h < mn ? h : mn; }
+            for (uint64_t t = s0 + 1; t < e; t++) { const uint32_t h = mtb_ham_sum(&qr, (uint32_t)rdv(t) & 0xFFFFFFu); mn = h < mn ? h : mn; }
             const uint32_t thr = mtb_ham_threshold(mn);
             uint32_t c = 0;
-            for (uint64_t t = s0; t < e; t++) { const uint64_t v = t == s0 ? v0 : ix.values[t]; c += mtb_ham_sum(&qr, (uint32_t)v & 0xFFFFFFu) <= thr ? 1u : 0u; }
+            for (uint64_t t = s0; t < e; t++) { const uint64_t v = t == s0 ? v0 : rdv(t); c += mtb_ham_sum(&qr, (uint32_t)v & 0xFFFFFFu) <= thr ? 1u : 0u; }
             rs[u] = s0; re[u] = e; thr_[u] = thr; cnt[u] = c; tot_c += c;
         }
         /* wave-scanned runs: threshold and count now, emission behind the reservation */
@@ -391,7 +442,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
                 } else {
                     for (uint64_t t0 = s0; t0 < e; t0 += 64) {
                         const uint64_t t = t0 + lane;
-                        const bool sel = t < e && mtb_ham_sum(&qr, (uint32_t)ix.values[t] & 0xFFFFFFu) <= thr;
+                        const bool sel = t < e && mtb_ham_sum(&qr, (uint32_t)rdv(t) & 0xFFFFFFu) <= thr;
                         c += (uint32_t)__popcll(__ballot(sel));
                     }
                 }
@@ -420,7 +471,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
                 for (uint64_t t0 = s0; t0 < e; t0 += 64) {
                     const uint64_t t = t0 + lane;
                     uint64_t v = 0; uint32_t td = 0, h = 255u;
-                    if (t < e) { v = ix.values[t]; td = (uint32_t)v & 0xFFFFFFu; h = mtb_ham_sum(&qr, td); }
+                    if (t < e) { v = rdv(t); td = (uint32_t)v & 0xFFFFFFu; h = mtb_ham_sum(&qr, td); }
                     const bool sel = h <= thr;
                     const uint64_t m = __ballot(sel);
                     if (!m) continue;
@@ -443,7 +494,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
             const bool rev = mtb_hammings_reversed(mtb_q_frame(k[u].qinfo), ix.kmer_format);
             bool first = true;
             for (uint64_t t = rs[u]; t < re[u]; t++) {
-                const uint64_t v = ix.values[t];
+                const uint64_t v = rdv(t);
                 const uint32_t td = (uint32_t)v & 0xFFFFFFu;
                 const uint32_t h = mtb_ham_sum(&qr, td);
                 if (h > thr_[u]) continue;
@@ -521,14 +572,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
                         if ((int)lane == leader) at0 = atomicAdd(&sa.cursor[r], (uint32_t)__popcll(m) * inc);
                         at0 = (uint32_t)__shfl((int)at0, leader, 64);
                     }
-                    if (sel) put(s0 + off, ix.values[s0 + off], cb[b] & 15u, own ? ~0u : (offr ? tcap : at0 + (uint32_t)__popcll(m & lt_mask)));
+                    if (sel) put(s0 + off, rdv(s0 + off), cb[b] & 15u, own ? ~0u : (offr ? tcap : at0 + (uint32_t)__popcll(m & lt_mask)));
                 }
                 continue;
             }
             for (uint64_t t0 = s0; t0 < e; t0 += 64) {      /* a lane met more than four possible candidates: second walk, 64 per step */
                 const uint64_t t = t0 + lane;
                 uint64_t v = 0; uint32_t h = 255u;
-                if (t < e) { v = ix.values[t]; h = mtb_ham_sum(&qr, (uint32_t)v & 0xFFFFFFu); }
+                if (t < e) { v = rdv(t); h = mtb_ham_sum(&qr, (uint32_t)v & 0xFFFFFFu); }
                 const bool sel = h <= thr;
                 const uint64_t m = __ballot(sel);
                 if (!m) continue;
@@ -550,11 +601,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
     for (int u = 0; u < Q; u++) {
         if (!valid[u]) continue;
         const uint64_t s = lo[u], e = e_hi[u];
-        uint64_t v0 = ix.values[s];
+        uint64_t v0 = rdv(s);
         const uint32_t info0 = PACKED ? (uint32_t)(v0 >> MTB_PACK_LOW) : ix.info[s];      /* flat state: issued now, the first candidate is selected more often than not */
         mtb_qrows qr; mtb_prepare_query_rows(s_hr, k[u].value, &qr);
         uint32_t mn = mtb_ham_sum(&qr, (uint32_t)v0 & 0xFFFFFFu);
-        for (uint64_t t = s + 1; t < e; t++) { const uint32_t h = mtb_ham_sum(&qr, (uint32_t)ix.values[t] & 0xFFFFFFu); mn = h < mn ? h : mn; }
+        for (uint64_t t = s + 1; t < e; t++) { const uint32_t h = mtb_ham_sum(&qr, (uint32_t)rdv(t) & 0xFFFFFFu); mn = h < mn ? h : mn; }
         const uint32_t thr = mtb_ham_threshold(mn);
         const uint32_t r = mtb_q_seq(k[u].qinfo) - 1;
         const uint32_t ord = mtb_q_pos(k[u].qinfo) >> 16;
@@ -567,7 +618,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
         const bool offr = !LONG && sa.off && sa.off[r];
         bool first = ord < direct && !offr;
         for (uint64_t t = s; t < e; t++) {
-            const uint64_t v = t == s ? v0 : ix.values[t];
+            const uint64_t v = t == s ? v0 : rdv(t);
             const uint32_t td = (uint32_t)v & 0xFFFFFFu;
             const uint32_t h = mtb_ham_sum(&qr, td);
             if (h > thr) continue;

@@ -738,6 +738,21 @@ static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint6
 #define MTB_LAUNCH_JV(QV, WV) hipLaunchKernelGGL((k_join_dir<true, 0, QV, WV>), dim3((uint32_t)((n + 256 * QV - 1) / (256 * QV))), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1))
             int join_variant = 0;                     /* MTB_JOIN_VARIANT=q<Q>w<W>, read per batch: bench.py compares the variants inside one process */
             if (const char *e = getenv("MTB_JOIN_VARIANT")) { if (e[0] == 'q' && e[1] >= '1' && e[1] <= '2' && e[2] == 'w' && e[3] >= '5' && e[3] <= '6') join_variant = ((e[1] - '0') << 4) | (e[3] - '0'); }
+            /* the window variant (kernels_dir.h, WIN): when the batch is dense enough that a tile of sorted queries addresses a span of the target
+             * array that fits LDS -- a query owns T / n targets on average; qt queries per workgroup so that the expected window is ~0.82 of the
+             * capacity; below 240 queries per workgroup (T / n > 13.5: smaller batches against a big index) the lookups stay sector-random --
+             * measured: the kernel is bound by the queries a CU has in flight, and idle lanes cost more than the window saves (r05_notes.md).
+             * MTB_JOIN_WIN=0 / 1 forces it off / on, MTB_JOIN_WIN_QT=<n> sets the tile (A/B legs of bench.py; read per batch). */
+            double per_q = (double)ix->T / (double)std::max<uint64_t>(n, 1);
+            uint32_t qt = (uint32_t)std::min<double>(256.0, 0.82 * MTB_JOIN_WINCAP / std::max(per_q, 1.0));
+            bool win = qt >= 240 && join_variant == 0;
+            if (const char *e = getenv("MTB_JOIN_WIN")) win = atoi(e) != 0 && join_variant == 0;
+            if (const char *e = getenv("MTB_JOIN_WIN_QT")) qt = (uint32_t)std::max(1, std::min(256, atoi(e)));
+            qt = std::max<uint32_t>(qt, 1);
+            if (win) {
+                hipLaunchKernelGGL((k_join_dir<true, 0, 1, 5, true>), dim3((uint32_t)((n + qt - 1) / qt)), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix),
+                                   (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1), qt);
+            } else
             switch (join_variant) {
             case 0x15: MTB_LAUNCH_JV(1, 5); break;
             case 0x16: MTB_LAUNCH_JV(1, 6); break;

@@ -421,10 +421,10 @@ template <class T> inline T shfl(Op op, uint32_t site, T v, int arg, int width) 
 #define __builtin_readcyclecounter() ((unsigned long long)__builtin_ia32_rdtsc())
 static inline uint32_t hipemu_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (8 * (sh & 3))); }
 #define __builtin_amdgcn_alignbyte(hi, lo, sh) hipemu_alignbyte((hi), (lo), (sh))
-/* global_load_lds, 4 bytes per lane: the wavefront's LDS base + 4 x lane <- every lane's own global address */
+/* global_load_lds, 4 or 16 bytes per lane: the wavefront's LDS base + size x lane <- every lane's own global address */
 static inline void hipemu_global_load_lds(const void *g, void *lds, int size, int, int) {
-    if (size != 4) { fprintf(stderr, "hipemu: global_load_lds of %d bytes is not modelled\n", size); abort(); }
-    memcpy((char *)lds + 4 * (hipemu::t_lane->tid.x & 63u), g, 4);
+    if (size != 4 && size != 16) { fprintf(stderr, "hipemu: global_load_lds of %d bytes is not modelled\n", size); abort(); }
+    memcpy((char *)lds + (size_t)size * (hipemu::t_lane->tid.x & 63u), g, (size_t)size);
 }
 #define __builtin_amdgcn_global_load_lds(g, lds, size, off, aux) hipemu_global_load_lds((const void *)(g), (void *)(lds), (size), (off), (aux))
 

@@ -871,6 +871,36 @@ def test_long_candidate_runs_are_scanned_by_the_wave(orc, tmp_path, seq_mode, de
 
 
 @pytest.mark.parametrize("seq_mode", [1, 2])
+def test_target_windows_staged_in_lds_give_the_same_matches(orc, tmp_path, seq_mode, monkeypatch):
+    """k_join_dir<.., WIN>: a workgroup.s tile of sorted queries stages the span of the target array between its first and its last bucket in
+    LDS (coalesced loads) and searches / evaluates there; tiles whose span exceeds the LDS capacity read global memory (same code).  Forced
+    on (MTB_JOIN_WIN=1) with tiles of 5, 64 and 256 queries -- spans from a few targets to far beyond the capacity, long candidate runs
+    (the wave scan) inside and outside a window -- the per-read answers and the match totals are the oracle's, and equal the sector-random
+    variant's (MTB_JOIN_WIN=0)."""
+    import metabuli_amd as M
+    from conftest import HotToy
+    t = HotToy(orc, tmp_path / "db", seq_mode=seq_mode, n_reads=150)
+    monkeypatch.setenv("MTB_DIR_DEPTH", "7")
+    c = M.Context(0)
+    p = M.default_params(seq_mode=seq_mode, syncmer=1)
+    ix = c.open_index(t.dbdir, p)
+    monkeypatch.delenv("MTB_DIR_DEPTH", raising=False)
+    ro = t.ref["results"]
+    amb = ro["flag"] != 0
+    for win, qt in (("1", "5"), ("1", "64"), ("1", "256"), ("0", "256")):
+        monkeypatch.setenv("MTB_JOIN_WIN", win); monkeypatch.setenv("MTB_JOIN_WIN_QT", qt)
+        res, tt, tc = c.classify_batch(ix, p, t.b1, t.o1, t.b2, t.o2)
+        assert ix.state()["packed"]
+        assert ((res["classification"] == ro["classification"]) | amb).all(), (win, qt)
+        assert ((res["score"].view(np.uint32) == ro["score"].view(np.uint32)) | amb).all(), (win, qt)
+        assert ((res["n_taxcnt"] == ro["n_taxcnt"]) | amb).all(), (win, qt)
+        if not amb.any():
+            assert (tt == t.ref["tc_tax"]).all() and (tc == t.ref["tc_cnt"]).all(), (win, qt)
+        assert c.last_stats().n_matches == len(t.ref["matches"]), (win, qt)
+    ix.close(); c.close()
+
+
+@pytest.mark.parametrize("seq_mode", [1, 2])
 def test_reads_that_meet_many_species_are_scored_from_their_slots(orc, tmp_path, seq_mode, monkeypatch):
     """A conserved protein filed under 160 species, each of which holds only a sparse subset of its metamers: a read of that gene brings a
     few hundred matches, most of them alone in their species.  Its tail overflows, so the slot scorers defer it; k_score_many
