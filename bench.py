@@ -971,6 +971,13 @@ def main(device=None):
         jt = max(1, sum(pc[16:21]))
         log("[rank 0] k_join_dir phase cycles (thread 0 of every workgroup): " + ", ".join(
             f"{n} {100.0 * pc[16 + i] / jt:.1f} %" for i, n in enumerate(("queries + directory", "bisection", "run ends", "wave-scanned runs", "per-lane evaluation + emission"))))
+    if hasattr(M.lib(), "mtb_debug_fast_reasons"):        # debugging build (MTB_LIB=.../libmtb_dbg.so): why reads leave the register-resident scorer
+        import ctypes
+        fr = (ctypes.c_ulonglong * 32)()
+        M.lib().mtb_debug_fast_reasons(ctx.h, fr)
+        names = ["tail overflow / buckets", "> 24 species rounds (pairs: runs) or > staging", "S1 not sorted", "S2 group of 2", "S3 > 64 paths", "handled"]
+        tot = max(1, sum(fr[:6]))
+        log("[rank 0] k_score_fast exits (all batches so far): " + ", ".join(f"{n} {fr[i]} ({100.0 * fr[i] / tot:.2f} %)" for i, n in enumerate(names)))
     wl_key = ("diversity" if big_world else "default") + ("" if args.seq_mode == 1 else f"_mode{args.seq_mode}")
     ps, kern, roofline, roofline_all, footprint, query_runs = profiled_step(ctx, M, index, params, step, args.streams, wl_key,
                                                                            (args.reads, args.read_len, int(T), args.seq_mode))

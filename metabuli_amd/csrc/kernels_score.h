@@ -73,6 +73,24 @@ __global__ __launch_bounds__(256) void k_count_flags(const uint8_t *__restrict__
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, (unsigned long long)c);
 }
 
+/* reads k_score_fast flagged 2 (tail overflow) -> the list of the deferred path: one atomic per workgroup of 256 reads */
+__global__ __launch_bounds__(256) void k_list_flag2(const uint8_t *__restrict__ f, uint64_t n, uint32_t *__restrict__ list, uint32_t *__restrict__ n_list) {
+    __shared__ uint32_t s_w[4]; __shared__ uint32_t s_base;
+    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool on = r < n && f[r] == 2;
+    const uint64_t m = __ballot(on);
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    if (lane == 0) s_w[wv] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) { const uint32_t tot = s_w[0] + s_w[1] + s_w[2] + s_w[3]; s_base = tot ? atomicAdd(n_list, tot) : 0u; }
+    __syncthreads();
+    if (on) {
+        uint32_t at = s_base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        for (uint32_t q = 0; q < wv; q++) at += s_w[q];
+        list[at] = (uint32_t)r;
+    }
+}
+
 /* list the reads whose segment does not fit the LDS staging of k_score; they
  * are sorted in HBM by k_segsort_large and scored out of per-workgroup slabs */
 __global__ __launch_bounds__(256) void k_list_large(const uint64_t *__restrict__ seg_start, uint64_t n_reads, uint32_t threshold,
@@ -687,7 +705,7 @@ __global__ __launch_bounds__(64, (CAP > MTB_SCORE_LDS ? 2 : MTB_SCORE_MINWAVES))
         unsigned long long kt0_ = __builtin_readcyclecounter();
 #endif
         const uint64_t r = list ? (uint64_t)list[it] : it;
-        if ((SLOT || DYN) && only_flagged && !only_flagged[r]) continue;   /* already scored by k_score_fast (slot mode) / by k_score_long (slab launches) */
+        if ((SLOT || DYN) && only_flagged && only_flagged[r] != 1) continue;   /* already scored by k_score_fast (slot mode) / by k_score_long (slab launches); 2 = listed for the deferred path by k_list_flag2 */
         if (SLOT && !DYN && !list && !only_flagged && it + gridDim.x < n_iter) {
             /* slot mode: start pulling the NEXT read's slots towards L2 now (one dword per 128-byte line, delivered
              * straight into a dummy LDS area: no register, nothing waits for it) -- the slot loads are one dependent

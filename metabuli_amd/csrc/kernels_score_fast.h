@@ -336,7 +336,10 @@ __global__ __launch_bounds__(64, K <= 3 ? 5 : 4) void k_score_fast(const mtb_slo
         if (!slow) { if (__any(bad)) MTB_FAST_COUNT(2, 1); else if (__any(bad2)) MTB_FAST_COUNT(3, 1); }
 #endif
         slow = slow || __any(bad || bad2);
-        if (slow) { if (lane == 0) slow_flag[r] = 1; continue; }        /* no shared counter: millions of returning atomics on one address cost tens of ms */
+        /* flag 2 = the read's tail overflowed: it is listed for the deferred path (k_list_flag2) and the generic kernel does not look at it.
+         * (No shared counter here: millions of returning atomics on one address cost tens of ms -- the generic kernel appended 1.1 M such
+         * reads to its list one atomic each, 11 of its 12.7 ms.) */
+        if (slow) { if (lane == 0) slow_flag[r] = cur > tail_cap ? 2 : 1; continue; }
         if (lane == 0) cnt_out[r] = (uint32_t)n_live;
         MTB_FAST_MARK(2);       /* own elements, flags, links */
         /* ---- chain DP as one segmented prefix sum; candidates for emission ---- */

@@ -935,6 +935,7 @@ static mtb_status dev_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, uint
               else if (S->stride <= 128) MTB_LAUNCH_FAST(2); else if (S->stride <= 192) MTB_LAUNCH_FAST(3); else if (S->stride <= 256) MTB_LAUNCH_FAST(4); else MTB_LAUNCH_FAST(5, 6, false); }
 #undef MTB_LAUNCH_FAST
             hipLaunchKernelGGL(k_count_flags, dim3(256), dim3(256), 0, c->stream, (const uint8_t *)d_slow, n_reads, (unsigned long long *)(c->d_scal + 6));
+            if (S->big_list && S->n_big) hipLaunchKernelGGL(k_list_flag2, dim3((uint32_t)((n_reads + 255) / 256)), dim3(256), 0, c->stream, (const uint8_t *)d_slow, n_reads, S->big_list, S->n_big);
             c->fast_used = true;
             S_rest = *S; S_rest.only_flagged = d_slow;
             S = &S_rest;

@@ -94,6 +94,8 @@ inline void dev_free(void *u) {
 }  // namespace hipemu
 
 static inline hipError_t hipGetLastError() { return hipSuccess; }
+enum { hipDeviceAttributeMultiprocessorCount = 63 };
+static inline hipError_t hipDeviceGetAttribute(int *v, int, int) { *v = 3; return hipSuccess; }      /* (a small "chip": persistent kernels loop over several tiles per workgroup) */
 static inline const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess (emulated)" : e == hipErrorOutOfMemory ? "out of memory (emulated device)" : "error (emulated device)"; }
 static inline hipError_t hipGetDeviceCount(int *n) { *n = hipemu::env_int("HIPEMU_DEVICES", 2); return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
