@@ -4,7 +4,7 @@ the mean KB per launch over the profiled bench run.  Usage: make_pmc_traffic.py 
 import csv, glob, json, re, sys
 base, reads, read_len, targets, seq_mode, label = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
 wl_key = sys.argv[7] if len(sys.argv) > 7 else "default"
-NAMES = [("k_join_dir", "join"), ("k_join<", "join"), ("k_score_fast", "score_fast"), ("k_score<", "score"), ("k_radix_scatter", "radix_scatter"),
+NAMES = [("k_seg_order", "segsort"), ("k_score_long<1024", "score_fast"), ("k_score_many", "score_many"), ("k_join_dir", "join"), ("k_join<", "join"), ("k_score_fast", "score_fast"), ("k_score<", "score"), ("k_radix_scatter", "radix_scatter"),
          ("k_radix_hist", "radix_hist"), ("k_extract<2>", "extract_emit"), ("k_extract<1>", "extract_emit"), ("k_extract<0>", "extract_count")]
 out = {}
 for suffix, counter, key in (("_d", "FETCH_SIZE", "fetch_size_kb"), ("_e", "WRITE_SIZE", "write_size_kb")):
