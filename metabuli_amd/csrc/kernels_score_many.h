@@ -112,6 +112,7 @@ __global__ __launch_bounds__(MTB_MSORT_NT) void k_many_sort(const mtb_slot16 *__
         for (uint32_t i = tid; i < n_src; i += MTB_MSORT_NT) {
             uint32_t s_, f_;
             if (!probe(i, &s_, &f_)) continue;
+            if (*(volatile uint32_t *)&s_full) break;                     /* the table has filled up: the read is handed on, nobody keeps probing */
             uint32_t h = (s_ * 0x9E3779B1u) >> 20; bool done = false;
             for (uint32_t p = 0; p < MTB_MSORT_HASH && !done; p++) {
                 const uint32_t old = atomicCAS(&h_key[h], 0xFFFFFFFFu, s_);
@@ -201,6 +202,7 @@ __global__ __launch_bounds__(64, (CAP > 192 ? 2 : 3)) void k_score_many(const mt
     static_assert(CAP * sizeof(mtb_path) >= MTB_SCORE_BKT * 13 + (MTB_LR_MAXE + MTB_LR_MAXE * MTB_LR_K) * 4, "decide arrays must fit the path area");
     uint32_t *const h_key = (uint32_t *)(s_ws + CAP * sizeof(mtb_match));
     uint32_t *const h_val = h_key + MTB_MANY_HASH;
+    __shared__ uint32_t s_tfull;                 /* the species table of the read in work has filled up: nobody keeps probing it (every further record walked all its entries) */
     const uint32_t lane = threadIdx.x;
     const uint64_t lt = lanemask_lt();
     const uint32_t tail_cap = stride - direct;
@@ -229,10 +231,12 @@ __global__ __launch_bounds__(64, (CAP > 192 ? 2 : 3)) void k_score_many(const mt
         if (!hand_on) {
             score_sync<uint16_t>();                      /* the previous read is through with the workspace */
             for (uint32_t q = lane; q < MTB_MANY_HASH; q += 64) { h_key[q] = 0xFFFFFFFFu; h_val[q] = 0u; }
+            if (lane == 0) s_tfull = 0;
             score_sync<uint16_t>();
             bool full = false;
             /* species `s` (never 0xFFFFFFFF: ids are < 2^31), frame f: find or claim the entry, mark the frame */
             auto enter = [&](uint32_t s, uint32_t f) {
+                if (*(volatile uint32_t *)&s_tfull) { full = true; return; }
                 uint32_t h = (s * 0x9E3779B1u) >> 22;
                 for (uint32_t p = 0; p < MTB_MANY_HASH; p++) {
                     const uint32_t old = atomicCAS(&h_key[h], 0xFFFFFFFFu, s);
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(64, (CAP > 192 ? 2 : 3)) void k_score_many(const mt
                     }
                     h = (h + 1u) & (MTB_MANY_HASH - 1u);
                 }
-                full = true;
+                full = true; s_tfull = 1;
             };
             for (uint32_t c0 = 0; c0 < stride; c0 += 64) {
                 const uint32_t i = c0 + lane;

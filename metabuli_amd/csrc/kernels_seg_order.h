@@ -27,8 +27,27 @@
 #define MTB_SO_MAXSP 768
 #define MTB_SO_TAIL 2048           /* tail matches of a read held in LDS as (key, index) */
 
+/* profiling build only (make libmtb_xsoprof.so X=-DMTB_SO_PHASE_CYCLES): cycles of thread 0 per phase, summed over the workgroups: 0 claim + clear, 1 pass 1
+ * (bits), 2 pass 2 (counts, tail keys), 3 single-match species, 4 tail sort, 5 species sort + offsets, 6 scatter pass, 7 tail pass */
+#ifdef MTB_SO_PHASE_CYCLES
+__device__ unsigned long long mtb_so_cycles[8];
+#define MTB_SO_MARK(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); so_acc[k] += t_ - so_t; so_t = t_; } while (0)
+#else
+#define MTB_SO_MARK(k) do {} while (0)
+#endif
 __device__ __forceinline__ uint32_t so_hash(int32_t species) { return ((uint32_t)species * 0x9E3779B1u) >> 22; }      /* 10 bits */
 __device__ __forceinline__ uint32_t so_bloom(int32_t species) { return ((uint32_t)species * 0x85EBCA6Bu) >> 16; }     /* 16 bits */
+
+/* a 24-byte Match record at an 8-byte aligned place: ONE 16-byte store + one 8-byte store (which half is the wide one depends on the
+ * place's alignment) instead of three 8-byte ones.  The ordering passes write records to unrelated places lane by lane -- their time is
+ * the NUMBER of write transactions (the tail pass: 100 M records per 50 k long reads on the heavy-tailed index = 71 % of the kernel). */
+typedef unsigned long long so_u64x2 __attribute__((vector_size(16)));
+__device__ __forceinline__ void so_store_match(mtb_match *p, const mtb_match &m) {
+    const uint64_t *q = (const uint64_t *)&m;
+    uint64_t *o = (uint64_t *)p;
+    if (((uintptr_t)o & 15u) == 0) { so_u64x2 v; v[0] = q[0]; v[1] = q[1]; *(so_u64x2 *)o = v; o[2] = q[2]; }
+    else { o[0] = q[0]; so_u64x2 v; v[0] = q[1]; v[1] = q[2]; *(so_u64x2 *)(o + 1) = v; }
+}
 
 /* all-ascending bitonic network over n keys with virtual +inf padding, payload idx[] moves with the key */
 __device__ __forceinline__ void so_bitonic(uint64_t *key, uint16_t *idx, uint32_t n, uint32_t tid) {
@@ -77,9 +96,13 @@ __global__ __launch_bounds__(MTB_SO_NT) void k_seg_order(const mtb_slot16 *__res
     __shared__ uint32_t s_nsp, s_bad, s_total, s_live, s_nkept;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const uint64_t lt = lanemask_lt();
+#ifdef MTB_SO_PHASE_CYCLES
+    unsigned long long so_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long so_t = __builtin_readcyclecounter();
+#endif
 
     for (;;) {
         __syncthreads();
+        MTB_SO_MARK(7);
         if (tid == 0) { s_r = atomicAdd(work, 1ull); s_nsp = 0; s_bad = 0; s_total = 0; s_live = 0; s_nkept = 0; }
         __syncthreads();
         const uint64_t r = s_r;
@@ -99,6 +122,7 @@ __global__ __launch_bounds__(MTB_SO_NT) void k_seg_order(const mtb_slot16 *__res
         /* wave quarter of the direct slots: whole 64-slot steps */
         const uint32_t q_len = ((d + MTB_SO_NW * 64 - 1) / (MTB_SO_NW * 64)) * 64;
         const uint32_t q_lo = wv * q_len < d ? wv * q_len : d, q_hi = (wv + 1) * q_len < d ? (wv + 1) * q_len : d;
+        MTB_SO_MARK(0);
         /* ---- pass 1: which species buckets are seen twice ---- */
         uint32_t my_live = 0;
         auto mark = [&](int32_t species) {
@@ -121,16 +145,21 @@ __global__ __launch_bounds__(MTB_SO_NT) void k_seg_order(const mtb_slot16 *__res
         /* hash slot of a species that may have two matches (inserting it): open addressing, linear probing */
         auto twice = [&](int32_t species) -> bool { const uint32_t b = so_bloom(species); return (b_twice[b >> 5] >> (b & 31u)) & 1u; };
         auto slot_of = [&](int32_t species) -> uint32_t {
+            /* a read with more candidate species than the table holds is handed on (s_bad): nobody keeps probing a table that fills up -- every
+             * further species of such a read walked all 1024 entries, one LDS atomic each: a handful of those reads held the kernel for tens of
+             * milliseconds after the other workgroups had finished */
+            if (*(volatile uint32_t *)&s_bad) return 0;
             uint32_t h = so_hash(species);
             for (uint32_t probe = 0; probe < MTB_SO_HASH; probe++) {
                 const int32_t old = atomicCAS(&h_key[h], -1, species);
-                if (old == -1) { atomicAdd(&s_nsp, 1u); return h; }
+                if (old == -1) { if (atomicAdd(&s_nsp, 1u) >= MTB_SO_MAXSP) s_bad = 1; return h; }
                 if (old == species) return h;
                 h = (h + 1) & (MTB_SO_HASH - 1);
             }
             s_bad = 1;
             return 0;
         };
+        MTB_SO_MARK(1);
         /* ---- pass 2: exact counts of those species, per wave quarter; the tail's sort keys ---- */
         for (uint32_t i0 = q_lo + lane; i0 < q_hi; i0 += 256) {
             mtb_slot16 x[4];
@@ -148,6 +177,7 @@ __global__ __launch_bounds__(MTB_SO_NT) void k_seg_order(const mtb_slot16 *__res
         }
         __syncthreads();
         if (s_bad || s_nsp > MTB_SO_MAXSP) { if (tid == 0) { live[r] = 0; fail_list[atomicAdd(n_fail, 1u)] = (uint32_t)r; } continue; }
+        MTB_SO_MARK(2);
         if (tid == 0 && n_all) atomicAdd(n_all, (unsigned long long)s_live);
         /* species with a single match after all (bucket collisions): dropped; their tail keys go behind the kept ones */
         for (uint32_t q = tid; q < MTB_SO_HASH; q += MTB_SO_NT)
@@ -155,6 +185,7 @@ __global__ __launch_bounds__(MTB_SO_NT) void k_seg_order(const mtb_slot16 *__res
         __syncthreads();
         for (uint32_t i = tid; i < t; i += MTB_SO_NT) { const uint64_t k = t_key[i]; if (k != ~0ull && h_key[(uint32_t)(k >> 46)] < -1) t_key[i] = ~0ull; }
         __syncthreads();
+        MTB_SO_MARK(3);
         /* ---- tail sorted by (hash slot, key); start of every species' range ---- */
         if (t > 1) so_bitonic(t_key, t_idx, t, tid);
         __syncthreads();
@@ -164,6 +195,8 @@ __global__ __launch_bounds__(MTB_SO_NT) void k_seg_order(const mtb_slot16 *__res
             const uint32_t h = (uint32_t)(k >> 46);
             if (i == 0 || (uint32_t)(t_key[i - 1] >> 46) != h) h_tstart[h] = i;
         }
+        __syncthreads();
+        MTB_SO_MARK(4);
         /* ---- kept species ascending -> start of every species' region in the output ---- */
         /* (only the kept species are sorted -- a few dozen for a typical read, not the table's 1024 slots: 15 - 21 network stages
          * with a barrier each instead of 55) */
@@ -206,6 +239,7 @@ __global__ __launch_bounds__(MTB_SO_NT) void k_seg_order(const mtb_slot16 *__res
             if (tid == 0) s_total = tot;
         }
         __syncthreads();
+        MTB_SO_MARK(5);
         /* ---- scatter pass: every wave its quarter, in order ---- */
         mtb_slot16 x_next; x_next.a = 0; x_next.b = 0;
         if (q_lo + lane < q_hi) x_next = seg[q_lo + lane];
@@ -237,16 +271,17 @@ __global__ __launch_bounds__(MTB_SO_NT) void k_seg_order(const mtb_slot16 *__res
                     lb = lo - b0;
                     if (lb < tc) atomicAdd(&t_diff[b0 + lb], 1u);           /* this match precedes the tail matches from there on */
                 }
-                const mtb_match m = mtb_lslot_unpack(x, (uint32_t)r + 1);
-                uint64_t *o = (uint64_t *)(dst + before + rank + lb);
-                const uint64_t *q = (const uint64_t *)&m;
-                o[0] = q[0]; o[1] = q[1]; o[2] = q[2];
+                so_store_match(dst + before + rank + lb, mtb_lslot_unpack(x, (uint32_t)r + 1));
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();       /* every peer has read the running position ... */
             if (lv && (peers & lt) == 0) h_run[wv][h] += (uint32_t)__popcll(peers);                         /* ... before the first of them moves it */
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
         }
+#if defined(MTB_SO_PHASE_CYCLES) && defined(__AMDGCN__)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       /* (profiling build: the scatter pass's stores are charged to the scatter pass) */
+#endif
         __syncthreads();
+        MTB_SO_MARK(6);
         /* ---- tail pass: a tail match sits behind the direct matches of its species that precede it and the tail matches before it ---- */
         if (t) {
             /* inclusive prefix sums of the difference array (t <= 2048: 8 per thread) */
@@ -266,15 +301,20 @@ __global__ __launch_bounds__(MTB_SO_NT) void k_seg_order(const mtb_slot16 *__res
                 const uint32_t ts = h_tstart[h];
                 const uint32_t direct_before = t_diff[j] - (ts ? t_diff[ts - 1] : 0u);
                 const mtb_slot16 x = seg[d + t_idx[j]];
-                const mtb_match m = mtb_lslot_unpack(x, (uint32_t)r + 1);
                 /* S[h] + all direct matches of the species that precede it + its rank in the species' tail */
-                uint64_t *o = (uint64_t *)(dst + h_S[h] + direct_before + (j - ts));
-                const uint64_t *q = (const uint64_t *)&m;
-                o[0] = q[0]; o[1] = q[1]; o[2] = q[2];
+                so_store_match(dst + h_S[h] + direct_before + (j - ts), mtb_lslot_unpack(x, (uint32_t)r + 1));
             }
         }
         if (tid == 0) live[r] = s_total;
+#if defined(MTB_SO_PHASE_CYCLES) && defined(__AMDGCN__)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        MTB_SO_MARK(7);
+#endif
     }
+#ifdef MTB_SO_PHASE_CYCLES
+    if (tid == 0) for (int k = 0; k < 8; k++) atomicAdd(&mtb_so_cycles[k], so_acc[k]);
+#endif
 }
 
 /* Reads k_seg_order could not take (more candidate species / tail matches than its LDS tables hold): their live slots are copied

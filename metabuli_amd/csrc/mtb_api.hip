@@ -2261,6 +2261,18 @@ static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, c
                                  (const uint32_t *)d_dcnt, (const uint32_t *)d_rc, tf, n_reads, d_m, d_live, (uint32_t *)(c->d_scal + 2), d_fail, d_work,
                                  (unsigned long long *)(c->d_scal + 3)); }
             HIPCHK(hipGetLastError());
+#ifdef MTB_SO_PHASE_CYCLES
+            {   HIPCHK(hipStreamSynchronize(st));
+                unsigned long long h[8], z[8] = {0};
+                HIPCHK(hipMemcpyFromSymbol(h, HIP_SYMBOL(mtb_so_cycles), sizeof(h)));
+                HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(mtb_so_cycles), z, sizeof(z)));
+                static const char *nm[8] = {"claim + clear", "pass 1 (bits)", "pass 2 (counts, tail keys)", "single-match species", "tail sort", "species sort + offsets", "scatter pass", "tail pass"};
+                unsigned long long tot = 0; for (int k = 0; k < 8; k++) tot += h[k];
+                fprintf(stderr, "k_seg_order phases (%llu reads):", (unsigned long long)n_reads);
+                for (int k = 0; k < 8; k++) fprintf(stderr, " %s %.1f %%;", nm[k], tot ? 100.0 * (double)h[k] / (double)tot : 0.0);
+                fprintf(stderr, "\n");
+            }
+#endif
             uint64_t sc2[2] = {0, 0};
             STCHK(d2h(c, sc2, c->d_scal + 2, 16));
             if (getenv("MTB_LSLOT_VERBOSE")) fprintf(stderr, "mtb: long-read slot path: %llu reads, tail factor %u/4, %llu slots, %llu matches, %llu reads beyond the LDS tables (sorted the general way)\n",
