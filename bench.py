@@ -890,8 +890,11 @@ def main(device=None):
         except M.MtbError as e:
             log(f"[rank {rank}] index not sealed: {e}")
     n_bases_step = args.reads * args.read_len * (2 if args.seq_mode == 2 else 1)
-    d_res = torch.empty(args.reads * 24, dtype=torch.uint8, device=dev)
-    tc_cap = args.reads * (20 + args.read_len // 9) * (2 if args.seq_mode == 2 else 1) + 1024
+    # (the legs of the other configurations reuse the result arrays: sized for the largest user)
+    n_res = max([args.reads] + [lg["n"] for lg in legs.values()])
+    d_res = torch.empty(n_res * 24, dtype=torch.uint8, device=dev)
+    tc_cap = max([args.reads * (20 + args.read_len // 9) * (2 if args.seq_mode == 2 else 1)] +
+                 [lg["n"] * (20 + lg["read_len"] // 9) * (2 if lg["seq_mode"] == 2 else 1) for lg in legs.values()]) + 1024
     d_tt = torch.empty(tc_cap, dtype=torch.int32, device=dev); d_tc = torch.empty(tc_cap, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
     log(f"[rank {rank}] setup {time.perf_counter()-t_setup:.1f}s: T={T} ({n_real - n_extras} genome-derived, {n_extras} shared-run extras), reads={args.reads}x{args.read_len}")

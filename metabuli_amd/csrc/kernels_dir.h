@@ -228,7 +228,7 @@ __device__ __forceinline__ uint32_t wave_min_shfl_u32(uint32_t v) {
                                        * (A window per WAVE -- 64 queries, 896 words, no workgroup barrier -- measured 81.8 ms against 73.6 for the workgroup's window
                                        * and 80.9 for the sector-random join: a sixth of the waves fell back, profiles/r05_notes.md) */
 template <bool PACKED, int MODE = 0, int QPT = ((PACKED && MODE == 0) ? MTB_JOIN_DIR_QPT0 : MTB_JOIN_DIR_QPT), int WAVES = MTB_JOIN_WAVES, bool WIN = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && MODE == 0) ? WAVES : 5))) void k_join_dir(const mtb_kmer *__restrict__ q, uint64_t n, mtb_index_view ix, uint64_t limit, mtb_dir_view dv,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && MODE != 2) ? WAVES : 5))) void k_join_dir(const mtb_kmer *__restrict__ q, uint64_t n, mtb_index_view ix, uint64_t limit, mtb_dir_view dv,
                                                    const mtb_tables *__restrict__ tabs, JoinSegArgs sa, uint32_t *__restrict__ overflow, uint32_t qt = 256) {
     constexpr int Q = QPT;
     static_assert(!WIN || (QPT == 1 && PACKED && MODE == 0), "the window variant: short reads, packed words, one query per thread");

@@ -730,7 +730,12 @@ static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint6
             else hipLaunchKernelGGL((k_join_dir<false, 2>), dim3(g2), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1));
         } else
         if (sa.rb) {        /* long reads: per-read slot ranges */
-            if (state_owner(ix)->packed) hipLaunchKernelGGL((k_join_dir<true, 1>), dim3(g2), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1));
+            if (state_owner(ix)->packed) {
+                /* one query per thread at 6 waves per SIMD here too (43.2 -> 41.5 ms per 50 k x 10 kb; MTB_JOIN_VARIANT=q2w5: round 4's instantiation, A/B) */
+                const char *e = getenv("MTB_JOIN_VARIANT");
+                if (!(e && !strcmp(e, "q2w5"))) hipLaunchKernelGGL((k_join_dir<true, 1, 1, 6>), dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1));
+                else hipLaunchKernelGGL((k_join_dir<true, 1, MTB_JOIN_DIR_QPT, 5>), dim3(g2), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1));
+            }
             else hipLaunchKernelGGL((k_join_dir<false, 1>), dim3(g2), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1));
         } else
         if (state_owner(ix)->packed) {

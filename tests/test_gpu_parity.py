@@ -1101,13 +1101,14 @@ def test_bench_heavy_tailed_workload_in_small(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--reads", "100000", "--targets", "2.5e8",
                           "--cpu-reads", "30000", "--cpu-stride", "8", "--species", "200", "--genome-len", "600000", "--filler-species", "5000",
-                          "--leg-pairs", "20000", "--leg-long", "100", "--leg-long-len", "5000", "--full-parity-reads", "4000", "--no-cpu"],
+                          "--leg-pairs", "20000", "--leg-long", "100", "--leg-long-len", "5000", "--leg-novel", "30000", "--heldout", "20", "--long-parity-reads", "40", "--full-parity-reads", "4000", "--no-cpu"],
                          capture_output=True, text=True, timeout=1500)
     assert out.returncode == 0, out.stderr[-3000:]
     line = json.loads(out.stdout.strip().split("\n")[-1])
     assert line["parity_sample"]["mismatches"] == 0 and line["parity_sample"]["reads"] == 30000
     assert line["other_configs"]["paired"]["mismatches"] == 0 and line["other_configs"]["long"]["mismatches"] == 0
-    assert line["best_case"]["ms_per_step"] > 0
+    assert line["other_configs"]["novel"]["mismatches"] == 0 and line["other_configs"]["novel"]["parity"]["reads"] == 4000        # reads of held-out organisms
+    assert line["best_case"]["ms_per_step"] > 0 and line["library"]["path"].endswith(".so") and line["ranks"][0]["rank"] == 0
     rl = line["run_lengths"]
     assert rl["index"]["shared_run_extras"] > 0 and rl["index"]["quantiles_over_targets"]["max_bin_upper"] >= 127
     assert rl["queries"]["quantiles"]["max_bin_upper"] >= 127            # queries meet runs of > 64 candidates: the wave-scanned path ran
