@@ -132,6 +132,7 @@ struct mtb_ctx {
      * earlier) is still waiting for its classify call, so TWO prefetches are outstanding for a moment -- with a single record classify(k)
      * found batch k+1's key, discarded it and uploaded k again */
     struct Prefetched { const void *key = nullptr, *key2 = nullptr; uint64_t n_reads = 0; bool valid = false; } pre[2];
+    struct JoinTune { uint64_t key = 0; int calls = 0, pending = -1, best = -1; float ms[3] = {0.0f, 0.0f, 0.0f}; hipEvent_t e0 = nullptr, e1 = nullptr; } join_tune;      /* dev_join: the short-read instantiation that is fastest for this index and batch size */
     uint64_t many_stats[4] = {0, 0, 0, 0};           /* last slot-path batch: reads deferred by the first scoring launches, of those scored by k_score_many, their matches, the survivors of the dead-species drop */
     uint32_t lslot_tf_start = 1;                     /* long-read slot ranges: tail factor the next batch starts with (1 = a quarter of the metamers, 4 = all) */
     uint32_t join_coop_min = MTB_JOIN_COOP_MIN;      /* k_join_dir: runs longer than this are scanned by the whole wave; MTB_JOIN_COOP_MIN in the environment at mtb_ctx_create */
@@ -393,6 +394,7 @@ void mtb_ctx_destroy(mtb_ctx *c) {
     if (c->down_done) e = hipEventDestroy(c->down_done);
     if (c->copy_stream) { e = hipStreamSynchronize(c->copy_stream); e = hipStreamDestroy(c->copy_stream); }
     for (int k = 0; k < 2; k++) { if (c->copy_done[k]) e = hipEventDestroy(c->copy_done[k]); if (c->unpacked[k]) e = hipEventDestroy(c->unpacked[k]); }
+    if (c->join_tune.e0) { e = hipEventDestroy(c->join_tune.e0); e = hipEventDestroy(c->join_tune.e1); }
     for (int i = 0; i < 8; i++) e = hipEventDestroy(c->ev[i]);
     for (auto &k : c->kev) { e = hipEventDestroy(k.a); e = hipEventDestroy(k.b); }
     for (auto &x : c->ev_pool) e = hipEventDestroy(x);
@@ -754,6 +756,41 @@ static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint6
             if (const char *e = getenv("MTB_JOIN_WIN")) win = atoi(e) != 0 && join_variant == 0;
             if (const char *e = getenv("MTB_JOIN_WIN_QT")) qt = (uint32_t)std::max(1, std::min(256, atoi(e)));
             qt = std::max<uint32_t>(qt, 1);
+            /* Which instantiation is fastest depends on the batch's locality, which the host cannot see: reads of a few genomes at high
+             * coverage (queries falling into few, L2-resident sectors) run best with two queries per thread, a metagenome of thousands of
+             * genomes with one query per thread at 6 waves, a dense one with the LDS window (measured: r05_notes.md).  All of them are exact,
+             * so a context TRIES them on its first batches against an index (second to fourth join of that shape: one instantiation each,
+             * timed with a pair of events) and keeps the fastest.  MTB_JOIN_VARIANT / MTB_JOIN_WIN in the environment switch the choice off. */
+            const bool forced = getenv("MTB_JOIN_VARIANT") || getenv("MTB_JOIN_WIN");
+            mtb_ctx::JoinTune &jt = c->join_tune;
+            int tuned = -1;                                  /* 0: one query per thread, 6 waves; 1: two per thread, 5 waves; 2: the window */
+            if (!forced && !c->is_lane) {
+                uint32_t lg = 0; for (uint64_t x = n; x > 1; x >>= 1) lg++;
+                const uint64_t key = (uint64_t)(uintptr_t)ix ^ ((uint64_t)lg << 56) ^ (ix->T << 8);
+                if (jt.key != key) { const hipEvent_t k0 = jt.e0, k1 = jt.e1; jt = mtb_ctx::JoinTune(); jt.key = key; jt.e0 = k0; jt.e1 = k1; }
+                if (jt.pending >= 0) {                       /* the previous join's time (that batch is long finished) */
+                    float ms = 0.0f;
+                    if (hipEventElapsedTime(&ms, jt.e0, jt.e1) == hipSuccess && ms > 0.0f) jt.ms[jt.pending] = ms; else { (void)hipGetLastError(); jt.ms[jt.pending] = 1e30f; }
+                    jt.pending = -1;
+                }
+                jt.calls++;
+                if (jt.best < 0 && jt.calls >= 2) {
+                    int next = -1;
+                    for (int v = 0; v < 3; v++) if (jt.ms[v] == 0.0f && (v != 2 || qt >= 240)) { next = v; break; }
+                    if (next >= 0) {
+                        if (!jt.e0) { HIPCHK(hipEventCreate(&jt.e0)); HIPCHK(hipEventCreate(&jt.e1)); }
+                        tuned = next; jt.pending = next;
+                        HIPCHK(hipEventRecord(jt.e0, c->stream));
+                    } else {
+                        jt.best = 0;
+                        for (int v = 1; v < 3; v++) if (jt.ms[v] > 0.0f && jt.ms[v] < jt.ms[jt.best]) jt.best = v;
+                        if (getenv("MTB_JOIN_VERBOSE")) fprintf(stderr, "mtb: join tuned for this index and batch size: q1w6 %.2f ms, q2w5 %.2f ms, window %.2f ms -> %s\n", jt.ms[0], jt.ms[1], jt.ms[2],
+                                                                jt.best == 0 ? "q1w6" : jt.best == 1 ? "q2w5" : "window");
+                    }
+                }
+                if (tuned < 0 && jt.best >= 0) tuned = jt.best;
+            }
+            if (tuned >= 0) { win = tuned == 2; join_variant = tuned == 1 ? 0x25 : 0; }
             if (win) {
                 hipLaunchKernelGGL((k_join_dir<true, 0, 1, 5, true>), dim3((uint32_t)((n + qt - 1) / qt)), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix),
                                    (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1), qt);
@@ -766,6 +803,7 @@ static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint6
             default: MTB_LAUNCH_JV(MTB_JOIN_DIR_QPT0, MTB_JOIN_WAVES); break;
             }
 #undef MTB_LAUNCH_JV
+            if (jt.pending >= 0 && tuned == jt.pending) HIPCHK(hipEventRecord(jt.e1, c->stream));
         }
         else hipLaunchKernelGGL((k_join_dir<false>), dim3(g2), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1));
     } else
