@@ -194,6 +194,13 @@ __global__ __launch_bounds__(256) void k_index_unpack(uint64_t *__restrict__ val
 #ifndef MTB_JOIN_EXACT_MIN
 #define MTB_JOIN_EXACT_MIN 8          /* diagnostics (k_join_run_hist): runs beyond this length count as long when a query finds its own DNA part in them */
 #endif
+#ifndef MTB_JOIN_LOCKSTEP_MIN
+#define MTB_JOIN_LOCKSTEP_MIN 0       /* experiment build switch (round 5): groups of at least this many lanes that hold the SAME long run walk it in lockstep (the wave loads the
+                                       * run once per pass, every lane evaluates every target against its own query) instead of one wave scan per query.  Exact
+                                       * (test_queries_that_share_a_long_run..., also run with -DMTB_JOIN_LOCKSTEP_MIN=3 on the emulated build), but SLOWER at 3: held-out
+                                       * reads' join 47 -> 71 ms per 2 M reads, headline 73 -> 82 -- a wave scan spends run / 64 steps on a query with all 64 lanes busy, the
+                                       * lockstep walk 2 x run serial steps with only the group's lanes busy.  0 = off */
+#endif
 #ifndef MTB_JOIN_COOP_MIN
 #define MTB_JOIN_COOP_MIN 32          /* default of JoinSegArgs::coop_min; MTB_JOIN_COOP_MIN=<n> in the environment of mtb_ctx_create overrides it (A/B runs) */
 #endif
@@ -518,6 +525,82 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
         const unsigned long long room = sa.ovf_stripes ? sa.ovf_region : sa.ovf_cap;
         if (o < room) sa.ovf[(uint64_t)stripe * sa.ovf_region + o] = mm; else *overflow = 1;
     };
+#if MTB_JOIN_LOCKSTEP_MIN > 0
+    /* EXPERIMENT, compiled out by default (measured slower, see MTB_JOIN_LOCKSTEP_MIN above).  Long runs SHARED by lanes of the wave, walked in lockstep.  The queries are sorted, so the queries that meet one long run -- an
+     * amino-acid 8-mer of a conserved protein, hit by every read that covers it -- sit next to each other: with reads of organisms that are
+     * not in the index (no equal target: nothing is skipped) most of a wave's 64 lanes hold the SAME run of a thousand or more targets, and
+     * the scan below took them one query at a time (42 % of the join's cycles on such reads).  Here the wave loads the run once per pass,
+     * 64 targets per step (coalesced), and hands every target to all the lanes of the group (readlane): each lane evaluates it against its
+     * OWN query -- first pass: the query's minimum hamming sum, second pass: the candidates within its threshold, emitted as the per-lane
+     * loop at the end of the kernel emits them (index order: the first one takes the ordinal slot). */
+#pragma unroll
+    for (int u = 0; u < Q; u++) {
+        uint64_t todo = __ballot(lng[u]);
+        while (todo) {
+            const int src = __ffsll((unsigned long long)todo) - 1;
+            const uint64_t s0 = wave_bcast64(lo[u], src), e = wave_bcast64(e_hi[u], src);
+            const bool mine = lng[u] && lo[u] == s0 && e_hi[u] == e;
+            const uint64_t grp = __ballot(mine);
+            todo &= ~grp;
+            if (__popcll(grp) < MTB_JOIN_LOCKSTEP_MIN) continue;     /* small groups: the wave's scan below */
+#if defined(MTB_GROUP_DEBUG) && !defined(__AMDGCN__)             /* emulated build only (tests/hipemu): how often the lockstep walk runs */
+            if (lane == (uint32_t)src) { static unsigned long n_grp = 0, n_q = 0; n_grp++; n_q += (unsigned long)__popcll(grp); if ((n_grp & (n_grp - 1)) == 0) fprintf(stderr, "lockstep groups so far: %lu (%lu queries)\n", n_grp, n_q); }
+#endif
+            mtb_qrows qr; mtb_prepare_query_rows(s_hr, k[u].value, &qr);
+            uint32_t mn = 255u;
+            for (uint64_t t0 = s0; t0 < e; t0 += 64) {
+                const uint64_t t = t0 + lane;
+                const uint64_t v = t < e ? rdv(t) : 0ull;
+                const uint32_t nstep = e - t0 < 64 ? (uint32_t)(e - t0) : 64u;
+                for (uint32_t j = 0; j < nstep; j++) {
+                    const uint32_t td = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)j) & 0xFFFFFFu;
+                    if (mine) { const uint32_t h = mtb_ham_sum(&qr, td); mn = h < mn ? h : mn; }
+                }
+            }
+            const uint32_t thr = mtb_ham_threshold(mn);
+            const uint32_t r = mine ? mtb_q_seq(k[u].qinfo) - 1 : 0u;
+            const uint32_t ord = mtb_q_pos(k[u].qinfo) >> 16;
+            const uint64_t qinfo = k[u].qinfo & ~0xFFFF0000ull;
+            const bool rev = mtb_hammings_reversed(mtb_q_frame(qinfo), ix.kmer_format);
+            uint32_t direct = sa.direct, tcap = tail_cap;
+            mtb_slot16 *seg = sa.seg;
+            if (mine) {
+                if (LONG) { direct = sa.dcnt[r]; tcap = mtb_lslot_tail(direct, sa.tf); seg = sa.seg + sa.rb[r]; }
+                else seg = sa.seg + (uint64_t)r * sa.stride;
+            }
+            const bool offr = mine && !LONG && sa.off && sa.off[r];
+            bool first = mine && ord < direct && !offr;
+            for (uint64_t t0 = s0; t0 < e; t0 += 64) {
+                const uint64_t t = t0 + lane;
+                const uint64_t v = t < e ? rdv(t) : 0ull;
+                const uint32_t info_l = (!PACKED && t < e) ? ix.info[t] : 0u;
+                const uint32_t nstep = e - t0 < 64 ? (uint32_t)(e - t0) : 64u;
+                for (uint32_t j = 0; j < nstep; j++) {
+                    const uint32_t vlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)j), vhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)j);
+                    const uint32_t inf = PACKED ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)info_l, (int)j);
+                    const uint32_t td = vlo & 0xFFFFFFu;
+                    if (!mine) continue;
+                    const uint32_t h = mtb_ham_sum(&qr, td);
+                    if (h > thr) continue;
+                    const uint64_t vv = ((uint64_t)vhi << 32) | vlo;
+                    const int32_t tid = (int32_t)((PACKED ? (uint32_t)(vv >> MTB_PACK_LOW) : inf) & ix.info_mask);
+                    const int32_t sp = (tid >= 0 && tid <= ix.max_taxid) ? ix.tax2species[tid] : 0;
+                    const uint16_t reh = mtb_hammings(&qr, td, rev);
+                    if (first) { const mtb_slot16 sl = LONG ? mtb_lslot_pack(qinfo, tid, sp, td, reh, h) : mtb_slot_pack(qinfo, tid, sp, td, reh, h, sa.epoch);
+                                 MTB_SLOT_STORE(sl, &seg[ord]); first = false; continue; }
+                    const uint32_t at = offr ? (atomicAdd(&sa.cursor[r], tcap + 1u), tcap) : atomicAdd(&sa.cursor[r], 1u);
+                    if (at < tcap) { const mtb_slot16 sl = LONG ? mtb_lslot_pack(qinfo, tid, sp, td, reh, h) : mtb_slot_pack(qinfo, tid, sp, td, reh, h, sa.epoch);
+                                     MTB_SLOT_STORE(sl, &seg[direct + at]); }
+                    else {
+                        mtb_match m; m.qinfo = qinfo; m.target_id = tid; m.species_id = sp; m.dna = td; m.right_end_hamming = reh; m.hamming = (uint8_t)h; m.pad = 0;
+                        ovf_put(m);
+                    }
+                }
+            }
+            if (mine) lng[u] = false;
+        }
+    }
+#endif
     /* wave-scanned runs: one pass (minimum + the few candidates that can be selected, kept in registers), then emission -- the selected
      * candidate with the lowest index takes the query's ordinal slot, the others the read's tail (ONE returning atomic per step for all
      * of them), beyond that the overflow list: the contract of the per-lane loop below */

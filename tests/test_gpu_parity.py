@@ -870,6 +870,38 @@ def test_long_candidate_runs_are_scanned_by_the_wave(orc, tmp_path, seq_mode, de
     ix.close(); c.close()
 
 
+@pytest.mark.parametrize("seq_mode", [1, 3])
+def test_queries_that_share_a_long_run_walk_it_in_lockstep(orc, tmp_path, seq_mode, monkeypatch):
+    """k_join_dir: sorted queries that meet the SAME long candidate run sit in neighbouring lanes.  High coverage of the genome that carries
+    the hot metamers (every hot metamer is met by several reads) with read errors (queries without an equal target): the per-read
+    answers and the match totals are the oracle's -- short reads into fixed slot segments (packed words, LDS window forced on and off),
+    long reads into slot ranges.  (Written for the lockstep walk of shared runs, an experiment that is compiled out because it measured
+    slower -- kernels_dir.h, MTB_JOIN_LOCKSTEP_MIN; with -DMTB_JOIN_LOCKSTEP_MIN=3 on the emulated build it exercises that walk, by default
+    the wave scan of many neighbouring queries with one run.)"""
+    import metabuli_amd as M
+    from conftest import HotToy
+    t = HotToy(orc, tmp_path / "db", seq_mode=seq_mode, n_reads=60 if seq_mode == 3 else 3000, length=4000 if seq_mode == 3 else 150,
+               lognormal=False, err=0.02, n_hot=90)
+    monkeypatch.setenv("MTB_DIR_DEPTH", "7")
+    c = M.Context(0)
+    p = M.default_params(seq_mode=seq_mode, syncmer=1)
+    ix = c.open_index(t.dbdir, p)
+    monkeypatch.delenv("MTB_DIR_DEPTH", raising=False)
+    ro = t.ref["results"]
+    amb = ro["flag"] != 0
+    for win in (("1", "0") if seq_mode == 1 else ("0",)):
+        monkeypatch.setenv("MTB_JOIN_WIN", win)
+        res, tt, tc = c.classify_batch(ix, p, t.b1, t.o1, t.b2, t.o2)
+        assert ((res["classification"] == ro["classification"]) | amb).all(), win
+        assert ((res["score"].view(np.uint32) == ro["score"].view(np.uint32)) | amb).all(), win
+        assert ((res["n_taxcnt"] == ro["n_taxcnt"]) | amb).all(), win
+        if not amb.any():
+            assert (tt == t.ref["tc_tax"]).all() and (tc == t.ref["tc_cnt"]).all(), win
+        if seq_mode != 3:
+            assert c.last_stats().n_matches == len(t.ref["matches"]), win
+    ix.close(); c.close()
+
+
 @pytest.mark.parametrize("seq_mode", [1, 2])
 def test_target_windows_staged_in_lds_give_the_same_matches(orc, tmp_path, seq_mode, monkeypatch):
     """k_join_dir<.., WIN>: a workgroup.s tile of sorted queries stages the span of the target array between its first and its last bucket in
