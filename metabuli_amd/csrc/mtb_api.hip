@@ -132,7 +132,7 @@ struct mtb_ctx {
      * earlier) is still waiting for its classify call, so TWO prefetches are outstanding for a moment -- with a single record classify(k)
      * found batch k+1's key, discarded it and uploaded k again */
     struct Prefetched { const void *key = nullptr, *key2 = nullptr; uint64_t n_reads = 0; bool valid = false; } pre[2];
-    struct JoinTune { uint64_t key = 0; int calls = 0, pending = -1, best = -1; float ms[3] = {0.0f, 0.0f, 0.0f}; hipEvent_t e0 = nullptr, e1 = nullptr; } join_tune;      /* dev_join: the short-read instantiation that is fastest for this index and batch size */
+    struct JoinTune { uint64_t key = 0; int calls = 0, pending = -1, best = -1; float ms[3] = {0.0f, 0.0f, 0.0f}; hipEvent_t e0 = nullptr, e1 = nullptr; } join_tunes[4]; uint32_t join_tune_next = 0;      /* dev_join: the short-read instantiation that is fastest for this index and batch size */
     uint64_t many_stats[4] = {0, 0, 0, 0};           /* last slot-path batch: reads deferred by the first scoring launches, of those scored by k_score_many, their matches, the survivors of the dead-species drop */
     uint32_t lslot_tf_start = 1;                     /* long-read slot ranges: tail factor the next batch starts with (1 = a quarter of the metamers, 4 = all) */
     uint32_t join_coop_min = MTB_JOIN_COOP_MIN;      /* k_join_dir: runs longer than this are scanned by the whole wave; MTB_JOIN_COOP_MIN in the environment at mtb_ctx_create */
@@ -394,7 +394,7 @@ void mtb_ctx_destroy(mtb_ctx *c) {
     if (c->down_done) e = hipEventDestroy(c->down_done);
     if (c->copy_stream) { e = hipStreamSynchronize(c->copy_stream); e = hipStreamDestroy(c->copy_stream); }
     for (int k = 0; k < 2; k++) { if (c->copy_done[k]) e = hipEventDestroy(c->copy_done[k]); if (c->unpacked[k]) e = hipEventDestroy(c->unpacked[k]); }
-    if (c->join_tune.e0) { e = hipEventDestroy(c->join_tune.e0); e = hipEventDestroy(c->join_tune.e1); }
+    for (int q = 0; q < 4; q++) if (c->join_tunes[q].e0) { e = hipEventDestroy(c->join_tunes[q].e0); e = hipEventDestroy(c->join_tunes[q].e1); }
     for (int i = 0; i < 8; i++) e = hipEventDestroy(c->ev[i]);
     for (auto &k : c->kev) { e = hipEventDestroy(k.a); e = hipEventDestroy(k.b); }
     for (auto &x : c->ev_pool) e = hipEventDestroy(x);
@@ -762,12 +762,15 @@ static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint6
              * so a context TRIES them on its first batches against an index (second to fourth join of that shape: one instantiation each,
              * timed with a pair of events) and keeps the fastest.  MTB_JOIN_VARIANT / MTB_JOIN_WIN in the environment switch the choice off. */
             const bool forced = getenv("MTB_JOIN_VARIANT") || getenv("MTB_JOIN_WIN");
-            mtb_ctx::JoinTune &jt = c->join_tune;
+            /* (a few (index, batch size) shapes are remembered: a host that alternates workloads -- bench.py's legs -- does not tune again) */
+            uint32_t lg_n = 0; for (uint64_t x = n; x > 1; x >>= 1) lg_n++;
+            const uint64_t tune_key = (uint64_t)(uintptr_t)ix ^ ((uint64_t)lg_n << 56) ^ (ix->T << 8);
+            int slot = -1;
+            for (int q = 0; q < 4; q++) if (c->join_tunes[q].key == tune_key) slot = q;
+            if (slot < 0) { slot = (int)(c->join_tune_next++ & 3u); const hipEvent_t k0 = c->join_tunes[slot].e0, k1 = c->join_tunes[slot].e1; c->join_tunes[slot] = mtb_ctx::JoinTune(); c->join_tunes[slot].key = tune_key; c->join_tunes[slot].e0 = k0; c->join_tunes[slot].e1 = k1; }
+            mtb_ctx::JoinTune &jt = c->join_tunes[slot];
             int tuned = -1;                                  /* 0: one query per thread, 6 waves; 1: two per thread, 5 waves; 2: the window */
             if (!forced && !c->is_lane) {
-                uint32_t lg = 0; for (uint64_t x = n; x > 1; x >>= 1) lg++;
-                const uint64_t key = (uint64_t)(uintptr_t)ix ^ ((uint64_t)lg << 56) ^ (ix->T << 8);
-                if (jt.key != key) { const hipEvent_t k0 = jt.e0, k1 = jt.e1; jt = mtb_ctx::JoinTune(); jt.key = key; jt.e0 = k0; jt.e1 = k1; }
                 if (jt.pending >= 0) {                       /* the previous join's time (that batch is long finished) */
                     float ms = 0.0f;
                     if (hipEventElapsedTime(&ms, jt.e0, jt.e1) == hipSuccess && ms > 0.0f) jt.ms[jt.pending] = ms; else { (void)hipGetLastError(); jt.ms[jt.pending] = 1e30f; }
