@@ -636,6 +636,11 @@ def test_database_opens_chunk_by_chunk(orc, tmp_path, monkeypatch, chunk, packed
     c.close()
 
 
+def _bench_script(root):
+    """bench.py -- or, when the tests run against the emulated library build (tests/hipemu), the wrapper that hands bench.main() a CPU device"""
+    return os.path.join(root, "tests", "hipemu", "bench_emulated.py") if os.environ.get("MTB_HIPEMU") else os.path.join(root, "bench.py")
+
+
 _needs_device = pytest.mark.skipif(bool(os.environ.get("MTB_HIPEMU")), reason="needs a HIP device of its own (torch device tensors / a hipcc build); not part of the emulated run (tests/hipemu)")
 
 
@@ -1105,7 +1110,7 @@ def test_bench_path_matches_the_oracle(tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for mode in (1, 2):
-        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--reads", "20000", "--targets", "3e6",
+        out = subprocess.run([sys.executable, _bench_script(root), "--steps", "1", "--warmup", "0", "--reads", "20000", "--targets", "3e6",
                               "--cpu-reads", "20000", "--cpu-stride", "4", "--species", "8", "--genome-len", "150000", "--filler-species", "3000",
                               "--leg-pairs", "3000", "--leg-long", "40", "--leg-long-len", "3000", "--full-parity-reads", "3000",
                               "--seq-mode", str(mode)], capture_output=True, text=True, timeout=900)
@@ -1131,7 +1136,7 @@ def test_bench_heavy_tailed_workload_in_small(tmp_path):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--reads", "100000", "--targets", "2.5e8",
+    out = subprocess.run([sys.executable, _bench_script(root), "--steps", "1", "--warmup", "0", "--reads", "100000", "--targets", "2.5e8",
                           "--cpu-reads", "30000", "--cpu-stride", "8", "--species", "200", "--genome-len", "600000", "--filler-species", "5000",
                           "--leg-pairs", "20000", "--leg-long", "100", "--leg-long-len", "5000", "--leg-novel", "30000", "--heldout", "20", "--long-parity-reads", "40", "--full-parity-reads", "4000", "--no-cpu"],
                          capture_output=True, text=True, timeout=1500)
