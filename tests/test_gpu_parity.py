@@ -875,6 +875,44 @@ def test_long_candidate_runs_are_scanned_by_the_wave(orc, tmp_path, seq_mode, de
     ix.close(); c.close()
 
 
+@pytest.mark.parametrize("shape", ["more species than the wave's table", "more survivors than the workgroup sorts"])
+def test_deferred_reads_beyond_a_tier_fall_to_the_next(orc, tmp_path, shape):
+    """The three tiers of the reads the slot scorers defer (kernels_score_many.h): `k_score_many` (a wave: <= 768 species, <= 192 survivors),
+    `k_many_sort` + `k_score_long<4096, 1024>` (a workgroup: <= 3072 species, <= 4096 survivors), exact segments sorted in HBM (anything).
+    (a) a conserved protein filed sparsely under 2600 species: a read meets more species than the wave's table holds and is handed to the
+    workgroup kernel; (b) filed under 680 species in full: a read brings more than 4096 matches that all survive the dead-species drop and
+    goes on to the exact-segment path.  Results = the oracle's either way; the statistics say which way the reads went."""
+    import metabuli_amd as M
+    from conftest import HotToy
+    if shape.startswith("more species"):
+        t = HotToy(orc, tmp_path / "db", seq_mode=1, n_reads=120, n_hot=2600, keep=0.06)
+    else:
+        t = HotToy(orc, tmp_path / "db", seq_mode=1, n_reads=120, n_hot=680)
+    per_read = np.bincount((t.ref["matches"]["qinfo"] >> np.uint64(32)).astype(np.int64) & 0x1FFFFFFF, minlength=t.n_reads + 1)[1:]
+    c = M.Context(0)
+    p = M.default_params(seq_mode=1, syncmer=1)
+    ix = c.open_index(t.dbdir, p)
+    res, tt, tc = c.classify_batch(ix, p, t.b1, t.o1)
+    ro = t.ref["results"]
+    amb = ro["flag"] != 0
+    assert ((res["classification"] == ro["classification"]) | amb).all()
+    assert ((res["score"].view(np.uint32) == ro["score"].view(np.uint32)) | amb).all()
+    assert ((res["n_taxcnt"] == ro["n_taxcnt"]) | amb).all()
+    if not amb.any():
+        assert (tt == t.ref["tc_tax"]).all() and (tc == t.ref["tc_cnt"]).all()
+    st = c.last_stats()
+    assert st.n_matches == len(t.ref["matches"]) and st.n_deferred_reads > 10
+    if shape.startswith("more species"):
+        sp = t.ref["matches"]["species_id"]; rd = (t.ref["matches"]["qinfo"] >> np.uint64(32)).astype(np.int64) & 0x1FFFFFFF
+        n_sp = np.array([len(np.unique(sp[rd == r + 1])) for r in np.flatnonzero(per_read > 700)[:20]])
+        assert len(n_sp) and n_sp.max() > 768, n_sp                      # beyond the 1024-entry table's 3/4
+        assert st.n_many_reads == st.n_deferred_reads                    # ... and the workgroup kernel took them
+    else:
+        assert per_read.max() > 4096
+        assert st.n_many_reads < st.n_deferred_reads                     # some reads went all the way to the exact segments
+    ix.close(); c.close()
+
+
 @pytest.mark.parametrize("seq_mode", [1, 3])
 def test_queries_that_share_a_long_run_walk_it_in_lockstep(orc, tmp_path, seq_mode, monkeypatch):
     """k_join_dir: sorted queries that meet the SAME long candidate run sit in neighbouring lanes.  High coverage of the genome that carries
