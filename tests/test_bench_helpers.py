@@ -114,3 +114,31 @@ def test_closure_positions_hold_every_candidate_and_the_last_entry(stride):
 def test_histogram_quantiles():
     q = bench.hist_summary([90, 5, 3, 1, 0, 0, 1])
     assert q["p50"] == 1 and q["p90"] == 1 and q["p99"] == 15 and q["max_bin_upper"] == 127 and q["n"] == 100
+
+
+def test_headline_line_is_short_whatever_the_detail_holds():
+    """the driver's line is built from a fixed set of keys: prose, histograms and per-kernel tables of the full record never reach it"""
+    import json
+    import bench
+    big = "x" * 4000
+    leg = dict(workload=big, reads=2_000_000, read_len=150, seq_mode=1, ms_per_step=80.123456, mreads_per_s=25.0, gbp_per_s=3.75, sub_batches=1,
+               stage_ms=dict(extract=1.0, sort=2.0, join=3.0, order=0.0, score=4.0, total=10.0), kernel_ms={f"k{i}": dict(ms=1.0, launches=1) for i in range(40)},
+               roofline=dict(frac=1.45, note=big), parity=dict(reads=16384, mismatches=0, index=big, dead_matches=dict(note=big)), query_runs=dict(note=big))
+    out = dict(metric="Mreads/s classified", value=62.123456789, unit="Mreads/s", n_gpus=1, steps=20, warmup=5, ms_per_step=160.6, higher_is_better=True, scaling="weak",
+               vs_baseline=None, dtype="u64", data="synthetic",
+               config=dict(workload="10M x 150 bp ...", reads_per_gpu=10_000_000, read_len=150, targets=16_000_000_000, seq_mode=1, gbp_per_s=9.3, note=big),
+               stage_ms=dict(extract=13.5, sort=30.7, join=73.7, regroup=0.0, segsort=0.0, score=42.7, total=160.6), kernel_ms=leg["kernel_ms"],
+               roofline=dict(bound="hbm", kernel="join", achieved=3270.0, peak=8000.0, unit="GB/s", frac=0.41, traffic=1.527e11, effective=0.26, write_amplification=2.13,
+                             avg_launch_ms=74.2, launches=1, algorithmic_bytes_per_launch=2.4268e11, peak_measured=4950.0, note=big, traffic_note=big, footprint=dict(note=big)),
+               roofline_all={f"k{i}": dict(ms=1.0, note=big) for i in range(20)}, join_footprint=dict(note=big), run_lengths=dict(index=dict(note=big), queries=dict(note=big)),
+               best_case=dict(leg), other_configs=dict(paired=dict(leg), long=dict(leg), novel=dict(leg)),
+               cpu_baseline=dict(value=0.118, unit="Mreads/s", cores=256, kind="port", sample="first 1000000 reads ...", cpu_model="AMD EPYC 9575F", single_thread_value=0.0108,
+                                 index_targets=1_320_000_000, numa={f"node{i}": big for i in range(8)}, stage_seconds=dict(match=7.0), cold_cache_note=big),
+               parity_sample=dict(reads=1_000_000, mismatches=0, matches=125_845_141, oracle_matches=125_845_141, ambiguous_excluded=0, index=big, dead_matches=dict(note=big)),
+               ranks=[dict(rank=i, library=big) for i in range(8)], deferred_reads=dict(note=big), ab=None)
+    text = json.dumps(bench.headline(out, "bench_detail.json"))
+    assert len(text) < 4096 and big[:100] not in text
+    line = json.loads(text)
+    assert line["roofline"]["frac"] == 0.41 and line["cpu_baseline"]["cores"] == 256 and line["parity_sample"]["mismatches"] == 0
+    assert set(line["other_configs"]) == {"paired", "long", "novel", "best_case"} and "roofline" not in line["other_configs"]["long"]
+    assert line["detail"] == "bench_detail.json" and line["value"] == 62.12346

@@ -123,3 +123,44 @@ def test_bench_line_of_two_ranks_on_the_emulator(emulated_lib, tmp_path):
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak" and line["unit"] == "Mreads/s"
     assert abs(line["value"] - 2 * 3000 * 2 / (line["ms_per_step"] * 2 / 1e3) / 1e6) < 1e-6 * max(1.0, line["value"])      # whole-job reads / max-over-ranks time
     assert line["config"]["classified_fraction"] > 0.5 and {"bound", "achieved", "peak", "frac", "traffic"} <= set(line["roofline"])      # (which kernel dominates is the executor's business)
+
+
+def test_bench_line_with_every_leg_stays_under_8_kb(emulated_lib, tmp_path):
+    """the driver could not parse round 5's 20.6 KB line.  bench.py with EVERY leg on (pairs, long reads, 24-genome reads,
+    held-out genomes; parity samples and the CPU baseline too) on the emulated build: ONE JSON line on stdout, shorter than 8 KB, with the
+    contract's keys and the short forms of roofline / cpu_baseline / parity_sample / other_configs; the histograms, footprints, notes and
+    per-kernel tables are in bench_detail.json (working directory), named by the line; no `frac` above 1 anywhere."""
+    import json
+    env = dict(os.environ, MTB_HIPEMU="1", MTB_LIB=emulated_lib, HIPEMU_THREADS="4")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hipemu", "bench_emulated.py"), "--steps", "1", "--warmup", "1", "--reads", "3000", "--targets", "3e6",
+                        "--species", "200", "--genome-len", "12000", "--filler-species", "2000", "--leg-pairs", "1000", "--leg-long", "40", "--leg-long-len", "3000",
+                        "--leg-novel", "1000", "--heldout", "20", "--cpu-reads", "1000", "--full-parity-reads", "256", "--long-parity-reads", "20"],
+                       env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out_lines = [ln for ln in r.stdout.split("\n") if ln.strip()]
+    assert len(out_lines) == 1, r.stdout[-2000:]
+    assert len(out_lines[0]) < 8192, len(out_lines[0])
+    line = json.loads(out_lines[0])
+    assert {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+            "roofline", "cpu_baseline", "parity_sample", "other_configs", "stage_ms", "detail"} <= set(line)
+    assert {"bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches", "algorithmic_bytes_per_launch"} <= set(line["roofline"])
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(line["cpu_baseline"]) and line["cpu_baseline"]["kind"] == "port"
+    assert line["parity_sample"]["mismatches"] == 0 and line["parity_sample"]["matches"] == line["parity_sample"]["oracle_matches"]
+    assert set(line["other_configs"]) == {"paired", "long", "best_case", "novel"}
+    for name, leg in line["other_configs"].items():
+        assert "frac" not in leg and leg["ms_per_step"] > 0
+        if name != "best_case":
+            assert leg["parity"]["mismatches"] == 0
+    detail = json.load(open(tmp_path / line["detail"]))
+    assert detail["value"] == pytest.approx(line["value"], rel=1e-5) and "roofline_all" in detail and "run_lengths" in detail
+
+    def fracs(x):
+        if isinstance(x, dict):
+            for k, v in x.items():
+                if k.startswith("frac") and isinstance(v, (int, float)):
+                    yield v
+                yield from fracs(v)
+        elif isinstance(x, list):
+            for v in x:
+                yield from fracs(v)
+    assert all(f <= 1.0 for f in fracs(detail)), [f for f in fracs(detail) if f > 1.0]
