@@ -755,7 +755,7 @@ def headline(out, detail_path):
     if out.get("best_case"):
         legs["best_case"] = out["best_case"]
     for name, e in legs.items():
-        o = _pick(e, ("reads", "read_len", "seq_mode", "ms_per_step", "mreads_per_s", "gbp_per_s", "sub_batches"))
+        o = _pick(e, ("reads", "read_len", "seq_mode", "ms_per_step", "mreads_per_s", "gbp_per_s", "sub_batches", "join_variant"))
         if e.get("stage_ms"):
             o["join_ms"] = e["stage_ms"].get("join"); o["score_ms"] = e["stage_ms"].get("score")
         if e.get("parity"):
@@ -1070,9 +1070,10 @@ def main(device=None):
         import ctypes
         pc = (ctypes.c_ulonglong * 24)()
         M.lib().mtb_debug_phase_cycles(ctx.h, pc)
-        jt = max(1, sum(pc[16:21]))
+        jt = max(1, sum(pc[16:23]))
         log("[rank 0] k_join_dir phase cycles (thread 0 of every workgroup): " + ", ".join(
-            f"{n} {100.0 * pc[16 + i] / jt:.1f} %" for i, n in enumerate(("queries + directory", "bisection", "run ends", "wave-scanned runs", "per-lane evaluation + emission"))))
+            f"{n} {100.0 * pc[16 + i] / jt:.1f} %" for i, n in enumerate(("(rest)", "bisection", "run ends", "wave-scanned runs", "per-lane evaluation + emission",
+                                                                         "queries + directory (+ window bounds)", "window staged + barrier"))))
     if hasattr(M.lib(), "mtb_debug_fast_reasons"):        # debugging build (MTB_LIB=.../libmtb_dbg.so): why reads leave the register-resident scorer
         import ctypes
         fr = (ctypes.c_ulonglong * 32)()
@@ -1098,8 +1099,7 @@ def main(device=None):
     def ab_legs(tag, fn, n_reads_leg):
         for setting in [x for x in args.ab.split(";") if "=" in x]:
             k, v = setting.split("=", 1)
-            old = os.environ.get(k)
-            os.environ[k] = v
+            ctx.set_option(k, v)                     # (the library reads its environment once, at mtb_ctx_create: a live context is switched through mtb_ctx_set_option)
             try:
                 ms = timed_leg(torch, fn, 1, 3)      # (a forced switch turns the tuner off; the shapes' tuned choices are remembered)
                 s2 = ctx.last_stats()
@@ -1107,10 +1107,7 @@ def main(device=None):
                                                        stage_ms=dict(extract=s2.ms_extract, sort=s2.ms_sort, join=s2.ms_join, score=s2.ms_score, total=s2.ms_total))
                 log(f"[rank 0] A/B {tag} {setting}: {ms:.1f} ms per step (join {s2.ms_join:.1f}, score {s2.ms_score:.1f})")
             finally:
-                if old is None:
-                    del os.environ[k]
-                else:
-                    os.environ[k] = old
+                ctx.set_option(k, os.environ.get(k))
         if args.ab:
             ms = timed_leg(torch, fn, 1, 3)
             s2 = ctx.last_stats()
@@ -1140,6 +1137,7 @@ def main(device=None):
                      stage_ms=dict(extract=ls.ms_extract, sort=ls.ms_sort, join=ls.ms_join, order=ls.ms_regroup + ls.ms_segsort, score=ls.ms_score, total=ls.ms_total),
                      query_metamers=int(ls.n_kmers), matches=int(ls.n_matches), classified_fraction=float((lres["is_classified"] != 0).mean()),
                      reads_scored_by_generic_kernel=int(ls.n_generic_reads),
+                     join_variant=M.JOIN_VARIANTS.get(int(ls.join_variant), str(ls.join_variant)) + (" (tuned)" if ls.join_tuned else ""),
                      reads_deferred=int(ls.n_deferred_reads), reads_scored_by_k_score_many=int(ls.n_many_reads),
                      join_ms_per_G_query_metamers=ls.ms_join / max(1, ls.n_kmers) * 1e9,
                      headline_join_ms_per_G_query_metamers=st.ms_join / max(1, st.n_kmers) * 1e9)
@@ -1158,7 +1156,7 @@ def main(device=None):
             entry["parity"] = lpar; entry["mismatches"] = lpar["mismatches"]
             if lpar["mismatches"]:
                 if "MTB_NO_SCORE_MANY" not in os.environ:        # diagnosis before giving up: the same sample with the deferred reads on round 4's exact-segment path
-                    os.environ["MTB_NO_SCORE_MANY"] = "1"
+                    ctx.set_option("MTB_NO_SCORE_MANY", "1")
                     _, lpar2 = oracle_parity(ctx, M, torch, dev, index, lp, taxdir, lg["b"], lg["b2"], lg["read_len"], lg["sub"], T, label=name + " (MTB_NO_SCORE_MANY=1)")
                     log(f"[rank 0] the same sample without k_score_many: {lpar2['mismatches']} mismatches")
                 raise SystemExit(f"parity check of the {name} leg failed: {lpar}")
@@ -1205,6 +1203,9 @@ def main(device=None):
                                gbp_per_s=value * args.read_len * (2 if args.seq_mode == 2 else 1) / 1e3, query_metamers=int(st.n_kmers), matches=int(st.n_matches),
                                classified_fraction=frac_cls, parallelism=f"reads sharded x{world_size}, index replicated", streams_per_gpu=args.streams,
                                sub_batches_per_step=sub_batches_timed, index_sealed=sealed, tuning_steps=tuning_steps,
+                               join_variant=M.JOIN_VARIANTS.get(int(st.join_variant), str(st.join_variant)) + (" (tuned)" if st.join_tuned else ""),
+                               join_tune_ms=dict(zip(("q1w6", "q2w5", "window"), [round(float(x), 2) for x in st.join_tune_ms])),
+                               join_tiles=dict(tiles=int(st.join_tiles), windowed=int(st.join_tiles_windowed), outside=int(st.join_tiles_outside)),
                                index_bytes=int(T * (8 if sealed else 12) + 4 * (21 ** index.state()["dir_depth"] + 1)), species=args.species, genome_len=args.genome_len,
                                conserved_segments=conserved, reads_scored_by_generic_kernel=int(ps.n_generic_reads), reads_on_ordinal_slots=int(ps.n_slot_reads)),
                    stage_ms=dict(extract=st.ms_extract, sort=st.ms_sort, join=st.ms_join, regroup=st.ms_regroup,

@@ -102,14 +102,24 @@ typedef struct {
      * immediately before and after every launch of that kernel.            */
     float    ms_kernel[MTB_NUM_KERNELS];
     uint32_t n_launch[MTB_NUM_KERNELS];
-    uint64_t n_generic_reads;   /* reads the register-resident scorer (k_score_fast) / the workgroup-per-read scorer of long reads (k_score_long) handed to the generic k_score */
+    uint64_t n_generic_reads;   /* reads the register-resident scorer (k_score_fast) / the workgroup-per-read scorer of long reads (k_score_long) handed to the generic k_score (short reads whose tails overflowed are NOT in here: n_deferred_reads) */
     uint64_t n_slot_reads;      /* reads whose matches went through per-read ordinal slots (short reads: fixed segments; long reads: per-read
                                  * ranges ordered by k_seg_order) instead of regroup + segment sort */
     /* short reads on slot segments: reads the first scoring launches deferred (tail overflow, more live records than the staging); of
      * those, the reads k_score_many scored straight from slots + overflow entries; the matches of these reads; and how many of them
      * survived the dead-species drop (Taxonomer.cpp:342: a species without a (species, frame) group of two never scores) */
     uint64_t n_deferred_reads, n_many_reads, n_many_matches, n_many_kept;
+    /* the short-read join on packed words: which exact instantiation ran on the (last sub-)batch (mtb_join_variant; 0 = another join path,
+     * negative = an A/B-only instantiation), whether the context's tuner chose it (1) or it was the default / pinned / still being tuned (0),
+     * and the tuner's timings of {q1w6, q2w5, window} for this (index, batch size) so far (0 = not timed).  Window variant: tiles launched, tiles
+     * whose target window was staged in LDS, tiles that found a query outside the announced window (0 while the list is sorted). */
+    int32_t  join_variant, join_tuned;
+    float    join_tune_ms[3];
+    uint32_t join_tiles, join_tiles_windowed, join_tiles_outside;
 } mtb_batch_stats;
+
+/* the exact instantiations of the short-read join (kernels_dir.h) */
+typedef enum { MTB_JOIN_AUTO = 0, MTB_JOIN_Q1W6 = 1, MTB_JOIN_Q2W5 = 2, MTB_JOIN_WINDOW = 3 } mtb_join_variant;
 
 const char *mtb_version(void);
 const char *mtb_last_error(void);
@@ -140,6 +150,16 @@ mtb_status mtb_ctx_set_workspace_limit(mtb_ctx *, uint64_t bytes);
  * search on, a new buffer is picked among a few candidate allocations by a random-store probe (one-time 0.6 - 3.8 s).  Off by
  * default: a process that allocates through this library only gets the good placement from the first hipMalloc. */
 mtb_status mtb_ctx_set_placement_probe(mtb_ctx *, int on);
+/* The short-read join has three exact instantiations (sector-random lookups with one or two queries per thread, LDS-staged target windows);
+ * by default (MTB_JOIN_AUTO) a context times them on its second to fourth batch of an (index, batch size) shape and keeps the fastest.  This
+ * pins one of them (mtb_join_variant) or hands the choice back to the tuner; results are identical either way.  What ran, and the tuner's
+ * timings, are in mtb_batch_stats (join_variant, join_tuned, join_tune_ms).  No reference counterpart (KmerMatcher.cpp:363-416 is one loop). */
+mtb_status mtb_ctx_set_join_variant(mtb_ctx *, int variant);
+/* Experiment / diagnosis switches (metabuli_amd/csrc/mtb_options.h lists them: MTB_JOIN_WIN, MTB_NO_SCORE_MANY, MTB_DIR_DEPTH, ...).  They are read
+ * from the environment ONCE, by mtb_ctx_create; this sets one on a live context (value NULL = as if the variable were unset).  They select among
+ * exact variants, size buffers or print -- never a result.  An index takes the switches of the context it is opened on at that moment.
+ * MTB_ERR_ARG: unknown name or unparsable value. */
+mtb_status mtb_ctx_set_option(mtb_ctx *, const char *name, const char *value);
 uint32_t   mtb_ctx_last_sub_batches(const mtb_ctx *);
 
 /* ---- index residency ---------------------------------------------------

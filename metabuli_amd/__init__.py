@@ -40,7 +40,12 @@ class BatchStats(C.Structure):
                 ("n_reads", C.c_uint64), ("n_bases", C.c_uint64), ("n_kmers", C.c_uint64),
                 ("n_matches", C.c_uint64), ("n_targets", C.c_uint64),
                 ("ms_kernel", C.c_float * 11), ("n_launch", C.c_uint32 * 11), ("n_generic_reads", C.c_uint64), ("n_slot_reads", C.c_uint64),
-                ("n_deferred_reads", C.c_uint64), ("n_many_reads", C.c_uint64), ("n_many_matches", C.c_uint64), ("n_many_kept", C.c_uint64)]
+                ("n_deferred_reads", C.c_uint64), ("n_many_reads", C.c_uint64), ("n_many_matches", C.c_uint64), ("n_many_kept", C.c_uint64),
+                ("join_variant", C.c_int32), ("join_tuned", C.c_int32), ("join_tune_ms", C.c_float * 3),
+                ("join_tiles", C.c_uint32), ("join_tiles_windowed", C.c_uint32), ("join_tiles_outside", C.c_uint32)]
+
+
+JOIN_VARIANTS = {0: "other", 1: "q1w6", 2: "q2w5", 3: "window", -3: "q1w5", -4: "q2w6"}      # mtb_batch_stats.join_variant (mtb_join_variant)
 
 
 class JoinFootprint(C.Structure):
@@ -162,6 +167,14 @@ class Context:
     def set_workspace_limit(self, nbytes):
         """workspace budget of a batch in bytes (0 = automatic from hipMemGetInfo): forces sub-batches in tests"""
         _chk(self.L.mtb_ctx_set_workspace_limit(self.h, C.c_uint64(int(nbytes))))
+
+    def set_join_variant(self, name):
+        """pin the short-read join's instantiation ("q1w6", "q2w5", "window") or hand the choice back to the context's tuner ("auto")"""
+        _chk(self.L.mtb_ctx_set_join_variant(self.h, C.c_int({"auto": 0, "q1w6": 1, "q2w5": 2, "window": 3}[name])))
+
+    def set_option(self, name, value):
+        """one of the library's experiment switches on this live context (value None = unset); the environment is read once, at creation"""
+        _chk(self.L.mtb_ctx_set_option(self.h, name.encode(), None if value is None else str(value).encode()))
 
     @property
     def last_sub_batches(self):

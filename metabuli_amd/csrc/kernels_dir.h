@@ -194,13 +194,8 @@ __global__ __launch_bounds__(256) void k_index_unpack(uint64_t *__restrict__ val
 #ifndef MTB_JOIN_EXACT_MIN
 #define MTB_JOIN_EXACT_MIN 8          /* diagnostics (k_join_run_hist): runs beyond this length count as long when a query finds its own DNA part in them */
 #endif
-#ifndef MTB_JOIN_LOCKSTEP_MIN
-#define MTB_JOIN_LOCKSTEP_MIN 0       /* experiment build switch (round 5): groups of at least this many lanes that hold the SAME long run walk it in lockstep (the wave loads the
-                                       * run once per pass, every lane evaluates every target against its own query) instead of one wave scan per query.  Exact
-                                       * (test_queries_that_share_a_long_run..., also run with -DMTB_JOIN_LOCKSTEP_MIN=3 on the emulated build), but SLOWER at 3: held-out
-                                       * reads' join 47 -> 71 ms per 2 M reads, headline 73 -> 82 -- a wave scan spends run / 64 steps on a query with all 64 lanes busy, the
-                                       * lockstep walk 2 x run serial steps with only the group's lanes busy.  0 = off */
-#endif
+/* (Round 5's experiment "queries of a wave that share a long run walk it in lockstep" measured slower -- held-out reads' join 47 -> 71 ms per 2 M reads,
+ * headline 73 -> 82 -- and lives in profiles/experiments/join_lockstep_walk.patch, not in this kernel.) */
 #ifndef MTB_JOIN_COOP_MIN
 #define MTB_JOIN_COOP_MIN 32          /* default of JoinSegArgs::coop_min; MTB_JOIN_COOP_MIN=<n> in the environment of mtb_ctx_create overrides it (A/B runs) */
 #endif
@@ -231,12 +226,64 @@ __device__ __forceinline__ uint32_t wave_min_shfl_u32(uint32_t v) {
 #ifndef MTB_WIN_AUX
 #define MTB_WIN_AUX 0                 /* cache policy bits of the window's direct-to-LDS loads (2 = nt: streamed once; A/B build switch) */
 #endif
+#if defined(__AMDGCN__)
+#define MTB_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")       /* direct-to-LDS loads count in vmcnt; the barrier that follows publishes them */
+#else
+#define MTB_WAIT_VMEM() do {} while (0)
+#endif
 #define MTB_JOIN_WINCAP 3968          /* 8-byte words = 31 pieces of 1 KiB (one wave-wide 16-byte direct-to-LDS load each): 31 KB -> five workgroups (20 waves) per CU.
                                        * (A window per WAVE -- 64 queries, 896 words, no workgroup barrier -- measured 81.8 ms against 73.6 for the workgroup's window
                                        * and 80.9 for the sector-random join: a sixth of the waves fell back, profiles/r05_notes.md) */
+/* The windows of the tiles, BEFORE the join (round 6): the queries are sorted on their top (64 - low_bits) bits -- six amino-acid letters
+ * of kmer_format 2, the top 32 bits of format 1 -- so the first and the last record of a tile bound the buckets all its queries can
+ * address: [first bucket with the first record's sort key, last bucket with the last record's sort key].  One thread per tile reads two
+ * records and four directory words and leaves {first word, words} (words = 0: no window, the tile reads global memory).  The join then
+ * STARTS with its window's direct-to-LDS loads and fetches its queries and their directory rows while the window is in flight: one
+ * exposed round trip before the search instead of three dependent ones (queries -> directory -> workgroup minimum / maximum -> window).
+ * The span is that of the exact minimum / maximum widened to whole sort-key groups at both ends (187 targets a group at 16 G targets);
+ * a query whose bucket is not inside it (never, unless the list is not sorted as announced) sends the whole tile to global memory. */
+struct mtb_tile_win { uint64_t first, words; };
+__global__ __launch_bounds__(256) void k_join_tile_win(const mtb_kmer *__restrict__ q, uint64_t n, uint32_t qt, mtb_dir_view dv, uint64_t limit, int low_bits,
+                                                        mtb_tile_win *__restrict__ win, uint32_t n_tiles, unsigned long long *__restrict__ stat) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    const bool live = t < n_tiles;
+    bool windowed = false;
+    if (live) {
+    const uint64_t j0 = (uint64_t)t * qt, j1 = (j0 + qt < n ? j0 + qt : n) - 1;
+    const uint64_t v0 = q[j0].value, v1 = q[j1].value;
+    mtb_tile_win w; w.first = 0; w.words = 0;
+    uint64_t blo, bhi; bool ok = true;
+    if (dv.kmer_format == 1) {
+        const int sh = low_bits - 24;                      /* bits of the amino-acid number below the sort key */
+        const uint64_t a_lo = ((v0 >> 24) >> sh) << sh, a_hi = (v1 >> 24) | ((1ull << sh) - 1ull);
+        blo = a_lo / 21ull; bhi = a_hi / 21ull;
+    } else {
+        uint32_t b0 = 0, b1 = 0;
+        for (int j = 0; j < 6; j++) {
+            const uint32_t l0 = (uint32_t)((v0 >> (59 - 5 * j)) & 31u), l1 = (uint32_t)((v1 >> (59 - 5 * j)) & 31u);
+            ok &= l0 < 21u && l1 < 21u;
+            b0 = b0 * 21u + l0; b1 = b1 * 21u + l1;
+        }
+        blo = (uint64_t)b0 * 21ull; bhi = (uint64_t)b1 * 21ull + 20ull;
+    }
+    if (ok && blo < dv.n_buckets && bhi >= blo) {
+        if (bhi >= dv.n_buckets) bhi = dv.n_buckets - 1;
+        uint64_t a0 = dv.base[blo >> 16] + dv.dir[blo], a1 = dv.base[(bhi + 1) >> 16] + dv.dir[bhi + 1];
+        if (a1 > limit) a1 = limit;
+        a0 &= ~1ull;                                       /* 16-byte aligned pieces */
+        if (a1 > a0 && a1 - a0 <= (uint64_t)MTB_JOIN_WINCAP) { w.first = a0; w.words = a1 - a0; windowed = true; }
+    }
+    win[t] = w;
+    }
+    /* statistics (mtb_batch_stats.join_tiles_windowed): one atomic per wave */
+    const uint64_t m = __ballot(windowed);
+    if ((threadIdx.x & 63u) == 0 && m) atomicAdd(stat, (unsigned long long)__popcll(m));
+}
+
 template <bool PACKED, int MODE = 0, int QPT = ((PACKED && MODE == 0) ? MTB_JOIN_DIR_QPT0 : MTB_JOIN_DIR_QPT), int WAVES = MTB_JOIN_WAVES, bool WIN = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && MODE != 2) ? WAVES : 5))) void k_join_dir(const mtb_kmer *__restrict__ q, uint64_t n, mtb_index_view ix, uint64_t limit, mtb_dir_view dv,
-                                                   const mtb_tables *__restrict__ tabs, JoinSegArgs sa, uint32_t *__restrict__ overflow, uint32_t qt = 256) {
+                                                   const mtb_tables *__restrict__ tabs, JoinSegArgs sa, uint32_t *__restrict__ overflow, uint32_t qt = 256,
+                                                   const mtb_tile_win *__restrict__ tile_win = nullptr, unsigned long long *__restrict__ win_stat = nullptr) {
     constexpr int Q = QPT;
     static_assert(!WIN || (QPT == 1 && PACKED && MODE == 0), "the window variant: short reads, packed words, one query per thread");
     __shared__ __attribute__((aligned(16))) uint64_t s_win[WIN ? MTB_JOIN_WINCAP : 2];
@@ -245,10 +292,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
     auto rdv = [&](uint64_t t) -> uint64_t { return (WIN && use_win) ? s_win[t - w0] : ix.values[t]; };
     constexpr bool LONG = MODE == 1, LIST = MODE == 2;
     const uint64_t AAM = ~0xFFFFFFull;
-    __shared__ uint32_t s_hr[8];                    /* hammingLookup rows as nibble words: the only table the join arithmetic reads */
-    if (threadIdx.x < 8) s_hr[threadIdx.x] = tabs->hamrow[threadIdx.x];
+    __shared__ uint32_t s_hr[8];                    /* hammingLookup rows as nibble words: the only table the join arithmetic reads (filled below, behind the loads that matter) */
     const uint64_t base_q = WIN ? (uint64_t)blockIdx.x * qt : (uint64_t)blockIdx.x * (256 * Q);
     if (WIN && threadIdx.x == 0) { s_w0 = ~0ull; s_w1 = 0ull; }
+    /* the window [a0, a1) -> s_win: 1 KiB pieces, a wave each, straight into LDS (global_load_lds_dwordx4: no staging registers, no wait
+     * between the pieces -- a loop of load / ds_write pairs waited for every load: a dozen dependent round trips per tile, measured 96 ms
+     * against 80 for the random join).  The last piece may reach beyond the window (never read) -- but not beyond the array. */
+    auto stage_window = [&](uint64_t a0, uint64_t a1) {
+        const uint32_t n_piece = (uint32_t)((a1 - a0 + 127) >> 7), wv_ = threadIdx.x >> 6, ln_ = threadIdx.x & 63u;
+        for (uint32_t pc = wv_; pc < n_piece; pc += 4) {
+            const uint64_t src = a0 + ((uint64_t)pc << 7) + 2u * ln_;
+            if (a0 + ((uint64_t)pc << 7) + 128 > ix.n_targets) {           /* the piece that holds the array's end (one per index): plain guarded loads */
+                if (src < ix.n_targets) s_win[((uint64_t)pc << 7) + 2u * ln_] = ix.values[src];
+                if (src + 1 < ix.n_targets) s_win[((uint64_t)pc << 7) + 2u * ln_ + 1] = ix.values[src + 1];
+                continue;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ix.values + src),
+                                             (__attribute__((address_space(3))) void *)(s_win + ((uint64_t)pc << 7)), 16, 0, MTB_WIN_AUX);
+        }
+    };
+    uint64_t pre_a0 = 0, pre_len = 0;
+    if (WIN && tile_win) {                           /* the window was bounded before the launch (k_join_tile_win): its loads go first */
+        const mtb_tile_win tw = tile_win[blockIdx.x];          /* (a uniform address of read-only memory: scalar loads) */
+        pre_a0 = tw.first; pre_len = tw.words;
+        if (pre_len) stage_window(pre_a0, pre_a0 + pre_len);
+    }
     MTB_JP_BEGIN();                                  /* profiling build only: cycles of thread 0 per phase (mtb_join_cycles: 0 queries + directory, 1 bisection, 2 run ends, 3 wave-scanned runs, 4 per-lane evaluation + emission) */
     mtb_kmer k[Q]; bool valid[Q]; uint64_t lo[Q], hi[Q];
 #pragma unroll
@@ -271,6 +339,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
             } else valid[u] = false;                        /* a metamer outside the directory's alphabet (stage API: any 64-bit value may arrive) has no candidate -- and no bucket row to read again below */
         }
     }
+    if (threadIdx.x < 8) s_hr[threadIdx.x] = tabs->hamrow[threadIdx.x];        /* (issued behind the window / query / directory loads: as the kernel's first statement it cost wave 0 a round trip of its own) */
+    if (WIN && tile_win) {
+        /* every query's bucket inside the announced window?  (one barrier: it also publishes s_hr and -- behind the explicit wait for the
+         * direct-to-LDS loads, which the workgroup-scope fence of a barrier is not documented to cover -- the window) */
+        const bool outside = pre_len != 0 && valid[0] && lo[0] < hi[0] && (lo[0] < pre_a0 || hi[0] > pre_a0 + pre_len);
+        MTB_WAIT_VMEM();
+        MTB_JP_MARK(5);
+        if (!__syncthreads_or(outside ? 1 : 0)) { if (pre_len) { use_win = true; w0 = pre_a0; } }
+        else if (threadIdx.x == 0 && win_stat) atomicAdd(win_stat + 1, 1ull);        /* (mtb_batch_stats.join_tiles_outside: stays 0 while the list is sorted as announced) */
+    } else {
     __syncthreads();                                 /* s_hr; the query and directory loads above are in flight meanwhile */
     if (WIN) {
         /* the tile's window: from the lowest bucket start to the highest bucket end of its queries */
@@ -281,26 +359,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
         }
         if ((threadIdx.x & 63u) == 0) { if (mn != ~0ull) atomicMin(&s_w0, (unsigned long long)mn); if (mx) atomicMax(&s_w1, (unsigned long long)mx); }
         __syncthreads();
+        MTB_JP_MARK(5);
         const uint64_t a0 = s_w0, a1 = s_w1;
-        if (a1 > a0 && a1 - a0 <= (uint64_t)MTB_JOIN_WINCAP) {
-            /* 1 KiB pieces, a wave each, straight into LDS (global_load_lds_dwordx4: no staging registers, no wait between the pieces -- a loop
-             * of load / ds_write pairs waited for every load: a dozen dependent round trips per tile, measured 96 ms against 80 for the random
-             * join).  The last piece may reach beyond the window (never read) -- but not beyond the array. */
-            const uint32_t n_piece = (uint32_t)((a1 - a0 + 127) >> 7), wv_ = threadIdx.x >> 6, ln_ = threadIdx.x & 63u;
-            for (uint32_t pc = wv_; pc < n_piece; pc += 4) {
-                const uint64_t src = a0 + ((uint64_t)pc << 7) + 2u * ln_;
-                if (a0 + ((uint64_t)pc << 7) + 128 > ix.n_targets) {           /* the piece that holds the array's end (one per index): plain guarded loads */
-                    if (src < ix.n_targets) s_win[((uint64_t)pc << 7) + 2u * ln_] = ix.values[src];
-                    if (src + 1 < ix.n_targets) s_win[((uint64_t)pc << 7) + 2u * ln_ + 1] = ix.values[src + 1];
-                    continue;
-                }
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ix.values + src),
-                                                 (__attribute__((address_space(3))) void *)(s_win + ((uint64_t)pc << 7)), 16, 0, MTB_WIN_AUX);
-            }
-            use_win = true; w0 = a0;
-        }
+        if (a1 > a0 && a1 - a0 <= (uint64_t)MTB_JOIN_WINCAP) { stage_window(a0, a1); use_win = true; w0 = a0; }
+        MTB_WAIT_VMEM();
         __syncthreads();
     }
+    }
+    MTB_JP_MARK(6);
     /* what tells targets of one bucket apart: the whole amino-acid part (flat state) or the packed word's eighth letter */
     auto tkey = [&](uint64_t w) -> uint64_t { return PACKED ? (w & 0x1F000000ull) : (w & AAM); };
     auto qkey = [&](uint64_t v) -> uint64_t {
@@ -525,82 +591,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
         const unsigned long long room = sa.ovf_stripes ? sa.ovf_region : sa.ovf_cap;
         if (o < room) sa.ovf[(uint64_t)stripe * sa.ovf_region + o] = mm; else *overflow = 1;
     };
-#if MTB_JOIN_LOCKSTEP_MIN > 0
-    /* EXPERIMENT, compiled out by default (measured slower, see MTB_JOIN_LOCKSTEP_MIN above).  Long runs SHARED by lanes of the wave, walked in lockstep.  The queries are sorted, so the queries that meet one long run -- an
-     * amino-acid 8-mer of a conserved protein, hit by every read that covers it -- sit next to each other: with reads of organisms that are
-     * not in the index (no equal target: nothing is skipped) most of a wave's 64 lanes hold the SAME run of a thousand or more targets, and
-     * the scan below took them one query at a time (42 % of the join's cycles on such reads).  Here the wave loads the run once per pass,
-     * 64 targets per step (coalesced), and hands every target to all the lanes of the group (readlane): each lane evaluates it against its
-     * OWN query -- first pass: the query's minimum hamming sum, second pass: the candidates within its threshold, emitted as the per-lane
-     * loop at the end of the kernel emits them (index order: the first one takes the ordinal slot). */
-#pragma unroll
-    for (int u = 0; u < Q; u++) {
-        uint64_t todo = __ballot(lng[u]);
-        while (todo) {
-            const int src = __ffsll((unsigned long long)todo) - 1;
-            const uint64_t s0 = wave_bcast64(lo[u], src), e = wave_bcast64(e_hi[u], src);
-            const bool mine = lng[u] && lo[u] == s0 && e_hi[u] == e;
-            const uint64_t grp = __ballot(mine);
-            todo &= ~grp;
-            if (__popcll(grp) < MTB_JOIN_LOCKSTEP_MIN) continue;     /* small groups: the wave's scan below */
-#if defined(MTB_GROUP_DEBUG) && !defined(__AMDGCN__)             /* emulated build only (tests/hipemu): how often the lockstep walk runs */
-            if (lane == (uint32_t)src) { static unsigned long n_grp = 0, n_q = 0; n_grp++; n_q += (unsigned long)__popcll(grp); if ((n_grp & (n_grp - 1)) == 0) fprintf(stderr, "lockstep groups so far: %lu (%lu queries)\n", n_grp, n_q); }
-#endif
-            mtb_qrows qr; mtb_prepare_query_rows(s_hr, k[u].value, &qr);
-            uint32_t mn = 255u;
-            for (uint64_t t0 = s0; t0 < e; t0 += 64) {
-                const uint64_t t = t0 + lane;
-                const uint64_t v = t < e ? rdv(t) : 0ull;
-                const uint32_t nstep = e - t0 < 64 ? (uint32_t)(e - t0) : 64u;
-                for (uint32_t j = 0; j < nstep; j++) {
-                    const uint32_t td = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)j) & 0xFFFFFFu;
-                    if (mine) { const uint32_t h = mtb_ham_sum(&qr, td); mn = h < mn ? h : mn; }
-                }
-            }
-            const uint32_t thr = mtb_ham_threshold(mn);
-            const uint32_t r = mine ? mtb_q_seq(k[u].qinfo) - 1 : 0u;
-            const uint32_t ord = mtb_q_pos(k[u].qinfo) >> 16;
-            const uint64_t qinfo = k[u].qinfo & ~0xFFFF0000ull;
-            const bool rev = mtb_hammings_reversed(mtb_q_frame(qinfo), ix.kmer_format);
-            uint32_t direct = sa.direct, tcap = tail_cap;
-            mtb_slot16 *seg = sa.seg;
-            if (mine) {
-                if (LONG) { direct = sa.dcnt[r]; tcap = mtb_lslot_tail(direct, sa.tf); seg = sa.seg + sa.rb[r]; }
-                else seg = sa.seg + (uint64_t)r * sa.stride;
-            }
-            const bool offr = mine && !LONG && sa.off && sa.off[r];
-            bool first = mine && ord < direct && !offr;
-            for (uint64_t t0 = s0; t0 < e; t0 += 64) {
-                const uint64_t t = t0 + lane;
-                const uint64_t v = t < e ? rdv(t) : 0ull;
-                const uint32_t info_l = (!PACKED && t < e) ? ix.info[t] : 0u;
-                const uint32_t nstep = e - t0 < 64 ? (uint32_t)(e - t0) : 64u;
-                for (uint32_t j = 0; j < nstep; j++) {
-                    const uint32_t vlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)j), vhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)j);
-                    const uint32_t inf = PACKED ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)info_l, (int)j);
-                    const uint32_t td = vlo & 0xFFFFFFu;
-                    if (!mine) continue;
-                    const uint32_t h = mtb_ham_sum(&qr, td);
-                    if (h > thr) continue;
-                    const uint64_t vv = ((uint64_t)vhi << 32) | vlo;
-                    const int32_t tid = (int32_t)((PACKED ? (uint32_t)(vv >> MTB_PACK_LOW) : inf) & ix.info_mask);
-                    const int32_t sp = (tid >= 0 && tid <= ix.max_taxid) ? ix.tax2species[tid] : 0;
-                    const uint16_t reh = mtb_hammings(&qr, td, rev);
-                    if (first) { const mtb_slot16 sl = LONG ? mtb_lslot_pack(qinfo, tid, sp, td, reh, h) : mtb_slot_pack(qinfo, tid, sp, td, reh, h, sa.epoch);
-                                 MTB_SLOT_STORE(sl, &seg[ord]); first = false; continue; }
-                    const uint32_t at = offr ? (atomicAdd(&sa.cursor[r], tcap + 1u), tcap) : atomicAdd(&sa.cursor[r], 1u);
-                    if (at < tcap) { const mtb_slot16 sl = LONG ? mtb_lslot_pack(qinfo, tid, sp, td, reh, h) : mtb_slot_pack(qinfo, tid, sp, td, reh, h, sa.epoch);
-                                     MTB_SLOT_STORE(sl, &seg[direct + at]); }
-                    else {
-                        mtb_match m; m.qinfo = qinfo; m.target_id = tid; m.species_id = sp; m.dna = td; m.right_end_hamming = reh; m.hamming = (uint8_t)h; m.pad = 0;
-                        ovf_put(m);
-                    }
-                }
-            }
-            if (mine) lng[u] = false;
-        }
-    }
-#endif
     /* wave-scanned runs: one pass (minimum + the few candidates that can be selected, kept in registers), then emission -- the selected
      * candidate with the lowest index takes the query's ordinal slot, the others the read's tail (ONE returning atomic per step for all
      * of them), beyond that the overflow list: the contract of the per-lane loop below */

@@ -78,6 +78,7 @@ struct JoinSegArgs {
      * every overflowing match a returning atomic on one address -- ~19 ns each once they no longer coalesce inside a wave, +100 ms per
      * 10 M reads of a sample in which the reads of conserved genes overflow their tails (profiles/r04_notes.md).  0: one dense list. */
     uint32_t ovf_stripes; uint64_t ovf_region;
+    uint32_t retry;     /* host side only (dev_join): this is a further attempt at a batch whose overflow list was too small: no tuning of the join's variant on it */
     uint32_t dense_ovf; /* host side only (dev_join): 1 = one dense overflow list even where the list would be striped -- the last retry of a batch: which
                          * workgroup emits a match beyond a read's tail depends on the order of the atomics, so the stripes fill differently from
                          * attempt to attempt and a list sized from the failed attempt's fullest stripe can fail again; the dense list needs the total only */

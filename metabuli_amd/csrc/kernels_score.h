@@ -65,10 +65,11 @@ __global__ __launch_bounds__(64) void k_taxcnt_bound(const uint64_t *__restrict_
     bound[r] = (uint32_t)(n < nb ? n : nb);
 }
 
-/* number of set bytes (reads k_score_fast left to the generic kernel; statistics) */
+/* number of bytes equal to 1 (reads k_score_fast / k_score_long left to the generic kernel; statistics).  Flag 2 -- a short read whose tail
+ * overflowed: it goes to the deferred path (k_score_many ...) and is counted there, not here */
 __global__ __launch_bounds__(256) void k_count_flags(const uint8_t *__restrict__ f, uint64_t n, unsigned long long *__restrict__ out) {
     uint32_t c = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) c += f[i] ? 1u : 0u;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) c += f[i] == 1 ? 1u : 0u;
     for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, (unsigned long long)c);
 }

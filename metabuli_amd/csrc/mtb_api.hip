@@ -30,6 +30,11 @@
 #include "kernels_seg_order.h"
 #include "kernels_sort.h"
 #include "mtb_core.h"
+#include "mtb_options.h"
+
+#if defined(__HIP_DEVICE_COMPILE__) && defined(__AMDGCN__) && !defined(__gfx950__)
+#error "libmtb is written for gfx950 (MI355X) only: 160 KB of LDS per workgroup (k_score_long<4096, 1024> holds 68 KB), global_load_lds_dwordx4, wave64"
+#endif
 
 static thread_local std::string g_err;
 static mtb_status fail(mtb_status s, const std::string &m) { g_err = m; return s; }
@@ -135,7 +140,7 @@ struct mtb_ctx {
     struct JoinTune { uint64_t key = 0; int calls = 0, pending = -1, best = -1; float ms[3] = {0.0f, 0.0f, 0.0f}; hipEvent_t e0 = nullptr, e1 = nullptr; } join_tunes[4]; uint32_t join_tune_next = 0;      /* dev_join: the short-read instantiation that is fastest for this index and batch size */
     uint64_t many_stats[4] = {0, 0, 0, 0};           /* last slot-path batch: reads deferred by the first scoring launches, of those scored by k_score_many, their matches, the survivors of the dead-species drop */
     uint32_t lslot_tf_start = 1;                     /* long-read slot ranges: tail factor the next batch starts with (1 = a quarter of the metamers, 4 = all) */
-    uint32_t join_coop_min = MTB_JOIN_COOP_MIN;      /* k_join_dir: runs longer than this are scanned by the whole wave; MTB_JOIN_COOP_MIN in the environment at mtb_ctx_create */
+    MtbOptions opt;                                  /* the experiment / diagnosis switches: the MTB_* environment at mtb_ctx_create, mtb_ctx_set_option afterwards (mtb_options.h) */
 };
 /* buffers that carry a call's inputs / outputs (host-buffer entry points) are not workspace */
 static bool is_io_buf(const std::string &n) { return n == "bases" || n == "offs" || n == "bases2" || n == "offs2" || n == "results" || n == "resultsb" || n == "tctax" || n == "tccnt" || n.compare(0, 2, "pk") == 0; }
@@ -261,11 +266,10 @@ static mtb_status ensure_placed(mtb_ctx *c, const char *name, size_t elems, mtb_
     const size_t bytes = std::max<size_t>(elems * sizeof(mtb_slot16), 64);
     /* experiment switch (tests/test_gpu_contig.py, profiles/r03_notes.md): the slot buffer -- of ANY size -- from physically
      * contiguous VRAM, the configuration in which round 2 saw pair scores differ from the oracle's */
-    static const char *contig = getenv("MTB_SEGM_CONTIG");
-    if (contig) {
+    if (c->opt.segm_contig) {
         if (b.cap >= bytes) { *out = (mtb_slot16 *)b.p; return MTB_OK; }
         if (b.p) { hipError_t e = hipFree(b.p); (void)e; b.p = nullptr; b.cap = 0; }
-        const size_t want = bytes + bytes / 16 + 256 + (getenv("MTB_SEGM_PAD") ? (1u << 20) : 0);
+        const size_t want = bytes + bytes / 16 + 256 + (c->opt.segm_pad ? (1u << 20) : 0);
         hipError_t e = hipExtMallocWithFlags(&b.p, want, hipDeviceMallocContiguous);
         if (e != hipSuccess) { b.p = nullptr; (void)hipGetLastError(); return fail(MTB_ERR_OOM, std::string("contiguous allocation failed for ") + name + ": " + hipGetErrorString(e)); }
         b.cap = want;
@@ -277,7 +281,7 @@ static mtb_status ensure_placed(mtb_ctx *c, const char *name, size_t elems, mtb_
      * (profiles/scripts/alloc_probe.hip, profiles/r03_notes.md section 3), and the search costs the first big batch 2.5 - 3.8 s
      * (profiles/r03_e2e_driver_30Mreads.txt).  A process with a long allocation history of its own (bench.py under torch's caching
      * allocator) turns it on. */
-    static const bool no_probe = getenv("MTB_NO_PLACEMENT_PROBE") != nullptr, env_probe = getenv("MTB_PLACEMENT_PROBE") != nullptr;
+    const bool no_probe = c->opt.no_placement_probe != 0, env_probe = c->opt.placement_probe != 0;
     if (b.cap >= bytes || bytes < (8ull << 30) || no_probe || !(c->placement_probe || env_probe)) return ensure(c, name, elems, out);
     if (b.p) { hipError_t e = hipFree(b.p); (void)e; b.p = nullptr; b.cap = 0; }
     const size_t want = bytes + bytes / 16 + 256;
@@ -336,7 +340,7 @@ static mtb_status ensure_placed(mtb_ctx *c, const char *name, size_t elems, mtb_
     for (size_t k = 1; k < held.size(); k++) if (held[k].ms < held[pick].ms) pick = k;
     for (size_t k = 0; k < held.size(); k++) if (k != pick) { hipError_t e = hipFree(held[k].p); (void)e; }
     std::vector<Cand> &cands = held;
-    if (getenv("MTB_PLACEMENT_VERBOSE")) { fprintf(stderr, "mtb: slot buffer placement probe:"); for (size_t k = 0; k < seen.size(); k++) fprintf(stderr, " %.3f@%p", seen[k], seen_p[k]); fprintf(stderr, " ms -> %.3f (%.0f ms spent)\n", cands[pick].ms, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count()); }
+    if (c->opt.placement_verbose) { fprintf(stderr, "mtb: slot buffer placement probe:"); for (size_t k = 0; k < seen.size(); k++) fprintf(stderr, " %.3f@%p", seen[k], seen_p[k]); fprintf(stderr, " ms -> %.3f (%.0f ms spent)\n", cands[pick].ms, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count()); }
     b.p = cands[pick].p; b.cap = cands[pick].bytes;
     *out = (mtb_slot16 *)b.p;
     return MTB_OK;
@@ -369,12 +373,12 @@ mtb_status mtb_ctx_create(int device, void *stream, mtb_ctx **out) {
     mtb_build_tables(&c->h_tabs);
     HIPCHK(hipMalloc((void **)&c->d_tabs, sizeof(mtb_tables)));
     HIPCHK(hipMemcpy(c->d_tabs, &c->h_tabs, sizeof(mtb_tables), hipMemcpyHostToDevice));
-    HIPCHK(hipMalloc((void **)&c->d_scal, 16 * sizeof(uint64_t)));
+    HIPCHK(hipMalloc((void **)&c->d_scal, 24 * sizeof(uint64_t)));      /* [16..23]: the join's tile statistics */
     c->d_xscal = c->d_scal + 8;
     HIPCHK(hipMalloc((void **)&c->d_ovfctr, MTB_OVF_STRIPES * 64));
     for (int i = 0; i < 8; i++) HIPCHK(hipEventCreate(&c->ev[i]));
     memset(&c->stats, 0, sizeof(c->stats));
-    if (const char *e = getenv("MTB_JOIN_COOP_MIN")) c->join_coop_min = (uint32_t)std::max(1, atoi(e));
+    mtbopt::from_environment(&c->opt);                 /* the ONLY place the library reads its MTB_* switches from the environment */
     *out = c;
     return MTB_OK;
 }
@@ -419,6 +423,17 @@ mtb_status mtb_ctx_set_workspace_limit(mtb_ctx *c, uint64_t bytes) {
     for (mtb_ctx *l : c->lanes) l->ws_limit = bytes;
     return MTB_OK;
 }
+mtb_status mtb_ctx_set_option(mtb_ctx *c, const char *name, const char *value) {
+    if (!c || !name) return fail(MTB_ERR_ARG, "NULL ctx / name");
+    if (!mtbopt::set(&c->opt, name, value)) return fail(MTB_ERR_ARG, std::string("unknown switch or bad value: ") + name + "=" + (value ? value : "(unset)"));
+    for (mtb_ctx *l : c->lanes) l->opt = c->opt;
+    return MTB_OK;
+}
+mtb_status mtb_ctx_set_join_variant(mtb_ctx *c, int variant) {
+    static const char *const names[] = {"auto", "q1w6", "q2w5", "window"};
+    if (!c || variant < 0 || variant > 3) return fail(MTB_ERR_ARG, "variant must be MTB_JOIN_AUTO .. MTB_JOIN_WINDOW");
+    return mtb_ctx_set_option(c, "MTB_JOIN_VARIANT", names[variant]);
+}
 uint32_t mtb_ctx_last_sub_batches(const mtb_ctx *c) { return c ? c->last_sub_batches : 0; }
 mtb_status mtb_ctx_set_streams(mtb_ctx *c, int n) {
     if (!c || n < 1 || n > 8) return fail(MTB_ERR_ARG, "streams must be 1..8");
@@ -426,9 +441,9 @@ mtb_status mtb_ctx_set_streams(mtb_ctx *c, int n) {
     while ((int)c->lanes.size() > (n == 1 ? 0 : n)) { mtb_ctx_destroy(c->lanes.back()); c->lanes.pop_back(); }
     while (n > 1 && (int)c->lanes.size() < n) {
         mtb_ctx *l = new mtb_ctx();
-        l->device = c->device; l->is_lane = true; l->d_tabs = c->d_tabs; l->h_tabs = c->h_tabs; l->profiling = c->profiling; l->placement_probe = c->placement_probe; l->join_coop_min = c->join_coop_min;
+        l->device = c->device; l->is_lane = true; l->d_tabs = c->d_tabs; l->h_tabs = c->h_tabs; l->profiling = c->profiling; l->placement_probe = c->placement_probe; l->opt = c->opt;
         HIPCHK(hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking));
-        HIPCHK(hipMalloc((void **)&l->d_scal, 16 * sizeof(uint64_t)));
+        HIPCHK(hipMalloc((void **)&l->d_scal, 24 * sizeof(uint64_t)));
         l->d_xscal = l->d_scal + 8;
         HIPCHK(hipMalloc((void **)&l->d_ovfctr, MTB_OVF_STRIPES * 64));
         for (int i = 0; i < 8; i++) HIPCHK(hipEventCreate(&l->ev[i]));
@@ -456,7 +471,7 @@ static mtb_status h2d(mtb_ctx *c, void *dst, const void *src, size_t bytes) {
 }
 
 /* fused-path sort: first pass on the top letter pair, the two lower pairs bucket-local (kernels_sort.h); MTB_SORT_LSD=1: the three LSD passes of round 2 (A/B) */
-static bool sort_msd_first() { static const bool lsd = getenv("MTB_SORT_LSD") != nullptr; return !lsd; }
+static bool sort_msd_first(const mtb_ctx *c) { return !c->opt.sort_lsd; }
 
 /* records the single-pass extractor's output buffer is sized for: six frames x L/3 windows bound the output by 2 metamers per base;
  * syncmer selection keeps about half of them, so the buffer follows the previous batch's yield (first batch of a context: < 1 metamer
@@ -484,7 +499,7 @@ static mtb_status dev_extract(mtb_ctx *c, const mtb_params *p, const char *d_bas
     *count = 0; *out = nullptr;
     if (real_count) *real_count = 0;
     if (n_reads == 0) return MTB_OK;
-    ExtractArgs a{d_bases, d_offs, d_bases2, d_offs2, n_reads, p->seq_mode, p->syncmer, p->smer_len, p->kmer_format, (single_pass && tag_ord) ? 1 : 0, sort_msd_first() ? 54 : 34};
+    ExtractArgs a{d_bases, d_offs, d_bases2, d_offs2, n_reads, p->seq_mode, p->syncmer, p->smer_len, p->kmer_format, (single_pass && tag_ord) ? 1 : 0, sort_msd_first(c) ? 54 : 34};
     /* grid sweep, 10 M reads: 7424 workgroups 23.5 ms, 16384 18.7, 65536 17.3, 262144 17.7 (and more blank tail records) */
     uint32_t grid = (uint32_t)std::min<uint64_t>(n_reads, 256ull * 256);
     HIPCHK(hipMemsetAsync(c->d_scal + 4, 0, 8, c->stream));
@@ -565,7 +580,7 @@ static mtb_status dev_sort(mtb_ctx *c, mtb_kmer *d_a, uint64_t n, int first_bit,
     STCHK(ensure(c, "hist", radix_hist_elems(n, bins), &d_hist));
     STCHK(ensure(c, "scanws", scan_ws_elems(radix_hist_elems(n, bins)), &d_ws));
     {
-        static const int xcd_map = getenv("MTB_SORT_NO_XCD") ? 0 : 1;
+        const int xcd_map = c->opt.sort_no_xcd ? 0 : 1;
         const uint32_t sc_threads = aa ? 512u : 256u;
         const uint64_t tile = (uint64_t)sc_threads * MTB_SORT_ITEMS;  /* MTB_SORT_ITEMS records per scatter thread */
         uint32_t tiles = (uint32_t)((n + tile - 1) / tile);
@@ -576,7 +591,7 @@ static mtb_status dev_sort(mtb_ctx *c, mtb_kmer *d_a, uint64_t n, int first_bit,
         if (dig_src) STCHK(ensure(c, "digB", n + 8, &dig_dst));
         /* the directory join (kernels_dir.h) looks every query up on its own: the sort only buys locality of the directory /
          * target accesses, so the fused path may stop after fewer letter pairs (aa_first_shift: 34 = six letters, 44 = four, 54 = two) */
-        if (aa && dig_src && aa_first_shift == 34 && sort_msd_first()) {
+        if (aa && dig_src && aa_first_shift == 34 && sort_msd_first(c)) {
             /* pass A: the top letter pair, over the whole list (its digits came with the records); passes B, C: the low and the middle
              * pair inside every bucket of pass A */
             uint32_t *d_plan;
@@ -658,7 +673,7 @@ static mtb_status ensure_flat_locked(mtb_index *ix) {       /* caller holds stat
     return MTB_OK;
 }
 static bool can_pack(const mtb_index *ix) {
-    return ix->d_dir && ix->dir_L == 7 && ix->own_tax && ix->views == 0 && !getenv("MTB_NO_PACK");
+    return ix->d_dir && ix->dir_L == 7 && ix->own_tax && ix->views == 0 && !(ix->ctx && ix->ctx->opt.no_pack);
 }
 static mtb_status ensure_packed_locked(mtb_index *ix) {
     if (ix->packed || !can_pack(ix)) return MTB_OK;
@@ -716,11 +731,12 @@ static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint6
     STCHK(ensure(c, "jbounds", 2ull * grid, &d_bounds));
     uint64_t limit = ix->T ? ix->T - (ix->match_last ? 0 : 1) : 0;          /* the last entry of the (whole) index is never a candidate */
     IndexUse use;                     /* released after the stream sync below (the d2h of the counters) */
+    uint32_t win_tiles = 0;           /* the window variant ran: tiles launched (their statistics sit in d_scal[16..17]) */
     const bool striped = seg && ix->d_dir && !seg->list && !seg->dense_ovf;       /* the slot modes of the directory join: striped overflow list */
     if (seg && ix->d_dir) {
         STCHK(use.acquire(ix, true));
         KTimer kt(c, MTB_K_JOIN);
-        JoinSegArgs sa = *seg; sa.ovf_counter = (unsigned long long *)c->d_scal; sa.coop_min = c->join_coop_min;
+        JoinSegArgs sa = *seg; sa.ovf_counter = (unsigned long long *)c->d_scal; sa.coop_min = c->opt.join_coop_min > 0 ? (uint32_t)c->opt.join_coop_min : (uint32_t)MTB_JOIN_COOP_MIN;
         if (striped) {
             HIPCHK(hipMemsetAsync(c->d_ovfctr, 0, MTB_OVF_STRIPES * 64, c->stream));
             sa.ovf_counter = c->d_ovfctr; sa.ovf_stripes = MTB_OVF_STRIPES; sa.ovf_region = sa.ovf_cap / MTB_OVF_STRIPES;
@@ -734,8 +750,7 @@ static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint6
         if (sa.rb) {        /* long reads: per-read slot ranges */
             if (state_owner(ix)->packed) {
                 /* one query per thread at 6 waves per SIMD here too (43.2 -> 41.5 ms per 50 k x 10 kb; MTB_JOIN_VARIANT=q2w5: round 4's instantiation, A/B) */
-                const char *e = getenv("MTB_JOIN_VARIANT");
-                if (!(e && !strcmp(e, "q2w5"))) hipLaunchKernelGGL((k_join_dir<true, 1, 1, 6>), dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1));
+                if (c->opt.join_variant != 0x25) hipLaunchKernelGGL((k_join_dir<true, 1, 1, 6>), dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1));
                 else hipLaunchKernelGGL((k_join_dir<true, 1, MTB_JOIN_DIR_QPT, 5>), dim3(g2), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1));
             }
             else hipLaunchKernelGGL((k_join_dir<false, 1>), dim3(g2), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1));
@@ -743,70 +758,84 @@ static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint6
         if (state_owner(ix)->packed) {
             /* the product instantiation, or one of its A/B variants (queries per thread x waves per SIMD) */
 #define MTB_LAUNCH_JV(QV, WV) hipLaunchKernelGGL((k_join_dir<true, 0, QV, WV>), dim3((uint32_t)((n + 256 * QV - 1) / (256 * QV))), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1))
-            int join_variant = 0;                     /* MTB_JOIN_VARIANT=q<Q>w<W>, read per batch: bench.py compares the variants inside one process */
-            if (const char *e = getenv("MTB_JOIN_VARIANT")) { if (e[0] == 'q' && e[1] >= '1' && e[1] <= '2' && e[2] == 'w' && e[3] >= '5' && e[3] <= '6') join_variant = ((e[1] - '0') << 4) | (e[3] - '0'); }
-            /* the window variant (kernels_dir.h, WIN): when the batch is dense enough that a tile of sorted queries addresses a span of the target
-             * array that fits LDS -- a query owns T / n targets on average; qt queries per workgroup so that the expected window is ~0.82 of the
-             * capacity; below 240 queries per workgroup (T / n > 13.5: smaller batches against a big index) the lookups stay sector-random --
-             * measured: the kernel is bound by the queries a CU has in flight, and idle lanes cost more than the window saves (r05_notes.md).
-             * MTB_JOIN_WIN=0 / 1 forces it off / on, MTB_JOIN_WIN_QT=<n> sets the tile (A/B legs of bench.py; read per batch). */
-            double per_q = (double)ix->T / (double)std::max<uint64_t>(n, 1);
+            /* Three exact instantiations of the short-read join on packed words (kernels_dir.h): sector-random lookups with one query per thread at 6 waves
+             * per SIMD (q1w6) or two at 5 (q2w5), and the LDS window.  The window needs a batch dense enough that a tile of sorted queries addresses a
+             * span of the target array that fits LDS -- a query owns T / n targets on average; qt queries per workgroup so that the expected window is
+             * ~0.82 of the capacity; below 240 queries per workgroup (T / n > 13.5: smaller batches against a big index) idle lanes cost more than the
+             * window saves (r05_notes.md).  Which one is fastest depends on the batch's locality, which the host cannot see: reads of a few genomes at
+             * high coverage run best with two queries per thread, a metagenome of thousands of genomes with one, a dense one with the window.  So a
+             * context TRIES them on its first batches of a shape (second to fourth join: one instantiation each, timed with a pair of events) and
+             * keeps the fastest; a few (index, batch size) shapes are remembered.  The caller can pin the choice (mtb_ctx_set_join_variant, or
+             * MTB_JOIN_VARIANT / MTB_JOIN_WIN in the environment of mtb_ctx_create); the choice and the tuner's timings are reported in
+             * mtb_batch_stats (join_variant, join_tuned, join_tune_ms). */
+            const double per_q = (double)ix->T / (double)std::max<uint64_t>(n, 1);
             uint32_t qt = (uint32_t)std::min<double>(256.0, 0.82 * MTB_JOIN_WINCAP / std::max(per_q, 1.0));
-            bool win = qt >= 240 && join_variant == 0;
-            if (const char *e = getenv("MTB_JOIN_WIN")) win = atoi(e) != 0 && join_variant == 0;
-            if (const char *e = getenv("MTB_JOIN_WIN_QT")) qt = (uint32_t)std::max(1, std::min(256, atoi(e)));
+            const bool win_ok = qt >= 240;
+            if (c->opt.join_win_qt > 0) qt = (uint32_t)std::min(256, c->opt.join_win_qt);
             qt = std::max<uint32_t>(qt, 1);
-            /* Which instantiation is fastest depends on the batch's locality, which the host cannot see: reads of a few genomes at high
-             * coverage (queries falling into few, L2-resident sectors) run best with two queries per thread, a metagenome of thousands of
-             * genomes with one query per thread at 6 waves, a dense one with the LDS window (measured: r05_notes.md).  All of them are exact,
-             * so a context TRIES them on its first batches against an index (second to fourth join of that shape: one instantiation each,
-             * timed with a pair of events) and keeps the fastest.  MTB_JOIN_VARIANT / MTB_JOIN_WIN in the environment switch the choice off. */
-            const bool forced = getenv("MTB_JOIN_VARIANT") || getenv("MTB_JOIN_WIN");
-            /* (a few (index, batch size) shapes are remembered: a host that alternates workloads -- bench.py's legs -- does not tune again) */
+            int choice = -1;                                 /* 0: q1w6, 1: q2w5, 2: window, 3 / 4: the A/B-only instantiations q1w5 / q2w6 */
+            switch (c->opt.join_variant) { case 0x16: choice = 0; break; case 0x25: choice = 1; break; case 0x100: choice = 2; break; case 0x15: choice = 3; break; case 0x26: choice = 4; break; default: break; }
+            if (choice < 0 && c->opt.join_win >= 0) choice = c->opt.join_win ? 2 : 0;
+            const bool forced = choice >= 0;
             uint32_t lg_n = 0; for (uint64_t x = n; x > 1; x >>= 1) lg_n++;
             const uint64_t tune_key = (uint64_t)(uintptr_t)ix ^ ((uint64_t)lg_n << 56) ^ (ix->T << 8);
             int slot = -1;
             for (int q = 0; q < 4; q++) if (c->join_tunes[q].key == tune_key) slot = q;
-            if (slot < 0) { slot = (int)(c->join_tune_next++ & 3u); const hipEvent_t k0 = c->join_tunes[slot].e0, k1 = c->join_tunes[slot].e1; c->join_tunes[slot] = mtb_ctx::JoinTune(); c->join_tunes[slot].key = tune_key; c->join_tunes[slot].e0 = k0; c->join_tunes[slot].e1 = k1; }
-            mtb_ctx::JoinTune &jt = c->join_tunes[slot];
-            int tuned = -1;                                  /* 0: one query per thread, 6 waves; 1: two per thread, 5 waves; 2: the window */
-            if (!forced && !c->is_lane) {
-                if (jt.pending >= 0) {                       /* the previous join's time (that batch is long finished) */
+            mtb_ctx::JoinTune *jt = slot >= 0 ? &c->join_tunes[slot] : nullptr;
+            bool timing_this = false; int tuned_flag = 0;
+            if (!forced && !c->is_lane && !sa.retry) {
+                if (!jt) { slot = (int)(c->join_tune_next++ & 3u); jt = &c->join_tunes[slot]; const hipEvent_t k0 = jt->e0, k1 = jt->e1; *jt = mtb_ctx::JoinTune(); jt->key = tune_key; jt->e0 = k0; jt->e1 = k1; }
+                if (jt->pending >= 0) {                      /* the previous join's time (that batch is long finished) */
                     float ms = 0.0f;
-                    if (hipEventElapsedTime(&ms, jt.e0, jt.e1) == hipSuccess && ms > 0.0f) jt.ms[jt.pending] = ms; else { (void)hipGetLastError(); jt.ms[jt.pending] = 1e30f; }
-                    jt.pending = -1;
+                    if (hipEventElapsedTime(&ms, jt->e0, jt->e1) == hipSuccess && ms > 0.0f) jt->ms[jt->pending] = ms; else { (void)hipGetLastError(); jt->ms[jt->pending] = 1e30f; }
+                    jt->pending = -1;
                 }
-                jt.calls++;
-                if (jt.best < 0 && jt.calls >= 2) {
+                jt->calls++;
+                if (jt->best < 0 && jt->calls >= 2) {
                     int next = -1;
-                    for (int v = 0; v < 3; v++) if (jt.ms[v] == 0.0f && (v != 2 || qt >= 240)) { next = v; break; }
+                    for (int v = 0; v < 3; v++) if (jt->ms[v] == 0.0f && (v != 2 || win_ok)) { next = v; break; }
                     if (next >= 0) {
-                        if (!jt.e0) { HIPCHK(hipEventCreate(&jt.e0)); HIPCHK(hipEventCreate(&jt.e1)); }
-                        tuned = next; jt.pending = next;
-                        HIPCHK(hipEventRecord(jt.e0, c->stream));
+                        if (!jt->e0) { HIPCHK(hipEventCreate(&jt->e0)); HIPCHK(hipEventCreate(&jt->e1)); }
+                        choice = next; jt->pending = next; timing_this = true;
+                        HIPCHK(hipEventRecord(jt->e0, c->stream));
                     } else {
-                        jt.best = 0;
-                        for (int v = 1; v < 3; v++) if (jt.ms[v] > 0.0f && jt.ms[v] < jt.ms[jt.best]) jt.best = v;
-                        if (getenv("MTB_JOIN_VERBOSE")) fprintf(stderr, "mtb: join tuned for this index and batch size: q1w6 %.2f ms, q2w5 %.2f ms, window %.2f ms -> %s\n", jt.ms[0], jt.ms[1], jt.ms[2],
-                                                                jt.best == 0 ? "q1w6" : jt.best == 1 ? "q2w5" : "window");
+                        jt->best = 0;
+                        for (int v = 1; v < 3; v++) if (jt->ms[v] > 0.0f && jt->ms[v] < jt->ms[jt->best]) jt->best = v;
+                        if (c->opt.join_verbose) fprintf(stderr, "mtb: join tuned for this index and batch size: q1w6 %.2f ms, q2w5 %.2f ms, window %.2f ms -> %s\n", jt->ms[0], jt->ms[1], jt->ms[2],
+                                                         jt->best == 0 ? "q1w6" : jt->best == 1 ? "q2w5" : "window");
                     }
                 }
-                if (tuned < 0 && jt.best >= 0) tuned = jt.best;
             }
-            if (tuned >= 0) { win = tuned == 2; join_variant = tuned == 1 ? 0x25 : 0; }
-            if (win) {
-                hipLaunchKernelGGL((k_join_dir<true, 0, 1, 5, true>), dim3((uint32_t)((n + qt - 1) / qt)), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix),
-                                   (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1), qt);
+            /* a remembered choice serves every batch of its log2-size bucket: the window only where THIS batch is dense enough for it;
+             * retries of a batch (overflow list too small) and lanes never time anything, they follow what is known */
+            if (choice < 0 && jt && jt->best >= 0) { choice = (jt->best == 2 && !win_ok) ? 0 : jt->best; tuned_flag = 1; }
+            if (choice < 0) choice = win_ok ? 2 : 0;         /* not tuned (yet): by density */
+            c->stats.join_variant = choice == 0 ? MTB_JOIN_Q1W6 : choice == 1 ? MTB_JOIN_Q2W5 : choice == 2 ? MTB_JOIN_WINDOW : -choice;
+            c->stats.join_tuned = tuned_flag;
+            if (jt) for (int v = 0; v < 3; v++) c->stats.join_tune_ms[v] = jt->ms[v] < 1e29f ? jt->ms[v] : 0.0f;
+            if (choice == 2) {
+                /* the tiles' windows first (k_join_tile_win): needs the list sorted on the announced bits */
+                const uint32_t n_tiles = (uint32_t)((n + qt - 1) / qt);
+                mtb_tile_win *d_tw = nullptr;
+                const bool prewin = !c->opt.join_no_prewin && (ix->params.kmer_format == 2 ? sort_low_bits == 34 : (sort_low_bits >= 24 && sort_low_bits <= 32));
+                HIPCHK(hipMemsetAsync(c->d_scal + 16, 0, 16, c->stream));
+                if (prewin) {
+                    STCHK(ensure(c, "jtilewin", (size_t)n_tiles, &d_tw));
+                    hipLaunchKernelGGL(k_join_tile_win, dim3((n_tiles + 255) / 256), dim3(256), 0, c->stream, d_q, n, qt, dir_view(ix), limit, sort_low_bits, d_tw, n_tiles,
+                                       (unsigned long long *)(c->d_scal + 16));
+                }
+                hipLaunchKernelGGL((k_join_dir<true, 0, 1, 5, true>), dim3(n_tiles), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix),
+                                   (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1), qt, (const mtb_tile_win *)d_tw, (unsigned long long *)(c->d_scal + 16));
+                win_tiles = n_tiles;
             } else
-            switch (join_variant) {
-            case 0x15: MTB_LAUNCH_JV(1, 5); break;
-            case 0x16: MTB_LAUNCH_JV(1, 6); break;
-            case 0x26: MTB_LAUNCH_JV(2, 6); break;
-            case 0x25: MTB_LAUNCH_JV(2, 5); break;
-            default: MTB_LAUNCH_JV(MTB_JOIN_DIR_QPT0, MTB_JOIN_WAVES); break;
+            switch (choice) {
+            case 1: MTB_LAUNCH_JV(2, 5); break;
+            case 3: MTB_LAUNCH_JV(1, 5); break;
+            case 4: MTB_LAUNCH_JV(2, 6); break;
+            default: MTB_LAUNCH_JV(1, 6); break;
             }
 #undef MTB_LAUNCH_JV
-            if (jt.pending >= 0 && tuned == jt.pending) HIPCHK(hipEventRecord(jt.e1, c->stream));
+            if (timing_this) HIPCHK(hipEventRecord(jt->e1, c->stream));
         }
         else hipLaunchKernelGGL((k_join_dir<false>), dim3(g2), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1));
     } else
@@ -827,6 +856,11 @@ static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint6
     HIPCHK(hipGetLastError());
     uint64_t sc[2];
     STCHK(d2h(c, sc, c->d_scal, 16));
+    if (win_tiles) {
+        uint64_t ws[2];
+        STCHK(d2h(c, ws, c->d_scal + 16, 16));
+        c->stats.join_tiles = win_tiles; c->stats.join_tiles_windowed = (uint32_t)ws[0]; c->stats.join_tiles_outside = (uint32_t)ws[1];
+    }
     if (striped) {
         /* entries per stripe: the list fits when the fullest region does; else the caller comes again with room for 256 x that */
         unsigned long long h[MTB_OVF_STRIPES * 8];
@@ -966,7 +1000,7 @@ static mtb_status dev_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, uint
         tc_base, S->list, S->n_list, S->cursor, S->stride, S->seg_by_list, S->direct, S->epoch, S->big_list, S->n_big, S->cnt_out, d_work, S->only_flagged, S->seg_cnt)
         ScoreSrc S_rest;
         const bool pairs = p->seq_mode == 2;
-        if (S->cursor && pass == 0 && key64 && S->stride <= 384u && !getenv("MTB_NO_FAST_SCORER") && !(pairs && getenv("MTB_NO_FAST_PAIRS"))) {
+        if (S->cursor && pass == 0 && key64 && S->stride <= 384u && !c->opt.no_fast_scorer && !(pairs && c->opt.no_fast_pairs)) {
             /* slot mode: the register-resident scorer takes every read with the common structure (slots in compareMatches order
              * once the species -- for pairs the (species, frame) runs -- are laid one after another, one match per position
              * group) and lists the others for the generic kernel below */
@@ -1120,10 +1154,10 @@ static mtb_status upload_taxonomy(mtb_index *ix) {
  * 7 (7.2 GB).  Not built (k_join is used) when the index holds a 5-bit letter >= 21 or a directory group spans 2^32 targets.
  * MTB_NO_DIR=1 disables it (A/B measurements). */
 static mtb_status build_directory(mtb_ctx *c, mtb_index *ix) {
-    if (ix->T < 2 || getenv("MTB_NO_DIR")) return MTB_OK;
+    if (ix->T < 2 || c->opt.no_dir) return MTB_OK;
     int L = 1;
     while (L < 7 && (uint64_t)mtb_pow21(L) < ix->T / 8) L++;
-    if (getenv("MTB_DIR_DEPTH")) L = std::max(1, std::min(7, atoi(getenv("MTB_DIR_DEPTH"))));       /* tests force depth 7 (packed state) on toy indices */
+    if (c->opt.dir_depth > 0) L = std::max(1, std::min(7, c->opt.dir_depth));       /* tests force depth 7 (packed state) on toy indices */
     const uint32_t nbk = mtb_pow21(L);
     const uint32_t n_groups = (nbk >> 16) + 1;
     size_t fr = 0, tot = 0;
@@ -1273,7 +1307,7 @@ static mtb_status decode_chunked(mtb_ctx *c, mtb_index *ix, const std::string &d
      * the words twice, tile tables, the info entries of its metamers, scan workspace); MTB_OPEN_CHUNK: tests (a few dozen words) */
     uint64_t CH = 128ull << 20;
     if (c->ws_limit) CH = std::max<uint64_t>(1u << 16, std::min<uint64_t>(CH, c->ws_limit / 16));
-    if (getenv("MTB_OPEN_CHUNK")) CH = std::max<uint64_t>(16, strtoull(getenv("MTB_OPEN_CHUNK"), nullptr, 10));
+    if (c->opt.open_chunk > 0) CH = std::max<uint64_t>(16, (uint64_t)c->opt.open_chunk);
     const int fmt = ix->params.kmer_format;
     const uint32_t nbk = want_dir ? mtb_pow21(L) : 0, n_groups = want_dir ? (nbk >> 16) + 1 : 0;
     uint32_t *d_flags = (uint32_t *)(c->d_scal + 6);
@@ -1400,6 +1434,13 @@ static mtb_status decode_chunked(mtb_ctx *c, mtb_index *ix, const std::string &d
  * before there was a reservation).  Returns the free bytes afterwards. */
 static size_t open_make_room(mtb_ctx *c) {
     c->reserve_cancel = true;
+    /* nothing may still be reading the workspace that is handed back: batches queued on the compute stream (another index of this context),
+     * results on their way down (asynchronous entry point), a prefetch into the input sets (those are I/O buffers and stay, but their
+     * records must not outlive a context whose streams were drained) -- ADVICE r5 */
+    { hipError_t e = hipStreamSynchronize(c->stream); (void)e;
+      if (c->down_stream) { e = hipStreamSynchronize(c->down_stream); (void)e; c->down_pending = false; }
+      if (c->copy_stream) { e = hipStreamSynchronize(c->copy_stream); (void)e; } }
+    c->last_sorted = nullptr; c->last_sorted_n = 0;       /* (pointed into the workspace) */
     { std::lock_guard<std::mutex> lk(c->reserve_mu); release_workspace(c); }
     size_t fr = 0, tot = 0;
     hipError_t e = hipMemGetInfo(&fr, &tot); (void)e;
@@ -1456,15 +1497,15 @@ static mtb_status open_impl(mtb_ctx *c, const char *dbdir, const char *taxonomy_
     /* the directory this index will have (build_directory's rule), decided before the load so that it is built chunk by chunk */
     int L = 1;
     while (L < 7 && (uint64_t)mtb_pow21(L) < T / 8) L++;
-    if (getenv("MTB_DIR_DEPTH")) L = std::max(1, std::min(7, atoi(getenv("MTB_DIR_DEPTH"))));
-    bool want_dir = T >= 2 && !getenv("MTB_NO_DIR");
+    if (c->opt.dir_depth > 0) L = std::max(1, std::min(7, c->opt.dir_depth));
+    bool want_dir = T >= 2 && !c->opt.no_dir;
     struct CancelReset { mtb_ctx *c; ~CancelReset() { c->reserve_cancel = false; } } cancel_reset{c};
     if (want_dir) {
         size_t fr = 0, tot = 0;
         HIPCHK(hipMemGetInfo(&fr, &tot));
         const uint32_t nbk = mtb_pow21(L);
         /* directory + target words + (flat state) info[] + the chunk buffers of the decode */
-        const bool pack_guess = L == 7 && !P.drop_last && !getenv("MTB_NO_PACK") && (getenv("MTB_OPEN_PACKED") ? atoi(getenv("MTB_OPEN_PACKED")) != 0 : T >= (1ull << 28));
+        const bool pack_guess = L == 7 && !P.drop_last && !c->opt.no_pack && (c->opt.open_packed >= 0 ? c->opt.open_packed != 0 : T >= (1ull << 28));
         const size_t need_dir = ((size_t)nbk + 1) * 4 + ((size_t)(nbk >> 16) + 3) * 8 + (T + 1) * 8 + (64u << 20);
         const size_t need_all = need_dir + (pack_guess ? 0 : (size_t)T * 4) + (std::min<uint64_t>(O.n16, 1ull << 27) * 12 + (64u << 20));
         if (need_all > fr && held_bytes(c) > 0) fr = open_make_room(c);      /* a reservation made for the first batches must not cost the index its directory */
@@ -1473,8 +1514,7 @@ static mtb_status open_impl(mtb_ctx *c, const char *dbdir, const char *taxonomy_
     /* pack on load: big databases (>= 2^28 targets; MTB_OPEN_PACKED=1 / 0 forces it on toy databases / off) whose directory has depth 7
      * open in the SEALED state -- packed 8-byte words, info[] never resident (mtb_index_seal's state; everything that needs the flat
      * arrays unpacks on demand as for any sealed index) */
-    const char *env_pack = getenv("MTB_OPEN_PACKED");
-    bool pack = want_dir && L == 7 && !P.drop_last && !getenv("MTB_NO_PACK") && (env_pack ? atoi(env_pack) != 0 : T >= (1ull << 28));
+    bool pack = want_dir && L == 7 && !P.drop_last && !c->opt.no_pack && (c->opt.open_packed >= 0 ? c->opt.open_packed != 0 : T >= (1ull << 28));
     { size_t fr = 0, tot = 0; HIPCHK(hipMemGetInfo(&fr, &tot)); ix->open_free0 = fr; }
     for (int attempt = 0; attempt < 2; attempt++) {
         ix->open_chunks = 0; ix->open_peak_bytes = 0;
@@ -1921,7 +1961,7 @@ mtb_status mtb_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, const mtb_m
     mtb_result *d_res; int32_t *d_tt; uint32_t *d_tc;
     STCHK(ensure(c, "results", n_reads, &d_res)); STCHK(ensure(c, "tctax", taxcnt_cap, &d_tt)); STCHK(ensure(c, "tccnt", taxcnt_cap, &d_tc));
     ScoreSrc src; src.m = d_m; src.seg = d_seg; src.sort = false; src.max_seg = max_seg;
-    mtb_status st = (p->seq_mode == 3 && !getenv("MTB_NO_LONG_SCORER"))
+    mtb_status st = (p->seq_mode == 3 && !c->opt.no_long_scorer)
         ? dev_score_long(c, ix, p, n_reads, d_ql, d_ql2, max_len, d_res, d_tt, d_tc, taxcnt_cap, n_taxcnt, 0, d_m, d_seg, max_seg)
         : dev_score(c, ix, p, n_reads, d_ql, d_ql2, max_len, d_res, d_tt, d_tc, taxcnt_cap, n_taxcnt, 0, src, nullptr);
     if (st != MTB_OK) return st;
@@ -1948,7 +1988,7 @@ static mtb_status score_join_order(mtb_ctx *c, mtb_index *ix, const mtb_params *
     HIPCHK(hipEventRecord(c->ev[4], st));
     /* segments that fit LDS are sorted inside k_score; only the big ones are sorted here.  Long reads: k_score_long streams sorted
      * segments, so every segment of two or more matches is sorted here */
-    const bool long_scorer = p->seq_mode == 3 && !getenv("MTB_NO_LONG_SCORER");
+    const bool long_scorer = p->seq_mode == 3 && !c->opt.no_long_scorer;
     uint32_t max_seg = 0;
     {
         uint32_t *d_large;
@@ -1982,7 +2022,7 @@ static mtb_status prepare_slots(mtb_ctx *c, uint64_t n_reads, uint32_t stride, m
     mtb_slot16 *d_segm;
     DevBuf &sb = c->bufs["segm"];
     STCHK(ensure_placed(c, "segm", n_reads * (uint64_t)stride, &d_segm));
-    static const char *clear_mode = getenv("MTB_SEGM_CLEAR");      /* experiment switch: kernel | sync | always (default: hipMemsetAsync when new / on epoch wrap) */
+    const char *clear_mode = c->opt.segm_clear[0] ? c->opt.segm_clear : nullptr;      /* experiment switch: kernel | sync | always (default: hipMemsetAsync when new / on epoch wrap) */
     const bool always = clear_mode && !strcmp(clear_mode, "always");
     /* cleared when the allocation is not the one this function cleared last (new, grown, or created by mtb_ctx_reserve: never
      * written by a clear), or when the tag wraps */
@@ -1996,8 +2036,8 @@ static mtb_status prepare_slots(mtb_ctx *c, uint64_t n_reads, uint32_t stride, m
     *out = d_segm; *epoch_out = c->seg_epoch;
     return MTB_OK;
 }
-static void slot_geometry(uint32_t max_q, uint32_t *direct, uint32_t *stride) {
-    static const uint32_t tail_min = getenv("MTB_TAIL_MIN") ? (uint32_t)std::max(8, atoi(getenv("MTB_TAIL_MIN"))) & ~7u : 16u;      /* experiment switch: longer tails */
+static void slot_geometry(const mtb_ctx *c, uint32_t max_q, uint32_t *direct, uint32_t *stride) {
+    const uint32_t tail_min = c->opt.tail_min > 0 ? (uint32_t)std::max(8, c->opt.tail_min) & ~7u : 16u;      /* experiment switch: longer tails */
     *direct = std::max<uint32_t>(8, (max_q + 7) & ~7u);
     *stride = *direct + std::max<uint32_t>(tail_min, (*direct / 8 + 7) & ~7u);
 }
@@ -2036,7 +2076,7 @@ static mtb_status score_fixed_slots(mtb_ctx *c, mtb_index *ix, const mtb_params 
         *go = n_big != 0;
         if (!n_big) return MTB_OK;
         c->many_stats[0] = n_big; c->many_stats[1] = 0;
-        const bool no_many = getenv("MTB_NO_SCORE_MANY") != nullptr;        /* A/B switch, read per batch: every deferred read through exact segments (round 4's path) */
+        const bool no_many = c->opt.no_score_many != 0;        /* A/B switch: every deferred read through exact segments (round 4's path) */
         if (!no_many && stride <= 384u) {
             /* ---- the reads of conserved genes (kernels_score_many.h): scored straight from their slots + their overflow entries, dead
              * species dropped before anything is ordered.  The overflow list is grouped by read first (counts from the tail cursors). ---- */
@@ -2070,11 +2110,11 @@ static mtb_status score_fixed_slots(mtb_ctx *c, mtb_index *ix, const mtb_params 
             STCHK(d2h(c, ms4, d_ms, 64));
             const uint32_t n_rest = (uint32_t)(ms4[0] & 0xFFFFFFFFull);
             c->many_stats[1] = n_big - n_rest; c->many_stats[2] = ms4[2]; c->many_stats[3] = ms4[3];
-            if (getenv("MTB_MANY_VERBOSE")) fprintf(stderr, "mtb: k_score_many: %u reads listed, %u handed on (routed off / buckets / counts %llu, species table full %llu, survivors beyond the staging %llu); %llu matches, %llu survive the dead-species drop\n",
+            if (c->opt.many_verbose) fprintf(stderr, "mtb: k_score_many: %u reads listed, %u handed on (routed off / buckets / counts %llu, species table full %llu, survivors beyond the staging %llu); %llu matches, %llu survive the dead-species drop\n",
                                                     n_big, n_rest, (unsigned long long)ms4[4], (unsigned long long)ms4[5], (unsigned long long)ms4[6], (unsigned long long)ms4[2], (unsigned long long)ms4[3]);
             n_big = n_rest;
             const unsigned long long *d_nleft = d_ms;                   /* where the number of reads still unscored sits on the device */
-            if (n_big && SL.key64 && !getenv("MTB_NO_MANY_SORT")) {
+            if (n_big && SL.key64 && !c->opt.no_many_sort) {
                 /* ---- reads beyond the staging (thousands of matches: conserved genes of organisms that are not in the index): a workgroup per
                  * read gathers, drops dead species, sorts in LDS and writes the read's exact segment; k_score_long streams it ---- */
                 uint32_t *d_bc3, *d_segcnt, *d_rest2; uint64_t *d_bs3; uint8_t *d_todo; mtb_match *d_big3;
@@ -2095,7 +2135,7 @@ static mtb_status score_fixed_slots(mtb_ctx *c, mtb_index *ix, const mtb_params 
                 HIPCHK(hipGetLastError());
                 uint64_t left = 0;
                 STCHK(d2h(c, &left, d_ms + 9, 8));
-                if (getenv("MTB_MANY_VERBOSE")) fprintf(stderr, "mtb: k_many_sort + k_score_long: %u reads (%llu records), %llu left for the exact-segment path\n", n_big, (unsigned long long)total3, (unsigned long long)(left & 0xFFFFFFFFull));
+                if (c->opt.many_verbose) fprintf(stderr, "mtb: k_many_sort + k_score_long: %u reads (%llu records), %llu left for the exact-segment path\n", n_big, (unsigned long long)total3, (unsigned long long)(left & 0xFFFFFFFFull));
                 n_big = (uint32_t)(left & 0xFFFFFFFFull);
                 d_rest = d_rest2; d_nleft = d_ms + 9;
             }
@@ -2203,7 +2243,7 @@ static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, c
     bool fixed = p->seq_mode != 3;
     /* long reads: ordinal slots too, with per-read slot ranges (k_join_dir<.., LONG>, kernels_seg_order.h) -- needs the directory join,
      * positions and ordinals below 2^16; otherwise (and after a failed attempt) exact segments via regroup + segment sort */
-    bool lslot = p->seq_mode == 3 && ix->d_dir && !c->no_lslot && !getenv("MTB_NO_LONG_SLOTS");
+    bool lslot = p->seq_mode == 3 && ix->d_dir && !c->no_lslot && !c->opt.no_long_slots;
     uint32_t *d_dcnt = nullptr;
     if (lslot) { STCHK(ensure(c, "dcnt", n_reads, &d_dcnt)); HIPCHK(hipMemsetAsync(d_dcnt, 0, n_reads * 4, st)); }
     uint16_t *d_dig = nullptr;               /* first radix pass's digits, written by the single-pass extractor */
@@ -2232,9 +2272,9 @@ static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, c
      * passes; three binary passes make the tiles too wide for the LDS window, measured); the tile's target window
      * comes from k_join_bounds */
     mtb_kmer *d_s;
-    const int low_bits = aa6 ? 34 : 32;
     int aa_first_shift = 34;
-    if (aa6 && fixed && ix->d_dir && getenv("MTB_SORT_PAIRS")) aa_first_shift = 64 - 10 * std::max(1, std::min(3, atoi(getenv("MTB_SORT_PAIRS"))));
+    if (aa6 && fixed && ix->d_dir && c->opt.sort_pairs > 0) aa_first_shift = 64 - 10 * std::max(1, std::min(3, c->opt.sort_pairs));
+    const int low_bits = aa6 ? aa_first_shift : 32;          /* the bits the list is NOT sorted on (the join's tile windows follow the sort key) */
     STCHK(dev_sort(c, d_k, nk, aa6 ? MTB_SORT_AA6 : 32, &d_s, aa_first_shift == 34 ? d_dig : nullptr, aa_first_shift));
     HIPCHK(hipEventRecord(c->ev[2], st));
     c->last_sorted = (fixed && ix->d_dir) ? d_s : nullptr; c->last_sorted_n = nk;
@@ -2245,7 +2285,7 @@ static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, c
     if (fixed) {
         /* ---- join straight into per-read slot segments (d_rc = per-read tail cursor) ---- */
         uint32_t direct, stride;
-        slot_geometry(max_q, &direct, &stride);
+        slot_geometry(c, max_q, &direct, &stride);
         mtb_slot16 *d_segm; mtb_match *d_ovf; uint64_t n_ovf = 0; uint32_t epoch = 0;
         STCHK(prepare_slots(c, n_reads, stride, &d_segm, &epoch));
         DevBuf &ob = c->bufs["ovf"];
@@ -2256,6 +2296,7 @@ static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, c
             sa.seg = d_segm; sa.stride = stride; sa.direct = direct; sa.cursor = d_rc; sa.ovf = d_ovf; sa.ovf_cap = ovf_cap;
             sa.ovf_counter = nullptr; sa.epoch = epoch; sa.off = route_off ? d_off : nullptr;
             sa.dense_ovf = attempt == 2 ? 1u : 0u;            /* last attempt: one list that holds the total, whatever the stripes' fill */
+            sa.retry = attempt > 0 ? 1u : 0u;
             mtb_status s2 = dev_join(c, ix, d_s, nk, nullptr, 0, nullptr, &n_ovf, &sa, low_bits);
             if (s2 == MTB_OK) break;
             if (s2 != MTB_ERR_CAPACITY || attempt == 2) return s2;
@@ -2293,7 +2334,7 @@ static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, c
             mtb_status s2 = dev_join(c, ix, d_s, nk, nullptr, 0, nullptr, &n_ovf, &sa, low_bits);
             if (s2 == MTB_ERR_CAPACITY) {                              /* some read's tail overran: larger tails */
                 c->lslot_tf_start = 4;
-                if (getenv("MTB_LSLOT_VERBOSE")) fprintf(stderr, "mtb: long-read slot path: %llu matches beyond the tails at tail factor %u/4\n", (unsigned long long)n_ovf, tf);
+                if (c->opt.lslot_verbose) fprintf(stderr, "mtb: long-read slot path: %llu matches beyond the tails at tail factor %u/4\n", (unsigned long long)n_ovf, tf);
                 continue;
             }
             if (s2 != MTB_OK) return s2;
@@ -2321,7 +2362,7 @@ static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, c
 #endif
             uint64_t sc2[2] = {0, 0};
             STCHK(d2h(c, sc2, c->d_scal + 2, 16));
-            if (getenv("MTB_LSLOT_VERBOSE")) fprintf(stderr, "mtb: long-read slot path: %llu reads, tail factor %u/4, %llu slots, %llu matches, %llu reads beyond the LDS tables (sorted the general way)\n",
+            if (c->opt.lslot_verbose) fprintf(stderr, "mtb: long-read slot path: %llu reads, tail factor %u/4, %llu slots, %llu matches, %llu reads beyond the LDS tables (sorted the general way)\n",
                                                      (unsigned long long)n_reads, tf, (unsigned long long)n_slots, (unsigned long long)sc2[1], (unsigned long long)(sc2[0] & 0xFFFFFFFFull));
             const uint32_t n_failed = (uint32_t)(sc2[0] & 0xFFFFFFFFull);
             /* reads beyond k_seg_order's LDS tables: their live slots -> exact segments, sorted the general way */
@@ -2411,6 +2452,9 @@ static void merge_stats(mtb_batch_stats &S, const mtb_batch_stats &L) {
     S.n_generic_reads += L.n_generic_reads; S.n_slot_reads += L.n_slot_reads;
     S.n_deferred_reads += L.n_deferred_reads; S.n_many_reads += L.n_many_reads; S.n_many_matches += L.n_many_matches; S.n_many_kept += L.n_many_kept;
     for (int i = 0; i < MTB_NUM_KERNELS; i++) { S.ms_kernel[i] += L.ms_kernel[i]; S.n_launch[i] += L.n_launch[i]; }
+    S.join_variant = L.join_variant; S.join_tuned = L.join_tuned;                 /* (of the last range) */
+    for (int v = 0; v < 3; v++) S.join_tune_ms[v] = L.join_tune_ms[v];
+    S.join_tiles += L.join_tiles; S.join_tiles_windowed += L.join_tiles_windowed; S.join_tiles_outside += L.join_tiles_outside;
 }
 
 /* HBM-budgeted batching (the reference sizes a QuerySplit from --max-ram, QueryIndexer.cpp:62,132, and redoes
@@ -2507,7 +2551,7 @@ mtb_status mtb_classify_batch_device(mtb_ctx *c, mtb_index *ix, const mtb_params
     std::vector<uint64_t> ntc(L, 0);
     std::vector<std::thread> th;
     /* `chunks` read ranges per stream, interleaved (range k runs on stream k % L) */
-    static const int chunks = getenv("MTB_CHUNKS_PER_STREAM") ? std::max(1, atoi(getenv("MTB_CHUNKS_PER_STREAM"))) : 1;   /* sweep: profiles/r01_notes.md */
+    const int chunks = std::max(1, c->opt.chunks_per_stream);   /* sweep: profiles/r01_notes.md */
     const size_t NC = L * (size_t)chunks;
     const uint64_t tc_share = taxcnt_cap / NC;
     std::vector<mtb_batch_stats> lane_stats(L);
@@ -2517,7 +2561,7 @@ mtb_status mtb_classify_batch_device(mtb_ctx *c, mtb_index *ix, const mtb_params
             mtb_ctx *l = c->lanes[i];
             /* experiment switch: lane i starts i * MTB_LANE_STAGGER_MS late, so that the lanes are in DIFFERENT stages at any moment
              * (the join is bound by store transactions, the sort by HBM bandwidth, extraction and scoring by VALU issue) */
-            static const int stagger_ms = getenv("MTB_LANE_STAGGER_MS") ? atoi(getenv("MTB_LANE_STAGGER_MS")) : 0;
+            const int stagger_ms = c->opt.lane_stagger_ms;
             if (stagger_ms > 0 && i > 0) std::this_thread::sleep_for(std::chrono::milliseconds((long)stagger_ms * (long)i));
             for (size_t k = i; k < NC; k += L) {
                 uint64_t lo = n_reads * k / NC, hi = n_reads * (k + 1) / NC;
@@ -2641,7 +2685,7 @@ static mtb_status classify_packed_impl(mtb_ctx *c, mtb_index *ix, const mtb_para
     const int rset = async ? c->res_set : 0;
     if (!packed2 || !nmask || !lens) return fail(MTB_ERR_ARG, "packed2/nmask/lens NULL");
     char *d_b = nullptr, *d_b2 = nullptr; uint64_t *d_o = nullptr, *d_o2 = nullptr; uint64_t nb = 0, nb2 = 0;
-    static const bool timing = getenv("MTB_HOST_TIMING") != nullptr;      /* wall time of the call's three parts on stderr (the uploads are synchronised for it) */
+    const bool timing = c->opt.host_timing != 0;      /* wall time of the call's three parts on stderr (the uploads are synchronised for it) */
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
     if (p->seq_mode == 2 && (!packed2_mate || !nmask_mate || !lens_mate)) return fail(MTB_ERR_ARG, "seq_mode 2 needs the mates");
@@ -2834,7 +2878,7 @@ mtb_status mtb_part_extract(mtb_ctx *c, const mtb_params *p, const char *d_bases
     int32_t *d_ql, *d_ql2;
     STCHK(ensure(c, "qlen", n_reads, &d_ql)); STCHK(ensure(c, "qlen2", n_reads, &d_ql2));
     mtb_kmer *d_k, *d_s; uint64_t nk; uint32_t max_len = 0;
-    if (part_starts && p->seq_mode != 3 && !getenv("MTB_PART_EXACT")) {
+    if (part_starts && p->seq_mode != 3 && !c->opt.part_exact) {
         /* the product path of short reads: single-pass extraction with ordinals, the sort on the leading amino-acid letters only (it is
          * there for the locality of the owners' directory joins) -- so a run is cut at PREFIX granularity and the metamers that share
          * their prefix with a bound go to both neighbours: a query finds candidates only in the range that holds its amino-acid
@@ -2879,7 +2923,7 @@ mtb_status mtb_part_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_kmers, uin
     HIPCHK(hipSetDevice(c->device));
     *count = 0;
     if (n == 0 || ix->T == 0) return MTB_OK;
-    if (ix->d_dir && !getenv("MTB_PART_EXACT")) {
+    if (ix->d_dir && !c->opt.part_exact) {
         /* the directory join, matches to a dense list: every record keeps its query's qinfo (with the ordinal tag of a slot-mode
          * batch) and says in `pad` whether it is the query's first match */
         JoinSegArgs sa; memset(&sa, 0, sizeof(sa));
@@ -2911,7 +2955,7 @@ mtb_status mtb_part_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, mtb_ma
          * then the slot scorers run */
         hipStream_t st = c->stream;
         uint32_t direct, stride;
-        slot_geometry(c->part_max_q, &direct, &stride);
+        slot_geometry(c, c->part_max_q, &direct, &stride);
         mtb_slot16 *d_segm; mtb_match *d_ovf; uint32_t epoch = 0; uint64_t n_ovf = 0;
         STCHK(prepare_slots(c, n_reads, stride, &d_segm, &epoch));
         DevBuf &ob = c->bufs["ovf"];
@@ -3240,7 +3284,7 @@ mtb_status mtb_ctx_reserve(mtb_ctx *c, const mtb_params *p, uint64_t n_reads, ui
     const double L = (double)n_bases / (double)n_reads / mates;
     const double per_read = std::max(0.0, L / 3.0 - 7.0) * 6.0 * mates * (p->syncmer ? 0.56 : 1.0) * 1.10;
     uint32_t direct, stride;
-    slot_geometry((uint32_t)std::min<double>(per_read, (double)MTB_SLOT_MAX_Q), &direct, &stride);
+    slot_geometry(c, (uint32_t)std::min<double>(per_read, (double)MTB_SLOT_MAX_Q), &direct, &stride);
     MTB_RESERVE_STEP(ensure(c, "segm", n_reads * (uint64_t)stride, &sg));
 #undef MTB_RESERVE_STEP
     return MTB_OK;

@@ -172,6 +172,8 @@ mtb_status mtb_ctx_set_profiling(mtb_ctx *, int) { return MTB_OK; }
 mtb_status mtb_ctx_set_streams(mtb_ctx *, int) { return MTB_OK; }
 mtb_status mtb_ctx_set_workspace_limit(mtb_ctx *, uint64_t) { return MTB_OK; }
 mtb_status mtb_ctx_set_placement_probe(mtb_ctx *, int) { return MTB_OK; }
+mtb_status mtb_ctx_set_join_variant(mtb_ctx *, int) { return MTB_OK; }
+mtb_status mtb_ctx_set_option(mtb_ctx *, const char *, const char *) { return MTB_OK; }
 uint32_t mtb_ctx_last_sub_batches(const mtb_ctx *) { return 1; }
 mtb_status mtb_ctx_reserve(mtb_ctx *c, const mtb_params *p, uint64_t, uint64_t) { return c && p ? MTB_OK : fail(MTB_ERR_ARG, "NULL argument"); }
 mtb_status mtb_db_parameters(const char *dbdir, mtb_params *p) {

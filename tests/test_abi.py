@@ -53,3 +53,42 @@ def test_headers_compile_as_c99_and_cxx17(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(c)])
     cc = tmp_path / "t.cpp"; cc.write_text('#include "mtb.hpp"\nint main() { return sizeof(mtb::Kmer) == 16 ? 0 : 1; }\n')
     subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(cc)])
+
+
+def test_option_table_parses_names_and_values(tmp_path):
+    """metabuli_amd/csrc/mtb_options.h (the library's experiment switches, read from the environment once per context): every name of the table is
+    settable, flags follow "the variable exists", integers and the join variant parse, unknown names and bad variants are refused -- and no
+    source of the product library calls getenv outside that header."""
+    import subprocess
+    src = tmp_path / "t.cpp"
+    src.write_text(r'''
+#include "mtb_options.h"
+#include <cstdio>
+int main() {
+    MtbOptions o;
+    int bad = 0;
+    for (const mtbopt::Entry &e : mtbopt::kTable) bad += !mtbopt::set(&o, e.name, e.kind == mtbopt::VARIANT ? "q2w5" : "1");
+    bad += !(o.join_variant == 0x25 && o.no_score_many == 1 && o.dir_depth == 1 && o.open_chunk == 1 && o.segm_clear[0] == '1');
+    bad += !mtbopt::set(&o, "MTB_JOIN_VARIANT", "window") || o.join_variant != 0x100;
+    bad += !mtbopt::set(&o, "MTB_JOIN_VARIANT", "auto") || o.join_variant != 0;
+    bad += mtbopt::set(&o, "MTB_JOIN_VARIANT", "q3w9");                 /* refused, value kept */
+    bad += mtbopt::set(&o, "MTB_NO_SUCH_SWITCH", "1");
+    bad += !mtbopt::set(&o, "MTB_NO_SCORE_MANY", nullptr) || o.no_score_many != 0;      /* unset */
+    bad += !mtbopt::set(&o, "MTB_NO_SCORE_MANY", "0") || o.no_score_many != 1;          /* a flag is on when the variable exists */
+    bad += !mtbopt::set(&o, "MTB_JOIN_WIN", nullptr) || o.join_win != -1;               /* back to the default */
+    bad += !mtbopt::set(&o, "MTB_OPEN_CHUNK", "4096") || o.open_chunk != 4096;
+    setenv("MTB_DIR_DEPTH", "7", 1); setenv("MTB_JOIN_WIN_QT", "64", 1);
+    MtbOptions e; mtbopt::from_environment(&e);
+    bad += !(e.dir_depth == 7 && e.join_win_qt == 64 && e.join_win == -1);
+    printf("bad %d\n", bad);
+    return bad;
+}
+''')
+    exe = tmp_path / "t"
+    csrc = os.path.join(ROOT, "metabuli_amd", "csrc")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-I", csrc, "-o", str(exe), str(src)])
+    env = {k: v for k, v in os.environ.items() if not k.startswith("MTB_")}
+    assert subprocess.run([str(exe)], env=env).returncode == 0
+    for f in os.listdir(csrc):
+        if f.endswith((".h", ".hip")) and f != "mtb_options.h":
+            assert "getenv" not in open(os.path.join(csrc, f)).read(), f

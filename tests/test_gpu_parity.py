@@ -561,7 +561,7 @@ def test_long_reads_on_ordinal_slots_and_on_exact_segments(toy, monkeypatch):
     st = c.last_stats()
     assert st.n_slot_reads == toy.n_reads and st.n_matches == len(toy.ref["matches"])
     assert st.n_generic_reads <= toy.n_reads // 2          # (reads with more position buckets than k_score_long's LDS table take the generic kernel)
-    monkeypatch.setenv("MTB_NO_LONG_SLOTS", "1")
+    c.set_option("MTB_NO_LONG_SLOTS", "1")          # (the environment is read once, at mtb_ctx_create: a live context is switched through its API)
     res2, tt2, tc2 = c.classify_batch(ix, p, toy.b1, toy.o1, toy.b2, toy.o2)
     _check_results(toy, res2, tt2, tc2)
     st = c.last_stats()
@@ -919,7 +919,7 @@ def test_queries_that_share_a_long_run_walk_it_in_lockstep(orc, tmp_path, seq_mo
     the hot metamers (every hot metamer is met by several reads) with read errors (queries without an equal target): the per-read
     answers and the match totals are the oracle's -- short reads into fixed slot segments (packed words, LDS window forced on and off),
     long reads into slot ranges.  (Written for the lockstep walk of shared runs, an experiment that is compiled out because it measured
-    slower -- kernels_dir.h, MTB_JOIN_LOCKSTEP_MIN; with -DMTB_JOIN_LOCKSTEP_MIN=3 on the emulated build it exercises that walk, by default
+    slower -- profiles/experiments/join_lockstep_walk.patch; with that patch and -DMTB_JOIN_LOCKSTEP_MIN=3 on the emulated build it exercises that walk, by default
     the wave scan of many neighbouring queries with one run.)"""
     import metabuli_amd as M
     from conftest import HotToy
@@ -933,7 +933,7 @@ def test_queries_that_share_a_long_run_walk_it_in_lockstep(orc, tmp_path, seq_mo
     ro = t.ref["results"]
     amb = ro["flag"] != 0
     for win in (("1", "0") if seq_mode == 1 else ("0",)):
-        monkeypatch.setenv("MTB_JOIN_WIN", win)
+        c.set_option("MTB_JOIN_WIN", win)
         res, tt, tc = c.classify_batch(ix, p, t.b1, t.o1, t.b2, t.o2)
         assert ((res["classification"] == ro["classification"]) | amb).all(), win
         assert ((res["score"].view(np.uint32) == ro["score"].view(np.uint32)) | amb).all(), win
@@ -962,16 +962,29 @@ def test_target_windows_staged_in_lds_give_the_same_matches(orc, tmp_path, seq_m
     monkeypatch.delenv("MTB_DIR_DEPTH", raising=False)
     ro = t.ref["results"]
     amb = ro["flag"] != 0
-    for win, qt in (("1", "5"), ("1", "64"), ("1", "256"), ("0", "256")):
-        monkeypatch.setenv("MTB_JOIN_WIN", win); monkeypatch.setenv("MTB_JOIN_WIN_QT", qt)
+    windowed = {}
+    for win, qt, noprewin in (("1", "5", None), ("1", "64", None), ("1", "256", None), ("1", "64", "1"), ("1", "256", "1"), ("0", "256", None)):
+        c.set_option("MTB_JOIN_WIN", win); c.set_option("MTB_JOIN_WIN_QT", qt); c.set_option("MTB_JOIN_NO_PREWIN", noprewin)
         res, tt, tc = c.classify_batch(ix, p, t.b1, t.o1, t.b2, t.o2)
+        st = c.last_stats()
+        tag = (win, qt, noprewin, M.JOIN_VARIANTS[st.join_variant])
         assert ix.state()["packed"]
-        assert ((res["classification"] == ro["classification"]) | amb).all(), (win, qt)
-        assert ((res["score"].view(np.uint32) == ro["score"].view(np.uint32)) | amb).all(), (win, qt)
-        assert ((res["n_taxcnt"] == ro["n_taxcnt"]) | amb).all(), (win, qt)
+        assert st.join_variant == (3 if win == "1" else 1) and st.join_tuned == 0, tag          # pinned: the tuner stays out
+        assert ((res["classification"] == ro["classification"]) | amb).all(), tag
+        assert ((res["score"].view(np.uint32) == ro["score"].view(np.uint32)) | amb).all(), tag
+        assert ((res["n_taxcnt"] == ro["n_taxcnt"]) | amb).all(), tag
         if not amb.any():
-            assert (tt == t.ref["tc_tax"]).all() and (tc == t.ref["tc_cnt"]).all(), (win, qt)
-        assert c.last_stats().n_matches == len(t.ref["matches"]), (win, qt)
+            assert (tt == t.ref["tc_tax"]).all() and (tc == t.ref["tc_cnt"]).all(), tag
+        assert st.n_matches == len(t.ref["matches"]), tag
+        if win == "1":
+            # tiles of the announced size; with the windows bounded before the launch (k_join_tile_win) the statistics say how many were staged,
+            # and no tile ever finds a query outside its announced window
+            assert st.join_tiles == (st.n_kmers + int(qt) - 1) // int(qt) or st.join_tiles >= st.n_kmers // int(qt), tag
+            assert st.join_tiles_outside == 0, tag
+            if noprewin is None:
+                windowed[qt] = st.join_tiles_windowed
+    assert windowed["5"] > 0 and windowed["64"] > 0, windowed           # small tiles: spans that fit LDS
+    assert windowed["256"] < (len(t.ref["matches"]) + 255) // 256 + 64   # (wide tiles over a toy index mostly exceed the capacity)
     ix.close(); c.close()
 
 
@@ -1003,11 +1016,11 @@ def test_reads_that_meet_many_species_are_scored_from_their_slots(orc, tmp_path,
     st = c.last_stats()
     assert st.n_deferred_reads > 20 and st.n_many_reads > 20, (st.n_deferred_reads, st.n_many_reads)
     assert 0 < st.n_many_kept < st.n_many_matches, (st.n_many_kept, st.n_many_matches)
-    monkeypatch.setenv("MTB_NO_SCORE_MANY", "1")
+    c.set_option("MTB_NO_SCORE_MANY", "1")
     check(*c.classify_batch(ix, p, t.b1, t.o1, t.b2, t.o2))
     st2 = c.last_stats()
     assert st2.n_many_reads == 0 and st2.n_deferred_reads == st.n_deferred_reads
-    monkeypatch.delenv("MTB_NO_SCORE_MANY")
+    c.set_option("MTB_NO_SCORE_MANY", None)
     check(*c.classify_batch(ix, p, t.b1, t.o1, t.b2, t.o2))
     ix.close(); c.close()
 
