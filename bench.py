@@ -473,11 +473,7 @@ def oracle_parity(ctx, M, torch, dev, index, params, taxdir, d_bases, d_bases2, 
     ncores = os.cpu_count() or 1
     cpu = None
     if time_cpu:
-        cold_s = None
-        if drop_page_cache():       # first run with the database files out of the page cache (they were just written)
-            tc0 = time.perf_counter()
-            orc.classify_batch(db, tax, op, bases, offs, bases2, offs2, threads=ncores)
-            cold_s = time.perf_counter() - tc0
+        cold_s = None               # (no cold-cache run: the GPU pool does not let a job drop the machine's page cache; the files were just written, so every run is warm)
         nw = min(n, 20000)          # untimed: creates the OpenMP thread pool
         orc.classify_batch(db, tax, op, bases[: nw * read_len], offs[: nw + 1], bases2[: nw * read_len] if paired else None, offs[: nw + 1] if paired else None, threads=ncores)
     t0 = time.perf_counter()
@@ -493,8 +489,7 @@ def oracle_parity(ctx, M, torch, dev, index, params, taxdir, d_bases, d_bases2, 
         fbytes = int(sum(os.path.getsize(os.path.join(d, f)) for f in ("diffIdx", "info")))
         cpu = dict(value=n / dt / 1e6, unit="Mreads/s", cores=ncores, kind="port", cpu_model=cpu_model(),
                    single_thread_value=n1 / dt1 / 1e6, stage_seconds={k: round(v, 3) for k, v in stage_s.items()},
-                   cold_cache_first_run_s=cold_s, cold_cache_note=("database files dropped from the page cache before the first run (includes creating the OpenMP pool)"
-                                                                   if cold_s is not None else "could not drop the page cache: warm runs only"),
+                   cold_cache_first_run_s=cold_s, cold_cache_note="warm runs only: the database files were written just before and sit in the page cache",
                    numa=numa_layout(), index_targets=int(len(cv)), index_file_bytes=fbytes, timed_index_targets=int(T),
                    sample=f"first {n} x {'2 x ' if paired else ''}{read_len} bp reads of the timed batch vs a {len(cv)}-target sub-database of the timed index "
                           f"(every {sub['stride']}th target + the candidate closure of the sample: same answers as against all {T} targets); "
@@ -549,17 +544,6 @@ def numa_layout():
     except OSError:
         pass
     return out
-
-
-def drop_page_cache():
-    """cold-cache run of the CPU baseline: needs root and a writable /proc/sys/vm/drop_caches"""
-    try:
-        os.sync()
-        with open("/proc/sys/vm/drop_caches", "w") as f:
-            f.write("3\n")
-        return True
-    except OSError:
-        return False
 
 
 def cpu_model():
