@@ -855,7 +855,7 @@ def main(device=None):
                     help="SURVEY 8(e) row 2: every rank owns one value range of the index; metamers and matches travel by all-to-all "
                          "(functional/perf check of that path; the default is the replicated index)")
     ap.add_argument("--no-seal", action="store_true", help="keep the flat {value, info} arrays next to the packed state (mtb_index_seal not called)")
-    ap.add_argument("--ab", default="", help="A/B legs after the timed region: ';'-separated NAME=VALUE settings of the library's per-batch experiment switches "
+    ap.add_argument("--ab", default="", help="A/B legs after the timed region: ';'-separated settings (NAME=VALUE, or several joined by ',') of the library's experiment switches "
                                              "(MTB_NO_SCORE_MANY=1, MTB_JOIN_VARIANT=q1w6 ...); each is timed on the headline batch (and the best-case batch) in this very process, "
                                              "on this very index and allocation")
     ap.add_argument("--reads-from", default="index", choices=["index", "heldout"],
@@ -1082,8 +1082,9 @@ def main(device=None):
 
     def ab_legs(tag, fn, n_reads_leg):
         for setting in [x for x in args.ab.split(";") if "=" in x]:
-            k, v = setting.split("=", 1)
-            ctx.set_option(k, v)                     # (the library reads its environment once, at mtb_ctx_create: a live context is switched through mtb_ctx_set_option)
+            pairs = [kv.split("=", 1) for kv in setting.split(",") if "=" in kv]          # one leg may set several switches: A=1,B=2
+            for k, v in pairs:
+                ctx.set_option(k, v)                 # (the library reads its environment once, at mtb_ctx_create: a live context is switched through mtb_ctx_set_option)
             try:
                 ms = timed_leg(torch, fn, 1, 3)      # (a forced switch turns the tuner off; the shapes' tuned choices are remembered)
                 s2 = ctx.last_stats()
@@ -1091,7 +1092,8 @@ def main(device=None):
                                                        stage_ms=dict(extract=s2.ms_extract, sort=s2.ms_sort, join=s2.ms_join, score=s2.ms_score, total=s2.ms_total))
                 log(f"[rank 0] A/B {tag} {setting}: {ms:.1f} ms per step (join {s2.ms_join:.1f}, score {s2.ms_score:.1f})")
             finally:
-                ctx.set_option(k, os.environ.get(k))
+                for k, _ in pairs:
+                    ctx.set_option(k, os.environ.get(k))
         if args.ab:
             ms = timed_leg(torch, fn, 1, 3)
             s2 = ctx.last_stats()

@@ -282,6 +282,7 @@ __global__ __launch_bounds__(256) void k_big_ovf(const mtb_match *__restrict__ o
         i += (uint64_t)blockIdx.y * region_cap;
     } else if (i >= n_ovf) return;
     mtb_match m = ovf[i];
+    if (m.pad & 2u) { m.qinfo &= ~0xFFFF0000ull; m.pad = 0; }      /* (the directory join's entries carry their place in the read's group: kernels_dir.h, ovf_put) */
     uint32_t b = bigidx[mtb_q_seq(m.qinfo) - 1];
     if (b == 0xFFFFFFFFu) return;         /* a read that is not on the list (scored by k_score_many from the grouped overflow entries): bigidx[] is set to ~0 before k_big_count */
     uint32_t slot = atomicAdd(&bigcur[b], 1u);

@@ -41,10 +41,14 @@ __global__ __launch_bounds__(256) void k_ovf_count(const uint32_t *__restrict__ 
     const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= n_reads) return;
     const uint32_t cur = cursor[r];
-    novf[r] = (cur > tail_cap && !(off && off[r])) ? cur - tail_cap : 0u;
+    const uint32_t n = (cur > tail_cap && !(off && off[r])) ? cur - tail_cap : 0u;
+    novf[r] = n <= 65535u ? n : 0u;          /* (the place of an entry in its group rides in 16 bits of the record; a read beyond that takes the exact-segment path) */
 }
-/* every entry of the overflow list -> its read's group (place by a returning atomic on the read's counter; the order inside a group is
- * irrelevant: the scorer sorts).  region_cap != 0: striped list (JoinSegArgs::ovf_stripes), blockIdx.y = stripe. */
+/* every entry of the overflow list -> its read's group.  The directory join's entries carry their place (pad & 2: bits [16, 32) of qinfo =
+ * the match's tail cursor value - the tail's capacity, k_join_dir's ovf_put): a plain store; the entries of the other producers (k_join<SEG>,
+ * k_slot_place) are placed by a returning atomic on the read's counter (the order inside a group is irrelevant: the scorer sorts; a read's
+ * entries all come from one producer).  The grouped records carry the reference's qinfo and pad = 0 again.
+ * region_cap != 0: striped list (JoinSegArgs::ovf_stripes), blockIdx.y = stripe. */
 __global__ __launch_bounds__(256) void k_ovf_group(const mtb_match *__restrict__ ovf, uint64_t n_ovf, const uint64_t *__restrict__ start, const uint32_t *__restrict__ novf,
                                                     uint32_t *__restrict__ ocur, mtb_match *__restrict__ out, uint64_t region_cap, const unsigned long long *__restrict__ counters) {
     uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -53,11 +57,13 @@ __global__ __launch_bounds__(256) void k_ovf_group(const mtb_match *__restrict__
         if (i >= cnt || i >= region_cap) return;
         i += (uint64_t)blockIdx.y * region_cap;
     } else if (i >= n_ovf) return;
-    const mtb_match m = ovf[i];
+    mtb_match m = ovf[i];
     const uint32_t r = mtb_q_seq(m.qinfo) - 1;
     const uint32_t cap = novf[r];
-    if (!cap) return;                                     /* a read routed around its slots */
-    const uint32_t at = atomicAdd(&ocur[r], 1u);
+    if (!cap) return;                                     /* a read routed around its slots, or one with more entries than a group holds */
+    uint32_t at;
+    if (m.pad & 2u) { at = (uint32_t)(m.qinfo >> 16) & 0xFFFFu; m.qinfo &= ~0xFFFF0000ull; m.pad = 0; }
+    else at = atomicAdd(&ocur[r], 1u);
     if (at < cap) out[start[r] + at] = m;
 }
 
@@ -224,6 +230,11 @@ __global__ __launch_bounds__(64, (CAP > 192 ? 2 : 3)) void k_score_many(const mt
         if (ovf_start) { o0 = ovf_start[r]; n_ov = (uint32_t)(ovf_start[r + 1] - o0); }
         bool hand_on = (off_reads && off_reads[r]) || nb > MTB_SCORE_BKT || cur - tail_n != n_ov;
         uint32_t why = 2;
+        /* a read with more than three times the staging in its tail + overflow entries alone (a conserved gene of an organism that is NOT in the
+         * index: ~1100 records over a thousand species, most of them with a pair of matches -- the dead-species drop barely shrinks it) would
+         * fail the staging after both passes over its records: handed on at once (the next tier, k_many_sort, takes any read within ITS budgets;
+         * which tier scores a read is a question of time, not of the result).  12 ms of this kernel's 12 on 2 M such reads were these passes. */
+        if (!hand_on && cur > 3u * (uint32_t)CAP) { hand_on = true; why = 4; }
         const mtb_slot16 *slots = slots_all + r * (uint64_t)stride;
         mtb_sws<uint16_t> w;
         mtb_sws_carve<uint16_t>(&w, s_ws, CAP);
