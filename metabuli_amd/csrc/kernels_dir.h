@@ -280,16 +280,25 @@ __global__ __launch_bounds__(256) void k_join_tile_win(const mtb_kmer *__restric
     if ((threadIdx.x & 63u) == 0 && m) atomicAdd(stat, (unsigned long long)__popcll(m));
 }
 
-template <bool PACKED, int MODE = 0, int QPT = ((PACKED && MODE == 0) ? MTB_JOIN_DIR_QPT0 : MTB_JOIN_DIR_QPT), int WAVES = MTB_JOIN_WAVES, bool WIN = false>
+/* WIN == 2 (round 6): the window holds only the LOW 32 bits of every packed word -- all that the search and the evaluation read (29 bits tell the
+ * targets of a bucket apart, 24 of them are the DNA part) -- staged by 4-byte direct-to-LDS loads (a lane per target); the full word is fetched
+ * from global memory (L2-warm: the window's load has just brought its sector) for SELECTED candidates only.  Half the LDS per tile: more
+ * workgroups per CU for a kernel whose waves spend 63 % of their time waiting on dependent accesses (profiles/r06_notes.md). */
+template <bool PACKED, int MODE = 0, int QPT = ((PACKED && MODE == 0) ? MTB_JOIN_DIR_QPT0 : MTB_JOIN_DIR_QPT), int WAVES = MTB_JOIN_WAVES, int WIN = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && MODE != 2) ? WAVES : 5))) void k_join_dir(const mtb_kmer *__restrict__ q, uint64_t n, mtb_index_view ix, uint64_t limit, mtb_dir_view dv,
                                                    const mtb_tables *__restrict__ tabs, JoinSegArgs sa, uint32_t *__restrict__ overflow, uint32_t qt = 256,
                                                    const mtb_tile_win *__restrict__ tile_win = nullptr, unsigned long long *__restrict__ win_stat = nullptr) {
     constexpr int Q = QPT;
-    static_assert(!WIN || (QPT == 1 && PACKED && MODE == 0), "the window variant: short reads, packed words, one query per thread");
-    __shared__ __attribute__((aligned(16))) uint64_t s_win[WIN ? MTB_JOIN_WINCAP : 2];
+    static_assert(!WIN || (QPT == 1 && PACKED && MODE != 2), "the window variants: packed words, one query per thread, slot modes");
+    __shared__ __attribute__((aligned(16))) uint64_t s_win[WIN == 1 ? MTB_JOIN_WINCAP : WIN == 2 ? MTB_JOIN_WINCAP / 2 : 2];
     __shared__ unsigned long long s_w0, s_w1;
     uint64_t w0 = 0; bool use_win = false;
-    auto rdv = [&](uint64_t t) -> uint64_t { return (WIN && use_win) ? s_win[t - w0] : ix.values[t]; };
+    /* rdv: what the search and the evaluation read (WIN == 2: the low 32 bits only); full_of: the whole word of a SELECTED candidate */
+    auto rdv = [&](uint64_t t) -> uint64_t {
+        if (WIN == 2) return use_win ? (uint64_t)((const uint32_t *)s_win)[t - w0] : ix.values[t];
+        return (WIN && use_win) ? s_win[t - w0] : ix.values[t];
+    };
+    auto full_of = [&](uint64_t t, uint64_t v) -> uint64_t { return (WIN == 2 && use_win) ? ix.values[t] : v; };
     constexpr bool LONG = MODE == 1, LIST = MODE == 2;
     const uint64_t AAM = ~0xFFFFFFull;
     __shared__ uint32_t s_hr[8];                    /* hammingLookup rows as nibble words: the only table the join arithmetic reads (filled below, behind the loads that matter) */
@@ -299,7 +308,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
      * between the pieces -- a loop of load / ds_write pairs waited for every load: a dozen dependent round trips per tile, measured 96 ms
      * against 80 for the random join).  The last piece may reach beyond the window (never read) -- but not beyond the array. */
     auto stage_window = [&](uint64_t a0, uint64_t a1) {
-        const uint32_t n_piece = (uint32_t)((a1 - a0 + 127) >> 7), wv_ = threadIdx.x >> 6, ln_ = threadIdx.x & 63u;
+        const uint32_t wv_ = threadIdx.x >> 6, ln_ = threadIdx.x & 63u;
+        if (WIN == 2) {                              /* 64 targets a piece: every lane fetches the low dword of its own target */
+            uint32_t *const s32 = (uint32_t *)s_win;
+            const uint32_t n_piece32 = (uint32_t)((a1 - a0 + 63) >> 6);
+            for (uint32_t pc = wv_; pc < n_piece32; pc += 4) {
+                uint64_t idx = a0 + ((uint64_t)pc << 6) + ln_;
+                if (idx >= ix.n_targets) idx = ix.n_targets - 1;            /* (behind the window: never read) */
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ix.values + idx),
+                                                 (__attribute__((address_space(3))) void *)(s32 + ((uint64_t)pc << 6)), 4, 0, MTB_WIN_AUX);
+            }
+            return;
+        }
+        const uint32_t n_piece = (uint32_t)((a1 - a0 + 127) >> 7);
         for (uint32_t pc = wv_; pc < n_piece; pc += 4) {
             const uint64_t src = a0 + ((uint64_t)pc << 7) + 2u * ln_;
             if (a0 + ((uint64_t)pc << 7) + 128 > ix.n_targets) {           /* the piece that holds the array's end (one per index): plain guarded loads */
@@ -650,7 +671,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
                         if ((int)lane == leader) at0 = atomicAdd(&sa.cursor[r], (uint32_t)__popcll(m) * inc);
                         at0 = (uint32_t)__shfl((int)at0, leader, 64);
                     }
-                    if (sel) put(s0 + off, rdv(s0 + off), cb[b] & 15u, own ? ~0u : (offr ? tcap : at0 + (uint32_t)__popcll(m & lt_mask)));
+                    if (sel) put(s0 + off, full_of(s0 + off, rdv(s0 + off)), cb[b] & 15u, own ? ~0u : (offr ? tcap : at0 + (uint32_t)__popcll(m & lt_mask)));
                 }
                 continue;
             }
@@ -669,7 +690,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
                     if ((int)lane == leader) at0 = atomicAdd(&sa.cursor[r], n_tail * inc);
                     at0 = (uint32_t)__shfl((int)at0, leader, 64);
                 }
-                if (sel) put(t, v, h, (first && rk == 0) ? ~0u : (offr ? tcap : at0 + rk - skip));
+                if (sel) put(t, full_of(t, v), h, (first && rk == 0) ? ~0u : (offr ? tcap : at0 + rk - skip));
                 first = false;
             }
         }
@@ -680,7 +701,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
         if (!valid[u]) continue;
         const uint64_t s = lo[u], e = e_hi[u];
         uint64_t v0 = rdv(s);
-        const uint32_t info0 = PACKED ? (uint32_t)(v0 >> MTB_PACK_LOW) : ix.info[s];      /* flat state: issued now, the first candidate is selected more often than not */
+        const uint32_t info0 = PACKED ? 0u : ix.info[s];      /* flat state: issued now, the first candidate is selected more often than not */
         mtb_qrows qr; mtb_prepare_query_rows(s_hr, k[u].value, &qr);
         uint32_t mn = mtb_ham_sum(&qr, (uint32_t)v0 & 0xFFFFFFu);
         for (uint64_t t = s + 1; t < e; t++) { const uint32_t h = mtb_ham_sum(&qr, (uint32_t)rdv(t) & 0xFFFFFFu); mn = h < mn ? h : mn; }
@@ -700,7 +721,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
             const uint32_t td = (uint32_t)v & 0xFFFFFFu;
             const uint32_t h = mtb_ham_sum(&qr, td);
             if (h > thr) continue;
-            const int32_t tid = (int32_t)((t == s ? info0 : (PACKED ? (uint32_t)(v >> MTB_PACK_LOW) : ix.info[t])) & ix.info_mask);
+            const int32_t tid = (int32_t)((PACKED ? (uint32_t)(full_of(t, v) >> MTB_PACK_LOW) : (t == s ? info0 : ix.info[t])) & ix.info_mask);
             const int32_t sp = (tid >= 0 && tid <= ix.max_taxid) ? ix.tax2species[tid] : 0;
             const uint16_t reh = mtb_hammings(&qr, td, rev);
             /* non-temporal stores: a slot line is written ~5 times at unrelated moments of the kernel and never read by it; keeping

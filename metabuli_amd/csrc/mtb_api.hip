@@ -774,7 +774,9 @@ static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint6
             if (c->opt.join_win_qt > 0) qt = (uint32_t)std::min(256, c->opt.join_win_qt);
             qt = std::max<uint32_t>(qt, 1);
             int choice = -1;                                 /* 0: q1w6, 1: q2w5, 2: window, 3 / 4: the A/B-only instantiations q1w5 / q2w6 */
-            switch (c->opt.join_variant) { case 0x16: choice = 0; break; case 0x25: choice = 1; break; case 0x100: choice = 2; break; case 0x15: choice = 3; break; case 0x26: choice = 4; break; default: break; }
+            int win32 = 0;                                   /* != 0: the window holds low dwords only (kernels_dir.h, WIN == 2), compiled for that many waves per SIMD */
+            switch (c->opt.join_variant) { case 0x16: choice = 0; break; case 0x25: choice = 1; break; case 0x100: choice = 2; break; case 0x15: choice = 3; break; case 0x26: choice = 4; break;
+                                           case 0x205: case 0x206: case 0x207: case 0x208: choice = 2; win32 = c->opt.join_variant & 15; break; default: break; }
             if (choice < 0 && c->opt.join_win >= 0) choice = c->opt.join_win ? 2 : 0;
             const bool forced = choice >= 0;
             uint32_t lg_n = 0; for (uint64_t x = n; x > 1; x >>= 1) lg_n++;
@@ -810,7 +812,7 @@ static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint6
              * retries of a batch (overflow list too small) and lanes never time anything, they follow what is known */
             if (choice < 0 && jt && jt->best >= 0) { choice = (jt->best == 2 && !win_ok) ? 0 : jt->best; tuned_flag = 1; }
             if (choice < 0) choice = win_ok ? 2 : 0;         /* not tuned (yet): by density */
-            c->stats.join_variant = choice == 0 ? MTB_JOIN_Q1W6 : choice == 1 ? MTB_JOIN_Q2W5 : choice == 2 ? MTB_JOIN_WINDOW : -choice;
+            c->stats.join_variant = choice == 0 ? MTB_JOIN_Q1W6 : choice == 1 ? MTB_JOIN_Q2W5 : choice == 2 ? (win32 ? -(10 + win32) : MTB_JOIN_WINDOW) : -choice;
             c->stats.join_tuned = tuned_flag;
             if (jt) for (int v = 0; v < 3; v++) c->stats.join_tune_ms[v] = jt->ms[v] < 1e29f ? jt->ms[v] : 0.0f;
             if (choice == 2) {
@@ -824,8 +826,16 @@ static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint6
                     hipLaunchKernelGGL(k_join_tile_win, dim3((n_tiles + 255) / 256), dim3(256), 0, c->stream, d_q, n, qt, dir_view(ix), limit, sort_low_bits, d_tw, n_tiles,
                                        (unsigned long long *)(c->d_scal + 16));
                 }
-                hipLaunchKernelGGL((k_join_dir<true, 0, 1, 5, true>), dim3(n_tiles), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix),
-                                   (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1), qt, (const mtb_tile_win *)d_tw, (unsigned long long *)(c->d_scal + 16));
+#define MTB_LAUNCH_JW(WV, WINV) hipLaunchKernelGGL((k_join_dir<true, 0, 1, WV, WINV>), dim3(n_tiles), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), \
+                                   (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1), qt, (const mtb_tile_win *)d_tw, (unsigned long long *)(c->d_scal + 16))
+                switch (win32) {
+                case 5: MTB_LAUNCH_JW(5, 2); break;
+                case 6: MTB_LAUNCH_JW(6, 2); break;
+                case 7: MTB_LAUNCH_JW(7, 2); break;
+                case 8: MTB_LAUNCH_JW(8, 2); break;
+                default: MTB_LAUNCH_JW(5, 1); break;
+                }
+#undef MTB_LAUNCH_JW
                 win_tiles = n_tiles;
             } else
             switch (choice) {

@@ -15,7 +15,7 @@
 
 struct MtbOptions {
     /* join (kernels_dir.h) */
-    int join_variant = 0;          /* MTB_JOIN_VARIANT: 0 auto (the context's tuner), else (Q << 4 | W) of q<Q>w<W>: 0x16, 0x25, 0x15, 0x26, or 0x100 = window */
+    int join_variant = 0;          /* MTB_JOIN_VARIANT: 0 auto (the context's tuner), else (Q << 4 | W) of q<Q>w<W>: 0x16, 0x25, 0x15, 0x26, 0x100 = window, 0x200 | W = the low-dword window at W waves per SIMD */
     int join_win = -1;             /* MTB_JOIN_WIN: -1 by density, 0 off, 1 on */
     int join_win_qt = 0;           /* MTB_JOIN_WIN_QT: queries per window tile (0 = from the batch's density) */
     int join_no_prewin = 0;        /* MTB_JOIN_NO_PREWIN: the window variant finds its window inside the kernel (round 5's form) */
@@ -78,6 +78,7 @@ static const Entry kTable[] = {
 static inline int parse_variant(const char *v) {
     if (!v || !*v || !strcmp(v, "auto")) return 0;
     if (!strcmp(v, "window")) return 0x100;
+    if (!strncmp(v, "win32w", 6) && v[6] >= '5' && v[6] <= '8' && !v[7]) return 0x200 | (v[6] - '0');       /* the low-dword window at 5..8 waves per SIMD (A/B) */
     if (v[0] == 'q' && v[1] >= '1' && v[1] <= '2' && v[2] == 'w' && v[3] >= '5' && v[3] <= '6' && !v[4]) return ((v[1] - '0') << 4) | (v[3] - '0');
     return -1;
 }

@@ -963,13 +963,15 @@ def test_target_windows_staged_in_lds_give_the_same_matches(orc, tmp_path, seq_m
     ro = t.ref["results"]
     amb = ro["flag"] != 0
     windowed = {}
-    for win, qt, noprewin in (("1", "5", None), ("1", "64", None), ("1", "256", None), ("1", "64", "1"), ("1", "256", "1"), ("0", "256", None)):
-        c.set_option("MTB_JOIN_WIN", win); c.set_option("MTB_JOIN_WIN_QT", qt); c.set_option("MTB_JOIN_NO_PREWIN", noprewin)
+    for win, qt, noprewin, variant in (("1", "5", None, None), ("1", "64", None, None), ("1", "256", None, None), ("1", "64", "1", None), ("1", "256", "1", None), ("0", "256", None, None),
+                                       ("1", "64", None, "win32w6"), ("1", "5", None, "win32w8"), ("1", "256", "1", "win32w7")):
+        # (win32w<W>: the window holds the low dwords only, the full word of a selected candidate comes from global memory)
+        c.set_option("MTB_JOIN_WIN", win); c.set_option("MTB_JOIN_WIN_QT", qt); c.set_option("MTB_JOIN_NO_PREWIN", noprewin); c.set_option("MTB_JOIN_VARIANT", variant)
         res, tt, tc = c.classify_batch(ix, p, t.b1, t.o1, t.b2, t.o2)
         st = c.last_stats()
         tag = (win, qt, noprewin, M.JOIN_VARIANTS[st.join_variant])
         assert ix.state()["packed"]
-        assert st.join_variant == (3 if win == "1" else 1) and st.join_tuned == 0, tag          # pinned: the tuner stays out
+        assert M.JOIN_VARIANTS[st.join_variant] == (variant or ("window" if win == "1" else "q1w6")) and st.join_tuned == 0, tag          # pinned: the tuner stays out
         assert ((res["classification"] == ro["classification"]) | amb).all(), tag
         assert ((res["score"].view(np.uint32) == ro["score"].view(np.uint32)) | amb).all(), tag
         assert ((res["n_taxcnt"] == ro["n_taxcnt"]) | amb).all(), tag
@@ -981,7 +983,7 @@ def test_target_windows_staged_in_lds_give_the_same_matches(orc, tmp_path, seq_m
             # and no tile ever finds a query outside its announced window
             assert st.join_tiles == (st.n_kmers + int(qt) - 1) // int(qt) or st.join_tiles >= st.n_kmers // int(qt), tag
             assert st.join_tiles_outside == 0, tag
-            if noprewin is None:
+            if noprewin is None and variant is None:
                 windowed[qt] = st.join_tiles_windowed
     assert windowed["5"] > 0 and windowed["64"] > 0, windowed           # small tiles: spans that fit LDS
     assert windowed["256"] < (len(t.ref["matches"]) + 255) // 256 + 64   # (wide tiles over a toy index mostly exceed the capacity)
