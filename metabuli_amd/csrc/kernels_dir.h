@@ -243,8 +243,13 @@ __device__ __forceinline__ uint32_t wave_min_shfl_u32(uint32_t v) {
  * The span is that of the exact minimum / maximum widened to whole sort-key groups at both ends (187 targets a group at 16 G targets);
  * a query whose bucket is not inside it (never, unless the list is not sorted as announced) sends the whole tile to global memory. */
 struct mtb_tile_win { uint64_t first, words; };
+__device__ __forceinline__ uint64_t wave_bcast64_pre(uint64_t v, int src) {
+    return ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 64) << 32) | (uint64_t)(uint32_t)__shfl((int)(uint32_t)v, src, 64);
+}
 __global__ __launch_bounds__(256) void k_join_tile_win(const mtb_kmer *__restrict__ q, uint64_t n, uint32_t qt, mtb_dir_view dv, uint64_t limit, int low_bits,
-                                                        mtb_tile_win *__restrict__ win, uint32_t n_tiles, unsigned long long *__restrict__ stat) {
+                                                        mtb_tile_win *__restrict__ win, uint32_t n_tiles, unsigned long long *__restrict__ stat,
+                                                        uint32_t cap = MTB_JOIN_WINCAP /* words a window may hold */,
+                                                        uint32_t *__restrict__ nowin_list = nullptr /* the tiles WITHOUT a window, listed (count in stat[2]): k_join_win leaves them to a launch of the sector-random form */) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     const bool live = t < n_tiles;
     bool windowed = false;
@@ -271,13 +276,23 @@ __global__ __launch_bounds__(256) void k_join_tile_win(const mtb_kmer *__restric
         uint64_t a0 = dv.base[blo >> 16] + dv.dir[blo], a1 = dv.base[(bhi + 1) >> 16] + dv.dir[bhi + 1];
         if (a1 > limit) a1 = limit;
         a0 &= ~1ull;                                       /* 16-byte aligned pieces */
-        if (a1 > a0 && a1 - a0 <= (uint64_t)MTB_JOIN_WINCAP) { w.first = a0; w.words = a1 - a0; windowed = true; }
+        if (a1 > a0 && a1 - a0 <= (uint64_t)cap) { w.first = a0; w.words = a1 - a0; windowed = true; }
     }
     win[t] = w;
     }
     /* statistics (mtb_batch_stats.join_tiles_windowed): one atomic per wave */
     const uint64_t m = __ballot(windowed);
     if ((threadIdx.x & 63u) == 0 && m) atomicAdd(stat, (unsigned long long)__popcll(m));
+    if (nowin_list) {                                /* one returning atomic per wave */
+        const uint64_t mm = __ballot(live && !windowed);
+        if (mm) {
+            const uint32_t ln = threadIdx.x & 63u;
+            unsigned long long at0 = 0;
+            if (ln == (uint32_t)(__ffsll((unsigned long long)mm) - 1)) at0 = atomicAdd(stat + 2, (unsigned long long)__popcll(mm));
+            at0 = wave_bcast64_pre(at0, __ffsll((unsigned long long)mm) - 1);
+            if (live && !windowed) nowin_list[at0 + (uint32_t)__popcll(mm & ((1ull << ln) - 1ull))] = t;
+        }
+    }
 }
 
 /* WIN == 2 (round 6): the window holds only the LOW 32 bits of every packed word -- all that the search and the evaluation read (29 bits tell the
@@ -287,7 +302,8 @@ __global__ __launch_bounds__(256) void k_join_tile_win(const mtb_kmer *__restric
 template <bool PACKED, int MODE = 0, int QPT = ((PACKED && MODE == 0) ? MTB_JOIN_DIR_QPT0 : MTB_JOIN_DIR_QPT), int WAVES = MTB_JOIN_WAVES, int WIN = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && MODE != 2) ? WAVES : 5))) void k_join_dir(const mtb_kmer *__restrict__ q, uint64_t n, mtb_index_view ix, uint64_t limit, mtb_dir_view dv,
                                                    const mtb_tables *__restrict__ tabs, JoinSegArgs sa, uint32_t *__restrict__ overflow, uint32_t qt = 256,
-                                                   const mtb_tile_win *__restrict__ tile_win = nullptr, unsigned long long *__restrict__ win_stat = nullptr) {
+                                                   const mtb_tile_win *__restrict__ tile_win = nullptr, unsigned long long *__restrict__ win_stat = nullptr,
+                                                   const uint32_t *__restrict__ tile_list = nullptr /* QPT == 1, no window: workgroup b takes the qt queries of tile tile_list[b] (the tiles k_join_win leaves out) */) {
     constexpr int Q = QPT;
     static_assert(!WIN || (QPT == 1 && PACKED && MODE != 2), "the window variants: packed words, one query per thread, slot modes");
     __shared__ __attribute__((aligned(16))) uint64_t s_win[WIN == 1 ? MTB_JOIN_WINCAP : WIN == 2 ? MTB_JOIN_WINCAP / 2 : 2];
@@ -302,7 +318,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
     constexpr bool LONG = MODE == 1, LIST = MODE == 2;
     const uint64_t AAM = ~0xFFFFFFull;
     __shared__ uint32_t s_hr[8];                    /* hammingLookup rows as nibble words: the only table the join arithmetic reads (filled below, behind the loads that matter) */
-    const uint64_t base_q = WIN ? (uint64_t)blockIdx.x * qt : (uint64_t)blockIdx.x * (256 * Q);
+    const uint64_t base_q = WIN ? (uint64_t)blockIdx.x * qt : (Q == 1 && tile_list) ? (uint64_t)tile_list[blockIdx.x] * qt : (uint64_t)blockIdx.x * (256 * Q);
     if (WIN && threadIdx.x == 0) { s_w0 = ~0ull; s_w1 = 0ull; }
     /* the window [a0, a1) -> s_win: 1 KiB pieces, a wave each, straight into LDS (global_load_lds_dwordx4: no staging registers, no wait
      * between the pieces -- a loop of load / ds_write pairs waited for every load: a dozen dependent round trips per tile, measured 96 ms
@@ -343,7 +359,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
 #pragma unroll
     for (int u = 0; u < Q; u++) {
         const uint64_t j = base_q + (uint64_t)u * 256 + threadIdx.x;
-        valid[u] = j < n && (!WIN || threadIdx.x < qt);
+        valid[u] = j < n && (!(WIN || (Q == 1 && tile_list)) || threadIdx.x < qt);
         k[u].value = 0; k[u].qinfo = 0;
         if (valid[u]) { k[u] = q[j]; valid[u] = mtb_q_seq(k[u].qinfo) != 0; }        /* blank slots carry sequenceID 0 */
     }
