@@ -31,20 +31,25 @@
                                        * (89 -> 64 registers by spilling 11): 5 waves 73.0 ms, 6: 66.7, 7: 63.2, 8: 62.0 against 83.6 for the 8-byte window */
 #endif
 
-/* MODE 0: slot segments of fixed stride (short reads); 1: per-read slot ranges (long reads) */
-template <int MODE, int WAVES = MTB_JW_WAVES>
+/* MODE 0: slot segments of fixed stride (short reads); 1: per-read slot ranges (long reads).
+ * WINDOW false: the same search WITHOUT a window -- the sector-random form at eight waves per SIMD: every offset is relative to the query's own bucket
+ * start (`base`, per lane), every access a 4-byte global load of a low dword.  For the tiles k_join_tile_win lists (tile_list: workgroup b takes
+ * tile tile_list[b]) and for batches too sparse for windows (tile_list NULL: workgroup b takes tile b). */
+template <int MODE, int WAVES = MTB_JW_WAVES, bool WINDOW = true>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES))) void k_join_win(const mtb_kmer *__restrict__ q, uint64_t n, mtb_index_view ix, uint64_t limit, mtb_dir_view dv,
                                                    const mtb_tables *__restrict__ tabs, JoinSegArgs sa, uint32_t *__restrict__ overflow, uint32_t qt,
-                                                   const mtb_tile_win *__restrict__ tile_win, unsigned long long *__restrict__ win_stat, uint32_t *__restrict__ redo_list) {
+                                                   const mtb_tile_win *__restrict__ tile_win, unsigned long long *__restrict__ win_stat, uint32_t *__restrict__ redo_list,
+                                                   const uint32_t *__restrict__ tile_list = nullptr) {
     constexpr bool LONG = MODE == 1;
-    __shared__ __attribute__((aligned(16))) uint32_t s_win[MTB_JW_CAP];
+    __shared__ __attribute__((aligned(16))) uint32_t s_win[WINDOW ? MTB_JW_CAP : 1];
     __shared__ uint32_t s_hr[8];                    /* hammingLookup rows as nibble words */
-    const mtb_tile_win tw = tile_win[blockIdx.x];   /* (a uniform address of read-only memory: scalar loads) */
-    if (tw.words == 0) return;                      /* no window: the tile is on k_join_tile_win's list */
-    const uint64_t w0 = tw.first;
-    const uint32_t wn = (uint32_t)tw.words;
+    uint64_t w0 = 0; uint32_t wn = 0;
     const uint32_t lane = threadIdx.x & 63u;
-    {   /* the window's low dwords, 64 targets a piece, a wave each: straight into LDS, no wait between the pieces */
+    if (WINDOW) {
+        const mtb_tile_win tw = tile_win[blockIdx.x];   /* (a uniform address of read-only memory: scalar loads) */
+        if (tw.words == 0) return;                      /* no window: the tile is on k_join_tile_win's list */
+        w0 = tw.first; wn = (uint32_t)tw.words;
+        /* the window's low dwords, 64 targets a piece, a wave each: straight into LDS, no wait between the pieces */
         const uint32_t n_piece = (wn + 63u) >> 6;
         for (uint32_t pc = threadIdx.x >> 6; pc < n_piece; pc += 4) {
             uint64_t idx = w0 + ((uint64_t)pc << 6) + lane;
@@ -53,8 +58,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES))) vo
                                              (__attribute__((address_space(3))) void *)(s_win + (pc << 6)), 4, 0, MTB_WIN_AUX);
         }
     }
-    /* the thread's query -> its bucket as a pair of offsets into the window */
-    const uint64_t j = (uint64_t)blockIdx.x * qt + threadIdx.x;
+    /* the thread's query -> its bucket as a pair of offsets from `base`: the window's first word, or (no window) the bucket's own start */
+    const uint32_t tile = (!WINDOW && tile_list) ? tile_list[blockIdx.x] : blockIdx.x;
+    const uint64_t j = (uint64_t)tile * qt + threadIdx.x;
+    uint64_t base = w0;
+    /* what the search and the evaluation read of target `t` (offset from base b): its low 32 bits */
+    auto rd = [&](uint64_t b, uint32_t t) -> uint32_t { return WINDOW ? s_win[t] : ((const uint32_t *)(ix.values + b))[2u * t]; };
     bool valid = j < n && threadIdx.x < qt;
     uint64_t qinfo_tagged = 0; uint32_t qc = 0, qk = 0, qdna = 0;
     uint32_t olo = 0, end = 0;
@@ -72,17 +81,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES))) vo
                 uint64_t lo = dv.base[b >> 16] + dv.dir[b], hi = dv.base[(b + 1) >> 16] + dv.dir[b + 1];
                 if (hi > limit) hi = limit;         /* the last entry of the (whole) index is never a candidate */
                 if (lo < hi) {
-                    if (lo < w0 || hi > w0 + wn) outside = true;
+                    if (!WINDOW) { base = lo; olo = 0; end = (uint32_t)(hi - lo); }      /* (a bucket holds < 2^32 targets: the directory's rows are 32-bit) */
+                    else if (lo < w0 || hi > w0 + wn) outside = true;
                     else { olo = (uint32_t)(lo - w0); end = (uint32_t)(hi - w0); }
                 } else valid = false;               /* an empty bucket */
             } else valid = false;                   /* a metamer outside the directory's alphabet has no candidate */
         }
     }
     if (threadIdx.x < 8) s_hr[threadIdx.x] = tabs->hamrow[threadIdx.x];
+    if (!WINDOW) __syncthreads();
+    else {
     MTB_WAIT_VMEM();                                 /* the direct-to-LDS loads count in vmcnt; the barrier publishes them */
     if (__syncthreads_or(outside ? 1 : 0)) {         /* (never while the list is sorted as announced) the whole tile is redone by the sector-random form */
         if (threadIdx.x == 0) redo_list[atomicAdd(win_stat + 1, 1ull)] = blockIdx.x;
         return;
+    }
     }
     /* ONE bisection per query on (eighth letter, DNA part): lands ON the block of targets equal to the query or inside / next to the run of
      * its amino-acid part (kernels_dir.h) */
@@ -91,34 +104,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES))) vo
         uint32_t hi_ = valid ? end : olo;
         while (p < hi_) {
             const uint32_t mid = (p + hi_) >> 1;
-            if ((s_win[mid] & 0x1FFFFFFFu) < qc) p = mid + 1; else hi_ = mid;
+            if ((rd(base, mid) & 0x1FFFFFFFu) < qc) p = mid + 1; else hi_ = mid;
         }
     }
     uint32_t s0 = p, e0 = p;
     if (valid) {
-        if (p < end && (s_win[p] & 0x1FFFFFFFu) == qc) {
+        if (p < end && (rd(base, p) & 0x1FFFFFFFu) == qc) {
             /* the block of targets equal to the query (several species may file the same metamer): hamming sum 0, threshold 0 -- the selection */
             e0 = p + 1;
             uint32_t c = 0;
-            while (e0 < end && c < 8u && (s_win[e0] & 0x1FFFFFFFu) == qc) { e0++; c++; }
-            if (c == 8u && e0 < end && (s_win[e0] & 0x1FFFFFFFu) == qc) {
+            while (e0 < end && c < 8u && (rd(base, e0) & 0x1FFFFFFFu) == qc) { e0++; c++; }
+            if (c == 8u && e0 < end && (rd(base, e0) & 0x1FFFFFFFu) == qc) {
                 uint32_t y = end;
-                while (e0 < y) { const uint32_t mid = (e0 + y) >> 1; if ((s_win[mid] & 0x1FFFFFFFu) <= qc) e0 = mid + 1; else y = mid; }
+                while (e0 < y) { const uint32_t mid = (e0 + y) >> 1; if ((rd(base, mid) & 0x1FFFFFFFu) <= qc) e0 = mid + 1; else y = mid; }
             }
         } else {
             /* the run of the query's amino-acid part around the landing place */
             uint32_t c = 0;
-            while (s0 > olo && c < 8u && (s_win[s0 - 1] & 0x1F000000u) == qk) { s0--; c++; }
-            if (c == 8u && s0 > olo && (s_win[s0 - 1] & 0x1F000000u) == qk) {
+            while (s0 > olo && c < 8u && (rd(base, s0 - 1) & 0x1F000000u) == qk) { s0--; c++; }
+            if (c == 8u && s0 > olo && (rd(base, s0 - 1) & 0x1F000000u) == qk) {
                 uint32_t x = olo, y = s0;
-                while (x < y) { const uint32_t mid = (x + y) >> 1; if ((s_win[mid] & 0x1F000000u) < qk) x = mid + 1; else y = mid; }
+                while (x < y) { const uint32_t mid = (x + y) >> 1; if ((rd(base, mid) & 0x1F000000u) < qk) x = mid + 1; else y = mid; }
                 s0 = x;
             }
             c = 0;
-            while (e0 < end && c < 8u && (s_win[e0] & 0x1F000000u) == qk) { e0++; c++; }
-            if (c == 8u && e0 < end && (s_win[e0] & 0x1F000000u) == qk) {
+            while (e0 < end && c < 8u && (rd(base, e0) & 0x1F000000u) == qk) { e0++; c++; }
+            if (c == 8u && e0 < end && (rd(base, e0) & 0x1F000000u) == qk) {
                 uint32_t y = end;
-                while (e0 < y) { const uint32_t mid = (e0 + y) >> 1; if ((s_win[mid] & 0x1F000000u) <= qk) e0 = mid + 1; else y = mid; }
+                while (e0 < y) { const uint32_t mid = (e0 + y) >> 1; if ((rd(base, mid) & 0x1F000000u) <= qk) e0 = mid + 1; else y = mid; }
             }
         }
         if (s0 >= e0) valid = false;
@@ -148,8 +161,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES))) vo
     };
     /* one selected candidate (window offset t, hamming sum h) of the query (qinfo: the reference's, tag stripped; qr: its rows) -> `at` = place in the
      * read's tail, or ~0u for the query's ordinal slot */
-    auto put = [&](const Dest &d, const mtb_qrows &qr, uint64_t qinfo, bool rev, uint32_t t, uint32_t h, uint32_t at) {
-        const uint64_t v = ix.values[w0 + t];        /* the full word: info entry in the upper bits */
+    auto put = [&](const Dest &d, const mtb_qrows &qr, uint64_t qinfo, bool rev, uint64_t b, uint32_t t, uint32_t h, uint32_t at) {
+        const uint64_t v = ix.values[b + t];         /* the full word: info entry in the upper bits */
         const uint32_t td = (uint32_t)v & 0xFFFFFFu;
         const int32_t tid = (int32_t)((uint32_t)(v >> MTB_PACK_LOW) & ix.info_mask);
         const int32_t sp = (tid >= 0 && tid <= ix.max_taxid) ? ix.tax2species[tid] : 0;
@@ -166,18 +179,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES))) vo
     if (valid) {
         mtb_qrows qr; mtb_prepare_query_rows(s_hr, (uint64_t)qdna, &qr);
         uint32_t mn = 255u;
-        for (uint32_t t = s0; t < e0; t++) { const uint32_t h = mtb_ham_sum(&qr, s_win[t] & 0xFFFFFFu); mn = h < mn ? h : mn; }
+        for (uint32_t t = s0; t < e0; t++) { const uint32_t h = mtb_ham_sum(&qr, rd(base, t) & 0xFFFFFFu); mn = h < mn ? h : mn; }
         const uint32_t thr = mtb_ham_threshold(mn);
         const Dest d = dest_of(qinfo_tagged);
         const uint64_t qinfo = qinfo_tagged & ~0xFFFF0000ull;      /* the record carries the reference's qinfo */
         const bool rev = mtb_hammings_reversed(mtb_q_frame(qinfo), ix.kmer_format);
         bool first = d.first;
         for (uint32_t t = s0; t < e0; t++) {
-            const uint32_t h = mtb_ham_sum(&qr, s_win[t] & 0xFFFFFFu);
+            const uint32_t h = mtb_ham_sum(&qr, rd(base, t) & 0xFFFFFFu);
             if (h > thr) continue;
-            if (first) { put(d, qr, qinfo, rev, t, h, ~0u); first = false; continue; }
+            if (first) { put(d, qr, qinfo, rev, base, t, h, ~0u); first = false; continue; }
             const uint32_t at = d.offr ? (atomicAdd(&sa.cursor[d.r], d.tcap + 1u), d.tcap) : atomicAdd(&sa.cursor[d.r], 1u);
-            put(d, qr, qinfo, rev, t, h, at);
+            put(d, qr, qinfo, rev, base, t, h, at);
         }
     }
     /* ---- wave-scanned runs: one pass (minimum + the few candidates that can be selected, kept in registers), then emission -- the selected
@@ -189,6 +202,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES))) vo
             const int src = __ffsll((unsigned long long)todo) - 1; todo &= todo - 1;
             const uint32_t rs = (uint32_t)__shfl((int)s0, src, 64), re = (uint32_t)__shfl((int)e0, src, 64);
             const uint64_t qi_t = wave_bcast64(qinfo_tagged, src);
+            const uint64_t bs = WINDOW ? w0 : wave_bcast64(base, src);
             mtb_qrows qr; mtb_prepare_query_rows(s_hr, (uint64_t)(uint32_t)__shfl((int)qdna, src, 64), &qr);
             /* ONE pass over the run, four 64-candidate steps in flight: the minimum (-> the threshold) and, per lane, the candidates of its stripe
              * with a sum <= 7 (no other can be selected) as (offset in the run << 4 | sum): the last four are kept, n_c counts them all */
@@ -196,7 +210,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES))) vo
             for (uint32_t t0 = rs + lane; t0 < re; t0 += 256) {
                 uint32_t v[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) v[u] = t0 + 64 * u < re ? s_win[t0 + 64 * u] : 0u;
+                for (int u = 0; u < 4; u++) v[u] = t0 + 64 * u < re ? rd(bs, t0 + 64 * u) : 0u;
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     if (t0 + 64 * u < re) {
@@ -230,14 +244,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES))) vo
                         if ((int)lane == leader) at0 = atomicAdd(&sa.cursor[d.r], (uint32_t)__popcll(m) * inc);
                         at0 = (uint32_t)__shfl((int)at0, leader, 64);
                     }
-                    if (sel) put(d, qr, qinfo, rev, rs + off, cb[b] & 15u, own ? ~0u : (d.offr ? d.tcap : at0 + (uint32_t)__popcll(m & lt_mask)));
+                    if (sel) put(d, qr, qinfo, rev, bs, rs + off, cb[b] & 15u, own ? ~0u : (d.offr ? d.tcap : at0 + (uint32_t)__popcll(m & lt_mask)));
                 }
                 continue;
             }
             for (uint32_t t0 = rs; t0 < re; t0 += 64) {      /* a lane met more than four possible candidates: second walk, 64 per step */
                 const uint32_t t = t0 + lane;
                 uint32_t h = 255u;
-                if (t < re) h = mtb_ham_sum(&qr, s_win[t] & 0xFFFFFFu);
+                if (t < re) h = mtb_ham_sum(&qr, rd(bs, t) & 0xFFFFFFu);
                 const bool sel = h <= thr;
                 const uint64_t m = __ballot(sel);
                 if (!m) continue;
@@ -249,7 +263,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES))) vo
                     if ((int)lane == leader) at0 = atomicAdd(&sa.cursor[d.r], n_tail * inc);
                     at0 = (uint32_t)__shfl((int)at0, leader, 64);
                 }
-                if (sel) put(d, qr, qinfo, rev, t, h, (first && rk == 0) ? ~0u : (d.offr ? d.tcap : at0 + rk - skip));
+                if (sel) put(d, qr, qinfo, rev, bs, t, h, (first && rk == 0) ? ~0u : (d.offr ? d.tcap : at0 + rk - skip));
                 first = false;
             }
         }

@@ -752,6 +752,9 @@ static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint6
         if (sa.rb) {        /* long reads: per-read slot ranges */
             if (state_owner(ix)->packed) {
                 /* one query per thread at 6 waves per SIMD here too (43.2 -> 41.5 ms per 50 k x 10 kb; MTB_JOIN_VARIANT=q2w5: round 4's instantiation, A/B) */
+                if (c->opt.join_variant == 0x408) hipLaunchKernelGGL((k_join_win<1, 8, false>), dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa,
+                                                                     (uint32_t *)(c->d_scal + 1), 256u, (const mtb_tile_win *)nullptr, (unsigned long long *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr);
+                else
                 if (c->opt.join_variant != 0x25) hipLaunchKernelGGL((k_join_dir<true, 1, 1, 6>), dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1));
                 else hipLaunchKernelGGL((k_join_dir<true, 1, MTB_JOIN_DIR_QPT, 5>), dim3(g2), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1));
             }
@@ -781,7 +784,8 @@ static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint6
             int jw = 0;                                      /* != 0: k_join_win (kernels_join_win.h) compiled for that many waves per SIMD + the sector-random form for the tiles without a window */
             switch (c->opt.join_variant) { case 0x16: choice = 0; break; case 0x25: choice = 1; break; case 0x100: choice = 2; break; case 0x15: choice = 3; break; case 0x26: choice = 4; break;
                                            case 0x205: case 0x206: case 0x207: case 0x208: choice = 2; win32 = c->opt.join_variant & 15; break;
-                                           case 0x305: case 0x306: case 0x307: case 0x308: choice = 2; jw = c->opt.join_variant & 15; break; default: break; }
+                                           case 0x305: case 0x306: case 0x307: case 0x308: choice = 2; jw = c->opt.join_variant & 15; break;
+                                           case 0x408: choice = 5; break; default: break; }
             if (choice < 0 && c->opt.join_win >= 0) choice = c->opt.join_win ? 2 : 0;
             const bool forced = choice >= 0;
             uint32_t lg_n = 0; for (uint64_t x = n; x > 1; x >>= 1) lg_n++;
@@ -836,8 +840,8 @@ static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint6
                                    (uint32_t *)(c->d_scal + 1), qt, (const mtb_tile_win *)d_tw, (unsigned long long *)(c->d_scal + 16), d_redo)
                 if (n_nowin < n_tiles) switch (jw) { case 5: MTB_LAUNCH_JWIN(5); break; case 6: MTB_LAUNCH_JWIN(6); break; case 7: MTB_LAUNCH_JWIN(7); break; default: MTB_LAUNCH_JWIN(8); break; }
 #undef MTB_LAUNCH_JWIN
-                if (n_nowin) hipLaunchKernelGGL((k_join_dir<true, 0, 1, 6>), dim3((uint32_t)n_nowin), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa,
-                                                (uint32_t *)(c->d_scal + 1), qt, (const mtb_tile_win *)nullptr, (unsigned long long *)nullptr, (const uint32_t *)d_list);
+                if (n_nowin) hipLaunchKernelGGL((k_join_win<0, 8, false>), dim3((uint32_t)n_nowin), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa,
+                                                (uint32_t *)(c->d_scal + 1), qt, (const mtb_tile_win *)nullptr, (unsigned long long *)nullptr, (uint32_t *)nullptr, (const uint32_t *)d_list);
                 win_tiles = n_tiles; redo_list = d_redo; redo_qt = qt;
             } else
             if (choice == 2) {
@@ -867,6 +871,8 @@ static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint6
             case 1: MTB_LAUNCH_JV(2, 5); break;
             case 3: MTB_LAUNCH_JV(1, 5); break;
             case 4: MTB_LAUNCH_JV(2, 6); break;
+            case 5: hipLaunchKernelGGL((k_join_win<0, 8, false>), dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa,
+                                       (uint32_t *)(c->d_scal + 1), 256u, (const mtb_tile_win *)nullptr, (unsigned long long *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr); break;
             default: MTB_LAUNCH_JV(1, 6); break;
             }
 #undef MTB_LAUNCH_JV

@@ -78,6 +78,7 @@ static const Entry kTable[] = {
 static inline int parse_variant(const char *v) {
     if (!v || !*v || !strcmp(v, "auto")) return 0;
     if (!strcmp(v, "window")) return 0x100;
+    if (!strcmp(v, "rnd8")) return 0x408;                                                                     /* k_join_win without windows: the sector-random form at 8 waves per SIMD */
     if (!strcmp(v, "win")) return 0x308;                                                                      /* k_join_win (kernels_join_win.h) */
     if (!strncmp(v, "winw", 4) && v[4] >= '5' && v[4] <= '8' && !v[5]) return 0x300 | (v[4] - '0');          /* ... compiled for 5..8 waves per SIMD (A/B) */
     if (!strncmp(v, "win32w", 6) && v[6] >= '5' && v[6] <= '8' && !v[7]) return 0x200 | (v[6] - '0');       /* the low-dword window at 5..8 waves per SIMD (A/B) */

@@ -932,9 +932,11 @@ def test_queries_that_share_a_long_run_walk_it_in_lockstep(orc, tmp_path, seq_mo
     monkeypatch.delenv("MTB_DIR_DEPTH", raising=False)
     ro = t.ref["results"]
     amb = ro["flag"] != 0
-    for win in (("1", "0", "win") if seq_mode == 1 else ("0",)):
+    for win in (("1", "0", "win", "rnd8") if seq_mode == 1 else ("0", "rnd8")):
         if win == "win":
             c.set_option("MTB_JOIN_WIN", None); c.set_option("MTB_JOIN_VARIANT", "win"); c.set_option("MTB_JOIN_WIN_QT", "48")
+        elif win == "rnd8":
+            c.set_option("MTB_JOIN_WIN", None); c.set_option("MTB_JOIN_VARIANT", "rnd8")
         else:
             c.set_option("MTB_JOIN_WIN", win)
         res, tt, tc = c.classify_batch(ix, p, t.b1, t.o1, t.b2, t.o2)
@@ -968,7 +970,7 @@ def test_target_windows_staged_in_lds_give_the_same_matches(orc, tmp_path, seq_m
     windowed = {}
     for win, qt, noprewin, variant in (("1", "5", None, None), ("1", "64", None, None), ("1", "256", None, None), ("1", "64", "1", None), ("1", "256", "1", None), ("0", "256", None, None),
                                        ("1", "64", None, "win32w6"), ("1", "5", None, "win32w8"), ("1", "256", "1", "win32w7"),
-                                       ("1", "64", None, "win"), ("1", "5", None, "winw6"), ("1", "256", None, "win"), ("1", "17", None, "winw7")):
+                                       ("1", "64", None, "win"), ("1", "5", None, "winw6"), ("1", "256", None, "win"), ("1", "17", None, "winw7"), ("0", "256", None, "rnd8")):
         # (win / winw<W>: k_join_win for the tiles with a window -- low dwords in LDS, 32-bit offsets --, the listed tiles without one through k_join_dir)
         # (win32w<W>: the window holds the low dwords only, the full word of a selected candidate comes from global memory)
         c.set_option("MTB_JOIN_WIN", win); c.set_option("MTB_JOIN_WIN_QT", qt); c.set_option("MTB_JOIN_NO_PREWIN", noprewin); c.set_option("MTB_JOIN_VARIANT", variant)
@@ -984,6 +986,7 @@ def test_target_windows_staged_in_lds_give_the_same_matches(orc, tmp_path, seq_m
             assert (tt == t.ref["tc_tax"]).all() and (tc == t.ref["tc_cnt"]).all(), tag
         assert st.n_matches == len(t.ref["matches"]), tag
         if win == "1":
+            # (rnd8: k_join_win without windows -- the sector-random form at eight waves per SIMD, offsets from the query's own bucket start)
             # tiles of the announced size; with the windows bounded before the launch (k_join_tile_win) the statistics say how many were staged,
             # and no tile ever finds a query outside its announced window
             assert st.join_tiles == (st.n_kmers + int(qt) - 1) // int(qt) or st.join_tiles >= st.n_kmers // int(qt), tag
