@@ -45,7 +45,7 @@ class BatchStats(C.Structure):
                 ("join_tiles", C.c_uint32), ("join_tiles_windowed", C.c_uint32), ("join_tiles_outside", C.c_uint32)]
 
 
-JOIN_VARIANTS = {0: "other", 1: "q1w6", 2: "q2w5", 3: "window", -3: "q1w5", -4: "q2w6", -15: "win32w5", -16: "win32w6", -17: "win32w7", -18: "win32w8", -25: "winw5", -26: "winw6", -27: "winw7", -28: "win", -5: "rnd8"}      # mtb_batch_stats.join_variant (mtb_join_variant)
+JOIN_VARIANTS = {0: "other", 1: "q1w6", 2: "q2w5", 3: "window", -3: "q1w5", -4: "q2w6", -15: "windoww5", -16: "windoww6", -17: "windoww7"}      # mtb_batch_stats.join_variant (mtb_join_variant)
 
 
 class JoinFootprint(C.Structure):

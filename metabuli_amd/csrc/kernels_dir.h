@@ -202,9 +202,6 @@ __global__ __launch_bounds__(256) void k_index_unpack(uint64_t *__restrict__ val
 __device__ __forceinline__ uint64_t wave_bcast64(uint64_t v, int src) {
     return ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 64) << 32) | (uint64_t)(uint32_t)__shfl((int)(uint32_t)v, src, 64);
 }
-__device__ __forceinline__ uint64_t wave_bcast_xor64(uint64_t v, int d) {
-    return ((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), d, 64) << 32) | (uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)v, d, 64);
-}
 __device__ __forceinline__ uint32_t wave_min_shfl_u32(uint32_t v) {
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64); v = o < v ? o : v; }
@@ -216,13 +213,21 @@ __device__ __forceinline__ uint32_t wave_min_shfl_u32(uint32_t v) {
 /* QPT = queries per thread, WAVES = waves per SIMD the register allocation aims at: template parameters so that the A/B variants of the
  * short-read instantiation live in ONE library and are compared inside one process, on one index, one allocation (MTB_JOIN_VARIANT=q<Q>w<W>
  * in the environment, read per batch; between processes the placement of a 27 GB slot buffer alone moved the join by 10 %) */
-/* WIN (short reads on packed words, one query per thread): the tile's TARGET WINDOW is staged in LDS.  The workgroup's `qt` sorted queries
+/* WIN (slot modes on packed words, one query per thread): the tile's TARGET WINDOW is staged in LDS.  The workgroup's `qt` sorted queries
  * (qt <= 256, chosen by the host from the batch's density) address buckets that lie next to each other: the span from the first query's
- * bucket to the last one's is read ONCE with coalesced 8-byte loads (all 256 threads), and every later access of the search and the
- * evaluation -- bisection steps, run ends, candidates, the wave scan of a long run -- is an LDS read.  With 10 M reads against 16 G targets
- * a query owns 12.5 targets of the array on average: the windows of a batch ARE the array, streamed once (128 GB at copy speed) instead of
- * ~8 dependent sector-random round trips per query (the kernel's time was latency x occupancy).  A tile whose window exceeds the LDS
- * capacity (sparse tiles, buckets of long candidate runs) keeps reading global memory: same code, rdv() picks the source per tile. */
+ * bucket to the last one's -- bounded BEFORE the launch by k_join_tile_win, so that the window's loads are the kernel's first instructions
+ * and the queries and their directory rows arrive while it is in flight -- is read ONCE, and every later access of the search and the
+ * evaluation (bisection steps, run ends, candidates, the wave scan of a long run) is an LDS read.  With 10 M reads against 16 G targets a
+ * query owns 12.5 targets of the array on average: the windows of a batch ARE the array.
+ * The window holds only the LOW 32 bits of every packed word -- all that the search and the evaluation read (29 bits tell the targets of a
+ * bucket apart, 24 of them are the DNA part) -- staged by 4-byte direct-to-LDS loads (a lane per target, no staging registers, no wait
+ * between the pieces); the full word is fetched from global memory (L2-warm: the window's load has just brought its sector) for SELECTED
+ * candidates only.  15.9 KB per tile and 64 registers: EIGHT waves per SIMD.  That is what the kernel's time depends on -- its waves spend
+ * two thirds of their time waiting on dependent accesses (bisection step -> run end -> candidate -> species id -> tail cursor), VALU issue
+ * is at 42 %, the array streams at a third of the HBM rate.  Measured in one process on the headline batch (profiles/r06_notes.md): round 5's
+ * 8-byte window (31.7 KB, 5 waves) 83.6 ms; low dwords at 5 / 6 / 7 / 8 waves 73.0 / 66.7 / 63.2 / 62.0; sector-random (q1w6) 80.7.
+ * A tile whose window exceeds the capacity (sparse tiles, buckets of long candidate runs) keeps reading global memory: same code, rdv()
+ * picks the source per tile. */
 #ifndef MTB_WIN_AUX
 #define MTB_WIN_AUX 0                 /* cache policy bits of the window's direct-to-LDS loads (2 = nt: streamed once; A/B build switch) */
 #endif
@@ -231,9 +236,9 @@ __device__ __forceinline__ uint32_t wave_min_shfl_u32(uint32_t v) {
 #else
 #define MTB_WAIT_VMEM() do {} while (0)
 #endif
-#define MTB_JOIN_WINCAP 3968          /* 8-byte words = 31 pieces of 1 KiB (one wave-wide 16-byte direct-to-LDS load each): 31 KB -> five workgroups (20 waves) per CU.
-                                       * (A window per WAVE -- 64 queries, 896 words, no workgroup barrier -- measured 81.8 ms against 73.6 for the workgroup's window
-                                       * and 80.9 for the sector-random join: a sixth of the waves fell back, profiles/r05_notes.md) */
+#define MTB_JOIN_WINCAP 3968          /* targets a window holds = 62 pieces of 64 low dwords (one wave-wide 4-byte direct-to-LDS load each): 15.9 KB -> eight workgroups
+                                       * (32 waves) per CU */
+#define MTB_JOIN_WIN_WAVES 8          /* waves per SIMD the window form is compiled for */
 /* The windows of the tiles, BEFORE the join (round 6): the queries are sorted on their top (64 - low_bits) bits -- six amino-acid letters
  * of kmer_format 2, the top 32 bits of format 1 -- so the first and the last record of a tile bound the buckets all its queries can
  * address: [first bucket with the first record's sort key, last bucket with the last record's sort key].  One thread per tile reads two
@@ -243,13 +248,8 @@ __device__ __forceinline__ uint32_t wave_min_shfl_u32(uint32_t v) {
  * The span is that of the exact minimum / maximum widened to whole sort-key groups at both ends (187 targets a group at 16 G targets);
  * a query whose bucket is not inside it (never, unless the list is not sorted as announced) sends the whole tile to global memory. */
 struct mtb_tile_win { uint64_t first, words; };
-__device__ __forceinline__ uint64_t wave_bcast64_pre(uint64_t v, int src) {
-    return ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 64) << 32) | (uint64_t)(uint32_t)__shfl((int)(uint32_t)v, src, 64);
-}
 __global__ __launch_bounds__(256) void k_join_tile_win(const mtb_kmer *__restrict__ q, uint64_t n, uint32_t qt, mtb_dir_view dv, uint64_t limit, int low_bits,
-                                                        mtb_tile_win *__restrict__ win, uint32_t n_tiles, unsigned long long *__restrict__ stat,
-                                                        uint32_t cap = MTB_JOIN_WINCAP /* words a window may hold */,
-                                                        uint32_t *__restrict__ nowin_list = nullptr /* the tiles WITHOUT a window, listed (count in stat[2]): k_join_win leaves them to a launch of the sector-random form */) {
+                                                        mtb_tile_win *__restrict__ win, uint32_t n_tiles, unsigned long long *__restrict__ stat) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     const bool live = t < n_tiles;
     bool windowed = false;
@@ -276,80 +276,44 @@ __global__ __launch_bounds__(256) void k_join_tile_win(const mtb_kmer *__restric
         uint64_t a0 = dv.base[blo >> 16] + dv.dir[blo], a1 = dv.base[(bhi + 1) >> 16] + dv.dir[bhi + 1];
         if (a1 > limit) a1 = limit;
         a0 &= ~1ull;                                       /* 16-byte aligned pieces */
-        if (a1 > a0 && a1 - a0 <= (uint64_t)cap) { w.first = a0; w.words = a1 - a0; windowed = true; }
+        if (a1 > a0 && a1 - a0 <= (uint64_t)MTB_JOIN_WINCAP) { w.first = a0; w.words = a1 - a0; windowed = true; }
     }
     win[t] = w;
     }
     /* statistics (mtb_batch_stats.join_tiles_windowed): one atomic per wave */
     const uint64_t m = __ballot(windowed);
     if ((threadIdx.x & 63u) == 0 && m) atomicAdd(stat, (unsigned long long)__popcll(m));
-    if (nowin_list) {                                /* one returning atomic per wave */
-        const uint64_t mm = __ballot(live && !windowed);
-        if (mm) {
-            const uint32_t ln = threadIdx.x & 63u;
-            unsigned long long at0 = 0;
-            if (ln == (uint32_t)(__ffsll((unsigned long long)mm) - 1)) at0 = atomicAdd(stat + 2, (unsigned long long)__popcll(mm));
-            at0 = wave_bcast64_pre(at0, __ffsll((unsigned long long)mm) - 1);
-            if (live && !windowed) nowin_list[at0 + (uint32_t)__popcll(mm & ((1ull << ln) - 1ull))] = t;
-        }
-    }
 }
 
-/* WIN == 2 (round 6): the window holds only the LOW 32 bits of every packed word -- all that the search and the evaluation read (29 bits tell the
- * targets of a bucket apart, 24 of them are the DNA part) -- staged by 4-byte direct-to-LDS loads (a lane per target); the full word is fetched
- * from global memory (L2-warm: the window's load has just brought its sector) for SELECTED candidates only.  Half the LDS per tile: more
- * workgroups per CU for a kernel whose waves spend 63 % of their time waiting on dependent accesses (profiles/r06_notes.md). */
-template <bool PACKED, int MODE = 0, int QPT = ((PACKED && MODE == 0) ? MTB_JOIN_DIR_QPT0 : MTB_JOIN_DIR_QPT), int WAVES = MTB_JOIN_WAVES, int WIN = 0>
+template <bool PACKED, int MODE = 0, int QPT = ((PACKED && MODE == 0) ? MTB_JOIN_DIR_QPT0 : MTB_JOIN_DIR_QPT), int WAVES = MTB_JOIN_WAVES, bool WIN = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && MODE != 2) ? WAVES : 5))) void k_join_dir(const mtb_kmer *__restrict__ q, uint64_t n, mtb_index_view ix, uint64_t limit, mtb_dir_view dv,
                                                    const mtb_tables *__restrict__ tabs, JoinSegArgs sa, uint32_t *__restrict__ overflow, uint32_t qt = 256,
-                                                   const mtb_tile_win *__restrict__ tile_win = nullptr, unsigned long long *__restrict__ win_stat = nullptr,
-                                                   const uint32_t *__restrict__ tile_list = nullptr /* QPT == 1, no window: workgroup b takes the qt queries of tile tile_list[b] (the tiles k_join_win leaves out) */) {
+                                                   const mtb_tile_win *__restrict__ tile_win = nullptr, unsigned long long *__restrict__ win_stat = nullptr) {
     constexpr int Q = QPT;
-    static_assert(!WIN || (QPT == 1 && PACKED && MODE != 2), "the window variants: packed words, one query per thread, slot modes");
-    __shared__ __attribute__((aligned(16))) uint64_t s_win[WIN == 1 ? MTB_JOIN_WINCAP : WIN == 2 ? MTB_JOIN_WINCAP / 2 : 2];
-    __shared__ unsigned long long s_w0, s_w1;
+    static_assert(!WIN || (QPT == 1 && PACKED && MODE != 2), "the window form: packed words, one query per thread, slot modes");
+    __shared__ __attribute__((aligned(16))) uint32_t s_win[WIN ? MTB_JOIN_WINCAP : 1];
     uint64_t w0 = 0; bool use_win = false;
-    /* rdv: what the search and the evaluation read (WIN == 2: the low 32 bits only); full_of: the whole word of a SELECTED candidate */
-    auto rdv = [&](uint64_t t) -> uint64_t {
-        if (WIN == 2) return use_win ? (uint64_t)((const uint32_t *)s_win)[t - w0] : ix.values[t];
-        return (WIN && use_win) ? s_win[t - w0] : ix.values[t];
-    };
-    auto full_of = [&](uint64_t t, uint64_t v) -> uint64_t { return (WIN == 2 && use_win) ? ix.values[t] : v; };
+    /* rdv: what the search and the evaluation read of a target (inside a window: its low 32 bits); full_of: the whole word of a SELECTED candidate */
+    auto rdv = [&](uint64_t t) -> uint64_t { return (WIN && use_win) ? (uint64_t)s_win[t - w0] : ix.values[t]; };
+    auto full_of = [&](uint64_t t, uint64_t v) -> uint64_t { return (WIN && use_win) ? ix.values[t] : v; };
     constexpr bool LONG = MODE == 1, LIST = MODE == 2;
     const uint64_t AAM = ~0xFFFFFFull;
     __shared__ uint32_t s_hr[8];                    /* hammingLookup rows as nibble words: the only table the join arithmetic reads (filled below, behind the loads that matter) */
-    const uint64_t base_q = WIN ? (uint64_t)blockIdx.x * qt : (Q == 1 && tile_list) ? (uint64_t)tile_list[blockIdx.x] * qt : (uint64_t)blockIdx.x * (256 * Q);
-    if (WIN && threadIdx.x == 0) { s_w0 = ~0ull; s_w1 = 0ull; }
-    /* the window [a0, a1) -> s_win: 1 KiB pieces, a wave each, straight into LDS (global_load_lds_dwordx4: no staging registers, no wait
-     * between the pieces -- a loop of load / ds_write pairs waited for every load: a dozen dependent round trips per tile, measured 96 ms
-     * against 80 for the random join).  The last piece may reach beyond the window (never read) -- but not beyond the array. */
+    const uint64_t base_q = WIN ? (uint64_t)blockIdx.x * qt : (uint64_t)blockIdx.x * (256 * Q);
+    /* the window [a0, a1) -> s_win: 64 targets a piece, a wave each, every lane the low dword of its own target, straight into LDS
+     * (global_load_lds_dword: no staging registers, no wait between the pieces -- a loop of load / ds_write pairs waited for every load: a
+     * dozen dependent round trips per tile, measured 96 ms against 80 for the random join).  The last piece may reach beyond the window (never read). */
     auto stage_window = [&](uint64_t a0, uint64_t a1) {
-        const uint32_t wv_ = threadIdx.x >> 6, ln_ = threadIdx.x & 63u;
-        if (WIN == 2) {                              /* 64 targets a piece: every lane fetches the low dword of its own target */
-            uint32_t *const s32 = (uint32_t *)s_win;
-            const uint32_t n_piece32 = (uint32_t)((a1 - a0 + 63) >> 6);
-            for (uint32_t pc = wv_; pc < n_piece32; pc += 4) {
-                uint64_t idx = a0 + ((uint64_t)pc << 6) + ln_;
-                if (idx >= ix.n_targets) idx = ix.n_targets - 1;            /* (behind the window: never read) */
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ix.values + idx),
-                                                 (__attribute__((address_space(3))) void *)(s32 + ((uint64_t)pc << 6)), 4, 0, MTB_WIN_AUX);
-            }
-            return;
-        }
-        const uint32_t n_piece = (uint32_t)((a1 - a0 + 127) >> 7);
-        for (uint32_t pc = wv_; pc < n_piece; pc += 4) {
-            const uint64_t src = a0 + ((uint64_t)pc << 7) + 2u * ln_;
-            if (a0 + ((uint64_t)pc << 7) + 128 > ix.n_targets) {           /* the piece that holds the array's end (one per index): plain guarded loads */
-                if (src < ix.n_targets) s_win[((uint64_t)pc << 7) + 2u * ln_] = ix.values[src];
-                if (src + 1 < ix.n_targets) s_win[((uint64_t)pc << 7) + 2u * ln_ + 1] = ix.values[src + 1];
-                continue;
-            }
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ix.values + src),
-                                             (__attribute__((address_space(3))) void *)(s_win + ((uint64_t)pc << 7)), 16, 0, MTB_WIN_AUX);
+        const uint32_t n_piece = (uint32_t)((a1 - a0 + 63) >> 6), ln_ = threadIdx.x & 63u;
+        for (uint32_t pc = threadIdx.x >> 6; pc < n_piece; pc += 4) {
+            uint64_t idx = a0 + ((uint64_t)pc << 6) + ln_;
+            if (idx >= ix.n_targets) idx = ix.n_targets - 1;                /* (behind the window) */
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ix.values + idx),
+                                             (__attribute__((address_space(3))) void *)(s_win + ((uint64_t)pc << 6)), 4, 0, MTB_WIN_AUX);
         }
     };
     uint64_t pre_a0 = 0, pre_len = 0;
-    if (WIN && tile_win) {                           /* the window was bounded before the launch (k_join_tile_win): its loads go first */
+    if (WIN) {                                       /* the window was bounded before the launch (k_join_tile_win): its loads go first */
         const mtb_tile_win tw = tile_win[blockIdx.x];          /* (a uniform address of read-only memory: scalar loads) */
         pre_a0 = tw.first; pre_len = tw.words;
         if (pre_len) stage_window(pre_a0, pre_a0 + pre_len);
@@ -359,7 +323,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
 #pragma unroll
     for (int u = 0; u < Q; u++) {
         const uint64_t j = base_q + (uint64_t)u * 256 + threadIdx.x;
-        valid[u] = j < n && (!(WIN || (Q == 1 && tile_list)) || threadIdx.x < qt);
+        valid[u] = j < n && (!WIN || threadIdx.x < qt);
         k[u].value = 0; k[u].qinfo = 0;
         if (valid[u]) { k[u] = q[j]; valid[u] = mtb_q_seq(k[u].qinfo) != 0; }        /* blank slots carry sequenceID 0 */
     }
@@ -377,32 +341,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
         }
     }
     if (threadIdx.x < 8) s_hr[threadIdx.x] = tabs->hamrow[threadIdx.x];        /* (issued behind the window / query / directory loads: as the kernel's first statement it cost wave 0 a round trip of its own) */
-    if (WIN && tile_win) {
+    if (WIN) {
         /* every query's bucket inside the announced window?  (one barrier: it also publishes s_hr and -- behind the explicit wait for the
          * direct-to-LDS loads, which the workgroup-scope fence of a barrier is not documented to cover -- the window) */
         const bool outside = pre_len != 0 && valid[0] && lo[0] < hi[0] && (lo[0] < pre_a0 || hi[0] > pre_a0 + pre_len);
         MTB_WAIT_VMEM();
         MTB_JP_MARK(5);
         if (!__syncthreads_or(outside ? 1 : 0)) { if (pre_len) { use_win = true; w0 = pre_a0; } }
-        else if (threadIdx.x == 0 && win_stat) atomicAdd(win_stat + 1, 1ull);        /* (mtb_batch_stats.join_tiles_outside: stays 0 while the list is sorted as announced) */
-    } else {
-    __syncthreads();                                 /* s_hr; the query and directory loads above are in flight meanwhile */
-    if (WIN) {
-        /* the tile's window: from the lowest bucket start to the highest bucket end of its queries */
-        uint64_t mn = valid[0] && lo[0] < hi[0] ? lo[0] : ~0ull, mx = valid[0] && lo[0] < hi[0] ? hi[0] : 0ull;
-        for (int d = 32; d > 0; d >>= 1) {
-            const uint64_t on = wave_bcast_xor64(mn, d), ox = wave_bcast_xor64(mx, d);
-            mn = on < mn ? on : mn; mx = ox > mx ? ox : mx;
-        }
-        if ((threadIdx.x & 63u) == 0) { if (mn != ~0ull) atomicMin(&s_w0, (unsigned long long)mn); if (mx) atomicMax(&s_w1, (unsigned long long)mx); }
-        __syncthreads();
-        MTB_JP_MARK(5);
-        const uint64_t a0 = s_w0, a1 = s_w1;
-        if (a1 > a0 && a1 - a0 <= (uint64_t)MTB_JOIN_WINCAP) { stage_window(a0, a1); use_win = true; w0 = a0; }
-        MTB_WAIT_VMEM();
-        __syncthreads();
-    }
-    }
+        else if (threadIdx.x == 0 && win_stat) atomicAdd(win_stat + 1, 1ull);        /* (mtb_batch_stats.join_tiles_outside: stays 0 while the list is sorted as announced; the tile reads global memory) */
+    } else __syncthreads();                          /* s_hr; the query and directory loads above are in flight meanwhile */
     MTB_JP_MARK(6);
     /* what tells targets of one bucket apart: the whole amino-acid part (flat state) or the packed word's eighth letter */
     auto tkey = [&](uint64_t w) -> uint64_t { return PACKED ? (w & 0x1F000000ull) : (w & AAM); };

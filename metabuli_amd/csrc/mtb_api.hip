@@ -22,7 +22,6 @@
 #include "kernels_index.h"
 #include "kernels_join.h"
 #include "kernels_dir.h"
-#include "kernels_join_win.h"
 #include "kernels_scan.h"
 #include "kernels_score.h"
 #include "kernels_score_fast.h"
@@ -733,7 +732,6 @@ static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint6
     uint64_t limit = ix->T ? ix->T - (ix->match_last ? 0 : 1) : 0;          /* the last entry of the (whole) index is never a candidate */
     IndexUse use;                     /* released after the stream sync below (the d2h of the counters) */
     uint32_t win_tiles = 0;           /* the window variant ran: tiles launched (their statistics sit in d_scal[16..17]) */
-    const uint32_t *redo_list = nullptr; uint32_t redo_qt = 0;      /* k_join_win: where a tile that found a query outside its window lists itself */
     const bool striped = seg && ix->d_dir && !seg->list && !seg->dense_ovf;       /* the slot modes of the directory join: striped overflow list */
     if (seg && ix->d_dir) {
         STCHK(use.acquire(ix, true));
@@ -752,9 +750,6 @@ static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint6
         if (sa.rb) {        /* long reads: per-read slot ranges */
             if (state_owner(ix)->packed) {
                 /* one query per thread at 6 waves per SIMD here too (43.2 -> 41.5 ms per 50 k x 10 kb; MTB_JOIN_VARIANT=q2w5: round 4's instantiation, A/B) */
-                if (c->opt.join_variant == 0x408) hipLaunchKernelGGL((k_join_win<1, 8, false>), dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa,
-                                                                     (uint32_t *)(c->d_scal + 1), 256u, (const mtb_tile_win *)nullptr, (unsigned long long *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr);
-                else
                 if (c->opt.join_variant != 0x25) hipLaunchKernelGGL((k_join_dir<true, 1, 1, 6>), dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1));
                 else hipLaunchKernelGGL((k_join_dir<true, 1, MTB_JOIN_DIR_QPT, 5>), dim3(g2), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1));
             }
@@ -774,18 +769,14 @@ static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint6
              * MTB_JOIN_VARIANT / MTB_JOIN_WIN in the environment of mtb_ctx_create); the choice and the tuner's timings are reported in
              * mtb_batch_stats (join_variant, join_tuned, join_tune_ms). */
             const double per_q = (double)ix->T / (double)std::max<uint64_t>(n, 1);
-            const uint32_t win_cap = (c->opt.join_variant & 0xF00) == 0x300 ? (uint32_t)MTB_JW_CAP : (uint32_t)MTB_JOIN_WINCAP;
-            uint32_t qt = (uint32_t)std::min<double>(256.0, 0.82 * win_cap / std::max(per_q, 1.0));
+            uint32_t qt = (uint32_t)std::min<double>(256.0, 0.82 * MTB_JOIN_WINCAP / std::max(per_q, 1.0));
             const bool win_ok = qt >= 240;
             if (c->opt.join_win_qt > 0) qt = (uint32_t)std::min(256, c->opt.join_win_qt);
             qt = std::max<uint32_t>(qt, 1);
             int choice = -1;                                 /* 0: q1w6, 1: q2w5, 2: window, 3 / 4: the A/B-only instantiations q1w5 / q2w6 */
-            int win32 = 0;                                   /* != 0: the window holds low dwords only (kernels_dir.h, WIN == 2), compiled for that many waves per SIMD */
-            int jw = 0;                                      /* != 0: k_join_win (kernels_join_win.h) compiled for that many waves per SIMD + the sector-random form for the tiles without a window */
+            int win_waves = MTB_JOIN_WIN_WAVES;              /* the window form's instantiation: waves per SIMD (5..7: A/B only) */
             switch (c->opt.join_variant) { case 0x16: choice = 0; break; case 0x25: choice = 1; break; case 0x100: choice = 2; break; case 0x15: choice = 3; break; case 0x26: choice = 4; break;
-                                           case 0x205: case 0x206: case 0x207: case 0x208: choice = 2; win32 = c->opt.join_variant & 15; break;
-                                           case 0x305: case 0x306: case 0x307: case 0x308: choice = 2; jw = c->opt.join_variant & 15; break;
-                                           case 0x408: choice = 5; break; default: break; }
+                                           case 0x205: case 0x206: case 0x207: choice = 2; win_waves = c->opt.join_variant & 15; break; default: break; }
             if (choice < 0 && c->opt.join_win >= 0) choice = c->opt.join_win ? 2 : 0;
             const bool forced = choice >= 0;
             uint32_t lg_n = 0; for (uint64_t x = n; x > 1; x >>= 1) lg_n++;
@@ -821,48 +812,26 @@ static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint6
              * retries of a batch (overflow list too small) and lanes never time anything, they follow what is known */
             if (choice < 0 && jt && jt->best >= 0) { choice = (jt->best == 2 && !win_ok) ? 0 : jt->best; tuned_flag = 1; }
             if (choice < 0) choice = win_ok ? 2 : 0;         /* not tuned (yet): by density */
-            c->stats.join_variant = choice == 0 ? MTB_JOIN_Q1W6 : choice == 1 ? MTB_JOIN_Q2W5 : choice == 2 ? (win32 ? -(10 + win32) : jw ? -(20 + jw) : MTB_JOIN_WINDOW) : -choice;
+            c->stats.join_variant = choice == 0 ? MTB_JOIN_Q1W6 : choice == 1 ? MTB_JOIN_Q2W5 : choice == 2 ? (win_waves != MTB_JOIN_WIN_WAVES ? -(10 + win_waves) : MTB_JOIN_WINDOW) : -choice;
             c->stats.join_tuned = tuned_flag;
             if (jt) for (int v = 0; v < 3; v++) c->stats.join_tune_ms[v] = jt->ms[v] < 1e29f ? jt->ms[v] : 0.0f;
-            if (choice == 2 && jw) {
-                /* k_join_win: windows bounded and the tiles without one listed first; those go to the sector-random form */
-                const bool sorted_ok = ix->params.kmer_format == 2 ? sort_low_bits == 34 : (sort_low_bits >= 24 && sort_low_bits <= 32);
-                if (!sorted_ok) return fail(MTB_ERR_ARG, "the window join needs the query list sorted on the announced bits");
-                const uint32_t n_tiles = (uint32_t)((n + qt - 1) / qt);
-                mtb_tile_win *d_tw; uint32_t *d_list, *d_redo;
-                STCHK(ensure(c, "jtilewin", (size_t)n_tiles, &d_tw)); STCHK(ensure(c, "jtilelist", (size_t)n_tiles, &d_list)); STCHK(ensure(c, "jtileredo", (size_t)n_tiles, &d_redo));
-                HIPCHK(hipMemsetAsync(c->d_scal + 16, 0, 24, c->stream));
-                hipLaunchKernelGGL(k_join_tile_win, dim3((n_tiles + 255) / 256), dim3(256), 0, c->stream, d_q, n, qt, dir_view(ix), limit, sort_low_bits, d_tw, n_tiles,
-                                   (unsigned long long *)(c->d_scal + 16), (uint32_t)MTB_JW_CAP, d_list);
-                uint64_t n_nowin = 0;
-                STCHK(d2h(c, &n_nowin, c->d_scal + 18, 8));
-#define MTB_LAUNCH_JWIN(WV) hipLaunchKernelGGL((k_join_win<0, WV>), dim3(n_tiles), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa, \
-                                   (uint32_t *)(c->d_scal + 1), qt, (const mtb_tile_win *)d_tw, (unsigned long long *)(c->d_scal + 16), d_redo)
-                if (n_nowin < n_tiles) switch (jw) { case 5: MTB_LAUNCH_JWIN(5); break; case 6: MTB_LAUNCH_JWIN(6); break; case 7: MTB_LAUNCH_JWIN(7); break; default: MTB_LAUNCH_JWIN(8); break; }
-#undef MTB_LAUNCH_JWIN
-                if (n_nowin) hipLaunchKernelGGL((k_join_win<0, 8, false>), dim3((uint32_t)n_nowin), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa,
-                                                (uint32_t *)(c->d_scal + 1), qt, (const mtb_tile_win *)nullptr, (unsigned long long *)nullptr, (uint32_t *)nullptr, (const uint32_t *)d_list);
-                win_tiles = n_tiles; redo_list = d_redo; redo_qt = qt;
-            } else
             if (choice == 2) {
-                /* the tiles' windows first (k_join_tile_win): needs the list sorted on the announced bits */
+                /* the tiles' windows first (k_join_tile_win): needs the list sorted on the announced bits (else every tile reads global memory) */
                 const uint32_t n_tiles = (uint32_t)((n + qt - 1) / qt);
-                mtb_tile_win *d_tw = nullptr;
-                const bool prewin = !c->opt.join_no_prewin && (ix->params.kmer_format == 2 ? sort_low_bits == 34 : (sort_low_bits >= 24 && sort_low_bits <= 32));
+                mtb_tile_win *d_tw;
+                const bool sorted_ok = ix->params.kmer_format == 2 ? sort_low_bits == 34 : (sort_low_bits >= 24 && sort_low_bits <= 32);
+                STCHK(ensure(c, "jtilewin", (size_t)n_tiles, &d_tw));
                 HIPCHK(hipMemsetAsync(c->d_scal + 16, 0, 16, c->stream));
-                if (prewin) {
-                    STCHK(ensure(c, "jtilewin", (size_t)n_tiles, &d_tw));
-                    hipLaunchKernelGGL(k_join_tile_win, dim3((n_tiles + 255) / 256), dim3(256), 0, c->stream, d_q, n, qt, dir_view(ix), limit, sort_low_bits, d_tw, n_tiles,
-                                       (unsigned long long *)(c->d_scal + 16));
-                }
-#define MTB_LAUNCH_JW(WV, WINV) hipLaunchKernelGGL((k_join_dir<true, 0, 1, WV, WINV>), dim3(n_tiles), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), \
+                if (sorted_ok) hipLaunchKernelGGL(k_join_tile_win, dim3((n_tiles + 255) / 256), dim3(256), 0, c->stream, d_q, n, qt, dir_view(ix), limit, sort_low_bits, d_tw, n_tiles,
+                                                  (unsigned long long *)(c->d_scal + 16));
+                else HIPCHK(hipMemsetAsync(d_tw, 0, (size_t)n_tiles * sizeof(mtb_tile_win), c->stream));
+#define MTB_LAUNCH_JW(WV) hipLaunchKernelGGL((k_join_dir<true, 0, 1, WV, true>), dim3(n_tiles), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), \
                                    (const mtb_tables *)c->d_tabs, sa, (uint32_t *)(c->d_scal + 1), qt, (const mtb_tile_win *)d_tw, (unsigned long long *)(c->d_scal + 16))
-                switch (win32) {
-                case 5: MTB_LAUNCH_JW(5, 2); break;
-                case 6: MTB_LAUNCH_JW(6, 2); break;
-                case 7: MTB_LAUNCH_JW(7, 2); break;
-                case 8: MTB_LAUNCH_JW(8, 2); break;
-                default: MTB_LAUNCH_JW(5, 1); break;
+                switch (win_waves) {
+                case 5: MTB_LAUNCH_JW(5); break;
+                case 6: MTB_LAUNCH_JW(6); break;
+                case 7: MTB_LAUNCH_JW(7); break;
+                default: MTB_LAUNCH_JW(MTB_JOIN_WIN_WAVES); break;
                 }
 #undef MTB_LAUNCH_JW
                 win_tiles = n_tiles;
@@ -871,8 +840,6 @@ static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint6
             case 1: MTB_LAUNCH_JV(2, 5); break;
             case 3: MTB_LAUNCH_JV(1, 5); break;
             case 4: MTB_LAUNCH_JV(2, 6); break;
-            case 5: hipLaunchKernelGGL((k_join_win<0, 8, false>), dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa,
-                                       (uint32_t *)(c->d_scal + 1), 256u, (const mtb_tile_win *)nullptr, (unsigned long long *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr); break;
             default: MTB_LAUNCH_JV(1, 6); break;
             }
 #undef MTB_LAUNCH_JV
@@ -895,18 +862,6 @@ static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint6
                            (const uint64_t *)d_bounds, d_out, cap, (unsigned long long *)c->d_scal, d_read_cnt, (uint32_t *)(c->d_scal + 1), sa);
     } }
     HIPCHK(hipGetLastError());
-    if (redo_list) {
-        /* (never, while the list is sorted as announced) tiles that found a query outside their window: redone by the sector-random form */
-        uint64_t n_redo = 0;
-        STCHK(d2h(c, &n_redo, c->d_scal + 17, 8));
-        if (n_redo) {
-            JoinSegArgs sa2 = *seg; sa2.ovf_counter = striped ? c->d_ovfctr : (unsigned long long *)c->d_scal; sa2.coop_min = c->opt.join_coop_min > 0 ? (uint32_t)c->opt.join_coop_min : (uint32_t)MTB_JOIN_COOP_MIN;
-            if (striped) { sa2.ovf_stripes = MTB_OVF_STRIPES; sa2.ovf_region = sa2.ovf_cap / MTB_OVF_STRIPES; }
-            hipLaunchKernelGGL((k_join_dir<true, 0, 1, 6>), dim3((uint32_t)n_redo), dim3(256), 0, c->stream, d_q, n, index_view(ix), limit, dir_view(ix), (const mtb_tables *)c->d_tabs, sa2,
-                               (uint32_t *)(c->d_scal + 1), redo_qt, (const mtb_tile_win *)nullptr, (unsigned long long *)nullptr, redo_list);
-            HIPCHK(hipGetLastError());
-        }
-    }
     uint64_t sc[2];
     STCHK(d2h(c, sc, c->d_scal, 16));
     if (win_tiles) {

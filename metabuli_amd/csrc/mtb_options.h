@@ -15,10 +15,9 @@
 
 struct MtbOptions {
     /* join (kernels_dir.h) */
-    int join_variant = 0;          /* MTB_JOIN_VARIANT: 0 auto (the context's tuner), else (Q << 4 | W) of q<Q>w<W>: 0x16, 0x25, 0x15, 0x26, 0x100 = window, 0x200 | W = the low-dword window at W waves per SIMD */
+    int join_variant = 0;          /* MTB_JOIN_VARIANT: 0 auto (the context's tuner), else (Q << 4 | W) of q<Q>w<W>: 0x16, 0x25, 0x15, 0x26, 0x100 = window (8 waves per SIMD), 0x200 | W = the window form at W waves (A/B) */
     int join_win = -1;             /* MTB_JOIN_WIN: -1 by density, 0 off, 1 on */
     int join_win_qt = 0;           /* MTB_JOIN_WIN_QT: queries per window tile (0 = from the batch's density) */
-    int join_no_prewin = 0;        /* MTB_JOIN_NO_PREWIN: the window variant finds its window inside the kernel (round 5's form) */
     int join_coop_min = 0;         /* MTB_JOIN_COOP_MIN: candidate runs longer than this are scanned by the wave (0 = compiled default) */
     int join_verbose = 0;          /* MTB_JOIN_VERBOSE */
     /* sort */
@@ -61,7 +60,7 @@ struct Entry { const char *name; Kind kind; size_t off; long long dflt; };
 #define MTB_OPT(N, K, F, D) {N, K, offsetof(MtbOptions, F), D}
 static const Entry kTable[] = {
     MTB_OPT("MTB_JOIN_VARIANT", VARIANT, join_variant, 0), MTB_OPT("MTB_JOIN_WIN", INT, join_win, -1), MTB_OPT("MTB_JOIN_WIN_QT", INT, join_win_qt, 0),
-    MTB_OPT("MTB_JOIN_NO_PREWIN", FLAG, join_no_prewin, 0), MTB_OPT("MTB_JOIN_COOP_MIN", INT, join_coop_min, 0), MTB_OPT("MTB_JOIN_VERBOSE", FLAG, join_verbose, 0),
+MTB_OPT("MTB_JOIN_COOP_MIN", INT, join_coop_min, 0), MTB_OPT("MTB_JOIN_VERBOSE", FLAG, join_verbose, 0),
     MTB_OPT("MTB_SORT_LSD", FLAG, sort_lsd, 0), MTB_OPT("MTB_SORT_NO_XCD", FLAG, sort_no_xcd, 0), MTB_OPT("MTB_SORT_PAIRS", INT, sort_pairs, 0),
     MTB_OPT("MTB_NO_SCORE_MANY", FLAG, no_score_many, 0), MTB_OPT("MTB_NO_MANY_SORT", FLAG, no_many_sort, 0), MTB_OPT("MTB_MANY_VERBOSE", FLAG, many_verbose, 0),
     MTB_OPT("MTB_NO_FAST_SCORER", FLAG, no_fast_scorer, 0), MTB_OPT("MTB_NO_FAST_PAIRS", FLAG, no_fast_pairs, 0), MTB_OPT("MTB_NO_LONG_SCORER", FLAG, no_long_scorer, 0),
@@ -78,10 +77,7 @@ static const Entry kTable[] = {
 static inline int parse_variant(const char *v) {
     if (!v || !*v || !strcmp(v, "auto")) return 0;
     if (!strcmp(v, "window")) return 0x100;
-    if (!strcmp(v, "rnd8")) return 0x408;                                                                     /* k_join_win without windows: the sector-random form at 8 waves per SIMD */
-    if (!strcmp(v, "win")) return 0x308;                                                                      /* k_join_win (kernels_join_win.h) */
-    if (!strncmp(v, "winw", 4) && v[4] >= '5' && v[4] <= '8' && !v[5]) return 0x300 | (v[4] - '0');          /* ... compiled for 5..8 waves per SIMD (A/B) */
-    if (!strncmp(v, "win32w", 6) && v[6] >= '5' && v[6] <= '8' && !v[7]) return 0x200 | (v[6] - '0');       /* the low-dword window at 5..8 waves per SIMD (A/B) */
+    if (!strncmp(v, "windoww", 7) && v[7] >= '5' && v[7] <= '7' && !v[8]) return 0x200 | (v[7] - '0');      /* the window form compiled for 5..7 waves per SIMD (A/B; "window" is 8) */
     if (v[0] == 'q' && v[1] >= '1' && v[1] <= '2' && v[2] == 'w' && v[3] >= '5' && v[3] <= '6' && !v[4]) return ((v[1] - '0') << 4) | (v[3] - '0');
     return -1;
 }

@@ -932,13 +932,8 @@ def test_queries_that_share_a_long_run_walk_it_in_lockstep(orc, tmp_path, seq_mo
     monkeypatch.delenv("MTB_DIR_DEPTH", raising=False)
     ro = t.ref["results"]
     amb = ro["flag"] != 0
-    for win in (("1", "0", "win", "rnd8") if seq_mode == 1 else ("0", "rnd8")):
-        if win == "win":
-            c.set_option("MTB_JOIN_WIN", None); c.set_option("MTB_JOIN_VARIANT", "win"); c.set_option("MTB_JOIN_WIN_QT", "48")
-        elif win == "rnd8":
-            c.set_option("MTB_JOIN_WIN", None); c.set_option("MTB_JOIN_VARIANT", "rnd8")
-        else:
-            c.set_option("MTB_JOIN_WIN", win)
+    for win in (("1", "0") if seq_mode == 1 else ("0",)):
+        c.set_option("MTB_JOIN_WIN", win)
         res, tt, tc = c.classify_batch(ix, p, t.b1, t.o1, t.b2, t.o2)
         assert ((res["classification"] == ro["classification"]) | amb).all(), win
         assert ((res["score"].view(np.uint32) == ro["score"].view(np.uint32)) | amb).all(), win
@@ -952,11 +947,11 @@ def test_queries_that_share_a_long_run_walk_it_in_lockstep(orc, tmp_path, seq_mo
 
 @pytest.mark.parametrize("seq_mode", [1, 2])
 def test_target_windows_staged_in_lds_give_the_same_matches(orc, tmp_path, seq_mode, monkeypatch):
-    """k_join_dir<.., WIN>: a workgroup.s tile of sorted queries stages the span of the target array between its first and its last bucket in
-    LDS (coalesced loads) and searches / evaluates there; tiles whose span exceeds the LDS capacity read global memory (same code).  Forced
-    on (MTB_JOIN_WIN=1) with tiles of 5, 64 and 256 queries -- spans from a few targets to far beyond the capacity, long candidate runs
-    (the wave scan) inside and outside a window -- the per-read answers and the match totals are the oracle's, and equal the sector-random
-    variant's (MTB_JOIN_WIN=0)."""
+    """k_join_dir<.., WIN>: a workgroup.s tile of sorted queries stages the low 32 bits of the target words between its first and its last bucket
+    in LDS (bounded before the launch by k_join_tile_win, 4-byte direct-to-LDS loads) and searches / evaluates there; the full word of a selected
+    candidate comes from global memory; tiles whose span exceeds the LDS capacity read global memory (same code).  Forced on (MTB_JOIN_WIN=1) with
+    tiles of 5, 17, 64 and 256 queries -- spans from a few targets to far beyond the capacity, long candidate runs (the wave scan) inside and
+    outside a window -- the per-read answers and the match totals are the oracle's, and equal the sector-random variant's (MTB_JOIN_WIN=0)."""
     import metabuli_amd as M
     from conftest import HotToy
     t = HotToy(orc, tmp_path / "db", seq_mode=seq_mode, n_reads=150)
@@ -968,15 +963,12 @@ def test_target_windows_staged_in_lds_give_the_same_matches(orc, tmp_path, seq_m
     ro = t.ref["results"]
     amb = ro["flag"] != 0
     windowed = {}
-    for win, qt, noprewin, variant in (("1", "5", None, None), ("1", "64", None, None), ("1", "256", None, None), ("1", "64", "1", None), ("1", "256", "1", None), ("0", "256", None, None),
-                                       ("1", "64", None, "win32w6"), ("1", "5", None, "win32w8"), ("1", "256", "1", "win32w7"),
-                                       ("1", "64", None, "win"), ("1", "5", None, "winw6"), ("1", "256", None, "win"), ("1", "17", None, "winw7"), ("0", "256", None, "rnd8")):
-        # (win / winw<W>: k_join_win for the tiles with a window -- low dwords in LDS, 32-bit offsets --, the listed tiles without one through k_join_dir)
-        # (win32w<W>: the window holds the low dwords only, the full word of a selected candidate comes from global memory)
-        c.set_option("MTB_JOIN_WIN", win); c.set_option("MTB_JOIN_WIN_QT", qt); c.set_option("MTB_JOIN_NO_PREWIN", noprewin); c.set_option("MTB_JOIN_VARIANT", variant)
+    for win, qt, variant in (("1", "5", None), ("1", "64", None), ("1", "256", None), ("0", "256", None), ("1", "64", "windoww6"), ("1", "17", "windoww7"), ("1", "256", "windoww5")):
+        # (windoww<W>: the window form compiled for fewer waves per SIMD -- the A/B instantiations)
+        c.set_option("MTB_JOIN_WIN", win); c.set_option("MTB_JOIN_WIN_QT", qt); c.set_option("MTB_JOIN_VARIANT", variant)
         res, tt, tc = c.classify_batch(ix, p, t.b1, t.o1, t.b2, t.o2)
         st = c.last_stats()
-        tag = (win, qt, noprewin, M.JOIN_VARIANTS[st.join_variant])
+        tag = (win, qt, M.JOIN_VARIANTS[st.join_variant])
         assert ix.state()["packed"]
         assert M.JOIN_VARIANTS[st.join_variant] == (variant or ("window" if win == "1" else "q1w6")) and st.join_tuned == 0, tag          # pinned: the tuner stays out
         assert ((res["classification"] == ro["classification"]) | amb).all(), tag
@@ -986,12 +978,11 @@ def test_target_windows_staged_in_lds_give_the_same_matches(orc, tmp_path, seq_m
             assert (tt == t.ref["tc_tax"]).all() and (tc == t.ref["tc_cnt"]).all(), tag
         assert st.n_matches == len(t.ref["matches"]), tag
         if win == "1":
-            # (rnd8: k_join_win without windows -- the sector-random form at eight waves per SIMD, offsets from the query's own bucket start)
             # tiles of the announced size; with the windows bounded before the launch (k_join_tile_win) the statistics say how many were staged,
             # and no tile ever finds a query outside its announced window
             assert st.join_tiles == (st.n_kmers + int(qt) - 1) // int(qt) or st.join_tiles >= st.n_kmers // int(qt), tag
             assert st.join_tiles_outside == 0, tag
-            if noprewin is None and variant is None:
+            if variant is None:
                 windowed[qt] = st.join_tiles_windowed
     assert windowed["5"] > 0 and windowed["64"] > 0, windowed           # small tiles: spans that fit LDS
     assert windowed["256"] < (len(t.ref["matches"]) + 255) // 256 + 64   # (wide tiles over a toy index mostly exceed the capacity)
