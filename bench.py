@@ -725,7 +725,7 @@ def headline(out, detail_path):
     index (profiled_step sets it to None otherwise) and never above 1."""
     line = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"))
     line["config"] = _pick(out["config"], ("workload", "reads_per_gpu", "read_len", "targets", "seq_mode", "gbp_per_s", "query_metamers", "matches", "classified_fraction",
-                                           "parallelism", "sub_batches_per_step", "index_sealed", "index_bytes", "tuning_steps", "join_variant", "species"))
+                                           "parallelism", "sub_batches_per_step", "index_sealed", "index_bytes", "tuning_steps", "join_variant", "species", "index_handover"))
     line["stage_ms"] = out.get("stage_ms")
     rf = out.get("roofline")
     line["roofline"] = _pick(rf, ("bound", "kernel", "achieved", "peak", "peak_measured", "unit", "frac", "traffic", "effective", "write_amplification",
@@ -861,6 +861,7 @@ def main(device=None):
     ap.add_argument("--reads-from", default="index", choices=["index", "heldout"],
                     help="heldout: the timed batch's reads come from the held-out genomes (species of indexed genera that are NOT in the index) -- the novel leg's workload as the "
                          "main one, for profiler runs")
+    ap.add_argument("--no-handover", action="store_true", help="N > 1: every rank synthesises its own replica of the index (default: rank 0 builds it once and the other ranks import it)")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--dist-backend", default="nccl", help="testing only: gloo lets several ranks share one GPU (RCCL refuses duplicate devices)")
     ap.add_argument("--shared-gpu", action="store_true", help="testing only: every rank uses cuda:0")
@@ -903,23 +904,63 @@ def main(device=None):
         build_world(args.seed, args.species, args.genome_len, args.filler_species)
     taxdir = tempfile.mkdtemp(prefix="mtb_tax_")
     world.tax.write(taxdir)
-    real_v, real_t, n_extras = extract_targets(ctx, M, world, params, torch if big_world else None, dev, hot_min=args.hot_min if conserved else 0, seed=args.seed)
-    n_filler = int(args.targets) - len(real_v)
-    if n_filler < 0:
-        raise SystemExit(f"--targets {int(args.targets)} is the TOTAL: the genomes alone give {len(real_v)} target metamers")
-    log(f"[rank {rank}] world: {len(world.genomes)} genomes x {args.genome_len} bp, {len(real_v) - n_extras} genome-derived target metamers + {n_extras} shared-run extras ({time.perf_counter()-t_setup:.1f}s)")
-    T_cap = n_filler + len(real_v)
-    free, total = torch.cuda.mem_get_info(dev)
-    need = T_cap * 12 + args.reads * (args.read_len + 8)
-    if need > free * 0.9:
-        raise SystemExit(f"index of {T_cap} targets needs {need/2**30:.0f} GiB, only {free/2**30:.0f} GiB free")
-    d_values = torch.empty(T_cap, dtype=torch.int64, device=dev)
-    d_info = torch.empty(T_cap, dtype=torch.int32, device=dev)
-    T = ctx.synth_index(args.seed, n_filler, world.filler_tax_lo, world.filler_tax_hi, real_v, real_t, d_values.data_ptr(), d_info.data_ptr())
-    taxid_list = np.concatenate([np.unique(real_t), np.arange(world.filler_tax_lo, world.filler_tax_hi + 1, dtype=np.int32)])
-    n_real = len(real_v)
-    del real_v, real_t
-    index = ctx.index_from_device(d_values.data_ptr(), d_info.data_ptr(), T, taxdir, taxid_list, params)
+    # N > 1, index replicated: rank 0 builds the index once and hands it to the other ranks' GPUs (mtb_index_export / mtb_index_import:
+    # inter-process handles, device-to-device copies over xGMI -- SURVEY 8(e) row 1 "load once, broadcast"); a rank whose import fails
+    # builds its own replica as every rank did before (the result is the same index either way: same seed)
+    handover = dist is not None and world_size > 1 and not args.partitioned and not args.no_handover
+    index = None; d_values = d_info = None; sealed = False
+    handed = dict(mode="local")
+    if handover and rank != 0:
+        box = [None]
+        dist.broadcast_object_list(box, src=0)          # (returns when rank 0 has built, sealed and exported)
+        if box[0] is not None:
+            try:
+                t_i = time.perf_counter()
+                index = ctx.import_index(box[0]["share"], taxdir, box[0]["taxid_list"], params)
+                torch.cuda.synchronize()
+                T, n_real, n_extras, n_filler = box[0]["T"], box[0]["n_real"], box[0]["n_extras"], box[0]["n_filler"]
+                sealed = index.state()["sealed"]
+                dt_i = time.perf_counter() - t_i
+                handed = dict(mode="imported from rank 0", seconds=dt_i, gb_per_s=T * 8 / dt_i / 1e9)
+                log(f"[rank {rank}] index imported from rank 0: {T} targets in {dt_i:.2f} s ({T * 8 / dt_i / 1e9:.0f} GB/s)")
+            except M.MtbError as e:
+                log(f"[rank {rank}] import failed ({e}): building a replica of my own")
+                index = None
+    if index is None:
+        real_v, real_t, n_extras = extract_targets(ctx, M, world, params, torch if big_world else None, dev, hot_min=args.hot_min if conserved else 0, seed=args.seed)
+        n_filler = int(args.targets) - len(real_v)
+        if n_filler < 0:
+            raise SystemExit(f"--targets {int(args.targets)} is the TOTAL: the genomes alone give {len(real_v)} target metamers")
+        log(f"[rank {rank}] world: {len(world.genomes)} genomes x {args.genome_len} bp, {len(real_v) - n_extras} genome-derived target metamers + {n_extras} shared-run extras ({time.perf_counter()-t_setup:.1f}s)")
+        T_cap = n_filler + len(real_v)
+        free, total = torch.cuda.mem_get_info(dev)
+        need = T_cap * 12 + args.reads * (args.read_len + 8)
+        if need > free * 0.9:
+            raise SystemExit(f"index of {T_cap} targets needs {need/2**30:.0f} GiB, only {free/2**30:.0f} GiB free")
+        d_values = torch.empty(T_cap, dtype=torch.int64, device=dev)
+        d_info = torch.empty(T_cap, dtype=torch.int32, device=dev)
+        T = ctx.synth_index(args.seed, n_filler, world.filler_tax_lo, world.filler_tax_hi, real_v, real_t, d_values.data_ptr(), d_info.data_ptr())
+        taxid_list = np.concatenate([np.unique(real_t), np.arange(world.filler_tax_lo, world.filler_tax_hi + 1, dtype=np.int32)])
+        n_real = len(real_v)
+        del real_v, real_t
+        index = ctx.index_from_device(d_values.data_ptr(), d_info.data_ptr(), T, taxdir, taxid_list, params)
+    if handover and rank == 0:
+        box = [None]
+        try:
+            if not args.no_seal:
+                try:
+                    index.seal(); sealed = True
+                    d_info = None
+                    torch.cuda.empty_cache()
+                except M.MtbError as e:                   # (an index too small for the packed state is handed over flat)
+                    log(f"[rank 0] index not sealed: {e}")
+            box[0] = dict(share=index.export(), taxid_list=taxid_list, T=int(T), n_real=int(n_real), n_extras=int(n_extras), n_filler=int(n_filler))
+            handed = dict(mode="exported to the other ranks")
+        except M.MtbError as e:
+            log(f"[rank 0] index not exported ({e}): every rank builds its own replica")
+        dist.broadcast_object_list(box, src=0)
+    if handover:
+        dist.barrier()                                   # the exporter keeps its index open and idle until every importer has its copy
     rseed = args.seed + 17 * (rank + 1)
     d_bases2 = None
     if args.seq_mode == 2:
@@ -956,13 +997,12 @@ def main(device=None):
         index_runs = dict(runs_by_log2_length=rl[:16], targets_by_log2_run_length=tl[:16], quantiles_over_targets=hist_summary(tl),
                           quantiles_over_runs=hist_summary(rl), genome_derived=int(n_real - n_extras), shared_run_extras=int(n_extras), filler=int(n_filler),
                           note="candidate runs (targets sharing one amino-acid part) of the whole timed index; bin b = lengths 2^b .. 2^(b+1)-1")
-    sealed = False
-    if not args.partitioned and not args.no_seal:
+    if not args.partitioned and not args.no_seal and not sealed:
         # dedicate the index to the fused path: packed 8-byte target words under the amino-acid directory; the info array lent to
         # the library is no longer needed by it and is freed here (64 GB at 16 G targets)
         try:
             index.seal(); sealed = True
-            del d_info
+            d_info = None
             torch.cuda.empty_cache()
         except M.MtbError as e:
             log(f"[rank {rank}] index not sealed: {e}")
@@ -1159,7 +1199,7 @@ def main(device=None):
             raise SystemExit(f"parity check against the timed index failed: {parity}")
 
     # which library was timed, on which device, per rank (SCALE runs are audited with this)
-    ident = dict(rank=rank, device=f"cuda:{local_rank}" if device is None else str(dev), library=os.path.realpath(M.LIB_PATH), version=M.lib().mtb_version().decode(),
+    ident = dict(rank=rank, index=handed, device=f"cuda:{local_rank}" if device is None else str(dev), library=os.path.realpath(M.LIB_PATH), version=M.lib().mtb_version().decode(),
                  device_name=(torch.cuda.get_device_name(local_rank) if device is None else "emulated"))
     log(f"[rank {rank}] library {ident['library']} ({ident['version']}) on {ident['device']} ({ident['device_name']})")
     ranks = [ident]
@@ -1189,6 +1229,7 @@ def main(device=None):
                                gbp_per_s=value * args.read_len * (2 if args.seq_mode == 2 else 1) / 1e3, query_metamers=int(st.n_kmers), matches=int(st.n_matches),
                                classified_fraction=frac_cls, parallelism=f"reads sharded x{world_size}, index replicated", streams_per_gpu=args.streams,
                                sub_batches_per_step=sub_batches_timed, index_sealed=sealed, tuning_steps=tuning_steps,
+                               index_handover=(f"{sum(1 for x in ranks if x['index']['mode'].startswith('imported'))} of {world_size - 1} ranks imported rank 0's index" if world_size > 1 else None),
                                join_variant=M.JOIN_VARIANTS.get(int(st.join_variant), str(st.join_variant)) + (" (tuned)" if st.join_tuned else ""),
                                join_tune_ms=dict(zip(("q1w6", "q2w5", "window"), [round(float(x), 2) for x in st.join_tune_ms])),
                                join_tiles=dict(tiles=int(st.join_tiles), windowed=int(st.join_tiles_windowed), outside=int(st.join_tiles_outside)),

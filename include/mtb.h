@@ -198,6 +198,26 @@ mtb_status mtb_index_from_device(mtb_ctx *, uint64_t *d_values, uint32_t *d_info
  * the taxonomy tables; the database files are read and decoded once per node, not once per GPU.  The copy is independent of its
  * source (own memory, own state).  `src` must not be a view.                                                          */
 mtb_status mtb_index_clone(mtb_index *src, mtb_ctx *dst_ctx, mtb_index **out);
+/* The same across PROCESSES (one process per GPU: torch.distributed / MPI launches): the process that holds a resident index describes
+ * it -- inter-process handles (hipIpcGetMemHandle) of the target words and the directory, sizes, state; a plain-old-data record that
+ * travels over any channel (a broadcast, a pipe) --, every other process of the node opens the handles and copies the arrays to ITS
+ * GPU device-to-device (over xGMI between GPUs) into memory of its own, then closes them: the database is read, decoded and packed once per
+ * node.  The exporter must keep the index open and unchanged (no classify call: the fused path may repack the array) until every importer
+ * has returned; the import is an independent index afterwards.  taxonomy_dir / taxid_list as for mtb_index_from_device (the taxonomy
+ * tables are host data: every process loads them itself).  `src` must not be a view.  No reference counterpart (one process, one address
+ * space: KmerMatcher.cpp:212-217). */
+typedef struct {
+    uint8_t  values_handle[64], info_handle[64], dir_handle[64], dirbase_handle[64];      /* hipIpcMemHandle_t of the allocations that hold the arrays */
+    uint64_t values_off, info_off, dir_off, dirbase_off;                                   /* the arrays' byte offsets inside those allocations */
+    uint64_t n_targets;
+    uint32_t dir_buckets, info_mask;
+    int32_t  dir_depth, packed, has_info, match_last, device;                               /* device: the exporter's ordinal (peer access) */
+    int64_t  exporter_pid;                                                                  /* an import inside the exporting process copies from the pointers directly */
+    uint64_t values_ptr, info_ptr, dir_ptr, dirbase_ptr;
+} mtb_index_share;
+mtb_status mtb_index_export(mtb_index *src, mtb_index_share *out);
+mtb_status mtb_index_import(mtb_ctx *, const mtb_index_share *, const char *taxonomy_dir, const int32_t *taxid_list, size_t n_taxids,
+                            const mtb_params *params, mtb_index **out);
 /* Dedicate an index to the fused path (mtb_classify_batch*): its target array goes to the packed state -- one 8-byte word per
  * target carrying the eighth amino-acid letter, the DNA bits and the info entry under the depth-7 amino-acid directory,
  * kernels_dir.h -- and info[] is let go of: freed if the library owns it, else the caller may free the array it lent

@@ -45,6 +45,7 @@ class BatchStats(C.Structure):
                 ("join_tiles", C.c_uint32), ("join_tiles_windowed", C.c_uint32), ("join_tiles_outside", C.c_uint32)]
 
 
+SHARE_BYTES = 4 * 64 + 4 * 8 + 8 + 2 * 4 + 5 * 4 + 4 + 8 + 4 * 8      # sizeof(mtb_index_share) (tests/test_abi.py checks it against the header)
 JOIN_VARIANTS = {0: "other", 1: "q1w6", 2: "q2w5", 3: "window", -3: "q1w5", -4: "q2w6", -15: "windoww5", -16: "windoww6", -17: "windoww7"}      # mtb_batch_stats.join_variant (mtb_join_variant)
 
 
@@ -195,6 +196,15 @@ class Context:
         """a copy of a resident index (of any context) on this context's GPU: peer copies, no file access (mtb_index_clone)"""
         h = C.c_void_p()
         _chk(self.L.mtb_index_clone(src.h, self.h, C.byref(h)))
+        return Index(self, h)
+
+    def import_index(self, share, taxonomy_dir, taxid_list, params):
+        """an index another PROCESS of the node holds resident (Index.export() there, the bytes sent over any channel) copied to this context's GPU
+        device to device (mtb_index_import); the exporter must keep its index open and idle until this returns"""
+        h = C.c_void_p()
+        tl = np.ascontiguousarray(taxid_list, dtype=np.int32)
+        buf = C.create_string_buffer(bytes(share), SHARE_BYTES)
+        _chk(self.L.mtb_index_import(self.h, buf, taxonomy_dir.encode(), _p(tl), C.c_size_t(len(tl)), C.byref(params), C.byref(h)))
         return Index(self, h)
 
     def index_from_device(self, d_values, d_info, n_targets, taxonomy_dir, taxid_list, params):
@@ -473,6 +483,12 @@ class Index:
         o = np.zeros(4, np.uint64)
         _chk(self.ctx.L.mtb_index_open_stats(self.h, _p(o)))
         return dict(chunks=int(o[0]), chunk_words=int(o[1]), peak_bytes=int(o[2]), packed_on_load=bool(o[3]))
+
+    def export(self):
+        """mtb_index_export: the record (bytes) another process of the node hands to Context.import_index; keep this index open and idle meanwhile"""
+        buf = C.create_string_buffer(SHARE_BYTES)
+        _chk(self.ctx.L.mtb_index_export(self.h, buf))
+        return buf.raw
 
     def seal(self):
         """mtb_index_seal: packed state + info[] released (the lender of a borrowed info array may free it afterwards)"""

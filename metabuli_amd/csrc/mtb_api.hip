@@ -1644,6 +1644,97 @@ mtb_status mtb_index_clone(mtb_index *src, mtb_ctx *dst, mtb_index **out) {
     return MTB_OK;
 }
 
+/* ---- the resident index handed to other PROCESSES of the node (include/mtb.h: mtb_index_share) ---- */
+static mtb_status ipc_describe(const void *p, uint8_t handle[64], uint64_t *off) {
+    static_assert(sizeof(hipIpcMemHandle_t) <= 64, "handle record");
+    memset(handle, 0, 64); *off = 0;
+    if (!p) return MTB_OK;
+    hipDeviceptr_t base = nullptr; size_t size = 0;
+    HIPCHK(hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)p));            /* the handle names the ALLOCATION (a torch tensor may sit inside a larger block) */
+    hipIpcMemHandle_t h;
+    HIPCHK(hipIpcGetMemHandle(&h, (void *)base));
+    memcpy(handle, &h, sizeof(h));
+    *off = (uint64_t)((const char *)p - (const char *)base);
+    return MTB_OK;
+}
+mtb_status mtb_index_export(mtb_index *src, mtb_index_share *out) {
+    if (!src || !out) return fail(MTB_ERR_ARG, "NULL argument");
+    if (src->parent) return fail(MTB_ERR_ARG, "a view cannot be exported: export its parent");
+    memset(out, 0, sizeof(*out));
+    HIPCHK(hipSetDevice(src->ctx->device));
+    HIPCHK(hipStreamSynchronize(src->ctx->stream));
+    std::unique_lock<std::mutex> lk(src->state_mu);
+    src->state_cv.wait(lk, [&] { return src->users == 0; });
+    STCHK(ipc_describe(src->d_values, out->values_handle, &out->values_off));
+    STCHK(ipc_describe(src->d_info, out->info_handle, &out->info_off));
+    STCHK(ipc_describe(src->d_dir, out->dir_handle, &out->dir_off));
+    STCHK(ipc_describe(src->d_dirbase, out->dirbase_handle, &out->dirbase_off));
+    out->n_targets = src->T; out->dir_buckets = src->dir_buckets; out->info_mask = src->info_mask; out->dir_depth = src->dir_L;
+    out->packed = src->packed ? 1 : 0; out->has_info = src->d_info ? 1 : 0; out->match_last = src->match_last ? 1 : 0; out->device = src->ctx->device;
+    out->exporter_pid = (int64_t)getpid();
+    out->values_ptr = (uint64_t)(uintptr_t)src->d_values; out->info_ptr = (uint64_t)(uintptr_t)src->d_info;
+    out->dir_ptr = (uint64_t)(uintptr_t)src->d_dir; out->dirbase_ptr = (uint64_t)(uintptr_t)src->d_dirbase;
+    return MTB_OK;
+}
+mtb_status mtb_index_import(mtb_ctx *c, const mtb_index_share *sh, const char *taxonomy_dir, const int32_t *taxid_list, size_t n_taxids,
+                            const mtb_params *params, mtb_index **out) {
+    if (!c || !sh || !taxonomy_dir || !params || !out) return fail(MTB_ERR_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(c->device));
+    mtb_index *ix = new mtb_index();
+    struct Guard { mtb_index *ix; ~Guard() { if (ix) mtb_index_close(ix); } } guard{ix};
+    ix->ctx = c; ix->params = *params; ix->own = true; ix->T = sh->n_targets; ix->info_mask = sh->info_mask; ix->match_last = sh->match_last != 0;
+    std::string err;
+    if (!mtbhost::load_taxonomy(taxonomy_dir, &ix->tax, &err)) return fail(MTB_ERR_IO, err);
+    mtbhost::build_tax2species(&ix->tax, taxid_list, n_taxids);
+    STCHK(upload_taxonomy(ix));
+    const bool same_process = sh->exporter_pid == (int64_t)getpid();
+    if (!same_process && sh->device != c->device) {                      /* the exporter's GPU is another one: copies go over the fabric */
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, c->device, sh->device) == hipSuccess && can) { const hipError_t e = hipDeviceEnablePeerAccess(sh->device, 0); if (e != hipSuccess) (void)hipGetLastError(); }
+        else (void)hipGetLastError();
+    }
+    void *opened[4] = {nullptr, nullptr, nullptr, nullptr};
+    struct Closer { void **o; ~Closer() { for (int k = 0; k < 4; k++) if (o[k]) { hipError_t e = hipIpcCloseMemHandle(o[k]); (void)e; } } } closer{opened};
+    /* array k of the exporter as a pointer this process may copy from */
+    auto source = [&](int k, const uint8_t handle[64], uint64_t off, uint64_t direct, const void **p) -> mtb_status {
+        *p = nullptr;
+        if (same_process) { *p = (const void *)(uintptr_t)direct; return MTB_OK; }
+        hipIpcMemHandle_t h; memcpy(&h, handle, sizeof(h));
+        HIPCHK(hipIpcOpenMemHandle(&opened[k], h, hipIpcMemLazyEnablePeerAccess));
+        *p = (const char *)opened[k] + off;
+        return MTB_OK;
+    };
+    auto copy = [&](void *d, const void *s_, size_t bytes) -> mtb_status {
+        const size_t CH = 1ull << 30;
+        for (size_t o = 0; o < bytes; o += CH) HIPCHK(hipMemcpyAsync((char *)d + o, (const char *)s_ + o, std::min(CH, bytes - o), hipMemcpyDefault, c->stream));
+        return MTB_OK;
+    };
+    const void *sp = nullptr;
+    STCHK(source(0, sh->values_handle, sh->values_off, sh->values_ptr, &sp));
+    HIPCHK(hipMalloc((void **)&ix->d_values, (ix->T + 1) * 8));
+    STCHK(copy(ix->d_values, sp, ix->T * 8));
+    if (sh->has_info) {
+        STCHK(source(1, sh->info_handle, sh->info_off, sh->info_ptr, &sp));
+        HIPCHK(hipMalloc((void **)&ix->d_info, std::max<uint64_t>(ix->T, 1) * 4));
+        STCHK(copy(ix->d_info, sp, ix->T * 4));
+    }
+    if (sh->dir_depth > 0) {
+        const uint32_t n_groups = (sh->dir_buckets >> 16) + 1;
+        HIPCHK(hipMalloc((void **)&ix->d_dir, ((size_t)sh->dir_buckets + 1) * 4));
+        HIPCHK(hipMalloc((void **)&ix->d_dirbase, ((size_t)n_groups + 2) * 8));
+        STCHK(source(2, sh->dir_handle, sh->dir_off, sh->dir_ptr, &sp));
+        STCHK(copy(ix->d_dir, sp, ((size_t)sh->dir_buckets + 1) * 4));
+        STCHK(source(3, sh->dirbase_handle, sh->dirbase_off, sh->dirbase_ptr, &sp));
+        STCHK(copy(ix->d_dirbase, sp, ((size_t)n_groups + 2) * 8));
+        ix->dir_L = sh->dir_depth; ix->dir_buckets = sh->dir_buckets;
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    ix->packed = sh->packed != 0;
+    guard.ix = nullptr;
+    *out = ix;
+    return MTB_OK;
+}
+
 void mtb_index_close(mtb_index *ix) {
     if (!ix) return;
     hipError_t e = hipSuccess;

@@ -110,6 +110,15 @@ static inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemGetInfo(size_t *fr, size_t *tot) { *tot = (size_t)hipemu::mem_total(); long long f = hipemu::mem_total() - hipemu::g_allocated.load(); *fr = f > 0 ? (size_t)f : 0; return hipSuccess; }
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { if (n) memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { if (n) memmove(d, s, n); return hipSuccess; }
+/* inter-process handles: the stand-in has one address space per process -- a handle is the pointer itself (an import inside the exporting
+ * process never opens it; across processes the real runtime is needed and the stand-in reports an error) */
+typedef void *hipDeviceptr_t;
+struct hipIpcMemHandle_t { char reserved[64]; };
+enum { hipIpcMemLazyEnablePeerAccess = 1 };
+static inline hipError_t hipMemGetAddressRange(hipDeviceptr_t *base, size_t *size, hipDeviceptr_t p) { *base = p; *size = 0; return hipSuccess; }
+static inline hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t *h, void *p) { memset(h, 0, sizeof(*h)); memcpy(h->reserved, &p, sizeof(p)); return hipSuccess; }
+static inline hipError_t hipIpcOpenMemHandle(void **, hipIpcMemHandle_t, unsigned) { return hipErrorInvalidValue; }
+static inline hipError_t hipIpcCloseMemHandle(void *) { return hipSuccess; }
 static inline hipError_t hipMemcpyPeerAsync(void *d, int, const void *s, int, size_t n, hipStream_t = nullptr) { if (n) memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t = nullptr) { if (n) memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipMemset(void *d, int v, size_t n) { if (n) memset(d, v, n); return hipSuccess; }

@@ -173,6 +173,8 @@ mtb_status mtb_ctx_set_streams(mtb_ctx *, int) { return MTB_OK; }
 mtb_status mtb_ctx_set_workspace_limit(mtb_ctx *, uint64_t) { return MTB_OK; }
 mtb_status mtb_ctx_set_placement_probe(mtb_ctx *, int) { return MTB_OK; }
 mtb_status mtb_ctx_set_join_variant(mtb_ctx *, int) { return MTB_OK; }
+mtb_status mtb_index_export(mtb_index *, mtb_index_share *) { return MTB_ERR_UNSUPPORTED; }
+mtb_status mtb_index_import(mtb_ctx *, const mtb_index_share *, const char *, const int32_t *, size_t, const mtb_params *, mtb_index **) { return MTB_ERR_UNSUPPORTED; }
 mtb_status mtb_ctx_set_option(mtb_ctx *, const char *, const char *) { return MTB_OK; }
 uint32_t mtb_ctx_last_sub_batches(const mtb_ctx *) { return 1; }
 mtb_status mtb_ctx_reserve(mtb_ctx *c, const mtb_params *p, uint64_t, uint64_t) { return c && p ? MTB_OK : fail(MTB_ERR_ARG, "NULL argument"); }

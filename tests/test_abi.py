@@ -92,3 +92,14 @@ int main() {
     for f in os.listdir(csrc):
         if f.endswith((".h", ".hip")) and f != "mtb_options.h":
             assert "getenv" not in open(os.path.join(csrc, f)).read(), f
+
+
+def test_share_record_size_matches_the_binding(tmp_path):
+    """mtb_index_share (the record a resident index is handed to other processes with) is plain old data of the size the Python binding allocates"""
+    import subprocess
+    import metabuli_amd as M
+    src = tmp_path / "s.c"
+    src.write_text('#include <stdio.h>\n#include "mtb.h"\nint main(void) { printf("%zu\\n", sizeof(mtb_index_share)); return 0; }\n')
+    exe = tmp_path / "s"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
+    assert int(subprocess.check_output([str(exe)]).decode()) == M.SHARE_BYTES

@@ -714,6 +714,65 @@ def test_index_clone_is_an_independent_equal_copy(toy, monkeypatch, state):
     cp.close(); b.close()
 
 
+def _import_worker(share, dbdir, out_path, b1, o1, b2, o2, pkw):
+    """a process of its own: opens the exporter's arrays through the inter-process handles, copies them, classifies on the copy"""
+    import metabuli_amd as M
+    c = M.Context(0)
+    p = M.default_params(**pkw)
+    tl = np.loadtxt(os.path.join(dbdir, "taxID_list"), dtype=np.int32, ndmin=1)
+    ix = c.import_index(share, os.path.join(dbdir, "taxonomy"), tl, p)
+    res, tt, tc = c.classify_batch(ix, p, b1, o1, b2, o2)
+    st = ix.state()
+    np.savez(out_path, res=res, tt=tt, tc=tc, packed=st["packed"], sealed=st["sealed"], depth=st["dir_depth"], T=ix.num_targets)
+    ix.close(); c.close()
+
+
+@pytest.mark.parametrize("state,other_process", [("flat", False), ("sealed", False), ("sealed", True)])
+def test_resident_index_handed_to_another_context_through_its_share_record(toy, monkeypatch, tmp_path, state, other_process):
+    """mtb_index_export / mtb_index_import (one process per GPU: how bench.py --gpus N and torch.distributed launches get the index that rank 0
+    built): the exporter describes its resident arrays (inter-process handles, offsets, state), the importer copies them device to device
+    into memory of its own and loads the taxonomy itself.  Inside one process the record's pointers are used directly; ACROSS processes
+    (spawned worker, real GPU only) the handles are opened.  The import classifies as the oracle says, in the exporter's state."""
+    import multiprocessing as mp
+    import metabuli_amd as M
+    if other_process and os.environ.get("MTB_HIPEMU"):
+        pytest.skip("inter-process handles need the real HIP runtime")
+    if state != "flat":
+        monkeypatch.setenv("MTB_DIR_DEPTH", "7")
+    a = M.Context(0)
+    p = _params(toy)
+    src = a.open_index(toy.dbdir, p)
+    monkeypatch.delenv("MTB_DIR_DEPTH", raising=False)
+    if state == "sealed":
+        if toy.p.seq_mode == 3:
+            src.close(); a.close(); pytest.skip("long toy reads may leave the index flat")
+        src.seal()
+    share = src.export()
+    assert len(share) == M.SHARE_BYTES
+    tl = np.loadtxt(os.path.join(toy.dbdir, "taxID_list"), dtype=np.int32, ndmin=1)
+    if other_process:
+        out = str(tmp_path / "imp.npz")
+        ctx = mp.get_context("spawn")
+        w = ctx.Process(target=_import_worker, args=(share, toy.dbdir, out, toy.b1, toy.o1, toy.b2, toy.o2,
+                                                        dict(seq_mode=toy.p.seq_mode, syncmer=toy.p.syncmer, smer_len=toy.p.smer_len, kmer_format=toy.p.kmer_format, accession_level=toy.p.accession_level)))
+        w.start(); w.join(600)
+        assert w.exitcode == 0
+        z = np.load(out)
+        assert bool(z["packed"]) == src.state()["packed"] and int(z["T"]) == len(toy.values)
+        _check_results(toy, z["res"], z["tt"], z["tc"])
+        src.close(); a.close()
+        return
+    b = M.Context(0)
+    cp = b.import_index(share, os.path.join(toy.dbdir, "taxonomy"), tl, p)
+    assert cp.state() == src.state() and cp.num_targets == len(toy.values)
+    src.close(); a.close()                                  # the import is independent of its source
+    res, tt, tc = b.classify_batch(cp, p, toy.b1, toy.o1, toy.b2, toy.o2)
+    _check_results(toy, res, tt, tc)
+    v, info = cp.download()
+    assert (v == toy.values).all() and (info.astype(np.int32) == toy.taxids).all()
+    cp.close(); b.close()
+
+
 @pytest.mark.parametrize("paired", [False, True])
 def test_a_few_long_reads_do_not_send_the_batch_down_the_exact_path(orc, tmp_path, paired):
     """one read of >= 4093 used bases (positions beyond a slot record's 12 bits) or with more than 384 metamers used
@@ -1165,9 +1224,11 @@ def test_bench_path_matches_the_oracle(tmp_path):
         out = subprocess.run([sys.executable, _bench_script(root), "--steps", "1", "--warmup", "0", "--reads", "20000", "--targets", "3e6",
                               "--cpu-reads", "20000", "--cpu-stride", "4", "--species", "8", "--genome-len", "150000", "--filler-species", "3000",
                               "--leg-pairs", "3000", "--leg-long", "40", "--leg-long-len", "3000", "--full-parity-reads", "3000",
-                              "--seq-mode", str(mode)], capture_output=True, text=True, timeout=900)
+                              "--seq-mode", str(mode)], capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
         assert out.returncode == 0, out.stderr[-2000:]
-        line = json.loads(out.stdout.strip().split("\n")[-1])
+        head = json.loads(out.stdout.strip().split("\n")[-1])            # the driver's line: short form
+        assert len(out.stdout.strip().split("\n")[-1]) < 8192 and head["parity_sample"]["mismatches"] == 0 and head["cpu_baseline"]["kind"] == "port"
+        line = json.load(open(tmp_path / head["detail"]))                 # the full record next to it
         ps = line["parity_sample"]
         assert ps["reads"] == 20000 and ps["mismatches"] == 0 and ps["classified"] > 10000, ps
         assert ps["matches"] == ps["oracle_matches"] > 0
@@ -1191,9 +1252,11 @@ def test_bench_heavy_tailed_workload_in_small(tmp_path):
     out = subprocess.run([sys.executable, _bench_script(root), "--steps", "1", "--warmup", "0", "--reads", "100000", "--targets", "2.5e8",
                           "--cpu-reads", "30000", "--cpu-stride", "8", "--species", "200", "--genome-len", "600000", "--filler-species", "5000",
                           "--leg-pairs", "20000", "--leg-long", "100", "--leg-long-len", "5000", "--leg-novel", "30000", "--heldout", "20", "--long-parity-reads", "40", "--full-parity-reads", "4000", "--no-cpu"],
-                         capture_output=True, text=True, timeout=1500)
+                         capture_output=True, text=True, timeout=1500, cwd=str(tmp_path))
     assert out.returncode == 0, out.stderr[-3000:]
-    line = json.loads(out.stdout.strip().split("\n")[-1])
+    head = json.loads(out.stdout.strip().split("\n")[-1])
+    assert set(head["other_configs"]) == {"paired", "long", "best_case", "novel"} and all(v.get("parity", {"mismatches": 0})["mismatches"] == 0 for v in head["other_configs"].values())
+    line = json.load(open(tmp_path / head["detail"]))
     assert line["parity_sample"]["mismatches"] == 0 and line["parity_sample"]["reads"] == 30000
     assert line["other_configs"]["paired"]["mismatches"] == 0 and line["other_configs"]["long"]["mismatches"] == 0
     assert line["other_configs"]["novel"]["mismatches"] == 0 and line["other_configs"]["novel"]["parity"]["reads"] == 4000        # reads of held-out organisms
@@ -1201,6 +1264,28 @@ def test_bench_heavy_tailed_workload_in_small(tmp_path):
     rl = line["run_lengths"]
     assert rl["index"]["shared_run_extras"] > 0 and rl["index"]["quantiles_over_targets"]["max_bin_upper"] >= 127
     assert rl["queries"]["quantiles"]["max_bin_upper"] >= 127            # queries meet runs of > 64 candidates: the wave-scanned path ran
+
+
+@_needs_device
+def test_bench_two_ranks_share_one_gpu_and_one_index_build(tmp_path):
+    """bench.py launched as the driver launches it for N = 2 (torch.distributed.run, one process per rank; here both on cuda:0 over gloo): rank 0
+    builds and seals the index ONCE, rank 1 imports it through the inter-process handles (mtb_index_export / mtb_index_import: the hand-over a
+    SCALE run does over xGMI) and both classify their own reads against their own copy; one JSON line for the job."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29800 + os.getpid() % 150
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--reads", "200000", "--targets", "6e8", "--species", "200",
+                          "--genome-len", "600000", "--filler-species", "5000", "--dist-backend", "gloo", "--shared-gpu"],
+                         capture_output=True, text=True, timeout=1500, cwd=str(tmp_path), env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    head = json.loads([ln for ln in out.stdout.strip().split("\n") if ln.startswith("{")][-1])
+    assert head["n_gpus"] == 2 and head["config"]["classified_fraction"] > 0.5
+    assert head["config"]["index_handover"] == "1 of 1 ranks imported rank 0's index", (head["config"]["index_handover"], out.stderr[-2000:])
+    line = json.load(open(tmp_path / head["detail"]))
+    assert [r["index"]["mode"] for r in line["ranks"]] == ["exported to the other ranks", "imported from rank 0"]
 
 
 def test_format1_database_without_kmer_format_line(ctx, orc, tmp_path):
