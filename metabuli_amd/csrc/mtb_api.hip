@@ -93,6 +93,7 @@ struct mtb_ctx {
     hipStream_t stream = nullptr;
     mtb_tables *d_tabs = nullptr;
     mtb_tables h_tabs;
+    uint8_t *d_ham2 = nullptr;       /* hamming sums of codon PAIRS: [query pair << 6 | target pair], 4096 bytes (k_join_dir stages it in LDS) */
     std::map<std::string, DevBuf> bufs;
     std::mutex bufs_mu;              /* the buffer table may be grown from a helper thread (mtb_ctx_reserve) while the context's thread opens an index */
     std::mutex reserve_mu;           /* held by mtb_ctx_reserve for its whole run */
@@ -373,6 +374,13 @@ mtb_status mtb_ctx_create(int device, void *stream, mtb_ctx **out) {
     mtb_build_tables(&c->h_tabs);
     HIPCHK(hipMalloc((void **)&c->d_tabs, sizeof(mtb_tables)));
     HIPCHK(hipMemcpy(c->d_tabs, &c->h_tabs, sizeof(mtb_tables), hipMemcpyHostToDevice));
+    {   /* pair p = codon a (bits 0-2) and codon b (bits 3-5): hammingLookup[qa][ta] + hammingLookup[qb][tb] */
+        uint8_t h2[4096];
+        for (uint32_t qp = 0; qp < 64; qp++) for (uint32_t tp = 0; tp < 64; tp++)
+            h2[(qp << 6) | tp] = (uint8_t)(((c->h_tabs.hamrow[qp & 7u] >> (4u * (tp & 7u))) & 15u) + ((c->h_tabs.hamrow[qp >> 3] >> (4u * (tp >> 3))) & 15u));
+        HIPCHK(hipMalloc((void **)&c->d_ham2, sizeof(h2)));
+        HIPCHK(hipMemcpy(c->d_ham2, h2, sizeof(h2), hipMemcpyHostToDevice));
+    }
     HIPCHK(hipMalloc((void **)&c->d_scal, 24 * sizeof(uint64_t)));      /* [16..23]: the join's tile statistics */
     c->d_xscal = c->d_scal + 8;
     HIPCHK(hipMalloc((void **)&c->d_ovfctr, MTB_OVF_STRIPES * 64));
@@ -390,6 +398,7 @@ void mtb_ctx_destroy(mtb_ctx *c) {
     e = hipStreamSynchronize(c->stream);
     for (auto &kv : c->bufs) if (kv.second.p) e = hipFree(kv.second.p);
     if (c->d_tabs && !c->is_lane) e = hipFree(c->d_tabs);
+    if (c->d_ham2 && !c->is_lane) e = hipFree(c->d_ham2);
     if (c->d_scal) e = hipFree(c->d_scal);
     if (c->d_ovfctr) e = hipFree(c->d_ovfctr);
     if (c->is_lane && c->stream) e = hipStreamDestroy(c->stream);
@@ -441,7 +450,7 @@ mtb_status mtb_ctx_set_streams(mtb_ctx *c, int n) {
     while ((int)c->lanes.size() > (n == 1 ? 0 : n)) { mtb_ctx_destroy(c->lanes.back()); c->lanes.pop_back(); }
     while (n > 1 && (int)c->lanes.size() < n) {
         mtb_ctx *l = new mtb_ctx();
-        l->device = c->device; l->is_lane = true; l->d_tabs = c->d_tabs; l->h_tabs = c->h_tabs; l->profiling = c->profiling; l->placement_probe = c->placement_probe; l->opt = c->opt;
+        l->device = c->device; l->is_lane = true; l->d_tabs = c->d_tabs; l->d_ham2 = c->d_ham2; l->h_tabs = c->h_tabs; l->profiling = c->profiling; l->placement_probe = c->placement_probe; l->opt = c->opt;
         HIPCHK(hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking));
         HIPCHK(hipMalloc((void **)&l->d_scal, 24 * sizeof(uint64_t)));
         l->d_xscal = l->d_scal + 8;
@@ -736,7 +745,7 @@ static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint6
     if (seg && ix->d_dir) {
         STCHK(use.acquire(ix, true));
         KTimer kt(c, MTB_K_JOIN);
-        JoinSegArgs sa = *seg; sa.ovf_counter = (unsigned long long *)c->d_scal; sa.coop_min = c->opt.join_coop_min > 0 ? (uint32_t)c->opt.join_coop_min : (uint32_t)MTB_JOIN_COOP_MIN;
+        JoinSegArgs sa = *seg; sa.ham2 = c->d_ham2; sa.ovf_counter = (unsigned long long *)c->d_scal; sa.coop_min = c->opt.join_coop_min > 0 ? (uint32_t)c->opt.join_coop_min : (uint32_t)MTB_JOIN_COOP_MIN;
         if (striped) {
             HIPCHK(hipMemsetAsync(c->d_ovfctr, 0, MTB_OVF_STRIPES * 64, c->stream));
             sa.ovf_counter = c->d_ovfctr; sa.ovf_stripes = MTB_OVF_STRIPES; sa.ovf_region = sa.ovf_cap / MTB_OVF_STRIPES;

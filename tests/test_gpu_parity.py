@@ -721,8 +721,8 @@ def _import_worker(share, dbdir, out_path, b1, o1, b2, o2, pkw):
     p = M.default_params(**pkw)
     tl = np.loadtxt(os.path.join(dbdir, "taxID_list"), dtype=np.int32, ndmin=1)
     ix = c.import_index(share, os.path.join(dbdir, "taxonomy"), tl, p)
+    st = ix.state()                      # (as imported: a mode whose reads take a flat-state path unpacks the array on its first batch)
     res, tt, tc = c.classify_batch(ix, p, b1, o1, b2, o2)
-    st = ix.state()
     np.savez(out_path, res=res, tt=tt, tc=tc, packed=st["packed"], sealed=st["sealed"], depth=st["dir_depth"], T=ix.num_targets)
     ix.close(); c.close()
 
