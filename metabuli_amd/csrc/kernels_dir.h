@@ -236,10 +236,8 @@ __device__ __forceinline__ uint32_t wave_min_shfl_u32(uint32_t v) {
 #else
 #define MTB_WAIT_VMEM() do {} while (0)
 #endif
-#ifndef MTB_JOIN_WINCAP
-#define MTB_JOIN_WINCAP 3840          /* targets a window holds = 60 pieces of 64 low dwords (one wave-wide 4-byte direct-to-LDS load each): 15.4 KB + the 4 KB pair table
-                                       * -> eight workgroups (32 waves) per CU */
-#endif
+#define MTB_JOIN_WINCAP 3968          /* targets a window holds = 62 pieces of 64 low dwords (one wave-wide 4-byte direct-to-LDS load each): 15.9 KB -> eight workgroups
+                                       * (32 waves) per CU */
 #define MTB_JOIN_WIN_WAVES 8          /* waves per SIMD the window form is compiled for */
 /* The windows of the tiles, BEFORE the join (round 6): the queries are sorted on their top (64 - low_bits) bits -- six amino-acid letters
  * of kmer_format 2, the top 32 bits of format 1 -- so the first and the last record of a tile bound the buckets all its queries can
@@ -300,23 +298,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
     auto full_of = [&](uint64_t t, uint64_t v) -> uint64_t { return (WIN && use_win) ? ix.values[t] : v; };
     constexpr bool LONG = MODE == 1, LIST = MODE == 2;
     const uint64_t AAM = ~0xFFFFFFull;
-    __shared__ uint32_t s_hr[8];                    /* hammingLookup rows as nibble words (getHammings of a selected candidate; filled below, behind the loads that matter) */
-    /* the hamming SUM of a candidate (getHammingDistanceSum, KmerMatcher.h:348-360 -- evaluated for every target of every candidate run: the kernel's
-     * arithmetic) from a table of codon PAIRS: s_h2[query pair << 6 | target pair] = the two codons' distances added (4 KB, built by the host from
-     * hammingLookup, mtb_ctx_create): four byte look-ups and three additions instead of eight shift / mask / add groups on nibble rows */
-    __shared__ __attribute__((aligned(16))) uint8_t s_h2[4096];
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(sa.ham2 + 16u * threadIdx.x),
-                                     (__attribute__((address_space(3))) void *)(s_h2 + 1024u * (threadIdx.x >> 6)), 16, 0, 0);
-    auto ham2 = [&](uint32_t qd, uint32_t td) -> uint32_t {
-#ifdef MTB_NO_HAM2               /* A/B build: the nibble rows (round 5) */
-        uint32_t s_ = 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) s_ += (s_hr[(qd >> (3 * i)) & 7u] >> (4 * ((td >> (3 * i)) & 7u))) & 15u;
-        return s_;
-#endif
-        return (uint32_t)s_h2[((qd & 63u) << 6) | (td & 63u)] + (uint32_t)s_h2[(((qd >> 6) & 63u) << 6) | ((td >> 6) & 63u)] +
-               (uint32_t)s_h2[(((qd >> 12) & 63u) << 6) | ((td >> 12) & 63u)] + (uint32_t)s_h2[((qd >> 18) << 6) | (td >> 18)];
-    };
+    __shared__ uint32_t s_hr[8];                    /* hammingLookup rows as nibble words: the only table the join arithmetic reads (filled below, behind the loads that matter) */
     const uint64_t base_q = WIN ? (uint64_t)blockIdx.x * qt : (uint64_t)blockIdx.x * (256 * Q);
     /* the window [a0, a1) -> s_win: 64 targets a piece, a wave each, every lane the low dword of its own target, straight into LDS
      * (global_load_lds_dword: no staging registers, no wait between the pieces -- a loop of load / ds_write pairs waited for every load: a
@@ -367,7 +349,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
         MTB_JP_MARK(5);
         if (!__syncthreads_or(outside ? 1 : 0)) { if (pre_len) { use_win = true; w0 = pre_a0; } }
         else if (threadIdx.x == 0 && win_stat) atomicAdd(win_stat + 1, 1ull);        /* (mtb_batch_stats.join_tiles_outside: stays 0 while the list is sorted as announced; the tile reads global memory) */
-    } else { MTB_WAIT_VMEM(); __syncthreads(); }     /* s_hr, s_h2; the query and directory loads above are in flight meanwhile */
+    } else __syncthreads();                          /* s_hr; the query and directory loads above are in flight meanwhile */
     MTB_JP_MARK(6);
     /* what tells targets of one bucket apart: the whole amino-acid part (flat state) or the packed word's eighth letter */
     auto tkey = [&](uint64_t w) -> uint64_t { return PACKED ? (w & 0x1F000000ull) : (w & AAM); };
@@ -469,7 +451,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 if (t0 + 64 * j < e) {
-                    const uint32_t h = ham2(qr.qdna, (uint32_t)v[j] & 0xFFFFFFu);
+                    const uint32_t h = mtb_ham_sum(&qr, (uint32_t)v[j] & 0xFFFFFFu);
                     mn = h < mn ? h : mn;
                     if (h <= 7u) { c3 = c2; c2 = c1; c1 = c0; c0 = ((uint32_t)(t0 + 64 * j - s) << 4) | h; n_c++; }
                 }
@@ -491,11 +473,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
             const uint64_t s0 = lo[u], e = e_hi[u];
             const uint64_t v0 = rdv(s0);
             mtb_qrows qr; mtb_prepare_query_rows(s_hr, k[u].value, &qr);
-            uint32_t mn = ham2(qr.qdna, (uint32_t)v0 & 0xFFFFFFu);
-            for (uint64_t t = s0 + 1; t < e; t++) { const uint32_t h = ham2(qr.qdna, (uint32_t)rdv(t) & 0xFFFFFFu); mn = h < mn ? h : mn; }
+            uint32_t mn = mtb_ham_sum(&qr, (uint32_t)v0 & 0xFFFFFFu);
+            for (uint64_t t = s0 + 1; t < e; t++) { const uint32_t h = mtb_ham_sum(&qr, (uint32_t)rdv(t) & 0xFFFFFFu); mn = h < mn ? h : mn; }
             const uint32_t thr = mtb_ham_threshold(mn);
             uint32_t c = 0;
-            for (uint64_t t = s0; t < e; t++) { const uint64_t v = t == s0 ? v0 : rdv(t); c += ham2(qr.qdna, (uint32_t)v & 0xFFFFFFu) <= thr ? 1u : 0u; }
+            for (uint64_t t = s0; t < e; t++) { const uint64_t v = t == s0 ? v0 : rdv(t); c += mtb_ham_sum(&qr, (uint32_t)v & 0xFFFFFFu) <= thr ? 1u : 0u; }
             rs[u] = s0; re[u] = e; thr_[u] = thr; cnt[u] = c; tot_c += c;
         }
         /* wave-scanned runs: threshold and count now, emission behind the reservation */
@@ -517,7 +499,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
                 } else {
                     for (uint64_t t0 = s0; t0 < e; t0 += 64) {
                         const uint64_t t = t0 + lane;
-                        const bool sel = t < e && ham2(qr.qdna, (uint32_t)rdv(t) & 0xFFFFFFu) <= thr;
+                        const bool sel = t < e && mtb_ham_sum(&qr, (uint32_t)rdv(t) & 0xFFFFFFu) <= thr;
                         c += (uint32_t)__popcll(__ballot(sel));
                     }
                 }
@@ -546,7 +528,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
                 for (uint64_t t0 = s0; t0 < e; t0 += 64) {
                     const uint64_t t = t0 + lane;
                     uint64_t v = 0; uint32_t td = 0, h = 255u;
-                    if (t < e) { v = rdv(t); td = (uint32_t)v & 0xFFFFFFu; h = ham2(qr.qdna, td); }
+                    if (t < e) { v = rdv(t); td = (uint32_t)v & 0xFFFFFFu; h = mtb_ham_sum(&qr, td); }
                     const bool sel = h <= thr;
                     const uint64_t m = __ballot(sel);
                     if (!m) continue;
@@ -571,7 +553,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
             for (uint64_t t = rs[u]; t < re[u]; t++) {
                 const uint64_t v = rdv(t);
                 const uint32_t td = (uint32_t)v & 0xFFFFFFu;
-                const uint32_t h = ham2(qr.qdna, td);
+                const uint32_t h = mtb_ham_sum(&qr, td);
                 if (h > thr_[u]) continue;
                 if (o < sa.ovf_cap) {
                     const int32_t tid = (int32_t)((PACKED ? (uint32_t)(v >> MTB_PACK_LOW) : ix.info[t]) & ix.info_mask);
@@ -659,7 +641,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
             for (uint64_t t0 = s0; t0 < e; t0 += 64) {      /* a lane met more than four possible candidates: second walk, 64 per step */
                 const uint64_t t = t0 + lane;
                 uint64_t v = 0; uint32_t h = 255u;
-                if (t < e) { v = rdv(t); h = ham2(qr.qdna, (uint32_t)v & 0xFFFFFFu); }
+                if (t < e) { v = rdv(t); h = mtb_ham_sum(&qr, (uint32_t)v & 0xFFFFFFu); }
                 const bool sel = h <= thr;
                 const uint64_t m = __ballot(sel);
                 if (!m) continue;
@@ -684,8 +666,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
         uint64_t v0 = rdv(s);
         const uint32_t info0 = PACKED ? 0u : ix.info[s];      /* flat state: issued now, the first candidate is selected more often than not */
         mtb_qrows qr; mtb_prepare_query_rows(s_hr, k[u].value, &qr);
-        uint32_t mn = ham2(qr.qdna, (uint32_t)v0 & 0xFFFFFFu);
-        for (uint64_t t = s + 1; t < e; t++) { const uint32_t h = ham2(qr.qdna, (uint32_t)rdv(t) & 0xFFFFFFu); mn = h < mn ? h : mn; }
+        uint32_t mn = mtb_ham_sum(&qr, (uint32_t)v0 & 0xFFFFFFu);
+        for (uint64_t t = s + 1; t < e; t++) { const uint32_t h = mtb_ham_sum(&qr, (uint32_t)rdv(t) & 0xFFFFFFu); mn = h < mn ? h : mn; }
         const uint32_t thr = mtb_ham_threshold(mn);
         const uint32_t r = mtb_q_seq(k[u].qinfo) - 1;
         const uint32_t ord = mtb_q_pos(k[u].qinfo) >> 16;
@@ -700,7 +682,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
         for (uint64_t t = s; t < e; t++) {
             const uint64_t v = t == s ? v0 : rdv(t);
             const uint32_t td = (uint32_t)v & 0xFFFFFFu;
-            const uint32_t h = ham2(qr.qdna, td);
+            const uint32_t h = mtb_ham_sum(&qr, td);
             if (h > thr) continue;
             const int32_t tid = (int32_t)((PACKED ? (uint32_t)(full_of(t, v) >> MTB_PACK_LOW) : (t == s ? info0 : ix.info[t])) & ix.info_mask);
             const int32_t sp = (tid >= 0 && tid <= ix.max_taxid) ? ix.tax2species[tid] : 0;

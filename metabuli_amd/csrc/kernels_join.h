@@ -82,7 +82,6 @@ struct JoinSegArgs {
     uint32_t dense_ovf; /* host side only (dev_join): 1 = one dense overflow list even where the list would be striped -- the last retry of a batch: which
                          * workgroup emits a match beyond a read's tail depends on the order of the atomics, so the stripes fill differently from
                          * attempt to attempt and a list sized from the failed attempt's fullest stripe can fail again; the dense list needs the total only */
-    const uint8_t *ham2; /* k_join_dir: the codon-pair table of hamming sums (4096 bytes on the device, mtb_ctx::d_ham2; set by dev_join) */
     const uint8_t *off; /* k_join_dir, fixed segments: reads marked here never use their slots -- every match goes to the overflow list and the read's
                          * tail cursor is pushed beyond the tail's capacity, so that the scorers hand the read to the exact-segment path */
 };

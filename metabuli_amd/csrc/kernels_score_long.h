@@ -65,16 +65,21 @@ __device__ __forceinline__ bool lpath_before(const mtb_lpath &a, const mtb_lpath
 
 /* MAXBLK / MAXSP: LDS budgets for the (species, frame) blocks of two or more matches and for the species with paths.  Long reads run the
  * defaults; the short reads of conserved genes whose organism is NOT in the index (thousands of matches over a thousand species, a few
- * of them with paths: kernels_score_many.h, k_many_sort) run <4096, 1024>. */
-template <int MAXBLK = MTB_LONG_MAXBLK, int MAXSP = MTB_LONG_MAXSP>
+ * of them with paths: kernels_score_many.h, k_many_sort) run <2048, 256, 256, 256> (below). */
+/* MAXP / MAXBKT: emitted paths and position buckets (the filter's buckets live in the dead path storage).  The short-read instantiation
+ * <2048, 256, 256, 256> -- a read of <= 4096 records has at most 2048 blocks of two, its paths need four matches in a row (a handful in a read
+ * whose species bring two or three matches each), its position buckets are a few dozen -- takes 27 KB of LDS instead of 70: five workgroups per
+ * CU instead of two for a kernel whose SIMDs issue a VALU instruction on a quarter of their cycles (profiles/r06_heldout_4M_pmc_sq.tsv). */
+template <int MAXBLK = MTB_LONG_MAXBLK, int MAXSP = MTB_LONG_MAXSP, int MAXP = MTB_LONG_MAXP, int MAXBKT = MTB_LONG_MAXBKT>
 __global__ __launch_bounds__(MTB_LONG_NT) void k_score_long(const mtb_match *__restrict__ matches, const uint64_t *__restrict__ seg_start, uint64_t n_reads,
                                                              const int32_t *__restrict__ qlen, const int32_t *__restrict__ qlen2, mtb_tax_view tx, mtb_score_params sp,
                                                              const uint64_t *__restrict__ tc_off, mtb_result *__restrict__ results, int32_t *__restrict__ tc_tax,
                                                              uint32_t *__restrict__ tc_cnt, uint64_t tc_cap, uint64_t tc_base, uint8_t *__restrict__ todo,
                                                              unsigned long long *__restrict__ work, const uint32_t *__restrict__ seg_cnt = nullptr,
                                                              const uint32_t *__restrict__ list = nullptr, uint32_t n_list = 0) {
-    __shared__ __attribute__((aligned(16))) mtb_lpath s_path[MTB_LONG_MAXP];
-    __shared__ uint16_t s_sidx[MTB_LONG_MAXP], s_acc[MTB_LONG_MAXP];
+    static_assert(MAXP * sizeof(mtb_lpath) >= MAXBKT * 8, "the filter's buckets live in the (dead) path storage");
+    __shared__ __attribute__((aligned(16))) mtb_lpath s_path[MAXP];
+    __shared__ uint16_t s_sidx[MAXP], s_acc[MAXP];
     __shared__ uint32_t s_blk[MAXBLK];
     __shared__ int32_t s_carry[MTB_LONG_NW][64][5];
     __shared__ uint16_t s_splo[MAXSP + 1];
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(MTB_LONG_NT) void k_score_long(const mtb_match *__r
             s_R = R;
         }
         if (n < 2) { __syncthreads(); if (tid == 0) results[r] = s_R; continue; }          /* no block of two matches: no path, unclassified */
-        if (nb > MTB_LONG_MAXBKT) { if (tid == 0) todo[r] = 1; continue; }
+        if (nb > MAXBKT) { if (tid == 0) todo[r] = 1; continue; }
 
         MTB_LP_MARK(0);
         /* ---- blocks: heads of the (species, frame) blocks that hold at least two matches, in order ---- */
@@ -179,7 +184,7 @@ __global__ __launch_bounds__(MTB_LONG_NT) void k_score_long(const mtb_match *__r
                     uint32_t q_pos = 0, q_dna = 0, q_reh = 0;
                     auto out_path = [&](uint32_t idx, uint32_t pos, uint32_t reh) {
                         const uint32_t at = atomicAdd(&s_npath, 1u);
-                        if (at < MTB_LONG_MAXP) {
+                        if (at < (uint32_t)MAXP) {
                             mtb_lpath P; P.start = p_start; P.end = (int32_t)pos + 23; P.score = p_score; P.ham = p_ham; P.rehs = (p_sreh & 0xFFFFu) | (reh << 16);
                             P.species = species; P.eidx = idx; P.spare = 0;
                             s_path[at] = P;
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(MTB_LONG_NT) void k_score_long(const mtb_match *__r
                 at0 = (uint32_t)__shfl((int)at0, 0, 64);
                 const uint32_t at = at0 + (uint32_t)__popcll(em & lt);
                 if (e) {
-                    if (at < MTB_LONG_MAXP) {
+                    if (at < (uint32_t)MAXP) {
                         mtb_lpath P; P.start = p_start; P.end = (int32_t)pos + 23; P.score = p_score; P.ham = p_ham; P.rehs = (p_sreh & 0xFFFFu) | (reh << 16);
                         P.species = species; P.eidx = idx; P.spare = 0;
                         s_path[at] = P;
@@ -486,7 +491,7 @@ __global__ __launch_bounds__(MTB_LONG_NT) void k_score_long(const mtb_match *__r
         const int32_t species = s_species;
         MTB_LP_MARK(6);
         /* ---- redundancy filter over the best species' matches; buckets in the (dead) path storage ---- */
-        uint32_t *hmin = (uint32_t *)s_path; int32_t *btax = (int32_t *)(hmin + MTB_LONG_MAXBKT);
+        uint32_t *hmin = (uint32_t *)s_path; int32_t *btax = (int32_t *)(hmin + MAXBKT);
         for (int32_t q = tid; q < nb; q += MTB_LONG_NT) { hmin[q] = 255u; btax[q] = -1; }
         __syncthreads();
         /* (both passes: the records of two steps requested together; the second pass was a quarter of the kernel because nearly every

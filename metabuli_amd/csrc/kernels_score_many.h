@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void k_ovf_group(const mtb_match *__restrict__
  *   pass 3   their 64-bit compareMatches keys (species, frame, position, hamming, dna: host-checked to fit) into the table's storage,
  *            bitonic sort of (key, source index) in LDS;
  *   pass 4   the records in order -> the read's exact segment in HBM (24-byte Match records), seg_cnt = survivors.
- * k_score_long<4096, 1024> (kernels_score_long.h: a workgroup per read streaming its sorted segment) scores them.  Reads beyond the
+ * k_score_long<2048, 256, 256, 256> (kernels_score_long.h: a workgroup per read streaming its sorted segment) scores them.  Reads beyond the
  * budgets here or there are flagged in `todo` and take the exact-segment path. */
 #define MTB_MSORT_NT 256
 #define MTB_MSORT_HASH 4096u

@@ -33,7 +33,7 @@
 #include "mtb_options.h"
 
 #if defined(__HIP_DEVICE_COMPILE__) && defined(__AMDGCN__) && !defined(__gfx950__)
-#error "libmtb is written for gfx950 (MI355X) only: 160 KB of LDS per workgroup (k_score_long<4096, 1024> holds 68 KB), global_load_lds_dwordx4, wave64"
+#error "libmtb is written for gfx950 (MI355X) only: 160 KB of LDS per CU (k_score_long holds 70 KB per workgroup), global_load_lds_dwordx4, wave64"
 #endif
 
 static thread_local std::string g_err;
@@ -93,7 +93,6 @@ struct mtb_ctx {
     hipStream_t stream = nullptr;
     mtb_tables *d_tabs = nullptr;
     mtb_tables h_tabs;
-    uint8_t *d_ham2 = nullptr;       /* hamming sums of codon PAIRS: [query pair << 6 | target pair], 4096 bytes (k_join_dir stages it in LDS) */
     std::map<std::string, DevBuf> bufs;
     std::mutex bufs_mu;              /* the buffer table may be grown from a helper thread (mtb_ctx_reserve) while the context's thread opens an index */
     std::mutex reserve_mu;           /* held by mtb_ctx_reserve for its whole run */
@@ -207,6 +206,7 @@ struct mtb_index {
     int views = 0;                   /* live mtb_index_slice views: they read the parent's flat arrays, so the parent stays flat */
     mtb_index *parent = nullptr;     /* of a view */
     uint64_t open_chunks = 0, open_chunk_words = 0, open_peak_bytes = 0, open_free0 = 0;      /* mtb_index_open_stats */
+    void *ipc_stage[4] = {nullptr, nullptr, nullptr, nullptr};       /* mtb_index_export: copies of the arrays too small for an inter-process handle of their own */
 };
 
 template <typename T>
@@ -374,13 +374,6 @@ mtb_status mtb_ctx_create(int device, void *stream, mtb_ctx **out) {
     mtb_build_tables(&c->h_tabs);
     HIPCHK(hipMalloc((void **)&c->d_tabs, sizeof(mtb_tables)));
     HIPCHK(hipMemcpy(c->d_tabs, &c->h_tabs, sizeof(mtb_tables), hipMemcpyHostToDevice));
-    {   /* pair p = codon a (bits 0-2) and codon b (bits 3-5): hammingLookup[qa][ta] + hammingLookup[qb][tb] */
-        uint8_t h2[4096];
-        for (uint32_t qp = 0; qp < 64; qp++) for (uint32_t tp = 0; tp < 64; tp++)
-            h2[(qp << 6) | tp] = (uint8_t)(((c->h_tabs.hamrow[qp & 7u] >> (4u * (tp & 7u))) & 15u) + ((c->h_tabs.hamrow[qp >> 3] >> (4u * (tp >> 3))) & 15u));
-        HIPCHK(hipMalloc((void **)&c->d_ham2, sizeof(h2)));
-        HIPCHK(hipMemcpy(c->d_ham2, h2, sizeof(h2), hipMemcpyHostToDevice));
-    }
     HIPCHK(hipMalloc((void **)&c->d_scal, 24 * sizeof(uint64_t)));      /* [16..23]: the join's tile statistics */
     c->d_xscal = c->d_scal + 8;
     HIPCHK(hipMalloc((void **)&c->d_ovfctr, MTB_OVF_STRIPES * 64));
@@ -398,7 +391,6 @@ void mtb_ctx_destroy(mtb_ctx *c) {
     e = hipStreamSynchronize(c->stream);
     for (auto &kv : c->bufs) if (kv.second.p) e = hipFree(kv.second.p);
     if (c->d_tabs && !c->is_lane) e = hipFree(c->d_tabs);
-    if (c->d_ham2 && !c->is_lane) e = hipFree(c->d_ham2);
     if (c->d_scal) e = hipFree(c->d_scal);
     if (c->d_ovfctr) e = hipFree(c->d_ovfctr);
     if (c->is_lane && c->stream) e = hipStreamDestroy(c->stream);
@@ -450,7 +442,7 @@ mtb_status mtb_ctx_set_streams(mtb_ctx *c, int n) {
     while ((int)c->lanes.size() > (n == 1 ? 0 : n)) { mtb_ctx_destroy(c->lanes.back()); c->lanes.pop_back(); }
     while (n > 1 && (int)c->lanes.size() < n) {
         mtb_ctx *l = new mtb_ctx();
-        l->device = c->device; l->is_lane = true; l->d_tabs = c->d_tabs; l->d_ham2 = c->d_ham2; l->h_tabs = c->h_tabs; l->profiling = c->profiling; l->placement_probe = c->placement_probe; l->opt = c->opt;
+        l->device = c->device; l->is_lane = true; l->d_tabs = c->d_tabs; l->h_tabs = c->h_tabs; l->profiling = c->profiling; l->placement_probe = c->placement_probe; l->opt = c->opt;
         HIPCHK(hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking));
         HIPCHK(hipMalloc((void **)&l->d_scal, 24 * sizeof(uint64_t)));
         l->d_xscal = l->d_scal + 8;
@@ -745,7 +737,7 @@ static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint6
     if (seg && ix->d_dir) {
         STCHK(use.acquire(ix, true));
         KTimer kt(c, MTB_K_JOIN);
-        JoinSegArgs sa = *seg; sa.ham2 = c->d_ham2; sa.ovf_counter = (unsigned long long *)c->d_scal; sa.coop_min = c->opt.join_coop_min > 0 ? (uint32_t)c->opt.join_coop_min : (uint32_t)MTB_JOIN_COOP_MIN;
+        JoinSegArgs sa = *seg; sa.ovf_counter = (unsigned long long *)c->d_scal; sa.coop_min = c->opt.join_coop_min > 0 ? (uint32_t)c->opt.join_coop_min : (uint32_t)MTB_JOIN_COOP_MIN;
         if (striped) {
             HIPCHK(hipMemsetAsync(c->d_ovfctr, 0, MTB_OVF_STRIPES * 64, c->stream));
             sa.ovf_counter = c->d_ovfctr; sa.ovf_stripes = MTB_OVF_STRIPES; sa.ovf_region = sa.ovf_cap / MTB_OVF_STRIPES;
@@ -1654,10 +1646,20 @@ mtb_status mtb_index_clone(mtb_index *src, mtb_ctx *dst, mtb_index **out) {
 }
 
 /* ---- the resident index handed to other PROCESSES of the node (include/mtb.h: mtb_index_share) ---- */
-static mtb_status ipc_describe(const void *p, uint8_t handle[64], uint64_t *off) {
+/* An allocation below a few MB is carved out of a larger block by the runtime and cannot be opened by another process (dmabuf handles name whole
+ * blocks: hipIpcOpenMemHandle answered "invalid argument" for the 160 KB target array of a toy database): such an array is copied to a 4 MiB
+ * allocation of its own first (`stage`, kept by the index until it is closed or exported again) and that one is handed over. */
+static mtb_status ipc_describe(mtb_ctx *c, const void *p, size_t bytes, void **stage, uint8_t handle[64], uint64_t *off) {
     static_assert(sizeof(hipIpcMemHandle_t) <= 64, "handle record");
     memset(handle, 0, 64); *off = 0;
+    if (*stage) { hipError_t e = hipFree(*stage); (void)e; *stage = nullptr; }
     if (!p) return MTB_OK;
+    if (bytes < (4ull << 20)) {
+        HIPCHK(hipMalloc(stage, 4ull << 20));
+        HIPCHK(hipMemcpyAsync(*stage, p, bytes, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        p = *stage;
+    }
     hipDeviceptr_t base = nullptr; size_t size = 0;
     HIPCHK(hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)p));            /* the handle names the ALLOCATION (a torch tensor may sit inside a larger block) */
     hipIpcMemHandle_t h;
@@ -1674,10 +1676,11 @@ mtb_status mtb_index_export(mtb_index *src, mtb_index_share *out) {
     HIPCHK(hipStreamSynchronize(src->ctx->stream));
     std::unique_lock<std::mutex> lk(src->state_mu);
     src->state_cv.wait(lk, [&] { return src->users == 0; });
-    STCHK(ipc_describe(src->d_values, out->values_handle, &out->values_off));
-    STCHK(ipc_describe(src->d_info, out->info_handle, &out->info_off));
-    STCHK(ipc_describe(src->d_dir, out->dir_handle, &out->dir_off));
-    STCHK(ipc_describe(src->d_dirbase, out->dirbase_handle, &out->dirbase_off));
+    const uint32_t n_groups = (src->dir_buckets >> 16) + 1;
+    STCHK(ipc_describe(src->ctx, src->d_values, src->T * 8, &src->ipc_stage[0], out->values_handle, &out->values_off));
+    STCHK(ipc_describe(src->ctx, src->d_info, src->T * 4, &src->ipc_stage[1], out->info_handle, &out->info_off));
+    STCHK(ipc_describe(src->ctx, src->d_dir, ((size_t)src->dir_buckets + 1) * 4, &src->ipc_stage[2], out->dir_handle, &out->dir_off));
+    STCHK(ipc_describe(src->ctx, src->d_dirbase, ((size_t)n_groups + 2) * 8, &src->ipc_stage[3], out->dirbase_handle, &out->dirbase_off));
     out->n_targets = src->T; out->dir_buckets = src->dir_buckets; out->info_mask = src->info_mask; out->dir_depth = src->dir_L;
     out->packed = src->packed ? 1 : 0; out->has_info = src->d_info ? 1 : 0; out->match_last = src->match_last ? 1 : 0; out->device = src->ctx->device;
     out->exporter_pid = (int64_t)getpid();
@@ -1747,6 +1750,7 @@ mtb_status mtb_index_import(mtb_ctx *c, const mtb_index_share *sh, const char *t
 void mtb_index_close(mtb_index *ix) {
     if (!ix) return;
     hipError_t e = hipSuccess;
+    for (int k = 0; k < 4; k++) if (ix->ipc_stage[k]) { e = hipFree(ix->ipc_stage[k]); ix->ipc_stage[k] = nullptr; }
     if (ix->parent) {                /* a view: the parent may be packed again once the last view is gone */
         { std::lock_guard<std::mutex> lk(ix->parent->state_mu); ix->parent->views--; }
         if (ix->d_dir) e = hipFree(ix->d_dir);
@@ -2237,7 +2241,7 @@ static mtb_status score_fixed_slots(mtb_ctx *c, mtb_index *ix, const mtb_params 
                 HIPCHK(hipMemsetAsync(d_todo, 0, n_reads, st));
                 hipLaunchKernelGGL(k_many_sort, dim3(std::min<uint32_t>(n_big, 256u * 4u)), dim3(MTB_MSORT_NT), 0, st, (const mtb_slot16 *)d_segm, stride, direct, epoch, (const uint32_t *)d_rc, d_off_reads,
                                    (const mtb_match *)d_ovfg, (const uint64_t *)d_ostart, (const uint32_t *)d_rest, n_big, SL.d_qlen, SL.d_qlen2, SL.sp.dna_shift, (const uint64_t *)d_bs3, d_big3, d_segcnt, d_todo);
-                hipLaunchKernelGGL((k_score_long<4096, 1024>), dim3(std::min<uint32_t>(n_big, 256u * 2u)), dim3(MTB_LONG_NT), 0, st, (const mtb_match *)d_big3, (const uint64_t *)d_bs3, n_reads, SL.d_qlen, SL.d_qlen2,
+                hipLaunchKernelGGL((k_score_long<2048, 256, 256, 256>), dim3(std::min<uint32_t>(n_big, 256u * 5u)), dim3(MTB_LONG_NT), 0, st, (const mtb_match *)d_big3, (const uint64_t *)d_bs3, n_reads, SL.d_qlen, SL.d_qlen2,
                                    tax_view(ix), SL.sp, SL.d_tcoff, SL.d_res, SL.d_tc_tax, SL.d_tc_cnt, SL.tc_cap, SL.tc_base, d_todo, d_ms + 8, (const uint32_t *)d_segcnt, (const uint32_t *)d_rest, n_big);
                 hipLaunchKernelGGL(k_list_flagged, dim3((n_big + 255) / 256), dim3(256), 0, st, (const uint32_t *)d_rest, n_big, (const uint8_t *)d_todo, (const uint32_t *)d_bc3, d_rest2, (uint32_t *)(d_ms + 9), d_cnt);
                 HIPCHK(hipGetLastError());

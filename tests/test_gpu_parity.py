@@ -889,7 +889,7 @@ def test_many_matches_per_query_take_the_large_segment_path(ctx, orc, tmp_path):
         assert (tt == ref["tc_tax"]).all() and (tc == ref["tc_cnt"]).all()
     assert (res["is_classified"] != 0).sum() > 60
     # round 5: such reads (a thousand matches, all of species with pairs of matches) are gathered, sorted in LDS by a workgroup each and
-    # scored by the streaming kernel (k_many_sort + k_score_long<4096, 1024>), not by the HBM-resident sort any more
+    # scored by the streaming kernel (k_many_sort + k_score_long<2048, 256, 256, 256>), not by the HBM-resident sort any more
     st = ctx.last_stats()
     assert st.n_deferred_reads > 30 and st.n_many_reads > 30, (st.n_deferred_reads, st.n_many_reads)
     assert st.n_matches == len(ref["matches"])
@@ -937,7 +937,7 @@ def test_long_candidate_runs_are_scanned_by_the_wave(orc, tmp_path, seq_mode, de
 @pytest.mark.parametrize("shape", ["more species than the wave's table", "more survivors than the workgroup sorts"])
 def test_deferred_reads_beyond_a_tier_fall_to_the_next(orc, tmp_path, shape):
     """The three tiers of the reads the slot scorers defer (kernels_score_many.h): `k_score_many` (a wave: <= 768 species, <= 192 survivors),
-    `k_many_sort` + `k_score_long<4096, 1024>` (a workgroup: <= 3072 species, <= 4096 survivors), exact segments sorted in HBM (anything).
+    `k_many_sort` + `k_score_long<2048, 256, 256, 256>` (a workgroup: <= 3072 species, <= 4096 survivors), exact segments sorted in HBM (anything).
     (a) a conserved protein filed sparsely under 2600 species: a read meets more species than the wave's table holds and is handed to the
     workgroup kernel; (b) filed under 680 species in full: a read brings more than 4096 matches that all survive the dead-species drop and
     goes on to the exact-segment path.  Results = the oracle's either way; the statistics say which way the reads went."""
