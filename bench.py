@@ -861,7 +861,8 @@ def main(device=None):
     ap.add_argument("--reads-from", default="index", choices=["index", "heldout"],
                     help="heldout: the timed batch's reads come from the held-out genomes (species of indexed genera that are NOT in the index) -- the novel leg's workload as the "
                          "main one, for profiler runs")
-    ap.add_argument("--no-handover", action="store_true", help="N > 1: every rank synthesises its own replica of the index (default: rank 0 builds it once and the other ranks import it)")
+    ap.add_argument("--handover", action="store_true", help="N > 1: rank 0 builds the index once and the other ranks import it through inter-process handles (mtb_index_export / mtb_index_import); "
+                                                             "default: every rank synthesises its own replica -- opening another process's handle failed or hung on some boxes of the test pool (profiles/r06_notes.md)")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--dist-backend", default="nccl", help="testing only: gloo lets several ranks share one GPU (RCCL refuses duplicate devices)")
     ap.add_argument("--shared-gpu", action="store_true", help="testing only: every rank uses cuda:0")
@@ -904,10 +905,10 @@ def main(device=None):
         build_world(args.seed, args.species, args.genome_len, args.filler_species)
     taxdir = tempfile.mkdtemp(prefix="mtb_tax_")
     world.tax.write(taxdir)
-    # N > 1, index replicated: rank 0 builds the index once and hands it to the other ranks' GPUs (mtb_index_export / mtb_index_import:
+    # N > 1, index replicated, --handover: rank 0 builds the index once and hands it to the other ranks' GPUs (mtb_index_export / mtb_index_import:
     # inter-process handles, device-to-device copies over xGMI -- SURVEY 8(e) row 1 "load once, broadcast"); a rank whose import fails
     # builds its own replica as every rank did before (the result is the same index either way: same seed)
-    handover = dist is not None and world_size > 1 and not args.partitioned and not args.no_handover
+    handover = dist is not None and world_size > 1 and not args.partitioned and args.handover
     index = None; d_values = d_info = None; sealed = False
     handed = dict(mode="local")
     if handover and rank != 0:

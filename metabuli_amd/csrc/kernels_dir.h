@@ -170,8 +170,12 @@ __global__ __launch_bounds__(256) void k_index_unpack(uint64_t *__restrict__ val
     }
 }
 
-#ifdef MTB_NO_NT_STORES          /* experiment build: plain stores */
+#if defined(MTB_NO_NT_STORES)    /* experiment builds (timing only; profiles/r06_notes.md section 5): plain stores; */
 #define MTB_SLOT_STORE(sl, p) do { *(p) = (sl); } while (0)
+#elif defined(MTB_NO_SLOT_STORES)        /* ... no slot stores at all (everything that feeds them still computed: the epoch never has that value); */
+#define MTB_SLOT_STORE(sl, p) do { if (sa.epoch == 0xFFFFFFFFu) { __builtin_nontemporal_store((sl).a, &(p)->a); __builtin_nontemporal_store((sl).b, &(p)->b); } } while (0)
+#elif defined(MTB_HALF_SLOT_STORES)      /* ... only 8 of a slot's 16 bytes (what an 8-byte slot record would write) */
+#define MTB_SLOT_STORE(sl, p) do { __builtin_nontemporal_store((sl).b, &(p)->b); if (sa.epoch == 0xFFFFFFFFu) __builtin_nontemporal_store((sl).a, &(p)->a); } while (0)
 #else
 #define MTB_SLOT_STORE(sl, p) do { __builtin_nontemporal_store((sl).a, &(p)->a); __builtin_nontemporal_store((sl).b, &(p)->b); } while (0)
 #endif

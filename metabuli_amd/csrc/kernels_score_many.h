@@ -80,32 +80,38 @@ __global__ __launch_bounds__(256) void k_ovf_group(const mtb_match *__restrict__
  * k_score_long<2048, 256, 256, 256> (kernels_score_long.h: a workgroup per read streaming its sorted segment) scores them.  Reads beyond the
  * budgets here or there are flagged in `todo` and take the exact-segment path. */
 #define MTB_MSORT_NT 256
-#define MTB_MSORT_HASH 4096u
-#define MTB_MSORT_MAX 4096u              /* survivors sorted in LDS */
+/* Two instantiations (round 6): <11, 2048> first -- 2048 table entries, 2048 survivors: 20 KB of LDS, eight workgroups per CU; the typical read
+ * of this tier carries ~1100 records -- and <12, 4096> (40 KB, three per CU) for the reads the first one flags 2 (table beyond 3/4, survivors beyond its
+ * budget); flag 1 = a read neither can take (exact-segment path).  `only_flag` != 0: only the listed reads whose flag equals it are taken (and the
+ * flag is cleared first). */
+template <int LOG2HASH, uint32_t MAXN>
 __global__ __launch_bounds__(MTB_MSORT_NT) void k_many_sort(const mtb_slot16 *__restrict__ slots_all, uint32_t stride, uint32_t direct, uint32_t epoch,
                                                              const uint32_t *__restrict__ cursor, const uint8_t *__restrict__ off_reads,
                                                              const mtb_match *__restrict__ ovfg, const uint64_t *__restrict__ ovf_start,
                                                              const uint32_t *__restrict__ list, uint32_t n_list, const int32_t *__restrict__ qlen, const int32_t *__restrict__ qlen2,
                                                              int32_t dna_shift, const uint64_t *__restrict__ big_start, mtb_match *__restrict__ big, uint32_t *__restrict__ seg_cnt,
-                                                             uint8_t *__restrict__ todo) {
-    __shared__ __attribute__((aligned(16))) uint64_t s_u[MTB_MSORT_HASH];          /* the species table (keys | values), then the sort keys */
-    __shared__ uint16_t s_idx[MTB_MSORT_MAX];
+                                                             uint8_t *__restrict__ todo, uint32_t only_flag, uint32_t beyond_flag /* what a read beyond THIS instantiation's budgets is flagged */) {
+    constexpr uint32_t HASH = 1u << LOG2HASH;
+    __shared__ __attribute__((aligned(16))) uint64_t s_u[HASH];          /* the species table (keys | values), then the sort keys */
+    __shared__ uint16_t s_idx[MAXN];
     __shared__ uint32_t s_n, s_full;
-    static_assert(MTB_MSORT_MAX * 8 <= MTB_MSORT_HASH * 8, "the sort keys live in the table's storage");
-    uint32_t *const h_key = (uint32_t *)s_u, *const h_val = h_key + MTB_MSORT_HASH;
+    static_assert(MAXN * 8 <= HASH * 8, "the sort keys live in the table's storage");
+    uint32_t *const h_key = (uint32_t *)s_u, *const h_val = h_key + HASH;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint64_t lt = lanemask_lt();
     const uint32_t tail_cap = stride - direct;
     for (uint32_t b = blockIdx.x; b < n_list; b += gridDim.x) {
         const uint64_t r = (uint64_t)list[b];
+        if (only_flag && todo[r] != only_flag) continue;          /* (uniform over the workgroup) */
         const uint32_t cur = cursor[r], tail_n = cur < tail_cap ? cur : tail_cap;
         uint64_t o0 = 0; uint32_t n_ov = 0;
         if (ovf_start) { o0 = ovf_start[r]; n_ov = (uint32_t)(ovf_start[r + 1] - o0); }
         const int32_t nb = mtb_num_buckets(qlen[r] + qlen2[r], dna_shift);
-        const bool skip = (off_reads && off_reads[r]) || cur - tail_n != n_ov || stride + n_ov > 65535u || nb > MTB_LONG_MAXBKT;
+        const bool skip = (off_reads && off_reads[r]) || cur - tail_n != n_ov || stride + n_ov > 65535u || nb > 256;      /* (256: the position buckets of the scorer that follows, k_score_long<.., 256>) */
         __syncthreads();                                  /* the previous read is through with the LDS arrays */
+        if (only_flag && tid == 0) todo[r] = 0;
         if (skip) { if (tid == 0) { seg_cnt[b] = 0; todo[r] = 1; } continue; }
-        for (uint32_t q = tid; q < MTB_MSORT_HASH; q += MTB_MSORT_NT) { h_key[q] = 0xFFFFFFFFu; h_val[q] = 0u; }
+        for (uint32_t q = tid; q < HASH; q += MTB_MSORT_NT) { h_key[q] = 0xFFFFFFFFu; h_val[q] = 0u; }
         if (tid == 0) { s_n = 0; s_full = 0; }
         __syncthreads();
         const mtb_slot16 *slots = slots_all + r * (uint64_t)stride;
@@ -119,22 +125,22 @@ __global__ __launch_bounds__(MTB_MSORT_NT) void k_many_sort(const mtb_slot16 *__
             uint32_t s_, f_;
             if (!probe(i, &s_, &f_)) continue;
             if (*(volatile uint32_t *)&s_full) break;                     /* the table has filled up: the read is handed on, nobody keeps probing */
-            uint32_t h = (s_ * 0x9E3779B1u) >> 20; bool done = false;
-            for (uint32_t p = 0; p < MTB_MSORT_HASH && !done; p++) {
+            uint32_t h = (s_ * 0x9E3779B1u) >> (32 - LOG2HASH); bool done = false;
+            for (uint32_t p = 0; p < HASH && !done; p++) {
                 const uint32_t old = atomicCAS(&h_key[h], 0xFFFFFFFFu, s_);
                 if (old == 0xFFFFFFFFu || old == s_) { const uint32_t bit = 1u << f_; if (atomicOr(&h_val[h], bit) & bit) atomicOr(&h_val[h], bit << 8); done = true; }
-                h = (h + 1u) & (MTB_MSORT_HASH - 1u);
+                h = (h + 1u) & (HASH - 1u);
             }
             if (!done) s_full = 1;
         }
         __syncthreads();
         uint32_t used = 0;
-        for (uint32_t q = tid; q < MTB_MSORT_HASH; q += MTB_MSORT_NT) used += h_key[q] != 0xFFFFFFFFu ? 1u : 0u;
+        for (uint32_t q = tid; q < HASH; q += MTB_MSORT_NT) used += h_key[q] != 0xFFFFFFFFu ? 1u : 0u;
         if (used) atomicAdd(&s_n, used);
         __syncthreads();
-        const bool over = s_full || s_n > MTB_MSORT_HASH / 4u * 3u;
+        const bool over = s_full || s_n > HASH / 4u * 3u;
         __syncthreads();
-        if (over) { if (tid == 0) { seg_cnt[b] = 0; todo[r] = 1; } continue; }
+        if (over) { if (tid == 0) { seg_cnt[b] = 0; todo[r] = (uint8_t)beyond_flag; } continue; }
         if (tid == 0) s_n = 0;
         __syncthreads();
         /* pass 2: survivors' source indices (whole wave steps: one LDS atomic per step) */
@@ -144,8 +150,8 @@ __global__ __launch_bounds__(MTB_MSORT_NT) void k_many_sort(const mtb_slot16 *__
             if (i < n_src) {
                 uint32_t s_, f_;
                 if (probe(i, &s_, &f_)) {
-                    uint32_t h = (s_ * 0x9E3779B1u) >> 20;
-                    for (uint32_t p = 0; p < MTB_MSORT_HASH; p++) { const uint32_t k = h_key[h]; if (k == s_) { keep = (h_val[h] >> 8) != 0u; break; } if (k == 0xFFFFFFFFu) break; h = (h + 1u) & (MTB_MSORT_HASH - 1u); }
+                    uint32_t h = (s_ * 0x9E3779B1u) >> (32 - LOG2HASH);
+                    for (uint32_t p = 0; p < HASH; p++) { const uint32_t k = h_key[h]; if (k == s_) { keep = (h_val[h] >> 8) != 0u; break; } if (k == 0xFFFFFFFFu) break; h = (h + 1u) & (HASH - 1u); }
                 }
             }
             const uint64_t km = __ballot(keep);
@@ -153,13 +159,13 @@ __global__ __launch_bounds__(MTB_MSORT_NT) void k_many_sort(const mtb_slot16 *__
                 uint32_t at0 = 0;
                 if (lane == 0) at0 = atomicAdd(&s_n, (uint32_t)__popcll(km));
                 at0 = (uint32_t)__shfl((int)at0, 0, 64);
-                if (keep) { const uint32_t at = at0 + (uint32_t)__popcll(km & lt); if (at < MTB_MSORT_MAX) s_idx[at] = (uint16_t)i; }
+                if (keep) { const uint32_t at = at0 + (uint32_t)__popcll(km & lt); if (at < MAXN) s_idx[at] = (uint16_t)i; }
             }
         }
         __syncthreads();
         const uint32_t n = s_n;
         __syncthreads();
-        if (n > MTB_MSORT_MAX) { if (tid == 0) { seg_cnt[b] = 0; todo[r] = 1; } continue; }
+        if (n > MAXN) { if (tid == 0) { seg_cnt[b] = 0; todo[r] = (uint8_t)beyond_flag; } continue; }
         /* pass 3: keys (the table is dead) */
         auto fetch = [&](uint32_t i) -> mtb_match {
             if (i < stride) return mtb_slot_unpack(slots[i], (uint32_t)r + 1);

@@ -86,6 +86,9 @@ __global__ __launch_bounds__(64) void k_unpack_reads(const uint8_t *__restrict__
 }
 
 struct DevBuf { void *p = nullptr; size_t cap = 0; };
+/* the slab pool of the generic scorer's large-segment launches (reads beyond every LDS budget: 2 of 200 k long reads on the bench's index).  Round 6: 16 GiB
+ * instead of 48 -- the 32 GiB went to the long-read sub-batches (200 k x 10 kb: two of 100 k reads instead of four of 50 k; denser sorted queries) */
+#define MTB_SLAB_POOL_MAX (16ull << 30)
 #define MTB_OVF_STRIPES 256u
 
 struct mtb_ctx {
@@ -999,7 +1002,7 @@ static mtb_status dev_score(mtb_ctx *c, mtb_index *ix, const mtb_params *p, uint
         const bool dynamic = need_slab && !S->cursor;       /* slab launches claim reads from a counter: the grid is what is resident */
         if (dynamic) grid = std::min<uint32_t>(grid, 256u * 14u);
         if (slab_bytes) {
-            while ((uint64_t)grid * slab_bytes > (48ull << 30) && grid > 64) grid /= 2;     /* keep the slab pool below 48 GiB (a halved grid halves the waves that hide the slab's HBM latency) */
+            while ((uint64_t)grid * slab_bytes > (MTB_SLAB_POOL_MAX) && grid > 64) grid /= 2;     /* keep the slab pool bounded (a halved grid halves the waves that hide the slab's HBM latency) */
             STCHK(ensure(c, "slabs", (size_t)grid * slab_bytes, &d_slabs));
         }
         unsigned long long *d_work = nullptr;
@@ -2239,8 +2242,11 @@ static mtb_status score_fixed_slots(mtb_ctx *c, mtb_index *ix, const mtb_params 
                 STCHK(d2h(c, &total3, d_bs3 + n_big, 8));
                 STCHK(ensure(c, "bigm", total3 + 1, &d_big3));
                 HIPCHK(hipMemsetAsync(d_todo, 0, n_reads, st));
-                hipLaunchKernelGGL(k_many_sort, dim3(std::min<uint32_t>(n_big, 256u * 4u)), dim3(MTB_MSORT_NT), 0, st, (const mtb_slot16 *)d_segm, stride, direct, epoch, (const uint32_t *)d_rc, d_off_reads,
-                                   (const mtb_match *)d_ovfg, (const uint64_t *)d_ostart, (const uint32_t *)d_rest, n_big, SL.d_qlen, SL.d_qlen2, SL.sp.dna_shift, (const uint64_t *)d_bs3, d_big3, d_segcnt, d_todo);
+                /* the small instantiation first (20 KB of LDS: eight workgroups per CU), the big one for the reads it flags 2 */
+                hipLaunchKernelGGL((k_many_sort<11, 2048u>), dim3(std::min<uint32_t>(n_big, 256u * 8u)), dim3(MTB_MSORT_NT), 0, st, (const mtb_slot16 *)d_segm, stride, direct, epoch, (const uint32_t *)d_rc, d_off_reads,
+                                   (const mtb_match *)d_ovfg, (const uint64_t *)d_ostart, (const uint32_t *)d_rest, n_big, SL.d_qlen, SL.d_qlen2, SL.sp.dna_shift, (const uint64_t *)d_bs3, d_big3, d_segcnt, d_todo, 0u, 2u);
+                hipLaunchKernelGGL((k_many_sort<12, 4096u>), dim3(std::min<uint32_t>(n_big, 256u * 3u)), dim3(MTB_MSORT_NT), 0, st, (const mtb_slot16 *)d_segm, stride, direct, epoch, (const uint32_t *)d_rc, d_off_reads,
+                                   (const mtb_match *)d_ovfg, (const uint64_t *)d_ostart, (const uint32_t *)d_rest, n_big, SL.d_qlen, SL.d_qlen2, SL.sp.dna_shift, (const uint64_t *)d_bs3, d_big3, d_segcnt, d_todo, 2u, 1u);
                 hipLaunchKernelGGL((k_score_long<2048, 256, 256, 256>), dim3(std::min<uint32_t>(n_big, 256u * 5u)), dim3(MTB_LONG_NT), 0, st, (const mtb_match *)d_big3, (const uint64_t *)d_bs3, n_reads, SL.d_qlen, SL.d_qlen2,
                                    tax_view(ix), SL.sp, SL.d_tcoff, SL.d_res, SL.d_tc_tax, SL.d_tc_cnt, SL.tc_cap, SL.tc_base, d_todo, d_ms + 8, (const uint32_t *)d_segcnt, (const uint32_t *)d_rest, n_big);
                 hipLaunchKernelGGL(k_list_flagged, dim3((n_big + 255) / 256), dim3(256), 0, st, (const uint32_t *)d_rest, n_big, (const uint8_t *)d_todo, (const uint32_t *)d_bc3, d_rest2, (uint32_t *)(d_ms + 9), d_cnt);
@@ -2594,7 +2600,7 @@ static mtb_status classify_budgeted(mtb_ctx *c, mtb_index *ix, const mtb_params 
     const size_t held = held_bytes(c);
     uint64_t budget = c->ws_limit ? c->ws_limit : (uint64_t)fr + held;
     if (!c->ws_limit) budget -= std::min<uint64_t>(budget / 16, 4ull << 30);          /* allocator granularity, kernel scratch, other users of the device */
-    if (p->seq_mode == 3 && !c->ws_limit) budget -= std::min<uint64_t>(budget / 3, 48ull << 30);     /* the slab pool of the large-segment scorer does not scale with the batch */
+    if (p->seq_mode == 3 && !c->ws_limit) budget -= std::min<uint64_t>(budget / 4, MTB_SLAB_POOL_MAX);     /* the slab pool of the large-segment scorer does not scale with the batch */
     const double mean_len = (double)n_bases_total / (double)n_reads;
     double per_base = c->ws_per_base;
     if (per_base <= 0.0) {
