@@ -992,9 +992,12 @@ def test_queries_that_share_a_long_run_walk_it_in_lockstep(orc, tmp_path, seq_mo
     monkeypatch.delenv("MTB_DIR_DEPTH", raising=False)
     ro = t.ref["results"]
     amb = ro["flag"] != 0
-    for win in (("1", "0") if seq_mode == 1 else ("0",)):
-        c.set_option("MTB_JOIN_WIN", win)
+    for win in ("1", "0"):           # (long reads, round 6: the window form exists for their slot ranges too -- k_join_dir<true, 1, 1, 8, true>)
+        c.set_option("MTB_JOIN_WIN", win); c.set_option("MTB_JOIN_WIN_QT", "48" if win == "1" else None)
         res, tt, tc = c.classify_batch(ix, p, t.b1, t.o1, t.b2, t.o2)
+        st = c.last_stats()
+        if win == "1" and ix.state()["packed"]:
+            assert M.JOIN_VARIANTS[st.join_variant] == "window" and st.join_tiles_windowed > 0 and st.join_tiles_outside == 0, (seq_mode, st.join_variant, st.join_tiles_windowed)
         assert ((res["classification"] == ro["classification"]) | amb).all(), win
         assert ((res["score"].view(np.uint32) == ro["score"].view(np.uint32)) | amb).all(), win
         assert ((res["n_taxcnt"] == ro["n_taxcnt"]) | amb).all(), win
