@@ -89,9 +89,7 @@ struct DevBuf { void *p = nullptr; size_t cap = 0; };
 /* the slab pool of the generic scorer's large-segment launches (reads beyond every LDS budget: 2 of 200 k long reads on the bench's index).  Round 6: 16 GiB
  * instead of 48 -- the 32 GiB went to the long-read sub-batches (200 k x 10 kb: two of 100 k reads instead of four of 50 k; denser sorted queries) */
 #define MTB_SLAB_POOL_MAX (16ull << 30)
-#ifndef MTB_LONG_WIN_MIN_QT
-#define MTB_LONG_WIN_MIN_QT 257       /* long reads: queries per window tile from which the window form is taken without being asked for (257 = never; see r06_notes) */
-#endif
+#define MTB_LONG_WIN_MAX_PER_Q 24.0   /* long reads: targets per query metamer up to which the window form is taken without being asked for */
 #define MTB_OVF_STRIPES 256u
 
 struct mtb_ctx {
@@ -757,14 +755,14 @@ static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint6
         if (sa.rb) {        /* long reads: per-read slot ranges */
             if (state_owner(ix)->packed) {
                 /* one query per thread at 6 waves per SIMD here too (43.2 -> 41.5 ms per 50 k x 10 kb; MTB_JOIN_VARIANT=q2w5: round 4's instantiation, A/B) */
-                /* the window form for long reads (round 6): the same tiles and windows; only where the (sub-)batch is dense enough -- long-read sub-batches
-                 * are sparser than short-read batches (100 k x 10 kb = 0.86 G metamers against 16 G targets: 18.6 targets per query, 175 queries per tile) */
+                /* the window form for long reads (round 6): the same tiles and windows, where the (sub-)batch is dense enough (100 k x 10 kb = 0.86 G metamers
+                 * against 16 G targets: 18.6 targets per query) */
                 const double per_q = (double)ix->T / (double)std::max<uint64_t>(n, 1);
-                uint32_t qt = (uint32_t)std::min<double>(256.0, 0.82 * MTB_JOIN_WINCAP / std::max(per_q, 1.0));
+                uint32_t qt = 256;                   /* full tiles: measured at 18.6 targets per query (200 k x 10 kb in two sub-batches): 256 queries per tile 124.3 ms, 175 (the density rule
+                                                      * of the short reads) 127.0, 128: 143.5, sector-random q1w6 146.3 -- tiles beyond the capacity read global memory at eight waves per SIMD */
                 if (c->opt.join_win_qt > 0) qt = (uint32_t)std::min(256, c->opt.join_win_qt);
-                qt = std::max<uint32_t>(qt, 1);
                 const bool sorted_ok = ix->params.kmer_format == 2 ? sort_low_bits == 34 : (sort_low_bits >= 24 && sort_low_bits <= 32);
-                const bool lwin = sorted_ok && (c->opt.join_variant == 0x100 || c->opt.join_win == 1 || (c->opt.join_variant == 0 && c->opt.join_win < 0 && qt >= MTB_LONG_WIN_MIN_QT));
+                const bool lwin = sorted_ok && (c->opt.join_variant == 0x100 || c->opt.join_win == 1 || (c->opt.join_variant == 0 && c->opt.join_win < 0 && per_q <= MTB_LONG_WIN_MAX_PER_Q));
                 if (lwin) {
                     const uint32_t n_tiles = (uint32_t)((n + qt - 1) / qt);
                     mtb_tile_win *d_tw;
