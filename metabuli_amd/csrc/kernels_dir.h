@@ -457,12 +457,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
                 if (t0 + 64 * j < e) {
                     const uint32_t h = mtb_ham_sum(&qr, (uint32_t)v[j] & 0xFFFFFFu);
                     mn = h < mn ? h : mn;
-#ifdef MTB_SCAN_LOOSE             /* A/B build: round 5's filter */
-                    if (h <= 7u)
-#else
-                    if (h <= 7u && h <= 2u * mn)         /* (mn = the lane's minimum so far >= the run's: a candidate beyond twice it is beyond the threshold) */
-#endif
-                    { c3 = c2; c2 = c1; c1 = c0; c0 = ((uint32_t)(t0 + 64 * j - s) << 4) | h; n_c++; }
+                    /* (also asking for h <= 2 x the lane's minimum so far -- a necessary condition -- changed nothing: headline join 64.3 - 70.2 vs 62.5 - 65.8 ms,
+                     * 10 M held-out reads 202.8 vs 201.6, alternating processes; profiles/r06_notes.md) */
+                    if (h <= 7u) { c3 = c2; c2 = c1; c1 = c0; c0 = ((uint32_t)(t0 + 64 * j - s) << 4) | h; n_c++; }
                 }
             }
         }

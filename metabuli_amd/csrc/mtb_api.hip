@@ -792,8 +792,12 @@ static mtb_status dev_join(mtb_ctx *c, mtb_index *ix, const mtb_kmer *d_q, uint6
              * MTB_JOIN_VARIANT / MTB_JOIN_WIN in the environment of mtb_ctx_create); the choice and the tuner's timings are reported in
              * mtb_batch_stats (join_variant, join_tuned, join_tune_ms). */
             const double per_q = (double)ix->T / (double)std::max<uint64_t>(n, 1);
-            uint32_t qt = (uint32_t)std::min<double>(256.0, 0.82 * MTB_JOIN_WINCAP / std::max(per_q, 1.0));
-            const bool win_ok = qt >= 240;
+            /* FULL tiles (256 queries) whatever the density: a tile whose span exceeds the window reads global memory at eight waves per SIMD, which beat smaller
+             * tiles with idle lanes everywhere it was measured (2 M pairs, 31 targets per query: 256 per tile 32.4 ms, 105 per tile 38.5, q1w6 37.0; long reads:
+             * 124.3 vs 127.0 at 175).  Beyond ~48 targets per query hardly a tile has a window (2 M held-out reads, 62 per query: 48.6 vs 47.1 for q1w6): the
+             * window form is not a candidate there */
+            uint32_t qt = 256;
+            const bool win_ok = per_q <= 48.0;
             if (c->opt.join_win_qt > 0) qt = (uint32_t)std::min(256, c->opt.join_win_qt);
             qt = std::max<uint32_t>(qt, 1);
             int choice = -1;                                 /* 0: q1w6, 1: q2w5, 2: window, 3 / 4: the A/B-only instantiations q1w5 / q2w6 */
