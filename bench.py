@@ -1106,7 +1106,7 @@ def main(device=None):
         names = ["tail overflow / buckets", "> 24 species rounds (pairs: runs) or > staging", "S1 not sorted", "S2 group of 2", "S3 > 64 paths", "handled"]
         tot = max(1, sum(fr[:6]))
         log("[rank 0] k_score_fast exits (all batches so far): " + ", ".join(f"{n} {fr[i]} ({100.0 * fr[i] / tot:.2f} %)" for i, n in enumerate(names)))
-    wl_key = ("diversity" if big_world else "default") + ("" if args.seq_mode == 1 else f"_mode{args.seq_mode}")
+    wl_key = ("diversity" if big_world else "default") + ("" if args.seq_mode == 1 else f"_mode{args.seq_mode}") + ("_heldout" if args.reads_from == "heldout" else "")
     ps, kern, roofline, roofline_all, footprint, query_runs = profiled_step(ctx, M, index, params, step, args.streams, wl_key,
                                                                            (args.reads, args.read_len, int(T), args.seq_mode))
 

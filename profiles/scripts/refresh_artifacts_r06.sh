@@ -40,7 +40,7 @@ timeout 600 python bench.py --seq-mode 2 --reads 12500000 --steps 3 --warmup 1 -
 cp bench_detail.json $O/${TAG}_bench_paired_detail.json 2>/dev/null
 # 6. reads of held-out genomes as the main workload: bench + kernel stats
 ( cd /tmp && timeout 500 rocprofv3 --kernel-trace --stats -d $S/prof_ho -o ks -- python $R/bench.py --reads-from heldout --steps 3 --warmup 1 --no-legs --no-cpu --cpu-reads 100000 > $O/${TAG}_bench_heldout.json 2> $O/${TAG}_bench_heldout.log )
-grep "stage ms\|parity" $O/${TAG}_bench_heldout.log | cut -c1-250; cp bench_detail.json $O/${TAG}_bench_heldout_detail.json 2>/dev/null
+grep "stage ms\|parity" $O/${TAG}_bench_heldout.log | cut -c1-250; cp /tmp/bench_detail.json $O/${TAG}_bench_heldout_detail.json 2>/dev/null      # (that run's working directory was /tmp)
 python profiles/scripts/rocpd_summary.py $(find $S/prof_ho -name "*.db" | head -1) > $O/${TAG}_heldout_10M_rocprofv3_kernel_stats.txt 2>&1; head -14 $O/${TAG}_heldout_10M_rocprofv3_kernel_stats.txt | cut -c1-150
 rm -rf $S
 du -sh $O
