@@ -76,7 +76,8 @@ __global__ __launch_bounds__(MTB_LONG_NT) void k_score_long(const mtb_match *__r
                                                              const uint64_t *__restrict__ tc_off, mtb_result *__restrict__ results, int32_t *__restrict__ tc_tax,
                                                              uint32_t *__restrict__ tc_cnt, uint64_t tc_cap, uint64_t tc_base, uint8_t *__restrict__ todo,
                                                              unsigned long long *__restrict__ work, const uint32_t *__restrict__ seg_cnt = nullptr,
-                                                             const uint32_t *__restrict__ list = nullptr, uint32_t n_list = 0) {
+                                                             const uint32_t *__restrict__ list = nullptr, uint32_t n_list = 0,
+                                                             uint32_t only_flag = 0 /* != 0: only the reads whose todo[] equals it (the flag is cleared first): the second launch, with larger budgets */) {
     static_assert(MAXP * sizeof(mtb_lpath) >= MAXBKT * 8, "the filter's buckets live in the (dead) path storage");
     __shared__ __attribute__((aligned(16))) mtb_lpath s_path[MAXP];
     __shared__ uint16_t s_sidx[MAXP], s_acc[MAXP];
@@ -105,6 +106,11 @@ __global__ __launch_bounds__(MTB_LONG_NT) void k_score_long(const mtb_match *__r
         const uint64_t it = s_r;
         if (it >= (list ? (uint64_t)n_list : n_reads)) break;
         const uint64_t r = list ? (uint64_t)list[it] : it;           /* optional: only the listed reads, their segments indexed by the list slot */
+        if (only_flag) {
+            if (todo[r] != only_flag) continue;                      /* (every thread reads the flag before thread 0 clears it behind the barrier) */
+            __syncthreads();
+            if (tid == 0) todo[r] = 0;
+        }
         const uint64_t s0 = seg_start[it];
         const int32_t n = seg_cnt ? (int32_t)seg_cnt[it] : (int32_t)(seg_start[it + 1] - s0);      /* (ordered slot segments: the read's records fill the front of its slot range) */
         const mtb_match *m = matches + s0;

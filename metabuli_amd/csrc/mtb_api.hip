@@ -1107,9 +1107,20 @@ static mtb_status dev_score_long(mtb_ctx *c, mtb_index *ix, const mtb_params *p,
     HIPCHK(hipMemsetAsync(d_work, 0, 8, c->stream));
     HIPCHK(hipMemsetAsync(c->d_scal + 6, 0, 8, c->stream));
     {   KTimer kt(c, MTB_K_SCORE_FAST);       /* booked with the register-resident scorer's id: the workgroup-per-read kernel of long reads */
-        const uint32_t grid = (uint32_t)std::min<uint64_t>(d_list ? n_list : n_reads, 256ull * 3);
-        hipLaunchKernelGGL((k_score_long<MTB_LONG_MAXBLK, MTB_LONG_MAXSP>), dim3(grid), dim3(MTB_LONG_NT), 0, c->stream, d_m, d_seg, n_reads, d_qlen, d_qlen2, tax_view(ix), sp, (const uint64_t *)d_tcoff,
-                           d_res, d_tc_tax, d_tc_cnt, tc_cap, tc_base, d_todo, d_work, d_segcnt, d_list, n_list);
+        /* two launches (round 6): <.., 512 paths, 2048 position buckets> first -- 33 KB of LDS, four workgroups per CU; reads up to ~18 kb with up to 512 emitted
+         * paths: nearly all -- then the full budgets (70 KB, two per CU) for the reads the first one flagged */
+        const uint64_t n_it = d_list ? n_list : n_reads;
+        hipLaunchKernelGGL((k_score_long<MTB_LONG_MAXBLK, MTB_LONG_MAXSP, 512, 2048>), dim3((uint32_t)std::min<uint64_t>(n_it, 256ull * 4)), dim3(MTB_LONG_NT), 0, c->stream, d_m, d_seg, n_reads, d_qlen, d_qlen2, tax_view(ix), sp, (const uint64_t *)d_tcoff,
+                           d_res, d_tc_tax, d_tc_cnt, tc_cap, tc_base, d_todo, d_work, d_segcnt, d_list, n_list, 0u);
+        hipLaunchKernelGGL(k_count_flags, dim3(256), dim3(256), 0, c->stream, (const uint8_t *)d_todo, n_reads, (unsigned long long *)(c->d_scal + 6));
+        uint64_t n_second = 0;
+        STCHK(d2h(c, &n_second, c->d_scal + 6, 8));
+        HIPCHK(hipMemsetAsync(c->d_scal + 6, 0, 8, c->stream));
+        if (n_second) {
+            HIPCHK(hipMemsetAsync(d_work, 0, 8, c->stream));
+            hipLaunchKernelGGL((k_score_long<MTB_LONG_MAXBLK, MTB_LONG_MAXSP>), dim3((uint32_t)std::min<uint64_t>(n_it, 256ull * 2)), dim3(MTB_LONG_NT), 0, c->stream, d_m, d_seg, n_reads, d_qlen, d_qlen2, tax_view(ix), sp, (const uint64_t *)d_tcoff,
+                               d_res, d_tc_tax, d_tc_cnt, tc_cap, tc_base, d_todo, d_work, d_segcnt, d_list, n_list, 1u);
+        }
 #ifdef MTB_LONG_PHASE_CYCLES
     {   /* profiling build: cycles of thread 0 per phase of k_score_long, summed over the workgroups (and reset) */
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -2236,11 +2247,12 @@ static mtb_status score_fixed_slots(mtb_ctx *c, mtb_index *ix, const mtb_params 
             unsigned long long *d_ms;                                  /* [0] reads handed on, [1] work counter, [2] matches seen, [3] survivors, [4..6] hand-over reasons */
             STCHK(ensure(c, "manystat", 16, &d_ms));
             HIPCHK(hipMemsetAsync(d_ms, 0, 16 * 8, st));
-            const uint32_t gridm = std::min<uint32_t>(n_big, 256u * (stride <= 192u ? 12u : 7u));
+            const bool cap192 = c->opt.many_cap ? c->opt.many_cap <= 192 : stride <= 192u;
+            const uint32_t gridm = std::min<uint32_t>(n_big, 256u * (cap192 ? 12u : 7u));
 #define MTB_LAUNCH_MANY(K64, CAPV) hipLaunchKernelGGL((k_score_many<K64, CAPV>), dim3(gridm), dim3(64), 0, st, (const mtb_slot16 *)d_segm, stride, direct, epoch, (const uint32_t *)d_rc, d_off_reads, \
             (const mtb_match *)d_ovfg, (const uint64_t *)d_ostart, (const uint32_t *)d_biglist, (const uint32_t *)(c->d_scal + 5), SL.d_qlen, SL.d_qlen2, tax_view(ix), SL.sp, SL.d_tcoff, SL.d_res, \
             SL.d_tc_tax, SL.d_tc_cnt, SL.tc_cap, SL.tc_base, d_rest, (uint32_t *)d_ms, d_cnt, d_ms + 1, d_ms + 2)
-            if (stride <= 192u) { if (SL.key64) MTB_LAUNCH_MANY(true, 192); else MTB_LAUNCH_MANY(false, 192); }
+            if (cap192) { if (SL.key64) MTB_LAUNCH_MANY(true, 192); else MTB_LAUNCH_MANY(false, 192); }
             else { if (SL.key64) MTB_LAUNCH_MANY(true, 320); else MTB_LAUNCH_MANY(false, 320); }
 #undef MTB_LAUNCH_MANY
             HIPCHK(hipGetLastError());

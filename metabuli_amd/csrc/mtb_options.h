@@ -27,6 +27,7 @@ struct MtbOptions {
     /* scoring */
     int no_score_many = 0;         /* MTB_NO_SCORE_MANY: deferred reads through exact segments (round 4's path) */
     int no_many_sort = 0;          /* MTB_NO_MANY_SORT */
+    int many_cap = 0;              /* MTB_MANY_CAP: staging of k_score_many, 192 or 320 records (0 = 192 up to 192 slots per read, else 320) */
     int many_verbose = 0;          /* MTB_MANY_VERBOSE */
     int no_fast_scorer = 0;        /* MTB_NO_FAST_SCORER */
     int no_fast_pairs = 0;         /* MTB_NO_FAST_PAIRS */
@@ -62,7 +63,7 @@ static const Entry kTable[] = {
     MTB_OPT("MTB_JOIN_VARIANT", VARIANT, join_variant, 0), MTB_OPT("MTB_JOIN_WIN", INT, join_win, -1), MTB_OPT("MTB_JOIN_WIN_QT", INT, join_win_qt, 0),
 MTB_OPT("MTB_JOIN_COOP_MIN", INT, join_coop_min, 0), MTB_OPT("MTB_JOIN_VERBOSE", FLAG, join_verbose, 0),
     MTB_OPT("MTB_SORT_LSD", FLAG, sort_lsd, 0), MTB_OPT("MTB_SORT_NO_XCD", FLAG, sort_no_xcd, 0), MTB_OPT("MTB_SORT_PAIRS", INT, sort_pairs, 0),
-    MTB_OPT("MTB_NO_SCORE_MANY", FLAG, no_score_many, 0), MTB_OPT("MTB_NO_MANY_SORT", FLAG, no_many_sort, 0), MTB_OPT("MTB_MANY_VERBOSE", FLAG, many_verbose, 0),
+    MTB_OPT("MTB_NO_SCORE_MANY", FLAG, no_score_many, 0), MTB_OPT("MTB_NO_MANY_SORT", FLAG, no_many_sort, 0), MTB_OPT("MTB_MANY_CAP", INT, many_cap, 0), MTB_OPT("MTB_MANY_VERBOSE", FLAG, many_verbose, 0),
     MTB_OPT("MTB_NO_FAST_SCORER", FLAG, no_fast_scorer, 0), MTB_OPT("MTB_NO_FAST_PAIRS", FLAG, no_fast_pairs, 0), MTB_OPT("MTB_NO_LONG_SCORER", FLAG, no_long_scorer, 0),
     MTB_OPT("MTB_NO_LONG_SLOTS", FLAG, no_long_slots, 0), MTB_OPT("MTB_LSLOT_VERBOSE", FLAG, lslot_verbose, 0), MTB_OPT("MTB_TAIL_MIN", INT, tail_min, 0),
     MTB_OPT("MTB_NO_DIR", FLAG, no_dir, 0), MTB_OPT("MTB_DIR_DEPTH", INT, dir_depth, 0), MTB_OPT("MTB_NO_PACK", FLAG, no_pack, 0), MTB_OPT("MTB_OPEN_PACKED", INT, open_packed, -1),
