@@ -203,13 +203,51 @@ __global__ __launch_bounds__(256) void k_index_unpack(uint64_t *__restrict__ val
 #ifndef MTB_JOIN_COOP_MIN
 #define MTB_JOIN_COOP_MIN 32          /* default of JoinSegArgs::coop_min; MTB_JOIN_COOP_MIN=<n> in the environment of mtb_ctx_create overrides it (A/B runs) */
 #endif
+/* the value of lane `src` (wave-uniform: the callers take it from a ballot) as a scalar: v_readlane, so that what depends on it -- a scanned run's
+ * bounds, its loop -- stays in scalar registers and scalar branches */
+__device__ __forceinline__ uint32_t wave_bcast32(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
 __device__ __forceinline__ uint64_t wave_bcast64(uint64_t v, int src) {
-    return ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 64) << 32) | (uint64_t)(uint32_t)__shfl((int)(uint32_t)v, src, 64);
+    return ((uint64_t)wave_bcast32((uint32_t)(v >> 32), src) << 32) | (uint64_t)wave_bcast32((uint32_t)v, src);
 }
 __device__ __forceinline__ uint32_t wave_min_shfl_u32(uint32_t v) {
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64); v = o < v ? o : v; }
     return v;
+}
+/* Hamming sums of a wave-scanned run out of ONE register per query (round 6).  The query of such a run is the same for all 64 lanes, so its side of
+ * getHammingDistanceSum (KmerMatcher.h:348-360) is tabulated across the wave: lane p = (c1 << 3 | c0) holds, in byte j, hammingLookup[q_2j][c0] +
+ * hammingLookup[q_2j+1][c1] -- codon pair j of the query against the codon pair (c0, c1).  A target's sum is then four ds_bpermute look-ups (the four 6-bit
+ * codon pairs of its DNA part address the lanes), two v_perm that keep byte j of look-up j, and one v_sad_u8 that adds the four bytes: 8 VALU + 4
+ * LDS-crossbar instructions instead of ~36 VALU for mtb_ham_sum's eight nibble extractions.  ds_bpermute returns 0 for a source lane that is switched
+ * off: every call site runs with all 64 lanes on (dummy targets beyond the run's end, their sums discarded). */
+__device__ __forceinline__ uint32_t wave_ham_table(const uint32_t *hamrow, uint32_t qdna) {
+    const uint32_t l = threadIdx.x & 63u, s0 = 4u * (l & 7u), s1 = 4u * (l >> 3);
+    uint32_t e = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        e |= (((hamrow[(qdna >> (6 * j)) & 7u] >> s0) & 15u) + ((hamrow[(qdna >> (6 * j + 3)) & 7u] >> s1) & 15u)) << (8 * j);
+    return e;
+}
+__device__ __forceinline__ uint32_t wave_ham_lookup(uint32_t tab, uint32_t tdna) {
+#if defined(__AMDGCN__)
+    /* byte address of lane i = 4 i; the instruction divides by four, so the two bits below a codon pair may ride along */
+#ifdef MTB_BPERM_EXACT_ADDR
+#define MTB_BPERM_ADDR(k) (((k) ? tdna >> (6 * (k) - 2) : tdna << 2) & 0xFCu)
+#else
+    const uint32_t t4 = tdna << 2;
+#define MTB_BPERM_ADDR(k) ((t4 >> (6 * (k))) & 0xFFu)
+#endif
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)MTB_BPERM_ADDR(0), (int)tab), r1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)MTB_BPERM_ADDR(1), (int)tab);
+    const uint32_t r2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)MTB_BPERM_ADDR(2), (int)tab), r3 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)MTB_BPERM_ADDR(3), (int)tab);
+#undef MTB_BPERM_ADDR
+    /* v_perm_b32: selector bytes 0-3 take bytes of the second operand, 4-7 of the first, 0x0C is zero: {r0.b0, r1.b1, 0, 0} and {0, 0, r2.b2, r3.b3};
+     * the sum of absolute differences of the two words IS the sum of the four bytes */
+    return __builtin_amdgcn_sad_u8(__builtin_amdgcn_perm(r1, r0, 0x0C0C0500u), __builtin_amdgcn_perm(r3, r2, 0x07020C0Cu), 0u);
+#else
+    uint32_t h = 0;
+    for (int k = 0; k < 4; k++) h += ((uint32_t)__shfl((int)tab, (int)((tdna >> (6 * k)) & 63u), 64) >> (8 * k)) & 0xFFu;
+    return h;
+#endif
 }
 
 /* MODE 0: slot segments of fixed stride (short reads); 1: per-read slot ranges (long reads); 2: dense list of Match records
@@ -446,20 +484,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
      * selection threshold) and, per lane, the candidates of its stripe with a sum <= 7 -- no other can be selected, the threshold
      * being min(2 x minimum, 7) -- as (offset in the run << 4 | sum): the last four are kept (c0 = newest), n_c counts them all.
      * Runs whose lanes all stay within four are emitted from these registers; the others are walked a second time. */
-    auto coop_scan = [&](const mtb_qrows &qr, uint64_t s, uint64_t e, uint32_t &c0, uint32_t &c1, uint32_t &c2, uint32_t &c3, uint32_t &n_c) -> uint32_t {
+    auto coop_scan = [&](uint32_t tab, uint64_t s, uint64_t e, uint32_t &c0, uint32_t &c1, uint32_t &c2, uint32_t &c3, uint32_t &n_c) -> uint32_t {
         uint32_t mn = 255u; n_c = 0; c0 = 0; c1 = 0; c2 = 0; c3 = 0;
-        for (uint64_t t0 = s + lane; t0 < e; t0 += 256) {
-            uint64_t v[4];
+        const uint32_t len = (uint32_t)(e - s);                          /* (runs are shorter than 2^28) */
+        for (uint32_t b0 = 0; b0 < len; b0 += 256) {                     /* wave-uniform: the table look-ups need all 64 lanes */
+            uint32_t v[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) v[j] = t0 + 64 * j < e ? rdv(t0 + 64 * j) : 0ull;
+            for (int j = 0; j < 4; j++) { const uint32_t o = b0 + 64 * j + lane; v[j] = o < len ? (uint32_t)rdv(s + o) : 0u; }
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                if (t0 + 64 * j < e) {
-                    const uint32_t h = mtb_ham_sum(&qr, (uint32_t)v[j] & 0xFFFFFFu);
+                if (b0 + 64 * j >= len) break;
+                const uint32_t o = b0 + 64 * j + lane;
+                const uint32_t h = wave_ham_lookup(tab, v[j]);
+                if (o < len) {
                     mn = h < mn ? h : mn;
                     /* (also asking for h <= 2 x the lane's minimum so far -- a necessary condition -- changed nothing: headline join 64.3 - 70.2 vs 62.5 - 65.8 ms,
                      * 10 M held-out reads 202.8 vs 201.6, alternating processes; profiles/r06_notes.md) */
-                    if (h <= 7u) { c3 = c2; c2 = c1; c1 = c0; c0 = ((uint32_t)(t0 + 64 * j - s) << 4) | h; n_c++; }
+                    if (h <= 7u) { c3 = c2; c2 = c1; c1 = c0; c0 = (o << 4) | h; n_c++; }
                 }
             }
         }
@@ -493,9 +534,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
             while (todo) {
                 const int src = __ffsll((unsigned long long)todo) - 1; todo &= todo - 1;
                 const uint64_t s0 = wave_bcast64(lo[u], src), e = wave_bcast64(e_hi[u], src);
-                mtb_qrows qr; mtb_prepare_query_rows(s_hr, wave_bcast64(k[u].value, src), &qr);
+                const uint32_t tab = wave_ham_table(s_hr, wave_bcast32((uint32_t)k[u].value, src) & 0xFFFFFFu);
                 uint32_t c0, c1, c2, c3, n_c;
-                const uint32_t thr = coop_scan(qr, s0, e, c0, c1, c2, c3, n_c);
+                const uint32_t thr = coop_scan(tab, s0, e, c0, c1, c2, c3, n_c);
                 uint32_t c = 0;
                 if (!__any(n_c > 4u)) {
                     const uint32_t mine = (n_c > 0 && (c0 & 15u) <= thr ? 1u : 0u) + (n_c > 1 && (c1 & 15u) <= thr ? 1u : 0u) +
@@ -505,8 +546,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
                 } else {
                     for (uint64_t t0 = s0; t0 < e; t0 += 64) {
                         const uint64_t t = t0 + lane;
-                        const bool sel = t < e && mtb_ham_sum(&qr, (uint32_t)rdv(t) & 0xFFFFFFu) <= thr;
-                        c += (uint32_t)__popcll(__ballot(sel));
+                        const uint32_t h = wave_ham_lookup(tab, t < e ? (uint32_t)rdv(t) : 0u);
+                        c += (uint32_t)__popcll(__ballot(t < e && h <= thr));
                     }
                 }
                 if ((int)lane == src) { rs[u] = s0; re[u] = e; thr_[u] = thr; cnt[u] = c; tot_c += c; }
@@ -526,16 +567,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
             while (todo) {
                 const int src = __ffsll((unsigned long long)todo) - 1; todo &= todo - 1;
                 const uint64_t s0 = wave_bcast64(rs[u], src), e = wave_bcast64(re[u], src), qi = wave_bcast64(k[u].qinfo, src);
-                const uint32_t thr = (uint32_t)__shfl((int)thr_[u], src, 64);
+                const uint32_t thr = wave_bcast32(thr_[u], src);
                 unsigned long long ob = wave_bcast64(o_of[u], src);
-                mtb_qrows qr; mtb_prepare_query_rows(s_hr, wave_bcast64(k[u].value, src), &qr);
+                const uint64_t qv = wave_bcast64(k[u].value, src);
+                const uint32_t tab = wave_ham_table(s_hr, (uint32_t)qv & 0xFFFFFFu);
+                mtb_qrows qr; mtb_prepare_query_rows(s_hr, qv, &qr);              /* (the per-codon fields of the selected candidates) */
                 const bool rev = mtb_hammings_reversed(mtb_q_frame(qi), ix.kmer_format);
                 bool first = true;
                 for (uint64_t t0 = s0; t0 < e; t0 += 64) {
                     const uint64_t t = t0 + lane;
-                    uint64_t v = 0; uint32_t td = 0, h = 255u;
-                    if (t < e) { v = rdv(t); td = (uint32_t)v & 0xFFFFFFu; h = mtb_ham_sum(&qr, td); }
-                    const bool sel = h <= thr;
+                    uint64_t v = 0; uint32_t td = 0;
+                    if (t < e) { v = rdv(t); td = (uint32_t)v & 0xFFFFFFu; }
+                    const uint32_t h = wave_ham_lookup(tab, td);
+                    const bool sel = t < e && h <= thr;
                     const uint64_t m = __ballot(sel);
                     if (!m) continue;
                     const uint32_t rk = (uint32_t)__popcll(m & lt_mask);
@@ -595,9 +639,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
         while (todo) {
             const int src = __ffsll((unsigned long long)todo) - 1; todo &= todo - 1;
             const uint64_t s0 = wave_bcast64(lo[u], src), e = wave_bcast64(e_hi[u], src), qi_t = wave_bcast64(k[u].qinfo, src);
-            mtb_qrows qr; mtb_prepare_query_rows(s_hr, wave_bcast64(k[u].value, src), &qr);
+            const uint64_t qv = wave_bcast64(k[u].value, src);
+            const uint32_t tab = wave_ham_table(s_hr, (uint32_t)qv & 0xFFFFFFu);
             uint32_t cb[4], n_c;
-            const uint32_t thr = coop_scan(qr, s0, e, cb[0], cb[1], cb[2], cb[3], n_c);
+            const uint32_t thr = coop_scan(tab, s0, e, cb[0], cb[1], cb[2], cb[3], n_c);
+            mtb_qrows qr; mtb_prepare_query_rows(s_hr, qv, &qr);                  /* (the per-codon fields of the selected candidates: after the scan, which needs the table only) */
             const uint32_t r = mtb_q_seq(qi_t) - 1, ord = mtb_q_pos(qi_t) >> 16;
             const uint64_t qinfo = qi_t & ~0xFFFF0000ull;
             const bool rev = mtb_hammings_reversed(mtb_q_frame(qinfo), ix.kmer_format);
@@ -638,7 +684,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
                     if (m) {
                         const int leader = __ffsll((unsigned long long)m) - 1;
                         if ((int)lane == leader) at0 = atomicAdd(&sa.cursor[r], (uint32_t)__popcll(m) * inc);
-                        at0 = (uint32_t)__shfl((int)at0, leader, 64);
+                        at0 = wave_bcast32(at0, leader);
                     }
                     if (sel) put(s0 + off, full_of(s0 + off, rdv(s0 + off)), cb[b] & 15u, own ? ~0u : (offr ? tcap : at0 + (uint32_t)__popcll(m & lt_mask)));
                 }
@@ -646,9 +692,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
             }
             for (uint64_t t0 = s0; t0 < e; t0 += 64) {      /* a lane met more than four possible candidates: second walk, 64 per step */
                 const uint64_t t = t0 + lane;
-                uint64_t v = 0; uint32_t h = 255u;
-                if (t < e) { v = rdv(t); h = mtb_ham_sum(&qr, (uint32_t)v & 0xFFFFFFu); }
-                const bool sel = h <= thr;
+                uint64_t v = 0;
+                if (t < e) v = rdv(t);
+                const uint32_t h = wave_ham_lookup(tab, (uint32_t)v);
+                const bool sel = t < e && h <= thr;
                 const uint64_t m = __ballot(sel);
                 if (!m) continue;
                 const uint32_t rk = (uint32_t)__popcll(m & lt_mask), n_sel = (uint32_t)__popcll(m);
@@ -657,7 +704,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
                 if (n_tail) {
                     const int leader = __ffsll((unsigned long long)m) - 1;
                     if ((int)lane == leader) at0 = atomicAdd(&sa.cursor[r], n_tail * inc);
-                    at0 = (uint32_t)__shfl((int)at0, leader, 64);
+                    at0 = wave_bcast32(at0, leader);
                 }
                 if (sel) put(t, full_of(t, v), h, (first && rk == 0) ? ~0u : (offr ? tcap : at0 + rk - skip));
                 first = false;

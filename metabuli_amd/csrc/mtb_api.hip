@@ -2646,6 +2646,10 @@ static mtb_status classify_budgeted(mtb_ctx *c, mtb_index *ix, const mtb_params 
     uint64_t fit = (uint64_t)((double)budget / (per_base * safety * mean_len));        /* reads per sub-batch */
     fit = std::max<uint64_t>(fit, 1);
     uint64_t n_sub = (n_reads + fit - 1) / fit;
+    if (c->opt.host_timing)
+        fprintf(stderr, "mtb budget: free %.1f GiB + held %.1f GiB -> budget %.1f GiB; %.1f bytes per base (%s) x %.2f -> %llu reads fit, %llu sub-batch(es) for %llu reads\n",
+                (double)fr / 1073741824.0, (double)held / 1073741824.0, (double)budget / 1073741824.0, per_base, c->ws_per_base > 0.0 ? "measured" : "estimate", safety,
+                (unsigned long long)fit, (unsigned long long)n_sub, (unsigned long long)n_reads);
     mtb_batch_stats S; memset(&S, 0, sizeof(S));
     uint64_t tc_used = 0, lo = 0;
     uint32_t done = 0;
@@ -2661,6 +2665,7 @@ static mtb_status classify_budgeted(mtb_ctx *c, mtb_index *ix, const mtb_params 
             if (st != MTB_ERR_OOM || cnt <= 1024) break;
             /* the estimate was too optimistic for this range: give the memory back, halve, redo */
             HIPCHK(hipStreamSynchronize(c->stream));
+            if (c->opt.host_timing) fprintf(stderr, "mtb budget: %llu reads ran out of memory (%s); halving\n", (unsigned long long)cnt, mtb_last_error());
             release_workspace(c);
             cnt = (cnt + 1) / 2; n_sub *= 2; done *= 2;
         }
@@ -2675,6 +2680,12 @@ static mtb_status classify_budgeted(mtb_ctx *c, mtb_index *ix, const mtb_params 
          * smaller one inflates the figure, more sub-batches follow, and the next measurement is worse still) */
         c->ws_max_sub_bases = std::max<uint64_t>(c->ws_max_sub_bases, c->stats.n_bases);
         if (c->ws_max_sub_bases) c->ws_per_base = (double)scaling_bytes(c) / (double)c->ws_max_sub_bases;
+        if (c->opt.host_timing) {
+            std::lock_guard<std::mutex> lk(c->bufs_mu);
+            fprintf(stderr, "mtb budget: sub-batch of %llu reads (%llu bases) done; buffers (GiB):", (unsigned long long)cnt, (unsigned long long)c->stats.n_bases);
+            for (auto &kv : c->bufs) if (kv.second.cap >= (256u << 20)) fprintf(stderr, " %s %.2f", kv.first.c_str(), (double)kv.second.cap / 1073741824.0);
+            fprintf(stderr, "\n");
+        }
         merge_stats(S, c->stats); S.ms_total += c->stats.ms_total;
         tc_used += n_tc; lo += cnt; done++;
     }
