@@ -161,6 +161,10 @@ mtb_status mtb_ctx_set_join_variant(mtb_ctx *, int variant);
  * MTB_ERR_ARG: unknown name or unparsable value. */
 mtb_status mtb_ctx_set_option(mtb_ctx *, const char *name, const char *value);
 uint32_t   mtb_ctx_last_sub_batches(const mtb_ctx *);
+/* Bytes of the last batch's scoring temporaries (grouped overflow list, deferred reads' segments) that were placed inside buffers the join had left dead
+ * -- the unsorted metamer buffer, the sort's digit arrays -- instead of allocations of their own (summed over the call's sub-batches).  Workspace
+ * bookkeeping only; no reference counterpart. */
+uint64_t   mtb_ctx_last_scratch_bytes(const mtb_ctx *);
 
 /* ---- index residency ---------------------------------------------------
  * Replaces the per-call fopen/fread/mmap of diffIdx, info, split inside

@@ -182,6 +182,11 @@ class Context:
         self.L.mtb_ctx_last_sub_batches.restype = C.c_uint32
         return int(self.L.mtb_ctx_last_sub_batches(self.h))
 
+    @property
+    def last_scratch_bytes(self):
+        self.L.mtb_ctx_last_scratch_bytes.restype = C.c_uint64
+        return int(self.L.mtb_ctx_last_scratch_bytes(self.h))
+
     def set_streams(self, n):
         _chk(self.L.mtb_ctx_set_streams(self.h, C.c_int(n)))
 

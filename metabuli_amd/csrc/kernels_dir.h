@@ -18,6 +18,7 @@
  * others to the read's tail (one atomic each, rare), beyond that to the overflow list -- same contract as k_join<SEG>.    */
 #ifndef MTB_KERNELS_DIR_H
 #define MTB_KERNELS_DIR_H
+#include <type_traits>
 #include "dev_util.h"
 #include "kernels_join.h"
 #include "mtb_core.h"
@@ -275,8 +276,10 @@ __device__ __forceinline__ uint32_t wave_ham_lookup(uint32_t tab, uint32_t tdna)
 #endif
 #if defined(__AMDGCN__)
 #define MTB_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")       /* direct-to-LDS loads count in vmcnt; the barrier that follows publishes them */
+#define MTB_DRAIN_VMEM() __builtin_amdgcn_s_waitcnt(0x0F70)                   /* vmcnt(0), expcnt and lgkmcnt left alone (gfx9 encoding: vmcnt [3:0] + [15:14], expcnt [6:4], lgkmcnt [11:8]) */
 #else
 #define MTB_WAIT_VMEM() do {} while (0)
+#define MTB_DRAIN_VMEM() do {} while (0)
 #endif
 #define MTB_JOIN_WINCAP 3968          /* targets a window holds = 62 pieces of 64 low dwords (one wave-wide 4-byte direct-to-LDS load each): 15.9 KB -> eight workgroups
                                        * (32 waves) per CU */
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
                                                    const mtb_tile_win *__restrict__ tile_win = nullptr, unsigned long long *__restrict__ win_stat = nullptr) {
     constexpr int Q = QPT;
     static_assert(!WIN || (QPT == 1 && PACKED && MODE != 2), "the window form: packed words, one query per thread, slot modes");
-    __shared__ __attribute__((aligned(16))) uint32_t s_win[WIN ? MTB_JOIN_WINCAP : 1];
+    __shared__ __attribute__((aligned(16))) uint32_t s_win[WIN ? MTB_JOIN_WINCAP + 4 : 1];        /* (+ 4: the evaluation reads four words from a run's first candidate, whatever the run's length) */
     uint64_t w0 = 0; bool use_win = false;
     /* rdv: what the search and the evaluation read of a target (inside a window: its low 32 bits); full_of: the whole word of a SELECTED candidate */
     auto rdv = [&](uint64_t t) -> uint64_t { return (WIN && use_win) ? (uint64_t)s_win[t - w0] : ix.values[t]; };
@@ -484,18 +487,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
      * selection threshold) and, per lane, the candidates of its stripe with a sum <= 7 -- no other can be selected, the threshold
      * being min(2 x minimum, 7) -- as (offset in the run << 4 | sum): the last four are kept (c0 = newest), n_c counts them all.
      * Runs whose lanes all stay within four are emitted from these registers; the others are walked a second time. */
-    auto coop_scan = [&](uint32_t tab, uint64_t s, uint64_t e, uint32_t &c0, uint32_t &c1, uint32_t &c2, uint32_t &c3, uint32_t &n_c) -> uint32_t {
+    auto coop_scan_from = [&](auto from_lds, uint32_t qdna, uint32_t &tab, uint64_t s, uint64_t e, uint32_t &c0, uint32_t &c1, uint32_t &c2, uint32_t &c3, uint32_t &n_c) -> uint32_t {
         uint32_t mn = 255u; n_c = 0; c0 = 0; c1 = 0; c2 = 0; c3 = 0;
         const uint32_t len = (uint32_t)(e - s);                          /* (runs are shorter than 2^28) */
-        for (uint32_t b0 = 0; b0 < len; b0 += 256) {                     /* wave-uniform: the table look-ups need all 64 lanes */
-            uint32_t v[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) { const uint32_t o = b0 + 64 * j + lane; v[j] = o < len ? (uint32_t)rdv(s + o) : 0u; }
+        /* a step's 256 candidates are fetched while the previous step's are evaluated -- and the first ones while the query's table is built: a scanned run
+         * costs ONE exposed round trip whatever its length (profiling build, reads of held-out genomes: 48 % of the join's cycles sat in these loops with
+         * a dependent fetch per step).  Two register sets taken in turns (no moves: a move would wait for the fetch); one loop per source -- LDS window or
+         * global memory, a property of the tile -- so that the compiler's wait counts see straight-line code. */
+        uint32_t v[4], w[4];
+        auto fetch = [&](uint32_t (&d)[4], uint32_t b0) {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                if (b0 + 64 * j >= len) break;
+                /* lanes beyond the run's end read its last candidate again (discarded in eval): an address clamp, not a branch -- with a predicated load the
+                 * compiler moved the first use into the load's block and waited for every load on the spot */
+                const uint32_t o = b0 + 64 * j + lane, oc = o < len ? o : len - 1u;
+                d[j] = decltype(from_lds)::value ? s_win[s + oc - w0] : ((const uint32_t *)ix.values)[2 * (s + oc)];       /* (the low dword: a 4-byte load, no dead high register to wait for) */
+            }
+        };
+        auto eval = [&](const uint32_t (&d)[4], uint32_t b0) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (b0 + 64 * j >= len) break;                           /* wave-uniform: the table look-ups need all 64 lanes */
                 const uint32_t o = b0 + 64 * j + lane;
-                const uint32_t h = wave_ham_lookup(tab, v[j]);
+                const uint32_t h = wave_ham_lookup(tab, d[j]);
                 if (o < len) {
                     mn = h < mn ? h : mn;
                     /* (also asking for h <= 2 x the lane's minimum so far -- a necessary condition -- changed nothing: headline join 64.3 - 70.2 vs 62.5 - 65.8 ms,
@@ -503,8 +517,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
                     if (h <= 7u) { c3 = c2; c2 = c1; c1 = c0; c0 = (o << 4) | h; n_c++; }
                 }
             }
+        };
+        /* the previous run's slot stores may still be in flight; gfx9 counts loads and stores in ONE counter and orders them only among their own kind, so with a
+         * store pending the compiler has to wait for vmcnt(0) at every use of a loaded value -- the prefetch would be waited for on the spot.  An explicit
+         * s_waitcnt (the builtin: an instruction the compiler's wait-count pass sees, unlike inline assembly) empties the counter here; from then on
+         * the loop holds loads only and waits for the older register set with vmcnt(4). */
+        MTB_DRAIN_VMEM();
+        fetch(v, 0);
+        tab = wave_ham_table(s_hr, qdna);
+        for (uint32_t b0 = 0; b0 < len; b0 += 512) {
+            fetch(w, b0 + 256);
+            eval(v, b0);
+            if (b0 + 256 >= len) break;
+            fetch(v, b0 + 512);
+            eval(w, b0 + 256);
         }
         return mtb_ham_threshold(wave_min_shfl_u32(mn));
+    };
+    auto coop_scan = [&](uint32_t qdna, uint32_t &tab, uint64_t s, uint64_t e, uint32_t &c0, uint32_t &c1, uint32_t &c2, uint32_t &c3, uint32_t &n_c) -> uint32_t {
+        if (WIN && use_win) return coop_scan_from(std::true_type(), qdna, tab, s, e, c0, c1, c2, c3, n_c);
+        return coop_scan_from(std::false_type(), qdna, tab, s, e, c0, c1, c2, c3, n_c);
     };
     if (LIST) {
         /* dense list (owner side of the partitioned index): count the selected candidates of the thread's queries, one workgroup
@@ -534,9 +566,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
             while (todo) {
                 const int src = __ffsll((unsigned long long)todo) - 1; todo &= todo - 1;
                 const uint64_t s0 = wave_bcast64(lo[u], src), e = wave_bcast64(e_hi[u], src);
-                const uint32_t tab = wave_ham_table(s_hr, wave_bcast32((uint32_t)k[u].value, src) & 0xFFFFFFu);
-                uint32_t c0, c1, c2, c3, n_c;
-                const uint32_t thr = coop_scan(tab, s0, e, c0, c1, c2, c3, n_c);
+                uint32_t tab, c0, c1, c2, c3, n_c;
+                const uint32_t thr = coop_scan(wave_bcast32((uint32_t)k[u].value, src) & 0xFFFFFFu, tab, s0, e, c0, c1, c2, c3, n_c);
                 uint32_t c = 0;
                 if (!__any(n_c > 4u)) {
                     const uint32_t mine = (n_c > 0 && (c0 & 15u) <= thr ? 1u : 0u) + (n_c > 1 && (c1 & 15u) <= thr ? 1u : 0u) +
@@ -640,9 +671,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
             const int src = __ffsll((unsigned long long)todo) - 1; todo &= todo - 1;
             const uint64_t s0 = wave_bcast64(lo[u], src), e = wave_bcast64(e_hi[u], src), qi_t = wave_bcast64(k[u].qinfo, src);
             const uint64_t qv = wave_bcast64(k[u].value, src);
-            const uint32_t tab = wave_ham_table(s_hr, (uint32_t)qv & 0xFFFFFFu);
-            uint32_t cb[4], n_c;
-            const uint32_t thr = coop_scan(tab, s0, e, cb[0], cb[1], cb[2], cb[3], n_c);
+            uint32_t tab, cb[4], n_c;
+            const uint32_t thr = coop_scan((uint32_t)qv & 0xFFFFFFu, tab, s0, e, cb[0], cb[1], cb[2], cb[3], n_c);
             mtb_qrows qr; mtb_prepare_query_rows(s_hr, qv, &qr);                  /* (the per-codon fields of the selected candidates: after the scan, which needs the table only) */
             const uint32_t r = mtb_q_seq(qi_t) - 1, ord = mtb_q_pos(qi_t) >> 16;
             const uint64_t qinfo = qi_t & ~0xFFFF0000ull;
@@ -716,11 +746,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
     for (int u = 0; u < Q; u++) {
         if (!valid[u]) continue;
         const uint64_t s = lo[u], e = e_hi[u];
-        uint64_t v0 = rdv(s);
-        const uint32_t info0 = PACKED ? 0u : ix.info[s];      /* flat state: issued now, the first candidate is selected more often than not */
+        /* a tile with a window reads the run's first four candidates at once (low dwords: all the evaluation needs) with the first one's full word from
+         * global memory next to them (it is the one selected more often than not): ONE round trip before the evaluation instead of one per candidate and
+         * pass -- runs are 1 - 4 entries as a rule, and the loops below were two chains of dependent reads (per-lane evaluation + emission: 38 % of the
+         * kernel's cycles).  Their sums are kept for the emission.  Without a window: the first candidate's word, the others one by one as before. */
+        const uint32_t len = (uint32_t)(e - s);                /* (<= coop_min: longer runs went to the wave) */
+        const bool win4 = WIN && use_win;                      /* a tile with a window: four LDS words with one address (the array is padded by three words) */
+        const uint32_t n_pre = win4 ? 4u : 1u;
+        uint32_t d0, d1 = 0, d2 = 0, d3 = 0, hi0 = 0;
+        if (win4) { const uint32_t *pw = s_win + (s - w0); d0 = pw[0]; d1 = pw[1]; d2 = pw[2]; d3 = pw[3]; if (PACKED) hi0 = ((const uint32_t *)ix.values)[2 * s + 1]; }
+        else { const uint64_t v0 = ix.values[s]; d0 = (uint32_t)v0; hi0 = (uint32_t)(v0 >> 32); }
+        const uint32_t info0 = PACKED ? 0u : ix.info[s];
         mtb_qrows qr; mtb_prepare_query_rows(s_hr, k[u].value, &qr);
-        uint32_t mn = mtb_ham_sum(&qr, (uint32_t)v0 & 0xFFFFFFu);
-        for (uint64_t t = s + 1; t < e; t++) { const uint32_t h = mtb_ham_sum(&qr, (uint32_t)rdv(t) & 0xFFFFFFu); mn = h < mn ? h : mn; }
+        /* the sums of the candidates read ahead, a byte each (a sum is <= 32); the others are read one by one */
+        uint32_t hp = mtb_ham_sum(&qr, d0 & 0xFFFFFFu);
+        uint32_t mn = hp;
+        if (win4) {
+            { const uint32_t h = mtb_ham_sum(&qr, d1 & 0xFFFFFFu); hp |= h << 8; if (len > 1u) mn = h < mn ? h : mn; }
+            { const uint32_t h = mtb_ham_sum(&qr, d2 & 0xFFFFFFu); hp |= h << 16; if (len > 2u) mn = h < mn ? h : mn; }
+            { const uint32_t h = mtb_ham_sum(&qr, d3 & 0xFFFFFFu); hp |= h << 24; if (len > 3u) mn = h < mn ? h : mn; }
+        }
+        for (uint64_t t = s + n_pre; t < e; t++) { const uint32_t h = mtb_ham_sum(&qr, (uint32_t)rdv(t) & 0xFFFFFFu); mn = h < mn ? h : mn; }
         const uint32_t thr = mtb_ham_threshold(mn);
         const uint32_t r = mtb_q_seq(k[u].qinfo) - 1;
         const uint32_t ord = mtb_q_pos(k[u].qinfo) >> 16;
@@ -732,12 +778,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
         else seg = sa.seg + (uint64_t)r * sa.stride;
         const bool offr = !LONG && sa.off && sa.off[r];
         bool first = ord < direct && !offr;
-        for (uint64_t t = s; t < e; t++) {
-            const uint64_t v = t == s ? v0 : rdv(t);
-            const uint32_t td = (uint32_t)v & 0xFFFFFFu;
-            const uint32_t h = mtb_ham_sum(&qr, td);
+        for (uint32_t i = 0; i < len; i++) {
+            uint32_t low, h;
+            if (i < n_pre) { low = d0; h = hp & 255u; d0 = d1; d1 = d2; d2 = d3; hp >>= 8; }       /* (one loop body for all candidates: the registers rotate) */
+            else { low = (uint32_t)rdv(s + i); h = mtb_ham_sum(&qr, low & 0xFFFFFFu); }
             if (h > thr) continue;
-            const int32_t tid = (int32_t)((PACKED ? (uint32_t)(full_of(t, v) >> MTB_PACK_LOW) : (t == s ? info0 : ix.info[t])) & ix.info_mask);
+            const uint64_t t = s + i;
+            const uint32_t td = low & 0xFFFFFFu;
+            const int32_t tid = (int32_t)((PACKED ? (((i == 0u ? hi0 : ((const uint32_t *)ix.values)[2 * t + 1]) << (32 - MTB_PACK_LOW)) | (low >> MTB_PACK_LOW)) : (i == 0u ? info0 : ix.info[t])) & ix.info_mask);
             const int32_t sp = (tid >= 0 && tid <= ix.max_taxid) ? ix.tax2species[tid] : 0;
             const uint16_t reh = mtb_hammings(&qr, td, rev);
             /* non-temporal stores: a slot line is written ~5 times at unrelated moments of the kernel and never read by it; keeping

@@ -127,6 +127,12 @@ struct mtb_ctx {
     bool fast_used = false;          /* the last dev_score call launched k_score_fast (its slow-list count sits in d_scal[6]) */
     bool no_lslot = false;           /* classify_one is redoing a long-read range on the exact-segment path */
     const mtb_kmer *last_sorted = nullptr; uint64_t last_sorted_n = 0;       /* the last fused slot-path batch's sorted metamers (mtb_ctx_join_footprint) */
+    /* what the join leaves dead until the next batch's extraction -- the metamer buffer that does NOT hold the sorted list, both digit arrays: the scorer's large
+     * per-batch temporaries (the grouped overflow list, the deferred reads' segments) are carved out of them (scratch()) instead of being allocations of their own:
+     * 10 M reads of held-out genomes need 133 instead of 154 GiB of workspace -- one sub-batch instead of two on a 288 GB part next to a 126 GiB index */
+    struct DeadSeg { char *p; size_t cap, used; };
+    DeadSeg dead[3]; int n_dead = 0;
+    uint64_t last_scratch_bytes = 0;     /* mtb_ctx_last_scratch_bytes */
     /* upload of the NEXT batch's packed reads while the current batch computes (mtb_prefetch_batch_packed): a copy stream, two sets of
      * input buffers, and what the set that is being filled holds */
     hipStream_t copy_stream = nullptr; hipEvent_t copy_done[2] = {nullptr, nullptr};       /* per input buffer set: the prefetch into it is complete */
@@ -246,6 +252,16 @@ static mtb_status ensure(mtb_ctx *c, const char *name, size_t elems, T **out) {
     }
     *out = (T *)b.p;
     return MTB_OK;
+}
+/* a per-batch temporary that is written before it is read: out of the buffers the join left dead (first fit, 256-byte aligned), else a buffer of its own */
+template <typename T>
+static mtb_status scratch(mtb_ctx *c, const char *name, size_t elems, T **out) {
+    const size_t bytes = (elems * sizeof(T) + 255) & ~(size_t)255;
+    for (int i = 0; i < c->n_dead; i++) {
+        mtb_ctx::DeadSeg &d = c->dead[i];
+        if (d.cap - d.used >= bytes) { *out = (T *)(d.p + d.used); d.used += bytes; c->last_scratch_bytes += bytes; return MTB_OK; }
+    }
+    return ensure(c, name, elems, out);
 }
 /* Placement of the slot buffer.  The join's 1.1 G scattered 16-byte slot stores miss the L1 TLB once each, and what a miss costs
  * depends on where the 27 GB buffer landed: the same process runs the join at 47.5 or at 56.5 ms depending on nothing but a
@@ -440,6 +456,7 @@ mtb_status mtb_ctx_set_join_variant(mtb_ctx *c, int variant) {
     return mtb_ctx_set_option(c, "MTB_JOIN_VARIANT", names[variant]);
 }
 uint32_t mtb_ctx_last_sub_batches(const mtb_ctx *c) { return c ? c->last_sub_batches : 0; }
+uint64_t mtb_ctx_last_scratch_bytes(const mtb_ctx *c) { return c ? c->last_scratch_bytes : 0; }
 mtb_status mtb_ctx_set_streams(mtb_ctx *c, int n) {
     if (!c || n < 1 || n > 8) return fail(MTB_ERR_ARG, "streams must be 1..8");
     HIPCHK(hipSetDevice(c->device));
@@ -2235,7 +2252,7 @@ static mtb_status score_fixed_slots(mtb_ctx *c, mtb_index *ix, const mtb_params 
             const bool have_ovf = ovf_region ? c->ovf_max_region != 0 : n_ovf != 0;
             if (have_ovf) {
                 STCHK(ensure(c, "novf", n_reads, &d_novf)); STCHK(ensure(c, "ocur", n_reads, &d_ocur)); STCHK(ensure(c, "ovfstart", n_reads + 1, &d_ostart));
-                STCHK(ensure(c, "ovfg", n_ovf + 1, &d_ovfg));
+                STCHK(scratch(c, "ovfg", n_ovf + 1, &d_ovfg));
                 HIPCHK(hipMemsetAsync(d_ocur, 0, n_reads * 4, st));
                 hipLaunchKernelGGL(k_ovf_count, dim3((uint32_t)((n_reads + 255) / 256)), dim3(256), 0, st, (const uint32_t *)d_rc, d_off_reads, n_reads, stride - direct, d_novf);
                 scan_launch<uint32_t, uint64_t, false>(st, d_novf, n_reads, true, d_ostart, d_ws2);
@@ -2275,7 +2292,7 @@ static mtb_status score_fixed_slots(mtb_ctx *c, mtb_index *ix, const mtb_params 
                 scan_launch<uint32_t, uint64_t, false>(st, d_bc3, n_big, true, d_bs3, d_ws2);
                 uint64_t total3 = 0;
                 STCHK(d2h(c, &total3, d_bs3 + n_big, 8));
-                STCHK(ensure(c, "bigm", total3 + 1, &d_big3));
+                STCHK(scratch(c, "bigm", total3 + 1, &d_big3));
                 HIPCHK(hipMemsetAsync(d_todo, 0, n_reads, st));
                 /* the small instantiation first (20 KB of LDS: eight workgroups per CU), the big one for the reads it flags 2 */
                 hipLaunchKernelGGL((k_many_sort<11, 2048u>), dim3(std::min<uint32_t>(n_big, 256u * 8u)), dim3(MTB_MSORT_NT), 0, st, (const mtb_slot16 *)d_segm, stride, direct, epoch, (const uint32_t *)d_rc, d_off_reads,
@@ -2308,7 +2325,7 @@ static mtb_status score_fixed_slots(mtb_ctx *c, mtb_index *ix, const mtb_params 
         uint64_t mx = 0;
         STCHK(d2h(c, &big_total, d_bigstart + n_big, 8));
         STCHK(d2h(c, &mx, c->d_scal + 3, 8));
-        STCHK(ensure(c, "bigm", big_total, &d_big));
+        STCHK(scratch(c, "bigm", big_total, &d_big));
         hipLaunchKernelGGL(k_big_copy, dim3(std::min<uint32_t>(n_big, 4096)), dim3(64), 0, st, (const mtb_slot16 *)d_segm, stride, direct, epoch,
                            (const uint32_t *)d_rc, (const uint32_t *)d_biglist, (const uint64_t *)d_bigstart, n_big, d_bigcur, d_big);
         if (ovf_region) {            /* striped list (the directory join's): every stripe's entries */
@@ -2459,6 +2476,17 @@ static mtb_status classify_one(mtb_ctx *c, mtb_index *ix, const mtb_params *p, c
         HIPCHK(hipEventRecord(c->ev[3], st));
         HIPCHK(hipEventRecord(c->ev[4], st));
         HIPCHK(hipEventRecord(c->ev[5], st));
+        {   /* dead from here to the next extraction (the sorted list itself stays: mtb_ctx_join_footprint / mtb_ctx_query_runs look at it after the batch) */
+            std::lock_guard<std::mutex> lk(c->bufs_mu);
+            c->n_dead = 0;
+            const size_t least = c->opt.scratch_alias > 0 ? 1 : (64u << 20);
+            for (const char *nm : {"kmersA", "kmersB", "digA", "digB"}) {
+                auto it = c->bufs.find(nm);
+                if (c->opt.scratch_alias < 0 || it == c->bufs.end() || !it->second.p || it->second.p == (void *)d_s || it->second.cap < least || c->n_dead == 3) continue;
+                c->dead[c->n_dead].p = (char *)it->second.p; c->dead[c->n_dead].cap = it->second.cap; c->dead[c->n_dead].used = 0; c->n_dead++;
+            }
+        }
+        struct DeadEnd { mtb_ctx *c; ~DeadEnd() { c->n_dead = 0; } } dead_end{c};
         STCHK(score_fixed_slots(c, ix, p, n_reads, d_ql, d_ql2, max_len, nk_real, d_segm, d_rc, stride, direct, epoch, d_ovf, n_ovf,
                                 d_results, d_taxcnt_tax, d_taxcnt_cnt, taxcnt_cap, n_taxcnt, tc_base, &nm, route_off ? max_len_all : 0, route_off ? d_off : nullptr, c->ovf_region));
     } else if (lslot) {
@@ -2624,7 +2652,7 @@ static mtb_status classify_budgeted(mtb_ctx *c, mtb_index *ix, const mtb_params 
                                     uint64_t *n_taxcnt, uint64_t tc_base0) {
     HIPCHK(hipSetDevice(c->device));
     *n_taxcnt = 0;
-    c->last_sub_batches = 0;
+    c->last_sub_batches = 0; c->last_scratch_bytes = 0;
     if (n_reads == 0) { memset(&c->stats, 0, sizeof(c->stats)); return MTB_OK; }
     if (c->ws_seq_mode != p->seq_mode) {             /* other buffer set: what the previous mode grew would only sit in the way */
         if (c->ws_seq_mode) { HIPCHK(hipStreamSynchronize(c->stream)); release_workspace(c); }

@@ -35,6 +35,7 @@ struct MtbOptions {
     int no_long_slots = 0;         /* MTB_NO_LONG_SLOTS */
     int lslot_verbose = 0;         /* MTB_LSLOT_VERBOSE */
     int tail_min = 0;              /* MTB_TAIL_MIN: tail slots of a short read's segment (0 = 16) */
+    int scratch_alias = 0;         /* MTB_SCRATCH_ALIAS: the scorer's big per-batch temporaries inside the buffers the join left dead: 0 = segments of >= 64 MiB, 1 = any size (tests), -1 = off (A/B) */
     /* index state */
     int no_dir = 0;                /* MTB_NO_DIR */
     int dir_depth = 0;             /* MTB_DIR_DEPTH: 1..7 (tests force depth 7 -- the packed state -- on toy indices; 0 = from the size) */
@@ -65,7 +66,7 @@ MTB_OPT("MTB_JOIN_COOP_MIN", INT, join_coop_min, 0), MTB_OPT("MTB_JOIN_VERBOSE",
     MTB_OPT("MTB_SORT_LSD", FLAG, sort_lsd, 0), MTB_OPT("MTB_SORT_NO_XCD", FLAG, sort_no_xcd, 0), MTB_OPT("MTB_SORT_PAIRS", INT, sort_pairs, 0),
     MTB_OPT("MTB_NO_SCORE_MANY", FLAG, no_score_many, 0), MTB_OPT("MTB_NO_MANY_SORT", FLAG, no_many_sort, 0), MTB_OPT("MTB_MANY_CAP", INT, many_cap, 0), MTB_OPT("MTB_MANY_VERBOSE", FLAG, many_verbose, 0),
     MTB_OPT("MTB_NO_FAST_SCORER", FLAG, no_fast_scorer, 0), MTB_OPT("MTB_NO_FAST_PAIRS", FLAG, no_fast_pairs, 0), MTB_OPT("MTB_NO_LONG_SCORER", FLAG, no_long_scorer, 0),
-    MTB_OPT("MTB_NO_LONG_SLOTS", FLAG, no_long_slots, 0), MTB_OPT("MTB_LSLOT_VERBOSE", FLAG, lslot_verbose, 0), MTB_OPT("MTB_TAIL_MIN", INT, tail_min, 0),
+    MTB_OPT("MTB_NO_LONG_SLOTS", FLAG, no_long_slots, 0), MTB_OPT("MTB_LSLOT_VERBOSE", FLAG, lslot_verbose, 0), MTB_OPT("MTB_TAIL_MIN", INT, tail_min, 0), MTB_OPT("MTB_SCRATCH_ALIAS", INT, scratch_alias, 0),
     MTB_OPT("MTB_NO_DIR", FLAG, no_dir, 0), MTB_OPT("MTB_DIR_DEPTH", INT, dir_depth, 0), MTB_OPT("MTB_NO_PACK", FLAG, no_pack, 0), MTB_OPT("MTB_OPEN_PACKED", INT, open_packed, -1),
     MTB_OPT("MTB_OPEN_CHUNK", LL, open_chunk, 0), MTB_OPT("MTB_PART_EXACT", FLAG, part_exact, 0),
     MTB_OPT("MTB_SEGM_CONTIG", FLAG, segm_contig, 0), MTB_OPT("MTB_SEGM_PAD", FLAG, segm_pad, 0), MTB_OPT("MTB_SEGM_CLEAR", STR, segm_clear, 0),

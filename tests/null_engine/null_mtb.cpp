@@ -177,6 +177,7 @@ mtb_status mtb_index_export(mtb_index *, mtb_index_share *) { return MTB_ERR_UNS
 mtb_status mtb_index_import(mtb_ctx *, const mtb_index_share *, const char *, const int32_t *, size_t, const mtb_params *, mtb_index **) { return MTB_ERR_UNSUPPORTED; }
 mtb_status mtb_ctx_set_option(mtb_ctx *, const char *, const char *) { return MTB_OK; }
 uint32_t mtb_ctx_last_sub_batches(const mtb_ctx *) { return 1; }
+uint64_t mtb_ctx_last_scratch_bytes(const mtb_ctx *) { return 0; }
 mtb_status mtb_ctx_reserve(mtb_ctx *c, const mtb_params *p, uint64_t, uint64_t) { return c && p ? MTB_OK : fail(MTB_ERR_ARG, "NULL argument"); }
 mtb_status mtb_db_parameters(const char *dbdir, mtb_params *p) {
     if (!dbdir || !p) return fail(MTB_ERR_ARG, "NULL argument");

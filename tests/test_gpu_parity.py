@@ -970,6 +970,15 @@ def test_deferred_reads_beyond_a_tier_fall_to_the_next(orc, tmp_path, shape):
     else:
         assert per_read.max() > 4096
         assert st.n_many_reads < st.n_deferred_reads                     # some reads went all the way to the exact segments
+    # the same with the tiers' temporaries carved out of the dead metamer / digit buffers (MTB_SCRATCH_ALIAS=1: whatever their size)
+    c.set_option("MTB_SCRATCH_ALIAS", "1")
+    res2, tt2, tc2 = c.classify_batch(ix, p, t.b1, t.o1)
+    if shape.startswith("more species"):               # (the other shape's lists -- > 4096 matches per read -- are larger than anything the join left dead: buffers of their own)
+        assert c.last_scratch_bytes > 0
+    assert (res2["classification"] == res["classification"]).all() and (res2["score"].view(np.uint32) == res["score"].view(np.uint32)).all()
+    assert (tt2 == tt).all() and (tc2 == tc).all()
+    st2 = c.last_stats()
+    assert (st2.n_matches, st2.n_deferred_reads, st2.n_many_reads) == (st.n_matches, st.n_deferred_reads, st.n_many_reads)
     ix.close(); c.close()
 
 
@@ -1086,6 +1095,20 @@ def test_reads_that_meet_many_species_are_scored_from_their_slots(orc, tmp_path,
     assert st2.n_many_reads == 0 and st2.n_deferred_reads == st.n_deferred_reads
     c.set_option("MTB_NO_SCORE_MANY", None)
     check(*c.classify_batch(ix, p, t.b1, t.o1, t.b2, t.o2))
+    # the grouped overflow list and the deferred reads' segments inside the buffers the join left dead (the unsorted metamer buffer, the digit arrays;
+    # toy buffers are below the 64 MiB at which the library does that by itself): same answers on all three deferred paths, and the carving is reported
+    assert c.last_scratch_bytes == 0
+    c.set_option("MTB_SCRATCH_ALIAS", "1")
+    for sw in (None, "MTB_NO_MANY_SORT", "MTB_NO_SCORE_MANY"):
+        if sw:
+            c.set_option(sw, "1")
+        check(*c.classify_batch(ix, p, t.b1, t.o1, t.b2, t.o2))
+        assert c.last_scratch_bytes > 0, sw
+        if sw:
+            c.set_option(sw, None)
+    c.set_option("MTB_SCRATCH_ALIAS", "-1")
+    check(*c.classify_batch(ix, p, t.b1, t.o1, t.b2, t.o2))
+    assert c.last_scratch_bytes == 0
     ix.close(); c.close()
 
 
