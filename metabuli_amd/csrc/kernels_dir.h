@@ -336,7 +336,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
                                                    const mtb_tile_win *__restrict__ tile_win = nullptr, unsigned long long *__restrict__ win_stat = nullptr) {
     constexpr int Q = QPT;
     static_assert(!WIN || (QPT == 1 && PACKED && MODE != 2), "the window form: packed words, one query per thread, slot modes");
-    __shared__ __attribute__((aligned(16))) uint32_t s_win[WIN ? MTB_JOIN_WINCAP + 4 : 1];        /* (+ 4: the evaluation reads four words from a run's first candidate, whatever the run's length) */
+    /* (four words of padding at either end: the run-end search reads the four words before and after a landing place, the evaluation four words from a
+     * run's first candidate, whatever the run's length) */
+    __shared__ __attribute__((aligned(16))) uint32_t s_win_raw[WIN ? MTB_JOIN_WINCAP + 8 : 1];
+    uint32_t *const s_win = s_win_raw + (WIN ? 4 : 0);
     uint64_t w0 = 0; bool use_win = false;
     /* rdv: what the search and the evaluation read of a target (inside a window: its low 32 bits); full_of: the whole word of a SELECTED candidate */
     auto rdv = [&](uint64_t t) -> uint64_t { return (WIN && use_win) ? (uint64_t)s_win[t - w0] : ix.values[t]; };
@@ -440,6 +443,53 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PACKED && 
             if (!valid[u]) continue;
             const uint64_t p = lo[u], end = e_hi[u], qk = qkey(k[u].value);
             uint64_t s0 = p, e0 = p;
+            if (WIN && use_win) {
+                /* a tile with a window: the four words before and the four from the landing place in ONE LDS round trip (one address, immediate offsets), the bucket's
+                 * start read again from the directory next to them -- the loops below are a chain of dependent reads, one per step (run ends: 18 % of the kernel's cycles);
+                 * runs are 1 - 4 entries as a rule.  A side whose four words all belong to the run is continued by those loops. */
+                const uint32_t *pw = s_win + (p - w0);
+                const uint32_t m4 = pw[-4], m3 = pw[-3], m2 = pw[-2], m1 = pw[-1], a0 = pw[0], a1 = pw[1], a2 = pw[2], a3 = pw[3];
+                const uint32_t room_up = end - p > 4u ? 4u : (uint32_t)(end - p);        /* candidates at p .. p + room_up - 1 are inside the bucket */
+                const uint32_t qc32 = (uint32_t)qc[u], qk32 = (uint32_t)qk;
+                if (room_up != 0u && (a0 & 0x1FFFFFFFu) == qc32) {
+                    uint32_t c = 1;
+                    if (c < room_up && (a1 & 0x1FFFFFFFu) == qc32) { c = 2; if (c < room_up && (a2 & 0x1FFFFFFFu) == qc32) { c = 3; if (c < room_up && (a3 & 0x1FFFFFFFu) == qc32) c = 4; } }
+                    e0 = p + c;
+                    if (c == 4u) {
+                        uint32_t n = 0;
+                        while (e0 < end && n < 8u && tcomp(rdv(e0)) == qc[u]) { e0++; n++; }
+                        if (n == 8u && e0 < end && tcomp(rdv(e0)) == qc[u]) {
+                            uint64_t y = end;
+                            while (e0 < y) { const uint64_t mid = e0 + ((y - e0) >> 1); if (tcomp(rdv(mid)) <= qc[u]) e0 = mid + 1; else y = mid; }
+                        }
+                    }
+                } else {
+                    const uint32_t bk = mtb_dir_bucket(k[u].value, dv.L, dv.kmer_format);
+                    const uint64_t blo = dv.base[bk >> 16] + dv.dir[bk];
+                    const uint32_t room_dn = p - blo > 4u ? 4u : (uint32_t)(p - blo);
+                    uint32_t cu = 0, cd = 0;
+                    if (cu < room_up && (a0 & 0x1F000000u) == qk32) { cu = 1; if (cu < room_up && (a1 & 0x1F000000u) == qk32) { cu = 2; if (cu < room_up && (a2 & 0x1F000000u) == qk32) { cu = 3; if (cu < room_up && (a3 & 0x1F000000u) == qk32) cu = 4; } } }
+                    if (cd < room_dn && (m1 & 0x1F000000u) == qk32) { cd = 1; if (cd < room_dn && (m2 & 0x1F000000u) == qk32) { cd = 2; if (cd < room_dn && (m3 & 0x1F000000u) == qk32) { cd = 3; if (cd < room_dn && (m4 & 0x1F000000u) == qk32) cd = 4; } } }
+                    s0 = p - cd; e0 = p + cu;
+                    if (cd == 4u) {
+                        uint32_t n = 0;
+                        while (s0 > blo && n < 8u && tkey(rdv(s0 - 1)) == qk) { s0--; n++; }
+                        if (n == 8u && s0 > blo && tkey(rdv(s0 - 1)) == qk) {
+                            uint64_t x = blo, y = s0;
+                            while (x < y) { const uint64_t mid = x + ((y - x) >> 1); if (tkey(rdv(mid)) < qk) x = mid + 1; else y = mid; }
+                            s0 = x;
+                        }
+                    }
+                    if (cu == 4u) {
+                        uint32_t n = 0;
+                        while (e0 < end && n < 8u && tkey(rdv(e0)) == qk) { e0++; n++; }
+                        if (n == 8u && e0 < end && tkey(rdv(e0)) == qk) {
+                            uint64_t y = end;
+                            while (e0 < y) { const uint64_t mid = e0 + ((y - e0) >> 1); if (tkey(rdv(mid)) <= qk) e0 = mid + 1; else y = mid; }
+                        }
+                    }
+                }
+            } else
             if (p < end && tcomp(rdv(p)) == qc[u]) {
                 /* the block of targets equal to the query (several species may file the same metamer) */
                 e0 = p + 1;
