@@ -202,7 +202,9 @@ __global__ __launch_bounds__(256) void k_index_unpack(uint64_t *__restrict__ val
 /* (Round 5's experiment "queries of a wave that share a long run walk it in lockstep" measured slower -- held-out reads' join 47 -> 71 ms per 2 M reads,
  * headline 73 -> 82 -- and lives in profiles/experiments/join_lockstep_walk.patch, not in this kernel.) */
 #ifndef MTB_JOIN_COOP_MIN
-#define MTB_JOIN_COOP_MIN 32          /* default of JoinSegArgs::coop_min; MTB_JOIN_COOP_MIN=<n> in the environment of mtb_ctx_create overrides it (A/B runs) */
+#define MTB_JOIN_COOP_MIN 12          /* default of JoinSegArgs::coop_min; MTB_JOIN_COOP_MIN=<n> in the environment of mtb_ctx_create overrides it (A/B runs).  32 until the wave scan took its
+                                       * hamming sums from a table and fetched a step ahead; since then (one process each, join ms at 8 / 12 / 16 / 24 / 32): headline 58.1 / 58.1 / 58.2 / 58.4 /
+                                       * 58.7, 200 k x 10 kb 118.9 / 118.9 / 119.1 / 119.4 / 119.7, 12.5 M pairs 145.3 / - / 145.6 / - / 146.7 (profiles/r06_notes.md section 10) */
 #endif
 /* the value of lane `src` (wave-uniform: the callers take it from a ballot) as a scalar: v_readlane, so that what depends on it -- a scanned run's
  * bounds, its loop -- stays in scalar registers and scalar branches */

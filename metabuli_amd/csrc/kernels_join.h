@@ -226,7 +226,9 @@ __device__ __forceinline__ bool seg_slot_live(const mtb_slot16 &s, uint32_t i, u
 __global__ __launch_bounds__(64) void k_big_count(const mtb_slot16 *__restrict__ seg, uint32_t stride, uint32_t direct, uint32_t epoch,
                                                    const uint32_t *__restrict__ cursor, const uint32_t *__restrict__ big_list, uint32_t n_big,
                                                    uint32_t *__restrict__ big_cnt, uint32_t *__restrict__ bigidx, uint32_t *__restrict__ max_seg,
-                                                   const uint8_t *__restrict__ off = nullptr /* reads routed around their slots: the join pushed their cursor by tail_cap + 1 per match */) {
+                                                   const uint8_t *__restrict__ off = nullptr /* reads routed around their slots: the join pushed their cursor by tail_cap + 1 per match */,
+                                                   const uint32_t *__restrict__ novf = nullptr /* entries of the read in the GROUPED overflow list (k_ovf_count), if there is one */,
+                                                   unsigned long long *__restrict__ n_ungrouped = nullptr /* += listed reads whose overflow entries are not in the grouped list */) {
     uint32_t mx = 0;
     for (uint32_t b = blockIdx.x; b < n_big; b += gridDim.x) {
         const uint32_t r = big_list[b];
@@ -239,8 +241,9 @@ __global__ __launch_bounds__(64) void k_big_count(const mtb_slot16 *__restrict__
             if (i < stride) { mtb_slot16 x = s[i]; live = seg_slot_live(x, i, direct, tail_n, epoch); }
             n += (uint32_t)__popcll(__ballot(live));
         }
-        n += (off && off[r]) ? cur / (tail_cap + 1u) : cur - tail_n;       /* overflow entries */
-        if (threadIdx.x == 0) { big_cnt[b] = n; bigidx[r] = b; }
+        const uint32_t n_o = (off && off[r]) ? cur / (tail_cap + 1u) : cur - tail_n;       /* overflow entries */
+        n += n_o;
+        if (threadIdx.x == 0) { big_cnt[b] = n; bigidx[r] = b; if (n_ungrouped && n_o && !(novf && novf[r])) atomicAdd(n_ungrouped, 1ull); }
         mx = n > mx ? n : mx;
     }
     if (threadIdx.x == 0 && mx) atomicMax(max_seg, mx);
@@ -248,7 +251,11 @@ __global__ __launch_bounds__(64) void k_big_count(const mtb_slot16 *__restrict__
 __global__ __launch_bounds__(64) void k_big_copy(const mtb_slot16 *__restrict__ seg, uint32_t stride, uint32_t direct, uint32_t epoch,
                                                   const uint32_t *__restrict__ cursor, const uint32_t *__restrict__ big_list,
                                                   const uint64_t *__restrict__ big_start, uint32_t n_big, uint32_t *__restrict__ bigcur,
-                                                  mtb_match *__restrict__ big) {
+                                                  mtb_match *__restrict__ big,
+                                                  /* the overflow list grouped by read (k_ovf_group), when the batch has one: a listed read's entries are copied from its group --
+                                                   * k_big_ovf's pass over the WHOLE list (7 ms per 10 M reads of held-out genomes, for 5 334 listed reads) is only launched for
+                                                   * reads that have no group (routed around their slots, more than 65535 entries) */
+                                                  const mtb_match *__restrict__ ovfg = nullptr, const uint64_t *__restrict__ ostart = nullptr, const uint32_t *__restrict__ novf = nullptr) {
     for (uint32_t b = blockIdx.x; b < n_big; b += gridDim.x) {
         const uint32_t r = big_list[b];
         const uint32_t cur = cursor[r], tail_cap = stride - direct, tail_n = cur < tail_cap ? cur : tail_cap;
@@ -268,13 +275,19 @@ __global__ __launch_bounds__(64) void k_big_copy(const mtb_slot16 *__restrict__ 
             }
             n += (uint32_t)__popcll(mask);
         }
+        if (novf) {
+            const uint32_t g = novf[r];
+            const mtb_match *src = ovfg + ostart[r];
+            for (uint32_t j = threadIdx.x; j < g; j += 64) dst[n + j] = src[j];
+            n += g;
+        }
         if (threadIdx.x == 0) bigcur[b] = n;
     }
 }
 /* region_cap != 0: the list is striped (JoinSegArgs::ovf_stripes): blockIdx.y = stripe, its entries [0, counters[8 * stripe]) */
 __global__ __launch_bounds__(256) void k_big_ovf(const mtb_match *__restrict__ ovf, uint64_t n_ovf, const uint32_t *__restrict__ bigidx,
                                                   const uint64_t *__restrict__ big_start, uint32_t *__restrict__ bigcur, mtb_match *__restrict__ big,
-                                                  uint64_t region_cap = 0, const unsigned long long *__restrict__ counters = nullptr) {
+                                                  uint64_t region_cap = 0, const unsigned long long *__restrict__ counters = nullptr, const uint32_t *__restrict__ novf = nullptr) {
     uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (region_cap) {
         const unsigned long long cnt = counters[8 * blockIdx.y];
@@ -283,6 +296,7 @@ __global__ __launch_bounds__(256) void k_big_ovf(const mtb_match *__restrict__ o
     } else if (i >= n_ovf) return;
     mtb_match m = ovf[i];
     if (m.pad & 2u) { m.qinfo &= ~0xFFFF0000ull; m.pad = 0; }      /* (the directory join's entries carry their place in the read's group: kernels_dir.h, ovf_put) */
+    if (novf && novf[mtb_q_seq(m.qinfo) - 1]) return;      /* (copied from its read's group by k_big_copy) */
     uint32_t b = bigidx[mtb_q_seq(m.qinfo) - 1];
     if (b == 0xFFFFFFFFu) return;         /* a read that is not on the list (scored by k_score_many from the grouped overflow entries): bigidx[] is set to ~0 before k_big_count */
     uint32_t slot = atomicAdd(&bigcur[b], 1u);

@@ -2243,11 +2243,12 @@ static mtb_status score_fixed_slots(mtb_ctx *c, mtb_index *ix, const mtb_params 
         if (!n_big) return MTB_OK;
         c->many_stats[0] = n_big; c->many_stats[1] = 0;
         const bool no_many = c->opt.no_score_many != 0;        /* A/B switch: every deferred read through exact segments (round 4's path) */
+        uint32_t *d_novf = nullptr; uint64_t *d_ostart = nullptr; mtb_match *d_ovfg = nullptr;      /* the overflow list grouped by read, once the many-species path has built it */
         if (!no_many && stride <= 384u) {
             /* ---- the reads of conserved genes (kernels_score_many.h): scored straight from their slots + their overflow entries, dead
              * species dropped before anything is ordered.  The overflow list is grouped by read first (counts from the tail cursors). ---- */
             KTimer ktm(c, MTB_K_SCORE_MANY);
-            uint32_t *d_novf = nullptr, *d_ocur = nullptr, *d_rest; uint64_t *d_ostart = nullptr; mtb_match *d_ovfg = nullptr;
+            uint32_t *d_ocur = nullptr, *d_rest;
             STCHK(ensure(c, "restlist", n_reads, &d_rest));
             const bool have_ovf = ovf_region ? c->ovf_max_region != 0 : n_ovf != 0;
             if (have_ovf) {
@@ -2320,20 +2321,26 @@ static mtb_status score_fixed_slots(mtb_ctx *c, mtb_index *ix, const mtb_params 
         HIPCHK(hipMemsetAsync(d_bigidx, 0xFF, n_reads * 4, st));        /* reads that are not listed (k_score_many took them) own entries of the overflow list too: k_big_ovf skips them */
         STCHK(ensure(c, "bigcnt", n_big, &d_bigcnt)); STCHK(ensure(c, "bigstart", (uint64_t)n_big + 1, &d_bigstart)); STCHK(ensure(c, "bigcur", n_big, &d_bigcur));
         hipLaunchKernelGGL(k_big_count, dim3(std::min<uint32_t>(n_big, 4096)), dim3(64), 0, st, (const mtb_slot16 *)d_segm, stride, direct, epoch,
-                           (const uint32_t *)d_rc, (const uint32_t *)d_biglist, n_big, d_bigcnt, d_bigidx, (uint32_t *)(c->d_scal + 3), d_off_reads);
+                           (const uint32_t *)d_rc, (const uint32_t *)d_biglist, n_big, d_bigcnt, d_bigidx, (uint32_t *)(c->d_scal + 3), d_off_reads,
+                           (const uint32_t *)(d_ovfg ? d_novf : nullptr), (unsigned long long *)(c->d_scal + 2));
         scan_launch<uint32_t, uint64_t, false>(st, d_bigcnt, n_big, true, d_bigstart, d_ws2);
-        uint64_t mx = 0;
+        uint64_t mx = 0, n_ungrouped = 0;
         STCHK(d2h(c, &big_total, d_bigstart + n_big, 8));
         STCHK(d2h(c, &mx, c->d_scal + 3, 8));
+        STCHK(d2h(c, &n_ungrouped, c->d_scal + 2, 8));
         STCHK(scratch(c, "bigm", big_total, &d_big));
         hipLaunchKernelGGL(k_big_copy, dim3(std::min<uint32_t>(n_big, 4096)), dim3(64), 0, st, (const mtb_slot16 *)d_segm, stride, direct, epoch,
-                           (const uint32_t *)d_rc, (const uint32_t *)d_biglist, (const uint64_t *)d_bigstart, n_big, d_bigcur, d_big);
-        if (ovf_region) {            /* striped list (the directory join's): every stripe's entries */
+                           (const uint32_t *)d_rc, (const uint32_t *)d_biglist, (const uint64_t *)d_bigstart, n_big, d_bigcur, d_big,
+                           (const mtb_match *)d_ovfg, (const uint64_t *)d_ostart, (const uint32_t *)(d_ovfg ? d_novf : nullptr));
+        /* the pass over the whole overflow list: only for listed reads whose entries are not in the grouped list (all of them when there is none) */
+        const uint32_t *skip_grouped = d_ovfg ? d_novf : nullptr;
+        if (d_ovfg && n_ungrouped == 0) { /* every listed read's entries came from its group */ }
+        else if (ovf_region) {            /* striped list (the directory join's): every stripe's entries */
             if (c->ovf_max_region) hipLaunchKernelGGL(k_big_ovf, dim3((uint32_t)((c->ovf_max_region + 255) / 256), MTB_OVF_STRIPES), dim3(256), 0, st, (const mtb_match *)d_ovf, n_ovf,
-                                                      (const uint32_t *)d_bigidx, (const uint64_t *)d_bigstart, d_bigcur, d_big, ovf_region, (const unsigned long long *)c->d_ovfctr);
+                                                      (const uint32_t *)d_bigidx, (const uint64_t *)d_bigstart, d_bigcur, d_big, ovf_region, (const unsigned long long *)c->d_ovfctr, skip_grouped);
         } else
         if (n_ovf) hipLaunchKernelGGL(k_big_ovf, dim3((uint32_t)((n_ovf + 255) / 256)), dim3(256), 0, st, (const mtb_match *)d_ovf, n_ovf,
-                                      (const uint32_t *)d_bigidx, (const uint64_t *)d_bigstart, d_bigcur, d_big);
+                                      (const uint32_t *)d_bigidx, (const uint64_t *)d_bigstart, d_bigcur, d_big, (uint64_t)0, (const unsigned long long *)nullptr, skip_grouped);
         /* segments of up to 512 matches (nearly all: a read of a conserved gene brings a few hundred) are sorted in LDS by one wave
          * each; only the ones beyond go through the HBM-resident bitonic network (36 global-memory stages for 256 records: it cost
          * ~70 us per segment, and 7 % of the reads of a realistic batch come here) */
