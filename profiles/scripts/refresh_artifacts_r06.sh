@@ -44,3 +44,5 @@ grep "stage ms\|parity" $O/${TAG}_bench_heldout.log | cut -c1-250; cp /tmp/bench
 python profiles/scripts/rocpd_summary.py $(find $S/prof_ho -name "*.db" | head -1) > $O/${TAG}_heldout_10M_rocprofv3_kernel_stats.txt 2>&1; head -14 $O/${TAG}_heldout_10M_rocprofv3_kernel_stats.txt | cut -c1-150
 rm -rf $S
 du -sh $O
+# 7. the GPU suite on the final state
+timeout 1500 python -m pytest tests -m gpu -q --timeout 400 > $O/${TAG}_pytest_gpu.txt 2>&1; tail -2 $O/${TAG}_pytest_gpu.txt
