@@ -1061,6 +1061,43 @@ def test_target_windows_staged_in_lds_give_the_same_matches(orc, tmp_path, seq_m
     ix.close(); c.close()
 
 
+@pytest.mark.parametrize("n_hot", [3, 6, 11, 14])
+def test_runs_of_a_dozen_candidates_inside_and_outside_a_window(orc, tmp_path, n_hot, monkeypatch):
+    """Candidate runs of 4 .. 15 targets (a metamer filed under n_hot further species, a third of them with the query's own DNA part): the lengths around
+    what a window tile reads ahead (four words before / after the landing place, a run's first four candidates) and around the wave-scan threshold (12) --
+    blocks of equal targets longer than four, runs that continue beyond the words read ahead on either side, per-lane evaluation of more than four
+    candidates.  Window form with tiles of 9 and 256 queries, the sector-random form, and the thresholds 4 / 64 (every such run scanned by the wave / by
+    its lane): the per-read answers and the match totals are the oracle's every time."""
+    import metabuli_amd as M
+    from conftest import HotToy
+    t = HotToy(orc, tmp_path / "db", seq_mode=1, n_reads=150, n_hot=n_hot)
+    assert n_hot < t.max_run <= n_hot + 6
+    monkeypatch.setenv("MTB_DIR_DEPTH", "7")
+    c = M.Context(0)
+    p = M.default_params(seq_mode=1, syncmer=1)
+    ix = c.open_index(t.dbdir, p)
+    monkeypatch.delenv("MTB_DIR_DEPTH", raising=False)
+    ro = t.ref["results"]
+    amb = ro["flag"] != 0
+    for win, qt, coop in (("1", "9", None), ("1", "256", None), ("0", "256", None), ("1", "9", "4"), ("1", "64", "64"), ("0", "256", "4")):
+        c.set_option("MTB_JOIN_WIN", win); c.set_option("MTB_JOIN_WIN_QT", qt); c.set_option("MTB_JOIN_COOP_MIN", coop)
+        res, tt, tc = c.classify_batch(ix, p, t.b1, t.o1)
+        st = c.last_stats()
+        tag = (n_hot, win, qt, coop, M.JOIN_VARIANTS[st.join_variant])
+        assert ix.state()["packed"]
+        assert ((res["classification"] == ro["classification"]) | amb).all(), tag
+        assert ((res["score"].view(np.uint32) == ro["score"].view(np.uint32)) | amb).all(), tag
+        assert ((res["n_taxcnt"] == ro["n_taxcnt"]) | amb).all(), tag
+        if not amb.any():
+            assert (tt == t.ref["tc_tax"]).all() and (tc == t.ref["tc_cnt"]).all(), tag
+        assert st.n_matches == len(t.ref["matches"]), tag
+        if win == "1":
+            assert st.join_tiles_outside == 0, tag
+            if qt == "9":
+                assert st.join_tiles_windowed > 0, tag
+    ix.close(); c.close()
+
+
 @pytest.mark.parametrize("seq_mode", [1, 2])
 def test_reads_that_meet_many_species_are_scored_from_their_slots(orc, tmp_path, seq_mode, monkeypatch):
     """A conserved protein filed under 160 species, each of which holds only a sparse subset of its metamers: a read of that gene brings a

@@ -101,8 +101,10 @@ def test_stages_and_fused_batch_on_the_emulator(emulated_lib):
 
 
 def test_long_reads_and_long_runs_on_the_emulator(emulated_lib):
-    """long reads on ordinal slots (k_join_dir<.., LONG>, k_seg_order, k_score_long) and the wave-cooperative scan of long candidate runs"""
-    _run(emulated_lib, "(test_fused_batch and sync_long) or (test_long_candidate_runs_are_scanned_by_the_wave and True-1) or test_empty_and_ragged_inputs")
+    """long reads on ordinal slots (k_join_dir<.., LONG>, k_seg_order, k_score_long) and the wave-cooperative scan of long candidate runs; window tiles
+    reading ahead around runs of a dozen candidates"""
+    _run(emulated_lib, "(test_fused_batch and sync_long) or (test_long_candidate_runs_are_scanned_by_the_wave and True-1) or test_empty_and_ragged_inputs "
+                       "or (test_runs_of_a_dozen_candidates_inside_and_outside_a_window and 11)")
 
 
 def test_bench_line_of_two_ranks_on_the_emulator(emulated_lib, tmp_path):
